@@ -1,0 +1,763 @@
+/*
+ * oracle/oracle.c -- CPU restatement (plain C) of the OpenIFEM INS fluid step.  TEST INFRASTRUCTURE ONLY.
+ * See oracle.h for the scope, the reference file:line map and the parity-pinning statement.
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define MAXD 3
+#define MAXNU 27
+#define MAXNP 8
+#define MAXQ 27
+#define MAXDOF (MAXD * MAXNU + MAXNP)
+
+/* ------------------------------------------------------------------ FE tables (deal.II FE_Q / QGauss, [3P] textbook) */
+typedef struct {
+  int dim, k, nn, nq;
+  double phi[MAXQ][MAXNU];
+  double dphi[MAXQ][MAXNU][MAXD];
+  double w[MAXQ];
+  double qp[MAXQ][MAXD];
+} fe_t;
+
+static void lagrange_1d(int k, double x, double *N, double *dN) {
+  /* Lagrange basis on the k+1 equidistant nodes j/k of [0,1] (FE_Q support points) */
+  for (int j = 0; j <= k; ++j) {
+    double xj = (double)j / k, v = 1.0, dv = 0.0;
+    for (int m = 0; m <= k; ++m)
+      if (m != j) v *= (x - (double)m / k) / (xj - (double)m / k);
+    for (int l = 0; l <= k; ++l) {
+      if (l == j) continue;
+      double t = 1.0 / (xj - (double)l / k);
+      for (int m = 0; m <= k; ++m)
+        if (m != j && m != l) t *= (x - (double)m / k) / (xj - (double)m / k);
+      dv += t;
+    }
+    N[j] = v;
+    dN[j] = dv;
+  }
+}
+
+static void gauss_1d(int n, double *x, double *w) {
+  /* Gauss-Legendre on [0,1] (QGauss<1>(n)) */
+  if (n == 1) { x[0] = 0.5; w[0] = 1.0; }
+  else if (n == 2) {
+    double a = 0.5 / sqrt(3.0);
+    x[0] = 0.5 - a; x[1] = 0.5 + a; w[0] = w[1] = 0.5;
+  } else if (n == 3) {
+    double a = 0.5 * sqrt(0.6);
+    x[0] = 0.5 - a; x[1] = 0.5; x[2] = 0.5 + a;
+    w[0] = w[2] = 5.0 / 18.0; w[1] = 8.0 / 18.0;
+  } else { fprintf(stderr, "oracle: gauss_1d n=%d unsupported\n", n); abort(); }
+}
+
+/* tabulate degree-k tensor Lagrange shapes at arbitrary reference points */
+static void shapes_at(int dim, int k, const double *xi, double *N, double (*dN)[MAXD]) {
+  double n1[MAXD][3], d1[MAXD][3];
+  for (int d = 0; d < dim; ++d) lagrange_1d(k, xi[d], n1[d], d1[d]);
+  int n = k + 1, nn = 1;
+  for (int d = 0; d < dim; ++d) nn *= n;
+  for (int a = 0; a < nn; ++a) {
+    int ia[MAXD], t = a;
+    for (int d = 0; d < dim; ++d) { ia[d] = t % n; t /= n; }
+    double v = 1.0;
+    for (int d = 0; d < dim; ++d) v *= n1[d][ia[d]];
+    N[a] = v;
+    for (int e = 0; e < dim; ++e) {
+      double g = 1.0;
+      for (int d = 0; d < dim; ++d) g *= (d == e) ? d1[d][ia[d]] : n1[d][ia[d]];
+      dN[a][e] = g;
+    }
+  }
+}
+
+static void fe_init(fe_t *fe, int dim, int k, int nq1d) {
+  memset(fe, 0, sizeof(*fe));
+  fe->dim = dim; fe->k = k;
+  int nn = 1, nq = 1;
+  for (int d = 0; d < dim; ++d) { nn *= (k + 1); nq *= nq1d; }
+  fe->nn = nn; fe->nq = nq;
+  double gx[3], gw[3];
+  gauss_1d(nq1d, gx, gw);
+  for (int q = 0; q < nq; ++q) {
+    int t = q; double w = 1.0;
+    for (int d = 0; d < dim; ++d) { int i = t % nq1d; t /= nq1d; fe->qp[q][d] = gx[i]; w *= gw[i]; }
+    fe->w[q] = w;
+    shapes_at(dim, k, fe->qp[q], fe->phi[q], fe->dphi[q]);
+  }
+}
+
+int32_t orc_fe_tables(int32_t dim, int32_t k, int32_t nq1d, double *phi, double *dphi, double *w, double *qp) {
+  fe_t fe; fe_init(&fe, dim, k, nq1d);
+  for (int q = 0; q < fe.nq; ++q) {
+    w[q] = fe.w[q];
+    for (int d = 0; d < dim; ++d) qp[q * dim + d] = fe.qp[q][d];
+    for (int a = 0; a < fe.nn; ++a) {
+      phi[q * fe.nn + a] = fe.phi[q][a];
+      for (int d = 0; d < dim; ++d) dphi[(q * fe.nn + a) * dim + d] = fe.dphi[q][a][d];
+    }
+  }
+  return fe.nq;
+}
+
+/* ------------------------------------------------------------------ small dense helpers */
+static double det_inv(int dim, const double J[MAXD][MAXD], double Ji[MAXD][MAXD]) {
+  if (dim == 2) {
+    double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    Ji[0][0] = J[1][1] / det; Ji[0][1] = -J[0][1] / det;
+    Ji[1][0] = -J[1][0] / det; Ji[1][1] = J[0][0] / det;
+    return det;
+  }
+  double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+  Ji[0][0] = c00 / det;
+  Ji[1][0] = c01 / det;
+  Ji[2][0] = c02 / det;
+  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+  return det;
+}
+
+/* ------------------------------------------------------------------ system */
+struct orc_system {
+  orc_mesh m;
+  fe_t feu, fep;          /* velocity Q_kv and pressure/mapping Q1 at the volume quadrature QGauss(kv+1) */
+  int nu, np, ndof_cell;  /* per cell: scalar velocity nodes, pressure nodes, system dofs */
+  int n_u, n_p, n;        /* global */
+  int64_t *rowptr; int32_t *col; int32_t *psplit; /* psplit[row] = #cols < n_u in that row */
+  double *A, *M, *rhs;
+  unsigned char *is_c[2]; double *cval[2];
+  /* Schur pieces rebuilt by every solve (mpi_insim.cpp:369) */
+  double *dinv;                       /* 1/diag(M_uu) */
+  int64_t *s_rowptr; int32_t *s_col; double *s_val; /* mass_schur(1,1) */
+  /* scratch for the block-Jacobi inner solver */
+  double *bj;                         /* [n_unodes][dim*dim] inverse diagonal node blocks */
+};
+
+static int cmp_i32(const void *a, const void *b) {
+  int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+  return (x > y) - (x < y);
+}
+
+static void cell_dofs(const orc_system *s, int cell, int32_t *idx) {
+  const orc_mesh *m = &s->m;
+  int dim = m->dim, nu = s->nu, np = s->np;
+  for (int a = 0; a < nu; ++a)
+    for (int c = 0; c < dim; ++c) idx[a * dim + c] = dim * m->cell_unodes[(size_t)cell * nu + a] + c;
+  for (int b = 0; b < np; ++b) idx[dim * nu + b] = s->n_u + m->cell_pnodes[(size_t)cell * np + b];
+}
+
+orc_system *orc_create(const orc_mesh *m) {
+  orc_system *s = (orc_system *)calloc(1, sizeof(*s));
+  s->m = *m;
+  int dim = m->dim;
+  fe_init(&s->feu, dim, m->kv, m->kv + 1);
+  fe_init(&s->fep, dim, 1, m->kv + 1);
+  s->nu = s->feu.nn; s->np = s->fep.nn;
+  s->ndof_cell = dim * s->nu + s->np;
+  s->n_u = dim * m->n_unodes; s->n_p = m->n_pnodes; s->n = s->n_u + s->n_p;
+  int n = s->n, nd = s->ndof_cell;
+  /* dof -> cells adjacency */
+  int64_t *cnt = (int64_t *)calloc((size_t)n + 1, sizeof(int64_t));
+  int32_t idx[MAXDOF];
+  for (int c = 0; c < m->n_cells; ++c) { cell_dofs(s, c, idx); for (int i = 0; i < nd; ++i) cnt[idx[i] + 1]++; }
+  for (int i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+  int32_t *adj = (int32_t *)malloc(sizeof(int32_t) * (size_t)cnt[n]);
+  int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+  memcpy(fill, cnt, sizeof(int64_t) * (size_t)n);
+  for (int c = 0; c < m->n_cells; ++c) { cell_dofs(s, c, idx); for (int i = 0; i < nd; ++i) adj[fill[idx[i]]++] = c; }
+  /* pattern: all couplings among the dofs of each cell (DoFTools::make_sparsity_pattern, mpi_fluid_solver.cpp:311) */
+  s->rowptr = (int64_t *)calloc((size_t)n + 1, sizeof(int64_t));
+  int maxc = 0;
+  for (int i = 0; i < n; ++i) { int k = (int)(cnt[i + 1] - cnt[i]); if (k > maxc) maxc = k; }
+  int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxc * nd);
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < n; ++i) {
+      int t = 0;
+      for (int64_t k = cnt[i]; k < cnt[i + 1]; ++k) { cell_dofs(s, adj[k], tmp + t); t += nd; }
+      qsort(tmp, (size_t)t, sizeof(int32_t), cmp_i32);
+      int u = 0;
+      for (int k = 0; k < t; ++k) if (k == 0 || tmp[k] != tmp[k - 1]) tmp[u++] = tmp[k];
+      if (pass == 0) s->rowptr[i + 1] = s->rowptr[i] + u;
+      else memcpy(s->col + s->rowptr[i], tmp, sizeof(int32_t) * (size_t)u);
+    }
+    if (pass == 0) s->col = (int32_t *)malloc(sizeof(int32_t) * (size_t)s->rowptr[n]);
+  }
+  free(tmp); free(adj); free(fill); free(cnt);
+  s->psplit = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    int k = 0; int64_t b = s->rowptr[i], e = s->rowptr[i + 1];
+    while (b + k < e && s->col[b + k] < s->n_u) ++k;
+    s->psplit[i] = k;
+  }
+  size_t nnz = (size_t)s->rowptr[n];
+  s->A = (double *)calloc(nnz, sizeof(double));
+  s->M = (double *)calloc(nnz, sizeof(double));
+  s->rhs = (double *)calloc((size_t)n, sizeof(double));
+  for (int w = 0; w < 2; ++w) {
+    s->is_c[w] = (unsigned char *)calloc((size_t)n, 1);
+    s->cval[w] = (double *)calloc((size_t)n, sizeof(double));
+  }
+  s->dinv = (double *)calloc((size_t)s->n_u, sizeof(double));
+  s->bj = (double *)calloc((size_t)m->n_unodes * dim * dim, sizeof(double));
+  return s;
+}
+
+void orc_destroy(orc_system *s) {
+  if (!s) return;
+  free(s->rowptr); free(s->col); free(s->psplit); free(s->A); free(s->M); free(s->rhs);
+  for (int w = 0; w < 2; ++w) { free(s->is_c[w]); free(s->cval[w]); }
+  free(s->dinv); free(s->s_rowptr); free(s->s_col); free(s->s_val); free(s->bj);
+  free(s);
+}
+
+int32_t orc_n_dofs(const orc_system *s) { return s->n; }
+int32_t orc_n_u(const orc_system *s) { return s->n_u; }
+const int64_t *orc_rowptr(const orc_system *s) { return s->rowptr; }
+const int32_t *orc_col(const orc_system *s) { return s->col; }
+double *orc_A(orc_system *s) { return s->A; }
+double *orc_M(orc_system *s) { return s->M; }
+double *orc_rhs(orc_system *s) { return s->rhs; }
+
+void orc_set_constraints(orc_system *s, int32_t which, int32_t n, const int32_t *dof, const double *val) {
+  memset(s->is_c[which], 0, (size_t)s->n);
+  memset(s->cval[which], 0, sizeof(double) * (size_t)s->n);
+  for (int i = 0; i < n; ++i) { s->is_c[which][dof[i]] = 1; s->cval[which][dof[i]] = val ? val[i] : 0.0; }
+}
+
+void orc_default_opts(orc_opts *o) {
+  o->fgmres_restart = 30; o->fgmres_maxit = 0; o->fgmres_rel = 1e-4; o->fgmres_abs = 1e-12;
+  o->inner_restart = 30; o->inner_maxit = 2000; o->inner_rel = 1e-8; o->n_threads = 0;
+}
+
+static inline int64_t find_pos(const orc_system *s, int row, int c) {
+  int64_t lo = s->rowptr[row], hi = s->rowptr[row + 1] - 1;
+  while (lo <= hi) {
+    int64_t mid = (lo + hi) >> 1; int32_t v = s->col[mid];
+    if (v == c) return mid;
+    if (v < c) lo = mid + 1; else hi = mid - 1;
+  }
+  fprintf(stderr, "oracle: entry (%d,%d) not in pattern\n", row, c); abort();
+}
+
+/* ------------------------------------------------------------------ cell integrals: mpi_insim.cpp:213-341 */
+static void cell_integrals(const orc_system *s, const orc_params *P, int cell, const double *eval,
+                           const double *present, const double *fsi_acc, double *Ke, double *Me, double *fe) {
+  const orc_mesh *m = &s->m;
+  const int dim = m->dim, nu = s->nu, np = s->np, nd = s->ndof_cell, nq = s->feu.nq;
+  const int nv = s->np; /* vertices = Q1 nodes */
+  const double *X = m->vcoords + (size_t)cell * nv * dim;
+  const int32_t *un = m->cell_unodes + (size_t)cell * nu;
+  const int32_t *pn = m->cell_pnodes + (size_t)cell * np;
+  const double viscosity = P->mu, gamma = P->gamma, rho = P->rho, dt = P->dt;
+  const int ind = m->indicator ? m->indicator[cell] : 0;
+  memset(Ke, 0, sizeof(double) * (size_t)nd * nd);
+  memset(Me, 0, sizeof(double) * (size_t)nd * nd);
+  memset(fe, 0, sizeof(double) * (size_t)nd);
+
+  double div_phi_u[MAXDOF], phi_u[MAXDOF][MAXD], grad_phi_u[MAXDOF][MAXD][MAXD], phi_p[MAXDOF];
+
+  for (int q = 0; q < nq; ++q) {
+    /* fe_values.reinit(cell): MappingQ1 Jacobian J[d][e] = dx_d/dxi_e, mpi_insim.cpp:213 */
+    double J[MAXD][MAXD] = {{0}}, Ji[MAXD][MAXD];
+    for (int v = 0; v < nv; ++v)
+      for (int d = 0; d < dim; ++d)
+        for (int e = 0; e < dim; ++e) J[d][e] += X[v * dim + d] * s->fep.dphi[q][v][e];
+    double det = det_inv(dim, J, Ji);
+    double JxW = fabs(det) * s->feu.w[q];
+    double gradN[MAXNU][MAXD];
+    for (int a = 0; a < nu; ++a)
+      for (int d = 0; d < dim; ++d) {
+        double g = 0;
+        for (int e = 0; e < dim; ++e) g += s->feu.dphi[q][a][e] * Ji[e][d];
+        gradN[a][d] = g;
+      }
+    /* get_function_values / gradients, mpi_insim.cpp:219-232 */
+    double cur_v[MAXD] = {0}, cur_g[MAXD][MAXD] = {{0}}, cur_p = 0, pre_v[MAXD] = {0}, acc_v[MAXD] = {0};
+    for (int a = 0; a < nu; ++a)
+      for (int c = 0; c < dim; ++c) {
+        double ue = eval[dim * un[a] + c];
+        cur_v[c] += s->feu.phi[q][a] * ue;
+        for (int d = 0; d < dim; ++d) cur_g[c][d] += ue * gradN[a][d];
+        pre_v[c] += s->feu.phi[q][a] * present[dim * un[a] + c];
+        if (fsi_acc) acc_v[c] += s->feu.phi[q][a] * fsi_acc[dim * un[a] + c];
+      }
+    for (int b = 0; b < np; ++b) cur_p += s->fep.phi[q][b] * eval[s->n_u + pn[b]];
+    /* cache shape data for all system shape functions k, mpi_insim.cpp:241-247 */
+    for (int k = 0; k < nd; ++k) {
+      for (int c = 0; c < dim; ++c) { phi_u[k][c] = 0; for (int d = 0; d < dim; ++d) grad_phi_u[k][c][d] = 0; }
+      div_phi_u[k] = 0; phi_p[k] = 0;
+      if (k < dim * nu) {
+        int a = k / dim, c = k % dim;
+        phi_u[k][c] = s->feu.phi[q][a];
+        for (int d = 0; d < dim; ++d) grad_phi_u[k][c][d] = gradN[a][d];
+        div_phi_u[k] = gradN[a][c];
+      } else phi_p[k] = s->fep.phi[q][k - dim * nu];
+    }
+    double cur_div = 0;
+    for (int c = 0; c < dim; ++c) cur_div += cur_g[c][c];
+    for (int i = 0; i < nd; ++i) {
+      for (int j = 0; j < nd; ++j) {
+        /* mpi_insim.cpp:263-276 */
+        double sp = 0, gpu_i = 0, conv = 0, mass = 0;
+        for (int a = 0; a < dim; ++a)
+          for (int b = 0; b < dim; ++b) sp += grad_phi_u[j][a][b] * grad_phi_u[i][a][b];
+        for (int a = 0; a < dim; ++a) {
+          double t1 = 0, t2 = 0;
+          for (int b = 0; b < dim; ++b) { t1 += cur_g[a][b] * phi_u[j][b]; t2 += grad_phi_u[j][a][b] * cur_v[b]; }
+          gpu_i += t1 * phi_u[i][a];
+          conv += t2 * phi_u[i][a];
+          mass += phi_u[i][a] * phi_u[j][a];
+        }
+        Ke[i * nd + j] += (viscosity * sp + gpu_i * rho + conv * rho - div_phi_u[i] * phi_p[j] -
+                           phi_p[i] * div_phi_u[j] + gamma * div_phi_u[j] * div_phi_u[i] * rho + mass / dt * rho) * JxW;
+        Me[i * nd + j] += (mass + phi_p[i] * phi_p[j]) * JxW;
+      }
+      /* mpi_insim.cpp:281-304 */
+      double sp = 0, adv = 0, inert = 0, grav = 0;
+      for (int a = 0; a < dim; ++a) {
+        double t = 0;
+        for (int b = 0; b < dim; ++b) { sp += cur_g[a][b] * grad_phi_u[i][a][b]; t += cur_g[a][b] * cur_v[b]; }
+        adv += t * phi_u[i][a];
+        inert += (cur_v[a] - pre_v[a]) * phi_u[i][a];
+        grav += P->g[a] * phi_u[i][a];
+      }
+      fe[i] += ((-viscosity * sp - adv * rho + cur_p * div_phi_u[i] + cur_div * phi_p[i] -
+                 gamma * cur_div * div_phi_u[i] * rho) - inert / dt * rho + grav * rho) * JxW;
+      if (ind == 1) {
+        /* cell_property fsi_stress is identically zero for MPI::InsIM; only a_fsi contributes */
+        double af = 0;
+        for (int a = 0; a < dim; ++a) af += acc_v[a] * rho * phi_u[i][a];
+        fe[i] += af * JxW;
+      }
+    }
+  }
+  /* Neumann faces, mpi_insim.cpp:313-341 */
+  if (P->n_neumann != 0 && m->cell_face_bid) {
+    int nq1 = m->kv + 1;
+    double gx[3], gw[3]; gauss_1d(nq1, gx, gw);
+    int nqf = (dim == 2) ? nq1 : nq1 * nq1;
+    for (int f = 0; f < 2 * dim; ++f) {
+      int bid = m->cell_face_bid[(size_t)cell * 2 * dim + f];
+      if (bid < 0) continue;
+      double pbc = 0; int found = 0;
+      for (int k = 0; k < P->n_neumann; ++k) if (P->neumann_id[k] == bid) { pbc = P->neumann_p[k]; found = 1; }
+      if (!found) continue;
+      int nd_ = f / 2; double side = (double)(f % 2);
+      for (int qf = 0; qf < nqf; ++qf) {
+        double xi[MAXD], w = 1.0; int t = qf;
+        for (int d = 0; d < dim; ++d) {
+          if (d == nd_) xi[d] = side;
+          else { int i = t % nq1; t /= nq1; xi[d] = gx[i]; w *= gw[i]; }
+        }
+        double N1[MAXNP], dN1[MAXNP][MAXD], Nu[MAXNU], dNu[MAXNU][MAXD];
+        shapes_at(dim, 1, xi, N1, dN1);
+        shapes_at(dim, m->kv, xi, Nu, dNu);
+        double J[MAXD][MAXD] = {{0}}, Ji[MAXD][MAXD];
+        for (int v = 0; v < nv; ++v)
+          for (int d = 0; d < dim; ++d)
+            for (int e = 0; e < dim; ++e) J[d][e] += X[v * dim + d] * dN1[v][e];
+        double det = det_inv(dim, J, Ji);
+        /* outward normal n ~ J^-T nhat, surface element = |det J| |J^-T nhat| (Nanson) */
+        double nv_[MAXD], nn = 0, sgn = (f % 2) ? 1.0 : -1.0;
+        for (int d = 0; d < dim; ++d) { nv_[d] = sgn * Ji[nd_][d]; nn += nv_[d] * nv_[d]; }
+        nn = sqrt(nn);
+        double JxWf = fabs(det) * nn * w;
+        for (int d = 0; d < dim; ++d) nv_[d] /= nn;
+        for (int a = 0; a < nu; ++a)
+          for (int c = 0; c < dim; ++c) fe[a * dim + c] += -(Nu[a] * nv_[c] * pbc * JxWf);
+      }
+    }
+  }
+}
+
+void orc_ins_cell(const orc_mesh *m, const orc_params *p, int32_t cell, const double *eval, const double *present,
+                  const double *fsi_acc, double *Ke, double *Me, double *fe) {
+  orc_system s; memset(&s, 0, sizeof(s));
+  s.m = *m;
+  fe_init(&s.feu, m->dim, m->kv, m->kv + 1);
+  fe_init(&s.fep, m->dim, 1, m->kv + 1);
+  s.nu = s.feu.nn; s.np = s.fep.nn; s.ndof_cell = m->dim * s.nu + s.np;
+  s.n_u = m->dim * m->n_unodes; s.n_p = m->n_pnodes; s.n = s.n_u + s.n_p;
+  cell_integrals(&s, p, cell, eval, present, fsi_acc, Ke, Me, fe);
+}
+
+/* ------------------------------------------------------------------ assemble: mpi_insim.cpp:153-362 */
+void orc_ins_assemble(orc_system *s, const orc_params *P, int32_t use_nonzero, const double *eval,
+                      const double *present, const double *fsi_acc) {
+  const int nd = s->ndof_cell, n = s->n;
+  size_t nnz = (size_t)s->rowptr[n];
+  memset(s->A, 0, sizeof(double) * nnz);   /* system_matrix = 0 */
+  memset(s->M, 0, sizeof(double) * nnz);   /* mass_matrix = 0 */
+  memset(s->rhs, 0, sizeof(double) * (size_t)n);
+  const unsigned char *isc = s->is_c[use_nonzero ? 1 : 0];
+  const double *cv = s->cval[use_nonzero ? 1 : 0];
+#pragma omp parallel
+  {
+    double *Ke = (double *)malloc(sizeof(double) * (size_t)nd * nd);
+    double *Me = (double *)malloc(sizeof(double) * (size_t)nd * nd);
+    double fe[MAXDOF]; int32_t idx[MAXDOF];
+#pragma omp for schedule(dynamic, 16)
+    for (int cell = 0; cell < s->m.n_cells; ++cell) {
+      cell_integrals(s, P, cell, eval, present, fsi_acc, Ke, Me, fe);
+      cell_dofs(s, cell, idx);
+      /* AffineConstraints::distribute_local_to_global(Ke, fe, idx, A, rhs, true)  [3P, SURVEY A.4] */
+      double avgK = 0, avgM = 0; int any_c = 0;
+      for (int i = 0; i < nd; ++i) { avgK += fabs(Ke[i * nd + i]); avgM += fabs(Me[i * nd + i]); if (isc[idx[i]]) any_c = 1; }
+      avgK /= nd; avgM /= nd;
+      for (int i = 0; i < nd; ++i) {
+        int gi = idx[i];
+        if (isc[gi]) {
+          double kd = fabs(Ke[i * nd + i]) != 0 ? fabs(Ke[i * nd + i]) : avgK;
+          double md = fabs(Me[i * nd + i]) != 0 ? fabs(Me[i * nd + i]) : avgM;
+          int64_t p = find_pos(s, gi, gi);
+#pragma omp atomic
+          s->A[p] += kd;
+#pragma omp atomic
+          s->M[p] += md;
+#pragma omp atomic
+          s->rhs[gi] += cv[gi] * kd;
+          continue;
+        }
+        double b = fe[i];
+        if (any_c)
+          for (int r = 0; r < nd; ++r) if (isc[idx[r]]) b -= Ke[i * nd + r] * cv[idx[r]];
+#pragma omp atomic
+        s->rhs[gi] += b;
+        for (int j = 0; j < nd; ++j) {
+          if (isc[idx[j]]) continue;
+          int64_t p = find_pos(s, gi, idx[j]);
+#pragma omp atomic
+          s->A[p] += Ke[i * nd + j];
+#pragma omp atomic
+          s->M[p] += Me[i * nd + j];
+        }
+      }
+    }
+    free(Ke); free(Me);
+  }
+}
+
+/* ------------------------------------------------------------------ vector helpers */
+static double vdot(int n, const double *a, const double *b) {
+  double s = 0;
+#pragma omp parallel for reduction(+ : s) if (n > 20000)
+  for (int i = 0; i < n; ++i) s += a[i] * b[i];
+  return s;
+}
+static double vnorm(int n, const double *a) { return sqrt(vdot(n, a, a)); }
+static void vaxpy(int n, double al, const double *x, double *y) {
+#pragma omp parallel for if (n > 20000)
+  for (int i = 0; i < n; ++i) y[i] += al * x[i];
+}
+
+void orc_spmv(const orc_system *s, const double *x, double *y) {
+#pragma omp parallel for schedule(static) if (s->n > 5000)
+  for (int i = 0; i < s->n; ++i) {
+    double t = 0;
+    for (int64_t k = s->rowptr[i]; k < s->rowptr[i + 1]; ++k) t += s->A[k] * x[s->col[k]];
+    y[i] = t;
+  }
+}
+/* y_u = A_uu x_u */
+static void spmv_uu(const orc_system *s, const double *x, double *y) {
+#pragma omp parallel for schedule(static) if (s->n > 5000)
+  for (int i = 0; i < s->n_u; ++i) {
+    double t = 0; int64_t b = s->rowptr[i], e = b + s->psplit[i];
+    for (int64_t k = b; k < e; ++k) t += s->A[k] * x[s->col[k]];
+    y[i] = t;
+  }
+}
+/* y_u = A_up x_p  (system_matrix.block(0,1)) */
+static void spmv_up(const orc_system *s, const double *xp, double *y) {
+#pragma omp parallel for schedule(static) if (s->n > 5000)
+  for (int i = 0; i < s->n_u; ++i) {
+    double t = 0; int64_t b = s->rowptr[i] + s->psplit[i], e = s->rowptr[i + 1];
+    for (int64_t k = b; k < e; ++k) t += s->A[k] * xp[s->col[k] - s->n_u];
+    y[i] = t;
+  }
+}
+/* y_p = M_pp x_p */
+static void spmv_mpp(const orc_system *s, const double *xp, double *y) {
+#pragma omp parallel for schedule(static) if (s->n > 5000)
+  for (int i = 0; i < s->n_p; ++i) {
+    int r = s->n_u + i; double t = 0; int64_t b = s->rowptr[r] + s->psplit[r], e = s->rowptr[r + 1];
+    for (int64_t k = b; k < e; ++k) t += s->M[k] * xp[s->col[k] - s->n_u];
+    y[i] = t;
+  }
+}
+static void spmv_schur(const orc_system *s, const double *xp, double *y) {
+#pragma omp parallel for schedule(static) if (s->n > 5000)
+  for (int i = 0; i < s->n_p; ++i) {
+    double t = 0;
+    for (int64_t k = s->s_rowptr[i]; k < s->s_rowptr[i + 1]; ++k) t += s->s_val[k] * xp[s->s_col[k]];
+    y[i] = t;
+  }
+}
+
+/* plain CG, absolute tolerance on ||r||, zero or given initial guess (PETSc KSPCG + PreconditionNone) */
+typedef void (*matvec_fn)(const orc_system *, const double *, double *);
+static int cg_solve(const orc_system *s, matvec_fn mv, int n, const double *b, double *x, double tol, int maxit) {
+  double *r = (double *)malloc(sizeof(double) * 3 * (size_t)n), *p = r + n, *q = p + n;
+  mv(s, x, q);
+  for (int i = 0; i < n; ++i) { r[i] = b[i] - q[i]; p[i] = r[i]; }
+  double rr = vdot(n, r, r); int it = 0;
+  while (sqrt(rr) > tol && it < maxit) {
+    mv(s, p, q);
+    double al = rr / vdot(n, p, q);
+    vaxpy(n, al, p, x); vaxpy(n, -al, q, r);
+    double rn = vdot(n, r, r), be = rn / rr; rr = rn;
+    for (int i = 0; i < n; ++i) p[i] = r[i] + be * p[i];
+    ++it;
+  }
+  free(r);
+  return it;
+}
+
+/* ------------------------------------------------------------------ BlockSchurPreconditioner ctor: mpi_insim.cpp:13-50 */
+static void schur_setup(orc_system *s) {
+  const int n_u = s->n_u, n_p = s->n_p, dim = s->m.dim;
+  /* d = 1/diag(M_uu)  (PreconditionJacobi(mass(0,0)).vmult(1)) */
+  for (int i = 0; i < n_u; ++i) s->dinv[i] = 1.0 / s->M[find_pos(s, i, i)];
+  /* mass_schur(1,1) = A10 * diag(d) * A01 via explicit sparse product (MatMatMult) */
+  free(s->s_rowptr); free(s->s_col); free(s->s_val);
+  s->s_rowptr = (int64_t *)calloc((size_t)n_p + 1, sizeof(int64_t));
+  int32_t *mark = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_p);
+  double *acc = (double *)calloc((size_t)n_p, sizeof(double));
+  int32_t *list = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_p);
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < n_p; ++i) mark[i] = -1;
+    for (int i = 0; i < n_p; ++i) {
+      int r = n_u + i, cnt = 0;
+      for (int64_t k = s->rowptr[r]; k < s->rowptr[r] + s->psplit[r]; ++k) {
+        int u = s->col[k]; double bik = s->A[k] * s->dinv[u];
+        for (int64_t l = s->rowptr[u] + s->psplit[u]; l < s->rowptr[u + 1]; ++l) {
+          int j = s->col[l] - n_u;
+          if (mark[j] != i) { mark[j] = i; list[cnt++] = j; acc[j] = 0; }
+          acc[j] += bik * s->A[l];
+        }
+      }
+      if (pass == 0) s->s_rowptr[i + 1] = s->s_rowptr[i] + cnt;
+      else {
+        qsort(list, (size_t)cnt, sizeof(int32_t), cmp_i32);
+        for (int k = 0; k < cnt; ++k) { s->s_col[s->s_rowptr[i] + k] = list[k]; s->s_val[s->s_rowptr[i] + k] = acc[list[k]]; }
+      }
+    }
+    if (pass == 0) {
+      s->s_col = (int32_t *)malloc(sizeof(int32_t) * (size_t)s->s_rowptr[n_p]);
+      s->s_val = (double *)malloc(sizeof(double) * (size_t)s->s_rowptr[n_p]);
+    }
+  }
+  free(mark); free(acc); free(list);
+  /* node-block Jacobi for the built-in inner solver: inverse of the dim x dim diagonal blocks of A_uu */
+  for (int nd_ = 0; nd_ < s->m.n_unodes; ++nd_) {
+    double B[MAXD][MAXD], Bi[MAXD][MAXD];
+    for (int a = 0; a < dim; ++a)
+      for (int b = 0; b < dim; ++b) B[a][b] = s->A[find_pos(s, nd_ * dim + a, nd_ * dim + b)];
+    det_inv(dim, B, Bi);
+    for (int a = 0; a < dim; ++a)
+      for (int b = 0; b < dim; ++b) s->bj[(size_t)nd_ * dim * dim + a * dim + b] = Bi[a][b];
+  }
+}
+
+void orc_schur_csr(const orc_system *s, const int64_t **rowptr, const int32_t **col, const double **val) {
+  *rowptr = s->s_rowptr; *col = s->s_col; *val = s->s_val;
+}
+
+/* right-preconditioned restarted GMRES on A_uu with node-block Jacobi: built-in stand-in for MUMPS */
+static void bj_apply(const orc_system *s, const double *x, double *y) {
+  int dim = s->m.dim;
+#pragma omp parallel for if (s->n_u > 20000)
+  for (int nd_ = 0; nd_ < s->m.n_unodes; ++nd_)
+    for (int a = 0; a < dim; ++a) {
+      double t = 0;
+      for (int b = 0; b < dim; ++b) t += s->bj[(size_t)nd_ * dim * dim + a * dim + b] * x[nd_ * dim + b];
+      y[nd_ * dim + a] = t;
+    }
+}
+
+typedef void (*op_fn)(void *ctx, const double *x, double *y);
+/* generic flexible GMRES(m): solves A x = b, x0 = 0.  Returns iterations; *res_out = last residual estimate */
+static int fgmres(int n, op_fn A, void *actx, op_fn Pinv, void *pctx, const double *b, double *x, int m, int maxit,
+                  double tol, double *res_out) {
+  double *V = (double *)malloc(sizeof(double) * (size_t)n * (m + 1));
+  double *Z = (double *)malloc(sizeof(double) * (size_t)n * m);
+  double *H = (double *)calloc((size_t)(m + 1) * m, sizeof(double));
+  double *cs = (double *)calloc((size_t)m, sizeof(double)), *sn = (double *)calloc((size_t)m, sizeof(double));
+  double *g = (double *)calloc((size_t)m + 1, sizeof(double)), *y = (double *)calloc((size_t)m, sizeof(double));
+  double *w = (double *)malloc(sizeof(double) * (size_t)n);
+  memset(x, 0, sizeof(double) * (size_t)n);
+  int it = 0; double res = vnorm(n, b);
+  int first = 1;
+  while (1) {
+    /* r = b - A x */
+    if (first) { memcpy(w, b, sizeof(double) * (size_t)n); first = 0; }
+    else { A(actx, x, w); for (int i = 0; i < n; ++i) w[i] = b[i] - w[i]; }
+    double beta = vnorm(n, w); res = beta;
+    if (res <= tol || it >= maxit) break;
+    for (int i = 0; i < n; ++i) V[i] = w[i] / beta;
+    memset(g, 0, sizeof(double) * ((size_t)m + 1)); g[0] = beta;
+    int j = 0, done = 0;
+    for (; j < m && it < maxit; ++j) {
+      double *vj = V + (size_t)n * j, *zj = Z + (size_t)n * j;
+      Pinv(pctx, vj, zj);
+      A(actx, zj, w);
+      for (int i = 0; i <= j; ++i) { /* modified Gram-Schmidt */
+        double h = vdot(n, w, V + (size_t)n * i);
+        H[i * m + j] = h; vaxpy(n, -h, V + (size_t)n * i, w);
+      }
+      double hn = vnorm(n, w);
+      H[(j + 1) * m + j] = hn;
+      if (hn != 0) for (int i = 0; i < n; ++i) V[(size_t)n * (j + 1) + i] = w[i] / hn;
+      for (int i = 0; i < j; ++i) { /* apply previous Givens rotations */
+        double t = cs[i] * H[i * m + j] + sn[i] * H[(i + 1) * m + j];
+        H[(i + 1) * m + j] = -sn[i] * H[i * m + j] + cs[i] * H[(i + 1) * m + j];
+        H[i * m + j] = t;
+      }
+      double a = H[j * m + j], bb = H[(j + 1) * m + j], r = hypot(a, bb);
+      cs[j] = a / r; sn[j] = bb / r;
+      H[j * m + j] = r; H[(j + 1) * m + j] = 0;
+      g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
+      res = fabs(g[j + 1]); ++it;
+      if (res <= tol) { ++j; done = 1; break; }
+    }
+    for (int i = j - 1; i >= 0; --i) { /* back substitution */
+      double t = g[i];
+      for (int k = i + 1; k < j; ++k) t -= H[i * m + k] * y[k];
+      y[i] = t / H[i * m + i];
+    }
+    for (int i = 0; i < j; ++i) vaxpy(n, y[i], Z + (size_t)n * i, x);
+    if (done || it >= maxit) break;
+  }
+  free(V); free(Z); free(H); free(cs); free(sn); free(g); free(y); free(w);
+  if (res_out) *res_out = res;
+  return it;
+}
+
+typedef struct { orc_system *s; const orc_params *P; const orc_opts *o; orc_ainv_fn ainv; void *user; int refresh;
+                 int64_t *uu_rowptr; int32_t *uu_col; double *uu_val; long n_ainv, it_mp, it_sm, it_inner; } pc_ctx;
+
+static void op_uu(void *c, const double *x, double *y) { spmv_uu(((pc_ctx *)c)->s, x, y); }
+static void op_bj(void *c, const double *x, double *y) { bj_apply(((pc_ctx *)c)->s, x, y); }
+static void op_full(void *c, const double *x, double *y) { orc_spmv(((pc_ctx *)c)->s, x, y); }
+
+static void extract_uu(pc_ctx *c) {
+  orc_system *s = c->s; int n_u = s->n_u;
+  c->uu_rowptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n_u + 1));
+  c->uu_rowptr[0] = 0;
+  for (int i = 0; i < n_u; ++i) c->uu_rowptr[i + 1] = c->uu_rowptr[i] + s->psplit[i];
+  c->uu_col = (int32_t *)malloc(sizeof(int32_t) * (size_t)c->uu_rowptr[n_u]);
+  c->uu_val = (double *)malloc(sizeof(double) * (size_t)c->uu_rowptr[n_u]);
+  for (int i = 0; i < n_u; ++i) {
+    memcpy(c->uu_col + c->uu_rowptr[i], s->col + s->rowptr[i], sizeof(int32_t) * (size_t)s->psplit[i]);
+    memcpy(c->uu_val + c->uu_rowptr[i], s->A + s->rowptr[i], sizeof(double) * (size_t)s->psplit[i]);
+  }
+}
+
+/* BlockSchurPreconditioner::vmult, mpi_insim.cpp:57-128 */
+static void pc_vmult(void *vc, const double *src, double *dst) {
+  pc_ctx *c = (pc_ctx *)vc; orc_system *s = c->s; const orc_params *P = c->P;
+  const int n_u = s->n_u, n_p = s->n_p;
+  const double *src0 = src, *src1 = src + n_u; double *dst0 = dst, *dst1 = dst + n_u;
+  double *utmp = (double *)malloc(sizeof(double) * (size_t)n_u);
+  double *tmp = (double *)calloc((size_t)n_p, sizeof(double));
+  double n1 = vnorm(n_p, src1);
+  /* CG for Mp: tol max(1e-10, 1e-6 ||src1||), :73-83 */
+  c->it_mp += cg_solve(s, spmv_mpp, n_p, src1, tmp, fmax(1e-10, 1e-6 * n1), n_p);
+  for (int i = 0; i < n_p; ++i) tmp[i] *= -(P->mu + P->gamma * P->rho);
+  /* CG for Sm: tol max(1e-10, 1e-3 ||src1||), :88-111 */
+  memset(dst1, 0, sizeof(double) * (size_t)n_p);
+  c->it_sm += cg_solve(s, spmv_schur, n_p, src1, dst1, fmax(1e-10, 1e-3 * n1), n_p);
+  for (int i = 0; i < n_p; ++i) dst1[i] = dst1[i] * (-P->rho / P->dt) + tmp[i];
+  /* utmp = src0 - A01 dst1, :116-120 */
+  spmv_up(s, dst1, utmp);
+  for (int i = 0; i < n_u; ++i) utmp[i] = src0[i] - utmp[i];
+  /* dst0 = A_uu^-1 utmp, :124-127 (MUMPS) */
+  if (c->ainv) {
+    if (!c->uu_rowptr) extract_uu(c);
+    c->ainv(c->user, c->refresh, n_u, c->uu_rowptr, c->uu_col, c->uu_val, utmp, dst0);
+    c->refresh = 0;
+  } else {
+    double r;
+    c->it_inner += fgmres(n_u, op_uu, c, op_bj, c, utmp, dst0, c->o->inner_restart, c->o->inner_maxit,
+                          c->o->inner_rel * vnorm(n_u, utmp), &r);
+  }
+  c->n_ainv++;
+  free(utmp); free(tmp);
+}
+
+void orc_precond_vmult(orc_system *s, const orc_params *p, const orc_opts *o, orc_ainv_fn ainv, void *user,
+                       const double *v, double *z) {
+  pc_ctx c; memset(&c, 0, sizeof(c));
+  c.s = s; c.P = p; c.o = o; c.ainv = ainv; c.user = user; c.refresh = 1;
+  schur_setup(s);
+  pc_vmult(&c, v, z);
+  free(c.uu_rowptr); free(c.uu_col); free(c.uu_val);
+}
+
+/* InsIM::solve, mpi_insim.cpp:365-395 */
+int32_t orc_ins_solve(orc_system *s, const orc_params *P, int32_t use_nonzero, const orc_opts *o, orc_ainv_fn ainv,
+                      void *user, double *newton_update, int32_t *iters, double *res) {
+#ifdef _OPENMP
+  if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
+#endif
+  pc_ctx c; memset(&c, 0, sizeof(c));
+  c.s = s; c.P = P; c.o = o; c.ainv = ainv; c.user = user; c.refresh = 1;
+  schur_setup(s); /* preconditioner.reset(new BlockSchurPreconditioner(...)) */
+  double tol = fmax(o->fgmres_abs, o->fgmres_rel * vnorm(s->n, s->rhs));
+  int maxit = o->fgmres_maxit > 0 ? o->fgmres_maxit : s->n;
+  double r = 0;
+  int it = fgmres(s->n, op_full, &c, pc_vmult, &c, s->rhs, newton_update, o->fgmres_restart, maxit, tol, &r);
+  /* constraints_used.distribute(newton_update) */
+  const unsigned char *isc = s->is_c[use_nonzero ? 1 : 0]; const double *cv = s->cval[use_nonzero ? 1 : 0];
+  for (int i = 0; i < s->n; ++i) if (isc[i]) newton_update[i] = cv[i];
+  if (iters) *iters = it;
+  if (res) *res = r;
+  free(c.uu_rowptr); free(c.uu_col); free(c.uu_val);
+  if (getenv("ORACLE_VERBOSE"))
+    fprintf(stderr, "oracle solve: fgmres %d its res %.3e | P applies %ld, CG(Mp) %ld, CG(Sm) %ld, inner %ld\n", it, r,
+            c.n_ainv, c.it_mp, c.it_sm, c.it_inner);
+  return r <= tol ? 0 : -2;
+}
+
+/* InsIM::run_one_step Newton loop, mpi_insim.cpp:416-473 */
+int32_t orc_ins_run_one_step(orc_system *s, const orc_params *P, int32_t apply_nonzero, double newton_tol,
+                             int32_t newton_maxit, const orc_opts *o, orc_ainv_fn ainv, void *user, double *present,
+                             const double *fsi_acc, double *log) {
+#ifdef _OPENMP
+  if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
+#endif
+  const int n = s->n;
+  double *evalp = (double *)malloc(sizeof(double) * (size_t)n), *upd = (double *)malloc(sizeof(double) * (size_t)n);
+  memcpy(evalp, present, sizeof(double) * (size_t)n);
+  double cur = 1.0, init = 1.0, rel = 1.0; int outer = 0, rc = 0;
+  while (rel > newton_tol && cur > 1e-11) {
+    if (outer >= newton_maxit) { rc = -1; break; }
+    memset(upd, 0, sizeof(double) * (size_t)n);
+    int nz = apply_nonzero && outer == 0;
+    orc_ins_assemble(s, P, nz, evalp, present, fsi_acc);
+    int32_t it = 0; double r = 0;
+    if (orc_ins_solve(s, P, nz, o, ainv, user, upd, &it, &r) != 0) { rc = -2; break; }
+    cur = vnorm(n, s->rhs);
+    for (int i = 0; i < n; ++i) evalp[i] += upd[i];
+    if (outer == 0) init = cur;
+    rel = cur / init;
+    if (log) { log[outer * 4 + 0] = cur; log[outer * 4 + 1] = rel; log[outer * 4 + 2] = it; log[outer * 4 + 3] = r; }
+    ++outer;
+  }
+  if (rc == 0) memcpy(present, evalp, sizeof(double) * (size_t)n);
+  free(evalp); free(upd);
+  return rc < 0 ? rc : outer;
+}

@@ -1,0 +1,117 @@
+/*
+ * oracle/oracle.h -- CPU restatement of the OpenIFEM incompressible Navier-Stokes fluid step.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load liboracle.so.  The product path (openifem_amd/) never
+ * includes, links or calls anything in this directory.
+ *
+ * What it restates (reference = /root/reference, OpenIFEM @ 2025-07-25):
+ *   orc_ins_assemble      source/mpi_insim.cpp:153-362   (InsIM::assemble: cell loop, Neumann faces,
+ *                                                          distribute_local_to_global)
+ *   orc_schur_setup       source/mpi_insim.cpp:13-50     (BlockSchurPreconditioner ctor: S_m = B diag(Mu)^-1 B^T)
+ *   orc_precond_vmult     source/mpi_insim.cpp:57-128    (BlockSchurPreconditioner::vmult)
+ *   orc_ins_solve         source/mpi_insim.cpp:365-395   (InsIM::solve: FGMRES(30) + constraints.distribute)
+ *   orc_ins_run_one_step  source/mpi_insim.cpp:398-490   (Newton loop)
+ *   orc_update_stress     source/mpi_fluid_solver.cpp:716-811
+ *
+ * Parity pinning: the reference cannot be built in this image (deal.II/PETSc/MUMPS absent), and its
+ * tests dump no element matrices, so the oracle is pinned against the reference tests' known answers
+ * (tests/fluid_pressure_driven: vmax = 2.5e-2; tests/fluid_gravity: pmax-pmin = 20;
+ * tests/fluid_pipe_mpi: vmax = 1.5) -- see tests/test_oracle_kat.py.  Element matrices and Krylov
+ * iterates are "parity unpinned" (SURVEY 8c): no reference artefact exists for them.
+ *
+ * Third-party arithmetic restated here because it is not under /root/reference (deal.II >= 9.3,
+ * unpinned): FE_Q Lagrange shapes on equidistant nodes, QGauss, MappingQ1, AffineConstraints::
+ * distribute_local_to_global, SolverFGMRES/SolverCG.  PETSc KSPCG -> plain CG; MUMPS -> caller-supplied
+ * exact solve callback (tests pass scipy splu) or the built-in iterative inner solver.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mesh + DoF tables.  Global DoF numbering is the reference's block layout [velocity | pressure]
+ * (mpi_fluid_solver.cpp:125-128) with velocity components interleaved per node:
+ *   u-dof = dim*unode + c,   p-dof = dim*n_unodes + pnode.
+ * Local node order is tensor-lexicographic (x fastest) for both Q_kv and Q1. */
+typedef struct {
+  int32_t dim;           /* 2 or 3 */
+  int32_t kv;            /* velocity degree: 1 or 2 (pressure degree is 1) */
+  int32_t n_cells, n_unodes, n_pnodes;
+  const double  *vcoords;       /* [n_cells][2^dim][dim] vertex coords (lexicographic vertex order) */
+  const int32_t *cell_unodes;   /* [n_cells][(kv+1)^dim] */
+  const int32_t *cell_pnodes;   /* [n_cells][2^dim] */
+  const int32_t *cell_face_bid; /* [n_cells][2*dim] boundary id or -1; faces x-,x+,y-,y+,z-,z+ */
+  const int32_t *indicator;     /* [n_cells] or NULL (0 real fluid, 1 artificial) */
+} orc_mesh;
+
+typedef struct {
+  double mu, rho, gamma, dt;
+  double g[3];
+  int32_t n_neumann;
+  int32_t neumann_id[8];
+  double  neumann_p[8];
+} orc_params;
+
+/* A^-1 u-block solve callback (stands in for MUMPS, mpi_insim.cpp:124-127).
+ * Called with the CSR of A_uu after every assemble when `refresh` != 0, then y = A_uu^-1 x. */
+typedef void (*orc_ainv_fn)(void *user, int32_t refresh, int32_t n, const int64_t *rowptr,
+                            const int32_t *col, const double *val, const double *x, double *y);
+
+typedef struct {
+  int32_t fgmres_restart;     /* 30 (deal.II default) */
+  int32_t fgmres_maxit;       /* n_dofs in the reference */
+  double  fgmres_rel, fgmres_abs; /* 1e-4, 1e-12 (mpi_insim.cpp:379-380) */
+  /* built-in inner solver for A^-1 when no callback is given: GMRES(m) + node-block Jacobi */
+  int32_t inner_restart, inner_maxit;
+  double  inner_rel;
+  int32_t n_threads;          /* OpenMP threads (0 = default) */
+} orc_opts;
+
+typedef struct orc_system orc_system;
+
+orc_system *orc_create(const orc_mesh *m);
+void orc_destroy(orc_system *s);
+int32_t orc_n_dofs(const orc_system *s);
+int32_t orc_n_u(const orc_system *s);
+/* which: 0 = zero_constraints, 1 = nonzero_constraints (Dirichlet lines: dof, inhomogeneity) */
+void orc_set_constraints(orc_system *s, int32_t which, int32_t n, const int32_t *dof, const double *val);
+void orc_default_opts(orc_opts *o);
+
+/* CSR of the full block system (all couplings, mpi_fluid_solver.cpp:311-322) */
+const int64_t *orc_rowptr(const orc_system *s);
+const int32_t *orc_col(const orc_system *s);
+double *orc_A(orc_system *s);      /* system_matrix values */
+double *orc_M(orc_system *s);      /* mass_matrix values (same pattern) */
+double *orc_rhs(orc_system *s);
+
+void orc_ins_assemble(orc_system *s, const orc_params *p, int32_t use_nonzero, const double *eval,
+                      const double *present, const double *fsi_acc);
+/* single-cell dense Ke/Me/fe (ndof x ndof row-major, local dof = [a*dim+c | p]) before constraints */
+void orc_ins_cell(const orc_mesh *m, const orc_params *p, int32_t cell, const double *eval,
+                  const double *present, const double *fsi_acc, double *Ke, double *Me, double *fe);
+
+int32_t orc_ins_solve(orc_system *s, const orc_params *p, int32_t use_nonzero, const orc_opts *o,
+                      orc_ainv_fn ainv, void *user, double *newton_update, int32_t *iters, double *res);
+/* returns number of Newton iterations, <0 on failure (-1 too many Newton its, -2 Krylov no convergence) */
+int32_t orc_ins_run_one_step(orc_system *s, const orc_params *p, int32_t apply_nonzero, double newton_tol,
+                             int32_t newton_maxit, const orc_opts *o, orc_ainv_fn ainv, void *user,
+                             double *present, const double *fsi_acc, double *log /* [maxit][4] or NULL */);
+
+/* y = A x with the assembled system matrix */
+void orc_spmv(const orc_system *s, const double *x, double *y);
+/* S_m explicit (mpi_insim.cpp:44-49): returns CSR of mass_schur(1,1) built by the last solve (may be NULL) */
+void orc_schur_csr(const orc_system *s, const int64_t **rowptr, const int32_t **col, const double **val);
+/* z = P^-1 v (block Schur preconditioner, mpi_insim.cpp:57-128) on the last assembled system */
+void orc_precond_vmult(orc_system *s, const orc_params *p, const orc_opts *o, orc_ainv_fn ainv, void *user,
+                       const double *v, double *z);
+
+/* FE tables for cross-checks: phi[q][a], dphi[q][a][dim] on the reference cell, weights */
+int32_t orc_fe_tables(int32_t dim, int32_t k, int32_t nq1d, double *phi, double *dphi, double *w, double *qp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,188 @@
+"""ctypes binding of oracle/liboracle.so (test infrastructure: the checker, never the product)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ODIR = os.path.join(_ROOT, "oracle")
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("kv", C.c_int32), ("n_cells", C.c_int32), ("n_unodes", C.c_int32),
+                ("n_pnodes", C.c_int32), ("vcoords", C.c_void_p), ("cell_unodes", C.c_void_p),
+                ("cell_pnodes", C.c_void_p), ("cell_face_bid", C.c_void_p), ("indicator", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("mu", C.c_double), ("rho", C.c_double), ("gamma", C.c_double), ("dt", C.c_double),
+                ("g", C.c_double * 3), ("n_neumann", C.c_int32), ("neumann_id", C.c_int32 * 8),
+                ("neumann_p", C.c_double * 8)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("fgmres_restart", C.c_int32), ("fgmres_maxit", C.c_int32), ("fgmres_rel", C.c_double),
+                ("fgmres_abs", C.c_double), ("inner_restart", C.c_int32), ("inner_maxit", C.c_int32),
+                ("inner_rel", C.c_double), ("n_threads", C.c_int32)]
+
+
+AINV = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+_lib = None
+
+
+def lib(native=False):
+    global _lib
+    name = "liboracle_native.so" if native else "liboracle.so"
+    path = os.path.join(_ODIR, name)
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", _ODIR] + (["native"] if native else []), stdout=subprocess.DEVNULL)
+    if native:
+        return _bind(C.CDLL(path))
+    if _lib is None:
+        _lib = _bind(C.CDLL(path))
+    return _lib
+
+
+def _bind(L):
+    L.orc_create.restype = C.c_void_p
+    L.orc_create.argtypes = [C.POINTER(_Mesh)]
+    L.orc_destroy.argtypes = [C.c_void_p]
+    L.orc_n_dofs.argtypes = [C.c_void_p]
+    L.orc_n_u.argtypes = [C.c_void_p]
+    L.orc_set_constraints.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.orc_default_opts.argtypes = [C.POINTER(Opts)]
+    for f, t in (("orc_rowptr", C.c_int64), ("orc_col", C.c_int32), ("orc_A", C.c_double), ("orc_M", C.c_double),
+                 ("orc_rhs", C.c_double)):
+        getattr(L, f).restype = C.POINTER(t)
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.orc_ins_assemble.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_ins_cell.argtypes = [C.POINTER(_Mesh), C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_ins_solve.restype = C.c_int32
+    L.orc_ins_solve.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(Opts), C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.orc_ins_run_one_step.restype = C.c_int32
+    L.orc_ins_run_one_step.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_double, C.c_int32,
+                                       C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_spmv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_precond_vmult.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Opts), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]
+    L.orc_fe_tables.restype = C.c_int32
+    L.orc_fe_tables.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return L
+
+
+def make_params(mu=1.0, rho=1.0, gamma=0.1, dt=1e-3, g=(0, 0, 0), neumann=None):
+    p = Params()
+    p.mu, p.rho, p.gamma, p.dt = mu, rho, gamma, dt
+    for i in range(3):
+        p.g[i] = g[i] if i < len(g) else 0.0
+    neumann = neumann or {}
+    p.n_neumann = len(neumann)
+    for k, (bid, val) in enumerate(sorted(neumann.items())):
+        p.neumann_id[k] = bid
+        p.neumann_p[k] = val
+    return p
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class SpluAinv:
+    """Exact A_uu^-1 through scipy splu: stands in for MUMPS (mpi_insim.cpp:124-127) in parity runs."""
+
+    def __init__(self):
+        self.lu = None
+        self.cb = AINV(self._call)
+        self.n_factor = 0
+
+    def _call(self, user, refresh, n, rowptr, col, val, x, y):
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spl
+        if refresh or self.lu is None:
+            rp = np.ctypeslib.as_array(rowptr, (n + 1,))
+            nnz = int(rp[-1])
+            A = sp.csr_matrix((np.ctypeslib.as_array(val, (nnz,)).copy(), np.ctypeslib.as_array(col, (nnz,)).copy(),
+                               rp.copy()), shape=(n, n))
+            self.lu = spl.splu(A.tocsc())
+            self.n_factor += 1
+        xv = np.ctypeslib.as_array(x, (n,))
+        yv = np.ctypeslib.as_array(y, (n,))
+        yv[:] = self.lu.solve(xv)
+
+
+class System:
+    """Thin owner of an orc_system plus the numpy arrays it borrows."""
+
+    def __init__(self, mesh, native=False):
+        self.L = lib(native)
+        self.mesh = mesh
+        self._keep = [np.ascontiguousarray(mesh.vcoords, float), np.ascontiguousarray(mesh.cell_unodes, np.int32),
+                      np.ascontiguousarray(mesh.cell_pnodes, np.int32),
+                      np.ascontiguousarray(mesh.cell_face_bid, np.int32),
+                      None if getattr(mesh, "indicator", None) is None else np.ascontiguousarray(mesh.indicator, np.int32)]
+        m = _Mesh(mesh.dim, mesh.kv, mesh.n_cells, mesh.n_unodes, mesh.n_pnodes, *[_ptr(a) for a in self._keep])
+        self.cmesh = m
+        self.h = C.c_void_p(self.L.orc_create(C.byref(m)))
+        self.n = self.L.orc_n_dofs(self.h)
+        self.n_u = self.L.orc_n_u(self.h)
+        self.opts = Opts()
+        self.L.orc_default_opts(C.byref(self.opts))
+
+    def __del__(self):
+        try:
+            self.L.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_constraints(self, which, dofs, vals=None):
+        dofs = np.ascontiguousarray(dofs, np.int32)
+        vals = None if vals is None else np.ascontiguousarray(vals, float)
+        self.L.orc_set_constraints(self.h, which, len(dofs), _ptr(dofs), _ptr(vals))
+
+    def assemble(self, params, use_nonzero, evalp, present, fsi_acc=None):
+        self.L.orc_ins_assemble(self.h, C.byref(params), int(use_nonzero), _ptr(evalp), _ptr(present), _ptr(fsi_acc))
+
+    def csr(self, which="A"):
+        import scipy.sparse as sp
+        rp = np.ctypeslib.as_array(self.L.orc_rowptr(self.h), (self.n + 1,)).copy()
+        nnz = int(rp[-1])
+        col = np.ctypeslib.as_array(self.L.orc_col(self.h), (nnz,)).copy()
+        val = np.ctypeslib.as_array(getattr(self.L, "orc_" + which)(self.h), (nnz,)).copy()
+        return sp.csr_matrix((val, col, rp), shape=(self.n, self.n))
+
+    def rhs(self):
+        return np.ctypeslib.as_array(self.L.orc_rhs(self.h), (self.n,)).copy()
+
+    def cell(self, params, cell, evalp, present, fsi_acc=None):
+        nd = self.mesh.dim * self.mesh.cell_unodes.shape[1] + self.mesh.cell_pnodes.shape[1]
+        Ke, Me, fe = np.zeros((nd, nd)), np.zeros((nd, nd)), np.zeros(nd)
+        self.L.orc_ins_cell(C.byref(self.cmesh), C.byref(params), cell, _ptr(evalp), _ptr(present), _ptr(fsi_acc),
+                            _ptr(Ke), _ptr(Me), _ptr(fe))
+        return Ke, Me, fe
+
+    def solve(self, params, use_nonzero, ainv=None):
+        upd = np.zeros(self.n)
+        it, res = C.c_int32(0), C.c_double(0)
+        cb = C.cast(ainv.cb, C.c_void_p) if ainv is not None else None
+        rc = self.L.orc_ins_solve(self.h, C.byref(params), int(use_nonzero), C.byref(self.opts), cb, None, _ptr(upd),
+                                  C.byref(it), C.byref(res))
+        return rc, upd, it.value, res.value
+
+    def run_one_step(self, params, apply_nonzero, present, newton_tol=1e-6, newton_maxit=8, ainv=None, fsi_acc=None):
+        log = np.zeros((newton_maxit + 1, 4))
+        cb = C.cast(ainv.cb, C.c_void_p) if ainv is not None else None
+        rc = self.L.orc_ins_run_one_step(self.h, C.byref(params), int(apply_nonzero), newton_tol, newton_maxit,
+                                         C.byref(self.opts), cb, None, _ptr(present), _ptr(fsi_acc), _ptr(log))
+        return rc, log[:max(rc, 0)]
+
+    def precond(self, params, v, ainv=None):
+        z = np.zeros(self.n)
+        cb = C.cast(ainv.cb, C.c_void_p) if ainv is not None else None
+        v = np.ascontiguousarray(v, float)
+        self.L.orc_precond_vmult(self.h, C.byref(params), C.byref(self.opts), cb, None, _ptr(v), _ptr(z))
+        return z

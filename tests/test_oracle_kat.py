@@ -1,0 +1,118 @@
+"""Pins the CPU oracle against the known answers the reference's own tests assert.
+
+The reference cannot be built here (deal.II/PETSc absent), so these analytic / regression constants
+are the only reference artefacts available; A_uu^-1 is an exact sparse LU (scipy splu) standing in for
+MUMPS / UMFPACK exactly as the reference does (mpi_insim.cpp:124-127, insim.cpp).
+"""
+import numpy as np
+import pytest
+
+import orc
+from boxmesh import BoxMesh
+
+
+def _run(mesh, bcs, params, n_steps, fields=None):
+    S = orc.System(mesh)
+    dofs, vals = mesh.dirichlet(bcs, fields)
+    S.set_constraints(1, dofs, vals)
+    S.set_constraints(0, dofs, None)
+    x = np.zeros(S.n)
+    ainv = orc.SpluAinv()
+    for step in range(n_steps):
+        rc, _ = S.run_one_step(params, step == 0, x, ainv=ainv)
+        assert rc > 0, f"Newton failed at step {step}: rc={rc}"
+    return S, x
+
+
+def test_fluid_pressure_driven_poiseuille():
+    # tests/fluid_pressure_driven/fluid_pressure_driven.cpp:33-45 (+ .prm): vmax = dP D^2 / (8 mu L) = 2.5e-2 at 1e-3.
+    # Poiseuille is exact in Q2, so the coarser 50x5 mesh (reference: 200x20) carries the same answer.
+    m = BoxMesh([50, 5], (0, 0), (2.0, 0.2), kv=2)
+    P = orc.make_params(mu=1, rho=1, gamma=0.1, dt=1e-3, neumann={0: 10.0})
+    S, x = _run(m, {2: (3, [0, 0]), 3: (3, [0, 0])}, P, 80)
+    vmax = x[:S.n_u].max()
+    assert abs(vmax - 2.5e-2) / 2.5e-2 < 1e-3
+    # stronger than the reference: full parabolic profile u = dP/(2 mu L) y (D - y), v = 0
+    y = m.unode_coords[:, 1]
+    u_exact = 10.0 / (2 * 2.0) * y * (0.2 - y)
+    assert np.abs(x[0:S.n_u:2] - u_exact).max() < 1e-7
+    assert np.abs(x[1:S.n_u:2]).max() < 1e-7
+
+
+def test_fluid_gravity_hydrostatic():
+    # tests/fluid_gravity/fluid_gravity.cpp:31-41: pmax - pmin = rho g L = 20 at 1e-3, one step dt = 0.1
+    m = BoxMesh([100, 10], (0, 0), (2.0, 0.2), kv=2)
+    P = orc.make_params(mu=0.002, rho=1, gamma=0.1, dt=1e-1, g=(10.0, 0.0))
+    S, x = _run(m, {0: (3, [0, 0]), 2: (3, [0, 0]), 3: (3, [0, 0])}, P, 1)
+    p = x[S.n_u:]
+    assert abs((p.max() - p.min()) - 20) / 20 < 1e-3
+
+
+def test_fluid_pipe_mpi_developed_profile():
+    # tests/fluid_pipe_mpi/fluid_pipe_mpi.cpp:38-55: uniform inflow 1 -> vmax = 1.5 at 1e-2, 20 steps dt = 0.1
+    m = BoxMesh([100, 10], (0, 0), (2.0, 0.2), kv=2)
+    P = orc.make_params(mu=0.002, rho=1, gamma=0.1, dt=1e-1)
+    S, x = _run(m, {0: (3, [1, 0]), 2: (3, [0, 0]), 3: (3, [0, 0])}, P, 20)
+    vmax = x[:S.n_u].max()
+    assert abs(vmax - 1.5) / 1.5 < 1e-2
+
+
+def test_poiseuille_3d_extension():
+    # the bench workload -- plane Poiseuille in a 3D box, z-walls constrained in z only (flag 4).
+    # Exact in Q2 => Umax = 2.5e-2 at every resolution.
+    m = BoxMesh([6, 3, 2], (0, 0, 0), (2.0, 0.2, 0.2), kv=2)
+    P = orc.make_params(mu=1, rho=1, gamma=0.1, dt=1e-3, neumann={0: 10.0})
+    bcs = {2: (7, [0, 0, 0]), 3: (7, [0, 0, 0]), 4: (4, [0]), 5: (4, [0])}
+    S, x = _run(m, bcs, P, 80)
+    y = m.unode_coords[:, 1]
+    u_exact = 10.0 / (2 * 2.0) * y * (0.2 - y)
+    assert abs(x[:S.n_u].max() - 2.5e-2) / 2.5e-2 < 1e-3
+    assert np.abs(x[0:S.n_u:3] - u_exact).max() < 1e-7
+    assert np.abs(x[1:S.n_u:3]).max() < 1e-7 and np.abs(x[2:S.n_u:3]).max() < 1e-7
+    # pressure is linear: p = 10 (1 - x/L)
+    px = m.pnode_coords[:, 0]
+    assert np.abs(x[S.n_u:] - 10.0 * (1 - px / 2.0)).max() < 1e-5
+
+
+@pytest.mark.parametrize("dim,kv", [(2, 1), (2, 2), (3, 1), (3, 2)])
+def test_fe_tables_textbook(dim, kv):
+    # FE_Q / QGauss are third-party (deal.II) arithmetic: check partition of unity, Kronecker property of the
+    # gradients' sum and quadrature exactness to degree 2n-1 (SURVEY 8c iii).
+    import ctypes as C
+    nq1 = kv + 1
+    nn, nq = (kv + 1) ** dim, nq1 ** dim
+    phi, dphi, w, qp = np.zeros((nq, nn)), np.zeros((nq, nn, dim)), np.zeros(nq), np.zeros((nq, dim))
+    n = orc.lib().orc_fe_tables(dim, kv, nq1, phi.ctypes.data_as(C.c_void_p), dphi.ctypes.data_as(C.c_void_p),
+                                w.ctypes.data_as(C.c_void_p), qp.ctypes.data_as(C.c_void_p))
+    assert n == nq
+    assert np.allclose(phi.sum(1), 1, atol=1e-14)
+    assert np.allclose(dphi.sum(1), 0, atol=1e-13)
+    assert abs(w.sum() - 1) < 1e-14
+    deg = 2 * nq1 - 1
+    for d in range(dim):
+        assert abs((w * qp[:, d] ** deg).sum() - 1.0 / (deg + 1)) < 1e-14
+    # interpolation of a degree-kv polynomial is exact
+    lat = np.stack(np.unravel_index(np.arange(nn), (kv + 1,) * dim), -1)[:, ::-1] / kv
+    f = lambda x: (1 + x[..., 0]) ** kv * (2 - x[..., -1]) ** kv
+    assert np.allclose(phi @ f(lat), f(qp), atol=1e-13)
+
+
+def test_cell_matrix_structure():
+    # structural identities of the restated integrand (SURVEY 8c iii): Me symmetric, Ke - Ke^T = convection only,
+    # zero velocity => Ke symmetric; constant pressure mode: sum_j Ke[u_i, p_j] = -int div(phi_i)
+    rng = np.random.default_rng(0)
+    m = BoxMesh([2, 2, 2], (0, 0, 0), (1.0, 0.7, 0.4), kv=2)
+    m.vcoords = m.vcoords + 0.03 * rng.standard_normal(m.vcoords.shape)  # trilinear-distorted cells
+    S = orc.System(m)
+    P = orc.make_params(mu=0.7, rho=1.3, gamma=0.2, dt=0.01)
+    zero = np.zeros(S.n)
+    Ke, Me, fe = S.cell(P, 3, zero, zero)
+    assert np.allclose(Me, Me.T, atol=1e-15)
+    assert np.allclose(Ke, Ke.T, atol=1e-13)
+    assert np.abs(fe).max() == 0
+    ev = rng.standard_normal(S.n)
+    Ke2, _, _ = S.cell(P, 3, ev, zero)
+    nu = 27 * 3
+    assert np.allclose(Ke2[nu:, :], Ke[nu:, :]) and np.allclose(Ke2[:, nu:], Ke[:, nu:])
+    assert not np.allclose(Ke2[:nu, :nu], Ke2[:nu, :nu].T)
+    assert np.allclose(Ke[nu:, nu:], 0)
