@@ -1,0 +1,181 @@
+/*
+ * ifem_hip.h -- C ABI of libifem_hip.so: the MI355X (gfx950) implementation of OpenIFEM's implicit
+ * incompressible Navier-Stokes fluid step (assemble + block-preconditioned FGMRES solve).
+ *
+ * The reference exposes no FFI for this path; the boundary is the C++ class hierarchy
+ *   Fluid::MPI::FluidSolver<dim>  include/mpi_fluid_solver.h:89-151,185-206
+ *   Fluid::MPI::InsIM<dim>        include/mpi_insim.h:35-99
+ * Each entry point below names the reference member it replaces.  A maintainer binds them from the
+ * reference's own C++; the host-side mirror of FluidSolver/InsIM that ships in this
+ * repository (openifem_amd/csrc/host/) is one such caller.
+ *
+ * Conventions
+ *  - return 0 on success, a negative IFEM_E_* code on failure; ifem_last_error() gives the message
+ *    (maps the reference's AssertThrow exceptions, e.g. "Too many Newton iterations!" mpi_insim.cpp:424).
+ *  - plain pointers and sizes only.  The caller owns host buffers; the context owns device buffers.
+ *  - one context per GPU / per process; in a multi-GPU run every call is collective over the ranks
+ *    (like the reference's MPI_COMM_WORLD collectives, mpi_fluid_solver.cpp:37).  Not re-entrant per context.
+ *  - there is NO CPU fallback: every compute entry point fails with IFEM_E_NODEVICE without a HIP device.
+ *
+ * DoF layout (reference: DoFRenumbering::component_wise with blocks [velocity | pressure],
+ * mpi_fluid_solver.cpp:125-128): a block vector is [ u | p ] with u = dim values per velocity node
+ * (components interleaved), local nodes ordered owned-first then ghosts:
+ *     index(u, node, c) = dim*node + c                      node in [0, n_unodes_local)
+ *     index(p, node)    = dim*n_unodes_local + node         node in [0, n_pnodes_local)
+ */
+#ifndef IFEM_HIP_H
+#define IFEM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IFEM_OK 0
+#define IFEM_E_BADPARAM (-1)
+#define IFEM_E_NODEVICE (-2)
+#define IFEM_E_HIP (-3)
+#define IFEM_E_KRYLOV_NOCONV (-4) /* deal.II SolverControl::NoConvergence */
+#define IFEM_E_NEWTON_MAXIT (-5)  /* "Too many Newton iterations!" mpi_insim.cpp:424-425 */
+#define IFEM_E_COMM (-6)
+
+typedef struct ifem_ctx ifem_ctx;
+
+/* Replaces what FluidSolver::setup_dofs (mpi_fluid_solver.cpp:116-162) leaves behind: the locally relevant
+ * part of the mesh and its cell -> DoF tables.  Local cell-node order is tensor-lexicographic (x fastest).
+ * Cells listed are the ones this rank assembles (owned cells plus the ghost layer touching owned rows). */
+typedef struct {
+  int32_t dim;               /* 2 or 3 */
+  int32_t kv;                /* velocity degree 1 or 2; pressure degree is 1 */
+  int32_t n_cells;
+  int32_t n_unodes_owned, n_unodes_local; /* owned first, then ghosts grouped by neighbour rank */
+  int32_t n_pnodes_owned, n_pnodes_local;
+  const double  *vcoords;       /* [n_cells][2^dim][dim] d-linear (MappingQ1) vertex coordinates */
+  const int32_t *cell_unodes;   /* [n_cells][(kv+1)^dim] local velocity-node ids */
+  const int32_t *cell_pnodes;   /* [n_cells][2^dim] local pressure-node ids */
+  const int32_t *cell_face_bid; /* [n_cells][2*dim] boundary id or -1 (faces x-,x+,y-,y+,z-,z+) */
+} ifem_mesh_desc;
+
+/* Replaces the ghost-exchange plans PETSc builds for the ghosted vectors / MatMult
+ * (mpi_fluid_solver.cpp:333-338).  NULL for a single-GPU run. */
+typedef struct {
+  int32_t rank, nranks;
+  int32_t n_neighbors;
+  const int32_t *neighbor_rank; /* [n_neighbors] */
+  const int32_t *send_u_ptr;    /* [n_neighbors+1] into send_u_idx */
+  const int32_t *send_u_idx;    /* owned velocity nodes to send, per neighbour */
+  const int32_t *recv_u_ptr;    /* [n_neighbors+1]: ghost velocity nodes of neighbour k are local ids
+                                   n_unodes_owned + [recv_u_ptr[k], recv_u_ptr[k+1]) */
+  const int32_t *send_p_ptr, *send_p_idx, *recv_p_ptr; /* same for pressure nodes */
+  const uint8_t *nccl_unique_id; /* 128 bytes from ifem_comm_unique_id(), identical on all ranks */
+} ifem_partition;
+
+/* Parameters::AllParameters subset used by InsIM::assemble (mpi_insim.cpp:157-161,240,272; parameters.cpp) */
+typedef struct {
+  double viscosity, rho, grad_div, dt;
+  double gravity[3];
+  int32_t n_neumann;          /* parameters.fluid_neumann_bcs (pressure BCs), mpi_insim.cpp:313-341 */
+  int32_t neumann_id[8];
+  double  neumann_p[8];
+} ifem_ins_params;
+
+/* How A~^-1 (MUMPS in the reference, mpi_insim.cpp:124-127) is replaced */
+#define IFEM_AINV_GMRES_BJACOBI 0 /* inner GMRES(m) on A_uu, node-block Jacobi preconditioned */
+
+typedef struct {
+  int32_t fgmres_restart;     /* 30: deal.II SolverFGMRES default */
+  int32_t fgmres_maxit;       /* 0 -> n_dofs (mpi_insim.cpp:379-380) */
+  double  fgmres_rel;         /* 1e-4 */
+  double  fgmres_abs;         /* 1e-12 */
+  double  mp_rel, mp_abs;     /* CG(M_p) 1e-6, 1e-10 (mpi_insim.cpp:73-74) */
+  double  sm_rel, sm_abs;     /* CG(S_m) 1e-3, 1e-10 (mpi_insim.cpp:88-89) */
+  int32_t ainv_kind;          /* IFEM_AINV_* */
+  int32_t inner_restart, inner_maxit;
+  double  inner_rel;          /* relative residual target of the inner A_uu solve */
+  int32_t verbose;
+} ifem_solver_opts;
+
+/* counters of the last ifem_solve (the timer2 sections of mpi_insim.cpp:70,87,125) */
+typedef struct {
+  uint32_t fgmres_iters; double fgmres_res;
+  uint32_t precond_applies, cg_mp_iters, cg_sm_iters, inner_iters;
+  double t_schur_setup_ms, t_cg_mp_ms, t_cg_sm_ms, t_ainv_ms, t_spmv_ms, t_total_ms;
+} ifem_solve_stats;
+
+/* context-resident block vectors (reference members of FluidSolver / InsIM) */
+enum {
+  IFEM_VEC_PRESENT = 0,   /* present_solution       mpi_fluid_solver.h:203 */
+  IFEM_VEC_EVAL = 1,      /* evaluation_point       mpi_insim.h */
+  IFEM_VEC_FSI_ACC = 2,   /* fsi_acceleration       mpi_fluid_solver.h:209 */
+  IFEM_VEC_UPDATE = 3,    /* newton_update */
+  IFEM_VEC_RHS = 4,       /* system_rhs */
+  IFEM_VEC_INCREMENT = 5, /* solution_increment */
+  IFEM_VEC_TMP = 6,
+  IFEM_N_VECS = 7
+};
+
+const char *ifem_last_error(void);
+int ifem_device_count(void);
+void ifem_default_solver_opts(ifem_solver_opts *o);
+/* RCCL bootstrap: rank 0 calls this and ships the 128 bytes to the other ranks by any channel */
+int ifem_comm_unique_id(uint8_t out[128]);
+
+/* FluidSolver::initialize_system (mpi_fluid_solver.cpp:305-365, mpi_insim.cpp:143-150): builds the block
+ * sparsity (A_uu as dim x dim BSR, B, B^T, M_p, S_m) on the device, scatter maps, halo plans and vectors. */
+int ifem_ctx_create(const ifem_mesh_desc *mesh, const ifem_partition *part, int device, ifem_ctx **out);
+void ifem_ctx_destroy(ifem_ctx *ctx);
+int64_t ifem_n_local_dofs(const ifem_ctx *ctx);
+int64_t ifem_nnz(const ifem_ctx *ctx, int block); /* 0: A_uu blocks, 1: B blocks, 2: M_p, 3: S_m */
+
+/* FluidSolver::make_constraints result (mpi_fluid_solver.cpp:165-280): which = 0 zero_constraints,
+ * 1 nonzero_constraints; Dirichlet lines (local dof, inhomogeneity). */
+int ifem_set_constraints(ifem_ctx *ctx, int which, int32_t n, const int32_t *dof, const double *inhom);
+/* cell_property[*].indicator written by MPI::FSI::update_indicator (mpi_fsi.cpp:291-321); NULL = all 0 */
+int ifem_set_cell_fields(ifem_ctx *ctx, const int32_t *indicator);
+
+/* block-vector plumbing (PETScWrappers::MPI::BlockVector assignments in run_one_step) */
+int ifem_vec_set(ifem_ctx *ctx, int vec, const double *host);
+int ifem_vec_get(ifem_ctx *ctx, int vec, double *host);
+int ifem_vec_copy(ifem_ctx *ctx, int dst, int src);
+int ifem_vec_zero(ifem_ctx *ctx, int vec);
+int ifem_vec_axpy(ifem_ctx *ctx, double a, int x, int y); /* y += a x */
+int ifem_vec_norm2(ifem_ctx *ctx, int vec, double *out);  /* l2_norm(), all-reduced over ranks */
+/* Utils::PETScVectorMax/Min over one block (source/utilities.cpp:635-651): block 0 velocity, 1 pressure */
+int ifem_vec_minmax(ifem_ctx *ctx, int vec, int block, double *vmin, double *vmax);
+int ifem_halo_exchange(ifem_ctx *ctx, int vec);           /* ghosted-vector assignment */
+
+/* InsIM::assemble(use_nonzero_constraints), mpi_insim.cpp:153-362.  Reads IFEM_VEC_EVAL, _PRESENT,
+ * _FSI_ACC; writes the device matrices (A_uu, B, B^T, diag(M_u), M_p) and IFEM_VEC_RHS. */
+int ifem_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
+/* InsIM::solve(use_nonzero_constraints), mpi_insim.cpp:365-395 incl. BlockSchurPreconditioner :13-128.
+ * Solves into IFEM_VEC_UPDATE and applies constraints.distribute(). */
+int ifem_solve(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int use_nonzero,
+               ifem_solve_stats *stats);
+/* system_rhs.l2_norm(), mpi_insim.cpp:438 */
+int ifem_rhs_norm(ifem_ctx *ctx, double *l2);
+/* the Newton loop of InsIM::run_one_step, mpi_insim.cpp:416-473.  log (may be NULL) receives
+ * [ABS_RES, REL_RES, GMRES_ITR, GMRES_RES] per iteration.  Returns the number of Newton iterations. */
+int ifem_ins_newton_step(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int apply_nonzero,
+                         double tolerance, int max_iterations, double *log);
+
+/* y = [A Bt; B 0] x on context vectors (system_matrix.vmult) -- test / bench hook */
+int ifem_system_vmult(ifem_ctx *ctx, int dst, int src);
+/* z = P^-1 v, BlockSchurPreconditioner::vmult (mpi_insim.cpp:57-128) on context vectors -- test hook */
+int ifem_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int dst, int src);
+
+/* Export the assembled block system as one CSR over the local dofs [u|p] (host arrays; call twice: first
+ * with col = val = NULL to get nnz through rowptr[n]).  which: 0 system_matrix, 1 mass (diag(M_u), M_p). */
+int ifem_export_csr(ifem_ctx *ctx, int which, int64_t *rowptr, int32_t *col, double *val);
+
+/* per-kernel timing of the last assemble/solve, HIP events on the context stream */
+typedef struct {
+  double assemble_ms;        /* whole ifem_ins_assemble */
+  double assemble_kernel_ms; /* the cell-integration + scatter kernel alone */
+  double spmv_uu_ms_avg; uint64_t spmv_uu_calls; /* A_uu BSR SpMV (dominant kernel of the solve) */
+  double spmv_uu_bytes;      /* algorithmic bytes per call */
+} ifem_timing;
+int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

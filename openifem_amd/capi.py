@@ -1,0 +1,236 @@
+"""ctypes binding of libifem_hip.so -- exactly the entry points declared in include/ifem_hip.h.
+
+This is plumbing for tests and bench.py; the product is the shared library.  There is no CPU fallback:
+loading works anywhere (hipcc cross-compiles), every compute call needs a HIP device.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libifem_hip.so")
+
+VEC_PRESENT, VEC_EVAL, VEC_FSI_ACC, VEC_UPDATE, VEC_RHS, VEC_INCREMENT, VEC_TMP = range(7)
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("kv", C.c_int32), ("n_cells", C.c_int32),
+                ("n_unodes_owned", C.c_int32), ("n_unodes_local", C.c_int32),
+                ("n_pnodes_owned", C.c_int32), ("n_pnodes_local", C.c_int32),
+                ("vcoords", C.c_void_p), ("cell_unodes", C.c_void_p), ("cell_pnodes", C.c_void_p),
+                ("cell_face_bid", C.c_void_p)]
+
+
+class Partition(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("nranks", C.c_int32), ("n_neighbors", C.c_int32),
+                ("neighbor_rank", C.c_void_p), ("send_u_ptr", C.c_void_p), ("send_u_idx", C.c_void_p),
+                ("recv_u_ptr", C.c_void_p), ("send_p_ptr", C.c_void_p), ("send_p_idx", C.c_void_p),
+                ("recv_p_ptr", C.c_void_p), ("nccl_unique_id", C.c_void_p)]
+
+
+class InsParams(C.Structure):
+    _fields_ = [("viscosity", C.c_double), ("rho", C.c_double), ("grad_div", C.c_double), ("dt", C.c_double),
+                ("gravity", C.c_double * 3), ("n_neumann", C.c_int32), ("neumann_id", C.c_int32 * 8),
+                ("neumann_p", C.c_double * 8)]
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [("fgmres_restart", C.c_int32), ("fgmres_maxit", C.c_int32), ("fgmres_rel", C.c_double),
+                ("fgmres_abs", C.c_double), ("mp_rel", C.c_double), ("mp_abs", C.c_double),
+                ("sm_rel", C.c_double), ("sm_abs", C.c_double), ("ainv_kind", C.c_int32),
+                ("inner_restart", C.c_int32), ("inner_maxit", C.c_int32), ("inner_rel", C.c_double),
+                ("verbose", C.c_int32)]
+
+
+class SolveStats(C.Structure):
+    _fields_ = [("fgmres_iters", C.c_uint32), ("fgmres_res", C.c_double), ("precond_applies", C.c_uint32),
+                ("cg_mp_iters", C.c_uint32), ("cg_sm_iters", C.c_uint32), ("inner_iters", C.c_uint32),
+                ("t_schur_setup_ms", C.c_double), ("t_cg_mp_ms", C.c_double), ("t_cg_sm_ms", C.c_double),
+                ("t_ainv_ms", C.c_double), ("t_spmv_ms", C.c_double), ("t_total_ms", C.c_double)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("assemble_ms", C.c_double), ("assemble_kernel_ms", C.c_double), ("spmv_uu_ms_avg", C.c_double),
+                ("spmv_uu_calls", C.c_uint64), ("spmv_uu_bytes", C.c_double)]
+
+
+EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "ifem_comm_unique_id",
+           "ifem_ctx_create", "ifem_ctx_destroy", "ifem_n_local_dofs", "ifem_nnz", "ifem_set_constraints",
+           "ifem_set_cell_fields", "ifem_vec_set", "ifem_vec_get", "ifem_vec_copy", "ifem_vec_zero", "ifem_vec_axpy",
+           "ifem_vec_norm2", "ifem_vec_minmax", "ifem_halo_exchange", "ifem_ins_assemble", "ifem_solve",
+           "ifem_rhs_norm", "ifem_ins_newton_step", "ifem_system_vmult", "ifem_precond_vmult", "ifem_export_csr",
+           "ifem_get_timing"]
+
+_lib = None
+
+
+class IfemError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ifem error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the HIP path)")
+    L = C.CDLL(LIB_PATH)
+    L.ifem_last_error.restype = C.c_char_p
+    L.ifem_n_local_dofs.restype = C.c_int64
+    L.ifem_n_local_dofs.argtypes = [C.c_void_p]
+    L.ifem_nnz.restype = C.c_int64
+    L.ifem_nnz.argtypes = [C.c_void_p, C.c_int]
+    L.ifem_default_solver_opts.argtypes = [C.POINTER(SolverOpts)]
+    L.ifem_ctx_create.argtypes = [C.POINTER(MeshDesc), C.POINTER(Partition), C.c_int, C.POINTER(C.c_void_p)]
+    L.ifem_ctx_destroy.argtypes = [C.c_void_p]
+    L.ifem_set_constraints.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p]
+    L.ifem_set_cell_fields.argtypes = [C.c_void_p, C.c_void_p]
+    L.ifem_vec_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.ifem_vec_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.ifem_vec_copy.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.ifem_vec_zero.argtypes = [C.c_void_p, C.c_int]
+    L.ifem_vec_axpy.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
+    L.ifem_vec_norm2.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    L.ifem_vec_minmax.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ifem_halo_exchange.argtypes = [C.c_void_p, C.c_int]
+    L.ifem_ins_assemble.argtypes = [C.c_void_p, C.POINTER(InsParams), C.c_int]
+    L.ifem_solve.argtypes = [C.c_void_p, C.POINTER(InsParams), C.POINTER(SolverOpts), C.c_int, C.POINTER(SolveStats)]
+    L.ifem_rhs_norm.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.ifem_ins_newton_step.argtypes = [C.c_void_p, C.POINTER(InsParams), C.POINTER(SolverOpts), C.c_int, C.c_double,
+                                       C.c_int, C.c_void_p]
+    L.ifem_system_vmult.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.ifem_precond_vmult.argtypes = [C.c_void_p, C.POINTER(InsParams), C.POINTER(SolverOpts), C.c_int, C.c_int]
+    L.ifem_export_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifem_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+    L.ifem_comm_unique_id.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_params(mu=1.0, rho=1.0, gamma=0.1, dt=1e-3, g=(0, 0, 0), neumann=None):
+    p = InsParams()
+    p.viscosity, p.rho, p.grad_div, p.dt = mu, rho, gamma, dt
+    for i in range(3):
+        p.gravity[i] = g[i] if i < len(g) else 0.0
+    neumann = neumann or {}
+    p.n_neumann = len(neumann)
+    for k, (bid, val) in enumerate(sorted(neumann.items())):
+        p.neumann_id[k] = bid
+        p.neumann_p[k] = val
+    return p
+
+
+class Context:
+    """RAII wrapper of one ifem_ctx built from plain numpy mesh tables."""
+
+    def __init__(self, dim, kv, vcoords, cell_unodes, cell_pnodes, cell_face_bid, n_unodes, n_pnodes,
+                 n_unodes_owned=None, n_pnodes_owned=None, partition=None, device=0):
+        self.L = load()
+        self._keep = [np.ascontiguousarray(vcoords, float), np.ascontiguousarray(cell_unodes, np.int32),
+                      np.ascontiguousarray(cell_pnodes, np.int32),
+                      None if cell_face_bid is None else np.ascontiguousarray(cell_face_bid, np.int32)]
+        m = MeshDesc(dim, kv, len(self._keep[1]), n_unodes if n_unodes_owned is None else n_unodes_owned, n_unodes,
+                     n_pnodes if n_pnodes_owned is None else n_pnodes_owned, n_pnodes, *[_ptr(a) for a in self._keep])
+        self.dim, self.kv = dim, kv
+        self.h = C.c_void_p()
+        self._chk(self.L.ifem_ctx_create(C.byref(m), partition, device, C.byref(self.h)))
+        self.n_local = self.L.ifem_n_local_dofs(self.h)
+        self.n_u = dim * m.n_unodes_local
+        self.n_owned = dim * m.n_unodes_owned + m.n_pnodes_owned
+        self.opts = SolverOpts()
+        self.L.ifem_default_solver_opts(C.byref(self.opts))
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise IfemError(rc, self.L.ifem_last_error().decode())
+        return rc
+
+    def close(self):
+        if self.h:
+            self.L.ifem_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_constraints(self, which, dofs, vals=None):
+        dofs = np.ascontiguousarray(dofs, np.int32)
+        vals = None if vals is None else np.ascontiguousarray(vals, float)
+        self._chk(self.L.ifem_set_constraints(self.h, which, len(dofs), _ptr(dofs), _ptr(vals)))
+
+    def set_indicator(self, ind):
+        ind = None if ind is None else np.ascontiguousarray(ind, np.int32)
+        self._chk(self.L.ifem_set_cell_fields(self.h, _ptr(ind)))
+
+    def _len(self, vec):
+        return self.n_local if vec in (VEC_PRESENT, VEC_EVAL, VEC_FSI_ACC, VEC_INCREMENT) else self.n_owned
+
+    def vec_set(self, vec, x):
+        x = np.ascontiguousarray(x, float)
+        assert x.size == self._len(vec)
+        self._chk(self.L.ifem_vec_set(self.h, vec, _ptr(x)))
+
+    def vec_get(self, vec):
+        x = np.zeros(self._len(vec))
+        self._chk(self.L.ifem_vec_get(self.h, vec, _ptr(x)))
+        return x
+
+    def assemble(self, params, use_nonzero):
+        self._chk(self.L.ifem_ins_assemble(self.h, C.byref(params), int(use_nonzero)))
+
+    def solve(self, params, use_nonzero):
+        st = SolveStats()
+        self._chk(self.L.ifem_solve(self.h, C.byref(params), C.byref(self.opts), int(use_nonzero), C.byref(st)))
+        return st
+
+    def rhs_norm(self):
+        v = C.c_double()
+        self._chk(self.L.ifem_rhs_norm(self.h, C.byref(v)))
+        return v.value
+
+    def newton_step(self, params, apply_nonzero, tol=1e-6, maxit=8):
+        log = np.zeros((maxit + 1, 4))
+        rc = self._chk(self.L.ifem_ins_newton_step(self.h, C.byref(params), C.byref(self.opts), int(apply_nonzero), tol,
+                                                   maxit, _ptr(log)))
+        return rc, log[:rc]
+
+    def minmax(self, vec, block):
+        a, b = C.c_double(), C.c_double()
+        self._chk(self.L.ifem_vec_minmax(self.h, vec, block, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def system_vmult(self, x):
+        self.vec_set(VEC_TMP, x)
+        self._chk(self.L.ifem_system_vmult(self.h, VEC_UPDATE, VEC_TMP))
+        return self.vec_get(VEC_UPDATE)
+
+    def precond_vmult(self, params, x):
+        self.vec_set(VEC_TMP, x)
+        self._chk(self.L.ifem_precond_vmult(self.h, C.byref(params), C.byref(self.opts), VEC_UPDATE, VEC_TMP))
+        return self.vec_get(VEC_UPDATE)
+
+    def export_csr(self, which=0):
+        import scipy.sparse as sp
+        n = self.n_owned
+        rp = np.zeros(n + 1, np.int64)
+        self._chk(self.L.ifem_export_csr(self.h, which, _ptr(rp), None, None))
+        col = np.zeros(rp[-1], np.int32)
+        val = np.zeros(rp[-1])
+        self._chk(self.L.ifem_export_csr(self.h, which, _ptr(rp), _ptr(col), _ptr(val)))
+        return sp.csr_matrix((val, col, rp), shape=(n, self.n_local))
+
+    def timing(self):
+        t = Timing()
+        self._chk(self.L.ifem_get_timing(self.h, C.byref(t)))
+        return t

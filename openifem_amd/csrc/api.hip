@@ -1,0 +1,368 @@
+// api.hip -- the extern "C" surface declared in include/ifem_hip.h.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ctx.hpp"
+#include "kernels.hpp"
+
+using namespace ifem;
+
+static thread_local std::string g_err;
+
+#define IFEM_API_BEGIN try {
+#define IFEM_API_END                                           \
+  }                                                            \
+  catch (const ifem::Error &e) { g_err = e.what(); return e.code; } \
+  catch (const std::exception &e) { g_err = e.what(); return IFEM_E_HIP; } \
+  return IFEM_OK;
+
+extern "C" {
+
+const char *ifem_last_error(void) { return g_err.c_str(); }
+
+int ifem_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void ifem_default_solver_opts(ifem_solver_opts *o) {
+  o->fgmres_restart = 30; o->fgmres_maxit = 0; o->fgmres_rel = 1e-4; o->fgmres_abs = 1e-12;
+  o->mp_rel = 1e-6; o->mp_abs = 1e-10; o->sm_rel = 1e-3; o->sm_abs = 1e-10;
+  o->ainv_kind = IFEM_AINV_GMRES_BJACOBI; o->inner_restart = 30; o->inner_maxit = 400; o->inner_rel = 1e-2;
+  o->verbose = 0;
+}
+
+int ifem_ctx_create(const ifem_mesh_desc *m, const ifem_partition *part, int device, ifem_ctx **out) {
+  ifem_ctx *ctx = nullptr;
+  IFEM_API_BEGIN
+  if (!m || !out) throw Error(IFEM_E_BADPARAM, "null argument");
+  if ((m->dim != 2 && m->dim != 3) || (m->kv != 1 && m->kv != 2)) throw Error(IFEM_E_BADPARAM, "dim must be 2|3, kv 1|2");
+  if (ifem_device_count() <= device) throw Error(IFEM_E_NODEVICE, "no HIP device: libifem_hip has no CPU fallback");
+  IFEM_HIP_CHECK(hipSetDevice(device));
+  ctx = new ifem_ctx();
+  ctx->device = device;
+  IFEM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  IFEM_HIP_CHECK(hipEventCreate(&ctx->ev0));
+  IFEM_HIP_CHECK(hipEventCreate(&ctx->ev1));
+  hipStream_t s = ctx->stream;
+  ctx->dim = m->dim; ctx->kv = m->kv;
+  build_fe_tables(ctx->fe, m->dim, m->kv);
+  ctx->nu = ctx->fe.nu; ctx->np = ctx->fe.np; ctx->nq = ctx->fe.nq;
+  ctx->d_fe.upload(&ctx->fe, 1, s);
+  ctx->n_cells = m->n_cells;
+  ctx->nUo = m->n_unodes_owned; ctx->nUl = m->n_unodes_local;
+  ctx->nPo = m->n_pnodes_owned; ctx->nPl = m->n_pnodes_local;
+  ctx->n_local = ctx->dim * ctx->nUl + ctx->nPl;
+  const int dim = ctx->dim, nu = ctx->nu, np = ctx->np;
+  ctx->vcoords.upload(m->vcoords, (size_t)m->n_cells * np * dim, s);
+  ctx->cell_unodes.upload(m->cell_unodes, (size_t)m->n_cells * nu, s);
+  ctx->cell_pnodes.upload(m->cell_pnodes, (size_t)m->n_cells * np, s);
+  if (m->cell_face_bid) ctx->cell_face_bid.upload(m->cell_face_bid, (size_t)m->n_cells * 2 * dim, s);
+  else {
+    std::vector<int32_t> none((size_t)m->n_cells * 2 * dim, -1);
+    ctx->cell_face_bid.upload(none.data(), none.size(), s);
+    IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  IFEM_HIP_CHECK(hipHostMalloc((void **)&ctx->h_scal, 256 * sizeof(double)));
+  ctx->scal.alloc(256);
+  comm_init(ctx, part);
+  // block sparsity + scatter maps (make_sparsity_pattern / matrix.reinit, mpi_fluid_solver.cpp:311-322)
+  build_pattern(ctx, ctx->Auu, dim * dim, ctx->nUo, nu, ctx->cell_unodes.p, nu, ctx->cell_unodes.p, ctx->posUU);
+  build_pattern(ctx, ctx->Bt, dim, ctx->nUo, nu, ctx->cell_unodes.p, np, ctx->cell_pnodes.p, ctx->posUP);
+  build_pattern(ctx, ctx->B, dim, ctx->nPo, np, ctx->cell_pnodes.p, nu, ctx->cell_unodes.p, ctx->posPU);
+  build_pattern(ctx, ctx->Mp, 1, ctx->nPo, np, ctx->cell_pnodes.p, np, ctx->cell_pnodes.p, ctx->posPP);
+  ctx->diagMu.alloc((size_t)dim * ctx->nUo);
+  ctx->dinvMu.alloc((size_t)dim * ctx->nUo);
+  ctx->bjac.alloc((size_t)dim * dim * ctx->nUo);
+  for (int v = 0; v < IFEM_N_VECS; ++v) {
+    ctx->vec[v].alloc((size_t)ctx->n_local);
+    IFEM_HIP_CHECK(hipMemsetAsync(ctx->vec[v].p, 0, ctx->n_local * sizeof(double), s));
+  }
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  *out = ctx;
+  }
+  catch (const ifem::Error &e) { g_err = e.what(); if (ctx) ifem_ctx_destroy(ctx); return e.code; }
+  catch (const std::exception &e) { g_err = e.what(); if (ctx) ifem_ctx_destroy(ctx); return IFEM_E_HIP; }
+  return IFEM_OK;
+}
+
+void ifem_ctx_destroy(ifem_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  comm_destroy(ctx);
+  if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  hipStream_t s = ctx->stream;
+  delete ctx;
+  if (s) (void)hipStreamDestroy(s);
+}
+
+int64_t ifem_n_local_dofs(const ifem_ctx *ctx) { return ctx->n_local; }
+int64_t ifem_nnz(const ifem_ctx *ctx, int block) {
+  switch (block) {
+  case 0: return ctx->Auu.nnzb;
+  case 1: return ctx->B.nnzb;
+  case 2: return ctx->Mp.nnzb;
+  default: return 0;
+  }
+}
+
+int ifem_set_constraints(ifem_ctx *ctx, int which, int32_t n, const int32_t *dof, const double *inhom) {
+  IFEM_API_BEGIN
+  if (which < 0 || which > 1) throw Error(IFEM_E_BADPARAM, "which must be 0 or 1");
+  std::vector<uint8_t> f((size_t)ctx->n_local, 0);
+  std::vector<double> v((size_t)ctx->n_local, 0.0);
+  for (int32_t i = 0; i < n; ++i) {
+    if (dof[i] < 0 || dof[i] >= ctx->n_local) throw Error(IFEM_E_BADPARAM, "constraint dof out of range");
+    if (dof[i] >= ctx->dim * ctx->nUl) throw Error(IFEM_E_BADPARAM, "pressure Dirichlet constraints are not supported");
+    f[dof[i]] = 1;
+    v[dof[i]] = inhom ? inhom[i] : 0.0;
+  }
+  ctx->is_c[which].upload(f.data(), f.size(), ctx->stream);
+  ctx->cval[which].upload(v.data(), v.size(), ctx->stream);
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->has_c[which] = n > 0;
+  IFEM_API_END
+}
+
+int ifem_set_cell_fields(ifem_ctx *ctx, const int32_t *indicator) {
+  IFEM_API_BEGIN
+  if (indicator) {
+    ctx->indicator.upload(indicator, (size_t)ctx->n_cells, ctx->stream);
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } else
+    ctx->indicator.release();
+  IFEM_API_END
+}
+
+static inline bool vec_ok(int v) { return v >= 0 && v < IFEM_N_VECS; }
+// PRESENT / EVAL / FSI_ACC / INCREMENT are ghosted (extended) vectors, the others hold owned entries only
+static inline bool is_ext(int v) { return v == IFEM_VEC_PRESENT || v == IFEM_VEC_EVAL || v == IFEM_VEC_FSI_ACC || v == IFEM_VEC_INCREMENT; }
+static inline int64_t vec_len(const ifem_ctx *c, int v) { return is_ext(v) ? c->n_local : c->dim * c->nUo + c->nPo; }
+static inline int64_t p_off(const ifem_ctx *c, int v) { return c->dim * (is_ext(v) ? c->nUl : c->nUo); }
+
+int ifem_vec_set(ifem_ctx *ctx, int vec, const double *host) {
+  IFEM_API_BEGIN
+  if (!vec_ok(vec)) throw Error(IFEM_E_BADPARAM, "bad vector id");
+  IFEM_HIP_CHECK(hipMemcpyAsync(ctx->vec[vec].p, host, vec_len(ctx, vec) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+int ifem_vec_get(ifem_ctx *ctx, int vec, double *host) {
+  IFEM_API_BEGIN
+  if (!vec_ok(vec)) throw Error(IFEM_E_BADPARAM, "bad vector id");
+  IFEM_HIP_CHECK(hipMemcpyAsync(host, ctx->vec[vec].p, vec_len(ctx, vec) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+int ifem_vec_zero(ifem_ctx *ctx, int vec) {
+  IFEM_API_BEGIN
+  if (!vec_ok(vec)) throw Error(IFEM_E_BADPARAM, "bad vector id");
+  v_zero(ctx, ctx->n_local, ctx->vec[vec].p);
+  IFEM_API_END
+}
+// owned entries of src -> dst (layouts may differ); ghosts of an extended dst are refreshed
+static void copy_owned(ifem_ctx *ctx, int dst, int src, double a_src, double b_dst) {
+  const int64_t nuo = ctx->dim * ctx->nUo;
+  v_axpby(ctx, nuo, a_src, ctx->vec[src].p, b_dst, ctx->vec[dst].p);
+  v_axpby(ctx, ctx->nPo, a_src, ctx->vec[src].p + p_off(ctx, src), b_dst, ctx->vec[dst].p + p_off(ctx, dst));
+  if (is_ext(dst)) {
+    halo_exchange(ctx, ctx->vec[dst].p);
+    halo_exchange_p(ctx, ctx->vec[dst].p + p_off(ctx, dst));
+  }
+}
+int ifem_vec_copy(ifem_ctx *ctx, int dst, int src) {
+  IFEM_API_BEGIN
+  if (!vec_ok(dst) || !vec_ok(src)) throw Error(IFEM_E_BADPARAM, "bad vector id");
+  copy_owned(ctx, dst, src, 1.0, 0.0);
+  IFEM_API_END
+}
+int ifem_vec_axpy(ifem_ctx *ctx, double a, int x, int y) {
+  IFEM_API_BEGIN
+  if (!vec_ok(x) || !vec_ok(y)) throw Error(IFEM_E_BADPARAM, "bad vector id");
+  copy_owned(ctx, y, x, a, 1.0);
+  IFEM_API_END
+}
+static double norm2_owned(ifem_ctx *ctx, int vec) {
+  const int64_t nuo = ctx->dim * ctx->nUo;
+  double d[2];
+  d[0] = v_dot(ctx, nuo, ctx->vec[vec].p, ctx->vec[vec].p);
+  d[1] = v_dot(ctx, ctx->nPo, ctx->vec[vec].p + p_off(ctx, vec), ctx->vec[vec].p + p_off(ctx, vec));
+  double s = d[0] + d[1];
+  allreduce_sum(ctx, &s, 1);
+  return std::sqrt(s);
+}
+int ifem_vec_norm2(ifem_ctx *ctx, int vec, double *out) {
+  IFEM_API_BEGIN
+  if (!vec_ok(vec)) throw Error(IFEM_E_BADPARAM, "bad vector id");
+  *out = norm2_owned(ctx, vec);
+  IFEM_API_END
+}
+int ifem_vec_minmax(ifem_ctx *ctx, int vec, int block, double *vmin, double *vmax) {
+  IFEM_API_BEGIN
+  if (!vec_ok(vec)) throw Error(IFEM_E_BADPARAM, "bad vector id");
+  double mn, mx;
+  if (block == 0) v_minmax(ctx, ctx->dim * ctx->nUo, ctx->vec[vec].p, &mn, &mx);
+  else v_minmax(ctx, ctx->nPo, ctx->vec[vec].p + p_off(ctx, vec), &mn, &mx);
+  if (ctx->halo.nranks > 1) { // max = -min(-x): reuse the sum all-reduce on {mn, -mx} is wrong; do two max-reductions
+    double t[2] = {-mn, mx};
+    allreduce_max(ctx, t, 2);
+    mn = -t[0]; mx = t[1];
+  }
+  if (vmin) *vmin = mn;
+  if (vmax) *vmax = mx;
+  IFEM_API_END
+}
+int ifem_halo_exchange(ifem_ctx *ctx, int vec) {
+  IFEM_API_BEGIN
+  if (!vec_ok(vec) || !is_ext(vec)) throw Error(IFEM_E_BADPARAM, "not a ghosted vector");
+  halo_exchange(ctx, ctx->vec[vec].p);
+  halo_exchange_p(ctx, ctx->vec[vec].p + p_off(ctx, vec));
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+
+int ifem_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) {
+  IFEM_API_BEGIN
+  if (!p || p->dt <= 0) throw Error(IFEM_E_BADPARAM, "bad ifem_ins_params");
+  auto t0 = std::chrono::steady_clock::now();
+  launch_ins_assemble(ctx, p, use_nonzero);
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->timing.assemble_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  IFEM_API_END
+}
+
+int ifem_solve(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats) {
+  IFEM_API_BEGIN
+  ifem_solver_opts def;
+  if (!o) { ifem_default_solver_opts(&def); o = &def; }
+  const int rc = ins_solve(ctx, p, o, use_nonzero, stats);
+  if (rc != 0) throw Error(rc, "FGMRES did not converge (SolverControl::NoConvergence)");
+  IFEM_API_END
+}
+
+int ifem_rhs_norm(ifem_ctx *ctx, double *l2) { return ifem_vec_norm2(ctx, IFEM_VEC_RHS, l2); }
+
+int ifem_ins_newton_step(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int apply_nonzero,
+                         double tolerance, int max_iterations, double *log) {
+  int outer = 0;
+  try {
+    ifem_solver_opts def;
+    if (!o) { ifem_default_solver_opts(&def); o = &def; }
+    double cur = 1.0, init = 1.0, rel = 1.0;
+    copy_owned(ctx, IFEM_VEC_EVAL, IFEM_VEC_PRESENT, 1.0, 0.0); // evaluation_point = present_solution (:420)
+    while (rel > tolerance && cur > 1e-11) {
+      if (outer >= max_iterations) throw Error(IFEM_E_NEWTON_MAXIT, "Too many Newton iterations!");
+      const int nz = apply_nonzero && outer == 0;
+      v_zero(ctx, ctx->n_local, ctx->vec[IFEM_VEC_UPDATE].p); // newton_update = 0 (:427)
+      launch_ins_assemble(ctx, p, nz);
+      ifem_solve_stats st{};
+      const int rc = ins_solve(ctx, p, o, nz, &st);
+      if (rc != 0) throw Error(rc, "FGMRES did not converge (SolverControl::NoConvergence)");
+      cur = norm2_owned(ctx, IFEM_VEC_RHS);                      // system_rhs.l2_norm() (:438)
+      copy_owned(ctx, IFEM_VEC_EVAL, IFEM_VEC_UPDATE, 1.0, 1.0); // evaluation_point += newton_update (:444-448)
+      if (outer == 0) init = cur;
+      rel = cur / init;
+      if (log) { log[outer * 4 + 0] = cur; log[outer * 4 + 1] = rel; log[outer * 4 + 2] = st.fgmres_iters; log[outer * 4 + 3] = st.fgmres_res; }
+      ++outer;
+    }
+    // solution_increment = present - evaluation; present = evaluation (:465-473)
+    copy_owned(ctx, IFEM_VEC_INCREMENT, IFEM_VEC_PRESENT, 1.0, 0.0);
+    copy_owned(ctx, IFEM_VEC_INCREMENT, IFEM_VEC_EVAL, -1.0, 1.0);
+    copy_owned(ctx, IFEM_VEC_PRESENT, IFEM_VEC_EVAL, 1.0, 0.0);
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  catch (const ifem::Error &e) { g_err = e.what(); return e.code; }
+  catch (const std::exception &e) { g_err = e.what(); return IFEM_E_HIP; }
+  return outer;
+}
+
+int ifem_system_vmult(ifem_ctx *ctx, int dst, int src) {
+  IFEM_API_BEGIN
+  if (!vec_ok(dst) || !vec_ok(src) || is_ext(dst) || is_ext(src)) throw Error(IFEM_E_BADPARAM, "use non-ghosted vectors");
+  ins_system_vmult(ctx, ctx->vec[src].p, ctx->vec[dst].p);
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+
+int ifem_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int dst, int src) {
+  IFEM_API_BEGIN
+  if (!vec_ok(dst) || !vec_ok(src) || is_ext(dst) || is_ext(src)) throw Error(IFEM_E_BADPARAM, "use non-ghosted vectors");
+  ifem_solver_opts def;
+  if (!o) { ifem_default_solver_opts(&def); o = &def; }
+  ins_precond_vmult(ctx, p, o, ctx->vec[src].p, ctx->vec[dst].p);
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+
+int ifem_export_csr(ifem_ctx *ctx, int which, int64_t *rowptr, int32_t *col, double *val) {
+  IFEM_API_BEGIN
+  hipStream_t s = ctx->stream;
+  const int dim = ctx->dim;
+  const int64_t nuo = dim * ctx->nUo, npo = ctx->nPo, n = nuo + npo, poff = dim * ctx->nUl;
+  auto rpA = ctx->Auu.rowptr.download(s), rpT = ctx->Bt.rowptr.download(s), rpB = ctx->B.rowptr.download(s),
+       rpM = ctx->Mp.rowptr.download(s);
+  // pattern: [A_uu | B^T ; B | M_p-pattern]  (explicit zeros kept so that both `which` share one pattern)
+  rowptr[0] = 0;
+  for (int64_t A = 0; A < ctx->nUo; ++A)
+    for (int c = 0; c < dim; ++c) rowptr[A * dim + c + 1] = (rpA[A + 1] - rpA[A]) * dim + (rpT[A + 1] - rpT[A]);
+  for (int64_t i = 0; i < npo; ++i) rowptr[nuo + i + 1] = (rpB[i + 1] - rpB[i]) * dim + (rpM[i + 1] - rpM[i]);
+  for (int64_t i = 0; i < n; ++i) rowptr[i + 1] += rowptr[i];
+  if (!col || !val) return IFEM_OK;
+  auto cA = ctx->Auu.col.download(s), cT = ctx->Bt.col.download(s), cB = ctx->B.col.download(s), cM = ctx->Mp.col.download(s);
+  auto vA = ctx->Auu.val.download(s), vT = ctx->Bt.val.download(s), vB = ctx->B.val.download(s), vM = ctx->Mp.val.download(s);
+  auto dM = ctx->diagMu.download(s);
+  for (int64_t A = 0; A < ctx->nUo; ++A) {
+    const int64_t rs = rpA[A], len = rpA[A + 1] - rs, ts = rpT[A], tlen = rpT[A + 1] - ts;
+    for (int c = 0; c < dim; ++c) {
+      int64_t o = rowptr[A * dim + c];
+      for (int64_t k = 0; k < len; ++k)
+        for (int d = 0; d < dim; ++d) {
+          col[o] = cA[rs + k] * dim + d;
+          if (which == 0) val[o] = vA[rs * dim * dim + (c * dim + d) * len + k];
+          else val[o] = (cA[rs + k] == A && c == d) ? dM[A * dim + c] : 0.0;
+          ++o;
+        }
+      for (int64_t k = 0; k < tlen; ++k) {
+        col[o] = int32_t(poff + cT[ts + k]);
+        val[o] = (which == 0) ? vT[ts * dim + c * tlen + k] : 0.0;
+        ++o;
+      }
+    }
+  }
+  for (int64_t i = 0; i < npo; ++i) {
+    const int64_t rs = rpB[i], len = rpB[i + 1] - rs, ms = rpM[i], mlen = rpM[i + 1] - ms;
+    int64_t o = rowptr[nuo + i];
+    for (int64_t k = 0; k < len; ++k)
+      for (int d = 0; d < dim; ++d) {
+        col[o] = cB[rs + k] * dim + d;
+        val[o] = (which == 0) ? vB[rs * dim + d * len + k] : 0.0;
+        ++o;
+      }
+    for (int64_t k = 0; k < mlen; ++k) {
+      col[o] = int32_t(poff + cM[ms + k]);
+      val[o] = (which == 0) ? 0.0 : vM[ms + k];
+      ++o;
+    }
+  }
+  IFEM_API_END
+}
+
+int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t) {
+  IFEM_API_BEGIN
+  *t = ctx->timing;
+  const int dim = ctx->dim;
+  // algorithmic bytes of one y_u = A_uu x_u (+ B^T x_p): values + block column indices + row pointers + x + y
+  t->spmv_uu_bytes = double(ctx->Auu.nnzb) * (dim * dim * 8 + 4) + double(ctx->Auu.n_rows) * (8 + 2 * dim * 8);
+  IFEM_API_END
+}
+
+int ifem_comm_unique_id(uint8_t out[128]) { return ifem::comm_unique_id(out); }
+
+} // extern "C"

@@ -1,0 +1,134 @@
+// ctx.hpp -- device-side state of one ifem_ctx (one per GPU / process).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/ifem_hip.h"
+
+namespace ifem {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define IFEM_HIP_CHECK(expr)                                                                        \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      throw ::ifem::Error(IFEM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " at " + \
+                                          __FILE__ + ":" + std::to_string(__LINE__));               \
+  } while (0)
+
+template <class T>
+struct DBuf { // owning device buffer
+  T *p = nullptr;
+  size_t n = 0;
+  DBuf() = default;
+  DBuf(const DBuf &) = delete;
+  DBuf &operator=(const DBuf &) = delete;
+  ~DBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) IFEM_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+  }
+  void upload(const T *h, size_t count, hipStream_t s) {
+    alloc(count);
+    if (count) IFEM_HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  std::vector<T> download(hipStream_t s) const {
+    std::vector<T> h(n);
+    if (n) {
+      IFEM_HIP_CHECK(hipMemcpyAsync(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+      IFEM_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return h;
+  }
+};
+
+// Row-planar block-CSR: row r owns blocks [rowptr[r], rowptr[r+1]); entry e (of BS per block) of the k-th
+// block of the row lives at val[BS*rowptr[r] + e*len_r + k].  Consecutive lanes (k) read consecutive
+// doubles for every e: fully coalesced without LDS staging.  BS = dim*dim (A_uu), dim (B, B^T) or 1.
+struct PlanarCsr {
+  int64_t n_rows = 0, nnzb = 0;
+  int bs = 1;
+  DBuf<int64_t> rowptr;
+  DBuf<int32_t> col;
+  DBuf<double> val;
+};
+
+// FE tables for one (dim, kv): reference-cell shape values/gradients at the volume quadrature points.
+struct FeTables {
+  int dim, kv, nu, np, nq;
+  double phi[27 * 27];       // [q][a]   Q_kv
+  double dphi[27 * 27 * 3];  // [q][a][e]
+  double psi[27 * 8];        // [q][b]   Q1 (pressure + geometry mapping)
+  double dpsi[27 * 8 * 3];   // [q][b][e]
+  double w[27];
+  // face quadrature: per face f, nqf points: Q_kv values and Q1 gradients
+  int nqf;
+  double fphi[6 * 9 * 27];     // [f][qf][a]
+  double fdpsi[6 * 9 * 8 * 3]; // [f][qf][v][e]
+  double fw[9];
+};
+void build_fe_tables(FeTables &t, int dim, int kv);
+
+struct Halo {
+  int rank = 0, nranks = 1;
+  std::vector<int> nbr;
+  std::vector<int32_t> send_u_ptr, recv_u_ptr, send_p_ptr, recv_p_ptr;
+  DBuf<int32_t> send_u_idx, send_p_idx;
+  DBuf<double> sendbuf;
+  void *comm = nullptr; // ncclComm_t
+};
+
+} // namespace ifem
+
+struct ifem_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int dim = 0, kv = 0, nu = 0, np = 0, nq = 0;
+  int64_t n_cells = 0;
+  int64_t nUo = 0, nUl = 0, nPo = 0, nPl = 0; // velocity / pressure nodes owned / local
+  int64_t n_local = 0;                        // dim*nUl + nPl
+  ifem::FeTables fe;
+  ifem::DBuf<ifem::FeTables> d_fe;
+  // mesh
+  ifem::DBuf<double> vcoords;
+  ifem::DBuf<int32_t> cell_unodes, cell_pnodes, cell_face_bid, indicator;
+  // matrices
+  ifem::PlanarCsr Auu; // rows: owned velocity nodes, cols: local velocity nodes, bs = dim*dim
+  ifem::PlanarCsr Bt;  // rows: owned velocity nodes, cols: local pressure nodes, bs = dim   (block (0,1))
+  ifem::PlanarCsr B;   // rows: owned pressure nodes, cols: local velocity nodes, bs = dim   (block (1,0))
+  ifem::PlanarCsr Mp;  // rows: owned pressure nodes, cols: local pressure nodes, bs = 1     (mass (1,1))
+  ifem::DBuf<double> diagMu;   // diag of mass (0,0), per velocity dof (owned)
+  ifem::DBuf<double> dinvMu;   // 1/diagMu
+  ifem::DBuf<double> bjac;     // inverse diagonal node blocks of A_uu [nUo][dim*dim]
+  // scatter maps: position of the column inside the row, 0xFFFF = row not owned here
+  ifem::DBuf<uint16_t> posUU, posUP, posPU, posPP;
+  // constraints (local dof numbering), sets 0 = zero, 1 = nonzero
+  ifem::DBuf<uint8_t> is_c[2];
+  ifem::DBuf<double> cval[2];
+  bool has_c[2] = {false, false};
+  // vectors
+  ifem::DBuf<double> vec[IFEM_N_VECS];
+  // Krylov workspace
+  ifem::DBuf<double> krylovV, krylovZ, innerV, work;
+  ifem::DBuf<double> scal; // device scalars for reductions
+  double *h_scal = nullptr; // pinned host mirror
+  ifem::Halo halo;
+  bool assembled = false;
+  // timing
+  ifem_timing timing{};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double spmv_uu_ms_total = 0;
+};

@@ -1,0 +1,71 @@
+// kernels.hpp -- host-callable launchers implemented in the .hip translation units.
+#pragma once
+#include "ctx.hpp"
+
+namespace ifem {
+
+// setup.hip
+void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, int R, const int32_t *d_rows, int C,
+                   const int32_t *d_cols, DBuf<uint16_t> &pos);
+
+// assemble.hip
+void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
+
+// linalg.hip -- all on ctx->stream.  Block vectors are [u (dim*nUl) | p (nPl)]; "owned" ranges only.
+struct VecLayout {
+  int64_t n_u_owned; // dim*nUo
+  int64_t p_off;     // dim*nUl
+  int64_t n_p_owned; // nPo
+};
+inline VecLayout layout_of(const ifem_ctx *c) { return {c->dim * c->nUo, c->dim * c->nUl, c->nPo}; }
+
+// y_u = A_uu x_u (+ B^T x_p when xp != nullptr)
+void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool time_it);
+// y_p = B x_u
+void spmv_b(ifem_ctx *ctx, const double *xu, double *yp);
+// y_u = B^T x_p
+void spmv_bt(ifem_ctx *ctx, const double *xp, double *yu);
+// y_p = M_p x_p
+void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp);
+// y_u = d .* x_u (diagonal scaling with 1/diag(M_u))
+void vec_mul(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y);
+// y = bjac * x  (node-block Jacobi)
+void bjac_apply(ifem_ctx *ctx, const double *x, double *y);
+void bjac_setup(ifem_ctx *ctx);
+void dinv_setup(ifem_ctx *ctx);
+
+// generic vector kernels over one contiguous range
+void v_axpy(ifem_ctx *ctx, int64_t n, double a, const double *x, double *y);            // y += a x
+void v_axpby(ifem_ctx *ctx, int64_t n, double a, const double *x, double b, double *y); // y = a x + b y
+void v_scale(ifem_ctx *ctx, int64_t n, double a, double *x);
+void v_copy(ifem_ctx *ctx, int64_t n, const double *x, double *y);
+void v_zero(ifem_ctx *ctx, int64_t n, double *x);
+double v_dot(ifem_ctx *ctx, int64_t n, const double *x, const double *y); // local (no all-reduce), syncs
+// multi-dot: out[i] = <V_i, w> for i < k (V column-major with leading dimension ld), one pass, syncs
+void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *w, double *out_host);
+// w -= sum_i h[i] V_i
+void v_maxpy(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *h_host, double *w);
+void v_minmax(ifem_ctx *ctx, int64_t n, const double *x, double *mn, double *mx);
+// x[dof] = value for constrained dofs (AffineConstraints::distribute, Dirichlet lines)
+void apply_constraints(ifem_ctx *ctx, int which, double *x);
+
+// all-reduce helpers (identity for a single rank)
+void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n);
+void allreduce_max(ifem_ctx *ctx, double *host_vals, int n);
+int comm_unique_id(uint8_t out[128]);
+// ghost refresh of a ghost-extended velocity buffer [dim*nUl] / pressure buffer [nPl] (RCCL send/recv over xGMI)
+void halo_exchange(ifem_ctx *ctx, double *xu_ext);
+void halo_exchange_p(ifem_ctx *ctx, double *xp_ext);
+void comm_init(ifem_ctx *ctx, const ifem_partition *part);
+void comm_destroy(ifem_ctx *ctx);
+
+// solver.hip
+int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats);
+void ins_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, const double *src, double *dst);
+void ins_system_vmult(ifem_ctx *ctx, const double *src, double *dst);
+
+// owned-range dot over a block vector (u range + p range), all-reduced
+double bv_dot(ifem_ctx *ctx, const double *x, const double *y);
+inline int64_t bv_len(const ifem_ctx *c) { return c->n_local; }
+
+} // namespace ifem

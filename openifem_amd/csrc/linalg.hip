@@ -1,0 +1,400 @@
+// linalg.hip -- bandwidth-bound kernels of the Krylov path: row-planar block SpMV, fused vector ops,
+// reductions.  These replace PETSc MatMult / Vec ops under deal.II's SolverFGMRES / SolverCG
+// (mpi_insim.cpp:75-82,103-108,383-388).
+#include <hip/hip_runtime.h>
+#include "ctx.hpp"
+#include "kernels.hpp"
+
+namespace ifem {
+
+// ---------------------------------------------------------------------------------------------------
+// Row-planar block SpMV.  G lanes cooperate on one row; lane k walks blocks k, k+G, ... of the row and
+// reads the BS = BR*BC planes of its block with stride len (coalesced across lanes), gathers BC values of x
+// and accumulates BR partial sums that are reduced over the G lanes with DPP-free shuffles.
+template <int BR, int BC, int G, bool ACC>
+__device__ inline void row_planar_dot(const int64_t rs, const int len, const int32_t *__restrict__ col,
+                                      const double *__restrict__ val, const double *__restrict__ x, const int lig,
+                                      double *acc) {
+  const double *vbase = val + rs * (BR * BC);
+  for (int k = lig; k < len; k += G) {
+    const int32_t c = col[rs + k];
+    double xv[BC];
+#pragma unroll
+    for (int j = 0; j < BC; ++j) xv[j] = x[int64_t(c) * BC + j];
+#pragma unroll
+    for (int r = 0; r < BR; ++r)
+#pragma unroll
+      for (int j = 0; j < BC; ++j) acc[r] += vbase[int64_t(r * BC + j) * len + k] * xv[j];
+  }
+}
+
+template <int G>
+__device__ inline double group_sum(double v) {
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// y_u = A_uu x_u + B^T x_p   (rows: owned velocity nodes)
+template <int DIM, int G>
+__global__ __launch_bounds__(256) void k_spmv_uu(int64_t n_rows, const int64_t *__restrict__ rp_a,
+                                                 const int32_t *__restrict__ col_a, const double *__restrict__ val_a,
+                                                 const int64_t *__restrict__ rp_t, const int32_t *__restrict__ col_t,
+                                                 const double *__restrict__ val_t, const double *__restrict__ xu,
+                                                 const double *__restrict__ xp, double *__restrict__ yu) {
+  const int64_t row = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  const int lig = threadIdx.x & (G - 1);
+  if (row >= n_rows) return; // whole groups exit together
+  double acc[DIM];
+#pragma unroll
+  for (int r = 0; r < DIM; ++r) acc[r] = 0;
+  {
+    const int64_t rs = rp_a[row];
+    const int len = int(rp_a[row + 1] - rs);
+    row_planar_dot<DIM, DIM, G, true>(rs, len, col_a, val_a, xu, lig, acc);
+  }
+  if (xp) {
+    const int64_t rs = rp_t[row];
+    const int len = int(rp_t[row + 1] - rs);
+    row_planar_dot<DIM, 1, G, true>(rs, len, col_t, val_t, xp, lig, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < DIM; ++r) acc[r] = group_sum<G>(acc[r]);
+  if (lig == 0) {
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) yu[row * DIM + r] = acc[r];
+  }
+}
+
+// y = M x with BR x BC blocks, generic (B: 1 x DIM, B^T: DIM x 1, M_p / S_m: 1 x 1)
+template <int BR, int BC, int G>
+__global__ __launch_bounds__(256) void k_spmv_planar(int64_t n_rows, const int64_t *__restrict__ rp,
+                                                     const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                     const double *__restrict__ x, double *__restrict__ y) {
+  const int64_t row = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  const int lig = threadIdx.x & (G - 1);
+  if (row >= n_rows) return;
+  double acc[BR];
+#pragma unroll
+  for (int r = 0; r < BR; ++r) acc[r] = 0;
+  const int64_t rs = rp[row];
+  const int len = int(rp[row + 1] - rs);
+  row_planar_dot<BR, BC, G, true>(rs, len, col, val, x, lig, acc);
+#pragma unroll
+  for (int r = 0; r < BR; ++r) acc[r] = group_sum<G>(acc[r]);
+  if (lig == 0) {
+#pragma unroll
+    for (int r = 0; r < BR; ++r) y[row * BR + r] = acc[r];
+  }
+}
+
+static inline unsigned blocks_for_rows(int64_t n_rows, int G) { return unsigned((n_rows * G + 255) / 256); }
+
+void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool time_it) {
+  const int64_t n = ctx->Auu.n_rows;
+  if (n == 0) return;
+  hipStream_t s = ctx->stream;
+  if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s));
+  if (ctx->dim == 3) {
+    constexpr int G = 32;
+    hipLaunchKernelGGL((k_spmv_uu<3, G>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
+                       ctx->Auu.col.p, ctx->Auu.val.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
+  } else {
+    constexpr int G = 16;
+    hipLaunchKernelGGL((k_spmv_uu<2, G>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
+                       ctx->Auu.col.p, ctx->Auu.val.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
+  }
+  if (time_it) {
+    IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+    IFEM_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    IFEM_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->spmv_uu_ms_total += ms;
+    ctx->timing.spmv_uu_calls++;
+  }
+}
+
+void spmv_b(ifem_ctx *ctx, const double *xu, double *yp) {
+  const int64_t n = ctx->B.n_rows;
+  if (n == 0) return;
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_spmv_planar<1, 3, 32>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n,
+                       ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, xu, yp);
+  else
+    hipLaunchKernelGGL((k_spmv_planar<1, 2, 16>), dim3(blocks_for_rows(n, 16)), dim3(256), 0, ctx->stream, n,
+                       ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, xu, yp);
+}
+
+void spmv_bt(ifem_ctx *ctx, const double *xp, double *yu) {
+  const int64_t n = ctx->Bt.n_rows;
+  if (n == 0) return;
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_spmv_planar<3, 1, 8>), dim3(blocks_for_rows(n, 8)), dim3(256), 0, ctx->stream, n,
+                       ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xp, yu);
+  else
+    hipLaunchKernelGGL((k_spmv_planar<2, 1, 4>), dim3(blocks_for_rows(n, 4)), dim3(256), 0, ctx->stream, n,
+                       ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xp, yu);
+}
+
+void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp) {
+  const int64_t n = ctx->Mp.n_rows;
+  if (n == 0) return;
+  hipLaunchKernelGGL((k_spmv_planar<1, 1, 8>), dim3(blocks_for_rows(n, 8)), dim3(256), 0, ctx->stream, n,
+                     ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->Mp.val.p, xp, yp);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// vector kernels: grid-stride, 16-byte accesses where alignment allows
+static inline unsigned vgrid(int64_t n) {
+  int64_t g = (n + 511) / 512;
+  return unsigned(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+__global__ void k_axpy(int64_t n, double a, const double *__restrict__ x, double *__restrict__ y) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] += a * x[i];
+}
+__global__ void k_axpby(int64_t n, double a, const double *__restrict__ x, double b, double *__restrict__ y) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] = a * x[i] + b * y[i];
+}
+__global__ void k_scale(int64_t n, double a, double *__restrict__ x) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) x[i] *= a;
+}
+__global__ void k_mul(int64_t n, const double *__restrict__ d, const double *__restrict__ x, double *__restrict__ y) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] = d[i] * x[i];
+}
+__global__ void k_recip(int64_t n, const double *__restrict__ d, double *__restrict__ y) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] = 1.0 / d[i];
+}
+
+void v_axpy(ifem_ctx *ctx, int64_t n, double a, const double *x, double *y) {
+  if (n) hipLaunchKernelGGL(k_axpy, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, x, y);
+}
+void v_axpby(ifem_ctx *ctx, int64_t n, double a, const double *x, double b, double *y) {
+  if (n) hipLaunchKernelGGL(k_axpby, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, x, b, y);
+}
+void v_scale(ifem_ctx *ctx, int64_t n, double a, double *x) {
+  if (n) hipLaunchKernelGGL(k_scale, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, x);
+}
+void v_copy(ifem_ctx *ctx, int64_t n, const double *x, double *y) {
+  if (n) IFEM_HIP_CHECK(hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+}
+void v_zero(ifem_ctx *ctx, int64_t n, double *x) {
+  if (n) IFEM_HIP_CHECK(hipMemsetAsync(x, 0, n * sizeof(double), ctx->stream));
+}
+void vec_mul(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y) {
+  if (n) hipLaunchKernelGGL(k_mul, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, d, x, y);
+}
+void dinv_setup(ifem_ctx *ctx) {
+  const int64_t n = ctx->diagMu.n;
+  if (n) hipLaunchKernelGGL(k_recip, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, ctx->diagMu.p, ctx->dinvMu.p);
+}
+
+// block reduction helper: sums K values per thread across the block, thread 0 of each wave adds atomically
+template <int K>
+__device__ inline void block_reduce_atomic(double *v, double *out) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double t = v[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    v[k] = t;
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) unsafeAtomicAdd(&out[k], v[k]);
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_mdot(int64_t n, int k0, const double *__restrict__ V, int64_t ld,
+                                              const double *__restrict__ w, double *__restrict__ out) {
+  double acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const double wi = w[i];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] += V[int64_t(k0 + k) * ld + i] * wi;
+  }
+  block_reduce_atomic<K>(acc, out + k0);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_maxpy(int64_t n, int k0, const double *__restrict__ V, int64_t ld,
+                                               const double *__restrict__ h, double *__restrict__ w) {
+  double hk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) hk[k] = h[k0 + k];
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    double t = w[i];
+#pragma unroll
+    for (int k = 0; k < K; ++k) t -= hk[k] * V[int64_t(k0 + k) * ld + i];
+    w[i] = t;
+  }
+}
+
+// out_host[i] = <V_i, w>, i < k.  Device scalars live in ctx->scal[0..63]; result is NOT all-reduced.
+void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *w, double *out_host) {
+  hipStream_t s = ctx->stream;
+  IFEM_HIP_CHECK(hipMemsetAsync(ctx->scal.p, 0, 64 * sizeof(double), s));
+  int k0 = 0;
+  while (k0 < k && n > 0) {
+    const int r = k - k0;
+    if (r >= 8) { hipLaunchKernelGGL((k_mdot<8>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, w, ctx->scal.p); k0 += 8; }
+    else if (r >= 4) { hipLaunchKernelGGL((k_mdot<4>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, w, ctx->scal.p); k0 += 4; }
+    else if (r >= 2) { hipLaunchKernelGGL((k_mdot<2>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, w, ctx->scal.p); k0 += 2; }
+    else { hipLaunchKernelGGL((k_mdot<1>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, w, ctx->scal.p); k0 += 1; }
+  }
+  IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->scal.p, k * sizeof(double), hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  for (int i = 0; i < k; ++i) out_host[i] = ctx->h_scal[i];
+}
+
+void v_maxpy(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *h_host, double *w) {
+  if (n == 0 || k == 0) return;
+  hipStream_t s = ctx->stream;
+  // coefficients go through the second half of the scalar buffer
+  for (int i = 0; i < k; ++i) ctx->h_scal[64 + i] = h_host[i];
+  IFEM_HIP_CHECK(hipMemcpyAsync(ctx->scal.p + 64, ctx->h_scal + 64, k * sizeof(double), hipMemcpyHostToDevice, s));
+  int k0 = 0;
+  while (k0 < k) {
+    const int r = k - k0;
+    if (r >= 8) { hipLaunchKernelGGL((k_maxpy<8>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, ctx->scal.p + 64, w); k0 += 8; }
+    else if (r >= 4) { hipLaunchKernelGGL((k_maxpy<4>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, ctx->scal.p + 64, w); k0 += 4; }
+    else if (r >= 2) { hipLaunchKernelGGL((k_maxpy<2>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, ctx->scal.p + 64, w); k0 += 2; }
+    else { hipLaunchKernelGGL((k_maxpy<1>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, ctx->scal.p + 64, w); k0 += 1; }
+  }
+  // h_scal[64..] must stay untouched until the copy has been consumed
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+double v_dot(ifem_ctx *ctx, int64_t n, const double *x, const double *y) {
+  double out = 0;
+  v_mdot(ctx, n, 1, x, n, y, &out);
+  return out;
+}
+
+double bv_dot(ifem_ctx *ctx, const double *x, const double *y) {
+  double d = v_dot(ctx, ctx->dim * ctx->nUo + ctx->nPo, x, y);
+  allreduce_sum(ctx, &d, 1);
+  return d;
+}
+
+__global__ __launch_bounds__(256) void k_minmax(int64_t n, const double *__restrict__ x, double *__restrict__ out) {
+  double mn = 1e300, mx = -1e300;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const double v = x[i];
+    mn = fmin(mn, v); mx = fmax(mx, v);
+  }
+  for (int off = 32; off > 0; off >>= 1) { mn = fmin(mn, __shfl_xor(mn, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64)); }
+  if ((threadIdx.x & 63) == 0) {
+    // f64 min/max through order-preserving CAS loops
+    unsigned long long *pmn = (unsigned long long *)&out[0], *pmx = (unsigned long long *)&out[1];
+    unsigned long long old = *pmn;
+    while (__longlong_as_double((long long)old) > mn) {
+      const unsigned long long prev = atomicCAS(pmn, old, (unsigned long long)__double_as_longlong(mn));
+      if (prev == old) break;
+      old = prev;
+    }
+    old = *pmx;
+    while (__longlong_as_double((long long)old) < mx) {
+      const unsigned long long prev = atomicCAS(pmx, old, (unsigned long long)__double_as_longlong(mx));
+      if (prev == old) break;
+      old = prev;
+    }
+  }
+}
+
+void v_minmax(ifem_ctx *ctx, int64_t n, const double *x, double *mn, double *mx) {
+  hipStream_t s = ctx->stream;
+  ctx->h_scal[0] = 1e300; ctx->h_scal[1] = -1e300;
+  IFEM_HIP_CHECK(hipMemcpyAsync(ctx->scal.p, ctx->h_scal, 2 * sizeof(double), hipMemcpyHostToDevice, s));
+  if (n) hipLaunchKernelGGL(k_minmax, dim3(vgrid(n)), dim3(256), 0, s, n, x, ctx->scal.p);
+  IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  *mn = ctx->h_scal[0]; *mx = ctx->h_scal[1];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// node-block Jacobi: inverse of the dim x dim diagonal blocks of A_uu
+template <int DIM>
+__global__ void k_bjac_setup(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                             const double *__restrict__ val, double *__restrict__ out) {
+  const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  const int64_t rs = rp[row];
+  const int len = int(rp[row + 1] - rs);
+  int lo = 0, hi = len - 1, pos = -1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const int32_t v = col[rs + mid];
+    if (v == row) { pos = mid; break; }
+    if (v < row) lo = mid + 1; else hi = mid - 1;
+  }
+  double D[DIM * DIM], Di[DIM * DIM];
+  for (int e = 0; e < DIM * DIM; ++e) D[e] = (pos >= 0) ? val[rs * DIM * DIM + int64_t(e) * len + pos] : ((e / DIM == e % DIM) ? 1.0 : 0.0);
+  if constexpr (DIM == 2) {
+    const double r = 1.0 / (D[0] * D[3] - D[1] * D[2]);
+    Di[0] = D[3] * r; Di[1] = -D[1] * r; Di[2] = -D[2] * r; Di[3] = D[0] * r;
+  } else {
+    const double c00 = D[4] * D[8] - D[5] * D[7], c01 = D[5] * D[6] - D[3] * D[8], c02 = D[3] * D[7] - D[4] * D[6];
+    const double r = 1.0 / (D[0] * c00 + D[1] * c01 + D[2] * c02);
+    Di[0] = c00 * r; Di[3] = c01 * r; Di[6] = c02 * r;
+    Di[1] = (D[2] * D[7] - D[1] * D[8]) * r; Di[4] = (D[0] * D[8] - D[2] * D[6]) * r; Di[7] = (D[1] * D[6] - D[0] * D[7]) * r;
+    Di[2] = (D[1] * D[5] - D[2] * D[4]) * r; Di[5] = (D[2] * D[3] - D[0] * D[5]) * r; Di[8] = (D[0] * D[4] - D[1] * D[3]) * r;
+  }
+  for (int e = 0; e < DIM * DIM; ++e) out[row * DIM * DIM + e] = Di[e];
+}
+
+template <int DIM>
+__global__ void k_bjac_apply(int64_t n_rows, const double *__restrict__ bj, const double *__restrict__ x,
+                             double *__restrict__ y) {
+  const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  double xv[DIM];
+  for (int j = 0; j < DIM; ++j) xv[j] = x[row * DIM + j];
+  for (int r = 0; r < DIM; ++r) {
+    double t = 0;
+    for (int j = 0; j < DIM; ++j) t += bj[row * DIM * DIM + r * DIM + j] * xv[j];
+    y[row * DIM + r] = t;
+  }
+}
+
+void bjac_setup(ifem_ctx *ctx) {
+  const int64_t n = ctx->nUo;
+  if (!n) return;
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_bjac_setup<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
+                       ctx->Auu.rowptr.p, ctx->Auu.col.p, ctx->Auu.val.p, ctx->bjac.p);
+  else
+    hipLaunchKernelGGL((k_bjac_setup<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
+                       ctx->Auu.rowptr.p, ctx->Auu.col.p, ctx->Auu.val.p, ctx->bjac.p);
+}
+
+void bjac_apply(ifem_ctx *ctx, const double *x, double *y) {
+  const int64_t n = ctx->nUo;
+  if (!n) return;
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_bjac_apply<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ctx->bjac.p, x, y);
+  else
+    hipLaunchKernelGGL((k_bjac_apply<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ctx->bjac.p, x, y);
+}
+
+// AffineConstraints::distribute for Dirichlet lines on a compact owned vector [u_o | p_o]
+__global__ void k_apply_constraints(int64_t n_u_owned, int64_t n_owned, int64_t p_off_ext,
+                                    const uint8_t *__restrict__ is_c, const double *__restrict__ cval,
+                                    double *__restrict__ x) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_owned; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t e = (i < n_u_owned) ? i : (p_off_ext + (i - n_u_owned));
+    if (is_c[e]) x[i] = cval[e];
+  }
+}
+
+void apply_constraints(ifem_ctx *ctx, int which, double *x) {
+  if (!ctx->has_c[which]) return;
+  const int64_t nuo = ctx->dim * ctx->nUo, n = nuo + ctx->nPo;
+  hipLaunchKernelGGL(k_apply_constraints, dim3(vgrid(n)), dim3(256), 0, ctx->stream, nuo, n, ctx->dim * ctx->nUl,
+                     ctx->is_c[which].p, ctx->cval[which].p, x);
+}
+
+} // namespace ifem

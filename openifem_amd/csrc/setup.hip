@@ -1,0 +1,134 @@
+// setup.hip -- device-side construction of the block sparsity and scatter maps.
+// Replaces DoFTools::make_sparsity_pattern + distribute_sparsity_pattern + PETSc matrix preallocation
+// (mpi_fluid_solver.cpp:311-322).  One-off per mesh; uses rocPRIM (sort/scan) as plumbing.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include "ctx.hpp"
+#include "kernels.hpp"
+
+namespace ifem {
+
+__global__ void k_gen_keys(int64_t n_cells, int R, int C, const int32_t *__restrict__ rows,
+                           const int32_t *__restrict__ cols, int64_t n_rows_owned, uint64_t *__restrict__ keys) {
+  const int64_t total = n_cells * R * C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cell = t / (R * C);
+    const int rc = int(t - cell * R * C);
+    const int r = rc / C, c = rc - r * C;
+    const int32_t row = rows[cell * R + r], col = cols[cell * C + c];
+    keys[t] = (row < n_rows_owned) ? ((uint64_t(uint32_t(row)) << 32) | uint32_t(col)) : ~uint64_t(0);
+  }
+}
+
+__global__ void k_flag_unique(int64_t n, const uint64_t *__restrict__ keys, int64_t *__restrict__ flags) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t k = keys[t];
+    flags[t] = (k != ~uint64_t(0) && (t == 0 || keys[t - 1] != k)) ? 1 : 0;
+  }
+}
+
+__global__ void k_emit(int64_t n, const uint64_t *__restrict__ keys, const int64_t *__restrict__ pos,
+                       int32_t *__restrict__ col, int64_t *__restrict__ rowcnt) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t k = keys[t];
+    if (k != ~uint64_t(0) && (t == 0 || keys[t - 1] != k)) {
+      col[pos[t]] = int32_t(uint32_t(k));
+      atomicAdd((unsigned long long *)&rowcnt[k >> 32], 1ull);
+    }
+  }
+}
+
+__global__ void k_pos_map(int64_t n_cells, int R, int C, const int32_t *__restrict__ rows,
+                          const int32_t *__restrict__ cols, int64_t n_rows_owned, const int64_t *__restrict__ rowptr,
+                          const int32_t *__restrict__ col, uint16_t *__restrict__ pos) {
+  const int64_t total = n_cells * R * C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cell = t / (R * C);
+    const int rc = int(t - cell * R * C);
+    const int r = rc / C, c = rc - r * C;
+    const int32_t row = rows[cell * R + r], cc = cols[cell * C + c];
+    uint16_t out = 0xFFFF;
+    if (row < n_rows_owned) {
+      int64_t lo = rowptr[row], hi = rowptr[row + 1] - 1;
+      const int64_t base = lo;
+      while (lo <= hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int32_t v = col[mid];
+        if (v == cc) { out = uint16_t(mid - base); break; }
+        if (v < cc) lo = mid + 1; else hi = mid - 1;
+      }
+    }
+    pos[t] = out;
+  }
+}
+
+static int grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return int(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+
+// Builds the sorted pattern of {(row, col)} pairs coupled through a common cell, plus the scatter map.
+void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, int R, const int32_t *d_rows, int C,
+                   const int32_t *d_cols, DBuf<uint16_t> &pos) {
+  hipStream_t s = ctx->stream;
+  const int64_t N = ctx->n_cells * R * C;
+  DBuf<uint64_t> k0, k1;
+  k0.alloc(N);
+  k1.alloc(N);
+  hipLaunchKernelGGL(k_gen_keys, dim3(grid_for(N)), dim3(256), 0, s, ctx->n_cells, R, C, d_rows, d_cols, n_rows_owned,
+                     k0.p);
+  size_t tmp_bytes = 0;
+  IFEM_HIP_CHECK(rocprim::radix_sort_keys(nullptr, tmp_bytes, k0.p, k1.p, (size_t)N, 0, 64, s));
+  DBuf<char> tmp;
+  tmp.alloc(tmp_bytes + 16);
+  IFEM_HIP_CHECK(rocprim::radix_sort_keys(tmp.p, tmp_bytes, k0.p, k1.p, (size_t)N, 0, 64, s));
+  int64_t *flags = reinterpret_cast<int64_t *>(k0.p); // k0 is dead after the sort
+  hipLaunchKernelGGL(k_flag_unique, dim3(grid_for(N)), dim3(256), 0, s, N, k1.p, flags);
+  DBuf<int64_t> posbuf;
+  posbuf.alloc(N + 1);
+  size_t tmp2 = 0;
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp2, flags, posbuf.p, int64_t(0), (size_t)N,
+                                         rocprim::plus<int64_t>(), s));
+  DBuf<char> tmpb;
+  tmpb.alloc(tmp2 + 16);
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(tmpb.p, tmp2, flags, posbuf.p, int64_t(0), (size_t)N,
+                                         rocprim::plus<int64_t>(), s));
+  int64_t last_pos = 0, last_flag = 0;
+  IFEM_HIP_CHECK(hipMemcpyAsync(&last_pos, posbuf.p + (N - 1), 8, hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipMemcpyAsync(&last_flag, flags + (N - 1), 8, hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  const int64_t nnzb = last_pos + last_flag;
+  M.n_rows = n_rows_owned;
+  M.nnzb = nnzb;
+  M.bs = bs;
+  M.col.alloc(nnzb);
+  DBuf<int64_t> rowcnt;
+  rowcnt.alloc(n_rows_owned + 1);
+  IFEM_HIP_CHECK(hipMemsetAsync(rowcnt.p, 0, (n_rows_owned + 1) * 8, s));
+  hipLaunchKernelGGL(k_emit, dim3(grid_for(N)), dim3(256), 0, s, N, k1.p, posbuf.p, M.col.p, rowcnt.p);
+  M.rowptr.alloc(n_rows_owned + 1);
+  size_t tmp3 = 0;
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp3, rowcnt.p, M.rowptr.p, int64_t(0), (size_t)(n_rows_owned + 1),
+                                         rocprim::plus<int64_t>(), s));
+  DBuf<char> tmpc;
+  tmpc.alloc(tmp3 + 16);
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(tmpc.p, tmp3, rowcnt.p, M.rowptr.p, int64_t(0), (size_t)(n_rows_owned + 1),
+                                         rocprim::plus<int64_t>(), s));
+  // longest row must fit the 16-bit scatter map
+  {
+    std::vector<int64_t> rc = rowcnt.download(s);
+    int64_t mx = 0;
+    for (int64_t i = 0; i < n_rows_owned; ++i) mx = rc[i] > mx ? rc[i] : mx;
+    if (mx >= 0xFFFF) throw Error(IFEM_E_BADPARAM, "row longer than 65534 blocks");
+  }
+  M.val.alloc((size_t)nnzb * bs);
+  IFEM_HIP_CHECK(hipMemsetAsync(M.val.p, 0, (size_t)nnzb * bs * sizeof(double), s));
+  pos.alloc(N);
+  hipLaunchKernelGGL(k_pos_map, dim3(grid_for(N)), dim3(256), 0, s, ctx->n_cells, R, C, d_rows, d_cols, n_rows_owned,
+                     M.rowptr.p, M.col.p, pos.p);
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  IFEM_HIP_CHECK(hipGetLastError());
+}
+
+} // namespace ifem

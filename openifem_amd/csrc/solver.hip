@@ -1,0 +1,294 @@
+// solver.hip -- host drivers of the Krylov path; every vector/matrix operation is a HIP kernel on ctx->stream.
+//   fgmres()            deal.II SolverFGMRES as used by InsIM::solve            (mpi_insim.cpp:379-388)
+//   cg()                PETSc KSPCG + PreconditionNone                          (mpi_insim.cpp:73-82,88-108)
+//   precond_vmult()     InsIM::BlockSchurPreconditioner::vmult                  (mpi_insim.cpp:57-128)
+//   ins_solve()         InsIM::solve                                            (mpi_insim.cpp:365-395)
+//   ins_newton_step()   Newton loop of InsIM::run_one_step                      (mpi_insim.cpp:416-473)
+// A~^-1 (MUMPS in the reference) is an inner right-preconditioned GMRES(m) on the BSR A_uu with node-block
+// Jacobi; the outer solver is *flexible* GMRES precisely so that such an inexact inner solve is admissible.
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <vector>
+#include "ctx.hpp"
+#include "kernels.hpp"
+
+namespace ifem {
+
+using OpFn = std::function<void(const double *, double *)>;
+using DotFn = std::function<void(int, const double *, const double *, double *)>; // out[i] = <V_i, w>, all-reduced
+
+struct Clock {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// (flexible) right-preconditioned restarted GMRES, x0 = 0.  V: (m+1) x n, Z: m x n (flexible) or 1 x n.
+// Orthogonalisation: classical Gram-Schmidt with one re-orthogonalisation pass (two fused multi-dot /
+// multi-axpy sweeps instead of deal.II's j+1 sequential dots; same Krylov space, fewer host round trips).
+static int gmres(ifem_ctx *ctx, int64_t n, const OpFn &A, const OpFn &Pinv, bool flexible, const double *b, double *x,
+                 int m, int maxit, double tol, double *V, double *Z, double *w, double *res_out,
+                 const std::function<void(int, const double *, int64_t, const double *, double *)> &mdot) {
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), h(m + 1), h2(m + 1);
+  v_zero(ctx, n, x);
+  int it = 0;
+  double res = 0;
+  bool first = true;
+  while (true) {
+    if (first) { v_copy(ctx, n, b, w); first = false; }
+    else { A(x, w); v_axpby(ctx, n, 1.0, b, -1.0, w); }
+    double bb;
+    mdot(1, w, n, w, &bb);
+    const double beta = std::sqrt(bb);
+    res = beta;
+    if (res <= tol || it >= maxit) break;
+    v_copy(ctx, n, w, V);
+    v_scale(ctx, n, 1.0 / beta, V);
+    std::fill(g.begin(), g.end(), 0.0);
+    g[0] = beta;
+    int j = 0;
+    bool done = false;
+    for (; j < m && it < maxit; ++j) {
+      double *vj = V + (int64_t)j * n;
+      double *zj = flexible ? Z + (int64_t)j * n : Z;
+      Pinv(vj, zj);
+      A(zj, w);
+      mdot(j + 1, V, n, w, h.data());
+      v_maxpy(ctx, n, j + 1, V, n, h.data(), w);
+      mdot(j + 1, V, n, w, h2.data());
+      v_maxpy(ctx, n, j + 1, V, n, h2.data(), w);
+      for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = h[i] + h2[i];
+      double ww;
+      mdot(1, w, n, w, &ww);
+      const double hn = std::sqrt(ww);
+      H[(size_t)(j + 1) * m + j] = hn;
+      if (hn > 0) {
+        v_copy(ctx, n, w, V + (int64_t)(j + 1) * n);
+        v_scale(ctx, n, 1.0 / hn, V + (int64_t)(j + 1) * n);
+      }
+      for (int i = 0; i < j; ++i) {
+        const double t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
+        H[(size_t)(i + 1) * m + j] = -sn[i] * H[(size_t)i * m + j] + cs[i] * H[(size_t)(i + 1) * m + j];
+        H[(size_t)i * m + j] = t;
+      }
+      const double a = H[(size_t)j * m + j], c = H[(size_t)(j + 1) * m + j], r = std::hypot(a, c);
+      cs[j] = a / r; sn[j] = c / r;
+      H[(size_t)j * m + j] = r; H[(size_t)(j + 1) * m + j] = 0;
+      g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
+      res = std::fabs(g[j + 1]);
+      ++it;
+      if (res <= tol || hn == 0) { ++j; done = true; break; }
+    }
+    for (int i = j - 1; i >= 0; --i) {
+      double t = g[i];
+      for (int k = i + 1; k < j; ++k) t -= H[(size_t)i * m + k] * y[k];
+      y[i] = t / H[(size_t)i * m + i];
+    }
+    if (flexible) {
+      for (int i = 0; i < j; ++i) h[i] = -y[i];
+      v_maxpy(ctx, n, j, Z, n, h.data(), x); // x += sum y_i z_i
+    } else {
+      // x += P^-1 (V y): one preconditioner application instead of storing every z_j
+      v_zero(ctx, n, w);
+      for (int i = 0; i < j; ++i) h[i] = -y[i];
+      v_maxpy(ctx, n, j, V, n, h.data(), w);
+      Pinv(w, Z);
+      v_axpy(ctx, n, 1.0, Z, x);
+    }
+    if (done || it >= maxit) break;
+  }
+  if (res_out) *res_out = res;
+  return it;
+}
+
+// plain CG, zero initial guess, absolute tolerance on ||r||_2
+static int cg(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *b, double *x, double tol, int maxit, double *r,
+              double *p, double *q, const std::function<double(const double *, const double *)> &dot) {
+  v_zero(ctx, n, x);
+  v_copy(ctx, n, b, r);
+  v_copy(ctx, n, b, p);
+  double rr = dot(r, r);
+  int it = 0;
+  while (std::sqrt(rr) > tol && it < maxit) {
+    A(p, q);
+    const double al = rr / dot(p, q);
+    v_axpy(ctx, n, al, p, x);
+    v_axpy(ctx, n, -al, q, r);
+    const double rn = dot(r, r);
+    v_axpby(ctx, n, 1.0, r, rn / rr, p);
+    rr = rn;
+    ++it;
+  }
+  return it;
+}
+
+struct SolveState {
+  ifem_ctx *ctx;
+  const ifem_ins_params *P;
+  const ifem_solver_opts *o;
+  ifem_solve_stats st{};
+  int64_t nuo, npo, n;
+  // workspace carved out of ctx->work
+  double *xu_ext, *xp_ext, *tu, *tp[6], *utmp, *inner_w, *inner_z, *outer_w;
+};
+
+// ghost-extended views of a compact owned vector [u_o | p_o]
+static void extend_u(SolveState &S, const double *xu, const double **out) {
+  ifem_ctx *c = S.ctx;
+  if (c->halo.nranks == 1) { *out = xu; return; }
+  v_copy(c, S.nuo, xu, S.xu_ext);
+  halo_exchange(c, S.xu_ext); // exchanges the u part only when given a u-extended buffer (see comm.hip)
+  *out = S.xu_ext;
+}
+static void extend_p(SolveState &S, const double *xp, const double **out) {
+  ifem_ctx *c = S.ctx;
+  if (c->halo.nranks == 1) { *out = xp; return; }
+  v_copy(c, S.npo, xp, S.xp_ext);
+  halo_exchange_p(c, S.xp_ext);
+  *out = S.xp_ext;
+}
+
+static void system_apply(SolveState &S, const double *x, double *y, bool time_it) {
+  ifem_ctx *c = S.ctx;
+  const double *xu, *xp;
+  extend_u(S, x, &xu);
+  extend_p(S, x + S.nuo, &xp);
+  spmv_uu(c, xu, xp, y, time_it);
+  spmv_b(c, xu, y + S.nuo);
+}
+
+static double dot_all(SolveState &S, int64_t n, const double *a, const double *b) {
+  double d = v_dot(S.ctx, n, a, b);
+  allreduce_sum(S.ctx, &d, 1);
+  return d;
+}
+
+static void precond_vmult(SolveState &S, const double *src, double *dst) {
+  ifem_ctx *c = S.ctx;
+  const ifem_ins_params *P = S.P;
+  const ifem_solver_opts *o = S.o;
+  const double *src0 = src, *src1 = src + S.nuo;
+  double *dst0 = dst, *dst1 = dst + S.nuo;
+  double *tmp = S.tp[0], *r = S.tp[1], *p = S.tp[2], *q = S.tp[3];
+  auto pdot = [&](const double *a, const double *b) { return dot_all(S, S.npo, a, b); };
+  const double n1 = std::sqrt(pdot(src1, src1));
+  Clock ck;
+  // CG for Mp (:69-84)
+  OpFn mp = [&](const double *x, double *y) { const double *xe; extend_p(S, x, &xe); spmv_mp(c, xe, y); };
+  S.st.cg_mp_iters += cg(c, S.npo, mp, src1, tmp, std::max(o->mp_abs, o->mp_rel * n1), (int)std::max<int64_t>(S.npo, 1), r, p, q, pdot);
+  v_scale(c, S.npo, -(P->viscosity + P->grad_div * P->rho), tmp);
+  IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
+  S.st.t_cg_mp_ms += ck.ms();
+  // CG for Sm (:86-112): S_m = B diag(M_u)^-1 B^T applied matrix-free
+  Clock ck2;
+  OpFn sm = [&](const double *x, double *y) {
+    const double *xe; extend_p(S, x, &xe);
+    spmv_bt(c, xe, S.tu);
+    vec_mul(c, S.nuo, c->dinvMu.p, S.tu, S.tu);
+    const double *te; extend_u(S, S.tu, &te);
+    spmv_b(c, te, y);
+  };
+  S.st.cg_sm_iters += cg(c, S.npo, sm, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), (int)std::max<int64_t>(S.npo, 1), r, p, q, pdot);
+  v_axpby(c, S.npo, 1.0, tmp, -P->rho / P->dt, dst1);
+  // utmp = src0 - B^T dst1 (:116-120)
+  {
+    const double *xe; extend_p(S, dst1, &xe);
+    spmv_bt(c, xe, S.utmp);
+    v_axpby(c, S.nuo, 1.0, src0, -1.0, S.utmp);
+  }
+  IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
+  S.st.t_cg_sm_ms += ck2.ms();
+  // A~^-1 utmp (:124-127)
+  Clock ck3;
+  OpFn Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_uu(c, xe, nullptr, y, false); };
+  OpFn Pj = [&](const double *x, double *y) { bjac_apply(c, x, y); };
+  auto mdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
+    v_mdot(c, S.nuo, k, V, ld, w, out);
+    allreduce_sum(c, out, k);
+  };
+  double un;
+  mdot(1, S.utmp, S.nuo, S.utmp, &un);
+  un = std::sqrt(un);
+  double res = 0;
+  S.st.inner_iters += gmres(c, S.nuo, Auu, Pj, false, S.utmp, dst0, o->inner_restart, o->inner_maxit, o->inner_rel * un,
+                            c->innerV.p, S.inner_z, S.inner_w, &res, mdot);
+  IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
+  S.st.t_ainv_ms += ck3.ms();
+  S.st.precond_applies++;
+}
+
+static void carve_workspace(SolveState &S) {
+  ifem_ctx *c = S.ctx;
+  const int64_t nul = c->dim * c->nUl, npl = c->nPl;
+  S.nuo = c->dim * c->nUo; S.npo = c->nPo; S.n = S.nuo + S.npo;
+  const int64_t need = nul + npl + 4 * nul + 6 * npl + S.n + 64;
+  if ((int64_t)c->work.n < need) c->work.alloc(need);
+  double *p = c->work.p;
+  S.xu_ext = p; p += nul;
+  S.xp_ext = p; p += npl;
+  S.tu = p; p += nul;
+  S.utmp = p; p += nul;
+  S.inner_w = p; p += nul;
+  S.inner_z = p; p += nul;
+  for (int i = 0; i < 6; ++i) { S.tp[i] = p; p += npl; }
+  S.outer_w = p;
+  const int m = S.o->fgmres_restart, mi = S.o->inner_restart;
+  if ((int64_t)c->krylovV.n < (int64_t)(m + 1) * S.n) c->krylovV.alloc((int64_t)(m + 1) * S.n);
+  if ((int64_t)c->krylovZ.n < (int64_t)m * S.n) c->krylovZ.alloc((int64_t)m * S.n);
+  if ((int64_t)c->innerV.n < (int64_t)(mi + 1) * S.nuo) c->innerV.alloc((int64_t)(mi + 1) * S.nuo);
+}
+
+void ins_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, const double *src, double *dst) {
+  SolveState S{ctx, P, o};
+  carve_workspace(S);
+  precond_vmult(S, src, dst);
+}
+
+void ins_system_vmult(ifem_ctx *ctx, const double *src, double *dst) {
+  ifem_solver_opts o;
+  ifem_default_solver_opts(&o);
+  SolveState S{ctx, nullptr, &o};
+  carve_workspace(S);
+  system_apply(S, src, dst, false);
+}
+
+int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, int use_nonzero,
+              ifem_solve_stats *stats) {
+  if (!ctx->assembled) throw Error(IFEM_E_BADPARAM, "ifem_solve called before ifem_ins_assemble");
+  SolveState S{ctx, P, o};
+  carve_workspace(S);
+  Clock total;
+  ctx->spmv_uu_ms_total = 0;
+  ctx->timing.spmv_uu_calls = 0;
+  double *rhs = ctx->vec[IFEM_VEC_RHS].p, *upd = ctx->vec[IFEM_VEC_UPDATE].p;
+  auto mdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
+    v_mdot(ctx, S.n, k, V, ld, w, out);
+    allreduce_sum(ctx, out, k);
+  };
+  double bn;
+  mdot(1, rhs, S.n, rhs, &bn);
+  bn = std::sqrt(bn);
+  const double tol = std::max(o->fgmres_abs, o->fgmres_rel * bn);
+  int64_t n_glob = S.n; // SolverControl(system_matrix.m(), ...)
+  const int maxit = o->fgmres_maxit > 0 ? o->fgmres_maxit : (int)std::min<int64_t>(n_glob, 1 << 30);
+  OpFn Aop = [&](const double *x, double *y) { system_apply(S, x, y, true); };
+  OpFn Pop = [&](const double *x, double *y) { precond_vmult(S, x, y); };
+  double res = 0;
+  const int it = gmres(ctx, S.n, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p, ctx->krylovZ.p,
+                       S.outer_w, &res, mdot);
+  apply_constraints(ctx, use_nonzero ? 1 : 0, upd); // constraints_used.distribute(newton_update)
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  S.st.fgmres_iters = it;
+  S.st.fgmres_res = res;
+  S.st.t_total_ms = total.ms();
+  S.st.t_spmv_ms = ctx->spmv_uu_ms_total;
+  ctx->timing.spmv_uu_ms_avg = ctx->timing.spmv_uu_calls ? ctx->spmv_uu_ms_total / ctx->timing.spmv_uu_calls : 0;
+  if (stats) *stats = S.st;
+  if (o->verbose)
+    fprintf(stderr, "[ifem] solve: fgmres %d its res %.3e (tol %.3e) | P applies %u CG(Mp) %u CG(Sm) %u inner %u | %.1f ms\n",
+            it, res, tol, S.st.precond_applies, S.st.cg_mp_iters, S.st.cg_sm_iters, S.st.inner_iters, S.st.t_total_ms);
+  return res <= tol ? 0 : IFEM_E_KRYLOV_NOCONV;
+}
+
+} // namespace ifem

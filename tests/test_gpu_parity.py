@@ -1,0 +1,221 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances (fp64 everywhere): assembled matrix / rhs entries agree to 1e-11 of the largest entry (the only
+difference is floating-point summation order: component-block form + atomics vs the reference's scalar loop);
+linear solves meet the reference's own stopping rule ||b - A x|| <= 1e-4 ||b|| (mpi_insim.cpp:379-380), checked
+with the ORACLE's matrix; converged Newton steps agree to 1e-6 relative (Newton tolerance of the .prm files).
+"""
+import numpy as np
+import pytest
+
+import orc
+from boxmesh import BoxMesh
+from cases import CHANNEL_BCS, CHANNEL_KW, channel3d_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _capi():
+    import openifem_amd.capi as capi
+    return capi
+
+
+def _ctx(m):
+    capi = _capi()
+    return capi.Context(m.dim, m.kv, m.vcoords, m.cell_unodes, m.cell_pnodes, m.cell_face_bid, m.n_unodes, m.n_pnodes)
+
+
+def _rand_state(m, rng, scale=1.0):
+    ev = scale * rng.standard_normal(m.n_dofs)
+    pr = scale * rng.standard_normal(m.n_dofs)
+    return ev, pr
+
+
+def _compare_assembly(m, dofs, vals, kw, ev, pr, use_nonzero, indicator=None, fsi_acc=None):
+    capi = _capi()
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.vec_set(capi.VEC_PRESENT, pr)
+    ctx.vec_set(capi.VEC_EVAL, ev)
+    if indicator is not None:
+        ctx.set_indicator(indicator)
+        ctx.vec_set(capi.VEC_FSI_ACC, fsi_acc)
+        m.indicator = indicator
+    ctx.assemble(capi.make_params(**kw), use_nonzero)
+    A = ctx.export_csr(0)
+    M = ctx.export_csr(1)
+    b = ctx.vec_get(capi.VEC_RHS)
+    S = orc.System(m)
+    S.set_constraints(0, dofs, None)
+    S.set_constraints(1, dofs, vals)
+    S.assemble(orc.make_params(**kw), use_nonzero, ev, pr, fsi_acc)
+    Ao, Mo, bo = S.csr("A"), S.csr("M"), S.rhs()
+    dA = abs(A - Ao).max() / abs(Ao).max()
+    db = np.abs(b - bo).max() / np.abs(bo).max()
+    assert dA < 1e-11, f"matrix mismatch {dA}"
+    assert db < 1e-11, f"rhs mismatch {db}"
+    # mass matrix: the HIP path keeps only what the preconditioner reads: diag(M_uu) and M_pp
+    n_u = m.dim * m.n_unodes
+    assert np.abs(M.diagonal()[:n_u] - Mo.diagonal()[:n_u]).max() / Mo.diagonal()[:n_u].max() < 1e-12
+    dMp = abs(M[n_u:, n_u:] - Mo[n_u:, n_u:]).max() / abs(Mo[n_u:, n_u:]).max()
+    assert dMp < 1e-12, f"M_p mismatch {dMp}"
+    m.indicator = None
+    ctx.close()
+    return A, b
+
+
+@pytest.mark.parametrize("dim,kv,reps", [(2, 2, (5, 3)), (2, 1, (6, 4)), (3, 2, (3, 2, 2)), (3, 1, (3, 3, 2))])
+@pytest.mark.parametrize("use_nonzero", [False, True])
+def test_assembly_matches_oracle(dim, kv, reps, use_nonzero):
+    rng = np.random.default_rng(7 + dim + kv)
+    p1 = (1.0, 0.6, 0.4)[:dim]
+    m = BoxMesh(reps, (0,) * dim, p1, kv=kv)
+    m.vcoords = m.vcoords.copy()
+    m.vcoords += 0.02 * rng.standard_normal(m.vcoords.shape)  # d-linear distorted cells (general Jacobians)
+    flag = 3 if dim == 2 else 7
+    bcs = {0: (flag, [0.3, -0.2, 0.1][:dim]), 2: (flag, [0.0] * dim), 3: (1, [0.05])}
+    dofs, vals = m.dirichlet(bcs)
+    kw = dict(mu=0.7, rho=1.3, gamma=0.2, dt=0.01, g=(0.3, -9.8, 0.5)[:dim], neumann={1: 2.5})
+    ev, pr = _rand_state(m, rng)
+    _compare_assembly(m, dofs, vals, kw, ev, pr, use_nonzero)
+
+
+def test_assembly_fsi_indicator_term():
+    # artificial-fluid cells add rho a_fsi . phi to the rhs (mpi_insim.cpp:298-304)
+    rng = np.random.default_rng(3)
+    m = BoxMesh((3, 3, 2), (0, 0, 0), (1, 1, 1), kv=2)
+    dofs, vals = m.dirichlet({2: (7, [0, 0, 0])})
+    ev, pr = _rand_state(m, rng)
+    ind = (rng.uniform(size=m.n_cells) < 0.4).astype(np.int32)
+    acc = rng.standard_normal(m.n_dofs)
+    _compare_assembly(m, dofs, vals, dict(mu=1, rho=2, gamma=0.1, dt=0.1), ev, pr, False, ind, acc)
+
+
+def test_system_vmult_matches_oracle_matrix():
+    capi = _capi()
+    m = BoxMesh((4, 3, 3), (0, 0, 0), (2.0, 0.2, 0.2), kv=2)
+    dofs, vals, present, ev, kw = channel3d_state(m)
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.vec_set(capi.VEC_PRESENT, present)
+    ctx.vec_set(capi.VEC_EVAL, ev)
+    ctx.assemble(capi.make_params(**kw), False)
+    A = ctx.export_csr(0)
+    x = np.random.default_rng(0).standard_normal(m.n_dofs)
+    y = ctx.system_vmult(x)
+    assert np.abs(y - A @ x).max() / np.abs(y).max() < 1e-13
+
+
+@pytest.mark.parametrize("reps", [(4, 4, 4), (8, 8, 8)])
+def test_solve_meets_reference_stopping_rule(reps):
+    capi = _capi()
+    m = BoxMesh(reps, (0, 0, 0), (2.0, 0.2, 0.2), kv=2)
+    dofs, vals, present, ev, kw = channel3d_state(m)
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.vec_set(capi.VEC_PRESENT, present)
+    ctx.vec_set(capi.VEC_EVAL, ev)
+    P = capi.make_params(**kw)
+    ctx.assemble(P, False)
+    st = ctx.solve(P, False)
+    upd = ctx.vec_get(capi.VEC_UPDATE)
+    S = orc.System(m)
+    S.set_constraints(0, dofs, None)
+    S.assemble(orc.make_params(**kw), False, ev, present)
+    A, b = S.csr("A"), S.rhs()
+    assert np.linalg.norm(A @ upd - b) <= 1.05e-4 * np.linalg.norm(b)
+    assert np.abs(upd[dofs]).max() == 0.0  # constraints.distribute with zero constraints
+    # tightening the Krylov tolerance converges to the exact Newton update of the oracle matrix (sparse LU)
+    import scipy.sparse.linalg as spl
+    exact = spl.spsolve(A.tocsc(), b)
+    ctx.opts.fgmres_rel = 1e-10
+    ctx.opts.inner_rel = 1e-4
+    ctx.solve(P, False)
+    upd = ctx.vec_get(capi.VEC_UPDATE)
+    assert np.linalg.norm(upd - exact) / np.linalg.norm(exact) < 1e-4
+    assert st.fgmres_iters > 0
+
+
+def test_preconditioner_matches_oracle():
+    # P^-1 v with tight inner tolerances against the oracle's BlockSchurPreconditioner::vmult with exact LU
+    capi = _capi()
+    m = BoxMesh((4, 3, 2), (0, 0, 0), (2.0, 0.2, 0.2), kv=2)
+    dofs, vals, present, ev, kw = channel3d_state(m)
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.vec_set(capi.VEC_PRESENT, present)
+    ctx.vec_set(capi.VEC_EVAL, ev)
+    P = capi.make_params(**kw)
+    ctx.assemble(P, False)
+    ctx.opts.inner_rel = 1e-12
+    ctx.opts.inner_maxit = 5000
+    ctx.opts.mp_rel = 1e-13
+    ctx.opts.sm_rel = 1e-13
+    v = np.random.default_rng(5).standard_normal(m.n_dofs)
+    z = ctx.precond_vmult(P, v)
+    S = orc.System(m)
+    S.set_constraints(0, dofs, None)
+    S.assemble(orc.make_params(**kw), False, ev, present)
+    A, M = S.csr("A"), S.csr("M")
+    n_u = m.dim * m.n_unodes
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    Auu, Aup, Apu = A[:n_u, :n_u].tocsc(), A[:n_u, n_u:], A[n_u:, :n_u]
+    Mp = M[n_u:, n_u:].tocsc()
+    Sm = (Apu @ sp.diags(1.0 / M.diagonal()[:n_u]) @ Aup).tocsc()
+    z1 = -(kw["mu"] + kw["gamma"] * kw["rho"]) * spl.spsolve(Mp, v[n_u:]) - kw["rho"] / kw["dt"] * spl.spsolve(Sm, v[n_u:])
+    z0 = spl.spsolve(Auu, v[:n_u] - Aup @ z1)
+    ref = np.concatenate([z0, z1])
+    assert np.linalg.norm(z - ref) / np.linalg.norm(ref) < 1e-7
+
+
+def test_newton_step_matches_oracle_2d_poiseuille_start():
+    # first time step of tests/fluid_pressure_driven (coarser mesh): HIP Newton loop vs oracle with exact LU
+    capi = _capi()
+    m = BoxMesh([20, 4], (0, 0), (2.0, 0.2), kv=2)
+    dofs, vals = m.dirichlet({2: (3, [0, 0]), 3: (3, [0, 0])})
+    kw = dict(mu=1, rho=1, gamma=0.1, dt=1e-3, neumann={0: 10.0})
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.opts.inner_rel = 1e-8
+    ctx.opts.inner_maxit = 2000
+    n_it, log = ctx.newton_step(capi.make_params(**kw), True)
+    x = ctx.vec_get(capi.VEC_PRESENT)
+    S = orc.System(m)
+    S.set_constraints(0, dofs, None)
+    S.set_constraints(1, dofs, vals)
+    xo = np.zeros(S.n)
+    rc, logo = S.run_one_step(orc.make_params(**kw), True, xo, ainv=orc.SpluAinv())
+    assert rc > 0 and n_it > 0
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-6
+    assert abs(log[0, 0] - logo[0, 0]) / logo[0, 0] < 1e-10  # first Newton residual = ||rhs|| of the same assembly
+
+
+def test_kat_poiseuille_3d_on_gpu():
+    # the bench workload's known answer, Umax = 2.5e-2 (exact in Q2), through the HIP path only
+    capi = _capi()
+    m = BoxMesh([6, 3, 2], (0, 0, 0), (2.0, 0.2, 0.2), kv=2)
+    dofs, vals = m.dirichlet(CHANNEL_BCS)
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.opts.inner_rel = 1e-6
+    ctx.opts.inner_maxit = 2000
+    P = capi.make_params(**CHANNEL_KW)
+    for step in range(80):
+        n_it, _ = ctx.newton_step(P, step == 0)
+        assert n_it > 0
+    vmin, vmax = ctx.minmax(capi.VEC_PRESENT, 0)
+    assert abs(vmax - 2.5e-2) / 2.5e-2 < 1e-3
+    x = ctx.vec_get(capi.VEC_PRESENT)
+    y = m.unode_coords[:, 1]
+    assert np.abs(x[0:ctx.n_u:3] - 10.0 / 4.0 * y * (0.2 - y)).max() < 1e-6
+
+
+def test_no_cpu_fallback_error_path():
+    capi = _capi()
+    L = capi.load()
+    assert L.ifem_device_count() >= 1
