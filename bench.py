@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""bench.py -- DoF/s for one Newton step (assemble + FGMRES solve) of the 3D Q2/Q1 channel (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one InsIM Newton iteration -- assemble(false) + solve(false), mpi_insim.cpp:436-437 -- at the timed state
+of SURVEY 8(d): present = analytic plane Poiseuille, evaluation point = present + seeded 1e-3 perturbation, all
+vectors and mesh tables resident in HBM before the timed region.  Weak scaling: every GPU owns an n^3 block of the
+channel (n = 128 by default: config "3D channel flow 128^3 Q2/Q1" at N = 1, 256^3 at N = 8).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(n_cpu, threads):
+    """The CPU oracle (a port of the reference algorithm, oracle/oracle.c) on a bounded sample of the same workload:
+    one assemble + solve of the n_cpu^3 channel with the same inner-solver settings, on the host cores."""
+    import numpy as np
+    import orc
+    from boxmesh import BoxMesh
+    from cases import channel3d_state
+    m = BoxMesh([n_cpu] * 3, (0, 0, 0), (2.0, 0.2, 0.2), kv=2)
+    dofs, vals, present, ev, kw = channel3d_state(m)
+    try:
+        S = orc.System(m, native=True)
+    except Exception:
+        S = orc.System(m)
+    S.set_constraints(0, dofs, None)
+    S.set_constraints(1, dofs, vals)
+    S.opts.inner_rel = 1e-2
+    S.opts.inner_restart = 30
+    S.opts.inner_maxit = 400
+    S.opts.n_threads = threads
+    P = orc.make_params(**kw)
+    t0 = time.time()
+    S.assemble(P, False, ev, present)
+    t1 = time.time()
+    rc, upd, it, res = S.solve(P, False)
+    t2 = time.time()
+    return {"value": m.n_dofs / (t2 - t0), "unit": "DoF/s", "cores": threads, "kind": "port",
+            "sample": f"1 Newton step (assemble {t1 - t0:.2f}s + solve {t2 - t1:.2f}s, FGMRES its {it}) of the "
+                      f"{n_cpu}^3 Q2/Q1 channel ({m.n_dofs} DoF), oracle/oracle.c with OpenMP"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=128, help="cells per direction per GPU")
+    ap.add_argument("--cpu-n", type=int, default=16, help="cells per direction of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--inner-rel", type=float, default=1e-2)
+    ap.add_argument("--verbose", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # rendezvous + barrier + max-over-ranks only (gloo on the host)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from openifem_amd import host, capi
+    n = args.n
+    if world == 1:
+        reps = (n, n, n)
+        solver = host.InsIM(host.channel_prm(3), reps, (0, 0, 0), (2.0, 0.2, 0.2), device=local_rank, verbose=False)
+        t_setup = time.time()
+        solver.setup(0)
+        t_setup = time.time() - t_setup
+    else:
+        from openifem_amd import multigpu
+        solver, reps, t_setup = multigpu.make_channel_solver(n, rank, world, local_rank, dist)
+    n_cells, n_u, n_p = solver.sizes()
+    n_dofs_global = solver.global_dofs() if world > 1 else n_u + n_p
+    solver.opts.inner_rel = args.inner_rel
+    solver.opts.verbose = args.verbose if rank == 0 else 0
+    solver.channel_state()
+    solver.set_profiling(True)
+
+    def step():
+        solver.assemble(False)
+        return solver.solve(False)
+
+    for _ in range(args.warmup):
+        step()
+    if dist:
+        dist.barrier()
+    t0 = time.time()
+    t_asm = t_solve = 0.0
+    spmv_ms, spmv_calls = 0.0, 0
+    last = None
+    for _ in range(args.steps):
+        ta = time.time()
+        solver.assemble(False)
+        tb = time.time()
+        last = solver.solve(False)
+        tc = time.time()
+        t_asm += tb - ta
+        t_solve += tc - tb
+        tm = solver.timing()
+        spmv_ms += tm.spmv_uu_ms_avg * tm.spmv_uu_calls
+        spmv_calls += tm.spmv_uu_calls
+    elapsed = time.time() - t0
+    if dist:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    tm = solver.timing()
+    ms_per_step = elapsed / args.steps * 1e3
+    if rank == 0:
+        spmv_avg_ms = spmv_ms / max(spmv_calls, 1)
+        achieved = tm.spmv_uu_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
+        out = {
+            "metric": "DoF/s per Newton step (assemble+solve), 3D INS Q2/Q1",
+            "value": n_dofs_global / (elapsed / args.steps),
+            "unit": "DoF/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"3D channel flow {'x'.join(str(r) for r in reps)} Q2/Q1, mpi_insim Newton step "
+                                   f"(plane Poiseuille + seeded 1e-3 perturbation), {n}^3 cells per GPU",
+                       "n_dofs": n_dofs_global, "cells_per_gpu": n_cells, "parallelism": f"dd{world}",
+                       "assemble_ms": t_asm / args.steps * 1e3, "solve_ms": t_solve / args.steps * 1e3,
+                       "assemble_kernel_ms": tm.assemble_kernel_ms, "setup_s": t_setup,
+                       "fgmres_iters": last.fgmres_iters, "cg_mp_iters": last.cg_mp_iters,
+                       "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel,
+                       "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_uu (A_uu BSR SpMV + fused B^T)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "launch_ms": spmv_avg_ms, "launches_timed": spmv_calls,
+                         "algorithmic_bytes": tm.spmv_uu_bytes},
+        }
+        if args.cpu_n > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

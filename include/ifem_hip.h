@@ -174,6 +174,8 @@ typedef struct {
   double spmv_uu_bytes;      /* algorithmic bytes per call */
 } ifem_timing;
 int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t);
+/* on != 0: time every A_uu SpMV launch with HIP events on the context stream (one sync per launch) */
+int ifem_set_profiling(ifem_ctx *ctx, int on);
 
 #ifdef __cplusplus
 }

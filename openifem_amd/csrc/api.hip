@@ -363,6 +363,8 @@ int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t) {
   IFEM_API_END
 }
 
+int ifem_set_profiling(ifem_ctx *ctx, int on) { ctx->profile = on != 0; return IFEM_OK; }
+
 int ifem_comm_unique_id(uint8_t out[128]) { return ifem::comm_unique_id(out); }
 
 } // extern "C"

@@ -127,6 +127,7 @@ struct ifem_ctx {
   double *h_scal = nullptr; // pinned host mirror
   ifem::Halo halo;
   bool assembled = false;
+  bool profile = false; // HIP-event timing of every A_uu SpMV launch (bench only: adds a sync per launch)
   // timing
   ifem_timing timing{};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

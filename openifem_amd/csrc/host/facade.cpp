@@ -1,0 +1,191 @@
+// facade.cpp -- flat C entry points over the C++ host mirror, so that tests/bench (ctypes) can drive
+// Fluid::MPI::InsIM<dim> exactly the way the reference's test drivers do (tests/*/*.cpp).
+#include <cstring>
+#include <random>
+#include <sstream>
+#include "insim.hpp"
+
+using namespace ifem_host;
+
+namespace {
+thread_local std::string g_err;
+struct Handle {
+  int dim;
+  std::unique_ptr<Triangulation<2>> t2;
+  std::unique_ptr<Triangulation<3>> t3;
+  std::unique_ptr<Fluid::MPI::InsIM<2>> s2;
+  std::unique_ptr<Fluid::MPI::InsIM<3>> s3;
+  std::ostringstream log;
+};
+template <class F>
+int guard(F f) {
+  try { f(); return 0; }
+  catch (const Fluid::MPI::SolverFailure &e) { g_err = e.what(); return e.code; }
+  catch (const std::exception &e) { g_err = e.what(); return IFEM_E_BADPARAM; }
+}
+} // namespace
+
+extern "C" {
+
+const char *ifemx_last_error(void) { return g_err.c_str(); }
+
+// Equivalent of a reference test driver: AllParameters(prm) + subdivided_hyper_rectangle(reps, p0, p1, true)
+// + InsIM<dim>(tria, params).  prm_text is the parameter file CONTENT.
+int ifemx_insim_create_box(const char *prm_text, int dim, const unsigned *reps, const double *p0, const double *p1,
+                           int device, int verbose, void **out) {
+  return guard([&] {
+    auto params = Parameters::AllParameters::from_string(prm_text);
+    if (params.dimension != dim) throw std::invalid_argument("Dimension in the parameter file differs from the mesh");
+    auto *h = new Handle();
+    h->dim = dim;
+    std::vector<unsigned> r(reps, reps + dim);
+    if (dim == 2) {
+      h->t2.reset(new Triangulation<2>());
+      GridGenerator::subdivided_hyper_rectangle<2>(*h->t2, r, {p0[0], p0[1]}, {p1[0], p1[1]}, true);
+      h->s2.reset(new Fluid::MPI::InsIM<2>(*h->t2, params, device));
+      h->s2->pcout = verbose ? &std::cout : nullptr;
+    } else {
+      h->t3.reset(new Triangulation<3>());
+      GridGenerator::subdivided_hyper_rectangle<3>(*h->t3, r, {p0[0], p0[1], p0[2]}, {p1[0], p1[1], p1[2]}, true);
+      h->s3.reset(new Fluid::MPI::InsIM<3>(*h->t3, params, device));
+      h->s3->pcout = verbose ? &std::cout : nullptr;
+    }
+    *out = h;
+  });
+}
+
+void ifemx_destroy(void *hv) { delete static_cast<Handle *>(hv); }
+
+#define DISPATCH(h, expr2, expr3) (static_cast<Handle *>(h)->dim == 2 ? (expr2) : (expr3))
+
+int ifemx_run(void *hv) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] { if (h->dim == 2) h->s2->run(); else h->s3->run(); });
+}
+// setup_dofs + make_constraints + initialize_system without running (refinements from the .prm applied)
+int ifemx_setup(void *hv, int global_refinements) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) { h->t2->refine_global(global_refinements); h->s2->setup_dofs(); h->s2->make_constraints(); h->s2->initialize_system(); }
+    else { h->t3->refine_global(global_refinements); h->s3->setup_dofs(); h->s3->make_constraints(); h->s3->initialize_system(); }
+  });
+}
+// host-only part of the set-up (no device needed): refine + setup_dofs + make_constraints
+int ifemx_setup_host_only(void *hv, int global_refinements) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) { h->t2->refine_global(global_refinements); h->s2->setup_dofs(); h->s2->make_constraints(); }
+    else { h->t3->refine_global(global_refinements); h->s3->setup_dofs(); h->s3->make_constraints(); }
+  });
+}
+// nonzero_constraints lines; call with dof = NULL to get the count
+int ifemx_constraints(void *hv, int32_t *dof, double *val, int64_t *n) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    std::vector<int32_t> d; std::vector<double> v;
+    if (h->dim == 2) h->s2->constraint_lines(d, v); else h->s3->constraint_lines(d, v);
+    *n = (int64_t)d.size();
+    if (dof) { std::memcpy(dof, d.data(), d.size() * 4); std::memcpy(val, v.data(), v.size() * 8); }
+  });
+}
+int ifemx_run_one_step(void *hv, int apply_nonzero) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] { if (h->dim == 2) h->s2->run_one_step(apply_nonzero); else h->s3->run_one_step(apply_nonzero); });
+}
+int ifemx_assemble(void *hv, int use_nonzero) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] { if (h->dim == 2) h->s2->assemble(use_nonzero); else h->s3->assemble(use_nonzero); });
+}
+int ifemx_solve(void *hv, int use_nonzero, ifem_solve_stats *st) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) { h->s2->solve(use_nonzero); if (st) *st = h->s2->last_stats; }
+    else { h->s3->solve(use_nonzero); if (st) *st = h->s3->last_stats; }
+  });
+}
+ifem_solver_opts *ifemx_solver_opts(void *hv) {
+  auto *h = static_cast<Handle *>(hv);
+  return h->dim == 2 ? &h->s2->solver_opts : &h->s3->solver_opts;
+}
+ifem_ctx *ifemx_ctx(void *hv) {
+  auto *h = static_cast<Handle *>(hv);
+  return h->dim == 2 ? h->s2->context() : h->s3->context();
+}
+int ifemx_sizes(void *hv, int64_t *n_cells, int64_t *n_u, int64_t *n_p) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) { *n_cells = (int64_t)h->t2->n_active_cells(); *n_u = h->s2->dof_tables().n_u(); *n_p = h->s2->dof_tables().n_pnodes; }
+    else { *n_cells = (int64_t)h->t3->n_active_cells(); *n_u = h->s3->dof_tables().n_u(); *n_p = h->s3->dof_tables().n_pnodes; }
+  });
+}
+int ifemx_get_solution(void *hv, double *out) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto x = h->dim == 2 ? h->s2->get_current_solution() : h->s3->get_current_solution();
+    std::memcpy(out, x.data(), x.size() * sizeof(double));
+  });
+}
+// support-point coordinates of velocity nodes [n_unodes][dim] and pressure nodes [n_pnodes][dim]
+int ifemx_node_coords(void *hv, double *ucoords, double *pcoords) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) {
+      auto &d = h->s2->dof_tables();
+      std::memcpy(ucoords, d.unode_coords.data(), d.unode_coords.size() * 2 * sizeof(double));
+      std::memcpy(pcoords, d.pnode_coords.data(), d.pnode_coords.size() * 2 * sizeof(double));
+    } else {
+      auto &d = h->s3->dof_tables();
+      std::memcpy(ucoords, d.unode_coords.data(), d.unode_coords.size() * 3 * sizeof(double));
+      std::memcpy(pcoords, d.pnode_coords.data(), d.pnode_coords.size() * 3 * sizeof(double));
+    }
+  });
+}
+// cell -> node tables (for cross-checks against the tests' independent builder)
+int ifemx_cell_tables(void *hv, int32_t *cell_unodes, int32_t *cell_pnodes, int32_t *face_bid, double *vcoords) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto copy = [&](auto &d) {
+      std::memcpy(cell_unodes, d.cell_unodes.data(), d.cell_unodes.size() * 4);
+      std::memcpy(cell_pnodes, d.cell_pnodes.data(), d.cell_pnodes.size() * 4);
+      std::memcpy(face_bid, d.cell_face_bid.data(), d.cell_face_bid.size() * 4);
+      std::memcpy(vcoords, d.vcoords.data(), d.vcoords.size() * 8);
+    };
+    if (h->dim == 2) copy(h->s2->dof_tables()); else copy(h->s3->dof_tables());
+  });
+}
+
+// The timed state of the bench: present = analytic plane Poiseuille for the pressure-driven channel
+// [0,L]x[0,H](x[0,W]), evaluation point = present + seeded perturbation (mt19937_64(seed), uniform +-rel*Umax on
+// unconstrained velocity dofs, +-rel*dP on pressure).  Uploads both; Dirichlet dofs keep the present values.
+int ifemx_channel_state(void *hv, double L, double H, double dP, double mu, uint64_t seed, double rel) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto fill = [&](auto &solver, auto dimtag) {
+      constexpr int D = decltype(dimtag)::value;
+      auto &d = solver.dof_tables();
+      const int64_t n_u = d.n_u(), n = d.n_dofs();
+      std::vector<double> present((size_t)n, 0.0), ev;
+      const double umax = dP * H * H / (8 * mu * L);
+      for (int64_t nd = 0; nd < d.n_unodes; ++nd) {
+        const double y = d.unode_coords[nd][1];
+        present[nd * D] = dP / (2 * mu * L) * y * (H - y);
+      }
+      for (int64_t nd = 0; nd < d.n_pnodes; ++nd) present[n_u + nd] = dP * (1.0 - d.pnode_coords[nd][0] / L);
+      ev = present;
+      std::mt19937_64 gen(seed);
+      std::uniform_real_distribution<double> U(-1.0, 1.0);
+      for (int64_t i = 0; i < n_u; ++i) ev[i] += rel * umax * U(gen);
+      for (int64_t i = n_u; i < n; ++i) ev[i] += rel * dP * U(gen);
+      // constrained dofs keep the boundary values
+      std::vector<int32_t> cd; std::vector<double> cv;
+      solver.constraint_lines(cd, cv);
+      for (size_t k = 0; k < cd.size(); ++k) ev[cd[k]] = present[cd[k]];
+      if (ifem_vec_set(solver.context(), IFEM_VEC_PRESENT, present.data()) < 0 ||
+          ifem_vec_set(solver.context(), IFEM_VEC_EVAL, ev.data()) < 0)
+        throw std::runtime_error(ifem_last_error());
+    };
+    if (h->dim == 2) fill(*h->s2, std::integral_constant<int, 2>()); else fill(*h->s3, std::integral_constant<int, 3>());
+  });
+}
+
+} // extern "C"

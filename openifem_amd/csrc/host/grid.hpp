@@ -1,0 +1,62 @@
+// grid.hpp -- minimal mesh + DoF layer standing in for the deal.II pieces the fluid step needs:
+//   Triangulation / GridGenerator::subdivided_hyper_rectangle(.., colorize=true)   (tests/*/.cpp drivers)
+//   DoFHandler::distribute_dofs + block renumbering [velocity | pressure]           (mpi_fluid_solver.cpp:116-162)
+//   VectorTools::interpolate_boundary_values on boundary ids with component masks   (mpi_fluid_solver.cpp:165-280)
+// Nodes are numbered lexicographically by support-point coordinates (z, then y, then x): a bandwidth-friendly
+// order like the reference's Cuthill-McKee pass, and identical to the lattice order on box meshes.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <stdexcept>
+#include <vector>
+
+namespace ifem_host {
+
+template <int dim>
+struct Triangulation {
+  static constexpr int NV = 1 << dim;
+  std::vector<std::array<double, dim>> vertices;
+  std::vector<std::array<int32_t, NV>> cells;          // lexicographic vertex order (x fastest)
+  std::vector<std::array<int32_t, 2 * dim>> face_bid;  // boundary id per face x-,x+,y-,y+,z-,z+ ; -1 interior
+  // structured provenance (set by subdivided_hyper_rectangle, cleared by anything unstructured)
+  bool is_box = false;
+  std::array<int, 3> reps{1, 1, 1};
+  std::array<double, 3> p0{0, 0, 0}, p1{1, 1, 1};
+  size_t n_active_cells() const { return cells.size(); }
+  void refine_global(int times);
+};
+
+namespace GridGenerator {
+template <int dim>
+void subdivided_hyper_rectangle(Triangulation<dim> &tria, const std::vector<unsigned> &repetitions,
+                                const std::array<double, dim> &p0, const std::array<double, dim> &p1, bool colorize);
+}
+
+// cell -> node tables for FESystem(FE_Q(kv)^dim, FE_Q(1)); local order tensor-lexicographic
+template <int dim>
+struct DoFTables {
+  int kv = 2, nu = 0, np = 0;
+  int64_t n_unodes = 0, n_pnodes = 0;
+  std::vector<int32_t> cell_unodes, cell_pnodes;
+  std::vector<double> vcoords;        // [n_cells][2^dim][dim]
+  std::vector<int32_t> cell_face_bid; // [n_cells][2*dim]
+  std::vector<std::array<double, dim>> unode_coords, pnode_coords; // support points (d-linear map of the unit lattice)
+  int64_t n_u() const { return dim * n_unodes; }
+  int64_t n_dofs() const { return dim * n_unodes + n_pnodes; }
+};
+
+template <int dim>
+void distribute_dofs(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out);
+
+// Dirichlet lines (dof, value) in block numbering [u|p]; `bcs`: id -> (component flag 1..7, values);
+// `hard_coded`: id -> f(point, component) overriding the constant values (add_hard_coded_boundary_condition).
+template <int dim>
+void make_dirichlet(const Triangulation<dim> &tria, const DoFTables<dim> &dofs,
+                    const std::map<unsigned, std::pair<unsigned, std::vector<double>>> &bcs,
+                    const std::map<int, std::function<double(const std::array<double, dim> &, unsigned)>> &hard_coded,
+                    std::vector<int32_t> &dof, std::vector<double> &value);
+
+} // namespace ifem_host

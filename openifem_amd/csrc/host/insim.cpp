@@ -1,0 +1,203 @@
+#include "insim.hpp"
+#include <cmath>
+#include <iomanip>
+
+namespace ifem_host {
+namespace Utils {
+bool Time::time_to_output() const {
+  auto delta = static_cast<unsigned int>(output_interval / delta_t);
+  return (timestep >= delta && timestep % delta == 0);
+}
+bool Time::time_to_refine() const {
+  auto delta = static_cast<unsigned int>(refinement_interval / delta_t);
+  return (timestep >= delta && timestep % delta == 0);
+}
+bool Time::time_to_save() const {
+  auto delta = static_cast<unsigned int>(save_interval / delta_t);
+  return (timestep >= delta && timestep % delta == 0);
+}
+void Time::increment() { time_current += delta_t; ++timestep; }
+void Time::decrement() { time_current -= delta_t; --timestep; }
+} // namespace Utils
+
+namespace Fluid {
+namespace MPI {
+
+template <int dim>
+FluidSolver<dim>::FluidSolver(Triangulation<dim> &tria, const Parameters::AllParameters &parameters, int device)
+    : triangulation(tria), parameters(parameters),
+      time(parameters.end_time, parameters.time_step, parameters.output_interval, parameters.refinement_interval,
+           parameters.save_interval),
+      device(device) {}
+
+template <int dim>
+FluidSolver<dim>::~FluidSolver() {
+  if (ctx) ifem_ctx_destroy(ctx);
+}
+
+template <int dim>
+void FluidSolver<dim>::check(int rc, const char *what) const {
+  if (rc < 0) throw SolverFailure(rc, std::string(what) + ": " + ifem_last_error());
+}
+
+template <int dim>
+void FluidSolver<dim>::add_hard_coded_boundary_condition(
+    const int id, const std::function<double(const Point &, const unsigned int, const double)> &value_function) {
+  if (parameters.fluid_dirichlet_bcs.find(id) == parameters.fluid_dirichlet_bcs.end())
+    throw std::invalid_argument("Hard coded BC ID not included in parameters file!");
+  if (!hard_coded_boundary_values.insert({id, value_function}).second)
+    throw std::invalid_argument("Duplicated hard coded boundary conditions!");
+}
+
+template <int dim>
+void FluidSolver<dim>::set_initial_condition(const std::function<double(const Point &, const unsigned int)> &condition) {
+  initial_condition_field.reset(new std::function<double(const Point &, const unsigned int)>(condition));
+}
+
+template <int dim>
+void FluidSolver<dim>::setup_dofs() {
+  distribute_dofs<dim>(triangulation, (int)parameters.fluid_velocity_degree, dofs);
+  dofs_per_block = {(size_t)dofs.n_u(), (size_t)dofs.n_pnodes};
+  if (this->pcout)
+    *this->pcout << "   Number of active fluid cells: " << triangulation.n_active_cells() << std::endl
+           << "   Number of degrees of freedom: " << dofs.n_dofs() << " (" << dofs.n_u() << '+' << dofs.n_pnodes << ')'
+           << std::endl;
+}
+
+template <int dim>
+void FluidSolver<dim>::make_constraints() {
+  std::map<int, std::function<double(const Point &, unsigned)>> hc;
+  const double t = time.current();
+  for (auto &kv : hard_coded_boundary_values) {
+    auto f = kv.second;
+    hc[kv.first] = [f, t](const Point &p, unsigned c) { return f(p, c, t); };
+  }
+  make_dirichlet<dim>(triangulation, dofs, parameters.fluid_dirichlet_bcs, hc, constraint_dofs, nonzero_values);
+  if (ctx) {
+    check(ifem_set_constraints(ctx, 1, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nonzero_values.data()), "make_constraints");
+    check(ifem_set_constraints(ctx, 0, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nullptr), "make_constraints");
+  }
+}
+
+template <int dim>
+void FluidSolver<dim>::initialize_system() {
+  if (ctx) { ifem_ctx_destroy(ctx); ctx = nullptr; }
+  ifem_mesh_desc m{};
+  m.dim = dim; m.kv = dofs.kv; m.n_cells = (int32_t)triangulation.n_active_cells();
+  m.n_unodes_owned = m.n_unodes_local = (int32_t)dofs.n_unodes;
+  m.n_pnodes_owned = m.n_pnodes_local = (int32_t)dofs.n_pnodes;
+  m.vcoords = dofs.vcoords.data(); m.cell_unodes = dofs.cell_unodes.data(); m.cell_pnodes = dofs.cell_pnodes.data();
+  m.cell_face_bid = dofs.cell_face_bid.data();
+  check(ifem_ctx_create(&m, nullptr, device, &ctx), "initialize_system");
+  check(ifem_set_constraints(ctx, 1, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nonzero_values.data()), "initialize_system");
+  check(ifem_set_constraints(ctx, 0, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nullptr), "initialize_system");
+  if (initial_condition_field) { // apply_initial_condition (mpi_fluid_solver.cpp:367-415): nodal interpolation
+    std::vector<double> x((size_t)dofs.n_dofs(), 0.0);
+    for (int64_t nd = 0; nd < dofs.n_unodes; ++nd)
+      for (int c = 0; c < dim; ++c) x[nd * dim + c] = (*initial_condition_field)(dofs.unode_coords[nd], c);
+    for (int64_t nd = 0; nd < dofs.n_pnodes; ++nd) x[dofs.n_u() + nd] = (*initial_condition_field)(dofs.pnode_coords[nd], dim);
+    check(ifem_vec_set(ctx, IFEM_VEC_PRESENT, x.data()), "apply_initial_condition");
+  }
+}
+
+template <int dim>
+std::vector<double> FluidSolver<dim>::get_current_solution() const {
+  std::vector<double> x((size_t)dofs.n_dofs());
+  check(ifem_vec_get(ctx, IFEM_VEC_PRESENT, x.data()), "get_current_solution");
+  return x;
+}
+
+template <int dim>
+InsIM<dim>::InsIM(Triangulation<dim> &tria, const Parameters::AllParameters &parameters, int device)
+    : FluidSolver<dim>(tria, parameters, device) {
+  if (parameters.fluid_velocity_degree - parameters.fluid_pressure_degree != 1)
+    throw std::invalid_argument("Velocity finite element should be one order higher than pressure!");
+  ifem_default_solver_opts(&solver_opts);
+}
+
+template <int dim>
+void InsIM<dim>::initialize_system() {
+  FluidSolver<dim>::initialize_system();
+}
+
+template <int dim>
+ifem_ins_params InsIM<dim>::ins_params() const {
+  ifem_ins_params p{};
+  p.viscosity = parameters.viscosity; p.rho = parameters.fluid_rho; p.grad_div = parameters.grad_div;
+  p.dt = time.get_delta_t();
+  for (int i = 0; i < dim; ++i) p.gravity[i] = parameters.gravity[i];
+  p.n_neumann = 0;
+  if (parameters.n_fluid_neumann_bcs != 0)
+    for (auto &kv : parameters.fluid_neumann_bcs) {
+      if (p.n_neumann >= 8) throw std::invalid_argument("at most 8 Neumann boundaries are supported");
+      p.neumann_id[p.n_neumann] = (int32_t)kv.first;
+      p.neumann_p[p.n_neumann++] = kv.second;
+    }
+  return p;
+}
+
+template <int dim>
+void InsIM<dim>::assemble(const bool use_nonzero_constraints) {
+  const ifem_ins_params p = ins_params();
+  check(ifem_ins_assemble(ctx, &p, use_nonzero_constraints), "assemble");
+}
+
+template <int dim>
+std::pair<unsigned int, double> InsIM<dim>::solve(const bool use_nonzero_constraints) {
+  const ifem_ins_params p = ins_params();
+  check(ifem_solve(ctx, &p, &solver_opts, use_nonzero_constraints, &last_stats), "solve");
+  return {last_stats.fgmres_iters, last_stats.fgmres_res};
+}
+
+template <int dim>
+void InsIM<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_system) {
+  static_cast<void>(assemble_system);
+  time.increment();
+  if (this->pcout)
+    *this->pcout << std::string(96, '*') << std::endl
+           << "Time step = " << time.get_timestep() << ", at t = " << std::scientific << time.current() << std::endl;
+  double current_residual = 1.0, initial_residual = 1.0, relative_residual = 1.0;
+  unsigned int outer_iteration = 0;
+  check(ifem_vec_copy(ctx, IFEM_VEC_EVAL, IFEM_VEC_PRESENT), "run_one_step"); // evaluation_point = present_solution
+  while (relative_residual > parameters.fluid_tolerance && current_residual > 1e-11) {
+    if (!(outer_iteration < parameters.fluid_max_iterations))
+      throw SolverFailure(IFEM_E_NEWTON_MAXIT, "Too many Newton iterations!");
+    check(ifem_vec_zero(ctx, IFEM_VEC_UPDATE), "run_one_step"); // newton_update = 0
+    assemble(apply_nonzero_constraints && outer_iteration == 0);
+    auto state = solve(apply_nonzero_constraints && outer_iteration == 0);
+    check(ifem_rhs_norm(ctx, &current_residual), "run_one_step");
+    check(ifem_vec_axpy(ctx, 1.0, IFEM_VEC_UPDATE, IFEM_VEC_EVAL), "run_one_step"); // evaluation_point += newton_update
+    if (outer_iteration == 0) initial_residual = current_residual;
+    relative_residual = current_residual / initial_residual;
+    if (this->pcout)
+      *this->pcout << std::scientific << std::left << " ITR = " << std::setw(2) << outer_iteration
+             << " ABS_RES = " << current_residual << " REL_RES = " << relative_residual
+             << " GMRES_ITR = " << std::setw(3) << state.first << " GMRES_RES = " << state.second << std::endl;
+    outer_iteration++;
+  }
+  // solution_increment = present - evaluation; present_solution = evaluation_point
+  check(ifem_vec_copy(ctx, IFEM_VEC_INCREMENT, IFEM_VEC_PRESENT), "run_one_step");
+  check(ifem_vec_axpy(ctx, -1.0, IFEM_VEC_EVAL, IFEM_VEC_INCREMENT), "run_one_step");
+  check(ifem_vec_copy(ctx, IFEM_VEC_PRESENT, IFEM_VEC_EVAL), "run_one_step");
+  // update_stress / save_checkpoint / output_results / refine_mesh: host plumbing, out of scope
+}
+
+template <int dim>
+void InsIM<dim>::run() {
+  if (this->pcout) *this->pcout << "Running with HIP on 1 MI355X rank(s)..." << std::endl;
+  this->triangulation.refine_global(parameters.global_refinements[0]);
+  this->setup_dofs();
+  this->make_constraints();
+  this->initialize_system();
+  run_one_step(true);
+  while (time.end() - time.current() > 1e-12) run_one_step(false);
+}
+
+template class FluidSolver<2>;
+template class FluidSolver<3>;
+template class InsIM<2>;
+template class InsIM<3>;
+
+} // namespace MPI
+} // namespace Fluid
+} // namespace ifem_host

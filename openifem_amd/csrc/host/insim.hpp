@@ -1,0 +1,114 @@
+// insim.hpp -- host-side mirror of the reference interface for the fluid step:
+//   Utils::Time                      include/utilities.h, source/utilities.cpp:6-36
+//   Fluid::MPI::FluidSolver<dim>     include/mpi_fluid_solver.h:89-151   (run, run_one_step, setup_dofs,
+//                                    make_constraints, initialize_system, get_current_solution, hooks)
+//   Fluid::MPI::InsIM<dim>           include/mpi_insim.h:35-99           (assemble, solve, run_one_step, run)
+// Same member names, argument meaning and error behaviour (exceptions with the reference's messages); the
+// PETSc matrices/vectors are replaced by one ifem_ctx (device) reached only through the C ABI of ifem_hip.h.
+#pragma once
+#include <functional>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../../include/ifem_hip.h"
+#include "grid.hpp"
+#include "parameters.hpp"
+
+namespace ifem_host {
+namespace Utils {
+class Time {
+public:
+  Time(double time_end, double delta_t, double output_interval, double refinement_interval, double save_interval)
+      : timestep(0), time_current(0.0), time_end(time_end), delta_t(delta_t), output_interval(output_interval),
+        refinement_interval(refinement_interval), save_interval(save_interval) {}
+  double current() const { return time_current; }
+  double end() const { return time_end; }
+  double get_delta_t() const { return delta_t; }
+  unsigned int get_timestep() const { return timestep; }
+  bool time_to_output() const;
+  bool time_to_refine() const;
+  bool time_to_save() const;
+  void increment();
+  void decrement();
+  void set_delta_t(double delta) { delta_t = delta; }
+
+private:
+  unsigned int timestep;
+  double time_current, time_end, delta_t;
+  const double output_interval, refinement_interval, save_interval;
+};
+} // namespace Utils
+
+namespace Fluid {
+namespace MPI {
+
+struct SolverFailure : std::runtime_error {
+  int code;
+  SolverFailure(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+template <int dim>
+class FluidSolver {
+public:
+  using Point = std::array<double, dim>;
+  FluidSolver(Triangulation<dim> &, const Parameters::AllParameters &, int device = 0);
+  virtual ~FluidSolver();
+  virtual void run() = 0;
+  void add_hard_coded_boundary_condition(const int id,
+                                         const std::function<double(const Point &, const unsigned int, const double)> &);
+  void set_initial_condition(const std::function<double(const Point &, const unsigned int)> &);
+  // block vector [velocity | pressure] (PETScWrappers::MPI::BlockVector get_current_solution())
+  std::vector<double> get_current_solution() const;
+  std::pair<size_t, size_t> dofs_per_block_sizes() const { return {(size_t)dofs.n_u(), (size_t)dofs.n_pnodes}; }
+  ifem_ctx *context() const { return ctx; }
+  const DoFTables<dim> &dof_tables() const { return dofs; }
+  void constraint_lines(std::vector<int32_t> &d, std::vector<double> &v) const { d = constraint_dofs; v = nonzero_values; }
+  std::ostream *pcout = &std::cout; // ConditionalOStream on rank 0; nullptr silences
+
+  virtual void run_one_step(bool apply_nonzero_constraints, bool assemble_system = true) = 0;
+  void setup_dofs();
+  void make_constraints();
+  virtual void initialize_system();
+
+protected:
+  void check(int rc, const char *what) const;
+  Triangulation<dim> &triangulation;
+  Parameters::AllParameters parameters;
+  DoFTables<dim> dofs;
+  std::vector<size_t> dofs_per_block;
+  std::map<int, std::function<double(const Point &, const unsigned int, const double)>> hard_coded_boundary_values;
+  std::shared_ptr<std::function<double(const Point &, const unsigned int)>> initial_condition_field;
+  Utils::Time time;
+  ifem_ctx *ctx = nullptr;
+  int device;
+  std::vector<int32_t> constraint_dofs;
+  std::vector<double> nonzero_values;
+};
+
+template <int dim>
+class InsIM : public FluidSolver<dim> {
+public:
+  InsIM(Triangulation<dim> &, const Parameters::AllParameters &, int device = 0);
+  void run() override;
+  void run_one_step(bool apply_nonzero_constraints, bool assemble_system = true) override;
+  void initialize_system() override;
+  // exposed for tests/bench (private in the reference, mpi_insim.h:66,75)
+  void assemble(const bool use_nonzero_constraints);
+  std::pair<unsigned int, double> solve(const bool use_nonzero_constraints);
+  ifem_solver_opts solver_opts;
+  ifem_solve_stats last_stats{};
+  ifem_ins_params ins_params() const;
+
+private:
+  using FluidSolver<dim>::parameters;
+  using FluidSolver<dim>::time;
+  using FluidSolver<dim>::ctx;
+  using FluidSolver<dim>::check;
+};
+
+} // namespace MPI
+} // namespace Fluid
+} // namespace ifem_host

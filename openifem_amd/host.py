@@ -1,0 +1,190 @@
+"""ctypes binding of the C++ host mirror (csrc/host/facade.cpp): Fluid::MPI::InsIM driven like a reference test."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class HostError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ifem host error {code}: {msg}")
+        self.code = code
+
+
+def _lib():
+    L = capi.load()
+    if getattr(L, "_ifemx_bound", False):
+        return L
+    L.ifemx_last_error.restype = C.c_char_p
+    L.ifemx_insim_create_box.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                         C.POINTER(C.c_void_p)]
+    L.ifemx_destroy.argtypes = [C.c_void_p]
+    L.ifemx_run.argtypes = [C.c_void_p]
+    L.ifemx_setup.argtypes = [C.c_void_p, C.c_int]
+    L.ifemx_run_one_step.argtypes = [C.c_void_p, C.c_int]
+    L.ifemx_setup_host_only.argtypes = [C.c_void_p, C.c_int]
+    L.ifemx_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    L.ifemx_assemble.argtypes = [C.c_void_p, C.c_int]
+    L.ifemx_solve.argtypes = [C.c_void_p, C.c_int, C.POINTER(capi.SolveStats)]
+    L.ifemx_solver_opts.restype = C.POINTER(capi.SolverOpts)
+    L.ifemx_solver_opts.argtypes = [C.c_void_p]
+    L.ifemx_ctx.restype = C.c_void_p
+    L.ifemx_ctx.argtypes = [C.c_void_p]
+    L.ifemx_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.ifemx_get_solution.argtypes = [C.c_void_p, C.c_void_p]
+    L.ifemx_node_coords.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifemx_cell_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifemx_channel_state.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_double]
+    L._ifemx_bound = True
+    return L
+
+
+class InsIM:
+    """Fluid::MPI::InsIM<dim> on a colorised subdivided_hyper_rectangle, configured by a .prm text."""
+
+    def __init__(self, prm_text, reps, p0, p1, device=0, verbose=False):
+        self.L = _lib()
+        self.dim = len(reps)
+        r = np.ascontiguousarray(reps, np.uint32)
+        a, b = np.ascontiguousarray(p0, float), np.ascontiguousarray(p1, float)
+        self.h = C.c_void_p()
+        self._chk(self.L.ifemx_insim_create_box(prm_text.encode(), self.dim, r.ctypes.data_as(C.c_void_p),
+                                                a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), device,
+                                                int(verbose), C.byref(self.h)))
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise HostError(rc, self.L.ifemx_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.L.ifemx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self):
+        self._chk(self.L.ifemx_run(self.h))
+
+    def setup(self, global_refinements=0):
+        self._chk(self.L.ifemx_setup(self.h, global_refinements))
+
+    def setup_host_only(self, global_refinements=0):
+        self._chk(self.L.ifemx_setup_host_only(self.h, global_refinements))
+
+    def constraints(self):
+        n = C.c_int64()
+        self._chk(self.L.ifemx_constraints(self.h, None, None, C.byref(n)))
+        d, v = np.zeros(n.value, np.int32), np.zeros(n.value)
+        self._chk(self.L.ifemx_constraints(self.h, d.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return d, v
+
+    def run_one_step(self, apply_nonzero):
+        self._chk(self.L.ifemx_run_one_step(self.h, int(apply_nonzero)))
+
+    def assemble(self, use_nonzero):
+        self._chk(self.L.ifemx_assemble(self.h, int(use_nonzero)))
+
+    def solve(self, use_nonzero):
+        st = capi.SolveStats()
+        self._chk(self.L.ifemx_solve(self.h, int(use_nonzero), C.byref(st)))
+        return st
+
+    @property
+    def opts(self):
+        return self.L.ifemx_solver_opts(self.h).contents
+
+    @property
+    def ctx(self):
+        return C.c_void_p(self.L.ifemx_ctx(self.h))
+
+    def sizes(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self.L.ifemx_sizes(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def get_current_solution(self):
+        _, n_u, n_p = self.sizes()
+        x = np.zeros(n_u + n_p)
+        self._chk(self.L.ifemx_get_solution(self.h, x.ctypes.data_as(C.c_void_p)))
+        return x[:n_u], x[n_u:]
+
+    def node_coords(self):
+        _, n_u, n_p = self.sizes()
+        uc, pc = np.zeros((n_u // self.dim, self.dim)), np.zeros((n_p, self.dim))
+        self._chk(self.L.ifemx_node_coords(self.h, uc.ctypes.data_as(C.c_void_p), pc.ctypes.data_as(C.c_void_p)))
+        return uc, pc
+
+    def cell_tables(self, kv=2):
+        n_cells, _, _ = self.sizes()
+        nu, nv = (kv + 1) ** self.dim, 2 ** self.dim
+        cu, cp = np.zeros((n_cells, nu), np.int32), np.zeros((n_cells, nv), np.int32)
+        fb, vc = np.zeros((n_cells, 2 * self.dim), np.int32), np.zeros((n_cells, nv, self.dim))
+        self._chk(self.L.ifemx_cell_tables(self.h, *[x.ctypes.data_as(C.c_void_p) for x in (cu, cp, fb, vc)]))
+        return cu, cp, fb, vc
+
+    def channel_state(self, L=2.0, H=0.2, dP=10.0, mu=1.0, seed=1234, rel=1e-3):
+        self._chk(self.L.ifemx_channel_state(self.h, L, H, dP, mu, seed, rel))
+
+    def set_profiling(self, on=True):
+        self.L.ifem_set_profiling(self.ctx, int(on))
+
+    def timing(self):
+        t = capi.Timing()
+        rc = self.L.ifem_get_timing(self.ctx, C.byref(t))
+        if rc < 0:
+            raise HostError(rc, self.L.ifem_last_error().decode())
+        return t
+
+
+def channel_prm(dim=3, dt=1e-3, end_time=8e-2, refinements=0):
+    """tests/fluid_pressure_driven/fluid_pressure_driven.prm transcribed for the 2D case and extended to the 3D
+    channel of SURVEY 8(d): no-slip on y-walls, w = 0 on z-walls, inlet pressure 10."""
+    if dim == 2:
+        dirichlet = ("  set Number of Dirichlet BCs = 2\n  set Dirichlet boundary id = 2, 3\n"
+                     "  set Dirichlet boundary components = 3, 3\n  set Dirichlet boundary values = 0, 0, 0, 0\n")
+        grav = "0.0, 0.0"
+    else:
+        dirichlet = ("  set Number of Dirichlet BCs = 4\n  set Dirichlet boundary id = 2, 3, 4, 5\n"
+                     "  set Dirichlet boundary components = 7, 7, 4, 4\n"
+                     "  set Dirichlet boundary values = 0, 0, 0, 0, 0, 0, 0, 0\n")
+        grav = "0.0, 0.0, 0.0"
+    return f"""
+subsection Simulation
+  set Simulation type = Fluid
+  set Dimension = {dim}
+  set Global refinements = {refinements}, 0
+  set End time = {end_time}
+  set Time step size = {dt}
+  set Output interval = 1e-2
+  set Refinement interval = 1000
+  set Save interval = 100
+  set Gravity = {grav}
+end
+subsection Fluid finite element system
+  set Pressure degree = 1
+  set Velocity degree = 2
+end
+subsection Fluid material properties
+  set Dynamic viscosity = 1
+  set Fluid density = 1
+end
+subsection Fluid solver control
+  set Grad-Div stabilization = 0.1
+  set Max Newton iterations = 8
+  set Nonlinear system tolerance = 1e-6
+end
+subsection Fluid Dirichlet BCs
+  set Use hard-coded boundary values = 0
+{dirichlet}end
+subsection Fluid Neumann BCs
+  set Number of Neumann BCs = 1
+  set Neumann boundary id = 0
+  set Neumann boundary values = 10
+end
+"""

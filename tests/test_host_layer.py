@@ -1,0 +1,103 @@
+"""CPU tests of the host logic (no GPU): C-ABI exports, .prm parsing, mesh/DoF tables and Dirichlet lines of the
+C++ host mirror cross-checked against the tests' independent numpy builder (tests/boxmesh.py)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from boxmesh import BoxMesh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import openifem_amd.capi as capi
+    L = capi.load()
+    hdr = open(os.path.join(ROOT, "include", "ifem_hip.h")).read()
+    declared = set(re.findall(r"\b(ifem_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ifem_ctx"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libifem_hip.so does not export {name}"
+    assert set(capi.EXPORTS) <= declared | {"ifem_last_error"}
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    import openifem_amd.capi as capi
+    L = capi.load()
+    if L.ifem_device_count() > 0:
+        pytest.skip("a GPU is present")
+    m = BoxMesh([2, 2], (0, 0), (1, 1), kv=2)
+    with pytest.raises(capi.IfemError) as e:
+        capi.Context(2, 2, m.vcoords, m.cell_unodes, m.cell_pnodes, m.cell_face_bid, m.n_unodes, m.n_pnodes)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+@pytest.mark.parametrize("dim,reps,p1", [(2, (5, 3), (2.0, 0.2)), (3, (4, 3, 2), (2.0, 0.2, 0.2))])
+def test_host_tables_match_independent_builder(dim, reps, p1):
+    from openifem_amd import host
+    s = host.InsIM(host.channel_prm(dim), reps, (0,) * dim, p1)
+    s.setup_host_only(0)
+    m = BoxMesh(reps, (0,) * dim, p1, kv=2)
+    n_cells, n_u, n_p = s.sizes()
+    assert (n_cells, n_u, n_p) == (m.n_cells, m.n_u, m.n_pnodes)
+    cu, cp, fb, vc = s.cell_tables()
+    assert np.array_equal(cu, m.cell_unodes) and np.array_equal(cp, m.cell_pnodes) and np.array_equal(fb, m.cell_face_bid)
+    assert np.abs(vc - m.vcoords).max() < 1e-15
+    uc, pc = s.node_coords()
+    assert np.abs(uc - m.unode_coords).max() < 1e-14 and np.abs(pc - m.pnode_coords).max() < 1e-15
+    d, v = s.constraints()
+    bcs = {2: (3, [0, 0]), 3: (3, [0, 0])} if dim == 2 else {2: (7, [0, 0, 0]), 3: (7, [0, 0, 0]), 4: (4, [0]), 5: (4, [0])}
+    d0, v0 = m.dirichlet(bcs)
+    assert set(d.tolist()) == set(d0.tolist()) and np.all(v == 0)
+
+
+def test_refine_global_doubles_the_box():
+    from openifem_amd import host
+    s = host.InsIM(host.channel_prm(2), (5, 2), (0, 0), (2.0, 0.2))
+    s.setup_host_only(1)
+    assert s.sizes()[0] == 40
+
+
+def test_first_boundary_id_wins_at_corners():
+    # tests/fluid_pipe_mpi: ids 0 (inflow u=1), 2, 3 (no slip): corner nodes keep the inflow value (id order)
+    from openifem_amd import host
+    prm = host.channel_prm(2).replace("set Number of Dirichlet BCs = 2", "set Number of Dirichlet BCs = 3") \
+        .replace("set Dirichlet boundary id = 2, 3", "set Dirichlet boundary id = 0, 2, 3") \
+        .replace("set Dirichlet boundary components = 3, 3", "set Dirichlet boundary components = 3, 3, 3") \
+        .replace("set Dirichlet boundary values = 0, 0, 0, 0", "set Dirichlet boundary values = 1, 0, 0, 0, 0, 0") \
+        .replace("set Number of Neumann BCs = 1", "set Number of Neumann BCs = 0")
+    s = host.InsIM(prm, (4, 2), (0, 0), (2.0, 0.2))
+    s.setup_host_only(0)
+    d, v = s.constraints()
+    m = BoxMesh((4, 2), (0, 0), (2.0, 0.2), kv=2)
+    d0, v0 = m.dirichlet({0: (3, [1, 0]), 2: (3, [0, 0]), 3: (3, [0, 0])})
+    a, b = dict(zip(d.tolist(), v.tolist())), dict(zip(d0.tolist(), v0.tolist()))
+    assert a == b
+    assert a[0] == 1.0  # node 0 = corner (0,0): u_x from the inflow boundary
+
+
+def test_prm_errors_match_reference_messages():
+    from openifem_amd import host
+    bad = host.channel_prm(2).replace("set Gravity = 0.0, 0.0", "set Gravity = 0.0")
+    with pytest.raises(host.HostError, match="Inconsistent dimension of gravity"):
+        host.InsIM(bad, (2, 2), (0, 0), (1, 1))
+    bad = host.channel_prm(2).replace("set Dirichlet boundary values = 0, 0, 0, 0", "set Dirichlet boundary values = 0, 0, 0")
+    with pytest.raises(host.HostError, match="Inconsistent boundary values"):
+        host.InsIM(bad, (2, 2), (0, 0), (1, 1))
+    bad = host.channel_prm(2).replace("set Velocity degree = 2", "set Velocity degree = 1")
+    with pytest.raises(host.HostError, match="one order higher"):
+        host.InsIM(bad, (2, 2), (0, 0), (1, 1))
+
+
+def test_reference_prm_files_parse():
+    # the reference's own parameter files for the hot-path tests are accepted verbatim (fixture data copied
+    # under tests/golden/prm; the solid subsections are ignored)
+    from openifem_amd import host
+    gdir = os.path.join(ROOT, "tests", "golden", "prm")
+    for name, dim in (("fluid_pressure_driven.prm", 2), ("fluid_gravity.prm", 2), ("fluid_pipe_mpi.prm", 2)):
+        s = host.InsIM(open(os.path.join(gdir, name)).read(), (4, 2), (0, 0), (2.0, 0.2))
+        s.setup_host_only(0)
+        assert s.sizes()[0] == 8
