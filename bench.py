@@ -23,6 +23,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def pmc_traffic(n):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["k_spmv_uu"][str(n)]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_cpu, threads):
     """The CPU oracle (a port of the reference algorithm, oracle/oracle.c) on a bounded sample of the same workload:
     one assemble + solve of the n_cpu^3 channel with the same inner-solver settings, on the host cores."""
@@ -59,7 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=128, help="cells per direction per GPU")
-    ap.add_argument("--cpu-n", type=int, default=16, help="cells per direction of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-n", type=int, default=24, help="cells per direction of the CPU baseline sample (0 = skip)")
     ap.add_argument("--inner-rel", type=float, default=1e-2)
     ap.add_argument("--verbose", type=int, default=0)
     args = ap.parse_args()
@@ -145,7 +154,7 @@ def main():
                        "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms},
             "roofline": {"bound": "hbm", "kernel": "k_spmv_uu (A_uu BSR SpMV + fused B^T)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "launch_ms": spmv_avg_ms, "launches_timed": spmv_calls,
+                         "traffic": pmc_traffic(n) if world == 1 else None, "launch_ms": spmv_avg_ms, "launches_timed": spmv_calls,
                          "algorithmic_bytes": tm.spmv_uu_bytes},
         }
         if args.cpu_n > 0:

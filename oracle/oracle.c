@@ -451,20 +451,31 @@ void orc_ins_assemble(orc_system *s, const orc_params *P, int32_t use_nonzero, c
 }
 
 /* ------------------------------------------------------------------ vector helpers */
+static int g_max_threads = 0;
+static int nthr(long n, long grain) {
+#ifdef _OPENMP
+  int mx = g_max_threads > 0 ? g_max_threads : omp_get_max_threads();
+  long t = n / grain;
+  if (t < 1) t = 1;
+  return (int)(t < mx ? t : mx);
+#else
+  (void)n; (void)grain; return 1;
+#endif
+}
 static double vdot(int n, const double *a, const double *b) {
   double s = 0;
-#pragma omp parallel for reduction(+ : s) if (n > 20000)
+#pragma omp parallel for reduction(+ : s) num_threads(nthr(n, 32768))
   for (int i = 0; i < n; ++i) s += a[i] * b[i];
   return s;
 }
 static double vnorm(int n, const double *a) { return sqrt(vdot(n, a, a)); }
 static void vaxpy(int n, double al, const double *x, double *y) {
-#pragma omp parallel for if (n > 20000)
+#pragma omp parallel for num_threads(nthr(n, 32768))
   for (int i = 0; i < n; ++i) y[i] += al * x[i];
 }
 
 void orc_spmv(const orc_system *s, const double *x, double *y) {
-#pragma omp parallel for schedule(static) if (s->n > 5000)
+#pragma omp parallel for schedule(static) num_threads(nthr(s->n, 2048))
   for (int i = 0; i < s->n; ++i) {
     double t = 0;
     for (int64_t k = s->rowptr[i]; k < s->rowptr[i + 1]; ++k) t += s->A[k] * x[s->col[k]];
@@ -473,7 +484,7 @@ void orc_spmv(const orc_system *s, const double *x, double *y) {
 }
 /* y_u = A_uu x_u */
 static void spmv_uu(const orc_system *s, const double *x, double *y) {
-#pragma omp parallel for schedule(static) if (s->n > 5000)
+#pragma omp parallel for schedule(static) num_threads(nthr(s->n, 2048))
   for (int i = 0; i < s->n_u; ++i) {
     double t = 0; int64_t b = s->rowptr[i], e = b + s->psplit[i];
     for (int64_t k = b; k < e; ++k) t += s->A[k] * x[s->col[k]];
@@ -482,7 +493,7 @@ static void spmv_uu(const orc_system *s, const double *x, double *y) {
 }
 /* y_u = A_up x_p  (system_matrix.block(0,1)) */
 static void spmv_up(const orc_system *s, const double *xp, double *y) {
-#pragma omp parallel for schedule(static) if (s->n > 5000)
+#pragma omp parallel for schedule(static) num_threads(nthr(s->n, 2048))
   for (int i = 0; i < s->n_u; ++i) {
     double t = 0; int64_t b = s->rowptr[i] + s->psplit[i], e = s->rowptr[i + 1];
     for (int64_t k = b; k < e; ++k) t += s->A[k] * xp[s->col[k] - s->n_u];
@@ -491,7 +502,7 @@ static void spmv_up(const orc_system *s, const double *xp, double *y) {
 }
 /* y_p = M_pp x_p */
 static void spmv_mpp(const orc_system *s, const double *xp, double *y) {
-#pragma omp parallel for schedule(static) if (s->n > 5000)
+#pragma omp parallel for schedule(static) num_threads(nthr(s->n, 2048))
   for (int i = 0; i < s->n_p; ++i) {
     int r = s->n_u + i; double t = 0; int64_t b = s->rowptr[r] + s->psplit[r], e = s->rowptr[r + 1];
     for (int64_t k = b; k < e; ++k) t += s->M[k] * xp[s->col[k] - s->n_u];
@@ -499,7 +510,7 @@ static void spmv_mpp(const orc_system *s, const double *xp, double *y) {
   }
 }
 static void spmv_schur(const orc_system *s, const double *xp, double *y) {
-#pragma omp parallel for schedule(static) if (s->n > 5000)
+#pragma omp parallel for schedule(static) num_threads(nthr(s->n, 2048))
   for (int i = 0; i < s->n_p; ++i) {
     double t = 0;
     for (int64_t k = s->s_rowptr[i]; k < s->s_rowptr[i + 1]; ++k) t += s->s_val[k] * xp[s->s_col[k]];
@@ -579,7 +590,7 @@ void orc_schur_csr(const orc_system *s, const int64_t **rowptr, const int32_t **
 /* right-preconditioned restarted GMRES on A_uu with node-block Jacobi: built-in stand-in for MUMPS */
 static void bj_apply(const orc_system *s, const double *x, double *y) {
   int dim = s->m.dim;
-#pragma omp parallel for if (s->n_u > 20000)
+#pragma omp parallel for num_threads(nthr(s->n_u, 32768))
   for (int nd_ = 0; nd_ < s->m.n_unodes; ++nd_)
     for (int a = 0; a < dim; ++a) {
       double t = 0;
@@ -711,7 +722,7 @@ void orc_precond_vmult(orc_system *s, const orc_params *p, const orc_opts *o, or
 int32_t orc_ins_solve(orc_system *s, const orc_params *P, int32_t use_nonzero, const orc_opts *o, orc_ainv_fn ainv,
                       void *user, double *newton_update, int32_t *iters, double *res) {
 #ifdef _OPENMP
-  if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
+  if (o->n_threads > 0) { omp_set_num_threads(o->n_threads); g_max_threads = o->n_threads; }
 #endif
   pc_ctx c; memset(&c, 0, sizeof(c));
   c.s = s; c.P = P; c.o = o; c.ainv = ainv; c.user = user; c.refresh = 1;
@@ -737,7 +748,7 @@ int32_t orc_ins_run_one_step(orc_system *s, const orc_params *P, int32_t apply_n
                              int32_t newton_maxit, const orc_opts *o, orc_ainv_fn ainv, void *user, double *present,
                              const double *fsi_acc, double *log) {
 #ifdef _OPENMP
-  if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
+  if (o->n_threads > 0) { omp_set_num_threads(o->n_threads); g_max_threads = o->n_threads; }
 #endif
   const int n = s->n;
   double *evalp = (double *)malloc(sizeof(double) * (size_t)n), *upd = (double *)malloc(sizeof(double) * (size_t)n);

@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 rocpd database (--kernel-trace --stats [--pmc ...]) into small CSVs for profiles/.
+
+    python tools/rocpd_summary.py <results.db> <out_prefix>
+writes <out_prefix>_kernel_stats.csv (calls, total/avg duration per kernel) and, when counters were collected,
+<out_prefix>_pmc.csv (per kernel: dispatches, mean counter value per dispatch).
+"""
+import csv
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", name)
+    return name if len(name) < 160 else name[:157] + "..."
+
+
+def main(db_path, prefix):
+    db = sqlite3.connect(db_path)
+    cur = db.cursor()
+    rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
+        for name, calls, tot, avg, pct in rows:
+            w.writerow([short(name), calls, f"{tot / 1e3:.3f}", f"{avg / 1e3:.3f}", f"{pct:.2f}"])
+    try:
+        q = ("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
+             "group by kernel_name, counter_name")
+        prow = list(cur.execute(q))
+    except sqlite3.Error as e:
+        prow = []
+        print("no counters:", e)
+    if prow:
+        with open(prefix + "_pmc.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch", "sum"])
+            for name, ctr, n, mean, tot in prow:
+                w.writerow([short(name), ctr, n, f"{mean:.6g}", f"{tot:.6g}"])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
