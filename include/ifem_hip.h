@@ -67,6 +67,8 @@ typedef struct {
                                    n_unodes_owned + [recv_u_ptr[k], recv_u_ptr[k+1]) */
   const int32_t *send_p_ptr, *send_p_idx, *recv_p_ptr; /* same for pressure nodes */
   const uint8_t *nccl_unique_id; /* 128 bytes from ifem_comm_unique_id(), identical on all ranks */
+  void *local_world;             /* NULL for RCCL.  Validation transport: a handle from ifem_local_world_create()
+                                    shared by several contexts (virtual ranks, one host thread each) of ONE process */
 } ifem_partition;
 
 /* Parameters::AllParameters subset used by InsIM::assemble (mpi_insim.cpp:157-161,240,272; parameters.cpp) */
@@ -118,6 +120,9 @@ int ifem_device_count(void);
 void ifem_default_solver_opts(ifem_solver_opts *o);
 /* RCCL bootstrap: rank 0 calls this and ships the 128 bytes to the other ranks by any channel */
 int ifem_comm_unique_id(uint8_t out[128]);
+/* validation transport (see ifem_partition::local_world): nranks contexts of one process on one GPU */
+void *ifem_local_world_create(int nranks);
+void ifem_local_world_destroy(void *world);
 
 /* FluidSolver::initialize_system (mpi_fluid_solver.cpp:305-365, mpi_insim.cpp:143-150): builds the block
  * sparsity (A_uu as dim x dim BSR, B, B^T, M_p, S_m) on the device, scatter maps, halo plans and vectors. */

@@ -26,7 +26,7 @@ class Partition(C.Structure):
     _fields_ = [("rank", C.c_int32), ("nranks", C.c_int32), ("n_neighbors", C.c_int32),
                 ("neighbor_rank", C.c_void_p), ("send_u_ptr", C.c_void_p), ("send_u_idx", C.c_void_p),
                 ("recv_u_ptr", C.c_void_p), ("send_p_ptr", C.c_void_p), ("send_p_idx", C.c_void_p),
-                ("recv_p_ptr", C.c_void_p), ("nccl_unique_id", C.c_void_p)]
+                ("recv_p_ptr", C.c_void_p), ("nccl_unique_id", C.c_void_p), ("local_world", C.c_void_p)]
 
 
 class InsParams(C.Structure):
@@ -56,6 +56,7 @@ class Timing(C.Structure):
 
 
 EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "ifem_comm_unique_id",
+           "ifem_local_world_create", "ifem_local_world_destroy",
            "ifem_ctx_create", "ifem_ctx_destroy", "ifem_n_local_dofs", "ifem_nnz", "ifem_set_constraints",
            "ifem_set_cell_fields", "ifem_vec_set", "ifem_vec_get", "ifem_vec_copy", "ifem_vec_zero", "ifem_vec_axpy",
            "ifem_vec_norm2", "ifem_vec_minmax", "ifem_halo_exchange", "ifem_ins_assemble", "ifem_solve",
@@ -107,6 +108,9 @@ def load():
     L.ifem_export_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifem_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.ifem_comm_unique_id.argtypes = [C.c_void_p]
+    L.ifem_local_world_create.restype = C.c_void_p
+    L.ifem_local_world_create.argtypes = [C.c_int]
+    L.ifem_local_world_destroy.argtypes = [C.c_void_p]
     L.ifem_set_profiling.argtypes = [C.c_void_p, C.c_int]
     _lib = L
     return L

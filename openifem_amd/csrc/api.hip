@@ -70,6 +70,11 @@ int ifem_ctx_create(const ifem_mesh_desc *m, const ifem_partition *part, int dev
   IFEM_HIP_CHECK(hipHostMalloc((void **)&ctx->h_scal, 256 * sizeof(double)));
   ctx->scal.alloc(256);
   comm_init(ctx, part);
+  {
+    double g[2] = {double(ctx->dim * ctx->nUo), double(ctx->nPo)};
+    allreduce_sum(ctx, g, 2);
+    ctx->n_global_u = (int64_t)g[0]; ctx->n_global_p = (int64_t)g[1];
+  }
   // block sparsity + scatter maps (make_sparsity_pattern / matrix.reinit, mpi_fluid_solver.cpp:311-322)
   build_pattern(ctx, ctx->Auu, dim * dim, ctx->nUo, nu, ctx->cell_unodes.p, nu, ctx->cell_unodes.p, ctx->posUU);
   build_pattern(ctx, ctx->Bt, dim, ctx->nUo, nu, ctx->cell_unodes.p, np, ctx->cell_pnodes.p, ctx->posUP);
@@ -366,5 +371,7 @@ int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t) {
 int ifem_set_profiling(ifem_ctx *ctx, int on) { ctx->profile = on != 0; return IFEM_OK; }
 
 int ifem_comm_unique_id(uint8_t out[128]) { return ifem::comm_unique_id(out); }
+void *ifem_local_world_create(int nranks) { return ifem::local_world_create(nranks); }
+void ifem_local_world_destroy(void *w) { ifem::local_world_destroy(w); }
 
 } // extern "C"

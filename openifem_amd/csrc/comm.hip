@@ -1,11 +1,19 @@
-// comm.hip -- the two collectives of the fluid step over RCCL / xGMI:
+// comm.hip -- the two collectives of the fluid step:
 //   halo exchange of a DoF vector   (PETSc VecScatter in MatMult and ghosted-vector assignment)
 //   all-reduce of a few scalars     (l2_norm(), Krylov dot products)
-// Point-to-point ncclSend/ncclRecv grouped per exchange: one message per neighbour = one per xGMI link for
-// an octant partition.  Single-rank runs never touch RCCL.
+// Transport 1 (product): RCCL over xGMI, one process per GPU.  Point-to-point ncclSend/ncclRecv grouped per
+// exchange: one message per neighbour = one per xGMI link for an octant partition.
+// Transport 2 (validation): "local world" -- several contexts (virtual ranks, one host thread each) inside ONE
+// process sharing one GPU; exchanges are device-to-device copies between the contexts, rendezvous by a host
+// barrier.  It exists so that the partitioned algorithm (ownership, ghost layers, halo plans, distributed Krylov)
+// can be validated on a single-GPU box; it shares everything with the RCCL path except the transport calls.
+// Single-rank runs never touch either.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include "ctx.hpp"
 #include "kernels.hpp"
 
@@ -18,6 +26,23 @@ namespace ifem {
       throw ::ifem::Error(IFEM_E_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));                \
   } while (0)
 
+struct LocalWorld {
+  int nranks;
+  std::mutex mu;
+  std::condition_variable cv;
+  int waiting = 0;
+  long generation = 0;
+  std::vector<ifem_ctx *> ctx;           // published contexts
+  std::vector<std::vector<double>> red;  // all-reduce staging
+  explicit LocalWorld(int n) : nranks(n), ctx(n, nullptr), red(n) {}
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const long gen = generation;
+    if (++waiting == nranks) { waiting = 0; ++generation; cv.notify_all(); }
+    else cv.wait(lk, [&] { return generation != gen; });
+  }
+};
+
 void comm_init(ifem_ctx *ctx, const ifem_partition *part) {
   Halo &h = ctx->halo;
   if (!part || part->nranks <= 1) { h.rank = 0; h.nranks = 1; return; }
@@ -28,15 +53,27 @@ void comm_init(ifem_ctx *ctx, const ifem_partition *part) {
   h.recv_u_ptr.assign(part->recv_u_ptr, part->recv_u_ptr + nn + 1);
   h.send_p_ptr.assign(part->send_p_ptr, part->send_p_ptr + nn + 1);
   h.recv_p_ptr.assign(part->recv_p_ptr, part->recv_p_ptr + nn + 1);
+  if (h.recv_u_ptr[nn] != ctx->nUl - ctx->nUo || h.recv_p_ptr[nn] != ctx->nPl - ctx->nPo)
+    throw Error(IFEM_E_BADPARAM, "ifem_partition: receive counts do not match the number of ghost nodes");
   h.send_u_idx.upload(part->send_u_idx, h.send_u_ptr[nn], ctx->stream);
   h.send_p_idx.upload(part->send_p_idx, h.send_p_ptr[nn], ctx->stream);
   h.sendbuf.alloc((size_t)ctx->dim * h.send_u_ptr[nn] + h.send_p_ptr[nn] + 8);
-  ncclUniqueId id;
-  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
-  std::memcpy(&id, part->nccl_unique_id, 128);
-  ncclComm_t comm;
-  IFEM_NCCL_CHECK(ncclCommInitRank(&comm, h.nranks, id, h.rank));
-  h.comm = comm;
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (part->local_world) {
+    auto *w = static_cast<LocalWorld *>(part->local_world);
+    if (w->nranks != h.nranks) throw Error(IFEM_E_BADPARAM, "local world size mismatch");
+    h.local = w;
+    w->ctx[h.rank] = ctx;
+    w->barrier();
+  } else {
+    if (!part->nccl_unique_id) throw Error(IFEM_E_BADPARAM, "ifem_partition needs nccl_unique_id or local_world");
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    std::memcpy(&id, part->nccl_unique_id, 128);
+    ncclComm_t comm;
+    IFEM_NCCL_CHECK(ncclCommInitRank(&comm, h.nranks, id, h.rank));
+    h.comm = comm;
+  }
 }
 
 void comm_destroy(ifem_ctx *ctx) {
@@ -53,14 +90,42 @@ __global__ void k_pack(int64_t n, int bs, const int32_t *__restrict__ idx, const
   }
 }
 
-static void exchange(ifem_ctx *ctx, double *x, int bs, int64_t n_owned, const std::vector<int32_t> &sptr,
-                     const DBuf<int32_t> &sidx, const std::vector<int32_t> &rptr, double *sendbuf) {
+// which: 0 = velocity nodes (bs = dim), 1 = pressure nodes (bs = 1)
+static void exchange(ifem_ctx *ctx, double *x, int which) {
   Halo &h = ctx->halo;
+  const int bs = which == 0 ? ctx->dim : 1;
+  const int64_t n_owned = which == 0 ? ctx->nUo : ctx->nPo;
+  const std::vector<int32_t> &sptr = which == 0 ? h.send_u_ptr : h.send_p_ptr;
+  const std::vector<int32_t> &rptr = which == 0 ? h.recv_u_ptr : h.recv_p_ptr;
+  const DBuf<int32_t> &sidx = which == 0 ? h.send_u_idx : h.send_p_idx;
+  auto sendbuf_of = [&](ifem_ctx *c) { return c->halo.sendbuf.p + (which == 0 ? 0 : (size_t)c->dim * c->halo.send_u_ptr.back()); };
+  double *sendbuf = sendbuf_of(ctx);
   const int nn = (int)h.nbr.size();
   const int64_t ns = sptr[nn];
   if (ns) {
     int64_t g = (ns * bs + 255) / 256;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, ctx->stream, ns, bs, sidx.p, x, sendbuf);
+  }
+  if (h.local) {
+    auto *w = static_cast<LocalWorld *>(h.local);
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // my send buffer is complete
+    w->barrier();
+    for (int k = 0; k < nn; ++k) {
+      const int64_t rc = int64_t(rptr[k + 1] - rptr[k]) * bs;
+      if (!rc) continue;
+      ifem_ctx *peer = w->ctx[h.nbr[k]];
+      const Halo &ph = peer->halo;
+      int me = -1;
+      for (size_t j = 0; j < ph.nbr.size(); ++j) if (ph.nbr[j] == h.rank) me = (int)j;
+      if (me < 0) throw Error(IFEM_E_COMM, "local world: neighbour lists are not symmetric");
+      const std::vector<int32_t> &psptr = which == 0 ? ph.send_u_ptr : ph.send_p_ptr;
+      if (int64_t(psptr[me + 1] - psptr[me]) * bs != rc) throw Error(IFEM_E_COMM, "local world: send/recv count mismatch");
+      IFEM_HIP_CHECK(hipMemcpyAsync(x + (n_owned + rptr[k]) * bs, sendbuf_of(peer) + int64_t(psptr[me]) * bs,
+                                    rc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    w->barrier(); // peers may now overwrite their send buffers
+    return;
   }
   IFEM_NCCL_CHECK(ncclGroupStart());
   for (int k = 0; k < nn; ++k) {
@@ -73,14 +138,12 @@ static void exchange(ifem_ctx *ctx, double *x, int bs, int64_t n_owned, const st
 
 void halo_exchange(ifem_ctx *ctx, double *xu_ext) {
   if (ctx->halo.nranks == 1) return;
-  exchange(ctx, xu_ext, ctx->dim, ctx->nUo, ctx->halo.send_u_ptr, ctx->halo.send_u_idx, ctx->halo.recv_u_ptr,
-           ctx->halo.sendbuf.p);
+  exchange(ctx, xu_ext, 0);
 }
 
 void halo_exchange_p(ifem_ctx *ctx, double *xp_ext) {
   if (ctx->halo.nranks == 1) return;
-  exchange(ctx, xp_ext, 1, ctx->nPo, ctx->halo.send_p_ptr, ctx->halo.send_p_idx, ctx->halo.recv_p_ptr,
-           ctx->halo.sendbuf.p + (size_t)ctx->dim * ctx->halo.send_u_ptr.back());
+  exchange(ctx, xp_ext, 1);
 }
 
 int comm_unique_id(uint8_t out[128]) {
@@ -90,20 +153,34 @@ int comm_unique_id(uint8_t out[128]) {
   return IFEM_OK;
 }
 
-static void allreduce(ifem_ctx *ctx, double *host_vals, int n, ncclRedOp_t op);
-void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, host_vals, n, ncclSum); }
-void allreduce_max(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, host_vals, n, ncclMax); }
-
-static void allreduce(ifem_ctx *ctx, double *host_vals, int n, ncclRedOp_t op) {
-  if (ctx->halo.nranks == 1) return;
+static void allreduce(ifem_ctx *ctx, double *host_vals, int n, bool is_max) {
+  Halo &h = ctx->halo;
+  if (h.nranks == 1) return;
+  if (h.local) {
+    auto *w = static_cast<LocalWorld *>(h.local);
+    w->red[h.rank].assign(host_vals, host_vals + n);
+    w->barrier();
+    std::vector<double> out(w->red[0]);
+    for (int r = 1; r < h.nranks; ++r)
+      for (int i = 0; i < n; ++i) out[i] = is_max ? std::max(out[i], w->red[r][i]) : out[i] + w->red[r][i];
+    w->barrier(); // everybody has read the staging slots
+    std::memcpy(host_vals, out.data(), n * sizeof(double));
+    return;
+  }
   hipStream_t s = ctx->stream;
   double *d = ctx->scal.p + 128;
   std::memcpy(ctx->h_scal + 128, host_vals, n * sizeof(double));
   IFEM_HIP_CHECK(hipMemcpyAsync(d, ctx->h_scal + 128, n * sizeof(double), hipMemcpyHostToDevice, s));
-  IFEM_NCCL_CHECK(ncclAllReduce(d, d, n, ncclDouble, op, (ncclComm_t)ctx->halo.comm, s));
+  IFEM_NCCL_CHECK(ncclAllReduce(d, d, n, ncclDouble, is_max ? ncclMax : ncclSum, (ncclComm_t)h.comm, s));
   IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal + 128, d, n * sizeof(double), hipMemcpyDeviceToHost, s));
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
   std::memcpy(host_vals, ctx->h_scal + 128, n * sizeof(double));
 }
+
+void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, host_vals, n, false); }
+void allreduce_max(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, host_vals, n, true); }
+
+void *local_world_create(int nranks) { return new LocalWorld(nranks); }
+void local_world_destroy(void *w) { delete static_cast<LocalWorld *>(w); }
 
 } // namespace ifem

@@ -88,7 +88,8 @@ struct Halo {
   std::vector<int32_t> send_u_ptr, recv_u_ptr, send_p_ptr, recv_p_ptr;
   DBuf<int32_t> send_u_idx, send_p_idx;
   DBuf<double> sendbuf;
-  void *comm = nullptr; // ncclComm_t
+  void *comm = nullptr;  // ncclComm_t
+  void *local = nullptr; // LocalWorld* (in-process virtual ranks, validation transport)
 };
 
 } // namespace ifem
@@ -100,6 +101,7 @@ struct ifem_ctx {
   int64_t n_cells = 0;
   int64_t nUo = 0, nUl = 0, nPo = 0, nPl = 0; // velocity / pressure nodes owned / local
   int64_t n_local = 0;                        // dim*nUl + nPl
+  int64_t n_global_u = 0, n_global_p = 0;     // owned counts summed over ranks (iteration limits must agree on all ranks)
   ifem::FeTables fe;
   ifem::DBuf<ifem::FeTables> d_fe;
   // mesh

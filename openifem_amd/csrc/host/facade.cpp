@@ -41,12 +41,12 @@ int ifemx_insim_create_box(const char *prm_text, int dim, const unsigned *reps, 
     std::vector<unsigned> r(reps, reps + dim);
     if (dim == 2) {
       h->t2.reset(new Triangulation<2>());
-      GridGenerator::subdivided_hyper_rectangle<2>(*h->t2, r, {p0[0], p0[1]}, {p1[0], p1[1]}, true);
+      GridGenerator::subdivided_hyper_rectangle<2>(*h->t2, r, {p0[0], p0[1]}, {p1[0], p1[1]}, true, /*lazy=*/true);
       h->s2.reset(new Fluid::MPI::InsIM<2>(*h->t2, params, device));
       h->s2->pcout = verbose ? &std::cout : nullptr;
     } else {
       h->t3.reset(new Triangulation<3>());
-      GridGenerator::subdivided_hyper_rectangle<3>(*h->t3, r, {p0[0], p0[1], p0[2]}, {p1[0], p1[1], p1[2]}, true);
+      GridGenerator::subdivided_hyper_rectangle<3>(*h->t3, r, {p0[0], p0[1], p0[2]}, {p1[0], p1[1], p1[2]}, true, /*lazy=*/true);
       h->s3.reset(new Fluid::MPI::InsIM<3>(*h->t3, params, device));
       h->s3->pcout = verbose ? &std::cout : nullptr;
     }
@@ -55,6 +55,46 @@ int ifemx_insim_create_box(const char *prm_text, int dim, const unsigned *reps, 
 }
 
 void ifemx_destroy(void *hv) { delete static_cast<Handle *>(hv); }
+
+// rank `rank` of a P[0] x P[1] x P[2] block partition; call before ifemx_setup.  Transport: nccl_unique_id (128 B)
+// or local_world (ifem_local_world_create), the other NULL.
+int ifemx_set_partition(void *hv, const int *P, int rank, const uint8_t *nccl_unique_id, void *local_world) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    std::array<int, 3> p{P[0], P[1], P[2]};
+    if (h->dim == 2) h->s2->set_partition(p, rank, nccl_unique_id, local_world);
+    else h->s3->set_partition(p, rank, nccl_unique_id, local_world);
+  });
+}
+// sizes of the partition tables: [n_unodes_owned, n_unodes_local, n_pnodes_owned, n_pnodes_local, n_neighbors,
+//  n_send_u, n_send_p, n_unodes_global, n_pnodes_global, n_cells_local]
+int ifemx_partition_sizes(void *hv, int64_t *out) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto fill = [&](auto &s) {
+      auto &d = s.dof_tables(); auto &p = s.partition();
+      out[0] = d.n_unodes_owned; out[1] = d.n_unodes; out[2] = d.n_pnodes_owned; out[3] = d.n_pnodes;
+      out[4] = (int64_t)p.neighbors.size(); out[5] = (int64_t)p.send_u_idx.size(); out[6] = (int64_t)p.send_p_idx.size();
+      out[7] = p.n_unodes_global; out[8] = p.n_pnodes_global; out[9] = (int64_t)(d.cell_unodes.size() / d.nu);
+    };
+    if (h->dim == 2) fill(*h->s2); else fill(*h->s3);
+  });
+}
+int ifemx_partition_tables(void *hv, int64_t *l2g_u, int64_t *l2g_p, int32_t *neighbors, int32_t *send_u_ptr,
+                           int32_t *send_u_idx, int32_t *recv_u_ptr, int32_t *send_p_ptr, int32_t *send_p_idx,
+                           int32_t *recv_p_ptr) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto fill = [&](auto &s) {
+      auto &p = s.partition();
+      auto cp = [](auto &v, auto *dst) { if (!v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+      cp(p.l2g_u, l2g_u); cp(p.l2g_p, l2g_p); cp(p.neighbors, neighbors);
+      cp(p.send_u_ptr, send_u_ptr); cp(p.send_u_idx, send_u_idx); cp(p.recv_u_ptr, recv_u_ptr);
+      cp(p.send_p_ptr, send_p_ptr); cp(p.send_p_idx, send_p_idx); cp(p.recv_p_ptr, recv_p_ptr);
+    };
+    if (h->dim == 2) fill(*h->s2); else fill(*h->s3);
+  });
+}
 
 #define DISPATCH(h, expr2, expr3) (static_cast<Handle *>(h)->dim == 2 ? (expr2) : (expr3))
 
@@ -114,8 +154,8 @@ ifem_ctx *ifemx_ctx(void *hv) {
 int ifemx_sizes(void *hv, int64_t *n_cells, int64_t *n_u, int64_t *n_p) {
   auto *h = static_cast<Handle *>(hv);
   return guard([&] {
-    if (h->dim == 2) { *n_cells = (int64_t)h->t2->n_active_cells(); *n_u = h->s2->dof_tables().n_u(); *n_p = h->s2->dof_tables().n_pnodes; }
-    else { *n_cells = (int64_t)h->t3->n_active_cells(); *n_u = h->s3->dof_tables().n_u(); *n_p = h->s3->dof_tables().n_pnodes; }
+    if (h->dim == 2) { auto &d = h->s2->dof_tables(); *n_cells = (int64_t)(d.cell_unodes.size() / d.nu); *n_u = d.n_u(); *n_p = d.n_pnodes; }
+    else { auto &d = h->s3->dof_tables(); *n_cells = (int64_t)(d.cell_unodes.size() / d.nu); *n_u = d.n_u(); *n_p = d.n_pnodes; }
   });
 }
 int ifemx_get_solution(void *hv, double *out) {
@@ -172,10 +212,17 @@ int ifemx_channel_state(void *hv, double L, double H, double dP, double mu, uint
       }
       for (int64_t nd = 0; nd < d.n_pnodes; ++nd) present[n_u + nd] = dP * (1.0 - d.pnode_coords[nd][0] / L);
       ev = present;
-      std::mt19937_64 gen(seed);
-      std::uniform_real_distribution<double> U(-1.0, 1.0);
-      for (int64_t i = 0; i < n_u; ++i) ev[i] += rel * umax * U(gen);
-      for (int64_t i = n_u; i < n; ++i) ev[i] += rel * dP * U(gen);
+      // perturbation keyed by the GLOBAL dof so that every partition of the mesh sees the same field:
+      // one mt19937_64(seed) draw sequence would depend on the local numbering
+      auto &pt = solver.partition();
+      auto unit = [&](uint64_t key) {
+        std::mt19937_64 gen(seed ^ (key * 0x9E3779B97F4A7C15ull));
+        gen.discard(1);
+        return std::uniform_real_distribution<double>(-1.0, 1.0)(gen);
+      };
+      for (int64_t nd = 0; nd < d.n_unodes; ++nd)
+        for (int c = 0; c < D; ++c) ev[nd * D + c] += rel * umax * unit((uint64_t)pt.l2g_u[nd] * D + c);
+      for (int64_t nd = 0; nd < d.n_pnodes; ++nd) ev[n_u + nd] += rel * dP * unit((uint64_t)(D * pt.n_unodes_global + pt.l2g_p[nd]));
       // constrained dofs keep the boundary values
       std::vector<int32_t> cd; std::vector<double> cv;
       solver.constraint_lines(cd, cv);

@@ -8,13 +8,17 @@ namespace ifem_host {
 namespace GridGenerator {
 template <int dim>
 void subdivided_hyper_rectangle(Triangulation<dim> &tria, const std::vector<unsigned> &repetitions,
-                                const std::array<double, dim> &p0, const std::array<double, dim> &p1, bool colorize) {
+                                const std::array<double, dim> &p0, const std::array<double, dim> &p1, bool colorize,
+                                bool lazy) {
   if ((int)repetitions.size() != dim) throw std::invalid_argument("subdivided_hyper_rectangle: repetitions size");
   std::array<int, 3> r{1, 1, 1};
   for (int d = 0; d < dim; ++d) r[d] = (int)repetitions[d];
   tria.is_box = true;
+  tria.colorized = colorize;
   tria.reps = r;
   for (int d = 0; d < dim; ++d) { tria.p0[d] = p0[d]; tria.p1[d] = p1[d]; }
+  tria.vertices.clear(); tria.cells.clear(); tria.face_bid.clear();
+  if (lazy) return;
   const int nvx = r[0] + 1, nvy = r[1] + 1, nvz = (dim == 3) ? r[2] + 1 : 1;
   tria.vertices.resize((size_t)nvx * nvy * nvz);
   for (int k = 0; k < nvz; ++k)
@@ -45,9 +49,9 @@ void subdivided_hyper_rectangle(Triangulation<dim> &tria, const std::vector<unsi
       }
 }
 template void subdivided_hyper_rectangle<2>(Triangulation<2> &, const std::vector<unsigned> &, const std::array<double, 2> &,
-                                            const std::array<double, 2> &, bool);
+                                            const std::array<double, 2> &, bool, bool);
 template void subdivided_hyper_rectangle<3>(Triangulation<3> &, const std::vector<unsigned> &, const std::array<double, 3> &,
-                                            const std::array<double, 3> &, bool);
+                                            const std::array<double, 3> &, bool, bool);
 } // namespace GridGenerator
 
 template <int dim>
@@ -59,9 +63,7 @@ void Triangulation<dim>::refine_global(int times) {
   std::array<double, dim> a, b;
   for (int d = 0; d < dim; ++d) { a[d] = p0[d]; b[d] = p1[d]; }
   // colorised ids survive refinement (children inherit the face's boundary id)
-  bool colorize = false;
-  for (auto &f : face_bid) for (int k = 0; k < 2 * dim; ++k) if (f[k] > 0) colorize = true;
-  GridGenerator::subdivided_hyper_rectangle<dim>(*this, r, a, b, colorize);
+  GridGenerator::subdivided_hyper_rectangle<dim>(*this, r, a, b, colorized, cells.empty());
 }
 template struct Triangulation<2>;
 template struct Triangulation<3>;
@@ -76,71 +78,207 @@ static void map_point(const double *X /*[NV][dim]*/, const double *xi, double *o
   }
 }
 
+// one lattice (velocity nodes with k = kv, pressure nodes with k = 1) of the partitioned box
+struct Lattice {
+  int k;
+  int64_t N[3];        // global nodes per direction
+  int64_t lo[3], hi[3]; // local box (inclusive)
+  int64_t ln[3];        // local box extents
+  std::vector<int32_t> local_id; // local box position -> local node id
+  int64_t gid(const int64_t *g) const { return (g[2] * N[1] + g[1]) * N[0] + g[0]; }
+  int64_t lpos(const int64_t *g) const { return ((g[2] - lo[2]) * ln[1] + (g[1] - lo[1])) * ln[0] + (g[0] - lo[0]); }
+};
+
+static int owner_block(int64_t g, int k, int n, int P) {
+  if (g == 0) return 0;
+  const int64_t b = (g - 1) / (int64_t(k) * n);
+  return int(b < P ? b : P - 1);
+}
+
 template <int dim>
-void distribute_dofs(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out) {
+void distribute_dofs_box(const std::array<int, 3> &reps, const std::array<double, 3> &p0, const std::array<double, 3> &p1,
+                         bool colorize, int kv, const std::array<int, 3> &P, int rank, DoFTables<dim> &out,
+                         PartitionTables &part) {
   constexpr int NV = 1 << dim;
   const int n1 = kv + 1;
   int nu = 1;
   for (int d = 0; d < dim; ++d) nu *= n1;
-  const size_t nc = tria.cells.size();
+  int G[3] = {1, 1, 1}, Pd[3] = {1, 1, 1}, n[3] = {1, 1, 1}, b[3] = {0, 0, 0};
+  for (int d = 0; d < dim; ++d) {
+    G[d] = reps[d]; Pd[d] = P[d];
+    if (Pd[d] < 1 || G[d] % Pd[d] != 0) throw std::invalid_argument("box partition: repetitions must be divisible by the process grid");
+    n[d] = G[d] / Pd[d];
+  }
+  for (int d = dim; d < 3; ++d) if (P[d] != 1) throw std::invalid_argument("box partition: process grid exceeds the dimension");
+  const int nranks = Pd[0] * Pd[1] * Pd[2];
+  if (rank < 0 || rank >= nranks) throw std::invalid_argument("box partition: bad rank");
+  b[0] = rank % Pd[0]; b[1] = (rank / Pd[0]) % Pd[1]; b[2] = rank / (Pd[0] * Pd[1]);
+  auto rank_of = [&](const int *bb) { return (bb[2] * Pd[1] + bb[1]) * Pd[0] + bb[0]; };
+  auto cell_range = [&](const int *bb, int d, int &c0, int &c1) {
+    if (d >= dim) { c0 = 0; c1 = 1; return; }
+    c0 = bb[d] * n[d];
+    c1 = std::min((bb[d] + 1) * n[d] + 1, G[d]);
+  };
+  auto make_lattice = [&](int k, const int *bb, Lattice &L) {
+    L.k = k;
+    for (int d = 0; d < 3; ++d) {
+      int c0, c1;
+      cell_range(bb, d, c0, c1);
+      L.N[d] = (d < dim) ? int64_t(k) * G[d] + 1 : 1;
+      L.lo[d] = (d < dim) ? int64_t(k) * c0 : 0;
+      L.hi[d] = (d < dim) ? int64_t(k) * c1 : 0;
+      L.ln[d] = L.hi[d] - L.lo[d] + 1;
+    }
+  };
+  auto owner_of = [&](int k, const int64_t *g) {
+    int ob[3] = {0, 0, 0};
+    for (int d = 0; d < dim; ++d) ob[d] = owner_block(g[d], k, n[d], Pd[d]);
+    return rank_of(ob);
+  };
+
+  part.rank = rank; part.nranks = nranks; part.P = {Pd[0], Pd[1], Pd[2]};
+  part.n_cells_global = int64_t(G[0]) * G[1] * G[2];
+
+  // ---- node numbering of one lattice: owned first (lexicographic), then ghosts grouped by owner rank
+  struct Ghost { int32_t owner; int64_t gid; int64_t lpos; };
+  auto number_lattice = [&](int k, Lattice &L, std::vector<int64_t> &l2g, int64_t &n_owned, std::vector<Ghost> &ghosts) {
+    make_lattice(k, b, L);
+    const int64_t nloc = L.ln[0] * L.ln[1] * L.ln[2];
+    L.local_id.assign((size_t)nloc, -1);
+    l2g.clear(); ghosts.clear();
+    int64_t g[3];
+    for (g[2] = L.lo[2]; g[2] <= L.hi[2]; ++g[2])
+      for (g[1] = L.lo[1]; g[1] <= L.hi[1]; ++g[1])
+        for (g[0] = L.lo[0]; g[0] <= L.hi[0]; ++g[0]) {
+          const int ow = owner_of(k, g);
+          if (ow == rank) { L.local_id[(size_t)L.lpos(g)] = (int32_t)l2g.size(); l2g.push_back(L.gid(g)); }
+          else ghosts.push_back({(int32_t)ow, L.gid(g), L.lpos(g)});
+        }
+    n_owned = (int64_t)l2g.size();
+    std::stable_sort(ghosts.begin(), ghosts.end(), [](const Ghost &a, const Ghost &c) { return a.owner != c.owner ? a.owner < c.owner : a.gid < c.gid; });
+    for (auto &gh : ghosts) { L.local_id[(size_t)gh.lpos] = (int32_t)l2g.size(); l2g.push_back(gh.gid); }
+  };
+  Lattice LU, LP;
+  std::vector<Ghost> gu, gp;
+  number_lattice(kv, LU, part.l2g_u, out.n_unodes_owned, gu);
+  number_lattice(1, LP, part.l2g_p, out.n_pnodes_owned, gp);
+  out.n_unodes = (int64_t)part.l2g_u.size();
+  out.n_pnodes = (int64_t)part.l2g_p.size();
+  part.n_unodes_global = LU.N[0] * LU.N[1] * LU.N[2];
+  part.n_pnodes_global = LP.N[0] * LP.N[1] * LP.N[2];
+
+  // ---- halo plans: neighbours are the adjacent blocks; both sides enumerate the shared nodes in global order
+  part.neighbors.clear();
+  std::vector<std::vector<int32_t>> send_u, send_p;
+  std::vector<int32_t> recv_u_cnt, recv_p_cnt;
+  for (int dz = -1; dz <= 1; ++dz)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        if (!dx && !dy && !dz) continue;
+        int bb[3] = {b[0] + dx, b[1] + dy, b[2] + dz};
+        bool ok = true;
+        for (int d = 0; d < 3; ++d) if (bb[d] < 0 || bb[d] >= Pd[d]) ok = false;
+        if (!ok) continue;
+        const int s = rank_of(bb);
+        auto sends_to = [&](int k, const Lattice &mine) {
+          Lattice Ls;
+          make_lattice(k, bb, Ls);
+          std::vector<int32_t> idx;
+          int64_t g[3];
+          for (g[2] = Ls.lo[2]; g[2] <= Ls.hi[2]; ++g[2])
+            for (g[1] = Ls.lo[1]; g[1] <= Ls.hi[1]; ++g[1])
+              for (g[0] = Ls.lo[0]; g[0] <= Ls.hi[0]; ++g[0])
+                if (owner_of(k, g) == rank) idx.push_back(mine.local_id[(size_t)mine.lpos(g)]);
+          return idx;
+        };
+        std::vector<int32_t> su = sends_to(kv, LU), sp = sends_to(1, LP);
+        int32_t ru = 0, rp = 0;
+        for (auto &gh : gu) if (gh.owner == s) ++ru;
+        for (auto &gh : gp) if (gh.owner == s) ++rp;
+        if (su.empty() && sp.empty() && !ru && !rp) continue;
+        part.neighbors.push_back(s);
+        send_u.push_back(su); send_p.push_back(sp);
+        recv_u_cnt.push_back(ru); recv_p_cnt.push_back(rp);
+      }
+  // sort neighbours by rank (ghosts are grouped by ascending owner rank)
+  std::vector<int> order(part.neighbors.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int a, int c) { return part.neighbors[a] < part.neighbors[c]; });
+  std::vector<int32_t> nb;
+  part.send_u_ptr = {0}; part.recv_u_ptr = {0}; part.send_p_ptr = {0}; part.recv_p_ptr = {0};
+  part.send_u_idx.clear(); part.send_p_idx.clear();
+  for (int o : order) {
+    nb.push_back(part.neighbors[o]);
+    part.send_u_idx.insert(part.send_u_idx.end(), send_u[o].begin(), send_u[o].end());
+    part.send_p_idx.insert(part.send_p_idx.end(), send_p[o].begin(), send_p[o].end());
+    part.send_u_ptr.push_back((int32_t)part.send_u_idx.size());
+    part.send_p_ptr.push_back((int32_t)part.send_p_idx.size());
+    part.recv_u_ptr.push_back(part.recv_u_ptr.back() + recv_u_cnt[o]);
+    part.recv_p_ptr.push_back(part.recv_p_ptr.back() + recv_p_cnt[o]);
+  }
+  part.neighbors = nb;
+  if (part.recv_u_ptr.back() != out.n_unodes - out.n_unodes_owned || part.recv_p_ptr.back() != out.n_pnodes - out.n_pnodes_owned)
+    throw std::logic_error("box partition: a ghost node has a non-adjacent owner");
+
+  // ---- local cells (lexicographic over the local cell box)
+  int c0[3], c1[3];
+  for (int d = 0; d < 3; ++d) cell_range(b, d, c0[d], c1[d]);
+  const size_t nc = size_t(c1[0] - c0[0]) * (c1[1] - c0[1]) * (c1[2] - c0[2]);
   out.kv = kv; out.nu = nu; out.np = NV;
   out.vcoords.resize(nc * NV * dim);
   out.cell_face_bid.resize(nc * 2 * dim);
-  for (size_t c = 0; c < nc; ++c) {
-    for (int v = 0; v < NV; ++v)
-      for (int d = 0; d < dim; ++d) out.vcoords[(c * NV + v) * dim + d] = tria.vertices[tria.cells[c][v]][d];
-    for (int f = 0; f < 2 * dim; ++f) out.cell_face_bid[c * 2 * dim + f] = tria.face_bid[c][f];
-  }
   out.cell_unodes.resize(nc * nu);
   out.cell_pnodes.resize(nc * NV);
-  if (tria.is_box) {
-    // lattice numbering, x fastest
-    const auto &r = tria.reps;
-    const int64_t nux = kv * r[0] + 1, nuy = kv * r[1] + 1, nuz = (dim == 3) ? kv * r[2] + 1 : 1;
-    const int64_t npx = r[0] + 1, npy = r[1] + 1, npz = (dim == 3) ? r[2] + 1 : 1;
-    out.n_unodes = nux * nuy * nuz;
-    out.n_pnodes = npx * npy * npz;
-    const int rz = (dim == 3) ? r[2] : 1;
-    for (int k = 0; k < rz; ++k)
-      for (int j = 0; j < r[1]; ++j)
-        for (int i = 0; i < r[0]; ++i) {
-          const size_t c = ((size_t)k * r[1] + j) * r[0] + i;
-          for (int a = 0; a < nu; ++a) {
-            const int ai = a % n1, aj = (a / n1) % n1, ak = (dim == 3) ? a / (n1 * n1) : 0;
-            out.cell_unodes[c * nu + a] = int32_t(((int64_t)(kv * k + ak) * nuy + (kv * j + aj)) * nux + (kv * i + ai));
-          }
-          for (int v = 0; v < NV; ++v) {
-            const int di = v & 1, dj = (v >> 1) & 1, dk = (v >> 2) & 1;
-            out.cell_pnodes[c * NV + v] = int32_t(((int64_t)(k + dk) * npy + (j + dj)) * npx + (i + di));
-          }
+  double h[3] = {0, 0, 0};
+  for (int d = 0; d < dim; ++d) h[d] = (p1[d] - p0[d]) / G[d];
+  size_t c = 0;
+  for (int ck = c0[2]; ck < c1[2]; ++ck)
+    for (int cj = c0[1]; cj < c1[1]; ++cj)
+      for (int ci = c0[0]; ci < c1[0]; ++ci, ++c) {
+        const int cc[3] = {ci, cj, ck};
+        for (int v = 0; v < NV; ++v) {
+          int64_t g[3] = {ci + (v & 1), cj + ((v >> 1) & 1), (dim == 3) ? ck + ((v >> 2) & 1) : 0};
+          for (int d = 0; d < dim; ++d) out.vcoords[(c * NV + v) * dim + d] = p0[d] + g[d] * h[d];
+          out.cell_pnodes[c * NV + v] = LP.local_id[(size_t)LP.lpos(g)];
         }
-  } else {
-    throw std::runtime_error("distribute_dofs: unstructured triangulations are not supported in this build");
-  }
-  // support points
+        for (int a = 0; a < nu; ++a) {
+          const int ai = a % n1, aj = (a / n1) % n1, ak = (dim == 3) ? a / (n1 * n1) : 0;
+          int64_t g[3] = {int64_t(kv) * ci + ai, int64_t(kv) * cj + aj, (dim == 3) ? int64_t(kv) * ck + ak : 0};
+          out.cell_unodes[c * nu + a] = LU.local_id[(size_t)LU.lpos(g)];
+        }
+        for (int d = 0; d < dim; ++d) {
+          out.cell_face_bid[c * 2 * dim + 2 * d] = (cc[d] == 0) ? (colorize ? 2 * d : 0) : -1;
+          out.cell_face_bid[c * 2 * dim + 2 * d + 1] = (cc[d] == G[d] - 1) ? (colorize ? 2 * d + 1 : 0) : -1;
+        }
+      }
+  // ---- support points (lattice points of the box; identical on every rank sharing the node)
   out.unode_coords.assign((size_t)out.n_unodes, {});
   out.pnode_coords.assign((size_t)out.n_pnodes, {});
-  std::vector<uint8_t> done_u((size_t)out.n_unodes, 0);
-  for (size_t c = 0; c < nc; ++c) {
-    const double *X = &out.vcoords[c * NV * dim];
-    for (int a = 0; a < nu; ++a) {
-      const int32_t nd = out.cell_unodes[c * nu + a];
-      if (done_u[nd]) continue;
-      done_u[nd] = 1;
-      double xi[3] = {0, 0, 0};
-      int t = a;
-      for (int d = 0; d < dim; ++d) { xi[d] = double(t % n1) / kv; t /= n1; }
-      map_point<dim>(X, xi, out.unode_coords[nd].data());
-    }
-    for (int v = 0; v < NV; ++v)
-      for (int d = 0; d < dim; ++d) out.pnode_coords[out.cell_pnodes[c * NV + v]][d] = X[v * dim + d];
+  for (int64_t i = 0; i < out.n_unodes; ++i) {
+    int64_t t = part.l2g_u[i];
+    for (int d = 0; d < dim; ++d) { out.unode_coords[i][d] = p0[d] + double(t % LU.N[d]) * (h[d] / kv); t /= LU.N[d]; }
   }
+  for (int64_t i = 0; i < out.n_pnodes; ++i) {
+    int64_t t = part.l2g_p[i];
+    for (int d = 0; d < dim; ++d) { out.pnode_coords[i][d] = p0[d] + double(t % LP.N[d]) * h[d]; t /= LP.N[d]; }
+  }
+}
+template void distribute_dofs_box<2>(const std::array<int, 3> &, const std::array<double, 3> &, const std::array<double, 3> &, bool,
+                                     int, const std::array<int, 3> &, int, DoFTables<2> &, PartitionTables &);
+template void distribute_dofs_box<3>(const std::array<int, 3> &, const std::array<double, 3> &, const std::array<double, 3> &, bool,
+                                     int, const std::array<int, 3> &, int, DoFTables<3> &, PartitionTables &);
+
+template <int dim>
+void distribute_dofs(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out) {
+  if (!tria.is_box) throw std::runtime_error("distribute_dofs: unstructured triangulations are not supported in this build");
+  PartitionTables part;
+  distribute_dofs_box<dim>(tria.reps, tria.p0, tria.p1, tria.colorized, kv, {1, 1, 1}, 0, out, part);
 }
 template void distribute_dofs<2>(const Triangulation<2> &, int, DoFTables<2> &);
 template void distribute_dofs<3>(const Triangulation<3> &, int, DoFTables<3> &);
 
 template <int dim>
-void make_dirichlet(const Triangulation<dim> &tria, const DoFTables<dim> &dofs,
+void make_dirichlet(const DoFTables<dim> &dofs,
                     const std::map<unsigned, std::pair<unsigned, std::vector<double>>> &bcs,
                     const std::map<int, std::function<double(const std::array<double, dim> &, unsigned)>> &hard_coded,
                     std::vector<int32_t> &dof, std::vector<double> &value) {
@@ -159,9 +297,10 @@ void make_dirichlet(const Triangulation<dim> &tria, const DoFTables<dim> &dofs,
     for (int c = 0; c < dim; ++c) if (flag & (1u << c)) comps.push_back(c);
     if (vals.size() < comps.size()) throw std::invalid_argument("Dirichlet boundary values: too few entries");
     auto hc = hard_coded.find(id);
-    for (size_t cell = 0; cell < tria.cells.size(); ++cell)
+    const size_t n_cells = dofs.cell_unodes.size() / nu;
+    for (size_t cell = 0; cell < n_cells; ++cell)
       for (int f = 0; f < 2 * dim; ++f) {
-        if (tria.face_bid[cell][f] != id) continue;
+        if (dofs.cell_face_bid[cell * 2 * dim + f] != id) continue;
         const int nd = f / 2, side = (f % 2) ? kv : 0;
         for (int a = 0; a < nu; ++a) {
           int idx[3] = {a % n1, (a / n1) % n1, (dim == 3) ? a / (n1 * n1) : 0};
@@ -178,11 +317,11 @@ void make_dirichlet(const Triangulation<dim> &tria, const DoFTables<dim> &dofs,
       }
   }
 }
-template void make_dirichlet<2>(const Triangulation<2> &, const DoFTables<2> &,
+template void make_dirichlet<2>(const DoFTables<2> &,
                                 const std::map<unsigned, std::pair<unsigned, std::vector<double>>> &,
                                 const std::map<int, std::function<double(const std::array<double, 2> &, unsigned)>> &,
                                 std::vector<int32_t> &, std::vector<double> &);
-template void make_dirichlet<3>(const Triangulation<3> &, const DoFTables<3> &,
+template void make_dirichlet<3>(const DoFTables<3> &,
                                 const std::map<unsigned, std::pair<unsigned, std::vector<double>>> &,
                                 const std::map<int, std::function<double(const std::array<double, 3> &, unsigned)>> &,
                                 std::vector<int32_t> &, std::vector<double> &);

@@ -23,16 +23,19 @@ struct Triangulation {
   std::vector<std::array<int32_t, 2 * dim>> face_bid;  // boundary id per face x-,x+,y-,y+,z-,z+ ; -1 interior
   // structured provenance (set by subdivided_hyper_rectangle, cleared by anything unstructured)
   bool is_box = false;
+  bool colorized = false;
   std::array<int, 3> reps{1, 1, 1};
   std::array<double, 3> p0{0, 0, 0}, p1{1, 1, 1};
-  size_t n_active_cells() const { return cells.size(); }
+  // box triangulations may be "lazy": only the metadata is kept and cells are generated per rank on demand
+  size_t n_active_cells() const { return is_box ? size_t(reps[0]) * reps[1] * reps[2] : cells.size(); }
   void refine_global(int times);
 };
 
 namespace GridGenerator {
 template <int dim>
 void subdivided_hyper_rectangle(Triangulation<dim> &tria, const std::vector<unsigned> &repetitions,
-                                const std::array<double, dim> &p0, const std::array<double, dim> &p1, bool colorize);
+                                const std::array<double, dim> &p0, const std::array<double, dim> &p1, bool colorize,
+                                bool lazy = false);
 }
 
 // cell -> node tables for FESystem(FE_Q(kv)^dim, FE_Q(1)); local order tensor-lexicographic
@@ -44,9 +47,30 @@ struct DoFTables {
   std::vector<double> vcoords;        // [n_cells][2^dim][dim]
   std::vector<int32_t> cell_face_bid; // [n_cells][2*dim]
   std::vector<std::array<double, dim>> unode_coords, pnode_coords; // support points (d-linear map of the unit lattice)
+  // multi-GPU: nodes [0, n_*_owned) are owned by this rank, the rest are ghosts (grouped by owner rank)
+  int64_t n_unodes_owned = 0, n_pnodes_owned = 0;
   int64_t n_u() const { return dim * n_unodes; }
   int64_t n_dofs() const { return dim * n_unodes + n_pnodes; }
 };
+
+// Block partition of a box mesh over a P[0] x P[1] x P[2] process grid: rank r owns the cells of its
+// lattice block; a node belongs to the lowest rank touching it; every rank also assembles the ghost cell layer on
+// its upper faces so that all cells touching an owned row are local ("owner computes row").
+struct PartitionTables {
+  int rank = 0, nranks = 1;
+  std::array<int, 3> P{1, 1, 1};
+  std::vector<int32_t> neighbors;                        // sorted ranks exchanging halo data with this rank
+  std::vector<int32_t> send_u_ptr, send_u_idx, recv_u_ptr; // ifem_partition layout
+  std::vector<int32_t> send_p_ptr, send_p_idx, recv_p_ptr;
+  std::vector<int64_t> l2g_u, l2g_p;                     // local node -> global lattice id
+  int64_t n_unodes_global = 0, n_pnodes_global = 0, n_cells_global = 0;
+};
+
+// local tables of rank `rank` for the box mesh reps x [p0,p1] without ever building the global mesh
+template <int dim>
+void distribute_dofs_box(const std::array<int, 3> &reps, const std::array<double, 3> &p0, const std::array<double, 3> &p1,
+                         bool colorize, int kv, const std::array<int, 3> &P, int rank, DoFTables<dim> &out,
+                         PartitionTables &part);
 
 template <int dim>
 void distribute_dofs(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out);
@@ -54,7 +78,7 @@ void distribute_dofs(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out
 // Dirichlet lines (dof, value) in block numbering [u|p]; `bcs`: id -> (component flag 1..7, values);
 // `hard_coded`: id -> f(point, component) overriding the constant values (add_hard_coded_boundary_condition).
 template <int dim>
-void make_dirichlet(const Triangulation<dim> &tria, const DoFTables<dim> &dofs,
+void make_dirichlet(const DoFTables<dim> &dofs,
                     const std::map<unsigned, std::pair<unsigned, std::vector<double>>> &bcs,
                     const std::map<int, std::function<double(const std::array<double, dim> &, unsigned)>> &hard_coded,
                     std::vector<int32_t> &dof, std::vector<double> &value);

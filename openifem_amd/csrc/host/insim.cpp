@@ -55,13 +55,24 @@ void FluidSolver<dim>::set_initial_condition(const std::function<double(const Po
 }
 
 template <int dim>
+void FluidSolver<dim>::set_partition(const std::array<int, 3> &P, int rank, const uint8_t *nccl_unique_id, void *world) {
+  proc_grid = P;
+  part_rank = rank;
+  nccl_id.clear();
+  if (nccl_unique_id) nccl_id.assign(nccl_unique_id, nccl_unique_id + 128);
+  local_world = world;
+}
+
+template <int dim>
 void FluidSolver<dim>::setup_dofs() {
-  distribute_dofs<dim>(triangulation, (int)parameters.fluid_velocity_degree, dofs);
-  dofs_per_block = {(size_t)dofs.n_u(), (size_t)dofs.n_pnodes};
+  if (!triangulation.is_box) throw std::runtime_error("setup_dofs: unstructured triangulations are not supported in this build");
+  distribute_dofs_box<dim>(triangulation.reps, triangulation.p0, triangulation.p1, triangulation.colorized,
+                           (int)parameters.fluid_velocity_degree, proc_grid, part_rank, dofs, part);
+  dofs_per_block = {(size_t)(dim * part.n_unodes_global), (size_t)part.n_pnodes_global};
   if (this->pcout)
     *this->pcout << "   Number of active fluid cells: " << triangulation.n_active_cells() << std::endl
-           << "   Number of degrees of freedom: " << dofs.n_dofs() << " (" << dofs.n_u() << '+' << dofs.n_pnodes << ')'
-           << std::endl;
+                 << "   Number of degrees of freedom: " << dofs_per_block[0] + dofs_per_block[1] << " (" << dofs_per_block[0]
+                 << '+' << dofs_per_block[1] << ')' << std::endl;
 }
 
 template <int dim>
@@ -72,7 +83,7 @@ void FluidSolver<dim>::make_constraints() {
     auto f = kv.second;
     hc[kv.first] = [f, t](const Point &p, unsigned c) { return f(p, c, t); };
   }
-  make_dirichlet<dim>(triangulation, dofs, parameters.fluid_dirichlet_bcs, hc, constraint_dofs, nonzero_values);
+  make_dirichlet<dim>(dofs, parameters.fluid_dirichlet_bcs, hc, constraint_dofs, nonzero_values);
   if (ctx) {
     check(ifem_set_constraints(ctx, 1, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nonzero_values.data()), "make_constraints");
     check(ifem_set_constraints(ctx, 0, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nullptr), "make_constraints");
@@ -83,12 +94,21 @@ template <int dim>
 void FluidSolver<dim>::initialize_system() {
   if (ctx) { ifem_ctx_destroy(ctx); ctx = nullptr; }
   ifem_mesh_desc m{};
-  m.dim = dim; m.kv = dofs.kv; m.n_cells = (int32_t)triangulation.n_active_cells();
-  m.n_unodes_owned = m.n_unodes_local = (int32_t)dofs.n_unodes;
-  m.n_pnodes_owned = m.n_pnodes_local = (int32_t)dofs.n_pnodes;
+  m.dim = dim; m.kv = dofs.kv; m.n_cells = (int32_t)(dofs.cell_unodes.size() / dofs.nu);
+  m.n_unodes_owned = (int32_t)dofs.n_unodes_owned; m.n_unodes_local = (int32_t)dofs.n_unodes;
+  m.n_pnodes_owned = (int32_t)dofs.n_pnodes_owned; m.n_pnodes_local = (int32_t)dofs.n_pnodes;
   m.vcoords = dofs.vcoords.data(); m.cell_unodes = dofs.cell_unodes.data(); m.cell_pnodes = dofs.cell_pnodes.data();
   m.cell_face_bid = dofs.cell_face_bid.data();
-  check(ifem_ctx_create(&m, nullptr, device, &ctx), "initialize_system");
+  ifem_partition ip{};
+  if (part.nranks > 1) {
+    ip.rank = part.rank; ip.nranks = part.nranks; ip.n_neighbors = (int32_t)part.neighbors.size();
+    ip.neighbor_rank = part.neighbors.data();
+    ip.send_u_ptr = part.send_u_ptr.data(); ip.send_u_idx = part.send_u_idx.data(); ip.recv_u_ptr = part.recv_u_ptr.data();
+    ip.send_p_ptr = part.send_p_ptr.data(); ip.send_p_idx = part.send_p_idx.data(); ip.recv_p_ptr = part.recv_p_ptr.data();
+    ip.nccl_unique_id = nccl_id.empty() ? nullptr : nccl_id.data();
+    ip.local_world = local_world;
+  }
+  check(ifem_ctx_create(&m, part.nranks > 1 ? &ip : nullptr, device, &ctx), "initialize_system");
   check(ifem_set_constraints(ctx, 1, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nonzero_values.data()), "initialize_system");
   check(ifem_set_constraints(ctx, 0, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nullptr), "initialize_system");
   if (initial_condition_field) { // apply_initial_condition (mpi_fluid_solver.cpp:367-415): nodal interpolation
@@ -184,7 +204,7 @@ void InsIM<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_syst
 
 template <int dim>
 void InsIM<dim>::run() {
-  if (this->pcout) *this->pcout << "Running with HIP on 1 MI355X rank(s)..." << std::endl;
+  if (this->pcout) *this->pcout << "Running with HIP on " << this->proc_grid[0] * this->proc_grid[1] * this->proc_grid[2] << " MI355X rank(s)..." << std::endl;
   this->triangulation.refine_global(parameters.global_refinements[0]);
   this->setup_dofs();
   this->make_constraints();

@@ -63,6 +63,11 @@ public:
   // block vector [velocity | pressure] (PETScWrappers::MPI::BlockVector get_current_solution())
   std::vector<double> get_current_solution() const;
   std::pair<size_t, size_t> dofs_per_block_sizes() const { return {(size_t)dofs.n_u(), (size_t)dofs.n_pnodes}; }
+  // Multi-GPU: this process is rank `rank` of a Px x Py x Pz block partition of the (box) triangulation
+  // (p4est Morton partition in the reference, include/mpi_fluid_solver.h:187).  Exactly one transport is set:
+  // nccl_unique_id (128 bytes, RCCL) or local_world (validation transport, see ifem_hip.h).
+  void set_partition(const std::array<int, 3> &P, int rank, const uint8_t *nccl_unique_id, void *local_world);
+  const PartitionTables &partition() const { return part; }
   ifem_ctx *context() const { return ctx; }
   const DoFTables<dim> &dof_tables() const { return dofs; }
   void constraint_lines(std::vector<int32_t> &d, std::vector<double> &v) const { d = constraint_dofs; v = nonzero_values; }
@@ -86,6 +91,11 @@ protected:
   int device;
   std::vector<int32_t> constraint_dofs;
   std::vector<double> nonzero_values;
+  PartitionTables part;
+  std::array<int, 3> proc_grid{1, 1, 1};
+  int part_rank = 0;
+  std::vector<uint8_t> nccl_id;
+  void *local_world = nullptr;
 };
 
 template <int dim>

@@ -53,6 +53,8 @@ void apply_constraints(ifem_ctx *ctx, int which, double *x);
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n);
 void allreduce_max(ifem_ctx *ctx, double *host_vals, int n);
 int comm_unique_id(uint8_t out[128]);
+void *local_world_create(int nranks);
+void local_world_destroy(void *w);
 // ghost refresh of a ghost-extended velocity buffer [dim*nUl] / pressure buffer [nPl] (RCCL send/recv over xGMI)
 void halo_exchange(ifem_ctx *ctx, double *xu_ext);
 void halo_exchange_p(ifem_ctx *ctx, double *xp_ext);

@@ -176,7 +176,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   Clock ck;
   // CG for Mp (:69-84)
   OpFn mp = [&](const double *x, double *y) { const double *xe; extend_p(S, x, &xe); spmv_mp(c, xe, y); };
-  S.st.cg_mp_iters += cg(c, S.npo, mp, src1, tmp, std::max(o->mp_abs, o->mp_rel * n1), (int)std::max<int64_t>(S.npo, 1), r, p, q, pdot);
+  S.st.cg_mp_iters += cg(c, S.npo, mp, src1, tmp, std::max(o->mp_abs, o->mp_rel * n1), (int)std::min<int64_t>(std::max<int64_t>(c->n_global_p, 1), 1 << 30), r, p, q, pdot);
   v_scale(c, S.npo, -(P->viscosity + P->grad_div * P->rho), tmp);
   IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
   S.st.t_cg_mp_ms += ck.ms();
@@ -189,7 +189,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     const double *te; extend_u(S, S.tu, &te);
     spmv_b(c, te, y);
   };
-  S.st.cg_sm_iters += cg(c, S.npo, sm, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), (int)std::max<int64_t>(S.npo, 1), r, p, q, pdot);
+  S.st.cg_sm_iters += cg(c, S.npo, sm, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), (int)std::min<int64_t>(std::max<int64_t>(c->n_global_p, 1), 1 << 30), r, p, q, pdot);
   v_axpby(c, S.npo, 1.0, tmp, -P->rho / P->dt, dst1);
   // utmp = src0 - B^T dst1 (:116-120)
   {
@@ -270,7 +270,7 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   mdot(1, rhs, S.n, rhs, &bn);
   bn = std::sqrt(bn);
   const double tol = std::max(o->fgmres_abs, o->fgmres_rel * bn);
-  int64_t n_glob = S.n; // SolverControl(system_matrix.m(), ...)
+  const int64_t n_glob = ctx->n_global_u + ctx->n_global_p; // SolverControl(system_matrix.m(), ...): identical on all ranks
   const int maxit = o->fgmres_maxit > 0 ? o->fgmres_maxit : (int)std::min<int64_t>(n_glob, 1 << 30);
   OpFn Aop = [&](const double *x, double *y) { system_apply(S, x, y, true); };
   OpFn Pop = [&](const double *x, double *y) { precond_vmult(S, x, y); };

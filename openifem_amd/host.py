@@ -35,6 +35,9 @@ def _lib():
     L.ifemx_get_solution.argtypes = [C.c_void_p, C.c_void_p]
     L.ifemx_node_coords.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifemx_cell_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifemx_set_partition.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.ifemx_partition_sizes.argtypes = [C.c_void_p, C.c_void_p]
+    L.ifemx_partition_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     L.ifemx_channel_state.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_double]
     L._ifemx_bound = True
     return L
@@ -67,6 +70,38 @@ class InsIM:
             self.close()
         except Exception:
             pass
+
+    def set_partition(self, P, rank, nccl_unique_id=None, local_world=None):
+        """rank `rank` of a P[0] x P[1] x P[2] block partition; call before setup()."""
+        Pa = np.ascontiguousarray(list(P) + [1] * (3 - len(P)), np.int32)
+        idbuf = None if nccl_unique_id is None else np.ascontiguousarray(nccl_unique_id, np.uint8)
+        self._chk(self.L.ifemx_set_partition(self.h, Pa.ctypes.data_as(C.c_void_p), rank,
+                                             None if idbuf is None else idbuf.ctypes.data_as(C.c_void_p), local_world))
+
+    def partition_sizes(self):
+        out = np.zeros(10, np.int64)
+        self._chk(self.L.ifemx_partition_sizes(self.h, out.ctypes.data_as(C.c_void_p)))
+        keys = ["n_unodes_owned", "n_unodes_local", "n_pnodes_owned", "n_pnodes_local", "n_neighbors", "n_send_u",
+                "n_send_p", "n_unodes_global", "n_pnodes_global", "n_cells_local"]
+        return dict(zip(keys, out.tolist()))
+
+    def partition_tables(self):
+        z = self.partition_sizes()
+        nn = z["n_neighbors"]
+        t = dict(l2g_u=np.zeros(z["n_unodes_local"], np.int64), l2g_p=np.zeros(z["n_pnodes_local"], np.int64),
+                 neighbors=np.zeros(nn, np.int32), send_u_ptr=np.zeros(nn + 1, np.int32),
+                 send_u_idx=np.zeros(z["n_send_u"], np.int32), recv_u_ptr=np.zeros(nn + 1, np.int32),
+                 send_p_ptr=np.zeros(nn + 1, np.int32), send_p_idx=np.zeros(z["n_send_p"], np.int32),
+                 recv_p_ptr=np.zeros(nn + 1, np.int32))
+        order = ["l2g_u", "l2g_p", "neighbors", "send_u_ptr", "send_u_idx", "recv_u_ptr", "send_p_ptr", "send_p_idx",
+                 "recv_p_ptr"]
+        self._chk(self.L.ifemx_partition_tables(self.h, *[t[k].ctypes.data_as(C.c_void_p) for k in order]))
+        t.update(z)
+        return t
+
+    def global_dofs(self):
+        z = self.partition_sizes()
+        return self.dim * z["n_unodes_global"] + z["n_pnodes_global"]
 
     def run(self):
         self._chk(self.L.ifemx_run(self.h))

@@ -1,0 +1,103 @@
+"""world_size-2 (and 4) CPU tests of the multi-GPU host logic over torch.distributed/gloo (no GPU):
+the block partition, ownership, ghost numbering and halo plans the RCCL path consumes."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, P, reps, dim, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import torch
+        import torch.distributed as dist
+        from openifem_amd import host
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        p1 = (2.0, 0.2, 0.2)[:dim]
+        s = host.InsIM(host.channel_prm(dim), reps, (0,) * dim, p1)
+        s.set_partition(P, rank)
+        s.setup_host_only(0)
+        t = s.partition_tables()
+        nUo, nUl, nPo, nPl = t["n_unodes_owned"], t["n_unodes_local"], t["n_pnodes_owned"], t["n_pnodes_local"]
+        # (a) every global node is owned by exactly one rank
+        for key, no, ng in (("l2g_u", nUo, t["n_unodes_global"]), ("l2g_p", nPo, t["n_pnodes_global"])):
+            cnt = torch.zeros(ng, dtype=torch.int64)
+            cnt[torch.from_numpy(t[key][:no])] += 1
+            dist.all_reduce(cnt)
+            assert int(cnt.min()) == 1 and int(cnt.max()) == 1, f"{key}: ownership is not a partition"
+        # (b) halo exchange through the send/recv plans reproduces f(global id) on the ghosts
+        for which, l2g, no, nl, bs in (("u", t["l2g_u"], nUo, nUl, dim), ("p", t["l2g_p"], nPo, nPl, 1)):
+            f = lambda g: np.sin(0.37 * g[:, None] + np.arange(bs)[None, :])
+            x = np.zeros((nl, bs))
+            x[:no] = f(l2g[:no])
+            sp, si, rp = t[f"send_{which}_ptr"], t[f"send_{which}_idx"], t[f"recv_{which}_ptr"]
+            reqs, bufs = [], []
+            for k, nb in enumerate(t["neighbors"]):
+                sbuf = torch.from_numpy(np.ascontiguousarray(x[si[sp[k]:sp[k + 1]]]))
+                rbuf = torch.zeros((rp[k + 1] - rp[k], bs), dtype=torch.float64)
+                bufs.append((k, rbuf))
+                if sbuf.numel():
+                    reqs.append(dist.isend(sbuf, int(nb)))
+                if rbuf.numel():
+                    reqs.append(dist.irecv(rbuf, int(nb)))
+            for r in reqs:
+                r.wait()
+            for k, rbuf in bufs:
+                x[no + rp[k]:no + rp[k + 1]] = rbuf.numpy()
+            assert np.abs(x - f(l2g)).max() == 0.0, f"halo {which}: ghost values differ from the owners'"
+        # (c) local connectivity maps to the global lattice connectivity; every global cell touching an owned node is local
+        from boxmesh import BoxMesh
+        m = BoxMesh(reps, (0,) * dim, p1, kv=2)
+        cu, cp, fb, vc = s.cell_tables()
+        gu = t["l2g_u"][cu]
+        key = {tuple(row): i for i, row in enumerate(m.cell_unodes.tolist())}
+        gcells = np.array([key[tuple(r)] for r in gu.tolist()])
+        assert np.array_equal(t["l2g_p"][cp], m.cell_pnodes[gcells])
+        assert np.array_equal(fb, m.cell_face_bid[gcells]) and np.abs(vc - m.vcoords[gcells]).max() < 1e-15
+        owned = set(t["l2g_u"][:nUo].tolist())
+        need = {c for c in range(m.n_cells) if owned & set(m.cell_unodes[c].tolist())}
+        assert need <= set(gcells.tolist()), "a cell touching an owned row is not local"
+        # (d) constraints cover exactly the constrained global dofs among the local ones
+        d, v = s.constraints()
+        bcs = {2: (3, [0, 0]), 3: (3, [0, 0])} if dim == 2 else {2: (7, [0, 0, 0]), 3: (7, [0, 0, 0]), 4: (4, [0]), 5: (4, [0])}
+        d0, _ = m.dirichlet(bcs)
+        gl = set((t["l2g_u"][d // dim] * dim + d % dim).tolist())
+        local_all = set((t["l2g_u"][:, None] * dim + np.arange(dim)[None, :]).ravel().tolist())
+        assert gl == (set(d0.tolist()) & local_all)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,P,reps,dim", [(2, (2, 1, 1), (4, 2, 2), 3), (4, (2, 2, 1), (4, 4, 2), 3), (2, (2, 1), (6, 3), 2)])
+def test_block_partition_over_gloo(world, P, reps, dim):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, P, reps, dim, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
