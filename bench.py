@@ -67,14 +67,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=128, help="cells per direction per GPU")
-    ap.add_argument("--cpu-n", type=int, default=24, help="cells per direction of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cells", dest="n", type=int, default=128, help="cells per direction per GPU")
+    ap.add_argument("--cpu-cells", dest="cpu_n", type=int, default=24, help="cells per direction of the CPU baseline sample (0 = skip)")
     ap.add_argument("--inner-rel", type=float, default=1e-2)
-    ap.add_argument("--verbose", type=int, default=0)
+    ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "IFEM_BENCH_DEVICE" in os.environ:  # debugging aid: several ranks on one GPU (RCCL normally refuses this)
+        local_rank = int(os.environ["IFEM_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:

@@ -120,6 +120,8 @@ int ifem_device_count(void);
 void ifem_default_solver_opts(ifem_solver_opts *o);
 /* RCCL bootstrap: rank 0 calls this and ships the 128 bytes to the other ranks by any channel */
 int ifem_comm_unique_id(uint8_t out[128]);
+/* one-rank RCCL round trip (communicator + all-reduce + grouped send/recv to self) on `device` */
+int ifem_comm_selftest(int device);
 /* validation transport (see ifem_partition::local_world): nranks contexts of one process on one GPU */
 void *ifem_local_world_create(int nranks);
 void ifem_local_world_destroy(void *world);

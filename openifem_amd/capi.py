@@ -56,7 +56,7 @@ class Timing(C.Structure):
 
 
 EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "ifem_comm_unique_id",
-           "ifem_local_world_create", "ifem_local_world_destroy",
+           "ifem_local_world_create", "ifem_local_world_destroy", "ifem_comm_selftest",
            "ifem_ctx_create", "ifem_ctx_destroy", "ifem_n_local_dofs", "ifem_nnz", "ifem_set_constraints",
            "ifem_set_cell_fields", "ifem_vec_set", "ifem_vec_get", "ifem_vec_copy", "ifem_vec_zero", "ifem_vec_axpy",
            "ifem_vec_norm2", "ifem_vec_minmax", "ifem_halo_exchange", "ifem_ins_assemble", "ifem_solve",

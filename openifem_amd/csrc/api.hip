@@ -371,6 +371,11 @@ int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t) {
 int ifem_set_profiling(ifem_ctx *ctx, int on) { ctx->profile = on != 0; return IFEM_OK; }
 
 int ifem_comm_unique_id(uint8_t out[128]) { return ifem::comm_unique_id(out); }
+int ifem_comm_selftest(int device) {
+  IFEM_API_BEGIN
+  ifem::comm_selftest(device);
+  IFEM_API_END
+}
 void *ifem_local_world_create(int nranks) { return ifem::local_world_create(nranks); }
 void ifem_local_world_destroy(void *w) { ifem::local_world_destroy(w); }
 

@@ -180,6 +180,35 @@ static void allreduce(ifem_ctx *ctx, double *host_vals, int n, bool is_max) {
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, host_vals, n, false); }
 void allreduce_max(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, host_vals, n, true); }
 
+// One-rank RCCL round trip (communicator, all-reduce, grouped send/recv to self) on `device`: checks on a
+// single-GPU box that the library, the RCCL it resolves at run time and the stream semantics fit together.
+int comm_selftest(int device) {
+  IFEM_HIP_CHECK(hipSetDevice(device));
+  hipStream_t s;
+  IFEM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  ncclUniqueId id;
+  IFEM_NCCL_CHECK(ncclGetUniqueId(&id));
+  ncclComm_t comm;
+  IFEM_NCCL_CHECK(ncclCommInitRank(&comm, 1, id, 0));
+  DBuf<double> a, b;
+  a.alloc(64); b.alloc(64);
+  std::vector<double> h(64);
+  for (int i = 0; i < 64; ++i) h[i] = i + 0.5;
+  IFEM_HIP_CHECK(hipMemcpyAsync(a.p, h.data(), 64 * 8, hipMemcpyHostToDevice, s));
+  IFEM_NCCL_CHECK(ncclAllReduce(a.p, a.p, 64, ncclDouble, ncclSum, comm, s));
+  IFEM_NCCL_CHECK(ncclGroupStart());
+  IFEM_NCCL_CHECK(ncclSend(a.p, 64, ncclDouble, 0, comm, s));
+  IFEM_NCCL_CHECK(ncclRecv(b.p, 64, ncclDouble, 0, comm, s));
+  IFEM_NCCL_CHECK(ncclGroupEnd());
+  std::vector<double> out(64);
+  IFEM_HIP_CHECK(hipMemcpyAsync(out.data(), b.p, 64 * 8, hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  ncclCommDestroy(comm);
+  (void)hipStreamDestroy(s);
+  for (int i = 0; i < 64; ++i) if (out[i] != h[i]) throw Error(IFEM_E_COMM, "RCCL self-test: wrong data");
+  return IFEM_OK;
+}
+
 void *local_world_create(int nranks) { return new LocalWorld(nranks); }
 void local_world_destroy(void *w) { delete static_cast<LocalWorld *>(w); }
 

@@ -53,6 +53,7 @@ void apply_constraints(ifem_ctx *ctx, int which, double *x);
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n);
 void allreduce_max(ifem_ctx *ctx, double *host_vals, int n);
 int comm_unique_id(uint8_t out[128]);
+int comm_selftest(int device);
 void *local_world_create(int nranks);
 void local_world_destroy(void *w);
 // ghost refresh of a ghost-extended velocity buffer [dim*nUl] / pressure buffer [nPl] (RCCL send/recv over xGMI)

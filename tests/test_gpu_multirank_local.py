@@ -102,3 +102,11 @@ def test_virtual_ranks_default_tolerances():
     rhsN, updN, its, _ = _run_ranks((8, 4, 4), (2, 1, 1), tight=False)
     assert abs(its[0] - it1) <= 1
     assert np.linalg.norm(updN - upd1) / np.linalg.norm(upd1) < 5e-2
+
+
+def test_rccl_single_rank_round_trip():
+    # the RCCL glue (unique id, communicator, all-reduce, grouped send/recv on a non-blocking stream)
+    from openifem_amd import capi
+    L = capi.load()
+    rc = L.ifem_comm_selftest(0)
+    assert rc == 0, L.ifem_last_error().decode()
