@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--cells", dest="n", type=int, default=128, help="cells per direction per GPU")
     ap.add_argument("--cpu-cells", dest="cpu_n", type=int, default=24, help="cells per direction of the CPU baseline sample (0 = skip)")
     ap.add_argument("--inner-rel", type=float, default=1e-2)
+    ap.add_argument("--ainv", type=int, default=1, help="IFEM_AINV_* kind of the A_uu^-1 replacement (1 = fp32 inner matrix)")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
     args = ap.parse_args()
 
@@ -100,6 +101,7 @@ def main():
     n_cells, n_u, n_p = solver.sizes()
     n_dofs_global = solver.global_dofs() if world > 1 else n_u + n_p
     solver.opts.inner_rel = args.inner_rel
+    solver.opts.ainv_kind = args.ainv
     solver.opts.verbose = args.verbose if rank == 0 else 0
     solver.channel_state()
     solver.set_profiling(True)
@@ -152,7 +154,7 @@ def main():
                        "assemble_ms": t_asm / args.steps * 1e3, "solve_ms": t_solve / args.steps * 1e3,
                        "assemble_kernel_ms": tm.assemble_kernel_ms, "setup_s": t_setup,
                        "fgmres_iters": last.fgmres_iters, "cg_mp_iters": last.cg_mp_iters,
-                       "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel,
+                       "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "ainv_kind": args.ainv,
                        "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms},
             "roofline": {"bound": "hbm", "kernel": "k_spmv_uu (A_uu BSR SpMV + fused B^T)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -81,7 +81,9 @@ typedef struct {
 } ifem_ins_params;
 
 /* How A~^-1 (MUMPS in the reference, mpi_insim.cpp:124-127) is replaced */
-#define IFEM_AINV_GMRES_BJACOBI 0 /* inner GMRES(m) on A_uu, node-block Jacobi preconditioned */
+#define IFEM_AINV_GMRES_BJACOBI 0     /* inner GMRES(m) on A_uu, node-block Jacobi preconditioned */
+#define IFEM_AINV_GMRES_BJACOBI_F32 1 /* same, with the inner SpMV reading a single-precision copy of A_uu (the outer
+                                         FGMRES operator stays fp64; only the preconditioner is approximated) */
 
 typedef struct {
   int32_t fgmres_restart;     /* 30: deal.II SolverFGMRES default */
@@ -93,6 +95,8 @@ typedef struct {
   int32_t ainv_kind;          /* IFEM_AINV_* */
   int32_t inner_restart, inner_maxit;
   double  inner_rel;          /* relative residual target of the inner A_uu solve */
+  int32_t explicit_schur;     /* 1: form S_m = B diag(M_u)^-1 B^T explicitly like the reference (single GPU);
+                                 0 (and always on several GPUs): apply it matrix-free as two SpMVs */
   int32_t verbose;
 } ifem_solver_opts;
 

@@ -395,6 +395,8 @@ void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzer
   IFEM_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->timing.assemble_kernel_ms = ms;
   ctx->assembled = true;
+  ctx->auu_f32_valid = false;
+  ctx->sm_valid = false;
 }
 
 } // namespace ifem

@@ -60,7 +60,7 @@ struct DBuf { // owning device buffer
 // doubles for every e: fully coalesced without LDS staging.  BS = dim*dim (A_uu), dim (B, B^T) or 1.
 struct PlanarCsr {
   int64_t n_rows = 0, nnzb = 0;
-  int bs = 1;
+  int bs = 1, max_row = 0;
   DBuf<int64_t> rowptr;
   DBuf<int32_t> col;
   DBuf<double> val;
@@ -112,6 +112,10 @@ struct ifem_ctx {
   ifem::PlanarCsr Bt;  // rows: owned velocity nodes, cols: local pressure nodes, bs = dim   (block (0,1))
   ifem::PlanarCsr B;   // rows: owned pressure nodes, cols: local velocity nodes, bs = dim   (block (1,0))
   ifem::PlanarCsr Mp;  // rows: owned pressure nodes, cols: local pressure nodes, bs = 1     (mass (1,1))
+  ifem::PlanarCsr Sm;  // mass_schur(1,1) = B diag(M_u)^-1 B^T, explicit (single rank only; empty otherwise)
+  bool sm_valid = false;
+  ifem::DBuf<float> Auu_f32;   // single-precision copy of Auu.val for the inner (preconditioner-only) solver
+  bool auu_f32_valid = false, last_spmv_f32 = false;
   ifem::DBuf<double> diagMu;   // diag of mass (0,0), per velocity dof (owned)
   ifem::DBuf<double> dinvMu;   // 1/diagMu
   ifem::DBuf<double> bjac;     // inverse diagonal node blocks of A_uu [nUo][dim*dim]

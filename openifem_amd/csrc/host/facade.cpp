@@ -66,6 +66,10 @@ int ifemx_set_partition(void *hv, const int *P, int rank, const uint8_t *nccl_un
     else h->s3->set_partition(p, rank, nccl_unique_id, local_world);
   });
 }
+int ifemx_set_node_order(void *hv, int morton) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] { if (h->dim == 2) h->s2->set_node_order(morton != 0); else h->s3->set_node_order(morton != 0); });
+}
 // sizes of the partition tables: [n_unodes_owned, n_unodes_local, n_pnodes_owned, n_pnodes_local, n_neighbors,
 //  n_send_u, n_send_p, n_unodes_global, n_pnodes_global, n_cells_local]
 int ifemx_partition_sizes(void *hv, int64_t *out) {

@@ -49,6 +49,8 @@ struct DoFTables {
   std::vector<std::array<double, dim>> unode_coords, pnode_coords; // support points (d-linear map of the unit lattice)
   // multi-GPU: nodes [0, n_*_owned) are owned by this rank, the rest are ghosts (grouped by owner rank)
   int64_t n_unodes_owned = 0, n_pnodes_owned = 0;
+  // input of distribute_dofs*: number owned nodes and order cells along a Morton curve (default) or lexicographically
+  bool morton = true;
   int64_t n_u() const { return dim * n_unodes; }
   int64_t n_dofs() const { return dim * n_unodes + n_pnodes; }
 };

@@ -68,6 +68,8 @@ public:
   // nccl_unique_id (128 bytes, RCCL) or local_world (validation transport, see ifem_hip.h).
   void set_partition(const std::array<int, 3> &P, int rank, const uint8_t *nccl_unique_id, void *local_world);
   const PartitionTables &partition() const { return part; }
+  // node/cell ordering used by setup_dofs: Morton curve (default, cache-friendly) or lexicographic
+  void set_node_order(bool morton) { dofs.morton = morton; }
   ifem_ctx *context() const { return ctx; }
   const DoFTables<dim> &dof_tables() const { return dofs; }
   void constraint_lines(std::vector<int32_t> &d, std::vector<double> &v) const { d = constraint_dofs; v = nonzero_values; }

@@ -8,6 +8,8 @@ namespace ifem {
 void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, int R, const int32_t *d_rows, int C,
                    const int32_t *d_cols, DBuf<uint16_t> &pos);
 
+void build_schur_pattern(ifem_ctx *ctx);
+
 // assemble.hip
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
 
@@ -20,13 +22,16 @@ struct VecLayout {
 inline VecLayout layout_of(const ifem_ctx *c) { return {c->dim * c->nUo, c->dim * c->nUl, c->nPo}; }
 
 // y_u = A_uu x_u (+ B^T x_p when xp != nullptr)
-void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool time_it);
+void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool use_f32);
 // y_p = B x_u
 void spmv_b(ifem_ctx *ctx, const double *xu, double *yp);
 // y_u = B^T x_p
 void spmv_bt(ifem_ctx *ctx, const double *xp, double *yu);
 // y_p = M_p x_p
 void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp);
+// explicit S_m: numeric product B diag(1/diag M_u) B^T into ctx->Sm (pattern must exist), and y_p = S_m x_p
+void schur_numeric(ifem_ctx *ctx);
+void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp);
 // y_u = d .* x_u (diagonal scaling with 1/diag(M_u))
 void vec_mul(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y);
 // y = bjac * x  (node-block Jacobi)

@@ -11,11 +11,11 @@ namespace ifem {
 // Row-planar block SpMV.  G lanes cooperate on one row; lane k walks blocks k, k+G, ... of the row and
 // reads the BS = BR*BC planes of its block with stride len (coalesced across lanes), gathers BC values of x
 // and accumulates BR partial sums that are reduced over the G lanes with DPP-free shuffles.
-template <int BR, int BC, int G, bool ACC>
+template <int BR, int BC, int G, bool ACC, class VT = double>
 __device__ inline void row_planar_dot(const int64_t rs, const int len, const int32_t *__restrict__ col,
-                                      const double *__restrict__ val, const double *__restrict__ x, const int lig,
+                                      const VT *__restrict__ val, const double *__restrict__ x, const int lig,
                                       double *acc) {
-  const double *vbase = val + rs * (BR * BC);
+  const VT *vbase = val + rs * (BR * BC);
   for (int k = lig; k < len; k += G) {
     const int32_t c = col[rs + k];
     double xv[BC];
@@ -36,9 +36,9 @@ __device__ inline double group_sum(double v) {
 }
 
 // y_u = A_uu x_u + B^T x_p   (rows: owned velocity nodes)
-template <int DIM, int G>
+template <int DIM, int G, class VT = double>
 __global__ __launch_bounds__(256) void k_spmv_uu(int64_t n_rows, const int64_t *__restrict__ rp_a,
-                                                 const int32_t *__restrict__ col_a, const double *__restrict__ val_a,
+                                                 const int32_t *__restrict__ col_a, const VT *__restrict__ val_a,
                                                  const int64_t *__restrict__ rp_t, const int32_t *__restrict__ col_t,
                                                  const double *__restrict__ val_t, const double *__restrict__ xu,
                                                  const double *__restrict__ xp, double *__restrict__ yu) {
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_spmv_uu(int64_t n_rows, const int64_t *
   {
     const int64_t rs = rp_a[row];
     const int len = int(rp_a[row + 1] - rs);
-    row_planar_dot<DIM, DIM, G, true>(rs, len, col_a, val_a, xu, lig, acc);
+    row_planar_dot<DIM, DIM, G, true, VT>(rs, len, col_a, val_a, xu, lig, acc);
   }
   if (xp) {
     const int64_t rs = rp_t[row];
@@ -90,21 +90,44 @@ __global__ __launch_bounds__(256) void k_spmv_planar(int64_t n_rows, const int64
 
 static inline unsigned blocks_for_rows(int64_t n_rows, int G) { return unsigned((n_rows * G + 255) / 256); }
 
-void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool time_it) {
+__global__ void k_to_f32(int64_t n, const double *__restrict__ a, float *__restrict__ b) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) b[i] = float(a[i]);
+}
+
+// single-precision copy of the A_uu values for the inner (preconditioner-only) solver: same planar layout
+void auu_f32_refresh(ifem_ctx *ctx) {
+  if (ctx->auu_f32_valid) return;
+  const int64_t n = (int64_t)ctx->Auu.val.n;
+  if (ctx->Auu_f32.n != (size_t)n) ctx->Auu_f32.alloc(n);
+  if (n) hipLaunchKernelGGL(k_to_f32, dim3(8192), dim3(256), 0, ctx->stream, n, ctx->Auu.val.p, ctx->Auu_f32.p);
+  ctx->auu_f32_valid = true;
+}
+
+void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool use_f32) {
   const int64_t n = ctx->Auu.n_rows;
   if (n == 0) return;
   hipStream_t s = ctx->stream;
-  time_it = ctx->profile && xp == nullptr; // the A_uu-only launches of the inner solver: the dominant kernel
+  const bool time_it = ctx->profile && xp == nullptr; // the A_uu-only launches of the inner solver: the dominant kernel
+  if (use_f32) auu_f32_refresh(ctx);
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s));
   if (ctx->dim == 3) {
     constexpr int G = 32;
-    hipLaunchKernelGGL((k_spmv_uu<3, G>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
-                       ctx->Auu.col.p, ctx->Auu.val.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
+    if (use_f32)
+      hipLaunchKernelGGL((k_spmv_uu<3, G, float>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
+                         ctx->Auu.col.p, ctx->Auu_f32.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
+    else
+      hipLaunchKernelGGL((k_spmv_uu<3, G, double>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
+                         ctx->Auu.col.p, ctx->Auu.val.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
   } else {
     constexpr int G = 16;
-    hipLaunchKernelGGL((k_spmv_uu<2, G>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
-                       ctx->Auu.col.p, ctx->Auu.val.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
+    if (use_f32)
+      hipLaunchKernelGGL((k_spmv_uu<2, G, float>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
+                         ctx->Auu.col.p, ctx->Auu_f32.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
+    else
+      hipLaunchKernelGGL((k_spmv_uu<2, G, double>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
+                         ctx->Auu.col.p, ctx->Auu.val.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
   }
+  ctx->last_spmv_f32 = use_f32;
   if (time_it) {
     IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
     IFEM_HIP_CHECK(hipEventSynchronize(ctx->ev1));
@@ -112,6 +135,9 @@ void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool
     IFEM_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->spmv_uu_ms_total += ms;
     ctx->timing.spmv_uu_calls++;
+    // algorithmic bytes of this launch: values (+4-byte block column index) + row pointers + x + y
+    const int d = ctx->dim;
+    ctx->timing.spmv_uu_bytes = double(ctx->Auu.nnzb) * (d * d * (use_f32 ? 4 : 8) + 4) + double(n) * (8 + 2 * d * 8);
   }
 }
 
@@ -142,6 +168,82 @@ void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp) {
   if (n == 0) return;
   hipLaunchKernelGGL((k_spmv_planar<1, 1, 8>), dim3(blocks_for_rows(n, 8)), dim3(256), 0, ctx->stream, n,
                      ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->Mp.val.p, xp, yp);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mass_schur(1,1) = B diag(1/diag M_u) B^T (mpi_insim.cpp:44-49, PETSc MatMatMult in the reference): one wave per
+// pressure row i; lanes walk the blocks k of B's row i, then the (short) row k of B^T, and accumulate into the
+// row's LDS copy through a binary search of the column.
+template <int DIM>
+__global__ __launch_bounds__(256) void k_schur_numeric(int64_t n_rows, int maxlen, const int64_t *__restrict__ rpS,
+                                                       const int32_t *__restrict__ colS, double *__restrict__ valS,
+                                                       const int64_t *__restrict__ rpB, const int32_t *__restrict__ colB,
+                                                       const double *__restrict__ valB, const int64_t *__restrict__ rpT,
+                                                       const int32_t *__restrict__ colT, const double *__restrict__ valT,
+                                                       const double *__restrict__ dinv) {
+  extern __shared__ __align__(16) unsigned char smem_s[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *acc = reinterpret_cast<double *>(smem_s) + size_t(wave) * maxlen;
+  int32_t *cols = reinterpret_cast<int32_t *>(reinterpret_cast<double *>(smem_s) + size_t(4) * maxlen) + size_t(wave) * maxlen;
+  const int64_t row = int64_t(blockIdx.x) * 4 + wave;
+  const bool active = row < n_rows;
+  const int64_t rs = active ? rpS[row] : 0;
+  const int len = active ? int(rpS[row + 1] - rs) : 0;
+  for (int i = lane; i < len; i += 64) { cols[i] = colS[rs + i]; acc[i] = 0.0; }
+  __syncthreads();
+  if (active) {
+    const int64_t bs = rpB[row];
+    const int blen = int(rpB[row + 1] - bs);
+    for (int kb = lane; kb < blen; kb += 64) {
+      const int32_t k = colB[bs + kb];
+      double bd[DIM];
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) bd[c] = valB[bs * DIM + int64_t(c) * blen + kb] * dinv[int64_t(k) * DIM + c];
+      const int64_t ts = rpT[k];
+      const int tlen = int(rpT[k + 1] - ts);
+      for (int t = 0; t < tlen; ++t) {
+        const int32_t j = colT[ts + t];
+        double v = 0;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) v += bd[c] * valT[ts * DIM + int64_t(c) * tlen + t];
+        int lo = 0, hi = len - 1;
+        while (lo <= hi) {
+          const int mid = (lo + hi) >> 1;
+          const int32_t cv = cols[mid];
+          if (cv == j) { unsafeAtomicAdd(&acc[mid], v); break; }
+          if (cv < j) lo = mid + 1; else hi = mid - 1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < len; i += 64) valS[rs + i] = acc[i];
+}
+
+void schur_numeric(ifem_ctx *ctx) {
+  if (ctx->sm_valid) return;
+  const int64_t n = ctx->Sm.n_rows;
+  if (n == 0) return;
+  const int maxlen = (ctx->Sm.max_row + 1) & ~1;
+  const size_t smem = size_t(4) * maxlen * (sizeof(double) + sizeof(int32_t));
+  const unsigned blocks = unsigned((n + 3) / 4);
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_schur_numeric<3>), dim3(blocks), dim3(256), smem, ctx->stream, n, maxlen, ctx->Sm.rowptr.p,
+                       ctx->Sm.col.p, ctx->Sm.val.p, ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, ctx->Bt.rowptr.p,
+                       ctx->Bt.col.p, ctx->Bt.val.p, ctx->dinvMu.p);
+  else
+    hipLaunchKernelGGL((k_schur_numeric<2>), dim3(blocks), dim3(256), smem, ctx->stream, n, maxlen, ctx->Sm.rowptr.p,
+                       ctx->Sm.col.p, ctx->Sm.val.p, ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, ctx->Bt.rowptr.p,
+                       ctx->Bt.col.p, ctx->Bt.val.p, ctx->dinvMu.p);
+  IFEM_HIP_CHECK(hipGetLastError());
+  ctx->sm_valid = true;
+}
+
+void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp) {
+  const int64_t n = ctx->Sm.n_rows;
+  if (n == 0) return;
+  hipLaunchKernelGGL((k_spmv_planar<1, 1, 32>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n,
+                     ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm.val.p, xp, yp);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -68,16 +68,11 @@ static int grid_for(int64_t n) {
   return int(g < 1 ? 1 : (g > 65536 ? 65536 : g));
 }
 
-// Builds the sorted pattern of {(row, col)} pairs coupled through a common cell, plus the scatter map.
-void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, int R, const int32_t *d_rows, int C,
-                   const int32_t *d_cols, DBuf<uint16_t> &pos) {
+// Sorts / uniques N (row << 32 | col) keys (invalid = ~0) into the CSR pattern of M; k0 is consumed.
+static void pattern_from_keys(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, DBuf<uint64_t> &k0, int64_t N) {
   hipStream_t s = ctx->stream;
-  const int64_t N = ctx->n_cells * R * C;
-  DBuf<uint64_t> k0, k1;
-  k0.alloc(N);
+  DBuf<uint64_t> k1;
   k1.alloc(N);
-  hipLaunchKernelGGL(k_gen_keys, dim3(grid_for(N)), dim3(256), 0, s, ctx->n_cells, R, C, d_rows, d_cols, n_rows_owned,
-                     k0.p);
   size_t tmp_bytes = 0;
   IFEM_HIP_CHECK(rocprim::radix_sort_keys(nullptr, tmp_bytes, k0.p, k1.p, (size_t)N, 0, 64, s));
   DBuf<char> tmp;
@@ -121,13 +116,73 @@ void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, in
     int64_t mx = 0;
     for (int64_t i = 0; i < n_rows_owned; ++i) mx = rc[i] > mx ? rc[i] : mx;
     if (mx >= 0xFFFF) throw Error(IFEM_E_BADPARAM, "row longer than 65534 blocks");
+    M.max_row = (int)mx;
   }
   M.val.alloc((size_t)nnzb * bs);
   IFEM_HIP_CHECK(hipMemsetAsync(M.val.p, 0, (size_t)nnzb * bs * sizeof(double), s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// Builds the sorted pattern of {(row, col)} pairs coupled through a common cell, plus the scatter map.
+void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, int R, const int32_t *d_rows, int C,
+                   const int32_t *d_cols, DBuf<uint16_t> &pos) {
+  hipStream_t s = ctx->stream;
+  const int64_t N = ctx->n_cells * R * C;
+  DBuf<uint64_t> k0;
+  k0.alloc(N);
+  hipLaunchKernelGGL(k_gen_keys, dim3(grid_for(N)), dim3(256), 0, s, ctx->n_cells, R, C, d_rows, d_cols, n_rows_owned,
+                     k0.p);
+  pattern_from_keys(ctx, M, bs, n_rows_owned, k0, N);
   pos.alloc(N);
   hipLaunchKernelGGL(k_pos_map, dim3(grid_for(N)), dim3(256), 0, s, ctx->n_cells, R, C, d_rows, d_cols, n_rows_owned,
                      M.rowptr.p, M.col.p, pos.p);
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  IFEM_HIP_CHECK(hipGetLastError());
+}
+
+
+// ---- mass_schur(1,1) pattern (compute_mmult_pattern(B, B^T), mpi_fluid_solver.cpp:326-329).  For the Q1 pressure space
+// pattern(B B^T) = pattern(M_p^2): p-nodes i, j couple iff cells c1 with i and c2 with j share a vertex.
+__global__ void k_sq_count(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                           int64_t *__restrict__ cnt) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t c = 0;
+    for (int64_t k = rp[i]; k < rp[i + 1]; ++k) { const int32_t m = col[k]; c += rp[m + 1] - rp[m]; }
+    cnt[i] = c;
+  }
+}
+__global__ void k_sq_fill(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                          const int64_t *__restrict__ off, uint64_t *__restrict__ keys) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t o = off[i];
+    for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
+      const int32_t m = col[k];
+      for (int64_t l = rp[m]; l < rp[m + 1]; ++l) keys[o++] = (uint64_t(uint32_t(i)) << 32) | uint32_t(col[l]);
+    }
+  }
+}
+
+void build_schur_pattern(ifem_ctx *ctx) {
+  if (ctx->halo.nranks != 1) throw Error(IFEM_E_BADPARAM, "explicit S_m needs a 2-deep pressure halo: single rank only");
+  hipStream_t s = ctx->stream;
+  const int64_t n = ctx->nPo;
+  DBuf<int64_t> cnt, off;
+  cnt.alloc(n + 1);
+  off.alloc(n + 1);
+  IFEM_HIP_CHECK(hipMemsetAsync(cnt.p, 0, (n + 1) * 8, s));
+  hipLaunchKernelGGL(k_sq_count, dim3(grid_for(n)), dim3(256), 0, s, n, ctx->Mp.rowptr.p, ctx->Mp.col.p, cnt.p);
+  size_t tb = 0;
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, cnt.p, off.p, int64_t(0), (size_t)(n + 1), rocprim::plus<int64_t>(), s));
+  DBuf<char> tmp;
+  tmp.alloc(tb + 16);
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(tmp.p, tb, cnt.p, off.p, int64_t(0), (size_t)(n + 1), rocprim::plus<int64_t>(), s));
+  int64_t N = 0;
+  IFEM_HIP_CHECK(hipMemcpyAsync(&N, off.p + n, 8, hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  DBuf<uint64_t> keys;
+  keys.alloc(N);
+  hipLaunchKernelGGL(k_sq_fill, dim3(grid_for(n)), dim3(256), 0, s, n, ctx->Mp.rowptr.p, ctx->Mp.col.p, off.p, keys.p);
+  pattern_from_keys(ctx, ctx->Sm, 1, n, keys, N);
   IFEM_HIP_CHECK(hipGetLastError());
 }
 

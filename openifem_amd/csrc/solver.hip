@@ -8,6 +8,7 @@
 // Jacobi; the outer solver is *flexible* GMRES precisely so that such an inexact inner solve is admissible.
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <vector>
@@ -27,8 +28,9 @@ struct Clock {
 // (flexible) right-preconditioned restarted GMRES, x0 = 0.  V: (m+1) x n, Z: m x n (flexible) or 1 x n.
 // Orthogonalisation: classical Gram-Schmidt with one re-orthogonalisation pass (two fused multi-dot /
 // multi-axpy sweeps instead of deal.II's j+1 sequential dots; same Krylov space, fewer host round trips).
-static int gmres(ifem_ctx *ctx, int64_t n, const OpFn &A, const OpFn &Pinv, bool flexible, const double *b, double *x,
-                 int m, int maxit, double tol, double *V, double *Z, double *w, double *res_out,
+static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &A, const OpFn &Pinv, bool flexible,
+                 const double *b, double *x, int m, int maxit, double tol, double *V, double *Z, double *w,
+                 double *res_out,
                  const std::function<void(int, const double *, int64_t, const double *, double *)> &mdot) {
   std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), h(m + 1), h2(m + 1);
   v_zero(ctx, n, x);
@@ -50,22 +52,25 @@ static int gmres(ifem_ctx *ctx, int64_t n, const OpFn &A, const OpFn &Pinv, bool
     int j = 0;
     bool done = false;
     for (; j < m && it < maxit; ++j) {
-      double *vj = V + (int64_t)j * n;
-      double *zj = flexible ? Z + (int64_t)j * n : Z;
+      double *vj = V + (int64_t)j * ld;
+      double *zj = flexible ? Z + (int64_t)j * ld : Z;
       Pinv(vj, zj);
       A(zj, w);
-      mdot(j + 1, V, n, w, h.data());
-      v_maxpy(ctx, n, j + 1, V, n, h.data(), w);
-      mdot(j + 1, V, n, w, h2.data());
-      v_maxpy(ctx, n, j + 1, V, n, h2.data(), w);
+      mdot(j + 1, V, ld, w, h.data());
+      v_maxpy(ctx, n, j + 1, V, ld, h.data(), w);
+      if (reorth) {
+        mdot(j + 1, V, ld, w, h2.data());
+        v_maxpy(ctx, n, j + 1, V, ld, h2.data(), w);
+      } else
+        std::fill(h2.begin(), h2.end(), 0.0);
       for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = h[i] + h2[i];
       double ww;
       mdot(1, w, n, w, &ww);
       const double hn = std::sqrt(ww);
       H[(size_t)(j + 1) * m + j] = hn;
       if (hn > 0) {
-        v_copy(ctx, n, w, V + (int64_t)(j + 1) * n);
-        v_scale(ctx, n, 1.0 / hn, V + (int64_t)(j + 1) * n);
+        v_copy(ctx, n, w, V + (int64_t)(j + 1) * ld);
+        v_scale(ctx, n, 1.0 / hn, V + (int64_t)(j + 1) * ld);
       }
       for (int i = 0; i < j; ++i) {
         const double t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
@@ -87,12 +92,12 @@ static int gmres(ifem_ctx *ctx, int64_t n, const OpFn &A, const OpFn &Pinv, bool
     }
     if (flexible) {
       for (int i = 0; i < j; ++i) h[i] = -y[i];
-      v_maxpy(ctx, n, j, Z, n, h.data(), x); // x += sum y_i z_i
+      v_maxpy(ctx, n, j, Z, ld, h.data(), x); // x += sum y_i z_i
     } else {
       // x += P^-1 (V y): one preconditioner application instead of storing every z_j
       v_zero(ctx, n, w);
       for (int i = 0; i < j; ++i) h[i] = -y[i];
-      v_maxpy(ctx, n, j, V, n, h.data(), w);
+      v_maxpy(ctx, n, j, V, ld, h.data(), w);
       Pinv(w, Z);
       v_axpy(ctx, n, 1.0, Z, x);
     }
@@ -121,6 +126,13 @@ static int cg(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *b, double *
     ++it;
   }
   return it;
+}
+
+// leading dimension of a Krylov basis: a multiple of 64 doubles plus an odd number of 256-byte lines, so that the
+// K+1 streams of a fused multi-dot do not start on the same HBM channel
+static int64_t basis_ld(int64_t n) {
+  static const int64_t pad = [] { const char *e = getenv("IFEM_LD_PAD"); return e ? atoll(e) : 32 * 33; }();
+  return ((n + 63) / 64) * 64 + pad;
 }
 
 struct SolveState {
@@ -154,7 +166,7 @@ static void system_apply(SolveState &S, const double *x, double *y, bool time_it
   const double *xu, *xp;
   extend_u(S, x, &xu);
   extend_p(S, x + S.nuo, &xp);
-  spmv_uu(c, xu, xp, y, time_it);
+  spmv_uu(c, xu, xp, y, false);
   spmv_b(c, xu, y + S.nuo);
 }
 
@@ -182,7 +194,13 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   S.st.t_cg_mp_ms += ck.ms();
   // CG for Sm (:86-112): S_m = B diag(M_u)^-1 B^T applied matrix-free
   Clock ck2;
+  const bool explicit_sm = c->halo.nranks == 1 && o->explicit_schur;
+  if (explicit_sm) { // BlockSchurPreconditioner ctor (:44-49): S_m assembled once per solve()
+    if (c->Sm.n_rows == 0) build_schur_pattern(c);
+    schur_numeric(c);
+  }
   OpFn sm = [&](const double *x, double *y) {
+    if (explicit_sm) { spmv_sm(c, x, y); return; }
     const double *xe; extend_p(S, x, &xe);
     spmv_bt(c, xe, S.tu);
     vec_mul(c, S.nuo, c->dinvMu.p, S.tu, S.tu);
@@ -201,7 +219,8 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   S.st.t_cg_sm_ms += ck2.ms();
   // A~^-1 utmp (:124-127)
   Clock ck3;
-  OpFn Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_uu(c, xe, nullptr, y, false); };
+  const bool f32 = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32;
+  OpFn Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_uu(c, xe, nullptr, y, f32); };
   OpFn Pj = [&](const double *x, double *y) { bjac_apply(c, x, y); };
   auto mdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
     v_mdot(c, S.nuo, k, V, ld, w, out);
@@ -211,8 +230,8 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   mdot(1, S.utmp, S.nuo, S.utmp, &un);
   un = std::sqrt(un);
   double res = 0;
-  S.st.inner_iters += gmres(c, S.nuo, Auu, Pj, false, S.utmp, dst0, o->inner_restart, o->inner_maxit, o->inner_rel * un,
-                            c->innerV.p, S.inner_z, S.inner_w, &res, mdot);
+  S.st.inner_iters += gmres(c, S.nuo, basis_ld(S.nuo), /*reorth=*/false, Auu, Pj, false, S.utmp, dst0, o->inner_restart,
+                            o->inner_maxit, o->inner_rel * un, c->innerV.p, S.inner_z, S.inner_w, &res, mdot);
   IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
   S.st.t_ainv_ms += ck3.ms();
   S.st.precond_applies++;
@@ -234,9 +253,9 @@ static void carve_workspace(SolveState &S) {
   for (int i = 0; i < 6; ++i) { S.tp[i] = p; p += npl; }
   S.outer_w = p;
   const int m = S.o->fgmres_restart, mi = S.o->inner_restart;
-  if ((int64_t)c->krylovV.n < (int64_t)(m + 1) * S.n) c->krylovV.alloc((int64_t)(m + 1) * S.n);
-  if ((int64_t)c->krylovZ.n < (int64_t)m * S.n) c->krylovZ.alloc((int64_t)m * S.n);
-  if ((int64_t)c->innerV.n < (int64_t)(mi + 1) * S.nuo) c->innerV.alloc((int64_t)(mi + 1) * S.nuo);
+  if ((int64_t)c->krylovV.n < (int64_t)(m + 1) * basis_ld(S.n)) c->krylovV.alloc((int64_t)(m + 1) * basis_ld(S.n));
+  if ((int64_t)c->krylovZ.n < (int64_t)m * basis_ld(S.n)) c->krylovZ.alloc((int64_t)m * basis_ld(S.n));
+  if ((int64_t)c->innerV.n < (int64_t)(mi + 1) * basis_ld(S.nuo)) c->innerV.alloc((int64_t)(mi + 1) * basis_ld(S.nuo));
 }
 
 void ins_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, const double *src, double *dst) {
@@ -275,7 +294,7 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   OpFn Aop = [&](const double *x, double *y) { system_apply(S, x, y, true); };
   OpFn Pop = [&](const double *x, double *y) { precond_vmult(S, x, y); };
   double res = 0;
-  const int it = gmres(ctx, S.n, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p, ctx->krylovZ.p,
+  const int it = gmres(ctx, S.n, basis_ld(S.n), /*reorth=*/true, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p, ctx->krylovZ.p,
                        S.outer_w, &res, mdot);
   apply_constraints(ctx, use_nonzero ? 1 : 0, upd); // constraints_used.distribute(newton_update)
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -36,6 +36,7 @@ def _lib():
     L.ifemx_node_coords.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifemx_cell_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifemx_set_partition.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.ifemx_set_node_order.argtypes = [C.c_void_p, C.c_int]
     L.ifemx_partition_sizes.argtypes = [C.c_void_p, C.c_void_p]
     L.ifemx_partition_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     L.ifemx_channel_state.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_double]
@@ -77,6 +78,9 @@ class InsIM:
         idbuf = None if nccl_unique_id is None else np.ascontiguousarray(nccl_unique_id, np.uint8)
         self._chk(self.L.ifemx_set_partition(self.h, Pa.ctypes.data_as(C.c_void_p), rank,
                                              None if idbuf is None else idbuf.ctypes.data_as(C.c_void_p), local_world))
+
+    def set_node_order(self, morton=True):
+        self._chk(self.L.ifemx_set_node_order(self.h, int(morton)))
 
     def partition_sizes(self):
         out = np.zeros(10, np.int64)

@@ -27,7 +27,13 @@ def _run_single(reps, tight):
     rhs, upd = np.zeros(n), np.zeros(n)
     L.ifem_vec_get(s.ctx, capi.VEC_RHS, rhs.ctypes.data_as(C.c_void_p))
     L.ifem_vec_get(s.ctx, capi.VEC_UPDATE, upd.ctypes.data_as(C.c_void_p))
-    return rhs, upd, st.fgmres_iters
+    # local (Morton) numbering -> global lattice numbering
+    t = s.partition_tables()
+    n_ug = t["n_unodes_global"]
+    g = np.concatenate([(t["l2g_u"][:, None] * 3 + np.arange(3)[None, :]).ravel(), 3 * n_ug + t["l2g_p"]])
+    rhs_g, upd_g = np.zeros(n), np.zeros(n)
+    rhs_g[g], upd_g[g] = rhs, upd
+    return rhs_g, upd_g, st.fgmres_iters
 
 
 def _run_ranks(reps, P, tight):

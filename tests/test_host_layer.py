@@ -39,6 +39,7 @@ def test_compute_entry_points_fail_loudly_without_gpu():
 def test_host_tables_match_independent_builder(dim, reps, p1):
     from openifem_amd import host
     s = host.InsIM(host.channel_prm(dim), reps, (0,) * dim, p1)
+    s.set_node_order(morton=False)  # lexicographic: identical numbering to the independent builder
     s.setup_host_only(0)
     m = BoxMesh(reps, (0,) * dim, p1, kv=2)
     n_cells, n_u, n_p = s.sizes()
@@ -70,6 +71,7 @@ def test_first_boundary_id_wins_at_corners():
         .replace("set Dirichlet boundary values = 0, 0, 0, 0", "set Dirichlet boundary values = 1, 0, 0, 0, 0, 0") \
         .replace("set Number of Neumann BCs = 1", "set Number of Neumann BCs = 0")
     s = host.InsIM(prm, (4, 2), (0, 0), (2.0, 0.2))
+    s.set_node_order(morton=False)
     s.setup_host_only(0)
     d, v = s.constraints()
     m = BoxMesh((4, 2), (0, 0), (2.0, 0.2), kv=2)
@@ -101,3 +103,21 @@ def test_reference_prm_files_parse():
         s = host.InsIM(open(os.path.join(gdir, name)).read(), (4, 2), (0, 0), (2.0, 0.2))
         s.setup_host_only(0)
         assert s.sizes()[0] == 8
+
+
+@pytest.mark.parametrize("dim,reps,p1", [(2, (5, 3), (2.0, 0.2)), (3, (4, 3, 2), (2.0, 0.2, 0.2))])
+def test_morton_order_is_a_permutation_of_the_lattice(dim, reps, p1):
+    # default (Morton) numbering: same mesh, permuted: cells map onto the independent builder's cells through l2g
+    from openifem_amd import host
+    s = host.InsIM(host.channel_prm(dim), reps, (0,) * dim, p1)
+    s.setup_host_only(0)
+    m = BoxMesh(reps, (0,) * dim, p1, kv=2)
+    t = s.partition_tables()
+    assert sorted(t["l2g_u"].tolist()) == list(range(m.n_unodes)) and sorted(t["l2g_p"].tolist()) == list(range(m.n_pnodes))
+    cu, cp, fb, vc = s.cell_tables()
+    key = {tuple(r): i for i, r in enumerate(m.cell_unodes.tolist())}
+    g = np.array([key[tuple(r)] for r in t["l2g_u"][cu].tolist()])
+    assert sorted(g.tolist()) == list(range(m.n_cells))
+    assert np.array_equal(t["l2g_p"][cp], m.cell_pnodes[g]) and np.array_equal(fb, m.cell_face_bid[g])
+    uc, pc = s.node_coords()
+    assert np.abs(uc - m.unode_coords[t["l2g_u"]]).max() < 1e-14
