@@ -85,6 +85,11 @@ typedef struct {
 #define IFEM_AINV_GMRES_BJACOBI_F32 1 /* same, with the inner SpMV reading a single-precision copy of A_uu (the outer
                                          FGMRES operator stays fp64; only the preconditioner is approximated) */
 
+#define IFEM_AINV_SCALAR_GMRES 2      /* inner GMRES(m) on the scalar operator S^ = mu K + rho C(u) + rho/dt M applied to
+                                         every velocity component (drops the grad-div and u-gradient couplings of A_uu:
+                                         8x less matrix traffic; adequate while gamma*rho*dim <~ mu).  Needs
+                                         ifem_set_ainv_kind(ctx, 2) before ifem_ins_assemble. */
+
 typedef struct {
   int32_t fgmres_restart;     /* 30: deal.II SolverFGMRES default */
   int32_t fgmres_maxit;       /* 0 -> n_dofs (mpi_insim.cpp:379-380) */
@@ -154,6 +159,8 @@ int ifem_vec_norm2(ifem_ctx *ctx, int vec, double *out);  /* l2_norm(), all-redu
 int ifem_vec_minmax(ifem_ctx *ctx, int vec, int block, double *vmin, double *vmax);
 int ifem_halo_exchange(ifem_ctx *ctx, int vec);           /* ghosted-vector assignment */
 
+/* Tells the next ifem_ins_assemble which extra operators the chosen A_uu^-1 replacement needs (IFEM_AINV_*). */
+int ifem_set_ainv_kind(ifem_ctx *ctx, int kind);
 /* InsIM::assemble(use_nonzero_constraints), mpi_insim.cpp:153-362.  Reads IFEM_VEC_EVAL, _PRESENT,
  * _FSI_ACC; writes the device matrices (A_uu, B, B^T, diag(M_u), M_p) and IFEM_VEC_RHS. */
 int ifem_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);

@@ -61,7 +61,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_set_cell_fields", "ifem_vec_set", "ifem_vec_get", "ifem_vec_copy", "ifem_vec_zero", "ifem_vec_axpy",
            "ifem_vec_norm2", "ifem_vec_minmax", "ifem_halo_exchange", "ifem_ins_assemble", "ifem_solve",
            "ifem_rhs_norm", "ifem_ins_newton_step", "ifem_system_vmult", "ifem_precond_vmult", "ifem_export_csr",
-           "ifem_get_timing", "ifem_set_profiling"]
+           "ifem_get_timing", "ifem_set_profiling", "ifem_set_ainv_kind"]
 
 _lib = None
 
@@ -112,6 +112,7 @@ def load():
     L.ifem_local_world_create.argtypes = [C.c_int]
     L.ifem_local_world_destroy.argtypes = [C.c_void_p]
     L.ifem_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.ifem_set_ainv_kind.argtypes = [C.c_void_p, C.c_int]
     _lib = L
     return L
 

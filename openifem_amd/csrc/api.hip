@@ -366,6 +366,7 @@ int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t) {
   IFEM_API_END
 }
 
+int ifem_set_ainv_kind(ifem_ctx *ctx, int kind) { ctx->want_shat = kind == IFEM_AINV_SCALAR_GMRES; return IFEM_OK; }
 int ifem_set_profiling(ifem_ctx *ctx, int on) { ctx->profile = on != 0; return IFEM_OK; }
 
 int ifem_comm_unique_id(uint8_t out[128]) { return ifem::comm_unique_id(out); }

@@ -33,6 +33,7 @@ struct AsmArgs {
   const uint16_t *posUU, *posUP, *posPU, *posPP;
   const int64_t *rp_uu, *rp_bt, *rp_b, *rp_mp;
   double *v_uu, *v_bt, *v_b, *v_mp, *diagMu, *rhs;
+  double *v_s; // scalar velocity operator (one value per A_uu block) or nullptr
   const uint8_t *is_c;
   const double *cval;
   const double *eval, *present, *fsi_acc;
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble(AsmArgs A) {
     const uint16_t pos = A.posUU[(cc * NU + a) * NU + b];
     double *base = A.v_uu + S.rs_uu[a] * (DIM * DIM) + pos;
     const int64_t row_dof0 = int64_t(DIM) * S.un[a];
+    if (A.v_s) unsafeAtomicAdd(A.v_s + S.rs_uu[a] + pos, s);
     for (int c = 0; c < DIM; ++c) {
       const bool rc = S.cf[a * DIM + c];
       for (int d = 0; d < DIM; ++d) {
@@ -361,6 +363,10 @@ void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzer
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->B.val.p, 0, ctx->B.val.n * sizeof(double), s));
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->Mp.val.p, 0, ctx->Mp.val.n * sizeof(double), s));
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->diagMu.p, 0, ctx->diagMu.n * sizeof(double), s));
+  if (ctx->want_shat) {
+    if (ctx->Shat.n != (size_t)ctx->Auu.nnzb) ctx->Shat.alloc((size_t)ctx->Auu.nnzb);
+    IFEM_HIP_CHECK(hipMemsetAsync(ctx->Shat.p, 0, ctx->Shat.n * sizeof(double), s));
+  }
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->vec[IFEM_VEC_RHS].p, 0, ctx->vec[IFEM_VEC_RHS].n * sizeof(double), s));
   AsmArgs A{};
   A.n_cells = ctx->n_cells; A.nUo = ctx->nUo; A.nUl = ctx->nUl; A.nPo = ctx->nPo;
@@ -371,6 +377,7 @@ void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzer
   A.rp_uu = ctx->Auu.rowptr.p; A.rp_bt = ctx->Bt.rowptr.p; A.rp_b = ctx->B.rowptr.p; A.rp_mp = ctx->Mp.rowptr.p;
   A.v_uu = ctx->Auu.val.p; A.v_bt = ctx->Bt.val.p; A.v_b = ctx->B.val.p; A.v_mp = ctx->Mp.val.p;
   A.diagMu = ctx->diagMu.p; A.rhs = ctx->vec[IFEM_VEC_RHS].p;
+  A.v_s = ctx->want_shat ? ctx->Shat.p : nullptr;
   const int w = use_nonzero ? 1 : 0;
   A.is_c = ctx->has_c[w] ? ctx->is_c[w].p : nullptr;
   A.cval = ctx->has_c[w] ? ctx->cval[w].p : nullptr;
@@ -397,6 +404,9 @@ void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzer
   ctx->assembled = true;
   ctx->auu_f32_valid = false;
   ctx->sm_valid = false;
+  ctx->shat_valid = ctx->want_shat;
+  ctx->shat_aux_valid = false;
+  ctx->asm_constraint_set = use_nonzero ? 1 : 0;
 }
 
 } // namespace ifem

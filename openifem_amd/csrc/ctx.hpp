@@ -114,6 +114,11 @@ struct ifem_ctx {
   ifem::PlanarCsr Mp;  // rows: owned pressure nodes, cols: local pressure nodes, bs = 1     (mass (1,1))
   ifem::PlanarCsr Sm;  // mass_schur(1,1) = B diag(M_u)^-1 B^T, explicit (single rank only; empty otherwise)
   bool sm_valid = false;
+  // scalar velocity operator S^ = mu K + rho C(u) + rho/dt M on the A_uu block pattern (IFEM_AINV_SCALAR_*)
+  ifem::DBuf<double> Shat, shat_dinv;
+  ifem::DBuf<float> Shat_f32;
+  bool want_shat = false, shat_valid = false, shat_aux_valid = false;
+  int asm_constraint_set = 0;
   ifem::DBuf<float> Auu_f32;   // single-precision copy of Auu.val for the inner (preconditioner-only) solver
   bool auu_f32_valid = false, last_spmv_f32 = false;
   ifem::DBuf<double> diagMu;   // diag of mass (0,0), per velocity dof (owned)
@@ -130,6 +135,7 @@ struct ifem_ctx {
   // Krylov workspace
   ifem::DBuf<double> krylovV, krylovZ, innerV, work;
   ifem::DBuf<double> scal; // device scalars for reductions
+  ifem::DBuf<double> partials; // per-block partial sums of the fused dot products [64][4096]
   double *h_scal = nullptr; // pinned host mirror
   ifem::Halo halo;
   bool assembled = false;

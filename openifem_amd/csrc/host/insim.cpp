@@ -159,6 +159,7 @@ ifem_ins_params InsIM<dim>::ins_params() const {
 template <int dim>
 void InsIM<dim>::assemble(const bool use_nonzero_constraints) {
   const ifem_ins_params p = ins_params();
+  check(ifem_set_ainv_kind(ctx, solver_opts.ainv_kind), "assemble");
   check(ifem_ins_assemble(ctx, &p, use_nonzero_constraints), "assemble");
 }
 

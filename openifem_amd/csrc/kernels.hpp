@@ -23,6 +23,10 @@ inline VecLayout layout_of(const ifem_ctx *c) { return {c->dim * c->nUo, c->dim 
 
 // y_u = A_uu x_u (+ B^T x_p when xp != nullptr)
 void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool use_f32);
+// scalar velocity operator S^ (IFEM_AINV_SCALAR_GMRES): auxiliary data, SpMV on all components, Jacobi
+void shat_refresh(ifem_ctx *ctx, bool f32);
+void spmv_shat(ifem_ctx *ctx, const double *xu, double *yu, bool f32);
+void shat_jacobi(ifem_ctx *ctx, const double *x, double *y);
 // y_p = B x_u
 void spmv_b(ifem_ctx *ctx, const double *xu, double *yp);
 // y_u = B^T x_p

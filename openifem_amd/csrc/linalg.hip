@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void k_spmv_planar(int64_t n_rows, const int64
 }
 
 static inline unsigned blocks_for_rows(int64_t n_rows, int G) { return unsigned((n_rows * G + 255) / 256); }
+static inline unsigned vgrid(int64_t n);
 
 __global__ void k_to_f32(int64_t n, const double *__restrict__ a, float *__restrict__ b) {
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) b[i] = float(a[i]);
@@ -139,6 +140,118 @@ void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool
     const int d = ctx->dim;
     ctx->timing.spmv_uu_bytes = double(ctx->Auu.nnzb) * (d * d * (use_f32 ? 4 : 8) + 4) + double(n) * (8 + 2 * d * 8);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Scalar velocity operator (IFEM_AINV_SCALAR_GMRES): A_uu ~ blockdiag_c( P_c S^ P_c + (I - P_c) diag ), one scalar
+// value per node pair applied to all dim components at once: 8 (4) bytes of matrix per block instead of 72 (36).
+template <int DIM, int G, class VT>
+__global__ __launch_bounds__(256) void k_spmv_scalar(int64_t n_rows, const int64_t *__restrict__ rp,
+                                                     const int32_t *__restrict__ col, const VT *__restrict__ val,
+                                                     const uint8_t *__restrict__ is_c, const double *__restrict__ sdiag,
+                                                     const double *__restrict__ x, double *__restrict__ y) {
+  const int64_t row = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  const int lig = threadIdx.x & (G - 1);
+  if (row >= n_rows) return;
+  double acc[DIM];
+#pragma unroll
+  for (int j = 0; j < DIM; ++j) acc[j] = 0;
+  const int64_t rs = rp[row];
+  const int len = int(rp[row + 1] - rs);
+  for (int k = lig; k < len; k += G) {
+    const int32_t c = col[rs + k];
+    const double v = double(val[rs + k]);
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+      double xv = x[int64_t(c) * DIM + j];
+      if (is_c && is_c[int64_t(c) * DIM + j]) xv = 0.0;
+      acc[j] += v * xv;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < DIM; ++j) acc[j] = group_sum<G>(acc[j]);
+  if (lig == 0) {
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+      const bool cst = is_c && is_c[row * DIM + j];
+      y[row * DIM + j] = cst ? sdiag[row] * x[row * DIM + j] : acc[j];
+    }
+  }
+}
+
+__global__ void k_csr_diag(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                           const double *__restrict__ val, double *__restrict__ d) {
+  const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  const int64_t rs = rp[row];
+  int lo = 0, hi = int(rp[row + 1] - rs) - 1;
+  double out = 1.0;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const int32_t v = col[rs + mid];
+    if (v == row) { out = val[rs + mid]; break; }
+    if (v < row) lo = mid + 1; else hi = mid - 1;
+  }
+  d[row] = out;
+}
+
+template <int DIM>
+__global__ void k_node_scale(int64_t n_nodes, const double *__restrict__ d, const double *__restrict__ x, double *__restrict__ y) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_nodes * DIM; i += int64_t(gridDim.x) * blockDim.x)
+    y[i] = x[i] / d[i / DIM];
+}
+
+void shat_refresh(ifem_ctx *ctx, bool f32) {
+  if (!ctx->shat_valid) throw Error(IFEM_E_BADPARAM, "scalar operator not assembled: call ifem_set_ainv_kind before ifem_ins_assemble");
+  if (ctx->shat_aux_valid) return;
+  const int64_t n = ctx->nUo, nnz = (int64_t)ctx->Shat.n;
+  if (ctx->shat_dinv.n != (size_t)n) ctx->shat_dinv.alloc(n);
+  if (n) hipLaunchKernelGGL(k_csr_diag, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ctx->Auu.rowptr.p,
+                            ctx->Auu.col.p, ctx->Shat.p, ctx->shat_dinv.p);
+  if (f32) {
+    if (ctx->Shat_f32.n != (size_t)nnz) ctx->Shat_f32.alloc(nnz);
+    if (nnz) hipLaunchKernelGGL(k_to_f32, dim3(8192), dim3(256), 0, ctx->stream, nnz, ctx->Shat.p, ctx->Shat_f32.p);
+  }
+  ctx->shat_aux_valid = true;
+}
+
+// y_u = S^ x_u per component with the constrained dofs of set `cset` kept as scaled identity rows
+void spmv_shat(ifem_ctx *ctx, const double *xu, double *yu, bool f32) {
+  const int64_t n = ctx->nUo;
+  if (n == 0) return;
+  hipStream_t s = ctx->stream;
+  const int cset = ctx->asm_constraint_set;
+  const uint8_t *isc = ctx->has_c[cset] ? ctx->is_c[cset].p : nullptr;
+  const bool time_it = ctx->profile;
+  if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s));
+  if (ctx->dim == 3) {
+    if (f32) hipLaunchKernelGGL((k_spmv_scalar<3, 32, float>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
+                                ctx->Auu.col.p, ctx->Shat_f32.p, isc, ctx->shat_dinv.p, xu, yu);
+    else hipLaunchKernelGGL((k_spmv_scalar<3, 32, double>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
+                            ctx->Auu.col.p, ctx->Shat.p, isc, ctx->shat_dinv.p, xu, yu);
+  } else {
+    if (f32) hipLaunchKernelGGL((k_spmv_scalar<2, 16, float>), dim3(blocks_for_rows(n, 16)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
+                                ctx->Auu.col.p, ctx->Shat_f32.p, isc, ctx->shat_dinv.p, xu, yu);
+    else hipLaunchKernelGGL((k_spmv_scalar<2, 16, double>), dim3(blocks_for_rows(n, 16)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
+                            ctx->Auu.col.p, ctx->Shat.p, isc, ctx->shat_dinv.p, xu, yu);
+  }
+  if (time_it) {
+    IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+    IFEM_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    IFEM_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->spmv_uu_ms_total += ms;
+    ctx->timing.spmv_uu_calls++;
+    const int d = ctx->dim;
+    ctx->timing.spmv_uu_bytes = double(ctx->Auu.nnzb) * ((f32 ? 4 : 8) + 4) + double(n) * (8 + 2 * d * 8 + 2 * d + 8);
+  }
+}
+
+void shat_jacobi(ifem_ctx *ctx, const double *x, double *y) {
+  const int64_t n = ctx->nUo;
+  if (!n) return;
+  if (ctx->dim == 3) hipLaunchKernelGGL((k_node_scale<3>), dim3(vgrid(n * 3)), dim3(256), 0, ctx->stream, n, ctx->shat_dinv.p, x, y);
+  else hipLaunchKernelGGL((k_node_scale<2>), dim3(vgrid(n * 2)), dim3(256), 0, ctx->stream, n, ctx->shat_dinv.p, x, y);
 }
 
 void spmv_b(ifem_ctx *ctx, const double *xu, double *yp) {
@@ -292,9 +405,12 @@ void dinv_setup(ifem_ctx *ctx) {
   if (n) hipLaunchKernelGGL(k_recip, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, ctx->diagMu.p, ctx->dinvMu.p);
 }
 
-// block reduction helper: sums K values per thread across the block, thread 0 of each wave adds atomically
+// Two-stage reduction: every block writes one partial per dot product (same-address atomics serialise in L2:
+// 16k of them cost more than streaming the vectors), k_reduce_final sums the partials.  Deterministic.
+constexpr int MDOT_MAXB = 4096;
 template <int K>
-__device__ inline void block_reduce_atomic(double *v, double *out) {
+__device__ inline void block_reduce_store(double *v, double *part /* [k][MDOT_MAXB] */) {
+  __shared__ double sh[4][K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     double t = v[k];
@@ -302,10 +418,28 @@ __device__ inline void block_reduce_atomic(double *v, double *out) {
     for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
     v[k] = t;
   }
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) unsafeAtomicAdd(&out[k], v[k]);
+    for (int k = 0; k < K; ++k) sh[wave][k] = v[k];
   }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double t = 0;
+    for (int w = 0; w < int(blockDim.x >> 6); ++w) t += sh[w][threadIdx.x];
+    part[int64_t(threadIdx.x) * MDOT_MAXB + blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_final(int nblk, const double *__restrict__ part, double *__restrict__ out) {
+  const int k = blockIdx.x;
+  double t = 0;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) t += part[int64_t(k) * MDOT_MAXB + i];
+  __shared__ double sh[4];
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) out[k] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
 template <int K>
@@ -319,7 +453,7 @@ __global__ __launch_bounds__(256) void k_mdot(int64_t n, int k0, const double *_
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] += V[int64_t(k0 + k) * ld + i] * wi;
   }
-  block_reduce_atomic<K>(acc, out + k0);
+  block_reduce_store<K>(acc, out + int64_t(k0) * MDOT_MAXB);
 }
 
 template <int K>
@@ -339,15 +473,18 @@ __global__ __launch_bounds__(256) void k_maxpy(int64_t n, int k0, const double *
 // out_host[i] = <V_i, w>, i < k.  Device scalars live in ctx->scal[0..63]; result is NOT all-reduced.
 void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *w, double *out_host) {
   hipStream_t s = ctx->stream;
-  IFEM_HIP_CHECK(hipMemsetAsync(ctx->scal.p, 0, 64 * sizeof(double), s));
+  if (ctx->partials.n == 0) ctx->partials.alloc(size_t(64) * MDOT_MAXB);
+  if (n == 0) { for (int i = 0; i < k; ++i) out_host[i] = 0; return; }
+  const unsigned nblk = vgrid(n);
   int k0 = 0;
   while (k0 < k && n > 0) {
     const int r = k - k0;
-    if (r >= 8) { hipLaunchKernelGGL((k_mdot<8>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, w, ctx->scal.p); k0 += 8; }
-    else if (r >= 4) { hipLaunchKernelGGL((k_mdot<4>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, w, ctx->scal.p); k0 += 4; }
-    else if (r >= 2) { hipLaunchKernelGGL((k_mdot<2>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, w, ctx->scal.p); k0 += 2; }
-    else { hipLaunchKernelGGL((k_mdot<1>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, w, ctx->scal.p); k0 += 1; }
+    if (r >= 8) { hipLaunchKernelGGL((k_mdot<8>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, w, ctx->partials.p); k0 += 8; }
+    else if (r >= 4) { hipLaunchKernelGGL((k_mdot<4>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, w, ctx->partials.p); k0 += 4; }
+    else if (r >= 2) { hipLaunchKernelGGL((k_mdot<2>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, w, ctx->partials.p); k0 += 2; }
+    else { hipLaunchKernelGGL((k_mdot<1>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, w, ctx->partials.p); k0 += 1; }
   }
+  hipLaunchKernelGGL(k_reduce_final, dim3(k), dim3(256), 0, s, (int)nblk, ctx->partials.p, ctx->scal.p);
   IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->scal.p, k * sizeof(double), hipMemcpyDeviceToHost, s));
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
   for (int i = 0; i < k; ++i) out_host[i] = ctx->h_scal[i];

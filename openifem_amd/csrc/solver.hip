@@ -221,7 +221,10 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   Clock ck3;
   const bool f32 = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32;
   OpFn Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_uu(c, xe, nullptr, y, f32); };
-  OpFn Pj = [&](const double *x, double *y) { bjac_apply(c, x, y); };
+  const bool scalar_op = o->ainv_kind == IFEM_AINV_SCALAR_GMRES;
+  if (scalar_op) shat_refresh(c, true);
+  if (scalar_op) Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_shat(c, xe, y, true); };
+  OpFn Pj = [&](const double *x, double *y) { if (scalar_op) shat_jacobi(c, x, y); else bjac_apply(c, x, y); };
   auto mdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
     v_mdot(c, S.nuo, k, V, ld, w, out);
     allreduce_sum(c, out, k);

@@ -219,3 +219,29 @@ def test_no_cpu_fallback_error_path():
     capi = _capi()
     L = capi.load()
     assert L.ifem_device_count() >= 1
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+def test_solve_with_cheaper_ainv_variants(kind):
+    # IFEM_AINV_GMRES_BJACOBI_F32 (1) and IFEM_AINV_SCALAR_GMRES (2) only change the preconditioner: the FGMRES result
+    # must still satisfy the reference stopping rule against the ORACLE's fp64 matrix
+    capi = _capi()
+    m = BoxMesh((8, 8, 8), (0, 0, 0), (2.0, 0.2, 0.2), kv=2)
+    dofs, vals, present, ev, kw = channel3d_state(m)
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.vec_set(capi.VEC_PRESENT, present)
+    ctx.vec_set(capi.VEC_EVAL, ev)
+    P = capi.make_params(**kw)
+    ctx.opts.ainv_kind = kind
+    assert ctx.L.ifem_set_ainv_kind(ctx.h, kind) == 0
+    ctx.assemble(P, False)
+    st = ctx.solve(P, False)
+    upd = ctx.vec_get(capi.VEC_UPDATE)
+    S = orc.System(m)
+    S.set_constraints(0, dofs, None)
+    S.assemble(orc.make_params(**kw), False, ev, present)
+    A, b = S.csr("A"), S.rhs()
+    assert np.linalg.norm(A @ upd - b) <= 1.05e-4 * np.linalg.norm(b)
+    assert st.fgmres_iters <= 12
