@@ -134,6 +134,7 @@ int ifem_set_constraints(ifem_ctx *ctx, int which, int32_t n, const int32_t *dof
   ctx->cval[which].upload(v.data(), v.size(), ctx->stream);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   ctx->has_c[which] = n > 0;
+  ctx->constraints_epoch++;
   IFEM_API_END
 }
 

@@ -403,7 +403,12 @@ void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzer
   ctx->timing.assemble_kernel_ms = ms;
   ctx->assembled = true;
   ctx->auu_f32_valid = false;
-  ctx->sm_valid = false;
+  // S_m = B diag(M_u)^-1 B^T depends only on the mesh and on WHICH dofs are constrained (not on the solution):
+  // keep it across assemblies until the constraint set changes (the reference rebuilds it every solve(); same values)
+  {
+    const int64_t key = ctx->constraints_epoch * 2 + (use_nonzero ? 1 : 0);
+    if (key != ctx->sm_key) { ctx->sm_valid = false; ctx->sm_key = key; }
+  }
   ctx->shat_valid = ctx->want_shat;
   ctx->shat_aux_valid = false;
   ctx->asm_constraint_set = use_nonzero ? 1 : 0;

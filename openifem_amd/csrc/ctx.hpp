@@ -114,6 +114,7 @@ struct ifem_ctx {
   ifem::PlanarCsr Mp;  // rows: owned pressure nodes, cols: local pressure nodes, bs = 1     (mass (1,1))
   ifem::PlanarCsr Sm;  // mass_schur(1,1) = B diag(M_u)^-1 B^T, explicit (single rank only; empty otherwise)
   bool sm_valid = false;
+  int64_t sm_key = -1, constraints_epoch = 0;
   // scalar velocity operator S^ = mu K + rho C(u) + rho/dt M on the A_uu block pattern (IFEM_AINV_SCALAR_*)
   ifem::DBuf<double> Shat, shat_dinv;
   ifem::DBuf<float> Shat_f32;

@@ -245,3 +245,23 @@ def test_solve_with_cheaper_ainv_variants(kind):
     A, b = S.csr("A"), S.rhs()
     assert np.linalg.norm(A @ upd - b) <= 1.05e-4 * np.linalg.norm(b)
     assert st.fgmres_iters <= 12
+
+
+def test_kat_fluid_cylinder_mpi_on_gpu():
+    # config "tests/fluid_cylinder_mpi 2D flow past cylinder, mpi_insim, 1xMI355X": the reference's regression
+    # constants vmax = 0.374235, pmax = 46.5226 (1e-3) through the HIP path on the unstructured cylinder mesh
+    from cylmesh import CylinderMesh, inflow_bc
+    capi = _capi()
+    m = CylinderMesh(3)
+    dofs, vals = m.dirichlet({0: (3, [0.2, 0]), 2: (3, [0, 0]), 3: (3, [0, 0]), 4: (3, [0, 0])}, {0: inflow_bc})
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.opts.inner_rel = 1e-3
+    ctx.opts.inner_maxit = 4000
+    n_it, log = ctx.newton_step(capi.make_params(mu=0.001, rho=1, gamma=0.1, dt=1e-2), True)
+    assert n_it > 0
+    _, vmax = ctx.minmax(capi.VEC_PRESENT, 0)
+    _, pmax = ctx.minmax(capi.VEC_PRESENT, 1)
+    assert abs(vmax - 0.374235) / 0.374235 < 1e-3
+    assert abs(pmax - 46.5226) / 46.5226 < 1e-3

@@ -116,3 +116,20 @@ def test_cell_matrix_structure():
     assert np.allclose(Ke2[nu:, :], Ke[nu:, :]) and np.allclose(Ke2[:, nu:], Ke[:, nu:])
     assert not np.allclose(Ke2[:nu, :nu], Ke2[:nu, :nu].T)
     assert np.allclose(Ke[nu:, nu:], 0)
+
+
+def test_fluid_cylinder_mpi_regression_constants():
+    # tests/fluid_cylinder_mpi/fluid_cylinder_mpi.cpp:89-96: MPI::InsIM<2>, cylinder mesh + 3 global refinements
+    # (5 888 cells, 54 192 DoF = 48 064 + 6 128), one step dt = 1e-2, parabolic inflow Umax = 0.3:
+    # vmax = 0.374235, pmax = 46.5226 at 1e-3 -- the only regression constants of the reference for mpi_insim.
+    # The oracle reproduces them to < 1e-6, which pins assembly on non-affine cells, inhomogeneous constraints
+    # and the Newton loop against real reference output.
+    from cylmesh import CylinderMesh, inflow_bc
+    m = CylinderMesh(3)
+    assert (m.n_cells, m.n_u, m.n_pnodes) == (5888, 48064, 6128)
+    P = orc.make_params(mu=0.001, rho=1, gamma=0.1, dt=1e-2)
+    bcs = {0: (3, [0.2, 0]), 2: (3, [0, 0]), 3: (3, [0, 0]), 4: (3, [0, 0])}
+    S, x = _run(m, bcs, P, 1, fields={0: inflow_bc})
+    vmax, pmax = x[:S.n_u].max(), x[S.n_u:].max()
+    assert abs(vmax - 0.374235) / 0.374235 < 1e-5
+    assert abs(pmax - 46.5226) / 46.5226 < 1e-5
