@@ -265,3 +265,25 @@ def test_kat_fluid_cylinder_mpi_on_gpu():
     _, pmax = ctx.minmax(capi.VEC_PRESENT, 1)
     assert abs(vmax - 0.374235) / 0.374235 < 1e-3
     assert abs(pmax - 46.5226) / 46.5226 < 1e-3
+
+
+def test_kat_fluid_cylinder_serial_100_steps_on_gpu():
+    # tests/fluid_cylinder (serial InsIM<2>): 100 time steps on the once-refined cylinder mesh, vmax = 0.4064759,
+    # pmax = 0.1539404 (1e-3) through the HIP Newton loop
+    from cylmesh import CylinderMesh, inflow_bc
+    capi = _capi()
+    m = CylinderMesh(1)
+    dofs, vals = m.dirichlet({0: (3, [0.2, 0]), 2: (3, [0, 0]), 3: (3, [0, 0]), 4: (3, [0, 0])}, {0: inflow_bc})
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.opts.inner_rel = 1e-3
+    ctx.opts.inner_maxit = 4000
+    P = capi.make_params(mu=0.001, rho=1, gamma=0.1, dt=1e-2)
+    for step in range(100):
+        n_it, _ = ctx.newton_step(P, step == 0)
+        assert n_it > 0
+    _, vmax = ctx.minmax(capi.VEC_PRESENT, 0)
+    _, pmax = ctx.minmax(capi.VEC_PRESENT, 1)
+    assert abs(vmax - 0.4064759) / 0.4064759 < 1e-3
+    assert abs(pmax - 0.1539404) / 0.1539404 < 1e-3

@@ -133,3 +133,17 @@ def test_fluid_cylinder_mpi_regression_constants():
     vmax, pmax = x[:S.n_u].max(), x[S.n_u:].max()
     assert abs(vmax - 0.374235) / 0.374235 < 1e-5
     assert abs(pmax - 46.5226) / 46.5226 < 1e-5
+
+
+def test_fluid_cylinder_serial_regression_constants():
+    # tests/fluid_cylinder/fluid_cylinder.cpp:83-85 (serial InsIM<2>, same integrals as MPI::InsIM): cylinder mesh with
+    # 1 refinement (368 cells), 100 time steps dt = 1e-2: vmax = 0.4064759, pmax = 0.1539404 at 1e-3.
+    # Pins the time loop (Newton restarts, zero constraints after the first step) over 100 steps: oracle error ~3e-8.
+    from cylmesh import CylinderMesh, inflow_bc
+    m = CylinderMesh(1)
+    P = orc.make_params(mu=0.001, rho=1, gamma=0.1, dt=1e-2)
+    bcs = {0: (3, [0.2, 0]), 2: (3, [0, 0]), 3: (3, [0, 0]), 4: (3, [0, 0])}
+    S, x = _run(m, bcs, P, 100, fields={0: inflow_bc})
+    vmax, pmax = x[:S.n_u].max(), x[S.n_u:].max()
+    assert abs(vmax - 0.4064759) / 0.4064759 < 1e-6
+    assert abs(pmax - 0.1539404) / 0.1539404 < 1e-6
