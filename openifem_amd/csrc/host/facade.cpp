@@ -54,6 +54,31 @@ int ifemx_insim_create_box(const char *prm_text, int dim, const unsigned *reps, 
   });
 }
 
+// tests/fluid_cylinder_mpi driver: AllParameters(prm) + GridCreator<2>::flow_around_cylinder(tria) + InsIM<2>(tria, params)
+int ifemx_insim_create_cylinder(const char *prm_text, int device, int verbose, void **out) {
+  return guard([&] {
+    auto params = Parameters::AllParameters::from_string(prm_text);
+    if (params.dimension != 2) throw std::invalid_argument("the cylinder mesh of this build is 2D");
+    auto *h = new Handle();
+    h->dim = 2;
+    h->t2.reset(new Triangulation<2>());
+    Utils::GridCreator<2>::flow_around_cylinder(*h->t2);
+    h->s2.reset(new Fluid::MPI::InsIM<2>(*h->t2, params, device));
+    h->s2->pcout = verbose ? &std::cout : nullptr;
+    *out = h;
+  });
+}
+
+// FluidSolver::add_hard_coded_boundary_condition(id, f): f(point[dim], component, time) -> value
+typedef double (*ifemx_bc_fn)(const double *point, unsigned component, double time);
+int ifemx_add_hard_coded_boundary_condition(void *hv, int id, ifemx_bc_fn fn) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) h->s2->add_hard_coded_boundary_condition(id, [fn](const std::array<double, 2> &p, unsigned c, double t) { return fn(p.data(), c, t); });
+    else h->s3->add_hard_coded_boundary_condition(id, [fn](const std::array<double, 3> &p, unsigned c, double t) { return fn(p.data(), c, t); });
+  });
+}
+
 void ifemx_destroy(void *hv) { delete static_cast<Handle *>(hv); }
 
 // rank `rank` of a P[0] x P[1] x P[2] block partition; call before ifemx_setup.  Transport: nccl_unique_id (128 B)

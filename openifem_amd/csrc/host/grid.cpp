@@ -1,6 +1,8 @@
 // grid.cpp -- see grid.hpp.
 #include "grid.hpp"
 #include <cmath>
+#include <functional>
+#include <map>
 #include <numeric>
 
 namespace ifem_host {
@@ -57,7 +59,13 @@ template void subdivided_hyper_rectangle<3>(Triangulation<3> &, const std::vecto
 template <int dim>
 void Triangulation<dim>::refine_global(int times) {
   if (times <= 0) return;
-  if (!is_box) throw std::runtime_error("refine_global: only box triangulations are supported in this build");
+  if (!is_box) {
+    if (!generator) throw std::runtime_error("refine_global: triangulation has neither box metadata nor a generator");
+    level += times;
+    auto gen = generator; // the generator rewrites *this
+    gen(*this, level);
+    return;
+  }
   std::vector<unsigned> r(dim);
   for (int d = 0; d < dim; ++d) r[d] = (unsigned)reps[d] << times;
   std::array<double, dim> a, b;
@@ -67,6 +75,160 @@ void Triangulation<dim>::refine_global(int times) {
 }
 template struct Triangulation<2>;
 template struct Triangulation<3>;
+
+namespace Utils {
+// The refined mesh is generated directly at `level`: bulk cells refine uniformly; in the 8 ring cells deal.II's
+// TransfiniteInterpolationManifold (one curved edge: the PolarManifold arc) reduces to
+//   x(xi, eta) = (1 - xi) Arc(eta) + xi Out(eta)
+// evaluated at the dyadic points (new vertices are chart-space averages pushed forward).  merge_triangulations keeps
+// the bulk's coordinates for the seam vertices; the circle is re-centred to (0.2, 0.2) (utilities.cpp:451-479).
+static void cylinder_2d(Triangulation<2> &tria, int level) {
+  const int s = 1 << level;
+  const double hx = 2.2 / 22, hy = 0.41 / 4, r_in = 0.05, PI = 3.14159265358979323846;
+  const double cx = 0.2, cy = 0.2, sx = 0.2, sy = 0.205;
+  const double O[8][2] = {{sx + 0.1, sy}, {sx + 0.1, sy + 0.1025}, {sx, sy + 0.1025}, {sx - 0.1, sy + 0.1025},
+                          {sx - 0.1, sy}, {sx - 0.1, sy - 0.1025}, {sx, sy - 0.1025}, {sx + 0.1, sy - 0.1025}};
+  tria.is_box = false;
+  tria.vertices.clear(); tria.cells.clear(); tria.face_bid.clear();
+  std::map<std::pair<long long, long long>, int32_t> vid;
+  auto vertex = [&](double x, double y) {
+    const std::pair<long long, long long> key{std::llround(x * 1e9), std::llround(y * 1e9)};
+    auto it = vid.find(key);
+    if (it != vid.end()) return it->second;
+    const int32_t id = (int32_t)tria.vertices.size();
+    vid[key] = id;
+    tria.vertices.push_back({x, y});
+    return id;
+  };
+  std::vector<int32_t> ids((size_t)(s + 1) * (s + 1));
+  auto emit_patch = [&](const std::function<void(double, double, double &, double &)> &map) {
+    for (int b = 0; b <= s; ++b)
+      for (int a = 0; a <= s; ++a) {
+        double x, y;
+        map(double(a) / s, double(b) / s, x, y);
+        ids[(size_t)a * (s + 1) + b] = vertex(x, y);
+      }
+    for (int b = 0; b < s; ++b)
+      for (int a = 0; a < s; ++a)
+        tria.cells.push_back({ids[(size_t)a * (s + 1) + b], ids[(size_t)(a + 1) * (s + 1) + b],
+                              ids[(size_t)a * (s + 1) + b + 1], ids[(size_t)(a + 1) * (s + 1) + b + 1]});
+  };
+  for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 22; ++i) {
+      if ((i == 1 || i == 2) && (j == 1 || j == 2)) continue; // cells within 0.15 of (0.2, 0.2) are removed
+      emit_patch([&](double xi, double eta, double &x, double &y) { x = (i + xi) * hx; y = (j + eta) * hy; });
+    }
+  for (int k = 0; k < 8; ++k)
+    emit_patch([&](double xi, double eta, double &x, double &y) {
+      const double th = 2 * PI * k / 8 + eta * (PI / 4);
+      const double ax = cx + r_in * std::cos(th), ay = cy + r_in * std::sin(th);
+      const double ox = (1 - eta) * O[k][0] + eta * O[(k + 1) % 8][0], oy = (1 - eta) * O[k][1] + eta * O[(k + 1) % 8][1];
+      x = (1 - xi) * ax + xi * ox; y = (1 - xi) * ay + xi * oy;
+    });
+  // boundary faces = edges used by one cell; ids from the face centre (utilities.cpp:493-523)
+  static const int fv[4][2] = {{0, 2}, {1, 3}, {0, 1}, {2, 3}};
+  std::map<std::pair<int32_t, int32_t>, int> count;
+  for (auto &c : tria.cells)
+    for (auto &f : fv) count[{std::min(c[f[0]], c[f[1]]), std::max(c[f[0]], c[f[1]])}]++;
+  tria.face_bid.assign(tria.cells.size(), {-1, -1, -1, -1});
+  for (size_t ci = 0; ci < tria.cells.size(); ++ci)
+    for (int f = 0; f < 4; ++f) {
+      const auto &c = tria.cells[ci];
+      if (count[{std::min(c[fv[f][0]], c[fv[f][1]]), std::max(c[fv[f][0]], c[fv[f][1]])}] != 1) continue;
+      const double mx = 0.5 * (tria.vertices[c[fv[f][0]]][0] + tria.vertices[c[fv[f][1]]][0]);
+      const double my = 0.5 * (tria.vertices[c[fv[f][0]]][1] + tria.vertices[c[fv[f][1]]][1]);
+      int id = 4;
+      if (std::abs(mx - 2.2) < 1e-12) id = 1;
+      else if (std::abs(mx) < 1e-12) id = 0;
+      else if (std::abs(my - 0.41) < 1e-12) id = 3;
+      else if (std::abs(my) < 1e-12) id = 2;
+      tria.face_bid[ci][f] = id;
+    }
+}
+
+template <>
+void GridCreator<2>::flow_around_cylinder(Triangulation<2> &tria) {
+  tria.level = 0;
+  tria.generator = [](Triangulation<2> &t, int level) {
+    auto gen = t.generator;
+    const int lv = level;
+    cylinder_2d(t, lv);
+    t.generator = gen;
+    t.level = lv;
+  };
+  cylinder_2d(tria, 0);
+}
+template <>
+void GridCreator<3>::flow_around_cylinder(Triangulation<3> &) {
+  throw std::runtime_error("GridCreator<3>::flow_around_cylinder (extruded mesh) is not built yet");
+}
+} // namespace Utils
+
+template <int dim>
+void distribute_dofs_unstructured(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out, PartitionTables &part) {
+  if constexpr (dim != 2) {
+    throw std::runtime_error("distribute_dofs: unstructured 3D triangulations are not supported in this build");
+  } else {
+    const size_t nc = tria.cells.size(), nV = tria.vertices.size();
+    const int n1 = kv + 1, nu = n1 * n1;
+    out.kv = kv; out.nu = nu; out.np = 4;
+    out.vcoords.resize(nc * 8);
+    out.cell_face_bid.resize(nc * 4);
+    out.cell_pnodes.resize(nc * 4);
+    out.cell_unodes.resize(nc * nu);
+    for (size_t c = 0; c < nc; ++c)
+      for (int v = 0; v < 4; ++v) {
+        out.vcoords[(c * 4 + v) * 2] = tria.vertices[tria.cells[c][v]][0];
+        out.vcoords[(c * 4 + v) * 2 + 1] = tria.vertices[tria.cells[c][v]][1];
+        out.cell_pnodes[c * 4 + v] = tria.cells[c][v];
+        out.cell_face_bid[c * 4 + v] = tria.face_bid[c][v];
+      }
+    out.pnode_coords.assign(tria.vertices.begin(), tria.vertices.end());
+    out.n_pnodes = out.n_pnodes_owned = (int64_t)nV;
+    if (kv == 1) {
+      out.cell_unodes = out.cell_pnodes;
+      out.unode_coords = out.pnode_coords;
+      out.n_unodes = out.n_unodes_owned = (int64_t)nV;
+    } else {
+      // Q2: vertices, then edge midpoints (one per vertex pair), then cell centres; local order x fastest
+      static const int ev[4][3] = {{1, 0, 1}, {3, 0, 2}, {5, 1, 3}, {7, 2, 3}}; // local node, vertex a, vertex b
+      static const int vloc[4] = {0, 2, 6, 8};
+      std::map<std::pair<int32_t, int32_t>, int32_t> eid;
+      out.unode_coords.assign(tria.vertices.begin(), tria.vertices.end());
+      for (size_t c = 0; c < nc; ++c) {
+        const auto &cv = tria.cells[c];
+        for (int v = 0; v < 4; ++v) out.cell_unodes[c * 9 + vloc[v]] = cv[v];
+        for (auto &e : ev) {
+          const std::pair<int32_t, int32_t> key{std::min(cv[e[1]], cv[e[2]]), std::max(cv[e[1]], cv[e[2]])};
+          auto it = eid.find(key);
+          if (it == eid.end()) {
+            it = eid.emplace(key, (int32_t)out.unode_coords.size()).first;
+            out.unode_coords.push_back({0.5 * (tria.vertices[cv[e[1]]][0] + tria.vertices[cv[e[2]]][0]),
+                                        0.5 * (tria.vertices[cv[e[1]]][1] + tria.vertices[cv[e[2]]][1])});
+          }
+          out.cell_unodes[c * 9 + e[0]] = it->second;
+        }
+      }
+      for (size_t c = 0; c < nc; ++c) {
+        const auto &cv = tria.cells[c];
+        out.cell_unodes[c * 9 + 4] = (int32_t)out.unode_coords.size();
+        double x = 0, y = 0;
+        for (int v = 0; v < 4; ++v) { x += 0.25 * tria.vertices[cv[v]][0]; y += 0.25 * tria.vertices[cv[v]][1]; }
+        out.unode_coords.push_back({x, y});
+      }
+      out.n_unodes = out.n_unodes_owned = (int64_t)out.unode_coords.size();
+    }
+    part = PartitionTables();
+    part.l2g_u.resize((size_t)out.n_unodes);
+    part.l2g_p.resize((size_t)out.n_pnodes);
+    std::iota(part.l2g_u.begin(), part.l2g_u.end(), 0);
+    std::iota(part.l2g_p.begin(), part.l2g_p.end(), 0);
+    part.send_u_ptr = part.recv_u_ptr = part.send_p_ptr = part.recv_p_ptr = {0};
+    part.n_unodes_global = out.n_unodes; part.n_pnodes_global = out.n_pnodes; part.n_cells_global = (int64_t)nc;
+  }
+}
+template void distribute_dofs_unstructured<2>(const Triangulation<2> &, int, DoFTables<2> &, PartitionTables &);
+template void distribute_dofs_unstructured<3>(const Triangulation<3> &, int, DoFTables<3> &, PartitionTables &);
 
 template <int dim>
 static void map_point(const double *X /*[NV][dim]*/, const double *xi, double *out) {

@@ -28,8 +28,22 @@ struct Triangulation {
   std::array<double, 3> p0{0, 0, 0}, p1{1, 1, 1};
   // box triangulations may be "lazy": only the metadata is kept and cells are generated per rank on demand
   size_t n_active_cells() const { return is_box ? size_t(reps[0]) * reps[1] * reps[2] : cells.size(); }
+  // unstructured triangulations built by a generator (Utils::GridCreator) are re-generated at the new level by
+  // refine_global: the generator places the new vertices on the manifolds the reference attaches
+  std::function<void(Triangulation<dim> &, int level)> generator;
+  int level = 0;
   void refine_global(int times);
 };
+
+namespace Utils {
+// GridCreator<2>::flow_around_cylinder (reference source/utilities.cpp:345-524): the DFG cylinder benchmark mesh,
+// 22 x 4 bulk cells with the 8-cell polar/transfinite ring around the cylinder, boundary ids 0 inflow, 1 outflow,
+// 2 y=0, 3 y=0.41, 4 cylinder.
+template <int dim>
+struct GridCreator {
+  static void flow_around_cylinder(Triangulation<dim> &tria);
+};
+} // namespace Utils
 
 namespace GridGenerator {
 template <int dim>
@@ -76,6 +90,9 @@ void distribute_dofs_box(const std::array<int, 3> &reps, const std::array<double
 
 template <int dim>
 void distribute_dofs(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out);
+// general (unstructured, single rank) variant: vertices, edge midpoints, cell centres; 2D only in this build
+template <int dim>
+void distribute_dofs_unstructured(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out, PartitionTables &part);
 
 // Dirichlet lines (dof, value) in block numbering [u|p]; `bcs`: id -> (component flag 1..7, values);
 // `hard_coded`: id -> f(point, component) overriding the constant values (add_hard_coded_boundary_condition).

@@ -65,7 +65,10 @@ void FluidSolver<dim>::set_partition(const std::array<int, 3> &P, int rank, cons
 
 template <int dim>
 void FluidSolver<dim>::setup_dofs() {
-  if (!triangulation.is_box) throw std::runtime_error("setup_dofs: unstructured triangulations are not supported in this build");
+  if (!triangulation.is_box) {
+    if (proc_grid[0] * proc_grid[1] * proc_grid[2] != 1) throw std::runtime_error("setup_dofs: unstructured triangulations run on one rank in this build");
+    distribute_dofs_unstructured<dim>(triangulation, (int)parameters.fluid_velocity_degree, dofs, part);
+  } else
   distribute_dofs_box<dim>(triangulation.reps, triangulation.p0, triangulation.p1, triangulation.colorized,
                            (int)parameters.fluid_velocity_degree, proc_grid, part_rank, dofs, part);
   dofs_per_block = {(size_t)(dim * part.n_unodes_global), (size_t)part.n_pnodes_global};

@@ -12,6 +12,9 @@ class HostError(RuntimeError):
         self.code = code
 
 
+BC_FN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_uint, C.c_double)
+
+
 def _lib():
     L = capi.load()
     if getattr(L, "_ifemx_bound", False):
@@ -20,6 +23,8 @@ def _lib():
     L.ifemx_insim_create_box.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                          C.POINTER(C.c_void_p)]
     L.ifemx_destroy.argtypes = [C.c_void_p]
+    L.ifemx_insim_create_cylinder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.ifemx_add_hard_coded_boundary_condition.argtypes = [C.c_void_p, C.c_int, BC_FN]
     L.ifemx_run.argtypes = [C.c_void_p]
     L.ifemx_setup.argtypes = [C.c_void_p, C.c_int]
     L.ifemx_run_one_step.argtypes = [C.c_void_p, C.c_int]
@@ -47,8 +52,14 @@ def _lib():
 class InsIM:
     """Fluid::MPI::InsIM<dim> on a colorised subdivided_hyper_rectangle, configured by a .prm text."""
 
-    def __init__(self, prm_text, reps, p0, p1, device=0, verbose=False):
+    def __init__(self, prm_text, reps=None, p0=None, p1=None, device=0, verbose=False, mesh="box"):
         self.L = _lib()
+        self._bc_keep = []
+        if mesh == "cylinder":  # Utils::GridCreator<2>::flow_around_cylinder
+            self.dim = 2
+            self.h = C.c_void_p()
+            self._chk(self.L.ifemx_insim_create_cylinder(prm_text.encode(), device, int(verbose), C.byref(self.h)))
+            return
         self.dim = len(reps)
         r = np.ascontiguousarray(reps, np.uint32)
         a, b = np.ascontiguousarray(p0, float), np.ascontiguousarray(p1, float)
@@ -71,6 +82,13 @@ class InsIM:
             self.close()
         except Exception:
             pass
+
+    def add_hard_coded_boundary_condition(self, bid, fn):
+        """fn(point: tuple, component: int, time: float) -> float, as FluidSolver::add_hard_coded_boundary_condition"""
+        dim = self.dim
+        cb = BC_FN(lambda p, c, t: float(fn(tuple(p[i] for i in range(dim)), int(c), float(t))))
+        self._bc_keep.append(cb)
+        self._chk(self.L.ifemx_add_hard_coded_boundary_condition(self.h, bid, cb))
 
     def set_partition(self, P, rank, nccl_unique_id=None, local_world=None):
         """rank `rank` of a P[0] x P[1] x P[2] block partition; call before setup()."""

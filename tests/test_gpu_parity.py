@@ -287,3 +287,26 @@ def test_kat_fluid_cylinder_serial_100_steps_on_gpu():
     _, pmax = ctx.minmax(capi.VEC_PRESENT, 1)
     assert abs(vmax - 0.4064759) / 0.4064759 < 1e-3
     assert abs(pmax - 0.1539404) / 0.1539404 < 1e-3
+
+
+def test_reference_driver_fluid_cylinder_mpi_through_host_mirror():
+    # the reference test driver, line for line (tests/fluid_cylinder_mpi/fluid_cylinder_mpi.cpp:82-96) on the C++ host
+    # mirror: AllParameters(prm) -> GridCreator<2>::flow_around_cylinder -> InsIM<2> -> add_hard_coded_boundary_condition
+    # -> run() -> PETScVectorMax of the velocity / pressure blocks, with the reference's own .prm file
+    import os
+    from openifem_amd import host
+    prm = open(os.path.join(os.path.dirname(__file__), "golden", "prm", "fluid_cylinder_mpi.prm")).read()
+
+    def inflow_bc(p, component, time):
+        if component == 0 and abs(p[0]) < 1e-10:
+            return 4 * 0.3 * p[1] * (0.41 - p[1]) / (0.41 * 0.41)
+        return 0.0
+
+    flow = host.InsIM(prm, mesh="cylinder")
+    flow.add_hard_coded_boundary_condition(0, inflow_bc)
+    flow.opts.inner_rel = 1e-3
+    flow.opts.inner_maxit = 4000
+    flow.run()
+    v, p = flow.get_current_solution()
+    assert abs(v.max() - 0.374235) / 0.374235 < 1e-3
+    assert abs(p.max() - 46.5226) / 46.5226 < 1e-3
