@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -70,6 +71,7 @@ int ifem_ctx_create(const ifem_mesh_desc *m, const ifem_partition *part, int dev
   }
   IFEM_HIP_CHECK(hipHostMalloc((void **)&ctx->h_scal, 256 * sizeof(double)));
   ctx->scal.alloc(256);
+  if (const char *e = getenv("IFEM_ASM")) ctx->asm_rows = std::string(e) == "rows";
   comm_init(ctx, part);
   {
     double g[2] = {double(ctx->dim * ctx->nUo), double(ctx->nPo)};

@@ -354,9 +354,16 @@ static void launch_t(ifem_ctx *ctx, const AsmArgs &A) {
   IFEM_HIP_CHECK(hipGetLastError());
 }
 
+static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero);
+
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) {
   hipStream_t s = ctx->stream;
   const int dim = ctx->dim;
+  if (ctx->asm_rows) {
+    launch_ins_assemble_rows(ctx, p, use_nonzero);
+    assemble_epilogue(ctx, use_nonzero);
+    return;
+  }
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->Bt.val.p, 0, ctx->Bt.val.n * sizeof(double), s));
@@ -395,6 +402,10 @@ void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzer
   else if (dim == 3 && ctx->kv == 2) launch_t<3, 2>(ctx, A);
   else throw Error(IFEM_E_BADPARAM, "unsupported (dim, kv)");
   IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+  assemble_epilogue(ctx, use_nonzero);
+}
+
+static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero) {
   dinv_setup(ctx);
   bjac_setup(ctx);
   IFEM_HIP_CHECK(hipEventSynchronize(ctx->ev1));

@@ -112,6 +112,10 @@ struct ifem_ctx {
   ifem::PlanarCsr Bt;  // rows: owned velocity nodes, cols: local pressure nodes, bs = dim   (block (0,1))
   ifem::PlanarCsr B;   // rows: owned pressure nodes, cols: local velocity nodes, bs = dim   (block (1,0))
   ifem::PlanarCsr Mp;  // rows: owned pressure nodes, cols: local pressure nodes, bs = 1     (mass (1,1))
+  ifem::PlanarCsr uinc, pinc;  // node -> (cell << 5 | local index) incidence lists (row-owner assembly)
+  ifem::DBuf<double> qdata;    // per cell, per quadrature point geometry + evaluation-point fields
+  bool asm_rows = false;       // true (IFEM_ASM=rows): atomics-free row-owner assembly (assemble_rows.hip): bit-reproducible,
+                               // ~3x slower at 128^3 (2.2x the VALU work: per-row recomputation of the cell gradients)
   ifem::PlanarCsr Sm;  // mass_schur(1,1) = B diag(M_u)^-1 B^T, explicit (single rank only; empty otherwise)
   bool sm_valid = false;
   int64_t sm_key = -1, constraints_epoch = 0;

@@ -9,6 +9,9 @@ void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, in
                    const int32_t *d_cols, DBuf<uint16_t> &pos);
 
 void build_schur_pattern(ifem_ctx *ctx);
+void build_incidence(ifem_ctx *ctx);
+// assemble_rows.hip: atomics-free row-owner assembly (records ev0/ev1 around its kernels)
+void launch_ins_assemble_rows(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
 
 // assemble.hip
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);

@@ -2,6 +2,7 @@
 // reductions.  These replace PETSc MatMult / Vec ops under deal.II's SolverFGMRES / SolverCG
 // (mpi_insim.cpp:75-82,103-108,383-388).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "ctx.hpp"
 #include "kernels.hpp"
 
@@ -112,13 +113,16 @@ void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool
   if (use_f32) auu_f32_refresh(ctx);
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s));
   if (ctx->dim == 3) {
-    constexpr int G = 32;
-    if (use_f32)
-      hipLaunchKernelGGL((k_spmv_uu<3, G, float>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
-                         ctx->Auu.col.p, ctx->Auu_f32.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
-    else
-      hipLaunchKernelGGL((k_spmv_uu<3, G, double>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
-                         ctx->Auu.col.p, ctx->Auu.val.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
+    static const int Gsel = [] { const char *e = getenv("IFEM_SPMV_G"); return e ? atoi(e) : 32; }();
+#define IFEM_SPMV3(G)                                                                                                  \
+  if (use_f32)                                                                                                         \
+    hipLaunchKernelGGL((k_spmv_uu<3, G, float>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,    \
+                       ctx->Auu.col.p, ctx->Auu_f32.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);   \
+  else                                                                                                                 \
+    hipLaunchKernelGGL((k_spmv_uu<3, G, double>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,   \
+                       ctx->Auu.col.p, ctx->Auu.val.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
+    if (Gsel == 16) { IFEM_SPMV3(16) } else if (Gsel == 64) { IFEM_SPMV3(64) } else if (Gsel == 8) { IFEM_SPMV3(8) } else { IFEM_SPMV3(32) }
+#undef IFEM_SPMV3
   } else {
     constexpr int G = 16;
     if (use_f32)

@@ -118,8 +118,10 @@ static void pattern_from_keys(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_row
     if (mx >= 0xFFFF) throw Error(IFEM_E_BADPARAM, "row longer than 65534 blocks");
     M.max_row = (int)mx;
   }
-  M.val.alloc((size_t)nnzb * bs);
-  IFEM_HIP_CHECK(hipMemsetAsync(M.val.p, 0, (size_t)nnzb * bs * sizeof(double), s));
+  if (bs > 0) { // bs == 0: pattern only (incidence lists)
+    M.val.alloc((size_t)nnzb * bs);
+    IFEM_HIP_CHECK(hipMemsetAsync(M.val.p, 0, (size_t)nnzb * bs * sizeof(double), s));
+  }
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
 }
 
@@ -160,6 +162,34 @@ __global__ void k_sq_fill(int64_t n_rows, const int64_t *__restrict__ rp, const 
       for (int64_t l = rp[m]; l < rp[m + 1]; ++l) keys[o++] = (uint64_t(uint32_t(i)) << 32) | uint32_t(col[l]);
     }
   }
+}
+
+// node -> (cell, local index) incidence lists for the row-owner assembly: CSR with entries (cell << 5 | a)
+__global__ void k_gen_inc_keys(int64_t n_cells, int R, const int32_t *__restrict__ rows, int64_t n_rows_owned,
+                               uint64_t *__restrict__ keys) {
+  const int64_t total = n_cells * R;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cell = t / R;
+    const int a = int(t - cell * R);
+    const int32_t row = rows[t];
+    keys[t] = (row < n_rows_owned) ? ((uint64_t(uint32_t(row)) << 32) | uint32_t((cell << 5) | a)) : ~uint64_t(0);
+  }
+}
+
+void build_incidence(ifem_ctx *ctx) {
+  if (ctx->n_cells >= (int64_t(1) << 26)) throw Error(IFEM_E_BADPARAM, "row assembly: too many local cells");
+  hipStream_t s = ctx->stream;
+  auto one = [&](PlanarCsr &M, int64_t n_rows, int R, const int32_t *rows) {
+    const int64_t N = ctx->n_cells * R;
+    DBuf<uint64_t> keys;
+    keys.alloc(N);
+    hipLaunchKernelGGL(k_gen_inc_keys, dim3(grid_for(N)), dim3(256), 0, s, ctx->n_cells, R, rows, n_rows, keys.p);
+    pattern_from_keys(ctx, M, 0, n_rows, keys, N);
+  };
+  one(ctx->uinc, ctx->nUo, ctx->nu, ctx->cell_unodes.p);
+  one(ctx->pinc, ctx->nPo, ctx->np, ctx->cell_pnodes.p);
+  if (ctx->uinc.max_row > 64 || ctx->pinc.max_row > 64)
+    throw Error(IFEM_E_BADPARAM, "row assembly: a node belongs to more than 64 cells (set IFEM_ASM=atomic)");
 }
 
 void build_schur_pattern(ifem_ctx *ctx) {
