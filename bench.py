@@ -23,11 +23,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def pmc_traffic(n):
+def pmc_traffic(n, variant):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["k_spmv_uu"][str(n)]["traffic_bytes"]
+            return json.load(f)["k_spmv_uu"][str(n)][variant]["traffic_bytes"]
     except Exception:
         return None
 
@@ -156,9 +156,9 @@ def main():
                        "fgmres_iters": last.fgmres_iters, "cg_mp_iters": last.cg_mp_iters,
                        "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "ainv_kind": args.ainv,
                        "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms},
-            "roofline": {"bound": "hbm", "kernel": "k_spmv_uu (A_uu BSR SpMV + fused B^T)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_uu<3,32,%s> (A_uu block-row SpMV of the inner solver)" % ("float" if args.ainv == 1 else "double"), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(n) if world == 1 else None, "launch_ms": spmv_avg_ms, "launches_timed": spmv_calls,
+                         "traffic": pmc_traffic(n, "f32" if args.ainv == 1 else "f64") if world == 1 and args.ainv in (0, 1) else None, "launch_ms": spmv_avg_ms, "launches_timed": spmv_calls,
                          "algorithmic_bytes": tm.spmv_uu_bytes},
         }
         if args.cpu_n > 0:
