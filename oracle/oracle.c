@@ -772,3 +772,357 @@ int32_t orc_ins_run_one_step(orc_system *s, const orc_params *P, int32_t apply_n
   free(evalp); free(upd);
   return rc < 0 ? rc : outer;
 }
+
+/* ================================================================================================================
+ * Fluid::MPI::SCnsIM -- slightly compressible NS with SUPG / PSPG / LSIC (source/mpi_scnsim.cpp:15-568), restated
+ * literally: deal.II Tensor operator* semantics (Tensor<1>*Tensor<2>: r_j = sum_i a_i T_ij; Tensor<2>*Tensor<1>:
+ * r_i = sum_j T_ij a_j; left-to-right evaluation), including the UGN length-scale quirk.
+ * ================================================================================================================ */
+static void vT(int dim, const double *v, const double T[MAXD][MAXD], double *r) { /* v * T */
+  for (int j = 0; j < dim; ++j) { double t = 0; for (int i = 0; i < dim; ++i) t += v[i] * T[i][j]; r[j] = t; }
+}
+static void Tv(int dim, const double T[MAXD][MAXD], const double *v, double *r) { /* T * v */
+  for (int i = 0; i < dim; ++i) { double t = 0; for (int j = 0; j < dim; ++j) t += T[i][j] * v[j]; r[i] = t; }
+}
+static double vv(int dim, const double *a, const double *b) { double t = 0; for (int i = 0; i < dim; ++i) t += a[i] * b[i]; return t; }
+
+static void scns_cell(const orc_system *s, const orc_scns_params *P, int cell, const double *eval, const double *present,
+                      const double *fsi_acc, double *Ke, double *fe) {
+  const orc_mesh *m = &s->m;
+  const int dim = m->dim, nu = s->nu, np = s->np, nd = s->ndof_cell, nq = s->feu.nq, nv = s->np;
+  const double *X = m->vcoords + (size_t)cell * nv * dim;
+  const int32_t *un = m->cell_unodes + (size_t)cell * nu;
+  const int32_t *pn = m->cell_pnodes + (size_t)cell * np;
+  const int ind = m->indicator ? m->indicator[cell] : 0;
+  const double dt = P->dt;
+  const double cp_to_cv = 1.4, atm = 1013250, kappa_s = 1e4; /* mpi_scnsim.cpp:124-126 */
+  memset(Ke, 0, sizeof(double) * (size_t)nd * nd);
+  memset(fe, 0, sizeof(double) * (size_t)nd);
+  double div_phi_u[MAXDOF], phi_u[MAXDOF][MAXD], grad_phi_u[MAXDOF][MAXD][MAXD], phi_p[MAXDOF], grad_phi_p[MAXDOF][MAXD];
+  const int n_stress = dim * (dim + 1) / 2;
+  const int n_un = m->n_unodes;
+  for (int q = 0; q < nq; ++q) {
+    double J[MAXD][MAXD] = {{0}}, Ji[MAXD][MAXD];
+    for (int v = 0; v < nv; ++v)
+      for (int d = 0; d < dim; ++d)
+        for (int e = 0; e < dim; ++e) J[d][e] += X[v * dim + d] * s->fep.dphi[q][v][e];
+    const double det = det_inv(dim, J, Ji);
+    const double JxW = fabs(det) * s->feu.w[q];
+    double gradN[MAXNU][MAXD], gradPsi[MAXNP][MAXD];
+    for (int a = 0; a < nu; ++a)
+      for (int d = 0; d < dim; ++d) { double g = 0; for (int e = 0; e < dim; ++e) g += s->feu.dphi[q][a][e] * Ji[e][d]; gradN[a][d] = g; }
+    for (int b = 0; b < np; ++b)
+      for (int d = 0; d < dim; ++d) { double g = 0; for (int e = 0; e < dim; ++e) g += s->fep.dphi[q][b][e] * Ji[e][d]; gradPsi[b][d] = g; }
+    /* fields (:152-206) */
+    double u[MAXD] = {0}, G[MAXD][MAXD] = {{0}}, pr = 0, gp[MAXD] = {0}, u0[MAXD] = {0}, p0 = 0, acc[MAXD] = {0};
+    double sgrad[MAXD][MAXD][MAXD] = {{{0}}}; /* d_k sigma_ij */
+    double fsi_s[6] = {0};
+    for (int a = 0; a < nu; ++a) {
+      for (int c = 0; c < dim; ++c) {
+        const double ue = eval[dim * un[a] + c];
+        u[c] += s->feu.phi[q][a] * ue;
+        for (int d = 0; d < dim; ++d) G[c][d] += ue * gradN[a][d];
+        u0[c] += s->feu.phi[q][a] * present[dim * un[a] + c];
+        if (fsi_acc) acc[c] += s->feu.phi[q][a] * fsi_acc[dim * un[a] + c];
+      }
+      if (P->stress)
+        for (int i = 0; i < dim; ++i)
+          for (int j = 0; j < dim; ++j) {
+            const double sv = P->stress[((size_t)i * dim + j) * n_un + un[a]];
+            for (int k = 0; k < dim; ++k) sgrad[i][j][k] += sv * gradN[a][k];
+          }
+      if (P->fsi_stress)
+        for (int k = 0; k < n_stress; ++k) fsi_s[k] += s->feu.phi[q][a] * P->fsi_stress[(size_t)k * n_un + un[a]];
+    }
+    for (int b = 0; b < np; ++b) {
+      const double pe = eval[s->n_u + pn[b]];
+      pr += s->fep.phi[q][b] * pe;
+      for (int d = 0; d < dim; ++d) gp[d] += pe * gradPsi[b][d];
+      p0 += s->fep.phi[q][b] * present[s->n_u + pn[b]];
+    }
+    const double sigma = P->sigma_pml ? P->sigma_pml[(size_t)cell * nq + q] : 0.0;
+    double bf[MAXD] = {0};
+    if (P->body_force) for (int d = 0; d < dim; ++d) bf[d] = P->body_force[((size_t)cell * nq + q) * dim + d];
+    const double rho = P->rho * (1 + p0 / atm) * (1 - ind) + ind * P->solid_rho; /* :210-213 */
+    const double viscosity = (ind == 1 ? 1 : P->mu);                              /* :214-216, no turbulence model */
+    for (int k = 0; k < nd; ++k) {
+      for (int c = 0; c < dim; ++c) { phi_u[k][c] = 0; grad_phi_p[k][c] = 0; for (int d = 0; d < dim; ++d) grad_phi_u[k][c][d] = 0; }
+      div_phi_u[k] = 0; phi_p[k] = 0;
+      if (k < dim * nu) {
+        const int a = k / dim, c = k % dim;
+        phi_u[k][c] = s->feu.phi[q][a];
+        for (int d = 0; d < dim; ++d) grad_phi_u[k][c][d] = gradN[a][d];
+        div_phi_u[k] = gradN[a][c];
+      } else {
+        const int b = k - dim * nu;
+        phi_p[k] = s->fep.phi[q][b];
+        for (int d = 0; d < dim; ++d) grad_phi_p[k][d] = gradPsi[b][d];
+      }
+    }
+    double fsi_T[MAXD][MAXD] = {{0}};
+    if (ind != 0) { int si = 0; for (int k = 0; k < dim; ++k) for (int mm = 0; mm <= k; ++mm) { fsi_T[k][mm] = fsi_T[mm][k] = fsi_s[si++]; } }
+    /* UGN tau's (:247-274): h sums |u0 . shape_grad(a)| over the first ndof/dofs_per_vertex SYSTEM shape functions in
+     * deal.II's cell-local order (vertex v: [u_0..u_{dim-1}, p]) -- reproduced as written */
+    double h = 0;
+    {
+      const int dpv = dim + 1, kv = m->kv;
+      for (int a = 0; a < nd / dpv; ++a) {
+        const int v = a / dpv, comp = a % dpv;
+        const double *gsh;
+        if (comp < dim) {
+          int la = 0, stride = 1;
+          for (int d = 0; d < dim; ++d) { la += ((v >> d) & 1) * kv * stride; stride *= (kv + 1); }
+          gsh = gradN[la];
+        } else gsh = gradPsi[v];
+        h += fabs(vv(dim, u0, gsh));
+      }
+    }
+    const double v_norm = sqrt(vv(dim, u0, u0));
+    if (h) h = 2 * v_norm / h; else h = 0;
+    const double nu_k = viscosity / rho;
+    double tau_SUPG;
+    if (h) tau_SUPG = 1 / sqrt(pow(2 / dt, 2) + pow(2 * v_norm / h, 2) + pow(4 * nu_k / pow(h, 2), 2));
+    else tau_SUPG = dt / 2;
+    const double tau_PSPG = tau_SUPG / rho;
+    const double localRe = v_norm * h / (2 * nu_k);
+    const double z = localRe <= 3 ? (localRe / 3) : 1;
+    const double tau_LSIC = h / 2 * v_norm * z;
+    double sdiv[MAXD];
+    for (int i = 0; i < dim; ++i) { double t = 0; for (int j = 0; j < dim; ++j) t += sgrad[i][j][j]; sdiv[i] = t * viscosity / P->mu; }
+    double gbf[MAXD]; for (int d = 0; d < dim; ++d) gbf[d] = P->g[d] + bf[d];
+    double cur_div = 0; for (int c = 0; c < dim; ++c) cur_div += G[c][c];
+    double u_G[MAXD]; vT(dim, u, G, u_G);       /* current_velocity_values * current_velocity_gradients */
+    double G_u[MAXD]; Tv(dim, G, u, G_u);       /* current_velocity_gradients * current_velocity_values */
+    double du[MAXD]; for (int c = 0; c < dim; ++c) du[c] = u[c] - u0[c];
+    for (int i = 0; i < nd; ++i) {
+      double u_Gi[MAXD]; vT(dim, u, grad_phi_u[i], u_Gi); /* u * grad_phi_u[i] */
+      for (int j = 0; j < nd; ++j) {
+        double pj_Gi[MAXD]; vT(dim, phi_u[j], grad_phi_u[i], pj_Gi); /* phi_u[j] * grad_phi_u[i] */
+        double pj_G[MAXD]; vT(dim, phi_u[j], G, pj_G);               /* phi_u[j] * grad u */
+        double G_pj[MAXD]; Tv(dim, G, phi_u[j], G_pj);               /* grad u * phi_u[j] */
+        double Gj_u[MAXD]; Tv(dim, grad_phi_u[j], u, Gj_u);          /* grad_phi_u[j] * u */
+        double u_Gj[MAXD]; vT(dim, u, grad_phi_u[j], u_Gj);          /* u * grad_phi_u[j] */
+        double sp = 0;
+        for (int a = 0; a < dim; ++a) for (int b = 0; b < dim; ++b) sp += grad_phi_u[j][a][b] * grad_phi_u[i][a][b];
+        const double pipj = vv(dim, phi_u[i], phi_u[j]);
+        double v = 0;
+        /* :307-316 */
+        v += ((viscosity * sp + rho * vv(dim, G_pj, phi_u[i]) + rho * vv(dim, Gj_u, phi_u[i]) - div_phi_u[i] * phi_p[j]) +
+              rho * pipj / dt) * JxW;
+        /* :318-321 PML */
+        v += (rho * sigma * pipj + sigma * phi_p[j] * phi_p[i] / atm) * JxW;
+        /* :323-392 SUPG / PSPG / LSIC */
+        v += (tau_SUPG * rho * vv(dim, u_Gi, pj_G) + tau_SUPG * rho * vv(dim, u_Gi, u_Gj) + tau_SUPG * rho * vv(dim, pj_Gi, u_G) +
+              tau_SUPG * rho * vv(dim, u_Gi, phi_u[j]) / dt + tau_SUPG * rho * vv(dim, pj_Gi, du) / dt +
+              tau_SUPG * vv(dim, u_Gi, grad_phi_p[j]) + tau_SUPG * vv(dim, pj_Gi, gp) - tau_SUPG * vv(dim, pj_Gi, sdiv) -
+              tau_SUPG * rho * vv(dim, pj_Gi, gbf) + tau_SUPG * rho * sigma * vv(dim, u_Gi, phi_u[j]) +
+              tau_SUPG * rho * sigma * vv(dim, pj_Gi, u) + tau_PSPG * rho * vv(dim, grad_phi_p[i], pj_G) +
+              tau_PSPG * rho * vv(dim, grad_phi_p[i], u_Gj) + tau_PSPG * rho * vv(dim, grad_phi_p[i], phi_u[j]) / dt +
+              tau_PSPG * vv(dim, grad_phi_p[i], grad_phi_p[j]) + tau_PSPG * rho * sigma * vv(dim, grad_phi_p[i], phi_u[j]) +
+              tau_LSIC * rho * div_phi_u[i] * phi_p[j] / dt * (1 - ind) / atm +
+              tau_LSIC * rho * 1 / kappa_s * div_phi_u[i] * phi_p[j] / dt * ind +
+              tau_LSIC * rho * cp_to_cv * div_phi_u[i] * div_phi_u[j] +
+              tau_LSIC * rho * cp_to_cv * div_phi_u[i] * pr * (1 - ind) * div_phi_u[j] / atm +
+              tau_LSIC * rho * cp_to_cv * div_phi_u[i] * phi_p[j] * (1 - ind) * cur_div / atm +
+              tau_LSIC * rho * div_phi_u[i] * vv(dim, u, grad_phi_p[j]) / atm * (1 - ind) +
+              tau_LSIC * rho * div_phi_u[i] * vv(dim, phi_u[j], gp) / atm * (1 - ind)) * JxW;
+        /* :399-413 continuity */
+        v += (cp_to_cv * (atm + pr * (1 - ind)) * div_phi_u[j] * phi_p[i] + phi_p[j] * cur_div * phi_p[i] * (1 - ind) +
+              vv(dim, u, grad_phi_p[j]) * phi_p[i] * (1 - ind) + vv(dim, phi_u[j], gp) * phi_p[i] * (1 - ind) +
+              phi_p[i] * phi_p[j] / dt * (1 - ind)) / atm * JxW +
+             1 / kappa_s * phi_p[i] * phi_p[j] * ind / dt * JxW;
+        if (ind == 1) { double ar[MAXD]; for (int c = 0; c < dim; ++c) ar[c] = acc[c] * rho; v += -(tau_SUPG * vv(dim, pj_Gi, ar)) * JxW; }
+        Ke[i * nd + j] += v;
+      }
+      /* rhs :425-512 */
+      double sp = 0;
+      for (int a = 0; a < dim; ++a) for (int b = 0; b < dim; ++b) sp += G[a][b] * grad_phi_u[i][a][b];
+      double r = 0;
+      r += ((-viscosity * sp - rho * vv(dim, G_u, phi_u[i]) + pr * div_phi_u[i]) - rho * vv(dim, du, phi_u[i]) / dt +
+            vv(dim, gbf, phi_u[i]) * rho) * JxW;
+      r += -(rho * sigma * vv(dim, u, phi_u[i]) + sigma * pr * phi_p[i] / atm) * JxW;
+      r += -(cp_to_cv * (atm + pr * (1 - ind)) * cur_div * phi_p[i] + vv(dim, u, gp) * phi_p[i] * (1 - ind) +
+             (pr - p0) * phi_p[i] / dt * (1 - ind)) / atm * JxW -
+           1 / kappa_s * (pr - p0) * phi_p[i] * ind / dt * JxW;
+      double R[MAXD];
+      for (int c = 0; c < dim; ++c) R[c] = rho * (du[c] / dt + u_G[c]) + gp[c] - sdiv[c] - rho * gbf[c] + rho * sigma * u[c];
+      r += -(tau_SUPG * vv(dim, u_Gi, R) + tau_PSPG * vv(dim, grad_phi_p[i], R)) * JxW;
+      r += -((tau_LSIC * rho * div_phi_u[i]) * ((pr - p0) / dt * (1 - ind) + cp_to_cv * atm * cur_div +
+                                                cp_to_cv * pr * cur_div * (1 - ind) + vv(dim, u, gp) * (1 - ind)) / atm +
+             (tau_LSIC * rho * div_phi_u[i]) * (1 / kappa_s * (pr - p0) / dt) * ind) * JxW;
+      if (ind == 1) {
+        double spf = 0;
+        for (int a = 0; a < dim; ++a) for (int b = 0; b < dim; ++b) spf += grad_phi_u[i][a][b] * fsi_T[a][b];
+        double w[MAXD]; for (int c = 0; c < dim; ++c) w[c] = phi_u[i][c] + tau_PSPG * grad_phi_p[i][c] + tau_SUPG * u_Gi[c];
+        double ar[MAXD]; for (int c = 0; c < dim; ++c) ar[c] = acc[c] * rho;
+        r += (spf + vv(dim, ar, w)) * JxW;
+      }
+      fe[i] += r;
+    }
+  }
+  /* Neumann faces :521-549 (same as InsIM) */
+  if (P->n_neumann != 0 && m->cell_face_bid) {
+    int nq1 = m->kv + 1;
+    double gx[3], gw[3]; gauss_1d(nq1, gx, gw);
+    int nqf = (dim == 2) ? nq1 : nq1 * nq1;
+    for (int f = 0; f < 2 * dim; ++f) {
+      int bid = m->cell_face_bid[(size_t)cell * 2 * dim + f];
+      if (bid < 0) continue;
+      double pbc = 0; int found = 0;
+      for (int k = 0; k < P->n_neumann; ++k) if (P->neumann_id[k] == bid) { pbc = P->neumann_p[k]; found = 1; }
+      if (!found) continue;
+      int nd_ = f / 2; double side = (double)(f % 2);
+      for (int qf = 0; qf < nqf; ++qf) {
+        double xi[MAXD], w = 1.0; int t = qf;
+        for (int d = 0; d < dim; ++d) { if (d == nd_) xi[d] = side; else { int i = t % nq1; t /= nq1; xi[d] = gx[i]; w *= gw[i]; } }
+        double N1[MAXNP], dN1[MAXNP][MAXD], Nu[MAXNU], dNu[MAXNU][MAXD];
+        shapes_at(dim, 1, xi, N1, dN1);
+        shapes_at(dim, m->kv, xi, Nu, dNu);
+        double J[MAXD][MAXD] = {{0}}, Ji[MAXD][MAXD];
+        for (int v = 0; v < nv; ++v) for (int d = 0; d < dim; ++d) for (int e = 0; e < dim; ++e) J[d][e] += X[v * dim + d] * dN1[v][e];
+        double det = det_inv(dim, J, Ji);
+        double nv_[MAXD], nn = 0, sgn = (f % 2) ? 1.0 : -1.0;
+        for (int d = 0; d < dim; ++d) { nv_[d] = sgn * Ji[nd_][d]; nn += nv_[d] * nv_[d]; }
+        nn = sqrt(nn);
+        double JxWf = fabs(det) * nn * w;
+        for (int d = 0; d < dim; ++d) nv_[d] /= nn;
+        for (int a = 0; a < nu; ++a) for (int c = 0; c < dim; ++c) fe[a * dim + c] += -(Nu[a] * nv_[c] * pbc * JxWf);
+      }
+    }
+  }
+}
+
+static void mini_system(orc_system *s, const orc_mesh *m) {
+  memset(s, 0, sizeof(*s));
+  s->m = *m;
+  fe_init(&s->feu, m->dim, m->kv, m->kv + 1);
+  fe_init(&s->fep, m->dim, 1, m->kv + 1);
+  s->nu = s->feu.nn; s->np = s->fep.nn; s->ndof_cell = m->dim * s->nu + s->np;
+  s->n_u = m->dim * m->n_unodes; s->n_p = m->n_pnodes; s->n = s->n_u + s->n_p;
+}
+
+void orc_scns_cell(const orc_mesh *m, const orc_scns_params *p, int32_t cell, const double *eval, const double *present,
+                   const double *fsi_acc, double *Ke, double *fe) {
+  orc_system s; mini_system(&s, m);
+  scns_cell(&s, p, cell, eval, present, fsi_acc, Ke, fe);
+}
+
+void orc_scns_assemble(orc_system *s, const orc_scns_params *P, int32_t use_nonzero, const double *eval,
+                       const double *present, const double *fsi_acc) {
+  const int nd = s->ndof_cell, n = s->n;
+  size_t nnz = (size_t)s->rowptr[n];
+  memset(s->A, 0, sizeof(double) * nnz);
+  memset(s->rhs, 0, sizeof(double) * (size_t)n);
+  const unsigned char *isc = s->is_c[use_nonzero ? 1 : 0];
+  const double *cv = s->cval[use_nonzero ? 1 : 0];
+#pragma omp parallel
+  {
+    double *Ke = (double *)malloc(sizeof(double) * (size_t)nd * nd);
+    double fe[MAXDOF]; int32_t idx[MAXDOF];
+#pragma omp for schedule(dynamic, 16)
+    for (int cell = 0; cell < s->m.n_cells; ++cell) {
+      scns_cell(s, P, cell, eval, present, fsi_acc, Ke, fe);
+      cell_dofs(s, cell, idx);
+      double avgK = 0; int any_c = 0;
+      for (int i = 0; i < nd; ++i) { avgK += fabs(Ke[i * nd + i]); if (isc[idx[i]]) any_c = 1; }
+      avgK /= nd;
+      for (int i = 0; i < nd; ++i) {
+        int gi = idx[i];
+        if (isc[gi]) {
+          double kd = fabs(Ke[i * nd + i]) != 0 ? fabs(Ke[i * nd + i]) : avgK;
+          int64_t p = find_pos(s, gi, gi);
+#pragma omp atomic
+          s->A[p] += kd;
+#pragma omp atomic
+          s->rhs[gi] += cv[gi] * kd;
+          continue;
+        }
+        double b = fe[i];
+        if (any_c) for (int r = 0; r < nd; ++r) if (isc[idx[r]]) b -= Ke[i * nd + r] * cv[idx[r]];
+#pragma omp atomic
+        s->rhs[gi] += b;
+        for (int j = 0; j < nd; ++j) {
+          if (isc[idx[j]]) continue;
+          int64_t p = find_pos(s, gi, idx[j]);
+#pragma omp atomic
+          s->A[p] += Ke[i * nd + j];
+        }
+      }
+    }
+    free(Ke);
+  }
+}
+
+int32_t orc_scns_run_one_step(orc_system *s, const orc_scns_params *P, int32_t apply_nonzero, double newton_tol,
+                              int32_t newton_maxit, orc_full_solve_fn solve, void *user, double *present,
+                              const double *fsi_acc, double *log) {
+  const int n = s->n;
+  double *evalp = (double *)malloc(sizeof(double) * (size_t)n), *upd = (double *)malloc(sizeof(double) * (size_t)n);
+  memcpy(evalp, present, sizeof(double) * (size_t)n);
+  double cur = 1.0, init = 1.0, rel = 1.0; int outer = 0, rc = 0;
+  while (rel > newton_tol && cur > 1e-14) { /* mpi_supg_solver.cpp:354-355 */
+    if (outer >= newton_maxit) { rc = -1; break; }
+    memset(upd, 0, sizeof(double) * (size_t)n);
+    int nz = apply_nonzero && outer == 0;
+    orc_scns_assemble(s, P, nz, evalp, present, fsi_acc);
+    solve(user, n, s->rowptr, s->col, s->A, s->rhs, upd);
+    const unsigned char *isc = s->is_c[nz ? 1 : 0]; const double *cv = s->cval[nz ? 1 : 0];
+    for (int i = 0; i < n; ++i) if (isc[i]) upd[i] = cv[i]; /* constraints.distribute(newton_update) */
+    cur = vnorm(n, s->rhs);
+    for (int i = 0; i < n; ++i) evalp[i] += upd[i];
+    if (outer == 0) init = cur;
+    rel = cur / init;
+    if (log) { log[outer * 4 + 0] = cur; log[outer * 4 + 1] = rel; log[outer * 4 + 2] = 0; log[outer * 4 + 3] = 0; }
+    ++outer;
+  }
+  if (rc == 0) memcpy(present, evalp, sizeof(double) * (size_t)n);
+  free(evalp); free(upd);
+  return rc < 0 ? rc : outer;
+}
+
+/* FluidSolver::update_stress, mpi_fluid_solver.cpp:716-811 */
+void orc_update_stress(const orc_mesh *m, double mu, const double *present, double *stress) {
+  orc_system s; mini_system(&s, m);
+  const int dim = m->dim, nu = s.nu, nq = s.feu.nq, nv = s.np, n_un = m->n_unodes;
+  /* qpt_to_dof = compute_projection_from_quadrature_points_matrix(scalar_fe, quad, quad): n_q == n_dofs here, so the L2
+   * projection interpolates: X = Phi^-1 with Phi[q][i] = phi_i(x_q) */
+  double Phi[MAXQ][MAXQ], Xm[MAXQ][MAXQ];
+  for (int q = 0; q < nq; ++q) for (int i = 0; i < nu; ++i) { Phi[q][i] = s.feu.phi[q][i]; Xm[q][i] = (q == i); }
+  for (int c = 0; c < nu; ++c) { /* Gauss-Jordan with partial pivoting */
+    int piv = c;
+    for (int r = c + 1; r < nu; ++r) if (fabs(Phi[r][c]) > fabs(Phi[piv][c])) piv = r;
+    if (piv != c) for (int k = 0; k < nu; ++k) { double t = Phi[c][k]; Phi[c][k] = Phi[piv][k]; Phi[piv][k] = t; t = Xm[c][k]; Xm[c][k] = Xm[piv][k]; Xm[piv][k] = t; }
+    const double d = Phi[c][c];
+    for (int k = 0; k < nu; ++k) { Phi[c][k] /= d; Xm[c][k] /= d; }
+    for (int r = 0; r < nu; ++r) if (r != c) { const double f = Phi[r][c]; for (int k = 0; k < nu; ++k) { Phi[r][k] -= f * Phi[c][k]; Xm[r][k] -= f * Xm[c][k]; } }
+  }
+  memset(stress, 0, sizeof(double) * (size_t)dim * dim * n_un);
+  double *cnt = (double *)calloc((size_t)n_un, sizeof(double));
+  for (int cell = 0; cell < m->n_cells; ++cell) {
+    const double *X = m->vcoords + (size_t)cell * nv * dim;
+    const int32_t *un = m->cell_unodes + (size_t)cell * nu;
+    double qs[MAXD][MAXD][MAXQ];
+    for (int q = 0; q < nq; ++q) {
+      double J[MAXD][MAXD] = {{0}}, Ji[MAXD][MAXD];
+      for (int v = 0; v < nv; ++v) for (int d = 0; d < dim; ++d) for (int e = 0; e < dim; ++e) J[d][e] += X[v * dim + d] * s.fep.dphi[q][v][e];
+      det_inv(dim, J, Ji);
+      double G[MAXD][MAXD] = {{0}};
+      for (int a = 0; a < nu; ++a)
+        for (int c = 0; c < dim; ++c) {
+          const double ue = present[dim * un[a] + c];
+          for (int d = 0; d < dim; ++d) { double g = 0; for (int e = 0; e < dim; ++e) g += s.feu.dphi[q][a][e] * Ji[e][d]; G[c][d] += ue * g; }
+        }
+      for (int i = 0; i < dim; ++i) for (int j = 0; j < dim; ++j) qs[i][j][q] = 2 * mu * 0.5 * (G[i][j] + G[j][i]);
+    }
+    for (int i = 0; i < dim; ++i)
+      for (int j = 0; j < dim; ++j)
+        for (int a = 0; a < nu; ++a) {
+          double t = 0;
+          for (int q = 0; q < nq; ++q) t += Xm[a][q] * qs[i][j][q];
+          stress[((size_t)i * dim + j) * n_un + un[a]] += t;
+        }
+    for (int a = 0; a < nu; ++a) cnt[un[a]] += 1.0;
+  }
+  for (int k = 0; k < dim * dim; ++k) for (int i = 0; i < n_un; ++i) stress[(size_t)k * n_un + i] /= cnt[i];
+  free(cnt);
+}

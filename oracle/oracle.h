@@ -108,6 +108,38 @@ void orc_schur_csr(const orc_system *s, const int64_t **rowptr, const int32_t **
 void orc_precond_vmult(orc_system *s, const orc_params *p, const orc_opts *o, orc_ainv_fn ainv, void *user,
                        const double *v, double *z);
 
+/* ---- slightly compressible NS with SUPG/PSPG/LSIC: Fluid::MPI::SCnsIM (source/mpi_scnsim.cpp:15-568) ------------
+ * The preconditioner of SUPGFluidSolver (Hypre-Euclid ILU(0), mpi_supg_solver.cpp:35-192) is third-party and only
+ * changes iteration counts; the oracle solves each Newton system through a caller-supplied full-system solve
+ * (tests pass scipy splu).  Parity pinning: tests/fluid_cylinder_mpi_scnsim (pmax = 1.03544). */
+typedef struct {
+  double mu, rho, dt, solid_rho;
+  double g[3];
+  int32_t n_neumann;
+  int32_t neumann_id[8];
+  double  neumann_p[8];
+  const double *stress;     /* [dim][dim][n_unodes] projected nodal viscous stress (update_stress) or NULL (= 0) */
+  const double *fsi_stress; /* [dim(dim+1)/2][n_unodes] nodal FSI stress or NULL */
+  const double *sigma_pml;  /* [n_cells][n_q] or NULL */
+  const double *body_force; /* [n_cells][n_q][dim] or NULL */
+} orc_scns_params;
+
+/* full-system solve callback: CSR of the assembled system (n x n), rhs -> x */
+typedef void (*orc_full_solve_fn)(void *user, int32_t n, const int64_t *rowptr, const int32_t *col, const double *val,
+                                  const double *rhs, double *x);
+
+void orc_scns_cell(const orc_mesh *m, const orc_scns_params *p, int32_t cell, const double *eval, const double *present,
+                   const double *fsi_acc, double *Ke, double *fe);
+void orc_scns_assemble(orc_system *s, const orc_scns_params *p, int32_t use_nonzero, const double *eval,
+                       const double *present, const double *fsi_acc);
+/* Newton loop of SUPGFluidSolver::run_one_step (mpi_supg_solver.cpp:331-425): floor 1e-14; returns iterations or <0 */
+int32_t orc_scns_run_one_step(orc_system *s, const orc_scns_params *p, int32_t apply_nonzero, double newton_tol,
+                              int32_t newton_maxit, orc_full_solve_fn solve, void *user, double *present,
+                              const double *fsi_acc, double *log);
+/* FluidSolver::update_stress (mpi_fluid_solver.cpp:716-811): stress[i][j][node] = nodal average of the per-cell
+ * projection of 2 mu sym(grad u) from the quadrature points to the Q_kv nodes */
+void orc_update_stress(const orc_mesh *m, double mu, const double *present, double *stress /*[dim][dim][n_unodes]*/);
+
 /* FE tables for cross-checks: phi[q][a], dphi[q][a][dim] on the reference cell, weights */
 int32_t orc_fe_tables(int32_t dim, int32_t k, int32_t nq1d, double *phi, double *dphi, double *w, double *qp);
 

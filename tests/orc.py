@@ -27,6 +27,16 @@ class Opts(C.Structure):
                 ("inner_rel", C.c_double), ("n_threads", C.c_int32)]
 
 
+class ScnsParams(C.Structure):
+    _fields_ = [("mu", C.c_double), ("rho", C.c_double), ("dt", C.c_double), ("solid_rho", C.c_double),
+                ("g", C.c_double * 3), ("n_neumann", C.c_int32), ("neumann_id", C.c_int32 * 8),
+                ("neumann_p", C.c_double * 8), ("stress", C.c_void_p), ("fsi_stress", C.c_void_p),
+                ("sigma_pml", C.c_void_p), ("body_force", C.c_void_p)]
+
+
+FULL_SOLVE = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                         C.POINTER(C.c_double), C.POINTER(C.c_double))
+
 AINV = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
@@ -70,6 +80,13 @@ def _bind(L):
     L.orc_spmv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_precond_vmult.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Opts), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]
+    L.orc_scns_assemble.argtypes = [C.c_void_p, C.POINTER(ScnsParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_scns_cell.argtypes = [C.POINTER(_Mesh), C.POINTER(ScnsParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p]
+    L.orc_scns_run_one_step.restype = C.c_int32
+    L.orc_scns_run_one_step.argtypes = [C.c_void_p, C.POINTER(ScnsParams), C.c_int32, C.c_double, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_update_stress.argtypes = [C.POINTER(_Mesh), C.c_double, C.c_void_p, C.c_void_p]
     L.orc_fe_tables.restype = C.c_int32
     L.orc_fe_tables.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
@@ -90,6 +107,39 @@ def make_params(mu=1.0, rho=1.0, gamma=0.1, dt=1e-3, g=(0, 0, 0), neumann=None):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_scns_params(mu, rho, dt, solid_rho=1.0, g=(0, 0, 0), neumann=None, stress=None, fsi_stress=None,
+                     sigma_pml=None, body_force=None):
+    p = ScnsParams()
+    p.mu, p.rho, p.dt, p.solid_rho = mu, rho, dt, solid_rho
+    for i in range(3):
+        p.g[i] = g[i] if i < len(g) else 0.0
+    neumann = neumann or {}
+    p.n_neumann = len(neumann)
+    for k, (bid, val) in enumerate(sorted(neumann.items())):
+        p.neumann_id[k] = bid
+        p.neumann_p[k] = val
+    p._keep = [None if a is None else np.ascontiguousarray(a, float) for a in (stress, fsi_stress, sigma_pml, body_force)]
+    p.stress, p.fsi_stress, p.sigma_pml, p.body_force = [_ptr(a) for a in p._keep]
+    return p
+
+
+class SpluFullSolve:
+    """Exact solve of the whole Newton system (stands in for FGMRES + the Euclid-ILU block preconditioner of
+    SUPGFluidSolver::solve, mpi_supg_solver.cpp:297-328: the preconditioner only changes iteration counts)."""
+
+    def __init__(self):
+        self.cb = FULL_SOLVE(self._call)
+
+    def _call(self, user, n, rowptr, col, val, rhs, x):
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spl
+        rp = np.ctypeslib.as_array(rowptr, (n + 1,))
+        nnz = int(rp[-1])
+        A = sp.csr_matrix((np.ctypeslib.as_array(val, (nnz,)).copy(), np.ctypeslib.as_array(col, (nnz,)).copy(), rp.copy()),
+                          shape=(n, n))
+        np.ctypeslib.as_array(x, (n,))[:] = spl.spsolve(A.tocsc(), np.ctypeslib.as_array(rhs, (n,)))
 
 
 class SpluAinv:
@@ -179,6 +229,28 @@ class System:
         rc = self.L.orc_ins_run_one_step(self.h, C.byref(params), int(apply_nonzero), newton_tol, newton_maxit,
                                          C.byref(self.opts), cb, None, _ptr(present), _ptr(fsi_acc), _ptr(log))
         return rc, log[:max(rc, 0)]
+
+    def scns_assemble(self, params, use_nonzero, evalp, present, fsi_acc=None):
+        self.L.orc_scns_assemble(self.h, C.byref(params), int(use_nonzero), _ptr(evalp), _ptr(present), _ptr(fsi_acc))
+
+    def scns_cell(self, params, cell, evalp, present, fsi_acc=None):
+        nd = self.mesh.dim * self.mesh.cell_unodes.shape[1] + self.mesh.cell_pnodes.shape[1]
+        Ke, fe = np.zeros((nd, nd)), np.zeros(nd)
+        self.L.orc_scns_cell(C.byref(self.cmesh), C.byref(params), cell, _ptr(evalp), _ptr(present), _ptr(fsi_acc),
+                             _ptr(Ke), _ptr(fe))
+        return Ke, fe
+
+    def scns_run_one_step(self, params, apply_nonzero, present, newton_tol=1e-6, newton_maxit=8, solver=None, fsi_acc=None):
+        solver = solver or SpluFullSolve()
+        log = np.zeros((newton_maxit + 1, 4))
+        rc = self.L.orc_scns_run_one_step(self.h, C.byref(params), int(apply_nonzero), newton_tol, newton_maxit,
+                                          C.cast(solver.cb, C.c_void_p), None, _ptr(present), _ptr(fsi_acc), _ptr(log))
+        return rc, log[:max(rc, 0)]
+
+    def update_stress(self, mu, present):
+        out = np.zeros((self.mesh.dim, self.mesh.dim, self.mesh.n_unodes))
+        self.L.orc_update_stress(C.byref(self.cmesh), mu, _ptr(present), _ptr(out))
+        return out
 
     def precond(self, params, v, ainv=None):
         z = np.zeros(self.n)

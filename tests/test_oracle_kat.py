@@ -147,3 +147,45 @@ def test_fluid_cylinder_serial_regression_constants():
     vmax, pmax = x[:S.n_u].max(), x[S.n_u:].max()
     assert abs(vmax - 0.4064759) / 0.4064759 < 1e-6
     assert abs(pmax - 0.1539404) / 0.1539404 < 1e-6
+
+
+def test_fluid_cylinder_mpi_scnsim_regression_constant():
+    # tests/fluid_cylinder_mpi_scnsim/fluid_cylinder_mpi_scnsim.cpp:81-88: MPI::SCnsIM<2> (slightly compressible NS with
+    # SUPG/PSPG/LSIC), cylinder mesh, Q1/Q1 (18 384 DoF), one step dt = 1e-2, inflow pulse Umax = 4.5 (time = dt < 2 dt):
+    # vmax = 4.5, pmax = 1.03544 at 1e-3.  Oracle: 1.0354357 -- pins the SCnsIM integrand incl. the UGN length-scale quirk.
+    from cylmesh import CylinderMesh
+    m = CylinderMesh(3, kv=1)
+    assert m.n_dofs == 18384
+    S = orc.System(m)
+
+    def inflow(p, c):
+        return 4 * 4.5 * p[1] * (0.41 - p[1]) / (0.41 * 0.41) if (c == 0 and abs(p[0]) < 1e-10) else 0.0
+
+    dofs, vals = m.dirichlet({0: (3, [0.2, 0]), 2: (3, [0, 0]), 3: (3, [0, 0]), 4: (3, [0, 0])}, {0: inflow})
+    S.set_constraints(1, dofs, vals)
+    S.set_constraints(0, dofs, None)
+    x = np.zeros(S.n)
+    rc, _ = S.scns_run_one_step(orc.make_scns_params(mu=1.8e-4, rho=1.3e-3, dt=1e-2), True, x)
+    assert rc > 0
+    vmax, pmax = x[:S.n_u].max(), x[S.n_u:].max()
+    assert abs(vmax - 4.5) / 4.5 < 1e-9
+    assert abs(pmax - 1.03544) / 1.03544 < 2e-5
+
+
+def test_update_stress_reproduces_linear_fields():
+    # FluidSolver::update_stress (mpi_fluid_solver.cpp:716-811): for a velocity field linear in x the viscous stress
+    # 2 mu sym(grad u) is constant, the per-cell projection and the nodal average must return it exactly
+    m = BoxMesh([3, 2, 2], (0, 0, 0), (1.0, 0.7, 0.4), kv=2)
+    rng = np.random.default_rng(1)
+    m.vcoords = m.vcoords + 0.02 * rng.standard_normal(m.vcoords.shape)
+    S = orc.System(m)
+    Amat = rng.standard_normal((3, 3))
+    x = np.zeros(S.n)
+    # nodal values of u = A x at the (straight-sided) support points are not isoparametric on distorted cells, so use
+    # the undistorted lattice coordinates for the field and undistorted cells for exactness
+    m2 = BoxMesh([3, 2, 2], (0, 0, 0), (1.0, 0.7, 0.4), kv=2)
+    S2 = orc.System(m2)
+    x[:S2.n_u] = (m2.unode_coords @ Amat.T).ravel()
+    st = S2.update_stress(0.7, x)
+    tau = 2 * 0.7 * 0.5 * (Amat + Amat.T)
+    assert np.abs(st - tau[:, :, None]).max() < 1e-12
