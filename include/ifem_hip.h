@@ -175,6 +175,31 @@ int ifem_rhs_norm(ifem_ctx *ctx, double *l2);
 int ifem_ins_newton_step(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int apply_nonzero,
                          double tolerance, int max_iterations, double *log);
 
+/* ---- Fluid::MPI::SCnsIM / SUPGFluidSolver (source/mpi_scnsim.cpp, source/mpi_supg_solver.cpp): slightly compressible
+ * Navier-Stokes with SUPG / PSPG / LSIC.  Single GPU in this build. */
+typedef struct {
+  double viscosity, rho, dt, solid_rho; /* parameters.viscosity, fluid_rho, time step, solid_rho (artificial fluid) */
+  double gravity[3];
+  int32_t n_neumann;
+  int32_t neumann_id[8];
+  double  neumann_p[8];
+} ifem_scns_params;
+/* optional cell / nodal fields of SCnsIM::assemble (each may be NULL = absent): sigma_pml [n_cells][n_q]
+ * (set_sigma_pml_field evaluated at the quadrature points, mpi_scnsim.cpp:188-192), body_force [n_cells][n_q][dim]
+ * (set_body_force, :193-197), fsi_stress [dim(dim+1)/2][n_unodes_local] (MPI::FSI, mpi_fsi.cpp:469-471) */
+int ifem_set_scns_fields(ifem_ctx *ctx, const double *sigma_pml, const double *body_force, const double *fsi_stress);
+/* FluidSolver::update_stress (mpi_fluid_solver.cpp:716-811) from IFEM_VEC_PRESENT into the context's nodal stress
+ * (read by the next ifem_scns_assemble); host_out (may be NULL) receives [dim][dim][n_unodes_local] */
+int ifem_update_stress(ifem_ctx *ctx, double viscosity, double *host_out);
+/* SCnsIM::assemble (mpi_scnsim.cpp:15-568): reads IFEM_VEC_EVAL/_PRESENT/_FSI_ACC and the fields above */
+int ifem_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonzero);
+/* SUPGFluidSolver::solve (mpi_supg_solver.cpp:297-328): FGMRES to 1e-6 ||rhs|| with the block Schur preconditioner of
+ * :35-192 in which the two Euclid ILU(0) factorisations are replaced by node-block Jacobi / Jacobi */
+int ifem_scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats);
+/* Newton loop of SUPGFluidSolver::run_one_step (:331-425, floor 1e-14) followed by update_stress */
+int ifem_scns_newton_step(ifem_ctx *ctx, const ifem_scns_params *p, const ifem_solver_opts *o, int apply_nonzero,
+                          double tolerance, int max_iterations, double *log);
+
 /* y = [A Bt; B 0] x on context vectors (system_matrix.vmult) -- test / bench hook */
 int ifem_system_vmult(ifem_ctx *ctx, int dst, int src);
 /* z = P^-1 v, BlockSchurPreconditioner::vmult (mpi_insim.cpp:57-128) on context vectors -- test hook */

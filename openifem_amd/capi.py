@@ -35,6 +35,12 @@ class InsParams(C.Structure):
                 ("neumann_p", C.c_double * 8)]
 
 
+class ScnsParams(C.Structure):
+    _fields_ = [("viscosity", C.c_double), ("rho", C.c_double), ("dt", C.c_double), ("solid_rho", C.c_double),
+                ("gravity", C.c_double * 3), ("n_neumann", C.c_int32), ("neumann_id", C.c_int32 * 8),
+                ("neumann_p", C.c_double * 8)]
+
+
 class SolverOpts(C.Structure):
     _fields_ = [("fgmres_restart", C.c_int32), ("fgmres_maxit", C.c_int32), ("fgmres_rel", C.c_double),
                 ("fgmres_abs", C.c_double), ("mp_rel", C.c_double), ("mp_abs", C.c_double),
@@ -61,7 +67,8 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_set_cell_fields", "ifem_vec_set", "ifem_vec_get", "ifem_vec_copy", "ifem_vec_zero", "ifem_vec_axpy",
            "ifem_vec_norm2", "ifem_vec_minmax", "ifem_halo_exchange", "ifem_ins_assemble", "ifem_solve",
            "ifem_rhs_norm", "ifem_ins_newton_step", "ifem_system_vmult", "ifem_precond_vmult", "ifem_export_csr",
-           "ifem_get_timing", "ifem_set_profiling", "ifem_set_ainv_kind"]
+           "ifem_get_timing", "ifem_set_profiling", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
+           "ifem_scns_assemble", "ifem_scns_solve", "ifem_scns_newton_step"]
 
 _lib = None
 
@@ -113,6 +120,12 @@ def load():
     L.ifem_local_world_destroy.argtypes = [C.c_void_p]
     L.ifem_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.ifem_set_ainv_kind.argtypes = [C.c_void_p, C.c_int]
+    L.ifem_set_scns_fields.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifem_update_stress.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+    L.ifem_scns_assemble.argtypes = [C.c_void_p, C.POINTER(ScnsParams), C.c_int]
+    L.ifem_scns_solve.argtypes = [C.c_void_p, C.POINTER(SolverOpts), C.c_int, C.POINTER(SolveStats)]
+    L.ifem_scns_newton_step.argtypes = [C.c_void_p, C.POINTER(ScnsParams), C.POINTER(SolverOpts), C.c_int, C.c_double,
+                                        C.c_int, C.c_void_p]
     _lib = L
     return L
 
@@ -124,6 +137,19 @@ def _ptr(a):
 def make_params(mu=1.0, rho=1.0, gamma=0.1, dt=1e-3, g=(0, 0, 0), neumann=None):
     p = InsParams()
     p.viscosity, p.rho, p.grad_div, p.dt = mu, rho, gamma, dt
+    for i in range(3):
+        p.gravity[i] = g[i] if i < len(g) else 0.0
+    neumann = neumann or {}
+    p.n_neumann = len(neumann)
+    for k, (bid, val) in enumerate(sorted(neumann.items())):
+        p.neumann_id[k] = bid
+        p.neumann_p[k] = val
+    return p
+
+
+def make_scns_params(mu, rho, dt, solid_rho=1.0, g=(0, 0, 0), neumann=None):
+    p = ScnsParams()
+    p.viscosity, p.rho, p.dt, p.solid_rho = mu, rho, dt, solid_rho
     for i in range(3):
         p.gravity[i] = g[i] if i < len(g) else 0.0
     neumann = neumann or {}
@@ -199,6 +225,29 @@ class Context:
         st = SolveStats()
         self._chk(self.L.ifem_solve(self.h, C.byref(params), C.byref(self.opts), int(use_nonzero), C.byref(st)))
         return st
+
+    def set_scns_fields(self, sigma_pml=None, body_force=None, fsi_stress=None):
+        keep = [None if a is None else np.ascontiguousarray(a, float) for a in (sigma_pml, body_force, fsi_stress)]
+        self._chk(self.L.ifem_set_scns_fields(self.h, *[_ptr(a) for a in keep]))
+
+    def update_stress(self, mu):
+        out = np.zeros((self.dim, self.dim, self.n_u // self.dim))
+        self._chk(self.L.ifem_update_stress(self.h, mu, _ptr(out)))
+        return out
+
+    def scns_assemble(self, params, use_nonzero):
+        self._chk(self.L.ifem_scns_assemble(self.h, C.byref(params), int(use_nonzero)))
+
+    def scns_solve(self, use_nonzero):
+        st = SolveStats()
+        self._chk(self.L.ifem_scns_solve(self.h, C.byref(self.opts), int(use_nonzero), C.byref(st)))
+        return st
+
+    def scns_newton_step(self, params, apply_nonzero, tol=1e-6, maxit=8):
+        log = np.zeros((maxit + 1, 4))
+        rc = self._chk(self.L.ifem_scns_newton_step(self.h, C.byref(params), C.byref(self.opts), int(apply_nonzero), tol,
+                                                    maxit, _ptr(log)))
+        return rc, log[:rc]
 
     def rhs_norm(self):
         v = C.c_double()

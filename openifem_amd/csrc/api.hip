@@ -292,6 +292,78 @@ int ifem_ins_newton_step(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_sol
   return outer;
 }
 
+int ifem_set_scns_fields(ifem_ctx *ctx, const double *sigma_pml, const double *body_force, const double *fsi_stress) {
+  IFEM_API_BEGIN
+  hipStream_t s = ctx->stream;
+  const size_t ncq = (size_t)ctx->n_cells * ctx->nq;
+  if (sigma_pml) ctx->sigma_pml.upload(sigma_pml, ncq, s); else ctx->sigma_pml.release();
+  if (body_force) ctx->body_force.upload(body_force, ncq * ctx->dim, s); else ctx->body_force.release();
+  if (fsi_stress) ctx->fsi_stress.upload(fsi_stress, (size_t)(ctx->dim * (ctx->dim + 1) / 2) * ctx->nUl, s); else ctx->fsi_stress.release();
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  IFEM_API_END
+}
+
+int ifem_update_stress(ifem_ctx *ctx, double viscosity, double *host_out) {
+  IFEM_API_BEGIN
+  launch_update_stress(ctx, viscosity);
+  if (host_out) {
+    IFEM_HIP_CHECK(hipMemcpyAsync(host_out, ctx->stress.p, ctx->stress.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  IFEM_API_END
+}
+
+int ifem_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonzero) {
+  IFEM_API_BEGIN
+  if (!p || p->dt <= 0 || p->viscosity <= 0) throw Error(IFEM_E_BADPARAM, "bad ifem_scns_params");
+  launch_scns_assemble(ctx, p, use_nonzero);
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+
+int ifem_scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats) {
+  IFEM_API_BEGIN
+  ifem_solver_opts def;
+  if (!o) { ifem_default_solver_opts(&def); o = &def; }
+  const int rc = scns_solve(ctx, o, use_nonzero, stats);
+  if (rc != 0) throw Error(rc, "FGMRES did not converge (SolverControl::NoConvergence)");
+  IFEM_API_END
+}
+
+int ifem_scns_newton_step(ifem_ctx *ctx, const ifem_scns_params *p, const ifem_solver_opts *o, int apply_nonzero,
+                          double tolerance, int max_iterations, double *log) {
+  int outer = 0;
+  try {
+    ifem_solver_opts def;
+    if (!o) { ifem_default_solver_opts(&def); o = &def; }
+    double cur = 1.0, init = 1.0, rel = 1.0;
+    copy_owned(ctx, IFEM_VEC_EVAL, IFEM_VEC_PRESENT, 1.0, 0.0);
+    while (rel > tolerance && cur > 1e-14) { // mpi_supg_solver.cpp:354-355
+      if (outer >= max_iterations) throw Error(IFEM_E_NEWTON_MAXIT, "Too many Newton iterations!");
+      const int nz = apply_nonzero && outer == 0;
+      v_zero(ctx, ctx->n_local, ctx->vec[IFEM_VEC_UPDATE].p);
+      launch_scns_assemble(ctx, p, nz);
+      ifem_solve_stats st{};
+      const int rc = scns_solve(ctx, o, nz, &st);
+      if (rc != 0) throw Error(rc, "FGMRES did not converge (SolverControl::NoConvergence)");
+      cur = norm2_owned(ctx, IFEM_VEC_RHS);
+      copy_owned(ctx, IFEM_VEC_EVAL, IFEM_VEC_UPDATE, 1.0, 1.0);
+      if (outer == 0) init = cur;
+      rel = cur / init;
+      if (log) { log[outer * 4 + 0] = cur; log[outer * 4 + 1] = rel; log[outer * 4 + 2] = st.fgmres_iters; log[outer * 4 + 3] = st.inner_iters; }
+      ++outer;
+    }
+    copy_owned(ctx, IFEM_VEC_INCREMENT, IFEM_VEC_PRESENT, 1.0, 0.0);
+    copy_owned(ctx, IFEM_VEC_INCREMENT, IFEM_VEC_EVAL, -1.0, 1.0);
+    copy_owned(ctx, IFEM_VEC_PRESENT, IFEM_VEC_EVAL, 1.0, 0.0);
+    launch_update_stress(ctx, p->viscosity); // update_stress() (:396), feeds the next assemble
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  catch (const ifem::Error &e) { g_err = e.what(); return e.code; }
+  catch (const std::exception &e) { g_err = e.what(); return IFEM_E_HIP; }
+  return outer;
+}
+
 int ifem_system_vmult(ifem_ctx *ctx, int dst, int src) {
   IFEM_API_BEGIN
   if (!vec_ok(dst) || !vec_ok(src) || is_ext(dst) || is_ext(src)) throw Error(IFEM_E_BADPARAM, "use non-ghosted vectors");
@@ -317,6 +389,8 @@ int ifem_export_csr(ifem_ctx *ctx, int which, int64_t *rowptr, int32_t *col, dou
   const int64_t nuo = dim * ctx->nUo, npo = ctx->nPo, n = nuo + npo, poff = dim * ctx->nUl;
   auto rpA = ctx->Auu.rowptr.download(s), rpT = ctx->Bt.rowptr.download(s), rpB = ctx->B.rowptr.download(s),
        rpM = ctx->Mp.rowptr.download(s);
+  std::vector<double> vApp;
+  if (ctx->has_app) vApp = ctx->App.download(s);
   // pattern: [A_uu | B^T ; B | M_p-pattern]  (explicit zeros kept so that both `which` share one pattern)
   rowptr[0] = 0;
   for (int64_t A = 0; A < ctx->nUo; ++A)
@@ -356,7 +430,7 @@ int ifem_export_csr(ifem_ctx *ctx, int which, int64_t *rowptr, int32_t *col, dou
       }
     for (int64_t k = 0; k < mlen; ++k) {
       col[o] = int32_t(poff + cM[ms + k]);
-      val[o] = (which == 0) ? 0.0 : vM[ms + k];
+      val[o] = (which == 0) ? (ctx->has_app ? vApp[ms + k] : 0.0) : vM[ms + k];
       ++o;
     }
   }

@@ -413,6 +413,7 @@ static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero) {
   IFEM_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->timing.assemble_kernel_ms = ms;
   ctx->assembled = true;
+  ctx->has_app = false;
   ctx->auu_f32_valid = false;
   // S_m = B diag(M_u)^-1 B^T depends only on the mesh and on WHICH dofs are constrained (not on the solution):
   // keep it across assemblies until the constraint set changes (the reference rebuilds it every solve(); same values)

@@ -112,6 +112,9 @@ struct ifem_ctx {
   ifem::PlanarCsr Bt;  // rows: owned velocity nodes, cols: local pressure nodes, bs = dim   (block (0,1))
   ifem::PlanarCsr B;   // rows: owned pressure nodes, cols: local velocity nodes, bs = dim   (block (1,0))
   ifem::PlanarCsr Mp;  // rows: owned pressure nodes, cols: local pressure nodes, bs = 1     (mass (1,1))
+  // SCnsIM (slightly compressible, SUPG): pressure-pressure block on the M_p pattern, nodal stress fields, cell fields
+  ifem::DBuf<double> App, app_diag, stress, fsi_stress, sigma_pml, body_force, xinv;
+  bool has_app = false, stress_valid = false;
   ifem::PlanarCsr uinc, pinc;  // node -> (cell << 5 | local index) incidence lists (row-owner assembly)
   ifem::DBuf<double> qdata;    // per cell, per quadrature point geometry + evaluation-point fields
   bool asm_rows = false;       // true (IFEM_ASM=rows): atomics-free row-owner assembly (assemble_rows.hip): bit-reproducible,

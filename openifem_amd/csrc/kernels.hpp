@@ -16,6 +16,10 @@ void launch_ins_assemble_rows(ifem_ctx *ctx, const ifem_ins_params *p, int use_n
 // assemble.hip
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
 
+// assemble_scns.hip
+void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonzero);
+void launch_update_stress(ifem_ctx *ctx, double mu);
+
 // linalg.hip -- all on ctx->stream.  Block vectors are [u (dim*nUl) | p (nPl)]; "owned" ranges only.
 struct VecLayout {
   int64_t n_u_owned; // dim*nUo
@@ -34,6 +38,9 @@ void shat_jacobi(ifem_ctx *ctx, const double *x, double *y);
 void spmv_b(ifem_ctx *ctx, const double *xu, double *yp);
 // y_u = B^T x_p
 void spmv_bt(ifem_ctx *ctx, const double *xp, double *yu);
+// y_p = A_pp x_p (SCnsIM pressure block on the M_p pattern); 1/diag(A_pp) for its Jacobi preconditioner
+void spmv_app(ifem_ctx *ctx, const double *xp, double *yp);
+void app_diag_setup(ifem_ctx *ctx);
 // y_p = M_p x_p
 void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp);
 // explicit S_m: numeric product B diag(1/diag M_u) B^T into ctx->Sm (pattern must exist), and y_p = S_m x_p
@@ -41,6 +48,7 @@ void schur_numeric(ifem_ctx *ctx);
 void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp);
 // y_u = d .* x_u (diagonal scaling with 1/diag(M_u))
 void vec_mul(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y);
+void vec_div(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y); // y = x ./ d (d == 0 -> 1)
 // y = bjac * x  (node-block Jacobi)
 void bjac_apply(ifem_ctx *ctx, const double *x, double *y);
 void bjac_setup(ifem_ctx *ctx);
@@ -78,6 +86,7 @@ void comm_destroy(ifem_ctx *ctx);
 int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats);
 void ins_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, const double *src, double *dst);
 void ins_system_vmult(ifem_ctx *ctx, const double *src, double *dst);
+int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats);
 
 // owned-range dot over a block vector (u range + p range), all-reduced
 double bv_dot(ifem_ctx *ctx, const double *x, const double *y);

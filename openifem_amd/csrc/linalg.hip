@@ -2,6 +2,7 @@
 // reductions.  These replace PETSc MatMult / Vec ops under deal.II's SolverFGMRES / SolverCG
 // (mpi_insim.cpp:75-82,103-108,383-388).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include "ctx.hpp"
 #include "kernels.hpp"
@@ -280,6 +281,20 @@ void spmv_bt(ifem_ctx *ctx, const double *xp, double *yu) {
                        ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xp, yu);
 }
 
+void spmv_app(ifem_ctx *ctx, const double *xp, double *yp) {
+  const int64_t n = ctx->Mp.n_rows;
+  if (n == 0) return;
+  hipLaunchKernelGGL((k_spmv_planar<1, 1, 8>), dim3(blocks_for_rows(n, 8)), dim3(256), 0, ctx->stream, n,
+                     ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->App.p, xp, yp);
+}
+
+void app_diag_setup(ifem_ctx *ctx) {
+  const int64_t n = ctx->Mp.n_rows;
+  if (ctx->app_diag.n != (size_t)n) ctx->app_diag.alloc(n);
+  if (n) hipLaunchKernelGGL(k_csr_diag, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ctx->Mp.rowptr.p,
+                            ctx->Mp.col.p, ctx->App.p, ctx->app_diag.p);
+}
+
 void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp) {
   const int64_t n = ctx->Mp.n_rows;
   if (n == 0) return;
@@ -404,6 +419,12 @@ void v_zero(ifem_ctx *ctx, int64_t n, double *x) {
 void vec_mul(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y) {
   if (n) hipLaunchKernelGGL(k_mul, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, d, x, y);
 }
+__global__ void k_div(int64_t n, const double *__restrict__ d, const double *__restrict__ x, double *__restrict__ y) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] = x[i] / (d[i] != 0.0 ? d[i] : 1.0);
+}
+void vec_div(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y) {
+  if (n) hipLaunchKernelGGL(k_div, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, d, x, y);
+}
 void dinv_setup(ifem_ctx *ctx) {
   const int64_t n = ctx->diagMu.n;
   if (n) hipLaunchKernelGGL(k_recip, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, ctx->diagMu.p, ctx->dinvMu.p);
@@ -476,6 +497,10 @@ __global__ __launch_bounds__(256) void k_maxpy(int64_t n, int k0, const double *
 
 // out_host[i] = <V_i, w>, i < k.  Device scalars live in ctx->scal[0..63]; result is NOT all-reduced.
 void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *w, double *out_host) {
+  if (k > 64) { // the staging buffers hold 64 dot products: long bases (GMRES(200)) go in chunks
+    for (int k0 = 0; k0 < k; k0 += 64) v_mdot(ctx, n, std::min(64, k - k0), V + int64_t(k0) * ld, ld, w, out_host + k0);
+    return;
+  }
   hipStream_t s = ctx->stream;
   if (ctx->partials.n == 0) ctx->partials.alloc(size_t(64) * MDOT_MAXB);
   if (n == 0) { for (int i = 0; i < k; ++i) out_host[i] = 0; return; }
@@ -496,6 +521,10 @@ void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const 
 
 void v_maxpy(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *h_host, double *w) {
   if (n == 0 || k == 0) return;
+  if (k > 64) {
+    for (int k0 = 0; k0 < k; k0 += 64) v_maxpy(ctx, n, std::min(64, k - k0), V + int64_t(k0) * ld, ld, h_host + k0, w);
+    return;
+  }
   hipStream_t s = ctx->stream;
   // coefficients go through the second half of the scalar buffer
   for (int i = 0; i < k; ++i) ctx->h_scal[64 + i] = h_host[i];

@@ -168,6 +168,10 @@ static void system_apply(SolveState &S, const double *x, double *y, bool time_it
   extend_p(S, x + S.nuo, &xp);
   spmv_uu(c, xu, xp, y, false);
   spmv_b(c, xu, y + S.nuo);
+  if (c->has_app) { // SCnsIM: y_p += A_pp x_p
+    spmv_app(c, xp, S.tp[5]);
+    v_axpy(c, S.npo, 1.0, S.tp[5], y + S.nuo);
+  }
 }
 
 static double dot_all(SolveState &S, int64_t n, const double *a, const double *b) {
@@ -273,6 +277,66 @@ void ins_system_vmult(ifem_ctx *ctx, const double *src, double *dst) {
   SolveState S{ctx, nullptr, &o};
   carve_workspace(S);
   system_apply(S, src, dst, false);
+}
+
+// SUPGFluidSolver::solve + BlockIncompSchurPreconditioner::vmult (mpi_supg_solver.cpp:35-192, 297-328).
+//   P_vv^-1  : node-block Jacobi of A_vv            (reference: Hypre-Euclid ILU(0))
+//   T_pp     : A_pp - A_pv P_vv^-1 A_vp, solved by GMRES(200) to 1e-3 ||.|| with Jacobi(diag A_pp)
+//                                                   (reference: ILU(0) of B2pp = A_pp - A_pv rowsum|A_vv|^-1 A_vp)
+int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats) {
+  if (!ctx->assembled || !ctx->has_app) throw Error(IFEM_E_BADPARAM, "ifem_scns_solve called before ifem_scns_assemble");
+  if (ctx->halo.nranks != 1) throw Error(IFEM_E_BADPARAM, "SCnsIM solve runs on one rank in this build");
+  SolveState S{ctx, nullptr, o};
+  carve_workspace(S);
+  Clock total;
+  app_diag_setup(ctx);
+  const int mt = 200;
+  if ((int64_t)ctx->innerV.n < (int64_t)(mt + 1) * basis_ld(S.npo)) ctx->innerV.alloc((int64_t)(mt + 1) * basis_ld(S.npo));
+  double *rhs = ctx->vec[IFEM_VEC_RHS].p, *upd = ctx->vec[IFEM_VEC_UPDATE].p;
+  auto mdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) { v_mdot(ctx, S.n, k, V, ld, w, out); };
+  auto mdot_p = [&](int k, const double *V, int64_t ld, const double *w, double *out) { v_mdot(ctx, S.npo, k, V, ld, w, out); };
+  double bn;
+  mdot(1, rhs, S.n, rhs, &bn);
+  bn = std::sqrt(bn);
+  const double tol = 1e-6 * bn; // mpi_supg_solver.cpp:311-312
+  const int maxit = o->fgmres_maxit > 0 ? o->fgmres_maxit : (int)std::min<int64_t>(S.n, 1 << 30);
+  OpFn Aop = [&](const double *x, double *y) { system_apply(S, x, y, false); };
+  OpFn Tpp = [&](const double *x, double *y) {
+    spmv_bt(ctx, x, S.tu);
+    bjac_apply(ctx, S.tu, S.utmp);
+    spmv_b(ctx, S.utmp, S.tp[4]);
+    spmv_app(ctx, x, y);
+    v_axpy(ctx, S.npo, -1.0, S.tp[4], y);
+  };
+  OpFn Jpp = [&](const double *x, double *y) { vec_div(ctx, S.npo, ctx->app_diag.p, x, y); };
+  OpFn Pop = [&](const double *src, double *dst) {
+    const double *src0 = src, *src1 = src + S.nuo;
+    double *dst0 = dst, *dst1 = dst + S.nuo;
+    bjac_apply(ctx, src0, S.inner_w);              // ptmp1 = P_vv^-1 src0
+    spmv_b(ctx, S.inner_w, S.tp[0]);               // A_pv ptmp1
+    v_axpby(ctx, S.npo, 1.0, src1, -1.0, S.tp[0]); // ptmp = src1 - A_pv ptmp1
+    double pn;
+    mdot_p(1, S.tp[0], S.npo, S.tp[0], &pn);
+    double res = 0;
+    S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.npo), /*reorth=*/true, Tpp, Jpp, false, S.tp[0], dst1, mt, 100000,
+                              1e-3 * std::sqrt(pn), ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p);
+    spmv_bt(ctx, dst1, S.tu);                      // A_vp dst1
+    bjac_apply(ctx, S.tu, S.utmp);
+    v_copy(ctx, S.nuo, S.inner_w, dst0);
+    v_axpy(ctx, S.nuo, -1.0, S.utmp, dst0);        // dst0 = P_vv^-1 src0 - P_vv^-1 A_vp dst1
+    S.st.precond_applies++;
+  };
+  double res = 0;
+  const int it = gmres(ctx, S.n, basis_ld(S.n), true, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p,
+                       ctx->krylovZ.p, S.outer_w, &res, mdot);
+  apply_constraints(ctx, use_nonzero ? 1 : 0, upd);
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  S.st.fgmres_iters = it; S.st.fgmres_res = res; S.st.t_total_ms = total.ms();
+  if (stats) *stats = S.st;
+  if (o->verbose)
+    fprintf(stderr, "[ifem] scns solve: fgmres %d its res %.3e (tol %.3e) | inner Tpp its %u | %.1f ms\n", it, res, tol,
+            S.st.inner_iters, S.st.t_total_ms);
+  return res <= tol ? 0 : IFEM_E_KRYLOV_NOCONV;
 }
 
 int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, int use_nonzero,
