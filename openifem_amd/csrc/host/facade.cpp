@@ -13,10 +13,26 @@ struct Handle {
   int dim;
   std::unique_ptr<Triangulation<2>> t2;
   std::unique_ptr<Triangulation<3>> t3;
-  std::unique_ptr<Fluid::MPI::InsIM<2>> s2;
-  std::unique_ptr<Fluid::MPI::InsIM<3>> s3;
+  std::unique_ptr<Fluid::MPI::FluidSolver<2>> s2; // InsIM or SCnsIM
+  std::unique_ptr<Fluid::MPI::FluidSolver<3>> s3;
   std::ostringstream log;
 };
+// the formulation named by the driver: "InsIM" (mpi_insim.h) or "SCnsIM" (mpi_scnsim.h)
+template <int dim>
+std::unique_ptr<Fluid::MPI::FluidSolver<dim>> make_solver(const char *kind, Triangulation<dim> &t,
+                                                          const Parameters::AllParameters &params, int device) {
+  const std::string k = kind ? kind : "InsIM";
+  if (k == "InsIM") return std::unique_ptr<Fluid::MPI::FluidSolver<dim>>(new Fluid::MPI::InsIM<dim>(t, params, device));
+  if (k == "SCnsIM") return std::unique_ptr<Fluid::MPI::FluidSolver<dim>>(new Fluid::MPI::SCnsIM<dim>(t, params, device));
+  throw std::invalid_argument("unknown fluid solver '" + k + "' (InsIM, SCnsIM)");
+}
+// assemble / solve / solver_opts live in the two solver families, not in FluidSolver (as in the reference)
+template <int dim, class FI, class FS>
+void with_family(Fluid::MPI::FluidSolver<dim> *s, FI fi, FS fs) {
+  if (auto *a = dynamic_cast<Fluid::MPI::InsIM<dim> *>(s)) fi(*a);
+  else if (auto *b = dynamic_cast<Fluid::MPI::SUPGFluidSolver<dim> *>(s)) fs(*b);
+  else throw std::logic_error("unknown solver family");
+}
 template <class F>
 int guard(F f) {
   try { f(); return 0; }
@@ -31,8 +47,8 @@ const char *ifemx_last_error(void) { return g_err.c_str(); }
 
 // Equivalent of a reference test driver: AllParameters(prm) + subdivided_hyper_rectangle(reps, p0, p1, true)
 // + InsIM<dim>(tria, params).  prm_text is the parameter file CONTENT.
-int ifemx_insim_create_box(const char *prm_text, int dim, const unsigned *reps, const double *p0, const double *p1,
-                           int device, int verbose, void **out) {
+int ifemx_solver_create_box(const char *kind, const char *prm_text, int dim, const unsigned *reps, const double *p0,
+                            const double *p1, int device, int verbose, void **out) {
   return guard([&] {
     auto params = Parameters::AllParameters::from_string(prm_text);
     if (params.dimension != dim) throw std::invalid_argument("Dimension in the parameter file differs from the mesh");
@@ -42,12 +58,12 @@ int ifemx_insim_create_box(const char *prm_text, int dim, const unsigned *reps, 
     if (dim == 2) {
       h->t2.reset(new Triangulation<2>());
       GridGenerator::subdivided_hyper_rectangle<2>(*h->t2, r, {p0[0], p0[1]}, {p1[0], p1[1]}, true, /*lazy=*/true);
-      h->s2.reset(new Fluid::MPI::InsIM<2>(*h->t2, params, device));
+      h->s2 = make_solver<2>(kind, *h->t2, params, device);
       h->s2->pcout = verbose ? &std::cout : nullptr;
     } else {
       h->t3.reset(new Triangulation<3>());
       GridGenerator::subdivided_hyper_rectangle<3>(*h->t3, r, {p0[0], p0[1], p0[2]}, {p1[0], p1[1], p1[2]}, true, /*lazy=*/true);
-      h->s3.reset(new Fluid::MPI::InsIM<3>(*h->t3, params, device));
+      h->s3 = make_solver<3>(kind, *h->t3, params, device);
       h->s3->pcout = verbose ? &std::cout : nullptr;
     }
     *out = h;
@@ -55,7 +71,7 @@ int ifemx_insim_create_box(const char *prm_text, int dim, const unsigned *reps, 
 }
 
 // tests/fluid_cylinder_mpi driver: AllParameters(prm) + GridCreator<2>::flow_around_cylinder(tria) + InsIM<2>(tria, params)
-int ifemx_insim_create_cylinder(const char *prm_text, int device, int verbose, void **out) {
+int ifemx_solver_create_cylinder(const char *kind, const char *prm_text, int device, int verbose, void **out) {
   return guard([&] {
     auto params = Parameters::AllParameters::from_string(prm_text);
     if (params.dimension != 2) throw std::invalid_argument("the cylinder mesh of this build is 2D");
@@ -63,7 +79,7 @@ int ifemx_insim_create_cylinder(const char *prm_text, int device, int verbose, v
     h->dim = 2;
     h->t2.reset(new Triangulation<2>());
     Utils::GridCreator<2>::flow_around_cylinder(*h->t2);
-    h->s2.reset(new Fluid::MPI::InsIM<2>(*h->t2, params, device));
+    h->s2 = make_solver<2>(kind, *h->t2, params, device);
     h->s2->pcout = verbose ? &std::cout : nullptr;
     *out = h;
   });
@@ -76,6 +92,45 @@ int ifemx_add_hard_coded_boundary_condition(void *hv, int id, ifemx_bc_fn fn) {
   return guard([&] {
     if (h->dim == 2) h->s2->add_hard_coded_boundary_condition(id, [fn](const std::array<double, 2> &p, unsigned c, double t) { return fn(p.data(), c, t); });
     else h->s3->add_hard_coded_boundary_condition(id, [fn](const std::array<double, 3> &p, unsigned c, double t) { return fn(p.data(), c, t); });
+  });
+}
+
+int ifemx_insim_create_box(const char *prm_text, int dim, const unsigned *reps, const double *p0, const double *p1,
+                           int device, int verbose, void **out) {
+  return ifemx_solver_create_box("InsIM", prm_text, dim, reps, p0, p1, device, verbose, out);
+}
+int ifemx_insim_create_cylinder(const char *prm_text, int device, int verbose, void **out) {
+  return ifemx_solver_create_cylinder("InsIM", prm_text, device, verbose, out);
+}
+// FluidSolver::set_body_force / set_sigma_pml_field: f(point[dim], component) -> value
+typedef double (*ifemx_field_fn)(const double *point, unsigned component);
+int ifemx_set_body_force(void *hv, ifemx_field_fn fn) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) h->s2->set_body_force([fn](const std::array<double, 2> &p, unsigned c) { return fn(p.data(), c); });
+    else h->s3->set_body_force([fn](const std::array<double, 3> &p, unsigned c) { return fn(p.data(), c); });
+  });
+}
+int ifemx_set_sigma_pml_field(void *hv, ifemx_field_fn fn) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) h->s2->set_sigma_pml_field([fn](const std::array<double, 2> &p, unsigned c) { return fn(p.data(), c); });
+    else h->s3->set_sigma_pml_field([fn](const std::array<double, 3> &p, unsigned c) { return fn(p.data(), c); });
+  });
+}
+int ifemx_set_initial_condition(void *hv, ifemx_field_fn fn) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) h->s2->set_initial_condition([fn](const std::array<double, 2> &p, unsigned c) { return fn(p.data(), c); });
+    else h->s3->set_initial_condition([fn](const std::array<double, 3> &p, unsigned c) { return fn(p.data(), c); });
+  });
+}
+// FluidSolver::update_stress: out[dim][dim][n_unodes]
+int ifemx_update_stress(void *hv, double *out) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto s = h->dim == 2 ? h->s2->update_stress() : h->s3->update_stress();
+    std::memcpy(out, s.data(), s.size() * sizeof(double));
   });
 }
 
@@ -163,18 +218,24 @@ int ifemx_run_one_step(void *hv, int apply_nonzero) {
 }
 int ifemx_assemble(void *hv, int use_nonzero) {
   auto *h = static_cast<Handle *>(hv);
-  return guard([&] { if (h->dim == 2) h->s2->assemble(use_nonzero); else h->s3->assemble(use_nonzero); });
+  return guard([&] {
+    if (h->dim == 2) with_family<2>(h->s2.get(), [&](auto &s) { s.assemble(use_nonzero); }, [&](auto &s) { s.assemble(use_nonzero); });
+    else with_family<3>(h->s3.get(), [&](auto &s) { s.assemble(use_nonzero); }, [&](auto &s) { s.assemble(use_nonzero); });
+  });
 }
 int ifemx_solve(void *hv, int use_nonzero, ifem_solve_stats *st) {
   auto *h = static_cast<Handle *>(hv);
   return guard([&] {
-    if (h->dim == 2) { h->s2->solve(use_nonzero); if (st) *st = h->s2->last_stats; }
-    else { h->s3->solve(use_nonzero); if (st) *st = h->s3->last_stats; }
+    auto run = [&](auto &s) { s.solve(use_nonzero); if (st) *st = s.last_stats; };
+    if (h->dim == 2) with_family<2>(h->s2.get(), run, run); else with_family<3>(h->s3.get(), run, run);
   });
 }
 ifem_solver_opts *ifemx_solver_opts(void *hv) {
   auto *h = static_cast<Handle *>(hv);
-  return h->dim == 2 ? &h->s2->solver_opts : &h->s3->solver_opts;
+  ifem_solver_opts *o = nullptr;
+  auto get = [&](auto &s) { o = &s.solver_opts; };
+  if (h->dim == 2) with_family<2>(h->s2.get(), get, get); else with_family<3>(h->s3.get(), get, get);
+  return o;
 }
 ifem_ctx *ifemx_ctx(void *hv) {
   auto *h = static_cast<Handle *>(hv);

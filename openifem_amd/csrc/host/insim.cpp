@@ -55,6 +55,23 @@ void FluidSolver<dim>::set_initial_condition(const std::function<double(const Po
 }
 
 template <int dim>
+void FluidSolver<dim>::set_body_force(const std::function<double(const Point &, const unsigned int)> &bf) {
+  body_force.reset(new std::function<double(const Point &, const unsigned int)>(bf));
+}
+
+template <int dim>
+void FluidSolver<dim>::set_sigma_pml_field(const std::function<double(const Point &, const unsigned int)> &pml) {
+  sigma_pml_field.reset(new std::function<double(const Point &, const unsigned int)>(pml));
+}
+
+template <int dim>
+std::vector<double> FluidSolver<dim>::update_stress() {
+  std::vector<double> s((size_t)(dim * dim) * (size_t)dofs.n_unodes);
+  check(ifem_update_stress(ctx, parameters.viscosity, s.data()), "update_stress");
+  return s;
+}
+
+template <int dim>
 void FluidSolver<dim>::set_partition(const std::array<int, 3> &P, int rank, const uint8_t *nccl_unique_id, void *world) {
   proc_grid = P;
   part_rank = rank;
@@ -81,7 +98,7 @@ void FluidSolver<dim>::setup_dofs() {
 template <int dim>
 void FluidSolver<dim>::make_constraints() {
   std::map<int, std::function<double(const Point &, unsigned)>> hc;
-  const double t = time.current();
+  const double t = field_time;
   for (auto &kv : hard_coded_boundary_values) {
     auto f = kv.second;
     hc[kv.first] = [f, t](const Point &p, unsigned c) { return f(p, c, t); };

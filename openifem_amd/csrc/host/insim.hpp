@@ -60,6 +60,11 @@ public:
   void add_hard_coded_boundary_condition(const int id,
                                          const std::function<double(const Point &, const unsigned int, const double)> &);
   void set_initial_condition(const std::function<double(const Point &, const unsigned int)> &);
+  // SCnsIM inputs evaluated at the quadrature points (mpi_fluid_solver.cpp:82-103, mpi_scnsim.cpp:188-197)
+  void set_body_force(const std::function<double(const Point &, const unsigned int)> &);
+  void set_sigma_pml_field(const std::function<double(const Point &, const unsigned int)> &);
+  // projected nodal viscous stress [dim][dim][n_unodes] of the present solution (mpi_fluid_solver.cpp:716-811)
+  std::vector<double> update_stress();
   // block vector [velocity | pressure] (PETScWrappers::MPI::BlockVector get_current_solution())
   std::vector<double> get_current_solution() const;
   std::pair<size_t, size_t> dofs_per_block_sizes() const { return {(size_t)dofs.n_u(), (size_t)dofs.n_pnodes}; }
@@ -88,6 +93,10 @@ protected:
   std::vector<size_t> dofs_per_block;
   std::map<int, std::function<double(const Point &, const unsigned int, const double)>> hard_coded_boundary_values;
   std::shared_ptr<std::function<double(const Point &, const unsigned int)>> initial_condition_field;
+  std::shared_ptr<std::function<double(const Point &, const unsigned int)>> body_force, sigma_pml_field;
+  // the time the hard coded boundary Fields carry (Field::advance_time): never advanced by InsIM::run
+  // (mpi_insim.cpp:493-519), advanced by dt before every step of SUPGFluidSolver::run (mpi_supg_solver.cpp:438-480)
+  double field_time = 0.0;
   Utils::Time time;
   ifem_ctx *ctx = nullptr;
   int device;
@@ -113,6 +122,44 @@ public:
   ifem_solver_opts solver_opts;
   ifem_solve_stats last_stats{};
   ifem_ins_params ins_params() const;
+
+private:
+  using FluidSolver<dim>::parameters;
+  using FluidSolver<dim>::time;
+  using FluidSolver<dim>::ctx;
+  using FluidSolver<dim>::check;
+};
+
+// Fluid::MPI::SUPGFluidSolver<dim> (include/mpi_supg_solver.h:39-104): Newton loop + FGMRES of the stabilised
+// solvers; assemble() is the hook of the derived formulation.
+template <int dim>
+class SUPGFluidSolver : public FluidSolver<dim> {
+public:
+  SUPGFluidSolver(Triangulation<dim> &, const Parameters::AllParameters &, int device = 0);
+  void run() override;
+  void run_one_step(bool apply_nonzero_constraints, bool assemble_system = true) override;
+  void initialize_system() override;
+  virtual void assemble(const bool use_nonzero_constraints) = 0;
+  std::pair<unsigned int, double> solve(const bool use_nonzero_constraints);
+  ifem_solver_opts solver_opts;
+  ifem_solve_stats last_stats{};
+
+protected:
+  // evaluates body_force / sigma_pml_field at the quadrature points and uploads them (once per initialize_system)
+  void upload_fields();
+  using FluidSolver<dim>::parameters;
+  using FluidSolver<dim>::time;
+  using FluidSolver<dim>::ctx;
+  using FluidSolver<dim>::check;
+};
+
+// Fluid::MPI::SCnsIM<dim> (include/mpi_scnsim.h, source/mpi_scnsim.cpp:15-568)
+template <int dim>
+class SCnsIM : public SUPGFluidSolver<dim> {
+public:
+  SCnsIM(Triangulation<dim> &, const Parameters::AllParameters &, int device = 0);
+  void assemble(const bool use_nonzero_constraints) override;
+  ifem_scns_params scns_params() const;
 
 private:
   using FluidSolver<dim>::parameters;

@@ -69,6 +69,7 @@ AllParameters AllParameters::from_string(const std::string &text) {
   p.fluid_velocity_degree = geti("Fluid finite element system", "Velocity degree", 2);
   p.viscosity = getd("Fluid material properties", "Dynamic viscosity", 1e-3);
   p.fluid_rho = getd("Fluid material properties", "Fluid density", 1.0);
+  p.solid_rho = getd("Solid material properties", "Solid density", 1.0);
   p.grad_div = getd("Fluid solver control", "Grad-Div stabilization", 1.0);
   p.fluid_max_iterations = geti("Fluid solver control", "Max Newton iterations", 8);
   p.fluid_tolerance = getd("Fluid solver control", "Nonlinear system tolerance", 1e-10);

@@ -19,6 +19,8 @@ struct AllParameters {
   unsigned fluid_pressure_degree = 1, fluid_velocity_degree = 2;
   // subsection Fluid material properties (:102-124)
   double viscosity = 1e-3, fluid_rho = 1.0;
+  // subsection Solid material properties (:386-435): density of the artificial fluid in SCnsIM (mpi_scnsim.cpp:210-213)
+  double solid_rho = 1.0;
   // subsection Fluid solver control (:126-156)
   double grad_div = 1.0;
   unsigned fluid_max_iterations = 8;

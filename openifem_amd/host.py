@@ -13,6 +13,7 @@ class HostError(RuntimeError):
 
 
 BC_FN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_uint, C.c_double)
+FIELD_FN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_uint)
 
 
 def _lib():
@@ -22,6 +23,12 @@ def _lib():
     L.ifemx_last_error.restype = C.c_char_p
     L.ifemx_insim_create_box.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                          C.POINTER(C.c_void_p)]
+    L.ifemx_solver_create_box.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_int, C.POINTER(C.c_void_p)]
+    L.ifemx_solver_create_cylinder.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    for f in (L.ifemx_set_body_force, L.ifemx_set_sigma_pml_field, L.ifemx_set_initial_condition):
+        f.argtypes = [C.c_void_p, FIELD_FN]
+    L.ifemx_update_stress.argtypes = [C.c_void_p, C.c_void_p]
     L.ifemx_destroy.argtypes = [C.c_void_p]
     L.ifemx_insim_create_cylinder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.ifemx_add_hard_coded_boundary_condition.argtypes = [C.c_void_p, C.c_int, BC_FN]
@@ -49,8 +56,10 @@ def _lib():
     return L
 
 
-class InsIM:
-    """Fluid::MPI::InsIM<dim> on a colorised subdivided_hyper_rectangle, configured by a .prm text."""
+class FluidSolver:
+    """Fluid::MPI::InsIM<dim> / SCnsIM<dim> on a colorised subdivided_hyper_rectangle (or the cylinder mesh of
+    Utils::GridCreator), configured by a .prm text and driven like the reference's test drivers."""
+    KIND = "InsIM"
 
     def __init__(self, prm_text, reps=None, p0=None, p1=None, device=0, verbose=False, mesh="box"):
         self.L = _lib()
@@ -58,15 +67,16 @@ class InsIM:
         if mesh == "cylinder":  # Utils::GridCreator<2>::flow_around_cylinder
             self.dim = 2
             self.h = C.c_void_p()
-            self._chk(self.L.ifemx_insim_create_cylinder(prm_text.encode(), device, int(verbose), C.byref(self.h)))
+            self._chk(self.L.ifemx_solver_create_cylinder(self.KIND.encode(), prm_text.encode(), device, int(verbose),
+                                                          C.byref(self.h)))
             return
         self.dim = len(reps)
         r = np.ascontiguousarray(reps, np.uint32)
         a, b = np.ascontiguousarray(p0, float), np.ascontiguousarray(p1, float)
         self.h = C.c_void_p()
-        self._chk(self.L.ifemx_insim_create_box(prm_text.encode(), self.dim, r.ctypes.data_as(C.c_void_p),
-                                                a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), device,
-                                                int(verbose), C.byref(self.h)))
+        self._chk(self.L.ifemx_solver_create_box(self.KIND.encode(), prm_text.encode(), self.dim,
+                                                 r.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p),
+                                                 b.ctypes.data_as(C.c_void_p), device, int(verbose), C.byref(self.h)))
 
     def _chk(self, rc):
         if rc < 0:
@@ -89,6 +99,28 @@ class InsIM:
         cb = BC_FN(lambda p, c, t: float(fn(tuple(p[i] for i in range(dim)), int(c), float(t))))
         self._bc_keep.append(cb)
         self._chk(self.L.ifemx_add_hard_coded_boundary_condition(self.h, bid, cb))
+
+    def _field(self, setter, fn):
+        dim = self.dim
+        cb = FIELD_FN(lambda p, c: float(fn(tuple(p[i] for i in range(dim)), int(c))))
+        self._bc_keep.append(cb)
+        self._chk(setter(self.h, cb))
+
+    def set_body_force(self, fn):
+        """fn(point, component) -> float, FluidSolver::set_body_force"""
+        self._field(self.L.ifemx_set_body_force, fn)
+
+    def set_sigma_pml_field(self, fn):
+        self._field(self.L.ifemx_set_sigma_pml_field, fn)
+
+    def set_initial_condition(self, fn):
+        self._field(self.L.ifemx_set_initial_condition, fn)
+
+    def update_stress(self):
+        _, n_u, _ = self.sizes()
+        out = np.zeros((self.dim, self.dim, n_u // self.dim))
+        self._chk(self.L.ifemx_update_stress(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def set_partition(self, P, rank, nccl_unique_id=None, local_world=None):
         """rank `rank` of a P[0] x P[1] x P[2] block partition; call before setup()."""
@@ -197,6 +229,14 @@ class InsIM:
         if rc < 0:
             raise HostError(rc, self.L.ifem_last_error().decode())
         return t
+
+
+class InsIM(FluidSolver):
+    KIND = "InsIM"
+
+
+class SCnsIM(FluidSolver):
+    KIND = "SCnsIM"
 
 
 def channel_prm(dim=3, dt=1e-3, end_time=8e-2, refinements=0):

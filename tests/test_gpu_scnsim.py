@@ -122,3 +122,80 @@ def test_kat_fluid_cylinder_mpi_scnsim_on_gpu():
     _, pmax = ctx.minmax(capi.VEC_PRESENT, 1)
     assert abs(vmax - 4.5) / 4.5 < 1e-3
     assert abs(pmax - 1.03544) / 1.03544 < 1e-3
+
+
+def _prm(name):
+    import os
+    return open(os.path.join(os.path.dirname(__file__), "golden", "prm", name)).read()
+
+
+def test_reference_driver_fluid_cylinder_mpi_scnsim_through_host_mirror():
+    # tests/fluid_cylinder_mpi_scnsim/fluid_cylinder_mpi_scnsim.cpp:31-88 on the C++ host mirror with the reference's own
+    # .prm: AllParameters -> flow_around_cylinder -> SCnsIM<2> -> add_hard_coded_boundary_condition -> run()
+    from openifem_amd import host
+    prm = _prm("fluid_cylinder_mpi_scnsim.prm")
+    dt = 1e-2
+
+    def inflow_bc(p, component, time):  # pulse: active only while time < 2 dt (the Field time is dt at the first step)
+        if component == 0 and abs(p[0]) < 1e-10 and time < 2 * dt:
+            return 4 * 4.5 * p[1] * (0.41 - p[1]) / (0.41 * 0.41)
+        return 0.0
+
+    flow = host.SCnsIM(prm, mesh="cylinder")
+    flow.add_hard_coded_boundary_condition(0, inflow_bc)
+    flow.run()
+    v, p = flow.get_current_solution()
+    assert abs(v.max() - 4.5) / 4.5 < 1e-3
+    assert abs(p.max() - 1.03544) / 1.03544 < 1e-3
+    # update_stress ran at the end of the step (mpi_supg_solver.cpp:411): the nodal stress matches the oracle's
+    cu, cp, fb, vc = flow.cell_tables(kv=1)
+    m = type("M", (), {})()
+    m.dim, m.kv, m.n_cells, m.n_unodes, m.n_pnodes = 2, 1, cu.shape[0], len(v) // 2, len(p)
+    m.vcoords, m.cell_unodes, m.cell_pnodes, m.cell_face_bid, m.indicator = vc, cu, cp, fb, None
+    st_o = orc.System(m).update_stress(1.8e-4, np.concatenate([v, p]))
+    st_g = flow.update_stress()
+    assert np.abs(st_g - st_o).max() / np.abs(st_o).max() < 1e-11
+
+
+def test_reference_driver_fluid_initial_condition_mpi():
+    # tests/fluid_initial_condition_mpi/fluid_initial_condition_mpi.cpp:32-62: pressure ramp as initial condition, one
+    # step of dt = 1e-11, pmax stays 1e4 to 1e-8
+    from openifem_amd import host
+
+    def initial_condition(pt, component):
+        if component == 2:
+            if 4.0 < pt[0] < 5.0:
+                return 1e4 * (pt[0] - 4.0)
+            if 5.0 <= pt[0] < 12.0:
+                return 1e4
+        return 0.0
+
+    flow = host.SCnsIM(_prm("fluid_initial_condition_mpi.prm"), (150, 20), (0, 0), (15, 2))
+    flow.set_initial_condition(initial_condition)
+    flow.run()
+    _, p = flow.get_current_solution()
+    assert abs(p.max() - 1e4) / 1e4 < 1e-8
+
+
+@pytest.mark.slow
+def test_reference_driver_fluid_body_force_mpi():
+    # tests/fluid_body_force_mpi/fluid_body_force_mpi.cpp:30-87: body force strip + PML, 500 steps of 1e-7; the pressure
+    # jump across the strip is 1e3 to 1e-3
+    from openifem_amd import host
+
+    def body_force(pt, component):
+        return 1.0e3 / 1.3e-3 if (3.5 - 5e-4 < pt[0] < 4.5 + 5e-4 and component == 0) else 0.0
+
+    def sigma_pml(pt, component):
+        s = 0.0
+        for b in (0.0, 8.0):
+            if abs(pt[0] - b) < 3.0:
+                s = 340000 * ((3.0 - abs(pt[0] - b)) / 3.0) ** 4
+        return s
+
+    flow = host.SCnsIM(_prm("fluid_body_force_mpi.prm"), (160, 30), (0, 0), (8, 2))
+    flow.set_body_force(body_force)
+    flow.set_sigma_pml_field(sigma_pml)
+    flow.run()
+    _, p = flow.get_current_solution()
+    assert abs((p.max() - p.min()) - 1e3) / 1e3 < 1e-3

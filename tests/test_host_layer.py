@@ -140,3 +140,27 @@ def test_cylinder_grid_creator_matches_independent_builder():
     assert np.abs(uc[cu] - m.unode_coords[m.cell_unodes]).max() < 1e-15
     assert np.abs(pc[cp] - m.pnode_coords[m.cell_pnodes]).max() < 1e-15
     assert len(np.unique(cu)) == m.n_unodes and len(np.unique(cp)) == m.n_pnodes
+
+
+def test_scnsim_host_mirror_setup_and_errors():
+    # Fluid::MPI::SCnsIM through the host mirror without a device: the reference's .prm files parse (Q1/Q1, solid
+    # density), equal-order is enforced (mpi_supg_solver.cpp:213-215), the cylinder tables are the Q1/Q1 ones
+    from openifem_amd import host
+    from cylmesh import CylinderMesh
+    gdir = os.path.join(ROOT, "tests", "golden", "prm")
+    prm = open(os.path.join(gdir, "fluid_cylinder_mpi_scnsim.prm")).read()
+    s = host.SCnsIM(prm, mesh="cylinder")
+    s.add_hard_coded_boundary_condition(0, lambda p, c, t: 1.0 if (c == 0 and t < 2e-2) else 0.0)
+    s.setup_host_only(3)
+    m = CylinderMesh(3, kv=1)
+    assert s.sizes() == (m.n_cells, m.n_u, m.n_pnodes) == (5888, 12256, 6128)
+    for name, reps, p1 in (("fluid_body_force_mpi.prm", (160, 30), (8, 2)), ("fluid_initial_condition_mpi.prm", (150, 20), (15, 2))):
+        b = host.SCnsIM(open(os.path.join(gdir, name)).read(), reps, (0, 0), p1)
+        b.setup_host_only(0)
+        assert b.sizes()[0] == reps[0] * reps[1]
+    with pytest.raises(host.HostError, match="same as pressure"):
+        host.SCnsIM(host.channel_prm(2), (2, 2), (0, 0), (1, 1))
+    with pytest.raises(host.HostError, match="unknown fluid solver"):
+        class Bad(host.FluidSolver):
+            KIND = "Stokes"
+        Bad(host.channel_prm(2), (2, 2), (0, 0), (1, 1))

@@ -189,3 +189,19 @@ def test_update_stress_reproduces_linear_fields():
     st = S2.update_stress(0.7, x)
     tau = 2 * 0.7 * 0.5 * (Amat + Amat.T)
     assert np.abs(st - tau[:, :, None]).max() < 1e-12
+
+
+def test_fluid_initial_condition_mpi_known_answer():
+    # tests/fluid_initial_condition_mpi/fluid_initial_condition_mpi.cpp:32-62: MPI::SCnsIM<2> on 150 x 20 cells of
+    # [0,15] x [0,2], Q1/Q1, pressure ramp as initial condition, one step of dt = 1e-11: pmax = 1e4 to 1e-8
+    m = BoxMesh([150, 20], (0, 0), (15.0, 2.0), kv=1)
+    S = orc.System(m)
+    dofs, vals = m.dirichlet({0: (1, [0]), 1: (1, [0]), 2: (2, [0]), 3: (2, [0])})
+    S.set_constraints(1, dofs, vals)
+    S.set_constraints(0, dofs, None)
+    x = np.zeros(S.n)
+    px = m.pnode_coords[:, 0]
+    x[S.n_u:] = np.where((px > 4.0) & (px < 5.0), 1e4 * (px - 4.0), np.where((px >= 5.0) & (px < 12.0), 1e4, 0.0))
+    rc, _ = S.scns_run_one_step(orc.make_scns_params(mu=1.8e-4, rho=1.3e-3, dt=1e-11), True, x)
+    assert rc > 0
+    assert abs(x[S.n_u:].max() - 1e4) / 1e4 < 1e-8
