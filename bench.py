@@ -117,6 +117,7 @@ def main():
     t0 = time.time()
     t_asm = t_solve = 0.0
     spmv_ms, spmv_calls = 0.0, 0
+    mf_ms, mf_calls = 0.0, 0
     last = None
     for _ in range(args.steps):
         ta = time.time()
@@ -129,6 +130,8 @@ def main():
         tm = solver.timing()
         spmv_ms += tm.spmv_uu_ms_avg * tm.spmv_uu_calls
         spmv_calls += tm.spmv_uu_calls
+        mf_ms += tm.mf_ms_avg * tm.mf_calls
+        mf_calls += tm.mf_calls
     elapsed = time.time() - t0
     if dist:
         import torch
@@ -155,7 +158,8 @@ def main():
                        "assemble_kernel_ms": tm.assemble_kernel_ms, "setup_s": t_setup,
                        "fgmres_iters": last.fgmres_iters, "cg_mp_iters": last.cg_mp_iters,
                        "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "ainv_kind": args.ainv,
-                       "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms},
+                       "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms,
+                       "mf_apply_ms": mf_ms / max(mf_calls, 1), "mf_applies": mf_calls},
             "roofline": {"bound": "hbm", "kernel": "k_spmv_uu<3,32,%s> (A_uu block-row SpMV of the inner solver)" % ("float" if args.ainv == 1 else "double"), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(n, "f32" if args.ainv == 1 else "f64") if world == 1 and args.ainv in (0, 1) else None, "launch_ms": spmv_avg_ms, "launches_timed": spmv_calls,

@@ -89,6 +89,9 @@ typedef struct {
                                          every velocity component (drops the grad-div and u-gradient couplings of A_uu:
                                          8x less matrix traffic; adequate while gamma*rho*dim <~ mu).  Needs
                                          ifem_set_ainv_kind(ctx, 2) before ifem_ins_assemble. */
+#define IFEM_AINV_GMRES_BJACOBI_MF 3  /* inner GMRES(m) whose operator applies A_uu matrix-free (sum-factorised cell
+                                         kernel on the evaluation point of the last ifem_ins_assemble): same operator
+                                         as kind 0 up to fp64 rounding, ~2 kB instead of ~40 kB of HBM traffic per cell */
 
 typedef struct {
   int32_t fgmres_restart;     /* 30: deal.II SolverFGMRES default */
@@ -202,6 +205,9 @@ int ifem_scns_newton_step(ifem_ctx *ctx, const ifem_scns_params *p, const ifem_s
 
 /* y = [A Bt; B 0] x on context vectors (system_matrix.vmult) -- test / bench hook */
 int ifem_system_vmult(ifem_ctx *ctx, int dst, int src);
+/* y_u = A_uu x_u on the velocity part of two context vectors -- test / bench hook.  variant: IFEM_AINV_GMRES_BJACOBI
+ * (stored fp64 matrix), _F32 (its single-precision copy) or _MF (matrix-free) */
+int ifem_uu_vmult(ifem_ctx *ctx, int dst, int src, int variant);
 /* z = P^-1 v, BlockSchurPreconditioner::vmult (mpi_insim.cpp:57-128) on context vectors -- test hook */
 int ifem_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int dst, int src);
 
@@ -215,6 +221,7 @@ typedef struct {
   double assemble_kernel_ms; /* the cell-integration + scatter kernel alone */
   double spmv_uu_ms_avg; uint64_t spmv_uu_calls; /* A_uu BSR SpMV (dominant kernel of the solve) */
   double spmv_uu_bytes;      /* algorithmic bytes per call */
+  double mf_ms_avg; uint64_t mf_calls; /* matrix-free A_uu application (IFEM_AINV_GMRES_BJACOBI_MF) */
 } ifem_timing;
 int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t);
 /* on != 0: time every A_uu SpMV launch with HIP events on the context stream (one sync per launch) */

@@ -58,7 +58,8 @@ class SolveStats(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("assemble_ms", C.c_double), ("assemble_kernel_ms", C.c_double), ("spmv_uu_ms_avg", C.c_double),
-                ("spmv_uu_calls", C.c_uint64), ("spmv_uu_bytes", C.c_double)]
+                ("spmv_uu_calls", C.c_uint64), ("spmv_uu_bytes", C.c_double), ("mf_ms_avg", C.c_double),
+                ("mf_calls", C.c_uint64)]
 
 
 EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "ifem_comm_unique_id",
@@ -66,7 +67,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_ctx_create", "ifem_ctx_destroy", "ifem_n_local_dofs", "ifem_nnz", "ifem_set_constraints",
            "ifem_set_cell_fields", "ifem_vec_set", "ifem_vec_get", "ifem_vec_copy", "ifem_vec_zero", "ifem_vec_axpy",
            "ifem_vec_norm2", "ifem_vec_minmax", "ifem_halo_exchange", "ifem_ins_assemble", "ifem_solve",
-           "ifem_rhs_norm", "ifem_ins_newton_step", "ifem_system_vmult", "ifem_precond_vmult", "ifem_export_csr",
+           "ifem_rhs_norm", "ifem_ins_newton_step", "ifem_system_vmult", "ifem_uu_vmult", "ifem_precond_vmult", "ifem_export_csr",
            "ifem_get_timing", "ifem_set_profiling", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
            "ifem_scns_assemble", "ifem_scns_solve", "ifem_scns_newton_step"]
 
@@ -111,6 +112,7 @@ def load():
     L.ifem_ins_newton_step.argtypes = [C.c_void_p, C.POINTER(InsParams), C.POINTER(SolverOpts), C.c_int, C.c_double,
                                        C.c_int, C.c_void_p]
     L.ifem_system_vmult.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.ifem_uu_vmult.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.ifem_precond_vmult.argtypes = [C.c_void_p, C.POINTER(InsParams), C.POINTER(SolverOpts), C.c_int, C.c_int]
     L.ifem_export_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifem_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
@@ -268,6 +270,12 @@ class Context:
     def system_vmult(self, x):
         self.vec_set(VEC_TMP, x)
         self._chk(self.L.ifem_system_vmult(self.h, VEC_UPDATE, VEC_TMP))
+        return self.vec_get(VEC_UPDATE)
+
+    def uu_vmult(self, x, variant=0):
+        """y_u = A_uu x_u; variant 0 stored fp64, 1 fp32 copy, 3 matrix-free"""
+        self.vec_set(VEC_TMP, x)
+        self._chk(self.L.ifem_uu_vmult(self.h, VEC_UPDATE, VEC_TMP, variant))
         return self.vec_get(VEC_UPDATE)
 
     def precond_vmult(self, params, x):

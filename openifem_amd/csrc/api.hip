@@ -372,6 +372,23 @@ int ifem_system_vmult(ifem_ctx *ctx, int dst, int src) {
   IFEM_API_END
 }
 
+int ifem_uu_vmult(ifem_ctx *ctx, int dst, int src, int variant) {
+  IFEM_API_BEGIN
+  if (!vec_ok(dst) || !vec_ok(src) || is_ext(dst) || is_ext(src) || dst == src) throw Error(IFEM_E_BADPARAM, "use two non-ghosted vectors");
+  if (!ctx->assembled) throw Error(IFEM_E_BADPARAM, "ifem_uu_vmult called before ifem_ins_assemble");
+  const int64_t nul = int64_t(ctx->dim) * ctx->nUl, nuo = int64_t(ctx->dim) * ctx->nUo;
+  if ((int64_t)ctx->work.n < nul) ctx->work.alloc(nul);
+  double *xe = ctx->work.p; // ghost-extended copy of the velocity part
+  v_copy(ctx, nuo, ctx->vec[src].p, xe);
+  if (ctx->halo.nranks > 1) halo_exchange(ctx, xe);
+  if (variant == IFEM_AINV_GMRES_BJACOBI_MF) apply_uu_mf(ctx, xe, ctx->vec[dst].p);
+  else if (variant == IFEM_AINV_GMRES_BJACOBI || variant == IFEM_AINV_GMRES_BJACOBI_F32)
+    spmv_uu(ctx, xe, nullptr, ctx->vec[dst].p, variant == IFEM_AINV_GMRES_BJACOBI_F32);
+  else throw Error(IFEM_E_BADPARAM, "variant: IFEM_AINV_GMRES_BJACOBI, _F32 or _MF");
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+
 int ifem_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int dst, int src) {
   IFEM_API_BEGIN
   if (!vec_ok(dst) || !vec_ok(src) || is_ext(dst) || is_ext(src)) throw Error(IFEM_E_BADPARAM, "use non-ghosted vectors");

@@ -1,0 +1,619 @@
+// apply_mf.hip -- matrix-free application of the velocity block A_uu of InsIM's Newton matrix:
+//   y_(a,c) = sum_q JxW { mu gN_a.g x_c + rho N_a (u.g x_c) + rho/dt N_a x_c + rho N_a x.g u_c + gamma rho d_c N_a div x }
+// which is row (a,c) of Ke x summed over the cells (reference: the u-u part of local_matrix, mpi_insim.cpp:263-289, after
+// distribute_local_to_global).  Used as the operator of the inner (preconditioner-only) Krylov solve that stands in for
+// MUMPS (mpi_insim.cpp:124-127): the assembled block matrix stays the operator of the outer FGMRES.
+//
+// One wavefront per cell, sum factorisation on the tensor-product element: nodal values -> Gauss points by one 1D
+// interpolation per direction, reference gradients by the collocation derivative on the Gauss points (exact: the
+// restriction of Q_k to a grid line has degree k and there are k+1 points), the weak form at the quadrature point
+// (one lane per point, MappingQ1 Jacobian from the cell vertices), then the transposed passes.  ~10 kFLOP and ~2.3 kB of
+// HBM traffic per 3D Q2 cell instead of 40 B per stored block entry (64 entries per row) of the assembled SpMV.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include "ctx.hpp"
+#include "kernels.hpp"
+
+namespace ifem {
+
+struct MfTables {
+  double N[9];  // [q][i]  1D Lagrange shape i (equidistant nodes) at Gauss point q
+  double D[9];  // [q][q'] derivative at Gauss point q of the Lagrange polynomial of Gauss point q'
+  double xi[3]; // Gauss points on [0,1]
+  double w[3];
+};
+
+struct MfArgs {
+  int64_t n_cells, nUo;
+  const double *vcoords;
+  const int32_t *cell_unodes;
+  const uint8_t *is_c; // constraint flags of the set the matrix was assembled with (local dofs) or nullptr
+  const double *eval;  // evaluation point of the assembled matrix, velocity part, ghost-extended
+  const double *x;     // ghost-extended input
+  double *y;           // owned rows, zeroed by the caller
+  double mu, rho, gamma, inv_dt;
+  int mode;
+  double *ycell;
+  MfTables t;
+};
+
+template <int DIM, int N1>
+struct MfGeo {
+  static constexpr int NN = (DIM == 2) ? N1 * N1 : N1 * N1 * N1;
+  static constexpr int NV = 1 << DIM;
+};
+
+// per-wave scratch in LDS
+template <int DIM, int N1>
+struct MfScratch {
+  static constexpr int NN = MfGeo<DIM, N1>::NN;
+  double A[2 * DIM * NN];       // ping
+  double B[2 * DIM * NN];       // pong: values at the Gauss points [field][q], fields = x_0..x_{dim-1}, u_0..u_{dim-1}
+  double G[DIM * 2 * DIM * NN]; // reference gradients [dir][field][q]; reused for T^ [dir][comp][q]
+  double X[MfGeo<DIM, N1>::NV * DIM];
+};
+
+// out[f][..o..] = sum_i M(o,i) in[f][..i..] along direction dir; M(o,i) = T ? m[i*N1+o] : m[o*N1+i]
+template <int DIM, int N1, int NF, bool T>
+__device__ inline void mf_pass(const double *__restrict__ in, double *__restrict__ out, const double *__restrict__ m,
+                               int dir, int lane) {
+  constexpr int NN = MfGeo<DIM, N1>::NN;
+  const int stride = dir == 0 ? 1 : (dir == 1 ? N1 : N1 * N1);
+  for (int t = lane; t < NF * NN; t += 64) {
+    const int r = t % NN;
+    const int o = (r / stride) % N1;
+    const int base = t - o * stride;
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < N1; ++i) acc += (T ? m[i * N1 + o] : m[o * N1 + i]) * in[base + i * stride];
+    out[t] = acc;
+  }
+}
+
+template <int DIM, int KV, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf(MfArgs A) {
+  constexpr int N1 = KV + 1, NN = MfGeo<DIM, N1>::NN, NV = 1 << DIM, NF = 2 * DIM;
+  __shared__ MfTables T;
+  __shared__ MfScratch<DIM, N1> SS[WPB];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x < 9) { T.N[threadIdx.x] = A.t.N[threadIdx.x]; T.D[threadIdx.x] = A.t.D[threadIdx.x]; }
+  if (threadIdx.x < 3) { T.xi[threadIdx.x] = A.t.xi[threadIdx.x]; T.w[threadIdx.x] = A.t.w[threadIdx.x]; }
+  MfScratch<DIM, N1> &S = SS[wave];
+  const int64_t cell = int64_t(blockIdx.x) * WPB + wave;
+  const bool active = cell < A.n_cells;
+  const int64_t cc = active ? cell : 0;
+
+  // ---- gather: nodal x (constrained columns are eliminated: x = 0 there) and evaluation point
+  int32_t my_node = 0;
+  bool my_c[DIM];
+  for (int a = lane; a < NN; a += 64) { // NN <= 27 < 64: one trip
+    const int32_t nd = A.cell_unodes[cc * NN + a];
+    my_node = nd;
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+      const int64_t dof = int64_t(DIM) * nd + c;
+      const bool con = A.is_c ? A.is_c[dof] != 0 : false;
+      my_c[c] = con;
+      S.A[c * NN + a] = con ? 0.0 : A.x[dof];
+      S.A[(DIM + c) * NN + a] = A.eval[dof];
+    }
+  }
+  for (int i = lane; i < NV * DIM; i += 64) S.X[i] = A.vcoords[cc * NV * DIM + i];
+  __syncthreads();
+
+  // ---- nodal values -> Gauss points, one direction at a time
+  mf_pass<DIM, N1, NF, false>(S.A, S.B, T.N, 0, lane);
+  __syncthreads();
+  mf_pass<DIM, N1, NF, false>(S.B, S.A, T.N, 1, lane);
+  __syncthreads();
+  if constexpr (DIM == 3) {
+    mf_pass<DIM, N1, NF, false>(S.A, S.B, T.N, 2, lane);
+    __syncthreads();
+  }
+  double *V = (DIM == 3) ? S.B : S.A; // values at the Gauss points
+  double *W = (DIM == 3) ? S.A : S.B; // free buffer
+  // ---- reference gradients by collocation
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) mf_pass<DIM, N1, NF, false>(V, S.G + d * NF * NN, T.D, d, lane);
+  __syncthreads();
+
+  // ---- weak form at the quadrature point (lane = q)
+  if (lane < NN) {
+    const int q = lane;
+    int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
+    // MappingQ1: J[e][d] = sum_v X[v][e] d_d N1_v(xi_q)
+    double L[3][2], J[DIM * DIM], Ji[DIM * DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) { L[d][1] = T.xi[qi[d]]; L[d][0] = 1.0 - L[d][1]; }
+#pragma unroll
+    for (int i = 0; i < DIM * DIM; ++i) J[i] = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int b[3] = {v & 1, (v >> 1) & 1, (v >> 2) & 1};
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) {
+        double g = b[d] ? 1.0 : -1.0;
+#pragma unroll
+        for (int o = 0; o < DIM; ++o)
+          if (o != d) g *= L[o][b[o]];
+#pragma unroll
+        for (int e = 0; e < DIM; ++e) J[e * DIM + d] += S.X[v * DIM + e] * g;
+      }
+    }
+    double det;
+    if constexpr (DIM == 2) {
+      det = J[0] * J[3] - J[1] * J[2];
+      const double r = 1.0 / det;
+      Ji[0] = J[3] * r; Ji[1] = -J[1] * r; Ji[2] = -J[2] * r; Ji[3] = J[0] * r;
+    } else {
+      const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+      det = J[0] * c00 + J[1] * c01 + J[2] * c02;
+      const double r = 1.0 / det;
+      Ji[0] = c00 * r; Ji[3] = c01 * r; Ji[6] = c02 * r;
+      Ji[1] = (J[2] * J[7] - J[1] * J[8]) * r; Ji[4] = (J[0] * J[8] - J[2] * J[6]) * r; Ji[7] = (J[1] * J[6] - J[0] * J[7]) * r;
+      Ji[2] = (J[1] * J[5] - J[2] * J[4]) * r; Ji[5] = (J[2] * J[3] - J[0] * J[5]) * r; Ji[8] = (J[0] * J[4] - J[1] * J[3]) * r;
+    }
+    double wq = T.w[qi[0]] * T.w[qi[1]];
+    if constexpr (DIM == 3) wq *= T.w[qi[2]];
+    const double JxW = fabs(det) * wq;
+    double xq[DIM], uq[DIM], gx[DIM][DIM], gu[DIM][DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+      xq[c] = V[c * NN + q];
+      uq[c] = V[(DIM + c) * NN + q];
+      double rx[DIM], ru[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) {
+        rx[d] = S.G[(d * NF + c) * NN + q];
+        ru[d] = S.G[(d * NF + DIM + c) * NN + q];
+      }
+      // physical gradient: (g f)_e = sum_d Ji[d][e] d^_d f
+#pragma unroll
+      for (int e = 0; e < DIM; ++e) {
+        double sx = 0, su = 0;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) { sx += Ji[d * DIM + e] * rx[d]; su += Ji[d * DIM + e] * ru[d]; }
+        gx[c][e] = sx; gu[c][e] = su;
+      }
+    }
+    double divx = 0;
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) divx += gx[c][c];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+      double conv = 0, newt = 0;
+#pragma unroll
+      for (int e = 0; e < DIM; ++e) { conv += uq[e] * gx[c][e]; newt += xq[e] * gu[c][e]; }
+      const double s = JxW * A.rho * (conv + A.inv_dt * xq[c] + newt);
+      double tp[DIM];
+#pragma unroll
+      for (int e = 0; e < DIM; ++e) tp[e] = JxW * (A.mu * gx[c][e] + (e == c ? A.gamma * A.rho * divx : 0.0));
+      W[c * NN + q] = s;
+      // back to reference directions: T^_d = sum_e Ji[d][e] tp[e]
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) {
+        double t = 0;
+#pragma unroll
+        for (int e = 0; e < DIM; ++e) t += Ji[d * DIM + e] * tp[e];
+        S.G[(d * DIM + c) * NN + q] = t; // [dir][comp][q]
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- W += sum_d D_d^T T^_d  (fused, one item per (comp, q))
+  for (int t = lane; t < DIM * NN; t += 64) {
+    const int r = t % NN;
+    double acc = W[t];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      const int stride = d == 0 ? 1 : (d == 1 ? N1 : N1 * N1);
+      const int o = (r / stride) % N1;
+      const double *src = S.G + d * DIM * NN + (t - o * stride);
+#pragma unroll
+      for (int i = 0; i < N1; ++i) acc += T.D[i * N1 + o] * src[i * stride];
+    }
+    V[t] = acc; // V is free now (the q stage consumed it)
+  }
+  __syncthreads();
+  // ---- transposed interpolation back to the nodes
+  mf_pass<DIM, N1, DIM, true>(V, W, T.N, 0, lane);
+  __syncthreads();
+  mf_pass<DIM, N1, DIM, true>(W, V, T.N, 1, lane);
+  __syncthreads();
+  const double *R = V;
+  if constexpr (DIM == 3) {
+    mf_pass<DIM, N1, DIM, true>(V, W, T.N, 2, lane);
+    __syncthreads();
+    R = W;
+  }
+  // ---- scatter into owned, unconstrained rows
+  if (A.mode == 1) return;
+  if (A.mode == 3) {
+    for (int t = lane; t < DIM * NN; t += 64) A.ycell[cell * (DIM * NN) + t] = R[(t % DIM) * NN + t / DIM];
+    return;
+  }
+  if (A.mode == 2) {
+    __shared__ int32_t nodes[WPB][NN];
+    __shared__ uint8_t cfl[WPB][NN * DIM];
+    if (lane < NN) {
+      nodes[wave][lane] = my_node;
+      for (int c = 0; c < DIM; ++c) cfl[wave][lane * DIM + c] = my_c[c];
+    }
+    __syncthreads();
+    if (active)
+      for (int t = lane; t < DIM * NN; t += 64) {
+        const int a = t / DIM, c = t % DIM;
+        const int32_t nd = nodes[wave][a];
+        if (nd < A.nUo && !cfl[wave][t]) unsafeAtomicAdd(&A.y[int64_t(DIM) * nd + c], R[c * NN + a]);
+      }
+    return;
+  }
+  if (active && lane < NN && my_node < A.nUo) {
+#pragma unroll
+    for (int c = 0; c < DIM; ++c)
+      if (!my_c[c]) unsafeAtomicAdd(&A.y[int64_t(DIM) * my_node + c], R[c * NN + lane]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2: half a wavefront (32 lanes) per cell, two cells per wave.  Every 1D pass is an in-register "pencil" operation
+// (one lane owns the N1 values of a grid line: N1 LDS reads, N1^2 FMAs against wave-uniform table entries that live in
+// SGPRs, N1 LDS writes, in place), the quadrature-point stage runs on 27 of 32 lanes, the trilinear geometry comes
+// from 8 monomial coefficients, and the only synchronisation is wave-local (LDS operations of one wave execute in
+// order).  ~330 wave instructions per 3D Q2 cell instead of ~1200 for the item-per-lane version above.
+__device__ inline void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int DIM, int N1>
+struct MfCell { // per-cell LDS scratch
+  static constexpr int NN = MfGeo<DIM, N1>::NN;
+  double V[2 * DIM * NN];  // nodal values -> values at the Gauss points -> integrand -> nodal result, in place
+  double G[2 * DIM * NN];  // one reference-gradient direction at a time
+  double C[8 * DIM];       // monomial coefficients of the d-linear map
+  double X[(1 << DIM) * DIM];
+  int32_t node[NN];
+  uint8_t flag[NN * DIM + 3];
+};
+
+template <int DIM, int KV, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
+  constexpr int N1 = KV + 1, NN = MfGeo<DIM, N1>::NN, NV = 1 << DIM;
+  constexpr int NP = NN / N1;        // pencils per field and direction
+  constexpr int NPL = DIM * NP;      // pencil lanes per round (one field group of DIM components)
+  __shared__ MfCell<DIM, N1> SS[2 * WPB];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+  MfCell<DIM, N1> &S = SS[2 * wave + half];
+  // ---- per-lane roles (fixed for the life of the wave)
+  const bool pen_lane = hl < NPL;
+  const int comp = pen_lane ? hl / NP : 0, pen = pen_lane ? hl % NP : 0;
+  int pbase[DIM], pstride[DIM];
+  if constexpr (DIM == 3) {
+    const int a = pen % N1, b = pen / N1;
+    pbase[0] = N1 * a + N1 * N1 * b; pstride[0] = 1;
+    pbase[1] = a + N1 * N1 * b;      pstride[1] = N1;
+    pbase[2] = a + N1 * b;           pstride[2] = N1 * N1;
+  } else {
+    pbase[0] = N1 * pen; pstride[0] = 1;
+    pbase[1] = pen;      pstride[1] = N1;
+  }
+  const bool q_lane = hl < NN;
+  const int q = q_lane ? hl : 0;
+  const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
+  double xi[3] = {0, 0, 0}, wq = 1.0;
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    // select from the wave-uniform tables without dynamic indexing of kernel arguments
+    double x_ = A.t.xi[0], w_ = A.t.w[0];
+#pragma unroll
+    for (int k = 1; k < N1; ++k) { x_ = qi[d] == k ? A.t.xi[k] : x_; w_ = qi[d] == k ? A.t.w[k] : w_; }
+    xi[d] = x_; wq *= w_;
+  }
+
+  const int64_t n_pairs = (A.n_cells + 1) / 2;
+  for (int64_t pair = int64_t(blockIdx.x) * WPB + wave; pair < n_pairs; pair += int64_t(gridDim.x) * WPB) {
+    const int64_t cell = 2 * pair + half;
+    const bool active = cell < A.n_cells;
+    const int64_t cc = active ? cell : 0;
+    // ---- gather
+    if (q_lane) {
+      const int32_t nd = A.cell_unodes[cc * NN + hl];
+      S.node[hl] = nd;
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) {
+        const int64_t dof = int64_t(DIM) * nd + c;
+        const bool con = A.is_c ? A.is_c[dof] != 0 : false;
+        S.flag[hl * DIM + c] = con;
+        if (A.mode == 5) { S.V[c * NN + hl] = double(dof & 255); S.V[(DIM + c) * NN + hl] = double(dof & 127); } else {
+        S.V[c * NN + hl] = con ? 0.0 : A.x[dof];
+        S.V[(DIM + c) * NN + hl] = A.eval[dof]; }
+      }
+    }
+    if (hl < NV * DIM) S.X[hl] = A.vcoords[cc * NV * DIM + hl];
+    wsync();
+    // monomial coefficients of x(xi) = sum_k C_k prod_{d in k} xi_d:  C_k = sum_{v subset of k} (-1)^{|k|-|v|} X_v
+    if (hl < NV * DIM) {
+      const int k = hl / DIM, e = hl % DIM;
+      double acc = 0;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const bool sub = (v & ~k) == 0;
+        const int par = __builtin_popcount(k ^ v) & 1;
+        const double xv = S.X[v * DIM + e];
+        acc += sub ? (par ? -xv : xv) : 0.0;
+      }
+      S.C[k * DIM + e] = acc;
+    }
+    // ---- nodal values -> Gauss points (x fields in round 0, evaluation-point fields in round 1), in place
+    if (pen_lane) {
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          double *b = S.V + (r * DIM + comp) * NN + pbase[d];
+          double in[N1];
+#pragma unroll
+          for (int i = 0; i < N1; ++i) in[i] = b[i * pstride[d]];
+#pragma unroll
+          for (int o = 0; o < N1; ++o) {
+            double acc = 0;
+#pragma unroll
+            for (int i = 0; i < N1; ++i) acc += A.t.N[o * N1 + i] * in[i];
+            b[o * pstride[d]] = acc;
+          }
+        }
+        wsync();
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) wsync();
+    }
+    // ---- geometry at the quadrature point
+    double Ji[DIM * DIM], JxW = 0;
+    {
+      double J[DIM * DIM];
+      if constexpr (DIM == 3) {
+        const double e_ = xi[1], z_ = xi[2], x_ = xi[0];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const double c1 = S.C[1 * 3 + e], c2 = S.C[2 * 3 + e], c3 = S.C[3 * 3 + e], c4 = S.C[4 * 3 + e],
+                       c5 = S.C[5 * 3 + e], c6 = S.C[6 * 3 + e], c7 = S.C[7 * 3 + e];
+          J[e * 3 + 0] = c1 + c3 * e_ + c5 * z_ + c7 * (e_ * z_);
+          J[e * 3 + 1] = c2 + c3 * x_ + c6 * z_ + c7 * (x_ * z_);
+          J[e * 3 + 2] = c4 + c5 * x_ + c6 * e_ + c7 * (x_ * e_);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const double c1 = S.C[1 * 2 + e], c2 = S.C[2 * 2 + e], c3 = S.C[3 * 2 + e];
+          J[e * 2 + 0] = c1 + c3 * xi[1];
+          J[e * 2 + 1] = c2 + c3 * xi[0];
+        }
+      }
+      double det;
+      if constexpr (DIM == 2) {
+        det = J[0] * J[3] - J[1] * J[2];
+        const double r = 1.0 / det;
+        Ji[0] = J[3] * r; Ji[1] = -J[1] * r; Ji[2] = -J[2] * r; Ji[3] = J[0] * r;
+      } else {
+        const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+        det = J[0] * c00 + J[1] * c01 + J[2] * c02;
+        const double r = 1.0 / det;
+        Ji[0] = c00 * r; Ji[3] = c01 * r; Ji[6] = c02 * r;
+        Ji[1] = (J[2] * J[7] - J[1] * J[8]) * r; Ji[4] = (J[0] * J[8] - J[2] * J[6]) * r; Ji[7] = (J[1] * J[6] - J[0] * J[7]) * r;
+        Ji[2] = (J[1] * J[5] - J[2] * J[4]) * r; Ji[5] = (J[2] * J[3] - J[0] * J[5]) * r; Ji[8] = (J[0] * J[4] - J[1] * J[3]) * r;
+      }
+      JxW = fabs(det) * wq;
+    }
+    // ---- physical gradients: one reference direction at a time through G
+    double gx[DIM][DIM], gu[DIM][DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c)
+#pragma unroll
+      for (int e = 0; e < DIM; ++e) { gx[c][e] = 0; gu[c][e] = 0; }
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      if (pen_lane) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int off = (r * DIM + comp) * NN + pbase[d];
+          double in[N1];
+#pragma unroll
+          for (int i = 0; i < N1; ++i) in[i] = S.V[off + i * pstride[d]];
+#pragma unroll
+          for (int o = 0; o < N1; ++o) {
+            double acc = 0;
+#pragma unroll
+            for (int i = 0; i < N1; ++i) acc += A.t.D[o * N1 + i] * in[i];
+            S.G[off + o * pstride[d]] = acc;
+          }
+        }
+      }
+      wsync();
+      if (q_lane) {
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+          const double rx = S.G[c * NN + q], ru = S.G[(DIM + c) * NN + q];
+#pragma unroll
+          for (int e = 0; e < DIM; ++e) { gx[c][e] += Ji[d * DIM + e] * rx; gu[c][e] += Ji[d * DIM + e] * ru; }
+        }
+      }
+      wsync();
+    }
+    // ---- weak form at the quadrature point
+    double That[DIM][DIM]; // [comp][ref dir]
+    if (q_lane) {
+      double xq[DIM], uq[DIM];
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) { xq[c] = S.V[c * NN + q]; uq[c] = S.V[(DIM + c) * NN + q]; }
+      double divx = 0;
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) divx += gx[c][c];
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) {
+        double conv = 0, newt = 0;
+#pragma unroll
+        for (int e = 0; e < DIM; ++e) { conv += uq[e] * gx[c][e]; newt += xq[e] * gu[c][e]; }
+        S.V[c * NN + q] = JxW * A.rho * (conv + A.inv_dt * xq[c] + newt);
+        double tp[DIM];
+#pragma unroll
+        for (int e = 0; e < DIM; ++e) tp[e] = JxW * (A.mu * gx[c][e] + (e == c ? A.gamma * A.rho * divx : 0.0));
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+          double t = 0;
+#pragma unroll
+          for (int e = 0; e < DIM; ++e) t += Ji[d * DIM + e] * tp[e];
+          That[c][d] = t;
+        }
+      }
+    }
+    // ---- V_c += D_d^T T^_{c,d}, one direction at a time
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      if (q_lane) {
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) S.G[c * NN + q] = That[c][d];
+      }
+      wsync();
+      if (pen_lane) {
+        const int off = comp * NN + pbase[d];
+        double t[N1];
+#pragma unroll
+        for (int i = 0; i < N1; ++i) t[i] = S.G[off + i * pstride[d]];
+#pragma unroll
+        for (int o = 0; o < N1; ++o) {
+          double acc = S.V[off + o * pstride[d]];
+#pragma unroll
+          for (int i = 0; i < N1; ++i) acc += A.t.D[i * N1 + o] * t[i];
+          S.V[off + o * pstride[d]] = acc;
+        }
+      }
+      wsync();
+    }
+    // ---- transposed interpolation back to the nodes, in place
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      if (pen_lane) {
+        double *b = S.V + comp * NN + pbase[d];
+        double in[N1];
+#pragma unroll
+        for (int i = 0; i < N1; ++i) in[i] = b[i * pstride[d]];
+#pragma unroll
+        for (int o = 0; o < N1; ++o) {
+          double acc = 0;
+#pragma unroll
+          for (int i = 0; i < N1; ++i) acc += A.t.N[i * N1 + o] * in[i];
+          b[o * pstride[d]] = acc;
+        }
+      }
+      wsync();
+    }
+    // ---- scatter into owned, unconstrained rows: consecutive lanes hit consecutive doubles of a node
+    if (active && A.mode != 4) {
+      for (int t = hl; t < DIM * NN; t += 32) {
+        const int a = t / DIM, c = t - a * DIM;
+        const int32_t nd = S.node[a];
+        if (nd < A.nUo && !S.flag[t]) unsafeAtomicAdd(&A.y[int64_t(DIM) * nd + c], S.V[c * NN + a]);
+      }
+    }
+    wsync();
+  }
+}
+
+// constrained rows of the assembled matrix carry only their diagonal: y_r = d_r x_r, d_r recovered from
+// the inverse node block (row and column r of the block are zero apart from d_r, so its inverse has 1/d_r there)
+template <int DIM>
+__global__ void k_mf_constrained_rows(int64_t n, const uint8_t *__restrict__ is_c, const double *__restrict__ bjac,
+                                      const double *__restrict__ x, double *__restrict__ y) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n || !is_c[i]) return;
+  const int64_t nd = i / DIM;
+  const int c = int(i - nd * DIM);
+  y[i] = x[i] / bjac[nd * DIM * DIM + c * DIM + c];
+}
+
+static void mf_tables(MfTables &t, int kv) {
+  const int n1 = kv + 1;
+  std::memset(&t, 0, sizeof(t));
+  if (n1 == 2) {
+    const double a = 0.5 / std::sqrt(3.0);
+    t.xi[0] = 0.5 - a; t.xi[1] = 0.5 + a; t.w[0] = t.w[1] = 0.5;
+  } else {
+    const double a = 0.5 * std::sqrt(0.6);
+    t.xi[0] = 0.5 - a; t.xi[1] = 0.5; t.xi[2] = 0.5 + a;
+    t.w[0] = t.w[2] = 5.0 / 18.0; t.w[1] = 8.0 / 18.0;
+  }
+  for (int q = 0; q < n1; ++q)
+    for (int i = 0; i < n1; ++i) {
+      double v = 1; // Lagrange shape i on the equidistant nodes j/kv
+      for (int j = 0; j < n1; ++j)
+        if (j != i) v *= (t.xi[q] - double(j) / kv) / (double(i) / kv - double(j) / kv);
+      t.N[q * n1 + i] = v;
+      double d = 0; // derivative at xi_q of the Lagrange polynomial of Gauss point i
+      for (int k = 0; k < n1; ++k) {
+        if (k == i) continue;
+        double p = 1.0 / (t.xi[i] - t.xi[k]);
+        for (int j = 0; j < n1; ++j)
+          if (j != i && j != k) p *= (t.xi[q] - t.xi[j]) / (t.xi[i] - t.xi[j]);
+        d += p;
+      }
+      t.D[q * n1 + i] = d;
+    }
+}
+
+void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu) {
+  if (!ctx->mf_valid) throw Error(IFEM_E_BADPARAM, "matrix-free A_uu: no assembled state (call ifem_ins_assemble first)");
+  const int64_t n = int64_t(ctx->dim) * ctx->nUo;
+  hipStream_t s = ctx->stream;
+  MfArgs a{};
+  a.n_cells = ctx->n_cells; a.nUo = ctx->nUo;
+  a.vcoords = ctx->vcoords.p; a.cell_unodes = ctx->cell_unodes.p;
+  a.is_c = ctx->has_c[ctx->asm_constraint_set] ? ctx->is_c[ctx->asm_constraint_set].p : nullptr;
+  a.eval = ctx->mf_eval.p; a.x = xu; a.y = yu;
+  a.mu = ctx->mf_params.viscosity; a.rho = ctx->mf_params.rho; a.gamma = ctx->mf_params.grad_div;
+  a.inv_dt = 1.0 / ctx->mf_params.dt;
+  mf_tables(a.t, ctx->kv);
+  { const char *e = getenv("IFEM_MF_MODE"); a.mode = e ? atoi(e) : 0; }
+  if (a.mode == 3) {
+    const size_t need = size_t(ctx->n_cells) * ctx->dim * ctx->nu;
+    if (ctx->qdata.n < need) ctx->qdata.alloc(need);
+    a.ycell = ctx->qdata.p;
+  }
+  const bool time_it = ctx->profile;
+  if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s));
+  IFEM_HIP_CHECK(hipMemsetAsync(yu, 0, size_t(n) * sizeof(double), s));
+  constexpr int WPB = 4;
+  const dim3 grid(unsigned((ctx->n_cells + WPB - 1) / WPB)), block(64 * WPB);
+  static const int v1 = [] { const char *e = getenv("IFEM_MF_V1"); return e ? atoi(e) : 0; }();
+  if (!v1 && (a.mode == 0 || a.mode >= 4)) {
+    const int64_t n_pairs = (ctx->n_cells + 1) / 2;
+    const dim3 g2(unsigned(std::min<int64_t>((n_pairs + WPB - 1) / WPB, 256 * 24)));
+    if (ctx->dim == 3 && ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf2<3, 2, WPB>), g2, block, 0, s, a);
+    else if (ctx->dim == 3) hipLaunchKernelGGL((k_apply_uu_mf2<3, 1, WPB>), g2, block, 0, s, a);
+    else if (ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf2<2, 2, WPB>), g2, block, 0, s, a);
+    else hipLaunchKernelGGL((k_apply_uu_mf2<2, 1, WPB>), g2, block, 0, s, a);
+  } else
+  if (ctx->dim == 3 && ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf<3, 2, WPB>), grid, block, 0, s, a);
+  else if (ctx->dim == 3) hipLaunchKernelGGL((k_apply_uu_mf<3, 1, WPB>), grid, block, 0, s, a);
+  else if (ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf<2, 2, WPB>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_apply_uu_mf<2, 1, WPB>), grid, block, 0, s, a);
+  if (a.is_c) {
+    if (ctx->dim == 3) hipLaunchKernelGGL((k_mf_constrained_rows<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, a.is_c, ctx->bjac.p, xu, yu);
+    else hipLaunchKernelGGL((k_mf_constrained_rows<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, a.is_c, ctx->bjac.p, xu, yu);
+  }
+  if (time_it) {
+    IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+    IFEM_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    IFEM_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->mf_ms_total += ms;
+    ctx->timing.mf_calls++;
+  }
+}
+
+} // namespace ifem

@@ -359,6 +359,13 @@ static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero);
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) {
   hipStream_t s = ctx->stream;
   const int dim = ctx->dim;
+  { // state the matrix-free A_uu needs to reproduce this matrix (apply_mf.hip)
+    const size_t nu = size_t(dim) * size_t(ctx->nUl);
+    if (ctx->mf_eval.n != nu) ctx->mf_eval.alloc(nu);
+    IFEM_HIP_CHECK(hipMemcpyAsync(ctx->mf_eval.p, ctx->vec[IFEM_VEC_EVAL].p, nu * sizeof(double), hipMemcpyDeviceToDevice, s));
+    ctx->mf_params = *p;
+    ctx->mf_valid = true;
+  }
   if (ctx->asm_rows) {
     launch_ins_assemble_rows(ctx, p, use_nonzero);
     assemble_epilogue(ctx, use_nonzero);

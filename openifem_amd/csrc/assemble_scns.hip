@@ -446,6 +446,7 @@ void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonz
   bjac_setup(ctx);
   ctx->assembled = true;
   ctx->has_app = true;
+  ctx->mf_valid = false;
   ctx->auu_f32_valid = false;
   ctx->sm_valid = false; ctx->sm_key = -1;
   ctx->shat_valid = false;

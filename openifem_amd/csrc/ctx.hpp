@@ -127,11 +127,18 @@ struct ifem_ctx {
   ifem::DBuf<float> Shat_f32;
   bool want_shat = false, shat_valid = false, shat_aux_valid = false;
   int asm_constraint_set = 0;
+  // matrix-free A_uu (IFEM_AINV_GMRES_BJACOBI_MF): state of the last ifem_ins_assemble
+  ifem::DBuf<double> mf_eval;  // velocity part of the evaluation point, ghost-extended
+  ifem_ins_params mf_params{};
+  bool mf_valid = false;
+  double mf_ms_total = 0;
   ifem::DBuf<float> Auu_f32;   // single-precision copy of Auu.val for the inner (preconditioner-only) solver
   bool auu_f32_valid = false, last_spmv_f32 = false;
   ifem::DBuf<double> diagMu;   // diag of mass (0,0), per velocity dof (owned)
   ifem::DBuf<double> dinvMu;   // 1/diagMu
   ifem::DBuf<double> bjac;     // inverse diagonal node blocks of A_uu [nUo][dim*dim]
+  ifem::DBuf<float> bjac_f32;  // single-precision copy for the inner solver (built on first use after bjac_setup)
+  bool bjac_f32_valid = false;
   // scatter maps: position of the column inside the row, 0xFFFF = row not owned here
   ifem::DBuf<uint16_t> posUU, posUP, posPU, posPP;
   // constraints (local dof numbering), sets 0 = zero, 1 = nonzero

@@ -30,6 +30,8 @@ inline VecLayout layout_of(const ifem_ctx *c) { return {c->dim * c->nUo, c->dim 
 
 // y_u = A_uu x_u (+ B^T x_p when xp != nullptr)
 void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool use_f32);
+// apply_mf.hip: y_u = A_uu x_u without the stored matrix (sum-factorised cell kernel on the state of the last assemble)
+void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu);
 // scalar velocity operator S^ (IFEM_AINV_SCALAR_GMRES): auxiliary data, SpMV on all components, Jacobi
 void shat_refresh(ifem_ctx *ctx, bool f32);
 void spmv_shat(ifem_ctx *ctx, const double *xu, double *yu, bool f32);
@@ -65,6 +67,11 @@ double v_dot(ifem_ctx *ctx, int64_t n, const double *x, const double *y); // loc
 void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *w, double *out_host);
 // w -= sum_i h[i] V_i
 void v_maxpy(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *h_host, double *w);
+// single-precision Krylov basis (inner solver): V float, w / coefficients / accumulation double
+void v_mdot_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, const double *w, double *out_host);
+void v_maxpy_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, const double *h_host, double *w, double *norm2_out);
+void v_scale_store_f32(ifem_ctx *ctx, int64_t n, double a, const double *w, float *v);
+void bjac_apply_f32(ifem_ctx *ctx, const float *x, double *y);
 void v_minmax(ifem_ctx *ctx, int64_t n, const double *x, double *mn, double *mx);
 // x[dof] = value for constrained dofs (AffineConstraints::distribute, Dirichlet lines)
 void apply_constraints(ifem_ctx *ctx, int which, double *x);

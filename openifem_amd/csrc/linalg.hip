@@ -541,6 +541,99 @@ void v_maxpy(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
 }
 
+// ---- single-precision Krylov basis of the inner (preconditioner-only) GMRES: V float, every other vector and all
+// accumulation double.  k is padded to a multiple of 4 by the callers' allocation (columns beyond k exist and are finite).
+template <int K>
+__global__ __launch_bounds__(256) void k_mdot_f32(int64_t n, int k0, const float *__restrict__ V, int64_t ld,
+                                                  const double *__restrict__ w, double *__restrict__ out) {
+  double acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const double wi = w[i];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] += double(V[int64_t(k0 + k) * ld + i]) * wi;
+  }
+  block_reduce_store<K>(acc, out + int64_t(k0) * MDOT_MAXB);
+}
+// w -= sum_k h_k V_k; NORM: also the block partials of ||w||^2 of the result (slot `slot` of the partials)
+template <int K, bool NORM>
+__global__ __launch_bounds__(256) void k_maxpy_f32(int64_t n, int k0, const float *__restrict__ V, int64_t ld,
+                                                   const double *__restrict__ h, double *__restrict__ w,
+                                                   double *__restrict__ part, int slot) {
+  double hk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) hk[k] = h[k0 + k];
+  double nn[1] = {0};
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    double t = w[i];
+#pragma unroll
+    for (int k = 0; k < K; ++k) t -= hk[k] * double(V[int64_t(k0 + k) * ld + i]);
+    w[i] = t;
+    if (NORM) nn[0] += t * t;
+  }
+  if (NORM) block_reduce_store<1>(nn, part + int64_t(slot) * MDOT_MAXB);
+}
+__global__ void k_scale_store_f32(int64_t n, double s, const double *__restrict__ w, float *__restrict__ v) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) v[i] = float(w[i] * s);
+}
+
+static inline int pad4(int k) { return (k + 3) & ~3; }
+
+void v_mdot_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, const double *w, double *out_host) {
+  hipStream_t s = ctx->stream;
+  if (ctx->partials.n == 0) ctx->partials.alloc(size_t(64) * MDOT_MAXB);
+  if (n == 0) { for (int i = 0; i < k; ++i) out_host[i] = 0; return; }
+  if (pad4(k) > 64) throw Error(IFEM_E_BADPARAM, "single-precision basis: at most 64 vectors");
+  const unsigned nblk = vgrid(n);
+  const int kp = pad4(k);
+  for (int k0 = 0; k0 < kp;) {
+    const int r = kp - k0;
+    if (r >= 16) { hipLaunchKernelGGL((k_mdot_f32<16>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, w, ctx->partials.p); k0 += 16; }
+    else if (r >= 12) { hipLaunchKernelGGL((k_mdot_f32<12>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, w, ctx->partials.p); k0 += 12; }
+    else if (r >= 8) { hipLaunchKernelGGL((k_mdot_f32<8>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, w, ctx->partials.p); k0 += 8; }
+    else { hipLaunchKernelGGL((k_mdot_f32<4>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, w, ctx->partials.p); k0 += 4; }
+  }
+  hipLaunchKernelGGL(k_reduce_final, dim3(k), dim3(256), 0, s, (int)nblk, ctx->partials.p, ctx->scal.p);
+  IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->scal.p, k * sizeof(double), hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  for (int i = 0; i < k; ++i) out_host[i] = ctx->h_scal[i];
+}
+
+// w -= sum_{i<k} h[i] V_i; when norm2_out != nullptr also returns ||w||^2 of the result (local, not all-reduced)
+void v_maxpy_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, const double *h_host, double *w, double *norm2_out) {
+  if (n == 0 || k == 0) { if (norm2_out) *norm2_out = 0; return; }
+  if (pad4(k) > 64) throw Error(IFEM_E_BADPARAM, "single-precision basis: at most 64 vectors");
+  hipStream_t s = ctx->stream;
+  const int kp = pad4(k);
+  for (int i = 0; i < kp; ++i) ctx->h_scal[64 + i] = i < k ? h_host[i] : 0.0;
+  IFEM_HIP_CHECK(hipMemcpyAsync(ctx->scal.p + 64, ctx->h_scal + 64, kp * sizeof(double), hipMemcpyHostToDevice, s));
+  const unsigned nblk = vgrid(n);
+  double *part = ctx->partials.p;
+  const double *hd = ctx->scal.p + 64;
+#define IFEM_MAXPY(K)                                                                                                  \
+  { if (last && norm2_out) hipLaunchKernelGGL((k_maxpy_f32<K, true>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, hd, w, part, 0); \
+    else hipLaunchKernelGGL((k_maxpy_f32<K, false>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, hd, w, part, 0);        \
+    k0 += K; }
+  for (int k0 = 0; k0 < kp;) {
+    const int r = kp - k0;
+    const int step = r >= 16 ? 16 : (r >= 12 ? 12 : (r >= 8 ? 8 : 4));
+    const bool last = k0 + step >= kp;
+    if (step == 16) IFEM_MAXPY(16) else if (step == 12) IFEM_MAXPY(12) else if (step == 8) IFEM_MAXPY(8) else IFEM_MAXPY(4)
+  }
+#undef IFEM_MAXPY
+  if (norm2_out) {
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, (int)nblk, part, ctx->scal.p);
+    IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  IFEM_HIP_CHECK(hipStreamSynchronize(s)); // h_scal[64..] must stay untouched until the copy has been consumed
+  if (norm2_out) *norm2_out = ctx->h_scal[0];
+}
+
+void v_scale_store_f32(ifem_ctx *ctx, int64_t n, double a, const double *w, float *v) {
+  if (n) hipLaunchKernelGGL(k_scale_store_f32, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, w, v);
+}
+
 double v_dot(ifem_ctx *ctx, int64_t n, const double *x, const double *y) {
   double out = 0;
   v_mdot(ctx, n, 1, x, n, y, &out);
@@ -633,7 +726,36 @@ __global__ void k_bjac_apply(int64_t n_rows, const double *__restrict__ bj, cons
   }
 }
 
+// node-block Jacobi on a single-precision vector with single-precision blocks (inner solver only): y (double) = bj * x
+template <int DIM>
+__global__ void k_bjac_apply_f32(int64_t n_rows, const float *__restrict__ bj, const float *__restrict__ x,
+                                 double *__restrict__ y) {
+  const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  float xv[DIM];
+  for (int j = 0; j < DIM; ++j) xv[j] = x[row * DIM + j];
+  for (int r = 0; r < DIM; ++r) {
+    double t = 0;
+    for (int j = 0; j < DIM; ++j) t += double(bj[row * DIM * DIM + r * DIM + j]) * double(xv[j]);
+    y[row * DIM + r] = t;
+  }
+}
+void bjac_apply_f32(ifem_ctx *ctx, const float *x, double *y) {
+  const int64_t n = ctx->nUo;
+  if (!n) return;
+  if (!ctx->bjac_f32_valid) {
+    if (ctx->bjac_f32.n != ctx->bjac.n) ctx->bjac_f32.alloc(ctx->bjac.n);
+    hipLaunchKernelGGL(k_to_f32, dim3(vgrid((int64_t)ctx->bjac.n)), dim3(256), 0, ctx->stream, (int64_t)ctx->bjac.n, ctx->bjac.p, ctx->bjac_f32.p);
+    ctx->bjac_f32_valid = true;
+  }
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_bjac_apply_f32<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ctx->bjac_f32.p, x, y);
+  else
+    hipLaunchKernelGGL((k_bjac_apply_f32<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ctx->bjac_f32.p, x, y);
+}
+
 void bjac_setup(ifem_ctx *ctx) {
+  ctx->bjac_f32_valid = false;
   const int64_t n = ctx->nUo;
   if (!n) return;
   if (ctx->dim == 3)

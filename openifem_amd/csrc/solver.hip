@@ -107,6 +107,75 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
   return it;
 }
 
+// Inner solver of the preconditioner: right-preconditioned restarted GMRES, x0 = 0, Krylov basis stored in single
+// precision (half the Gram-Schmidt traffic; everything else fp64), single-pass classical Gram-Schmidt with the norm of
+// the orthogonalised vector fused into the multi-axpy sweep.  Only used where an approximate A^-1 is admissible.
+using OpF32 = std::function<void(const float *, double *)>;
+static int gmres_f32basis(ifem_ctx *ctx, int64_t n, int64_t ld, const OpFn &A, const OpF32 &Pinv, const double *b, double *x,
+                          int m, int maxit, double tol, float *V, double *z, double *w, double *res_out,
+                          const std::function<void(double *, int)> &allreduce) {
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), h(m + 4);
+  v_zero(ctx, n, x);
+  int it = 0;
+  double res = 0;
+  bool first = true;
+  while (true) {
+    if (first) { v_copy(ctx, n, b, w); first = false; }
+    else { A(x, w); v_axpby(ctx, n, 1.0, b, -1.0, w); }
+    double bb = v_dot(ctx, n, w, w);
+    allreduce(&bb, 1);
+    const double beta = std::sqrt(bb);
+    res = beta;
+    if (res <= tol || it >= maxit) break;
+    v_scale_store_f32(ctx, n, 1.0 / beta, w, V);
+    std::fill(g.begin(), g.end(), 0.0);
+    g[0] = beta;
+    int j = 0;
+    bool done = false;
+    for (; j < m && it < maxit; ++j) {
+      Pinv(V + (int64_t)j * ld, z);
+      A(z, w);
+      v_mdot_f32(ctx, n, j + 1, V, ld, w, h.data());
+      allreduce(h.data(), j + 1);
+      double ww;
+      v_maxpy_f32(ctx, n, j + 1, V, ld, h.data(), w, &ww);
+      allreduce(&ww, 1);
+      for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = h[i];
+      const double hn = std::sqrt(ww);
+      H[(size_t)(j + 1) * m + j] = hn;
+      if (hn > 0) v_scale_store_f32(ctx, n, 1.0 / hn, w, V + (int64_t)(j + 1) * ld);
+      for (int i = 0; i < j; ++i) {
+        const double t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
+        H[(size_t)(i + 1) * m + j] = -sn[i] * H[(size_t)i * m + j] + cs[i] * H[(size_t)(i + 1) * m + j];
+        H[(size_t)i * m + j] = t;
+      }
+      const double a = H[(size_t)j * m + j], c = H[(size_t)(j + 1) * m + j], r = std::hypot(a, c);
+      cs[j] = a / r; sn[j] = c / r;
+      H[(size_t)j * m + j] = r; H[(size_t)(j + 1) * m + j] = 0;
+      g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
+      res = std::fabs(g[j + 1]);
+      ++it;
+      if (res <= tol || hn == 0) { ++j; done = true; break; }
+    }
+    for (int i = j - 1; i >= 0; --i) {
+      double t = g[i];
+      for (int k = i + 1; k < j; ++k) t -= H[(size_t)i * m + k] * y[k];
+      y[i] = t / H[(size_t)i * m + i];
+    }
+    // x += P^-1 (V y): round V y to the basis precision (column m+1 of the basis is free at this point)
+    v_zero(ctx, n, w);
+    for (int i = 0; i < j; ++i) h[i] = -y[i];
+    v_maxpy_f32(ctx, n, j, V, ld, h.data(), w, nullptr);
+    float *vy = V + (int64_t)(m + 1) * ld;
+    v_scale_store_f32(ctx, n, 1.0, w, vy);
+    Pinv(vy, z);
+    v_axpy(ctx, n, 1.0, z, x);
+    if (done || it >= maxit) break;
+  }
+  if (res_out) *res_out = res;
+  return it;
+}
+
 // plain CG, zero initial guess, absolute tolerance on ||r||_2
 static int cg(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *b, double *x, double tol, int maxit, double *r,
               double *p, double *q, const std::function<double(const double *, const double *)> &dot) {
@@ -225,6 +294,8 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   Clock ck3;
   const bool f32 = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32;
   OpFn Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_uu(c, xe, nullptr, y, f32); };
+  if (o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF)
+    Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); apply_uu_mf(c, xe, y); };
   const bool scalar_op = o->ainv_kind == IFEM_AINV_SCALAR_GMRES;
   if (scalar_op) shat_refresh(c, true);
   if (scalar_op) Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_shat(c, xe, y, true); };
@@ -237,6 +308,13 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   mdot(1, S.utmp, S.nuo, S.utmp, &un);
   un = std::sqrt(un);
   double res = 0;
+  const bool f32_basis = (f32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF) && o->inner_restart + 6 <= 64;
+  if (f32_basis) { // columns 0..m: basis, m+1: scratch for V y, up to the next multiple of 4: padding read by the fused kernels
+    OpF32 Pf = [&](const float *x, double *y) { bjac_apply_f32(c, x, y); };
+    S.st.inner_iters += gmres_f32basis(c, S.nuo, basis_ld(S.nuo), Auu, Pf, S.utmp, dst0, o->inner_restart, o->inner_maxit,
+                                       o->inner_rel * un, reinterpret_cast<float *>(c->innerV.p), S.inner_z, S.inner_w, &res,
+                                       [&](double *v, int k) { allreduce_sum(c, v, k); });
+  } else
   S.st.inner_iters += gmres(c, S.nuo, basis_ld(S.nuo), /*reorth=*/false, Auu, Pj, false, S.utmp, dst0, o->inner_restart,
                             o->inner_maxit, o->inner_rel * un, c->innerV.p, S.inner_z, S.inner_w, &res, mdot);
   IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -262,7 +340,11 @@ static void carve_workspace(SolveState &S) {
   const int m = S.o->fgmres_restart, mi = S.o->inner_restart;
   if ((int64_t)c->krylovV.n < (int64_t)(m + 1) * basis_ld(S.n)) c->krylovV.alloc((int64_t)(m + 1) * basis_ld(S.n));
   if ((int64_t)c->krylovZ.n < (int64_t)m * basis_ld(S.n)) c->krylovZ.alloc((int64_t)m * basis_ld(S.n));
-  if ((int64_t)c->innerV.n < (int64_t)(mi + 1) * basis_ld(S.nuo)) c->innerV.alloc((int64_t)(mi + 1) * basis_ld(S.nuo));
+  if ((int64_t)c->innerV.n < (int64_t)(mi + 1) * basis_ld(S.nuo)) {
+    c->innerV.alloc((int64_t)(mi + 1) * basis_ld(S.nuo));
+    // the single-precision basis reads (with zero coefficients) up to 3 columns past the ones in use: keep them finite
+    IFEM_HIP_CHECK(hipMemsetAsync(c->innerV.p, 0, c->innerV.n * sizeof(double), c->stream));
+  }
 }
 
 void ins_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, const double *src, double *dst) {
@@ -347,6 +429,8 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   Clock total;
   ctx->spmv_uu_ms_total = 0;
   ctx->timing.spmv_uu_calls = 0;
+  ctx->mf_ms_total = 0;
+  ctx->timing.mf_calls = 0;
   double *rhs = ctx->vec[IFEM_VEC_RHS].p, *upd = ctx->vec[IFEM_VEC_UPDATE].p;
   auto mdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
     v_mdot(ctx, S.n, k, V, ld, w, out);
@@ -369,6 +453,7 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   S.st.fgmres_res = res;
   S.st.t_total_ms = total.ms();
   S.st.t_spmv_ms = ctx->spmv_uu_ms_total;
+  ctx->timing.mf_ms_avg = ctx->timing.mf_calls ? ctx->mf_ms_total / ctx->timing.mf_calls : 0;
   ctx->timing.spmv_uu_ms_avg = ctx->timing.spmv_uu_calls ? ctx->spmv_uu_ms_total / ctx->timing.spmv_uu_calls : 0;
   if (stats) *stats = S.st;
   if (o->verbose)

@@ -221,9 +221,9 @@ def test_no_cpu_fallback_error_path():
     assert L.ifem_device_count() >= 1
 
 
-@pytest.mark.parametrize("kind", [1, 2])
+@pytest.mark.parametrize("kind", [1, 2, 3])
 def test_solve_with_cheaper_ainv_variants(kind):
-    # IFEM_AINV_GMRES_BJACOBI_F32 (1) and IFEM_AINV_SCALAR_GMRES (2) only change the preconditioner: the FGMRES result
+    # IFEM_AINV_GMRES_BJACOBI_F32 (1), IFEM_AINV_SCALAR_GMRES (2) and the matrix-free operator (3) only change the preconditioner: the FGMRES result
     # must still satisfy the reference stopping rule against the ORACLE's fp64 matrix
     capi = _capi()
     m = BoxMesh((8, 8, 8), (0, 0, 0), (2.0, 0.2, 0.2), kv=2)
@@ -245,6 +245,40 @@ def test_solve_with_cheaper_ainv_variants(kind):
     A, b = S.csr("A"), S.rhs()
     assert np.linalg.norm(A @ upd - b) <= 1.05e-4 * np.linalg.norm(b)
     assert st.fgmres_iters <= 12
+
+
+@pytest.mark.parametrize("dim,kv,reps", [(2, 2, (5, 3)), (2, 1, (6, 4)), (3, 2, (3, 2, 2)), (3, 1, (3, 3, 2))])
+@pytest.mark.parametrize("use_nonzero", [False, True])
+def test_matrix_free_uu_apply_equals_assembled_block(dim, kv, reps, use_nonzero):
+    # apply_mf.hip (sum-factorised cell kernel, no stored matrix) against the u-u block of the ORACLE's matrix on
+    # distorted cells with Dirichlet elimination: same operator to fp64 rounding
+    capi = _capi()
+    rng = np.random.default_rng(17 + dim + kv)
+    m = BoxMesh(reps, (0,) * dim, (1.0, 0.6, 0.4)[:dim], kv=kv)
+    m.vcoords = m.vcoords + 0.02 * rng.standard_normal(m.vcoords.shape)
+    flag = 3 if dim == 2 else 7
+    dofs, vals = m.dirichlet({0: (flag, [0.3, -0.2, 0.1][:dim]), 2: (flag, [0.0] * dim), 3: (1, [0.05])})
+    kw = dict(mu=0.7, rho=1.3, gamma=0.2, dt=0.01, g=(0.3, -9.8, 0.5)[:dim], neumann={1: 2.5})
+    ev, pr = _rand_state(m, rng)
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.vec_set(capi.VEC_PRESENT, pr)
+    ctx.vec_set(capi.VEC_EVAL, ev)
+    ctx.assemble(capi.make_params(**kw), use_nonzero)
+    ctx.vec_set(capi.VEC_EVAL, pr)  # the operator must keep the evaluation point of the assemble, not the live vector
+    S = orc.System(m)
+    S.set_constraints(0, dofs, None)
+    S.set_constraints(1, dofs, vals)
+    S.assemble(orc.make_params(**kw), use_nonzero, ev, pr)
+    n_u = m.dim * m.n_unodes
+    Auu = S.csr("A")[:n_u, :n_u]
+    x = rng.standard_normal(m.n_dofs)
+    want = Auu @ x[:n_u]
+    for variant, tol in ((0, 1e-13), (3, 1e-12)):
+        y = ctx.uu_vmult(x, variant)[:n_u]
+        assert np.abs(y - want).max() / np.abs(want).max() < tol, variant
+    ctx.close()
 
 
 def test_kat_fluid_cylinder_mpi_on_gpu():
