@@ -72,6 +72,34 @@ int ifem_ctx_create(const ifem_mesh_desc *m, const ifem_partition *part, int dev
   IFEM_HIP_CHECK(hipHostMalloc((void **)&ctx->h_scal, 256 * sizeof(double)));
   ctx->scal.alloc(256);
   if (const char *e = getenv("IFEM_ASM")) ctx->asm_rows = std::string(e) == "rows";
+  { // greedy cell colouring on the vertices (two cells share a node iff they share a vertex)
+    const char *e = getenv("IFEM_ASM");
+    if (!(e && std::string(e) == "atomic")) {
+      std::vector<uint64_t> used((size_t)ctx->nPl, 0);
+      std::vector<uint8_t> col((size_t)m->n_cells);
+      int ncol = 0;
+      bool ok = true;
+      for (int64_t c = 0; c < m->n_cells && ok; ++c) {
+        uint64_t msk = 0;
+        for (int v = 0; v < np; ++v) msk |= used[m->cell_pnodes[c * np + v]];
+        if (~msk == 0) { ok = false; break; }
+        const int k = __builtin_ctzll(~msk);
+        col[c] = (uint8_t)k;
+        ncol = std::max(ncol, k + 1);
+        for (int v = 0; v < np; ++v) used[m->cell_pnodes[c * np + v]] |= uint64_t(1) << k;
+      }
+      if (ok && m->n_cells > 0) {
+        ctx->color_ptr.assign((size_t)ncol + 1, 0);
+        for (int64_t c = 0; c < m->n_cells; ++c) ctx->color_ptr[col[c] + 1]++;
+        for (int k = 0; k < ncol; ++k) ctx->color_ptr[k + 1] += ctx->color_ptr[k];
+        std::vector<int64_t> next(ctx->color_ptr.begin(), ctx->color_ptr.end() - 1);
+        std::vector<int32_t> order((size_t)m->n_cells);
+        for (int64_t c = 0; c < m->n_cells; ++c) order[next[col[c]]++] = (int32_t)c;
+        ctx->color_order.upload(order.data(), order.size(), s);
+        IFEM_HIP_CHECK(hipStreamSynchronize(s));
+      }
+    }
+  }
   comm_init(ctx, part);
   {
     double g[2] = {double(ctx->dim * ctx->nUo), double(ctx->nPo)};

@@ -12,56 +12,9 @@
 #include <hip/hip_runtime.h>
 #include "ctx.hpp"
 #include "kernels.hpp"
+#include "assemble_common.hpp"
 
 namespace ifem {
-
-template <int DIM, int KV>
-struct Geo {
-  static constexpr int N1 = KV + 1;
-  static constexpr int NU = (DIM == 2) ? N1 * N1 : N1 * N1 * N1;
-  static constexpr int NP = (DIM == 2) ? 4 : 8;
-  static constexpr int NQ = NU;
-  static constexpr int ND = NU * DIM + NP;
-};
-
-struct AsmArgs {
-  int64_t n_cells;
-  int64_t nUo, nUl, nPo;
-  const FeTables *fe;
-  const double *vcoords;
-  const int32_t *cell_unodes, *cell_pnodes, *cell_face_bid, *indicator;
-  const uint16_t *posUU, *posUP, *posPU, *posPP;
-  const int64_t *rp_uu, *rp_bt, *rp_b, *rp_mp;
-  double *v_uu, *v_bt, *v_b, *v_mp, *diagMu, *rhs;
-  double *v_s; // scalar velocity operator (one value per A_uu block) or nullptr
-  const uint8_t *is_c;
-  const double *cval;
-  const double *eval, *present, *fsi_acc;
-  double mu, rho, gamma, inv_dt;
-  double g[3];
-  int n_neumann;
-  int neumann_id[8];
-  double neumann_p[8];
-  int use_inhom; // constraint set carries non-zero inhomogeneities
-};
-
-template <int DIM>
-__device__ inline double inv_small(const double *J, double *Ji) {
-  if constexpr (DIM == 2) {
-    const double det = J[0] * J[3] - J[1] * J[2];
-    const double r = 1.0 / det;
-    Ji[0] = J[3] * r; Ji[1] = -J[1] * r; Ji[2] = -J[2] * r; Ji[3] = J[0] * r;
-    return det;
-  } else {
-    const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
-    const double det = J[0] * c00 + J[1] * c01 + J[2] * c02;
-    const double r = 1.0 / det;
-    Ji[0] = c00 * r; Ji[3] = c01 * r; Ji[6] = c02 * r;
-    Ji[1] = (J[2] * J[7] - J[1] * J[8]) * r; Ji[4] = (J[0] * J[8] - J[2] * J[6]) * r; Ji[7] = (J[1] * J[6] - J[0] * J[7]) * r;
-    Ji[2] = (J[1] * J[5] - J[2] * J[4]) * r; Ji[5] = (J[2] * J[3] - J[0] * J[5]) * r; Ji[8] = (J[0] * J[4] - J[1] * J[3]) * r;
-    return det;
-  }
-}
 
 template <int DIM, int KV>
 struct CellScratch {
@@ -89,7 +42,7 @@ struct SharedTables {
   double w[G_::NQ];
 };
 
-template <int DIM, int KV, int WPB>
+template <int DIM, int KV, int WPB, bool ATOMIC>
 __global__ __launch_bounds__(64 * WPB) void k_ins_assemble(AsmArgs A) {
   using G_ = Geo<DIM, KV>;
   constexpr int NU = G_::NU, NP = G_::NP, NQ = G_::NQ, ND = G_::ND;
@@ -105,9 +58,9 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble(AsmArgs A) {
   for (int i = threadIdx.x; i < NQ * NP * DIM; i += blockDim.x) T.dpsi[i] = A.fe->dpsi[i];
   for (int i = threadIdx.x; i < NQ; i += blockDim.x) T.w[i] = A.fe->w[i];
 
-  const int64_t cell = int64_t(blockIdx.x) * WPB + wave;
-  const bool active = cell < A.n_cells;
-  const int64_t cc = active ? cell : 0;
+  const int64_t idx = int64_t(blockIdx.x) * WPB + wave;
+  const bool active = idx < A.count;
+  const int64_t cc = active ? (A.order ? int64_t(A.order[A.first + idx]) : idx) : 0;
   const int64_t p_off = int64_t(DIM) * A.nUl;
 
   // ---- phase 0: ids, coordinates, nodal values, row descriptors, constraint flags
@@ -237,8 +190,22 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble(AsmArgs A) {
 
   const double wgam = A.gamma * A.rho, rdt = A.rho * A.inv_dt;
   // ---- phase 4: velocity-velocity blocks + scatter
+  // (plain read-modify-write variant: the old values are requested before the contraction and consumed after it, so
+  //  the load latency hides behind ~1000 FMAs instead of stalling the wave)
   for (int t = lane; t < NU * NU; t += 64) {
     const int a = t / NU, b = t - a * NU;
+    const int len = S.len_uu[a];
+    const bool row_here = active && len >= 0; // row owned by this rank
+    double *base = nullptr;
+    double old[DIM * DIM];
+    if (row_here) {
+      const uint16_t pos = A.posUU[(cc * NU + a) * NU + b];
+      base = A.v_uu + S.rs_uu[a] * (DIM * DIM) + pos;
+      if constexpr (!ATOMIC) {
+#pragma unroll
+        for (int e = 0; e < DIM * DIM; ++e) old[e] = base[int64_t(e) * len];
+      }
+    }
     double s = 0, acc[DIM * DIM];
     for (int i = 0; i < DIM * DIM; ++i) acc[i] = 0;
     for (int q = 0; q < NQ; ++q) {
@@ -252,23 +219,21 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble(AsmArgs A) {
         for (int d = 0; d < DIM; ++d) acc[c * DIM + d] += m * S.gq[q * DIM * DIM + c * DIM + d] + wg * ga[c] * gb[d];
     }
     for (int c = 0; c < DIM; ++c) acc[c * DIM + c] += s;
-    if (!active) continue;
-    const int len = S.len_uu[a];
-    if (len < 0) continue; // row owned by another rank
-    const uint16_t pos = A.posUU[(cc * NU + a) * NU + b];
-    double *base = A.v_uu + S.rs_uu[a] * (DIM * DIM) + pos;
+    if (!row_here) continue;
     const int64_t row_dof0 = int64_t(DIM) * S.un[a];
-    if (A.v_s) unsafeAtomicAdd(A.v_s + S.rs_uu[a] + pos, s);
+    if (A.v_s) gadd<ATOMIC>(A.v_s + (base - A.v_uu - S.rs_uu[a] * (DIM * DIM)) + S.rs_uu[a], s);
     for (int c = 0; c < DIM; ++c) {
       const bool rc = S.cf[a * DIM + c];
       for (int d = 0; d < DIM; ++d) {
         const bool ccn = S.cf[b * DIM + d];
         const double v = acc[c * DIM + d];
-        if (!rc && !ccn) unsafeAtomicAdd(base + int64_t(c * DIM + d) * len, v);
-        else if (rc) {
+        double *dst = base + int64_t(c * DIM + d) * len;
+        if (!rc && !ccn) {
+          if constexpr (ATOMIC) unsafeAtomicAdd(dst, v); else *dst = old[c * DIM + d] + v;
+        } else if (rc) {
           if (a == b && c == d) { // |Ke(r,r)| on the diagonal, rhs so that the update equals the inhomogeneity
-            unsafeAtomicAdd(base + int64_t(c * DIM + d) * len, fabs(v));
-            if (A.use_inhom) unsafeAtomicAdd(&A.rhs[row_dof0 + c], S.cv[a * DIM + c] * fabs(v));
+            if constexpr (ATOMIC) unsafeAtomicAdd(dst, fabs(v)); else *dst = old[c * DIM + d] + fabs(v);
+            if (A.use_inhom) gadd<ATOMIC>(&A.rhs[row_dof0 + c], S.cv[a * DIM + c] * fabs(v));
           }
         } else if (A.use_inhom) {
           const double g = S.cv[b * DIM + d];
@@ -280,6 +245,19 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble(AsmArgs A) {
   // ---- phase 5: velocity-pressure blocks (block (0,1) = B^T and block (1,0) = B)
   for (int t = lane; t < NU * NP; t += 64) {
     const int a = t / NP, pb = t - a * NP;
+    const bool bt_here = active && S.len_bt[a] >= 0, b_here = active && S.len_b[pb] >= 0;
+    double *base_bt = nullptr, *base_b = nullptr;
+    double old_bt[DIM], old_b[DIM];
+    if (bt_here) {
+      base_bt = A.v_bt + S.rs_bt[a] * DIM + A.posUP[(cc * NU + a) * NP + pb];
+      if constexpr (!ATOMIC)
+        for (int c = 0; c < DIM; ++c) old_bt[c] = base_bt[int64_t(c) * S.len_bt[a]];
+    }
+    if (b_here) {
+      base_b = A.v_b + S.rs_b[pb] * DIM + A.posPU[(cc * NP + pb) * NU + a];
+      if constexpr (!ATOMIC)
+        for (int c = 0; c < DIM; ++c) old_b[c] = base_b[int64_t(c) * S.len_b[pb]];
+    }
     double v[DIM];
     for (int c = 0; c < DIM; ++c) v[c] = 0;
     for (int q = 0; q < NQ; ++q) {
@@ -288,20 +266,18 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble(AsmArgs A) {
     }
     if (!active) continue;
     const bool pc = S.cf[NU * DIM + pb];
-    if (S.len_bt[a] >= 0) {
+    if (bt_here) {
       const int len = S.len_bt[a];
-      double *base = A.v_bt + S.rs_bt[a] * DIM + A.posUP[(cc * NU + a) * NP + pb];
       for (int c = 0; c < DIM; ++c) {
         if (S.cf[a * DIM + c]) continue;
-        if (!pc) unsafeAtomicAdd(base + int64_t(c) * len, v[c]);
+        if (!pc) { if constexpr (ATOMIC) unsafeAtomicAdd(base_bt + int64_t(c) * len, v[c]); else base_bt[int64_t(c) * len] = old_bt[c] + v[c]; }
         else if (A.use_inhom && S.cv[NU * DIM + pb] != 0.0) unsafeAtomicAdd(&S.fe[a * DIM + c], -v[c] * S.cv[NU * DIM + pb]);
       }
     }
-    if (S.len_b[pb] >= 0 && !pc) {
+    if (b_here && !pc) {
       const int len = S.len_b[pb];
-      double *base = A.v_b + S.rs_b[pb] * DIM + A.posPU[(cc * NP + pb) * NU + a];
       for (int c = 0; c < DIM; ++c) {
-        if (!S.cf[a * DIM + c]) unsafeAtomicAdd(base + int64_t(c) * len, v[c]);
+        if (!S.cf[a * DIM + c]) { if constexpr (ATOMIC) unsafeAtomicAdd(base_b + int64_t(c) * len, v[c]); else base_b[int64_t(c) * len] = old_b[c] + v[c]; }
         else if (A.use_inhom && S.cv[a * DIM + c] != 0.0) unsafeAtomicAdd(&S.fe[NU * DIM + pb], -v[c] * S.cv[a * DIM + c]);
       }
     }
@@ -314,14 +290,14 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble(AsmArgs A) {
     if (!active || S.len_mp[pa] < 0) continue;
     const bool ra = S.cf[NU * DIM + pa], cb = S.cf[NU * DIM + pb];
     double *dst = A.v_mp + S.rs_mp[pa] + A.posPP[(cc * NP + pa) * NP + pb];
-    if (!ra && !cb) unsafeAtomicAdd(dst, m);
-    else if (ra && pa == pb) unsafeAtomicAdd(dst, fabs(m));
+    if (!ra && !cb) gadd<ATOMIC>(dst, m);
+    else if (ra && pa == pb) gadd<ATOMIC>(dst, fabs(m));
   }
   for (int a = lane; a < NU; a += 64) {
     double m = 0;
     for (int q = 0; q < NQ; ++q) { const double N = T.phi[q * NU + a]; m += S.JxW[q] * N * N; }
     if (active && S.len_uu[a] >= 0)
-      for (int c = 0; c < DIM; ++c) unsafeAtomicAdd(&A.diagMu[int64_t(DIM) * S.un[a] + c], m);
+      for (int c = 0; c < DIM; ++c) gadd<ATOMIC>(&A.diagMu[int64_t(DIM) * S.un[a] + c], m);
   }
   __syncthreads();
   // ---- phase 7: rhs scatter (unconstrained owned rows; constrained rows were handled with the diagonal)
@@ -330,10 +306,10 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble(AsmArgs A) {
       if (S.cf[i]) continue;
       if (i < NU * DIM) {
         const int a = i / DIM, c = i - a * DIM;
-        if (S.len_uu[a] >= 0) unsafeAtomicAdd(&A.rhs[int64_t(DIM) * S.un[a] + c], S.fe[i]);
+        if (S.len_uu[a] >= 0) gadd<ATOMIC>(&A.rhs[int64_t(DIM) * S.un[a] + c], S.fe[i]);
       } else {
         const int b = i - NU * DIM;
-        if (S.len_b[b] >= 0) unsafeAtomicAdd(&A.rhs[int64_t(DIM) * A.nUo + S.pn[b]], S.fe[i]);
+        if (S.len_b[b] >= 0) gadd<ATOMIC>(&A.rhs[int64_t(DIM) * A.nUo + S.pn[b]], S.fe[i]);
       }
     }
   }
@@ -345,16 +321,32 @@ static void launch_t(ifem_ctx *ctx, const AsmArgs &A) {
   const size_t smem = sizeof(SharedTables<DIM, KV>) + WPB * sizeof(CellScratch<DIM, KV>);
   static bool attr_set = false;
   if (!attr_set) {
-    IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ins_assemble<DIM, KV, WPB>),
+    IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ins_assemble<DIM, KV, WPB, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ins_assemble<DIM, KV, WPB, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
-  const int64_t nblk = (A.n_cells + WPB - 1) / WPB;
-  hipLaunchKernelGGL((k_ins_assemble<DIM, KV, WPB>), dim3((unsigned)nblk), dim3(64 * WPB), smem, ctx->stream, A);
+  static const bool use_rmw = [] { const char *e = getenv("IFEM_ASM_SCATTER"); return e && std::string(e) == "rmw"; }();
+  if (ctx->color_ptr.empty() || !use_rmw) { // one launch, hardware atomics (see assemble2.hip for the measurement)
+    AsmArgs B = A;
+    B.order = nullptr; B.first = 0; B.count = A.n_cells;
+    const int64_t nblk = (B.count + WPB - 1) / WPB;
+    hipLaunchKernelGGL((k_ins_assemble<DIM, KV, WPB, true>), dim3((unsigned)nblk), dim3(64 * WPB), smem, ctx->stream, B);
+  } else { // one launch per colour (stream order separates them): conflict-free plain read-modify-write
+    for (size_t k = 0; k + 1 < ctx->color_ptr.size(); ++k) {
+      AsmArgs B = A;
+      B.order = ctx->color_order.p; B.first = ctx->color_ptr[k]; B.count = ctx->color_ptr[k + 1] - ctx->color_ptr[k];
+      if (B.count == 0) continue;
+      const int64_t nblk = (B.count + WPB - 1) / WPB;
+      hipLaunchKernelGGL((k_ins_assemble<DIM, KV, WPB, false>), dim3((unsigned)nblk), dim3(64 * WPB), smem, ctx->stream, B);
+    }
+  }
   IFEM_HIP_CHECK(hipGetLastError());
 }
 
 static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero);
+void launch_ins_assemble2_kernel(ifem_ctx *ctx, const AsmArgs &A);
 
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) {
   hipStream_t s = ctx->stream;
@@ -403,7 +395,9 @@ void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzer
   A.n_neumann = p->n_neumann;
   for (int i = 0; i < 8; ++i) { A.neumann_id[i] = p->neumann_id[i]; A.neumann_p[i] = p->neumann_p[i]; }
   IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s));
-  if (dim == 2 && ctx->kv == 1) launch_t<2, 1>(ctx, A);
+  static const bool v1 = [] { const char *e = getenv("IFEM_ASM"); return e && std::string(e) == "v1"; }();
+  if (!v1) launch_ins_assemble2_kernel(ctx, A); // assemble2.hip (quadrature-point-outer, register accumulators)
+  else if (dim == 2 && ctx->kv == 1) launch_t<2, 1>(ctx, A);
   else if (dim == 2 && ctx->kv == 2) launch_t<2, 2>(ctx, A);
   else if (dim == 3 && ctx->kv == 1) launch_t<3, 1>(ctx, A);
   else if (dim == 3 && ctx->kv == 2) launch_t<3, 2>(ctx, A);

@@ -1,0 +1,67 @@
+// assemble_common.hpp -- argument block and small helpers shared by the InsIM assembly kernels (assemble.hip: first
+// version with the physical-gradient table in LDS; assemble2.hip: quadrature-point-outer version with register
+// accumulators).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ctx.hpp"
+
+namespace ifem {
+
+template <int DIM, int KV>
+struct Geo {
+  static constexpr int N1 = KV + 1;
+  static constexpr int NU = (DIM == 2) ? N1 * N1 : N1 * N1 * N1;
+  static constexpr int NP = (DIM == 2) ? 4 : 8;
+  static constexpr int NQ = NU;
+  static constexpr int ND = NU * DIM + NP;
+};
+
+struct AsmArgs {
+  int64_t n_cells;
+  const int32_t *order; // cells of the colour being assembled (nullptr: all cells, atomics)
+  int64_t first, count; // range of `order` handled by this launch
+  int64_t nUo, nUl, nPo;
+  const FeTables *fe;
+  const double *vcoords;
+  const int32_t *cell_unodes, *cell_pnodes, *cell_face_bid, *indicator;
+  const uint16_t *posUU, *posUP, *posPU, *posPP;
+  const int64_t *rp_uu, *rp_bt, *rp_b, *rp_mp;
+  double *v_uu, *v_bt, *v_b, *v_mp, *diagMu, *rhs;
+  double *v_s; // scalar velocity operator (one value per A_uu block) or nullptr
+  const uint8_t *is_c;
+  const double *cval;
+  const double *eval, *present, *fsi_acc;
+  double mu, rho, gamma, inv_dt;
+  double g[3];
+  int n_neumann;
+  int neumann_id[8];
+  double neumann_p[8];
+  int use_inhom; // constraint set carries non-zero inhomogeneities
+};
+
+template <int DIM>
+__device__ inline double inv_small(const double *J, double *Ji) {
+  if constexpr (DIM == 2) {
+    const double det = J[0] * J[3] - J[1] * J[2];
+    const double r = 1.0 / det;
+    Ji[0] = J[3] * r; Ji[1] = -J[1] * r; Ji[2] = -J[2] * r; Ji[3] = J[0] * r;
+    return det;
+  } else {
+    const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+    const double det = J[0] * c00 + J[1] * c01 + J[2] * c02;
+    const double r = 1.0 / det;
+    Ji[0] = c00 * r; Ji[3] = c01 * r; Ji[6] = c02 * r;
+    Ji[1] = (J[2] * J[7] - J[1] * J[8]) * r; Ji[4] = (J[0] * J[8] - J[2] * J[6]) * r; Ji[7] = (J[1] * J[6] - J[0] * J[7]) * r;
+    Ji[2] = (J[1] * J[5] - J[2] * J[4]) * r; Ji[5] = (J[2] * J[3] - J[0] * J[5]) * r; Ji[8] = (J[0] * J[4] - J[1] * J[3]) * r;
+    return det;
+  }
+}
+
+// scatter add into global memory: hardware atomic, or plain read-modify-write when the launch covers one colour
+template <bool ATOMIC>
+__device__ inline void gadd(double *p, double v) {
+  if constexpr (ATOMIC) unsafeAtomicAdd(p, v);
+  else *p += v;
+}
+
+} // namespace ifem

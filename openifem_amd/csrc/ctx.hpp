@@ -115,6 +115,10 @@ struct ifem_ctx {
   // SCnsIM (slightly compressible, SUPG): pressure-pressure block on the M_p pattern, nodal stress fields, cell fields
   ifem::DBuf<double> App, app_diag, stress, fsi_stress, sigma_pml, body_force, xinv;
   bool has_app = false, stress_valid = false;
+  // cell colouring: cells of one colour share no node, so a launch over one colour scatters with plain read-modify-write
+  // instead of atomics (gfx950 retires f64 atomics at ~24 G 64-byte segments/s whatever the scope; plain RMW is 2-5x faster)
+  ifem::DBuf<int32_t> color_order; // cells sorted by colour (stable: Morton order inside a colour)
+  std::vector<int64_t> color_ptr;  // [n_colors + 1]; empty = colouring unavailable, atomics are used
   ifem::PlanarCsr uinc, pinc;  // node -> (cell << 5 | local index) incidence lists (row-owner assembly)
   ifem::DBuf<double> qdata;    // per cell, per quadrature point geometry + evaluation-point fields
   bool asm_rows = false;       // true (IFEM_ASM=rows): atomics-free row-owner assembly (assemble_rows.hip): bit-reproducible,
