@@ -20,16 +20,37 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (MI355X_MICROARCH.md; 68-77 TF measured, profiles/r01_microbench.txt)
 
 
-def pmc_traffic(n, variant):
+def pmc_traffic(kernel, n, variant):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["k_spmv_uu"][str(n)][variant]["traffic_bytes"]
+            return json.load(f)[kernel][str(n)][variant]["traffic_bytes"]
     except Exception:
         return None
+
+
+def kernel_models(L, ctx, n_cells, n_u, n_p, dim=3, nu=27, npn=8):
+    """Algorithmic bytes / flops per launch of the two heaviest kernels (DESIGN.md section 4 states the same figures).
+
+    assembly (k_ins_assemble2): every stored matrix / vector value written once + per cell the mesh tables and the three
+      nodal vectors it gathers (~46 kB per 3D Q2/Q1 cell); flops of the component-block form actually
+      executed: per (node pair, point) 24 FMA + 5 mul, per (u-node, p-node, point) 1 + dim FMA.
+    matrix-free A_uu (k_apply_uu_mf2): x, evaluation point, constraint flags and y once per entry + per cell vertex
+      coordinates and node ids; flops of the sum-factorised passes + the quadrature-point stage.
+    """
+    nnz_uu, nnz_b, nnz_mp = L.ifem_nnz(ctx, 0), L.ifem_nnz(ctx, 1), L.ifem_nnz(ctx, 2)
+    nd = nu * dim + npn
+    asm_bytes = 8.0 * (nnz_uu * dim * dim + 2 * nnz_b * dim + nnz_mp + n_u + n_u + n_p) + n_cells * (npn * dim * 8 + (nu + npn) * 4 + 3 * nd * 8)
+    asm_flops = n_cells * nu * (nu * nu * (2 * 24 + 5) + nu * npn * 2 * (1 + dim))
+    mf_bytes = n_u * (8 + 8 + 8 + 1) + n_cells * (npn * dim * 8 + nu * 4)
+    n1 = round(nu ** (1.0 / dim))
+    passes = (2 * dim) * dim * nu * n1 * 2 * 2 + dim * dim * nu * n1 * 2 * 2  # eval+grad of 2*dim fields, transposed grad+eval of dim fields
+    mf_flops = n_cells * (passes + nu * 190)
+    return {"asm": (asm_bytes, asm_flops), "mf": (mf_bytes, mf_flops)}
 
 
 def cpu_baseline(n_cpu, threads):
@@ -70,7 +91,7 @@ def main():
     ap.add_argument("--cells", dest="n", type=int, default=128, help="cells per direction per GPU")
     ap.add_argument("--cpu-cells", dest="cpu_n", type=int, default=24, help="cells per direction of the CPU baseline sample (0 = skip)")
     ap.add_argument("--inner-rel", type=float, default=1e-2)
-    ap.add_argument("--ainv", type=int, default=1, help="IFEM_AINV_* kind of the A_uu^-1 replacement (1 = fp32 inner matrix)")
+    ap.add_argument("--ainv", type=int, default=3, help="IFEM_AINV_* kind of the A_uu^-1 replacement (3 = matrix-free inner operator, 1 = fp32 inner matrix, 0 = fp64 matrix)")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
     args = ap.parse_args()
 
@@ -142,7 +163,31 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     if rank == 0:
         spmv_avg_ms = spmv_ms / max(spmv_calls, 1)
-        achieved = tm.spmv_uu_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
+        mf_avg_ms = mf_ms / max(mf_calls, 1)
+        # dominant kernel = largest total time per step among the three heavy kernels, each timed live with HIP events
+        totals = {"asm": tm.assemble_kernel_ms, "mf": mf_ms / args.steps, "spmv": spmv_ms / args.steps}
+        dom = max(totals, key=totals.get)
+        models = kernel_models(solver.L, solver.ctx, n_cells, n_u, n_p)
+        if dom == "spmv":
+            achieved = tm.spmv_uu_bytes / (spmv_avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_spmv_uu<3,32,%s> (A_uu block-row SpMV of the inner solver)" % ("float" if args.ainv == 1 else "double"),
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": pmc_traffic("k_spmv_uu", n, "f32" if args.ainv == 1 else "f64") if world == 1 else None,
+                    "launch_ms": spmv_avg_ms, "launches_timed": spmv_calls, "algorithmic_bytes": tm.spmv_uu_bytes}
+        else:
+            name = {"asm": "k_ins_assemble2<3,2> (cell integration + scatter)", "mf": "k_apply_uu_mf2<3,2> (matrix-free A_uu of the inner solver)"}[dom]
+            ms = tm.assemble_kernel_ms if dom == "asm" else mf_avg_ms
+            nb, nf = models[dom]
+            gbs, tfs = nb / (ms * 1e-3) / 1e9, nf / (ms * 1e-3) / 1e12
+            # report against the nearer ceiling; both fractions stay in the line
+            if tfs / FP64_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS:
+                roof = {"bound": "mfma", "achieved": tfs, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / FP64_PEAK_TFLOPS}
+            else:
+                roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+            roof.update({"kernel": name, "traffic": pmc_traffic("k_ins_assemble2" if dom == "asm" else "k_apply_uu_mf2", n, "f64") if world == 1 else None,
+                         "launch_ms": ms, "launches_timed": args.steps if dom == "asm" else mf_calls,
+                         "algorithmic_bytes": nb, "algorithmic_flops": nf, "hbm_frac": gbs / HBM_PEAK_GBS, "fp64_frac": tfs / FP64_PEAK_TFLOPS,
+                         "kernel_ms_per_step": totals})
         out = {
             "metric": "DoF/s per Newton step (assemble+solve), 3D INS Q2/Q1",
             "value": n_dofs_global / (elapsed / args.steps),
@@ -160,10 +205,7 @@ def main():
                        "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "ainv_kind": args.ainv,
                        "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms,
                        "mf_apply_ms": mf_ms / max(mf_calls, 1), "mf_applies": mf_calls},
-            "roofline": {"bound": "hbm", "kernel": "k_spmv_uu<3,32,%s> (A_uu block-row SpMV of the inner solver)" % ("float" if args.ainv == 1 else "double"), "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(n, "f32" if args.ainv == 1 else "f64") if world == 1 and args.ainv in (0, 1) else None, "launch_ms": spmv_avg_ms, "launches_timed": spmv_calls,
-                         "algorithmic_bytes": tm.spmv_uu_bytes},
+            "roofline": roof,
         }
         if args.cpu_n > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, os.cpu_count() or 1)

@@ -47,7 +47,7 @@ void app_diag_setup(ifem_ctx *ctx);
 void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp);
 // explicit S_m: numeric product B diag(1/diag M_u) B^T into ctx->Sm (pattern must exist), and y_p = S_m x_p
 void schur_numeric(ifem_ctx *ctx);
-void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp);
+void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp, bool use_f32);
 // y_u = d .* x_u (diagonal scaling with 1/diag(M_u))
 void vec_mul(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y);
 void vec_div(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y); // y = x ./ d (d == 0 -> 1)

@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256) void k_spmv_uu(int64_t n_rows, const int64_t *
 }
 
 // y = M x with BR x BC blocks, generic (B: 1 x DIM, B^T: DIM x 1, M_p / S_m: 1 x 1)
-template <int BR, int BC, int G>
+template <int BR, int BC, int G, class VT = double>
 __global__ __launch_bounds__(256) void k_spmv_planar(int64_t n_rows, const int64_t *__restrict__ rp,
-                                                     const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                     const int32_t *__restrict__ col, const VT *__restrict__ val,
                                                      const double *__restrict__ x, double *__restrict__ y) {
   const int64_t row = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
   const int lig = threadIdx.x & (G - 1);
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_spmv_planar(int64_t n_rows, const int64
   for (int r = 0; r < BR; ++r) acc[r] = 0;
   const int64_t rs = rp[row];
   const int len = int(rp[row + 1] - rs);
-  row_planar_dot<BR, BC, G, true>(rs, len, col, val, x, lig, acc);
+  row_planar_dot<BR, BC, G, true, VT>(rs, len, col, val, x, lig, acc);
 #pragma unroll
   for (int r = 0; r < BR; ++r) acc[r] = group_sum<G>(acc[r]);
   if (lig == 0) {
@@ -369,13 +369,24 @@ void schur_numeric(ifem_ctx *ctx) {
                        ctx->Bt.col.p, ctx->Bt.val.p, ctx->dinvMu.p);
   IFEM_HIP_CHECK(hipGetLastError());
   ctx->sm_valid = true;
+  ctx->sm_f32_valid = false;
 }
 
-void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp) {
+void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp, bool use_f32) {
   const int64_t n = ctx->Sm.n_rows;
   if (n == 0) return;
-  hipLaunchKernelGGL((k_spmv_planar<1, 1, 32>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n,
-                     ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm.val.p, xp, yp);
+  if (use_f32 && !ctx->sm_f32_valid) {
+    const int64_t nv = (int64_t)ctx->Sm.val.n;
+    if (ctx->Sm_f32.n != (size_t)nv) ctx->Sm_f32.alloc(nv);
+    hipLaunchKernelGGL(k_to_f32, dim3(8192), dim3(256), 0, ctx->stream, nv, ctx->Sm.val.p, ctx->Sm_f32.p);
+    ctx->sm_f32_valid = true;
+  }
+  if (use_f32)
+    hipLaunchKernelGGL((k_spmv_planar<1, 1, 32, float>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n,
+                       ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm_f32.p, xp, yp);
+  else
+    hipLaunchKernelGGL((k_spmv_planar<1, 1, 32>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n,
+                       ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm.val.p, xp, yp);
 }
 
 // ---------------------------------------------------------------------------------------------------

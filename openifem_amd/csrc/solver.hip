@@ -273,7 +273,9 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     schur_numeric(c);
   }
   OpFn sm = [&](const double *x, double *y) {
-    if (explicit_sm) { spmv_sm(c, x, y); return; }
+    // the approximate-preconditioner kinds (1, 3) also stream S_m in single precision: it only ever acts inside CG to
+    // 1e-3 ||v|| and the rounding (6e-8 relative) is far below the eigenvalue ratio of this Laplacian-like operator
+    if (explicit_sm) { spmv_sm(c, x, y, o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF); return; }
     const double *xe; extend_p(S, x, &xe);
     spmv_bt(c, xe, S.tu);
     vec_mul(c, S.nuo, c->dinvMu.p, S.tu, S.tu);

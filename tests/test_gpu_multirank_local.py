@@ -11,11 +11,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run_single(reps, tight):
+def _run_single(reps, tight, ainv=0):
     from openifem_amd import host, capi
     s = host.InsIM(host.channel_prm(3), reps, (0, 0, 0), (2.0, 0.2, 0.2))
     s.setup(0)
     s.channel_state()
+    s.opts.ainv_kind = ainv
     if tight:
         s.opts.fgmres_rel = 1e-10
         s.opts.inner_rel = 1e-6
@@ -36,7 +37,7 @@ def _run_single(reps, tight):
     return rhs_g, upd_g, st.fgmres_iters
 
 
-def _run_ranks(reps, P, tight):
+def _run_ranks(reps, P, tight, ainv=0):
     from openifem_amd import host, capi
     L = capi.load()
     world = int(np.prod(P))
@@ -51,6 +52,7 @@ def _run_ranks(reps, P, tight):
             s.channel_state()
             rc = L.ifem_halo_exchange(s.ctx, capi.VEC_EVAL)
             assert rc == 0
+            s.opts.ainv_kind = ainv
             if tight:
                 s.opts.fgmres_rel = 1e-10
                 s.opts.inner_rel = 1e-6
@@ -103,9 +105,19 @@ def test_virtual_ranks_match_single_context(P, reps):
     assert np.linalg.norm(updN - upd1) / np.linalg.norm(upd1) < 1e-6
 
 
-def test_virtual_ranks_default_tolerances():
-    rhs1, upd1, it1 = _run_single((8, 4, 4), tight=False)
-    rhsN, updN, its, _ = _run_ranks((8, 4, 4), (2, 1, 1), tight=False)
+def test_virtual_ranks_matrix_free_inner_operator():
+    # 8 octants with the bench's preconditioner variant: ghost-layer cells feed the matrix-free A_uu, owned rows only
+    rhs1, upd1, it1 = _run_single((6, 6, 6), tight=True, ainv=3)
+    rhsN, updN, its, norms = _run_ranks((6, 6, 6), (2, 2, 2), tight=True, ainv=3)
+    assert len(set(its)) == 1
+    assert np.linalg.norm(updN - upd1) / np.linalg.norm(upd1) < 1e-6
+
+
+@pytest.mark.parametrize("ainv", [0, 3])
+def test_virtual_ranks_default_tolerances(ainv):
+    # ainv = 3: the bench configuration (matrix-free inner operator, single-precision inner basis) on partitioned meshes
+    rhs1, upd1, it1 = _run_single((8, 4, 4), tight=False, ainv=ainv)
+    rhsN, updN, its, _ = _run_ranks((8, 4, 4), (2, 1, 1), tight=False, ainv=ainv)
     assert abs(its[0] - it1) <= 1
     assert np.linalg.norm(updN - upd1) / np.linalg.norm(upd1) < 5e-2
 
