@@ -514,7 +514,13 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
       wsync();
     }
     // ---- scatter into owned, unconstrained rows: consecutive lanes hit consecutive doubles of a node
-    if (active && A.mode != 4) {
+    if (A.ycell) { // two-stage scatter: coalesced plain stores per cell, summed per node by k_mf_gather
+      if (active)
+        for (int t = hl; t < DIM * NN; t += 32) {
+          const int a = t / DIM, c = t - a * DIM;
+          A.ycell[cell * (DIM * NN) + t] = S.V[c * NN + a];
+        }
+    } else if (active && A.mode != 4) {
       for (int t = hl; t < DIM * NN; t += 32) {
         const int a = t / DIM, c = t - a * DIM;
         const int32_t nd = S.node[a];
@@ -535,6 +541,26 @@ __global__ void k_mf_constrained_rows(int64_t n, const uint8_t *__restrict__ is_
   const int64_t nd = i / DIM;
   const int c = int(i - nd * DIM);
   y[i] = x[i] / bjac[nd * DIM * DIM + c * DIM + c];
+}
+
+// second stage of the atomics-free scatter: y_i = sum over the cells touching node(i) of the cell's local result (fixed
+// order: deterministic), constrained rows y_r = d_r x_r as above
+template <int DIM>
+__global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc,
+                            const double *__restrict__ ycell, const uint8_t *__restrict__ is_c,
+                            const double *__restrict__ bjac, const double *__restrict__ x, double *__restrict__ y) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t nd = i / DIM;
+  const int c = int(i - nd * DIM);
+  if (is_c && is_c[i]) { y[i] = x[i] / bjac[nd * DIM * DIM + c * DIM + c]; return; }
+  double s = 0;
+  const int64_t k1 = inc_ptr[nd + 1];
+  for (int64_t k = inc_ptr[nd]; k < k1; ++k) {
+    const int32_t e = inc[k];
+    s += ycell[int64_t(e >> 5) * (DIM * nn) + (e & 31) * DIM + c];
+  }
+  y[i] = s;
 }
 
 static void mf_tables(MfTables &t, int kv) {
@@ -579,13 +605,23 @@ void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu) {
   a.inv_dt = 1.0 / ctx->mf_params.dt;
   mf_tables(a.t, ctx->kv);
   { const char *e = getenv("IFEM_MF_MODE"); a.mode = e ? atoi(e) : 0; }
+  a.ycell = nullptr;
   if (a.mode == 3) {
     const size_t need = size_t(ctx->n_cells) * ctx->dim * ctx->nu;
     if (ctx->qdata.n < need) ctx->qdata.alloc(need);
     a.ycell = ctx->qdata.p;
   }
   const bool time_it = ctx->profile;
-  IFEM_HIP_CHECK(hipMemsetAsync(yu, 0, size_t(n) * sizeof(double), s));
+  // scatter: two-stage (per-cell results + per-node gather; atomics-free, deterministic) unless IFEM_MF_SCATTER=atomic
+  static const bool want_atomic = [] { const char *e = getenv("IFEM_MF_SCATTER"); return e && std::string(e) == "atomic"; }();
+  const bool two_stage = !want_atomic && a.mode == 0 && ctx->n_cells < (int64_t(1) << 26) && ctx->nu <= 32;
+  if (two_stage) {
+    if (ctx->uinc.n_rows == 0 && ctx->nUo) build_incidence(ctx);
+    const size_t need = size_t(ctx->n_cells) * ctx->dim * ctx->nu;
+    if (ctx->mf_ycell.n < need) ctx->mf_ycell.alloc(need);
+    a.ycell = ctx->mf_ycell.p;
+  } else
+    IFEM_HIP_CHECK(hipMemsetAsync(yu, 0, size_t(n) * sizeof(double), s));
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s)); // the cell kernel alone (what rocprofv3 reports for it)
   constexpr int WPB = 4;
   const dim3 grid(unsigned((ctx->n_cells + WPB - 1) / WPB)), block(64 * WPB);
@@ -603,6 +639,14 @@ void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu) {
   else if (ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf<2, 2, WPB>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((k_apply_uu_mf<2, 1, WPB>), grid, block, 0, s, a);
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+  if (two_stage) {
+    if (ctx->dim == 3)
+      hipLaunchKernelGGL((k_mf_gather<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
+                         ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu);
+    else
+      hipLaunchKernelGGL((k_mf_gather<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
+                         ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu);
+  } else
   if (a.is_c) {
     if (ctx->dim == 3) hipLaunchKernelGGL((k_mf_constrained_rows<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, a.is_c, ctx->bjac.p, xu, yu);
     else hipLaunchKernelGGL((k_mf_constrained_rows<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, a.is_c, ctx->bjac.p, xu, yu);

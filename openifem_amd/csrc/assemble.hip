@@ -388,6 +388,7 @@ void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzer
   A.is_c = ctx->has_c[w] ? ctx->is_c[w].p : nullptr;
   A.cval = ctx->has_c[w] ? ctx->cval[w].p : nullptr;
   A.use_inhom = (use_nonzero && ctx->has_c[1]) ? 1 : 0;
+  { const char *e = getenv("IFEM_ASM_SKIP"); A.debug_skip = e ? atoi(e) : 0; }
   A.eval = ctx->vec[IFEM_VEC_EVAL].p; A.present = ctx->vec[IFEM_VEC_PRESENT].p;
   A.fsi_acc = ctx->indicator.p ? ctx->vec[IFEM_VEC_FSI_ACC].p : nullptr;
   A.mu = p->viscosity; A.rho = p->rho; A.gamma = p->grad_div; A.inv_dt = 1.0 / p->dt;

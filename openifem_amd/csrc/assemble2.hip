@@ -346,6 +346,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
       for (int i = 0; i < DIM * DIM; ++i) gqs[i] = S.gqs[q * DIM * DIM + i];
 #pragma unroll
       for (int j = 0; j < RP; ++j) {
+        if (A.debug_skip == 2) continue;
         const double *pa = tb + oa[j], *pb = tb + ob[j];
         const double Na = pa[0], Nb = pb[0], ugb = pb[4];
         double ga[DIM], gb[DIM], gg = 0;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
     // ---- scatter the velocity-velocity pairs of this pass
 #pragma unroll
     for (int j = 0; j < RP; ++j) {
-      if (!pbase[j]) continue; // no pair in this slot, inactive cell or row owned by another rank
+      if (!pbase[j] || A.debug_skip) continue; // no pair in this slot, inactive cell or row owned by another rank
       const int a = oa[j] / TS, b = ob[j] / TS;
       const int len = S.len_uu[a];
       double *base = pbase[j];

@@ -37,6 +37,7 @@ struct AsmArgs {
   int neumann_id[8];
   double neumann_p[8];
   int use_inhom; // constraint set carries non-zero inhomogeneities
+  int debug_skip; // measurement aid (IFEM_ASM_SKIP): 1 = skip the A_uu scatter, 2 = skip the pair contraction too
 };
 
 template <int DIM>

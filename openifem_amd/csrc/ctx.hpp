@@ -134,6 +134,7 @@ struct ifem_ctx {
   bool want_shat = false, shat_valid = false, shat_aux_valid = false;
   int asm_constraint_set = 0;
   // matrix-free A_uu (IFEM_AINV_GMRES_BJACOBI_MF): state of the last ifem_ins_assemble
+  ifem::DBuf<double> mf_ycell; // per-cell results of the matrix-free apply [n_cells][nu][dim] (two-stage scatter)
   ifem::DBuf<double> mf_eval;  // velocity part of the evaluation point, ghost-extended
   ifem_ins_params mf_params{};
   bool mf_valid = false;
