@@ -417,6 +417,7 @@ static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero) {
   ctx->assembled = true;
   ctx->has_app = false;
   ctx->auu_f32_valid = false;
+  ctx->bbt_f32_valid = false;
   // S_m = B diag(M_u)^-1 B^T depends only on the mesh and on WHICH dofs are constrained (not on the solution):
   // keep it across assemblies until the constraint set changes (the reference rebuilds it every solve(); same values)
   {

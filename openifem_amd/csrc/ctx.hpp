@@ -125,6 +125,8 @@ struct ifem_ctx {
                                // ~3x slower at 128^3 (2.2x the VALU work: per-row recomputation of the cell gradients)
   ifem::PlanarCsr Sm;  // mass_schur(1,1) = B diag(M_u)^-1 B^T, explicit (single rank only; empty otherwise)
   bool sm_valid = false;
+  ifem::DBuf<float> B_f32, Bt_f32; // single-precision copies for the matrix-free S_m of the approximate-preconditioner kinds
+  bool bbt_f32_valid = false;
   ifem::DBuf<float> Sm_f32; // single-precision copy of the S_m values for its SpMV (approximate-preconditioner kinds)
   bool sm_f32_valid = false;
   int64_t sm_key = -1, constraints_epoch = 0;

@@ -40,6 +40,8 @@ void shat_jacobi(ifem_ctx *ctx, const double *x, double *y);
 void spmv_b(ifem_ctx *ctx, const double *xu, double *yp);
 // y_u = B^T x_p
 void spmv_bt(ifem_ctx *ctx, const double *xp, double *yu);
+void spmv_b_f32(ifem_ctx *ctx, const double *xu, double *yp);  // same with single-precision copies of the values
+void spmv_bt_f32(ifem_ctx *ctx, const double *xp, double *yu); // (matrix-free S_m inside the preconditioner only)
 // y_p = A_pp x_p (SCnsIM pressure block on the M_p pattern); 1/diag(A_pp) for its Jacobi preconditioner
 void spmv_app(ifem_ctx *ctx, const double *xp, double *yp);
 void app_diag_setup(ifem_ctx *ctx);

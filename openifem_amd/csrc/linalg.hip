@@ -281,6 +281,40 @@ void spmv_bt(ifem_ctx *ctx, const double *xp, double *yu) {
                        ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xp, yu);
 }
 
+// single-precision copies of B and B^T for the matrix-free S_m = B diag(M_u)^-1 B^T inside the approximate-preconditioner
+// kinds on several ranks (an explicit S_m would need a 2-deep pressure halo): rebuilt lazily after every assemble
+static void bbt_f32_refresh(ifem_ctx *ctx) {
+  if (ctx->bbt_f32_valid) return;
+  const int64_t nb = (int64_t)ctx->B.val.n, nt = (int64_t)ctx->Bt.val.n;
+  if (ctx->B_f32.n != (size_t)nb) ctx->B_f32.alloc(nb);
+  if (ctx->Bt_f32.n != (size_t)nt) ctx->Bt_f32.alloc(nt);
+  if (nb) hipLaunchKernelGGL(k_to_f32, dim3(8192), dim3(256), 0, ctx->stream, nb, ctx->B.val.p, ctx->B_f32.p);
+  if (nt) hipLaunchKernelGGL(k_to_f32, dim3(8192), dim3(256), 0, ctx->stream, nt, ctx->Bt.val.p, ctx->Bt_f32.p);
+  ctx->bbt_f32_valid = true;
+}
+void spmv_b_f32(ifem_ctx *ctx, const double *xu, double *yp) {
+  const int64_t n = ctx->B.n_rows;
+  if (n == 0) return;
+  bbt_f32_refresh(ctx);
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_spmv_planar<1, 3, 32, float>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n,
+                       ctx->B.rowptr.p, ctx->B.col.p, ctx->B_f32.p, xu, yp);
+  else
+    hipLaunchKernelGGL((k_spmv_planar<1, 2, 16, float>), dim3(blocks_for_rows(n, 16)), dim3(256), 0, ctx->stream, n,
+                       ctx->B.rowptr.p, ctx->B.col.p, ctx->B_f32.p, xu, yp);
+}
+void spmv_bt_f32(ifem_ctx *ctx, const double *xp, double *yu) {
+  const int64_t n = ctx->Bt.n_rows;
+  if (n == 0) return;
+  bbt_f32_refresh(ctx);
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_spmv_planar<3, 1, 8, float>), dim3(blocks_for_rows(n, 8)), dim3(256), 0, ctx->stream, n,
+                       ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt_f32.p, xp, yu);
+  else
+    hipLaunchKernelGGL((k_spmv_planar<2, 1, 4, float>), dim3(blocks_for_rows(n, 4)), dim3(256), 0, ctx->stream, n,
+                       ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt_f32.p, xp, yu);
+}
+
 void spmv_app(ifem_ctx *ctx, const double *xp, double *yp) {
   const int64_t n = ctx->Mp.n_rows;
   if (n == 0) return;

@@ -276,11 +276,12 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     // the approximate-preconditioner kinds (1, 3) also stream S_m in single precision: it only ever acts inside CG to
     // 1e-3 ||v|| and the rounding (6e-8 relative) is far below the eigenvalue ratio of this Laplacian-like operator
     if (explicit_sm) { spmv_sm(c, x, y, o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF); return; }
+    const bool lowp = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF;
     const double *xe; extend_p(S, x, &xe);
-    spmv_bt(c, xe, S.tu);
+    if (lowp) spmv_bt_f32(c, xe, S.tu); else spmv_bt(c, xe, S.tu);
     vec_mul(c, S.nuo, c->dinvMu.p, S.tu, S.tu);
     const double *te; extend_u(S, S.tu, &te);
-    spmv_b(c, te, y);
+    if (lowp) spmv_b_f32(c, te, y); else spmv_b(c, te, y);
   };
   S.st.cg_sm_iters += cg(c, S.npo, sm, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), (int)std::min<int64_t>(std::max<int64_t>(c->n_global_p, 1), 1 << 30), r, p, q, pdot);
   v_axpby(c, S.npo, 1.0, tmp, -P->rho / P->dt, dst1);
