@@ -179,7 +179,8 @@ int ifem_ins_newton_step(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_sol
                          double tolerance, int max_iterations, double *log);
 
 /* ---- Fluid::MPI::SCnsIM / SUPGFluidSolver (source/mpi_scnsim.cpp, source/mpi_supg_solver.cpp): slightly compressible
- * Navier-Stokes with SUPG / PSPG / LSIC.  Single GPU in this build. */
+ * Navier-Stokes with SUPG / PSPG / LSIC.  Partitioned contexts work as for InsIM (owner-computes rows, halo refresh of
+ * the Krylov vectors and of the projected stress). */
 typedef struct {
   double viscosity, rho, dt, solid_rho; /* parameters.viscosity, fluid_rho, time step, solid_rho (artificial fluid) */
   double gravity[3];

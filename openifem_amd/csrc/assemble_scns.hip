@@ -407,7 +407,6 @@ static void launch_scns_t(ifem_ctx *ctx, const ScnsArgs &A) {
 
 void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonzero) {
   hipStream_t s = ctx->stream;
-  if (ctx->halo.nranks != 1) throw Error(IFEM_E_BADPARAM, "SCnsIM assembly runs on one rank in this build");
   if (ctx->App.n != ctx->Mp.val.n) ctx->App.alloc(ctx->Mp.val.n);
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->Bt.val.p, 0, ctx->Bt.val.n * sizeof(double), s));
@@ -498,13 +497,22 @@ __global__ __launch_bounds__(256) void k_update_stress(int64_t n_cells, int64_t 
   }
 }
 
+// [plane i*dim + j][node] <-> interleaved [node][j] for one i: lets the velocity halo plan refresh the ghost stresses
+__global__ void k_stress_pack(int64_t n, int dim, int i, const double *__restrict__ stress, double *__restrict__ buf, int dir) {
+  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < n * dim; t += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t nd = t / dim;
+    const int j = int(t - nd * dim);
+    if (dir == 0) buf[t] = stress[int64_t(i * dim + j) * n + nd];
+    else const_cast<double *>(stress)[int64_t(i * dim + j) * n + nd] = buf[t];
+  }
+}
+
 __global__ void k_stress_avg(int64_t n, int nk, const double *__restrict__ cnt, double *__restrict__ stress) {
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n * nk; i += int64_t(gridDim.x) * blockDim.x)
     stress[i] /= cnt[i % n];
 }
 
 void launch_update_stress(ifem_ctx *ctx, double mu) {
-  if (ctx->halo.nranks != 1) throw Error(IFEM_E_BADPARAM, "update_stress runs on one rank in this build");
   hipStream_t s = ctx->stream;
   const int dim = ctx->dim, nu = ctx->nu, nq = ctx->nq;
   const int64_t n = ctx->nUl;
@@ -538,6 +546,15 @@ void launch_update_stress(ifem_ctx *ctx, double mu) {
   else IFEM_US(3, 2);
 #undef IFEM_US
   hipLaunchKernelGGL(k_stress_avg, dim3(1024), dim3(256), 0, s, n, dim * dim, cnt.p, ctx->stress.p);
+  if (ctx->halo.nranks > 1) { // owned nodes saw every cell that touches them; ghosts take the owner's average
+    DBuf<double> buf;
+    buf.alloc((size_t)dim * n);
+    for (int i = 0; i < dim; ++i) {
+      hipLaunchKernelGGL(k_stress_pack, dim3(1024), dim3(256), 0, s, n, dim, i, ctx->stress.p, buf.p, 0);
+      halo_exchange(ctx, buf.p);
+      hipLaunchKernelGGL(k_stress_pack, dim3(1024), dim3(256), 0, s, n, dim, i, ctx->stress.p, buf.p, 1);
+    }
+  }
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
   ctx->stress_valid = true;
 }

@@ -370,7 +370,6 @@ void ins_system_vmult(ifem_ctx *ctx, const double *src, double *dst) {
 //                                                   (reference: ILU(0) of B2pp = A_pp - A_pv rowsum|A_vv|^-1 A_vp)
 int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats) {
   if (!ctx->assembled || !ctx->has_app) throw Error(IFEM_E_BADPARAM, "ifem_scns_solve called before ifem_scns_assemble");
-  if (ctx->halo.nranks != 1) throw Error(IFEM_E_BADPARAM, "SCnsIM solve runs on one rank in this build");
   SolveState S{ctx, nullptr, o};
   carve_workspace(S);
   Clock total;
@@ -378,19 +377,30 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
   const int mt = 200;
   if ((int64_t)ctx->innerV.n < (int64_t)(mt + 1) * basis_ld(S.npo)) ctx->innerV.alloc((int64_t)(mt + 1) * basis_ld(S.npo));
   double *rhs = ctx->vec[IFEM_VEC_RHS].p, *upd = ctx->vec[IFEM_VEC_UPDATE].p;
-  auto mdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) { v_mdot(ctx, S.n, k, V, ld, w, out); };
-  auto mdot_p = [&](int k, const double *V, int64_t ld, const double *w, double *out) { v_mdot(ctx, S.npo, k, V, ld, w, out); };
+  auto mdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
+    v_mdot(ctx, S.n, k, V, ld, w, out);
+    allreduce_sum(ctx, out, k);
+  };
+  auto mdot_p = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
+    v_mdot(ctx, S.npo, k, V, ld, w, out);
+    allreduce_sum(ctx, out, k);
+  };
   double bn;
   mdot(1, rhs, S.n, rhs, &bn);
   bn = std::sqrt(bn);
   const double tol = 1e-6 * bn; // mpi_supg_solver.cpp:311-312
-  const int maxit = o->fgmres_maxit > 0 ? o->fgmres_maxit : (int)std::min<int64_t>(S.n, 1 << 30);
+  const int64_t n_glob = ctx->n_global_u + ctx->n_global_p; // identical on all ranks
+  const int maxit = o->fgmres_maxit > 0 ? o->fgmres_maxit : (int)std::min<int64_t>(n_glob, 1 << 30);
   OpFn Aop = [&](const double *x, double *y) { system_apply(S, x, y, false); };
+  // y_u = A_vp x_p and y_p = A_pv x_u on compact owned vectors (ghosts refreshed first on several ranks)
+  auto bt_apply = [&](const double *xp, double *yu) { const double *xe; extend_p(S, xp, &xe); spmv_bt(ctx, xe, yu); };
+  auto b_apply = [&](const double *xu, double *yp) { const double *xe; extend_u(S, xu, &xe); spmv_b(ctx, xe, yp); };
   OpFn Tpp = [&](const double *x, double *y) {
-    spmv_bt(ctx, x, S.tu);
+    const double *xe; extend_p(S, x, &xe);
+    spmv_bt(ctx, xe, S.tu);
     bjac_apply(ctx, S.tu, S.utmp);
-    spmv_b(ctx, S.utmp, S.tp[4]);
-    spmv_app(ctx, x, y);
+    b_apply(S.utmp, S.tp[4]);
+    spmv_app(ctx, xe, y);
     v_axpy(ctx, S.npo, -1.0, S.tp[4], y);
   };
   OpFn Jpp = [&](const double *x, double *y) { vec_div(ctx, S.npo, ctx->app_diag.p, x, y); };
@@ -398,14 +408,14 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
     const double *src0 = src, *src1 = src + S.nuo;
     double *dst0 = dst, *dst1 = dst + S.nuo;
     bjac_apply(ctx, src0, S.inner_w);              // ptmp1 = P_vv^-1 src0
-    spmv_b(ctx, S.inner_w, S.tp[0]);               // A_pv ptmp1
+    b_apply(S.inner_w, S.tp[0]);                   // A_pv ptmp1
     v_axpby(ctx, S.npo, 1.0, src1, -1.0, S.tp[0]); // ptmp = src1 - A_pv ptmp1
     double pn;
     mdot_p(1, S.tp[0], S.npo, S.tp[0], &pn);
     double res = 0;
     S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.npo), /*reorth=*/true, Tpp, Jpp, false, S.tp[0], dst1, mt, 100000,
                               1e-3 * std::sqrt(pn), ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p);
-    spmv_bt(ctx, dst1, S.tu);                      // A_vp dst1
+    bt_apply(dst1, S.tu);                          // A_vp dst1
     bjac_apply(ctx, S.tu, S.utmp);
     v_copy(ctx, S.nuo, S.inner_w, dst0);
     v_axpy(ctx, S.nuo, -1.0, S.utmp, dst0);        // dst0 = P_vv^-1 src0 - P_vv^-1 A_vp dst1
