@@ -187,7 +187,12 @@ typedef struct {
   int32_t n_neumann;
   int32_t neumann_id[8];
   double  neumann_p[8];
+  int32_t formulation; /* IFEM_FORM_SCNSIM (SCnsIM::assemble, mpi_scnsim.cpp:137-563) or IFEM_FORM_SUPG_INSIM
+                          (SUPGInsIM::assemble, mpi_insim_supg.cpp:15-327: incompressible, constant density, no PML /
+                          projected-stress / FSI terms); both are solved by ifem_scns_solve (SUPGFluidSolver::solve) */
 } ifem_scns_params;
+#define IFEM_FORM_SCNSIM 0
+#define IFEM_FORM_SUPG_INSIM 1
 /* optional cell / nodal fields of SCnsIM::assemble (each may be NULL = absent): sigma_pml [n_cells][n_q]
  * (set_sigma_pml_field evaluated at the quadrature points, mpi_scnsim.cpp:188-192), body_force [n_cells][n_q][dim]
  * (set_body_force, :193-197), fsi_stress [dim(dim+1)/2][n_unodes_local] (MPI::FSI, mpi_fsi.cpp:469-471) */

@@ -38,7 +38,10 @@ class InsParams(C.Structure):
 class ScnsParams(C.Structure):
     _fields_ = [("viscosity", C.c_double), ("rho", C.c_double), ("dt", C.c_double), ("solid_rho", C.c_double),
                 ("gravity", C.c_double * 3), ("n_neumann", C.c_int32), ("neumann_id", C.c_int32 * 8),
-                ("neumann_p", C.c_double * 8)]
+                ("neumann_p", C.c_double * 8), ("formulation", C.c_int32)]
+
+
+FORM_SCNSIM, FORM_SUPG_INSIM = 0, 1
 
 
 class SolverOpts(C.Structure):
@@ -149,8 +152,9 @@ def make_params(mu=1.0, rho=1.0, gamma=0.1, dt=1e-3, g=(0, 0, 0), neumann=None):
     return p
 
 
-def make_scns_params(mu, rho, dt, solid_rho=1.0, g=(0, 0, 0), neumann=None):
+def make_scns_params(mu, rho, dt, solid_rho=1.0, g=(0, 0, 0), neumann=None, formulation=FORM_SCNSIM):
     p = ScnsParams()
+    p.formulation = formulation
     p.viscosity, p.rho, p.dt, p.solid_rho = mu, rho, dt, solid_rho
     for i in range(3):
         p.gravity[i] = g[i] if i < len(g) else 0.0

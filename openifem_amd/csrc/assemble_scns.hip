@@ -45,6 +45,7 @@ struct ScnsArgs {
   int neumann_id[8];
   double neumann_p[8];
   int use_inhom;
+  int inc; // IFEM_FORM_SUPG_INSIM: the incompressible integrand of mpi_insim_supg.cpp
 };
 
 template <int DIM>
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(64 * WPB) void k_scns_assemble(ScnsArgs A) {
   const bool active = cell < A.n_cells;
   const int64_t cc = active ? cell : 0;
   const int64_t p_off = int64_t(DIM) * A.nUl;
-  const int ind = (active && A.indicator) ? A.indicator[cc] : 0;
+  const bool inc = A.inc != 0;
+  const int ind = (active && A.indicator && !inc) ? A.indicator[cc] : 0; // SUPGInsIM has no artificial-fluid terms
   const double cp_to_cv = 1.4, atm = 1013250, kappa_s = 1e4; // mpi_scnsim.cpp:124-126
   // ---- phase 0: gather
   for (int i = lane; i < NP * DIM; i += 64) S.X[i] = A.vcoords[cc * NP * DIM + i];
@@ -222,8 +224,8 @@ __global__ __launch_bounds__(64 * WPB) void k_scns_assemble(ScnsArgs A) {
       p0 += T.psi[q * NP + b] * S.p0e[b];
       for (int d = 0; d < DIM; ++d) gp[d] += S.pe[b] * S.gP[(q * NP + b) * DIM + d];
     }
-    const double sigma = A.sigma_pml ? A.sigma_pml[cc * NQ + q] : 0.0;
-    const double rho = A.rho_f * (1 + p0 / atm) * (1 - ind) + ind * A.rho_s; // :210-213
+    const double sigma = (A.sigma_pml && !inc) ? A.sigma_pml[cc * NQ + q] : 0.0;
+    const double rho = inc ? A.rho_f : A.rho_f * (1 + p0 / atm) * (1 - ind) + ind * A.rho_s; // :210-213 | insim_supg :109
     const double visc = (ind == 1 ? 1.0 : A.mu);                              // :214-216 (no turbulence model)
     // UGN length scale: first ND/(DIM+1) system shape functions in deal.II's vertex-major order (:252-258)
     double h = 0;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(64 * WPB) void k_scns_assemble(ScnsArgs A) {
       Q.u[c] = u[c]; Q.u0[c] = u0[c]; Q.du[c] = u[c] - u0[c]; Q.acc[c] = acc[c]; Q.gp[c] = gp[c];
       double sd = 0;
       for (int j = 0; j < DIM; ++j) sd += sg[(c * DIM + j) * DIM + j];
-      Q.sdiv[c] = sd * visc / A.mu;
+      Q.sdiv[c] = inc ? 0.0 : sd * visc / A.mu;
       Q.gbf[c] = A.g[c] + (A.body_force ? A.body_force[(cc * NQ + q) * DIM + c] : 0.0);
       double t1 = 0, t2 = 0;
       for (int a = 0; a < DIM; ++a) { t1 += u[a] * G[a * DIM + c]; t2 += G[c * DIM + a] * u[a]; }
@@ -279,6 +281,11 @@ __global__ __launch_bounds__(64 * WPB) void k_scns_assemble(ScnsArgs A) {
       if (si.c < DIM) for (int b = 0; b < DIM; ++b) sp += Q.G[si.c * DIM + b] * si.g[b];
       double r = ((-Q.visc * sp - Q.rho * dotd<DIM>(Q.Gu, pu) + Q.pr * dvi) - Q.rho * dotd<DIM>(Q.du, pu) / A.dt +
                   dotd<DIM>(Q.gbf, pu) * Q.rho);
+      if (inc) { // mpi_insim_supg.cpp:236-262 (sigma = sdiv = 0 make Q.R the incompressible residual)
+        r += -(Q.cdiv * ppi);
+        r += -(Q.tS * dotd<DIM>(uGi, Q.R) + Q.tP * dotd<DIM>(gpi, Q.R));
+        r += -(Q.tL * Q.rho * dvi) * Q.cdiv;
+      } else {
       r += -(Q.rho * Q.sigma * dotd<DIM>(Q.u, pu) + Q.sigma * Q.pr * ppi / atm);
       r += -(cp_to_cv * (atm + Q.pr * (1 - ind)) * Q.cdiv * ppi + dotd<DIM>(Q.u, Q.gp) * ppi * (1 - ind) +
              (Q.pr - Q.p0) * ppi / A.dt * (1 - ind)) / atm -
@@ -287,6 +294,7 @@ __global__ __launch_bounds__(64 * WPB) void k_scns_assemble(ScnsArgs A) {
       r += -((Q.tL * Q.rho * dvi) * ((Q.pr - Q.p0) / A.dt * (1 - ind) + cp_to_cv * atm * Q.cdiv +
                                       cp_to_cv * Q.pr * Q.cdiv * (1 - ind) + dotd<DIM>(Q.u, Q.gp) * (1 - ind)) / atm +
              (Q.tL * Q.rho * dvi) * (1 / kappa_s * (Q.pr - Q.p0) / A.dt) * ind);
+      }
       if (ind == 1) {
         double spf = 0;
         if (si.c < DIM) for (int b = 0; b < DIM; ++b) spf += si.g[b] * Q.fT[si.c * DIM + b];
@@ -346,6 +354,16 @@ __global__ __launch_bounds__(64 * WPB) void k_scns_assemble(ScnsArgs A) {
       const double pipj = dotd<DIM>(pui, puj);
       const double rho = Q.rho, tS = Q.tS, tP = Q.tP, tL = Q.tL, sig = Q.sigma;
       double e = ((Q.visc * sp + rho * dotd<DIM>(Gpj, pui) + rho * dotd<DIM>(Gju, pui) - dvi * ppj) + rho * pipj / A.dt);
+      if (inc) { // mpi_insim_supg.cpp:181-232
+        e += (tS * rho * dotd<DIM>(uGi, pjG) + tS * rho * dotd<DIM>(uGi, uGj) + tS * rho * dotd<DIM>(pjGi, Q.uG) +
+              tS * rho * dotd<DIM>(uGi, puj) / A.dt + tS * rho * dotd<DIM>(pjGi, Q.du) / A.dt + tS * dotd<DIM>(uGi, gpj) +
+              tS * dotd<DIM>(pjGi, Q.gp) - tS * rho * dotd<DIM>(pjGi, Q.gbf) + tP * rho * dotd<DIM>(gpi, pjG) +
+              tP * rho * dotd<DIM>(gpi, uGj) + tP * rho * dotd<DIM>(gpi, puj) / A.dt + tP * dotd<DIM>(gpi, gpj) +
+              tL * rho * dvi * dvj);
+        e += dvj * ppi;
+        v += e * Q.JxW;
+        continue;
+      }
       e += (rho * sig * pipj + sig * ppj * ppi / atm);
       e += (tS * rho * dotd<DIM>(uGi, pjG) + tS * rho * dotd<DIM>(uGi, uGj) + tS * rho * dotd<DIM>(pjGi, Q.uG) +
             tS * rho * dotd<DIM>(uGi, puj) / A.dt + tS * rho * dotd<DIM>(pjGi, Q.du) / A.dt + tS * dotd<DIM>(uGi, gpj) +
@@ -433,6 +451,8 @@ void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonz
   A.sigma_pml = ctx->sigma_pml.n ? ctx->sigma_pml.p : nullptr;
   A.body_force = ctx->body_force.n ? ctx->body_force.p : nullptr;
   A.mu = p->viscosity; A.rho_f = p->rho; A.rho_s = p->solid_rho; A.dt = p->dt;
+  if (p->formulation != IFEM_FORM_SCNSIM && p->formulation != IFEM_FORM_SUPG_INSIM) throw Error(IFEM_E_BADPARAM, "ifem_scns_params.formulation");
+  A.inc = p->formulation == IFEM_FORM_SUPG_INSIM;
   for (int i = 0; i < 3; ++i) A.g[i] = p->gravity[i];
   A.n_neumann = p->n_neumann;
   for (int i = 0; i < 8; ++i) { A.neumann_id[i] = p->neumann_id[i]; A.neumann_p[i] = p->neumann_p[i]; }

@@ -24,7 +24,8 @@ std::unique_ptr<Fluid::MPI::FluidSolver<dim>> make_solver(const char *kind, Tria
   const std::string k = kind ? kind : "InsIM";
   if (k == "InsIM") return std::unique_ptr<Fluid::MPI::FluidSolver<dim>>(new Fluid::MPI::InsIM<dim>(t, params, device));
   if (k == "SCnsIM") return std::unique_ptr<Fluid::MPI::FluidSolver<dim>>(new Fluid::MPI::SCnsIM<dim>(t, params, device));
-  throw std::invalid_argument("unknown fluid solver '" + k + "' (InsIM, SCnsIM)");
+  if (k == "SUPGInsIM") return std::unique_ptr<Fluid::MPI::FluidSolver<dim>>(new Fluid::MPI::SUPGInsIM<dim>(t, params, device));
+  throw std::invalid_argument("unknown fluid solver '" + k + "' (InsIM, SCnsIM, SUPGInsIM)");
 }
 // assemble / solve / solver_opts live in the two solver families, not in FluidSolver (as in the reference)
 template <int dim, class FI, class FS>

@@ -153,6 +153,21 @@ protected:
   using FluidSolver<dim>::check;
 };
 
+// Fluid::MPI::SUPGInsIM<dim> (include/mpi_insim_supg.h:26-60, source/mpi_insim_supg.cpp:15-327): incompressible NS with
+// SUPG / PSPG / LSIC on equal-order elements
+template <int dim>
+class SUPGInsIM : public SUPGFluidSolver<dim> {
+public:
+  SUPGInsIM(Triangulation<dim> &, const Parameters::AllParameters &, int device = 0);
+  void assemble(const bool use_nonzero_constraints) override;
+
+private:
+  using FluidSolver<dim>::parameters;
+  using FluidSolver<dim>::time;
+  using FluidSolver<dim>::ctx;
+  using FluidSolver<dim>::check;
+};
+
 // Fluid::MPI::SCnsIM<dim> (include/mpi_scnsim.h, source/mpi_scnsim.cpp:15-568)
 template <int dim>
 class SCnsIM : public SUPGFluidSolver<dim> {

@@ -117,6 +117,7 @@ ifem_scns_params SCnsIM<dim>::scns_params() const {
   ifem_scns_params p{};
   p.viscosity = parameters.viscosity; p.rho = parameters.fluid_rho; p.dt = time.get_delta_t();
   p.solid_rho = parameters.solid_rho;
+  p.formulation = IFEM_FORM_SCNSIM;
   for (int i = 0; i < dim; ++i) p.gravity[i] = parameters.gravity[i];
   p.n_neumann = 0;
   if (parameters.n_fluid_neumann_bcs != 0)
@@ -134,6 +135,28 @@ void SCnsIM<dim>::assemble(const bool use_nonzero_constraints) {
   check(ifem_scns_assemble(ctx, &p, use_nonzero_constraints), "assemble");
 }
 
+template <int dim>
+SUPGInsIM<dim>::SUPGInsIM(Triangulation<dim> &tria, const Parameters::AllParameters &parameters, int device)
+    : SUPGFluidSolver<dim>(tria, parameters, device) {}
+
+template <int dim>
+void SUPGInsIM<dim>::assemble(const bool use_nonzero_constraints) {
+  ifem_scns_params p{};
+  p.viscosity = parameters.viscosity; p.rho = parameters.fluid_rho; p.dt = time.get_delta_t();
+  p.solid_rho = parameters.solid_rho;
+  for (int i = 0; i < dim; ++i) p.gravity[i] = parameters.gravity[i];
+  if (parameters.n_fluid_neumann_bcs != 0)
+    for (auto &kv : parameters.fluid_neumann_bcs) {
+      if (p.n_neumann >= 8) throw std::invalid_argument("at most 8 Neumann boundaries are supported");
+      p.neumann_id[p.n_neumann] = (int32_t)kv.first;
+      p.neumann_p[p.n_neumann++] = kv.second;
+    }
+  p.formulation = IFEM_FORM_SUPG_INSIM;
+  check(ifem_scns_assemble(ctx, &p, use_nonzero_constraints), "assemble");
+}
+
+template class SUPGInsIM<2>;
+template class SUPGInsIM<3>;
 template class SUPGFluidSolver<2>;
 template class SUPGFluidSolver<3>;
 template class SCnsIM<2>;

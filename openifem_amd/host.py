@@ -239,6 +239,10 @@ class SCnsIM(FluidSolver):
     KIND = "SCnsIM"
 
 
+class SUPGInsIM(FluidSolver):
+    KIND = "SUPGInsIM"
+
+
 def channel_prm(dim=3, dt=1e-3, end_time=8e-2, refinements=0):
     """tests/fluid_pressure_driven/fluid_pressure_driven.prm transcribed for the 2D case and extended to the 3D
     channel of SURVEY 8(d): no-slip on y-walls, w = 0 on z-walls, inlet pressure 10."""

@@ -793,7 +793,8 @@ static void scns_cell(const orc_system *s, const orc_scns_params *P, int cell, c
   const double *X = m->vcoords + (size_t)cell * nv * dim;
   const int32_t *un = m->cell_unodes + (size_t)cell * nu;
   const int32_t *pn = m->cell_pnodes + (size_t)cell * np;
-  const int ind = m->indicator ? m->indicator[cell] : 0;
+  const int inc = P->formulation == 1;                        /* SUPGInsIM: mpi_insim_supg.cpp */
+  const int ind = (m->indicator && !inc) ? m->indicator[cell] : 0;
   const double dt = P->dt;
   const double cp_to_cv = 1.4, atm = 1013250, kappa_s = 1e4; /* mpi_scnsim.cpp:124-126 */
   memset(Ke, 0, sizeof(double) * (size_t)nd * nd);
@@ -840,10 +841,10 @@ static void scns_cell(const orc_system *s, const orc_scns_params *P, int cell, c
       for (int d = 0; d < dim; ++d) gp[d] += pe * gradPsi[b][d];
       p0 += s->fep.phi[q][b] * present[s->n_u + pn[b]];
     }
-    const double sigma = P->sigma_pml ? P->sigma_pml[(size_t)cell * nq + q] : 0.0;
+    const double sigma = (P->sigma_pml && !inc) ? P->sigma_pml[(size_t)cell * nq + q] : 0.0;
     double bf[MAXD] = {0};
     if (P->body_force) for (int d = 0; d < dim; ++d) bf[d] = P->body_force[((size_t)cell * nq + q) * dim + d];
-    const double rho = P->rho * (1 + p0 / atm) * (1 - ind) + ind * P->solid_rho; /* :210-213 */
+    const double rho = inc ? P->rho : P->rho * (1 + p0 / atm) * (1 - ind) + ind * P->solid_rho; /* :210-213 | insim_supg :109 */
     const double viscosity = (ind == 1 ? 1 : P->mu);                              /* :214-216, no turbulence model */
     for (int k = 0; k < nd; ++k) {
       for (int c = 0; c < dim; ++c) { phi_u[k][c] = 0; grad_phi_p[k][c] = 0; for (int d = 0; d < dim; ++d) grad_phi_u[k][c][d] = 0; }
@@ -888,7 +889,7 @@ static void scns_cell(const orc_system *s, const orc_scns_params *P, int cell, c
     const double z = localRe <= 3 ? (localRe / 3) : 1;
     const double tau_LSIC = h / 2 * v_norm * z;
     double sdiv[MAXD];
-    for (int i = 0; i < dim; ++i) { double t = 0; for (int j = 0; j < dim; ++j) t += sgrad[i][j][j]; sdiv[i] = t * viscosity / P->mu; }
+    for (int i = 0; i < dim; ++i) { double t = 0; for (int j = 0; j < dim; ++j) t += sgrad[i][j][j]; sdiv[i] = inc ? 0.0 : t * viscosity / P->mu; }
     double gbf[MAXD]; for (int d = 0; d < dim; ++d) gbf[d] = P->g[d] + bf[d];
     double cur_div = 0; for (int c = 0; c < dim; ++c) cur_div += G[c][c];
     double u_G[MAXD]; vT(dim, u, G, u_G);       /* current_velocity_values * current_velocity_gradients */
@@ -906,6 +907,19 @@ static void scns_cell(const orc_system *s, const orc_scns_params *P, int cell, c
         for (int a = 0; a < dim; ++a) for (int b = 0; b < dim; ++b) sp += grad_phi_u[j][a][b] * grad_phi_u[i][a][b];
         const double pipj = vv(dim, phi_u[i], phi_u[j]);
         double v = 0;
+        if (inc) { /* mpi_insim_supg.cpp:163-232 */
+          v += ((viscosity * sp + rho * vv(dim, G_pj, phi_u[i]) + rho * vv(dim, Gj_u, phi_u[i]) - div_phi_u[i] * phi_p[j]) +
+                rho * pipj / dt) * JxW;
+          v += (tau_SUPG * rho * vv(dim, u_Gi, pj_G) + tau_SUPG * rho * vv(dim, u_Gi, u_Gj) + tau_SUPG * rho * vv(dim, pj_Gi, u_G) +
+                tau_SUPG * rho * vv(dim, u_Gi, phi_u[j]) / dt + tau_SUPG * rho * vv(dim, pj_Gi, du) / dt +
+                tau_SUPG * vv(dim, u_Gi, grad_phi_p[j]) + tau_SUPG * vv(dim, pj_Gi, gp) - tau_SUPG * rho * vv(dim, pj_Gi, gbf) +
+                tau_PSPG * rho * vv(dim, grad_phi_p[i], pj_G) + tau_PSPG * rho * vv(dim, grad_phi_p[i], u_Gj) +
+                tau_PSPG * rho * vv(dim, grad_phi_p[i], phi_u[j]) / dt + tau_PSPG * vv(dim, grad_phi_p[i], grad_phi_p[j]) +
+                tau_LSIC * rho * div_phi_u[i] * div_phi_u[j]) * JxW;
+          v += div_phi_u[j] * phi_p[i] * JxW;
+          Ke[i * nd + j] += v;
+          continue;
+        }
         /* :307-316 */
         v += ((viscosity * sp + rho * vv(dim, G_pj, phi_u[i]) + rho * vv(dim, Gj_u, phi_u[i]) - div_phi_u[i] * phi_p[j]) +
               rho * pipj / dt) * JxW;
@@ -940,6 +954,15 @@ static void scns_cell(const orc_system *s, const orc_scns_params *P, int cell, c
       double r = 0;
       r += ((-viscosity * sp - rho * vv(dim, G_u, phi_u[i]) + pr * div_phi_u[i]) - rho * vv(dim, du, phi_u[i]) / dt +
             vv(dim, gbf, phi_u[i]) * rho) * JxW;
+      if (inc) { /* mpi_insim_supg.cpp:236-262 */
+        double Ri[MAXD];
+        for (int c = 0; c < dim; ++c) Ri[c] = rho * (du[c] / dt + u_G[c]) + gp[c] - rho * gbf[c];
+        r += -(cur_div * phi_p[i]) * JxW;
+        r += -(tau_SUPG * vv(dim, u_Gi, Ri) + tau_PSPG * vv(dim, grad_phi_p[i], Ri)) * JxW;
+        r += -(tau_LSIC * rho * div_phi_u[i]) * cur_div * JxW;
+        fe[i] += r;
+        continue;
+      }
       r += -(rho * sigma * vv(dim, u, phi_u[i]) + sigma * pr * phi_p[i] / atm) * JxW;
       r += -(cp_to_cv * (atm + pr * (1 - ind)) * cur_div * phi_p[i] + vv(dim, u, gp) * phi_p[i] * (1 - ind) +
              (pr - p0) * phi_p[i] / dt * (1 - ind)) / atm * JxW -

@@ -122,6 +122,10 @@ typedef struct {
   const double *fsi_stress; /* [dim(dim+1)/2][n_unodes] nodal FSI stress or NULL */
   const double *sigma_pml;  /* [n_cells][n_q] or NULL */
   const double *body_force; /* [n_cells][n_q][dim] or NULL */
+  int32_t formulation;      /* 0: SCnsIM (source/mpi_scnsim.cpp:137-563); 1: SUPGInsIM, the incompressible SUPG/PSPG/LSIC
+                               integrand of source/mpi_insim_supg.cpp:100-262 (constant density, div-free continuity, no
+                               PML / stress / FSI terms).  Pinned by tests/fluid_pressure_driven_mpi_insim_supg (vmax
+                               2.5e-2) and tests/fluid_plane_wall_driven_mpi_insim_supg (|v|_2 = 4.7112) */
 } orc_scns_params;
 
 /* full-system solve callback: CSR of the assembled system (n x n), rhs -> x */

@@ -31,7 +31,7 @@ class ScnsParams(C.Structure):
     _fields_ = [("mu", C.c_double), ("rho", C.c_double), ("dt", C.c_double), ("solid_rho", C.c_double),
                 ("g", C.c_double * 3), ("n_neumann", C.c_int32), ("neumann_id", C.c_int32 * 8),
                 ("neumann_p", C.c_double * 8), ("stress", C.c_void_p), ("fsi_stress", C.c_void_p),
-                ("sigma_pml", C.c_void_p), ("body_force", C.c_void_p)]
+                ("sigma_pml", C.c_void_p), ("body_force", C.c_void_p), ("formulation", C.c_int32)]
 
 
 FULL_SOLVE = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double),
@@ -110,8 +110,10 @@ def _ptr(a):
 
 
 def make_scns_params(mu, rho, dt, solid_rho=1.0, g=(0, 0, 0), neumann=None, stress=None, fsi_stress=None,
-                     sigma_pml=None, body_force=None):
+                     sigma_pml=None, body_force=None, formulation=0):
+    """formulation 0: SCnsIM, 1: SUPGInsIM (mpi_insim_supg.cpp)"""
     p = ScnsParams()
+    p.formulation = formulation
     p.mu, p.rho, p.dt, p.solid_rho = mu, rho, dt, solid_rho
     for i in range(3):
         p.g[i] = g[i] if i < len(g) else 0.0

@@ -199,3 +199,56 @@ def test_reference_driver_fluid_body_force_mpi():
     flow.run()
     _, p = flow.get_current_solution()
     assert abs((p.max() - p.min()) - 1e3) / 1e3 < 1e-3
+
+
+@pytest.mark.parametrize("dim,kv,reps", [(2, 1, (5, 4)), (3, 1, (3, 3, 2)), (2, 2, (3, 2))])
+def test_supg_insim_assembly_matches_oracle(dim, kv, reps):
+    # IFEM_FORM_SUPG_INSIM (mpi_insim_supg.cpp:100-262): the incompressible SUPG/PSPG/LSIC integrand; indicator, PML and
+    # stress inputs are present on purpose and must be ignored by this formulation
+    capi = _capi()
+    rng = np.random.default_rng(23 + dim + kv)
+    m = BoxMesh(reps, (0,) * dim, (1.0, 0.6, 0.4)[:dim], kv=kv)
+    m.vcoords = m.vcoords + 0.02 * rng.standard_normal(m.vcoords.shape)
+    flag = 3 if dim == 2 else 7
+    dofs, vals = m.dirichlet({0: (flag, [0.3, -0.2, 0.1][:dim]), 2: (flag, [0.0] * dim)})
+    nq = (kv + 1) ** dim
+    ev, pr = rng.standard_normal(m.n_dofs), rng.standard_normal(m.n_dofs)
+    bf = rng.standard_normal((m.n_cells, nq, dim))
+    kw = dict(mu=0.03, rho=1.2, dt=0.01, g=(0.3, -9.8, 0.5)[:dim], neumann={1: 2.5})
+    S = orc.System(m)
+    S.set_constraints(0, dofs, None)
+    S.set_constraints(1, dofs, vals)
+    S.scns_assemble(orc.make_scns_params(body_force=bf, formulation=1, **kw), True, ev, pr)
+    Ao, bo = S.csr("A"), S.rhs()
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.vec_set(capi.VEC_PRESENT, pr)
+    ctx.vec_set(capi.VEC_EVAL, ev)
+    ctx.set_indicator((rng.uniform(size=m.n_cells) < 0.5).astype(np.int32))
+    ctx.set_scns_fields(rng.uniform(0, 3, (m.n_cells, nq)), bf, None)
+    ctx.update_stress(kw["mu"])
+    ctx.scns_assemble(capi.make_scns_params(formulation=capi.FORM_SUPG_INSIM, **kw), True)
+    A, b = ctx.export_csr(0), ctx.vec_get(capi.VEC_RHS)
+    assert abs(A - Ao).max() / abs(Ao).max() < 1e-11
+    assert np.abs(b - bo).max() / np.abs(bo).max() < 1e-11
+
+
+def test_reference_driver_fluid_pressure_driven_mpi_insim_supg():
+    # tests/fluid_pressure_driven_mpi_insim_supg/*.cpp:31-56 on the host mirror with the reference's .prm
+    from openifem_amd import host
+    flow = host.SUPGInsIM(_prm("fluid_pressure_driven_mpi_insim_supg.prm"), (100, 10), (0, 0), (2.0, 0.2))
+    flow.run()
+    v, _ = flow.get_current_solution()
+    v = np.sort(v)[::-1]
+    assert abs(v[0] - 2.5e-2) / 2.5e-2 < 2e-2
+    assert abs(v[29] - 2.5e-2) / 2.5e-2 < 1e-3
+
+
+def test_reference_driver_fluid_plane_wall_driven_mpi_insim_supg():
+    # tests/fluid_plane_wall_driven_mpi_insim_supg/*.cpp:31-50: |v|_2 = 4.7112 at 1e-3
+    from openifem_amd import host
+    flow = host.SUPGInsIM(_prm("fluid_plane_wall_driven_mpi_insim_supg.prm"), (20, 16), (0, 0), (2.0, 0.4))
+    flow.run()
+    v, _ = flow.get_current_solution()
+    assert abs(np.linalg.norm(v) - 4.7112) / 4.7112 < 1e-3

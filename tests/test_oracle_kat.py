@@ -205,3 +205,35 @@ def test_fluid_initial_condition_mpi_known_answer():
     rc, _ = S.scns_run_one_step(orc.make_scns_params(mu=1.8e-4, rho=1.3e-3, dt=1e-11), True, x)
     assert rc > 0
     assert abs(x[S.n_u:].max() - 1e4) / 1e4 < 1e-8
+
+
+def _supg_insim_run(m, bcs, mu, n_steps, neumann=None):
+    S = orc.System(m)
+    dofs, vals = m.dirichlet(bcs)
+    S.set_constraints(1, dofs, vals)
+    S.set_constraints(0, dofs, None)
+    x = np.zeros(S.n)
+    P = orc.make_scns_params(mu=mu, rho=1.0, dt=1e-2, neumann=neumann, formulation=1)
+    for step in range(n_steps):
+        rc, _ = S.scns_run_one_step(P, step == 0, x)
+        assert rc > 0
+    return S, x
+
+
+def test_fluid_pressure_driven_mpi_insim_supg_known_answer():
+    # tests/fluid_pressure_driven_mpi_insim_supg: MPI::SUPGInsIM<2> (mpi_insim_supg.cpp), 100 x 10 cells refined once,
+    # Q1/Q1, 10 steps of 1e-2: vmax within 2 % of P D^2 / (8 mu L) = 2.5e-2, the 30th largest value within 1e-3
+    m = BoxMesh([200, 20], (0, 0), (2.0, 0.2), kv=1)
+    S, x = _supg_insim_run(m, {2: (3, [0, 0]), 3: (3, [0, 0])}, 1.0, 10, neumann={0: 10.0})
+    v = np.sort(x[:S.n_u])[::-1]
+    assert abs(v[0] - 2.5e-2) / 2.5e-2 < 2e-2
+    assert abs(v[29] - 2.5e-2) / 2.5e-2 < 1e-3
+
+
+def test_fluid_plane_wall_driven_mpi_insim_supg_regression_constant():
+    # tests/fluid_plane_wall_driven_mpi_insim_supg: 20 x 16 cells of [0,2] x [0,0.4], top wall u = (1, 0), mu = 0.002,
+    # 10 steps: the l2 norm of the velocity block is 4.7112 at 1e-3
+    m = BoxMesh([20, 16], (0, 0), (2.0, 0.4), kv=1)
+    S, x = _supg_insim_run(m, {2: (3, [0, 0]), 3: (3, [1, 0])}, 0.002, 10)
+    l2 = np.linalg.norm(x[:S.n_u])
+    assert abs(l2 - 4.7112) / 4.7112 < 1e-3
