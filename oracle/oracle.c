@@ -773,6 +773,199 @@ int32_t orc_ins_run_one_step(orc_system *s, const orc_params *P, int32_t apply_n
   return rc < 0 ? rc : outer;
 }
 
+
+/* ================================================================================================================
+ * Fluid::MPI::InsIMEX -- implicit-explicit incompressible NS (source/mpi_insimex.cpp:150-446): symmetric, solution-
+ * independent matrix (viscous + grad-div + mass/dt + B, B^T), explicit convection in the rhs, no Newton loop.
+ * ================================================================================================================ */
+static void Tv(int dim, const double T[MAXD][MAXD], const double *v, double *r);
+static double vv(int dim, const double *a, const double *b);
+
+/* pressure boundary integral of one face: fe(i) += -(phi_i . n) p_bc JxW_face (mpi_insimex.cpp:287-318) */
+static void face_neumann(const orc_system *s, int cell, int f, double pbc, double *fe) {
+  const orc_mesh *m = &s->m;
+  const int dim = m->dim, nu = s->nu, nv = s->np;
+  const double *X = m->vcoords + (size_t)cell * nv * dim;
+  const int nq1 = m->kv + 1;
+  double gx[3], gw[3]; gauss_1d(nq1, gx, gw);
+  const int nqf = (dim == 2) ? nq1 : nq1 * nq1;
+  const int nd_ = f / 2; const double side = (double)(f % 2);
+  for (int qf = 0; qf < nqf; ++qf) {
+    double xi[MAXD], w = 1.0; int t = qf;
+    for (int d = 0; d < dim; ++d) {
+      if (d == nd_) xi[d] = side;
+      else { int i = t % nq1; t /= nq1; xi[d] = gx[i]; w *= gw[i]; }
+    }
+    double N1[MAXNP], dN1[MAXNP][MAXD], Nu[MAXNU], dNu[MAXNU][MAXD];
+    shapes_at(dim, 1, xi, N1, dN1);
+    shapes_at(dim, m->kv, xi, Nu, dNu);
+    double J[MAXD][MAXD] = {{0}}, Ji[MAXD][MAXD];
+    for (int v = 0; v < nv; ++v)
+      for (int d = 0; d < dim; ++d)
+        for (int e = 0; e < dim; ++e) J[d][e] += X[v * dim + d] * dN1[v][e];
+    const double det = det_inv(dim, J, Ji);
+    double nv_[MAXD], nn = 0; const double sgn = (f % 2) ? 1.0 : -1.0;
+    for (int d = 0; d < dim; ++d) { nv_[d] = sgn * Ji[nd_][d]; nn += nv_[d] * nv_[d]; }
+    nn = sqrt(nn);
+    const double JxWf = fabs(det) * nn * w;
+    for (int d = 0; d < dim; ++d) nv_[d] /= nn;
+    for (int a = 0; a < nu; ++a)
+      for (int c = 0; c < dim; ++c) fe[a * dim + c] += -(Nu[a] * nv_[c] * pbc * JxWf);
+  }
+}
+
+static void imex_cell(const orc_system *s, const orc_params *P, int cell, int assemble_system, const double *present,
+                      const double *fsi_acc, double *Ke, double *Me, double *fe) {
+  const orc_mesh *m = &s->m;
+  const int dim = m->dim, nu = s->nu, np = s->np, nd = s->ndof_cell, nq = s->feu.nq, nv = s->np;
+  const double *X = m->vcoords + (size_t)cell * nv * dim;
+  const int32_t *un = m->cell_unodes + (size_t)cell * nu;
+  const int32_t *pn = m->cell_pnodes + (size_t)cell * np;
+  const double viscosity = P->mu, gamma = P->gamma, rho = P->rho, dt = P->dt;
+  const int ind = m->indicator ? m->indicator[cell] : 0;
+  if (assemble_system) { memset(Ke, 0, sizeof(double) * (size_t)nd * nd); memset(Me, 0, sizeof(double) * (size_t)nd * nd); }
+  memset(fe, 0, sizeof(double) * (size_t)nd);
+  double div_phi_u[MAXDOF], phi_u[MAXDOF][MAXD], grad_phi_u[MAXDOF][MAXD][MAXD], phi_p[MAXDOF];
+  for (int q = 0; q < nq; ++q) {
+    double J[MAXD][MAXD] = {{0}}, Ji[MAXD][MAXD];
+    for (int v = 0; v < nv; ++v)
+      for (int d = 0; d < dim; ++d)
+        for (int e = 0; e < dim; ++e) J[d][e] += X[v * dim + d] * s->fep.dphi[q][v][e];
+    const double det = det_inv(dim, J, Ji);
+    const double JxW = fabs(det) * s->feu.w[q];
+    double gradN[MAXNU][MAXD];
+    for (int a = 0; a < nu; ++a)
+      for (int d = 0; d < dim; ++d) { double g = 0; for (int e = 0; e < dim; ++e) g += s->feu.dphi[q][a][e] * Ji[e][d]; gradN[a][d] = g; }
+    /* all fields from present_solution (:219-234) */
+    double u[MAXD] = {0}, G[MAXD][MAXD] = {{0}}, pr = 0, acc[MAXD] = {0}, dv = 0;
+    for (int a = 0; a < nu; ++a)
+      for (int c = 0; c < dim; ++c) {
+        const double ue = present[dim * un[a] + c];
+        u[c] += s->feu.phi[q][a] * ue;
+        for (int d = 0; d < dim; ++d) G[c][d] += ue * gradN[a][d];
+        if (fsi_acc) acc[c] += s->feu.phi[q][a] * fsi_acc[dim * un[a] + c];
+      }
+    for (int c = 0; c < dim; ++c) dv += G[c][c];
+    for (int b = 0; b < np; ++b) pr += s->fep.phi[q][b] * present[s->n_u + pn[b]];
+    for (int k = 0; k < nd; ++k) {
+      for (int c = 0; c < dim; ++c) { phi_u[k][c] = 0; for (int d = 0; d < dim; ++d) grad_phi_u[k][c][d] = 0; }
+      div_phi_u[k] = 0; phi_p[k] = 0;
+      if (k < dim * nu) {
+        const int a = k / dim, c = k % dim;
+        phi_u[k][c] = s->feu.phi[q][a];
+        for (int d = 0; d < dim; ++d) grad_phi_u[k][c][d] = gradN[a][d];
+        div_phi_u[k] = gradN[a][c];
+      } else phi_p[k] = s->fep.phi[q][k - dim * nu];
+    }
+    double G_u[MAXD]; Tv(dim, G, u, G_u); /* current_velocity_gradients * current_velocity_values */
+    for (int i = 0; i < nd; ++i) {
+      if (assemble_system)
+        for (int j = 0; j < nd; ++j) { /* :248-262 */
+          double sp = 0;
+          for (int a = 0; a < dim; ++a) for (int b = 0; b < dim; ++b) sp += grad_phi_u[j][a][b] * grad_phi_u[i][a][b];
+          const double pipj = vv(dim, phi_u[i], phi_u[j]);
+          Ke[i * nd + j] += (viscosity * sp - div_phi_u[i] * phi_p[j] - phi_p[i] * div_phi_u[j] +
+                             gamma * div_phi_u[j] * div_phi_u[i] * rho + pipj / dt * rho) * JxW;
+          Me[i * nd + j] += (pipj + phi_p[i] * phi_p[j]) * JxW;
+        }
+      double sp = 0; /* :264-277 */
+      for (int a = 0; a < dim; ++a) for (int b = 0; b < dim; ++b) sp += G[a][b] * grad_phi_u[i][a][b];
+      double gphi = 0; for (int c = 0; c < dim; ++c) gphi += P->g[c] * phi_u[i][c];
+      fe[i] -= (viscosity * sp - dv * phi_p[i] - pr * div_phi_u[i] + gamma * dv * div_phi_u[i] * rho +
+                vv(dim, G_u, phi_u[i]) * rho - gphi * rho) * JxW;
+      if (ind == 1) fe[i] += (vv(dim, acc, phi_u[i]) * rho) * JxW; /* :278-284; cell fsi_stress is identically zero */
+    }
+  }
+  /* Neumann faces (:287-318), same as InsIM */
+  if (P->n_neumann != 0 && m->cell_face_bid) {
+    for (int f = 0; f < 2 * dim; ++f) {
+      const int bid = m->cell_face_bid[(size_t)cell * 2 * dim + f];
+      if (bid < 0) continue;
+      double pbc = 0; int hit = 0;
+      for (int k = 0; k < P->n_neumann; ++k) if (P->neumann_id[k] == bid) { pbc = P->neumann_p[k]; hit = 1; }
+      if (!hit) continue;
+      face_neumann(s, cell, f, pbc, fe);
+    }
+  }
+}
+
+void orc_imex_assemble(orc_system *s, const orc_params *P, int32_t use_nonzero, int32_t assemble_system,
+                       const double *present, const double *fsi_acc) {
+  const int nd = s->ndof_cell, n = s->n;
+  size_t nnz = (size_t)s->rowptr[n];
+  if (assemble_system) { memset(s->A, 0, sizeof(double) * nnz); memset(s->M, 0, sizeof(double) * nnz); }
+  memset(s->rhs, 0, sizeof(double) * (size_t)n);
+  const unsigned char *isc = s->is_c[use_nonzero ? 1 : 0];
+  const double *cv = s->cval[use_nonzero ? 1 : 0];
+#pragma omp parallel
+  {
+    double *Ke = (double *)malloc(sizeof(double) * (size_t)nd * nd);
+    double *Me = (double *)malloc(sizeof(double) * (size_t)nd * nd);
+    double fe[MAXDOF]; int32_t idx[MAXDOF];
+#pragma omp for schedule(dynamic, 16)
+    for (int cell = 0; cell < s->m.n_cells; ++cell) {
+      imex_cell(s, P, cell, assemble_system, present, fsi_acc, Ke, Me, fe);
+      cell_dofs(s, cell, idx);
+      if (!assemble_system) { /* distribute_local_to_global(local_rhs, idx, system_rhs): constrained rows dropped (:343-346) */
+        for (int i = 0; i < nd; ++i) {
+          if (isc[idx[i]]) continue;
+#pragma omp atomic
+          s->rhs[idx[i]] += fe[i];
+        }
+        continue;
+      }
+      double avgK = 0, avgM = 0; int any_c = 0;
+      for (int i = 0; i < nd; ++i) { avgK += fabs(Ke[i * nd + i]); avgM += fabs(Me[i * nd + i]); if (isc[idx[i]]) any_c = 1; }
+      avgK /= nd; avgM /= nd;
+      for (int i = 0; i < nd; ++i) {
+        int gi = idx[i];
+        if (isc[gi]) {
+          double kd = fabs(Ke[i * nd + i]) != 0 ? fabs(Ke[i * nd + i]) : avgK;
+          double md = fabs(Me[i * nd + i]) != 0 ? fabs(Me[i * nd + i]) : avgM;
+          int64_t p = find_pos(s, gi, gi);
+#pragma omp atomic
+          s->A[p] += kd;
+#pragma omp atomic
+          s->M[p] += md;
+#pragma omp atomic
+          s->rhs[gi] += cv[gi] * kd;
+          continue;
+        }
+        double b = fe[i];
+        if (any_c)
+          for (int r = 0; r < nd; ++r) if (isc[idx[r]]) b -= Ke[i * nd + r] * cv[idx[r]];
+#pragma omp atomic
+        s->rhs[gi] += b;
+        for (int j = 0; j < nd; ++j) {
+          if (isc[idx[j]]) continue;
+          int64_t p = find_pos(s, gi, idx[j]);
+#pragma omp atomic
+          s->A[p] += Ke[i * nd + j];
+#pragma omp atomic
+          s->M[p] += Me[i * nd + j];
+        }
+      }
+    }
+    free(Ke); free(Me);
+  }
+}
+
+/* InsIMEX::run_one_step (:396-446): increment = 0; assemble; FGMRES to min(1e-9, 1e-8 ||rhs||) (:369-370); present += increment */
+int32_t orc_imex_run_one_step(orc_system *s, const orc_params *P, int32_t apply_nonzero, int32_t assemble_system,
+                              const orc_opts *o, orc_ainv_fn ainv, void *user, double *present, const double *fsi_acc,
+                              int32_t *iters, double *res) {
+  const int n = s->n;
+  double *upd = (double *)calloc((size_t)n, sizeof(double));
+  orc_imex_assemble(s, P, apply_nonzero, assemble_system, present, fsi_acc);
+  orc_opts oo = *o;
+  oo.fgmres_rel = 0.0;
+  oo.fgmres_abs = fmin(1e-9, 1e-8 * vnorm(n, s->rhs));
+  const int32_t rc = orc_ins_solve(s, P, apply_nonzero, &oo, ainv, user, upd, iters, res);
+  if (rc == 0) for (int i = 0; i < n; ++i) present[i] += upd[i];
+  free(upd);
+  return rc;
+}
+
 /* ================================================================================================================
  * Fluid::MPI::SCnsIM -- slightly compressible NS with SUPG / PSPG / LSIC (source/mpi_scnsim.cpp:15-568), restated
  * literally: deal.II Tensor operator* semantics (Tensor<1>*Tensor<2>: r_j = sum_i a_i T_ij; Tensor<2>*Tensor<1>:

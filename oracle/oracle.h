@@ -108,6 +108,16 @@ void orc_schur_csr(const orc_system *s, const int64_t **rowptr, const int32_t **
 void orc_precond_vmult(orc_system *s, const orc_params *p, const orc_opts *o, orc_ainv_fn ainv, void *user,
                        const double *v, double *z);
 
+/* ---- Fluid::MPI::InsIMEX (source/mpi_insimex.cpp:150-446): symmetric solution-independent matrix, explicit convection.
+ * assemble_system = 0 re-assembles the rhs only (distribute_local_to_global of the vector: constrained rows dropped).
+ * Pinned by tests/fluid_cylinder_mpi_insimex (vmax 0.374062, pmax 46.5308 after one step). */
+void orc_imex_assemble(orc_system *s, const orc_params *p, int32_t use_nonzero, int32_t assemble_system,
+                       const double *present, const double *fsi_acc);
+/* InsIMEX::run_one_step (:396-446): FGMRES to min(1e-9, 1e-8 ||rhs||), present += solution_time_increment */
+int32_t orc_imex_run_one_step(orc_system *s, const orc_params *p, int32_t apply_nonzero, int32_t assemble_system,
+                              const orc_opts *o, orc_ainv_fn ainv, void *user, double *present, const double *fsi_acc,
+                              int32_t *iters, double *res);
+
 /* ---- slightly compressible NS with SUPG/PSPG/LSIC: Fluid::MPI::SCnsIM (source/mpi_scnsim.cpp:15-568) ------------
  * The preconditioner of SUPGFluidSolver (Hypre-Euclid ILU(0), mpi_supg_solver.cpp:35-192) is third-party and only
  * changes iteration counts; the oracle solves each Newton system through a caller-supplied full-system solve

@@ -74,6 +74,7 @@ def _bind(L):
     L.orc_ins_solve.restype = C.c_int32
     L.orc_ins_solve.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(Opts), C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.orc_imex_run_one_step.restype = C.c_int32
     L.orc_ins_run_one_step.restype = C.c_int32
     L.orc_ins_run_one_step.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_double, C.c_int32,
                                        C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -231,6 +232,17 @@ class System:
         rc = self.L.orc_ins_run_one_step(self.h, C.byref(params), int(apply_nonzero), newton_tol, newton_maxit,
                                          C.byref(self.opts), cb, None, _ptr(present), _ptr(fsi_acc), _ptr(log))
         return rc, log[:max(rc, 0)]
+
+    def imex_assemble(self, params, use_nonzero, assemble_system, present, fsi_acc=None):
+        self.L.orc_imex_assemble(self.h, C.byref(params), int(use_nonzero), int(assemble_system), _ptr(present), _ptr(fsi_acc))
+
+    def imex_run_one_step(self, params, apply_nonzero, assemble_system, present, ainv=None, fsi_acc=None):
+        """InsIMEX::run_one_step on `present` (updated in place); returns (rc, fgmres iterations, residual)"""
+        cb = C.cast(ainv.cb, C.c_void_p) if ainv is not None else None
+        it, res = C.c_int32(), C.c_double()
+        rc = self.L.orc_imex_run_one_step(self.h, C.byref(params), int(apply_nonzero), int(assemble_system),
+                                          C.byref(self.opts), cb, None, _ptr(present), _ptr(fsi_acc), C.byref(it), C.byref(res))
+        return rc, it.value, res.value
 
     def scns_assemble(self, params, use_nonzero, evalp, present, fsi_acc=None):
         self.L.orc_scns_assemble(self.h, C.byref(params), int(use_nonzero), _ptr(evalp), _ptr(present), _ptr(fsi_acc))

@@ -237,3 +237,41 @@ def test_fluid_plane_wall_driven_mpi_insim_supg_regression_constant():
     S, x = _supg_insim_run(m, {2: (3, [0, 0]), 3: (3, [1, 0])}, 0.002, 10)
     l2 = np.linalg.norm(x[:S.n_u])
     assert abs(l2 - 4.7112) / 4.7112 < 1e-3
+
+
+def test_fluid_cylinder_mpi_insimex_regression_constants():
+    # tests/fluid_cylinder_mpi_insimex/fluid_cylinder_mpi_insimex.cpp:65-77: MPI::InsIMEX<2> (mpi_insimex.cpp), cylinder
+    # mesh refined 3 times, Q2/Q1, one step dt = 1e-2: vmax = 0.374062, pmax = 46.5308 at 1e-3
+    from cylmesh import CylinderMesh, inflow_bc
+    m = CylinderMesh(3)
+    S = orc.System(m)
+    dofs, vals = m.dirichlet({0: (3, [0.2, 0]), 2: (3, [0, 0]), 3: (3, [0, 0]), 4: (3, [0, 0])}, {0: inflow_bc})
+    S.set_constraints(1, dofs, vals)
+    S.set_constraints(0, dofs, None)
+    x = np.zeros(S.n)
+    rc, it, res = S.imex_run_one_step(orc.make_params(mu=0.001, rho=1, gamma=0.1, dt=1e-2), True, True, x, ainv=orc.SpluAinv())
+    assert rc == 0
+    vmax, pmax = x[:S.n_u].max(), x[S.n_u:].max()
+    assert abs(vmax - 0.374062) / 0.374062 < 1e-4
+    assert abs(pmax - 46.5308) / 46.5308 < 1e-4
+
+
+def test_fluid_cylinder_insimex_serial_time_loop_constants():
+    # tests/fluid_cylinder_insimex (serial InsIMEX, same integrand and the same run() schedule as mpi_insimex.cpp:455-470):
+    # 1 refinement, 100 steps of 1e-2, matrix assembled in the first two steps only (nonzero, then zero constraints),
+    # rhs-only afterwards: vmax = 0.4081072, pmax = 0.1539 at 1e-3.  Pins assemble_system = false and the time loop.
+    from cylmesh import CylinderMesh, inflow_bc
+    m = CylinderMesh(1)
+    S = orc.System(m)
+    dofs, vals = m.dirichlet({0: (3, [0.2, 0]), 2: (3, [0, 0]), 3: (3, [0, 0]), 4: (3, [0, 0])}, {0: inflow_bc})
+    S.set_constraints(1, dofs, vals)
+    S.set_constraints(0, dofs, None)
+    x = np.zeros(S.n)
+    P = orc.make_params(mu=0.001, rho=1, gamma=0.1, dt=1e-2)
+    ainv = orc.SpluAinv()
+    for step in range(100):
+        rc, _, _ = S.imex_run_one_step(P, step == 0, step < 2, x, ainv=ainv)
+        assert rc == 0
+    vmax, pmax = x[:S.n_u].max(), x[S.n_u:].max()
+    assert abs(vmax - 0.4081072) / 0.4081072 < 1e-3
+    assert abs(pmax - 0.1539) / 0.1539 < 1e-3
