@@ -178,6 +178,21 @@ int ifem_rhs_norm(ifem_ctx *ctx, double *l2);
 int ifem_ins_newton_step(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int apply_nonzero,
                          double tolerance, int max_iterations, double *log);
 
+/* ---- Fluid::MPI::InsIMEX (source/mpi_insimex.cpp): implicit-explicit incompressible NS.  The matrix (viscous +
+ * grad-div + mass/dt + B, B^T: symmetric, independent of the solution) is assembled when assemble_system != 0; the
+ * right-hand side (explicit convection, everything evaluated at IFEM_VEC_PRESENT) always.  With assemble_system = 0 only
+ * the rhs is integrated and constrained rows are dropped (AffineConstraints::distribute_local_to_global of a vector,
+ * mpi_insimex.cpp:343-346). */
+int ifem_imex_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero, int assemble_system);
+/* InsIMEX::solve (:358-393): FGMRES to min(1e-9, 1e-8 ||rhs||) with the block Schur preconditioner of :8-131 (CG(M_p),
+ * CG(S_m), A_uu^-1 through the inner solver selected by o->ainv_kind; the reference's CG(A_uu) tolerance is
+ * o->inner_rel = 1e-4), result in IFEM_VEC_UPDATE (solution_time_increment) */
+int ifem_imex_solve(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats);
+/* InsIMEX::run_one_step (:396-446) without output/checkpoint: increment = 0, assemble, solve, present += increment,
+ * update_stress */
+int ifem_imex_step(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int apply_nonzero, int assemble_system,
+                   ifem_solve_stats *stats);
+
 /* ---- Fluid::MPI::SCnsIM / SUPGFluidSolver (source/mpi_scnsim.cpp, source/mpi_supg_solver.cpp): slightly compressible
  * Navier-Stokes with SUPG / PSPG / LSIC.  Partitioned contexts work as for InsIM (owner-computes rows, halo refresh of
  * the Krylov vectors and of the projected stress). */

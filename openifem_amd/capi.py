@@ -72,7 +72,8 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_vec_norm2", "ifem_vec_minmax", "ifem_halo_exchange", "ifem_ins_assemble", "ifem_solve",
            "ifem_rhs_norm", "ifem_ins_newton_step", "ifem_system_vmult", "ifem_uu_vmult", "ifem_precond_vmult", "ifem_export_csr",
            "ifem_get_timing", "ifem_set_profiling", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
-           "ifem_scns_assemble", "ifem_scns_solve", "ifem_scns_newton_step"]
+           "ifem_scns_assemble", "ifem_scns_solve", "ifem_scns_newton_step", "ifem_imex_assemble", "ifem_imex_solve",
+           "ifem_imex_step"]
 
 _lib = None
 
@@ -128,6 +129,9 @@ def load():
     L.ifem_set_scns_fields.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifem_update_stress.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
     L.ifem_scns_assemble.argtypes = [C.c_void_p, C.POINTER(ScnsParams), C.c_int]
+    L.ifem_imex_assemble.argtypes = [C.c_void_p, C.POINTER(InsParams), C.c_int, C.c_int]
+    L.ifem_imex_solve.argtypes = [C.c_void_p, C.POINTER(InsParams), C.POINTER(SolverOpts), C.c_int, C.POINTER(SolveStats)]
+    L.ifem_imex_step.argtypes = [C.c_void_p, C.POINTER(InsParams), C.POINTER(SolverOpts), C.c_int, C.c_int, C.POINTER(SolveStats)]
     L.ifem_scns_solve.argtypes = [C.c_void_p, C.POINTER(SolverOpts), C.c_int, C.POINTER(SolveStats)]
     L.ifem_scns_newton_step.argtypes = [C.c_void_p, C.POINTER(ScnsParams), C.POINTER(SolverOpts), C.c_int, C.c_double,
                                         C.c_int, C.c_void_p]
@@ -240,6 +244,19 @@ class Context:
         out = np.zeros((self.dim, self.dim, self.n_u // self.dim))
         self._chk(self.L.ifem_update_stress(self.h, mu, _ptr(out)))
         return out
+
+    def imex_assemble(self, params, use_nonzero, assemble_system=True):
+        self._chk(self.L.ifem_imex_assemble(self.h, C.byref(params), int(use_nonzero), int(assemble_system)))
+
+    def imex_solve(self, params, use_nonzero):
+        st = SolveStats()
+        self._chk(self.L.ifem_imex_solve(self.h, C.byref(params), C.byref(self.opts), int(use_nonzero), C.byref(st)))
+        return st
+
+    def imex_step(self, params, apply_nonzero, assemble_system=True):
+        st = SolveStats()
+        self._chk(self.L.ifem_imex_step(self.h, C.byref(params), C.byref(self.opts), int(apply_nonzero), int(assemble_system), C.byref(st)))
+        return st
 
     def scns_assemble(self, params, use_nonzero):
         self._chk(self.L.ifem_scns_assemble(self.h, C.byref(params), int(use_nonzero)))

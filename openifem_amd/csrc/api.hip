@@ -275,6 +275,47 @@ int ifem_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) 
   IFEM_API_END
 }
 
+int ifem_imex_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero, int assemble_system) {
+  IFEM_API_BEGIN
+  if (!p || p->dt <= 0) throw Error(IFEM_E_BADPARAM, "bad ifem_ins_params");
+  auto t0 = std::chrono::steady_clock::now();
+  launch_ins_assemble_ex(ctx, p, use_nonzero, 1, assemble_system);
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->timing.assemble_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  IFEM_API_END
+}
+
+static int imex_solve_impl(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats) {
+  ifem_solver_opts oo;
+  if (o) oo = *o; else { ifem_default_solver_opts(&oo); oo.inner_rel = 1e-4; }
+  const double bn = norm2_owned(ctx, IFEM_VEC_RHS);
+  oo.fgmres_rel = 0.0;
+  oo.fgmres_abs = std::min(1e-9, 1e-8 * bn); // mpi_insimex.cpp:369-370
+  return ins_solve(ctx, p, &oo, use_nonzero, stats);
+}
+
+int ifem_imex_solve(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats) {
+  IFEM_API_BEGIN
+  if (!p) throw Error(IFEM_E_BADPARAM, "null params");
+  const int rc = imex_solve_impl(ctx, p, o, use_nonzero, stats);
+  if (rc != 0) { g_err = "FGMRES did not converge (SolverControl::NoConvergence)"; return rc; }
+  IFEM_API_END
+}
+
+int ifem_imex_step(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int apply_nonzero, int assemble_system,
+                   ifem_solve_stats *stats) {
+  IFEM_API_BEGIN
+  if (!p || p->dt <= 0) throw Error(IFEM_E_BADPARAM, "bad ifem_ins_params");
+  v_zero(ctx, ctx->n_local, ctx->vec[IFEM_VEC_UPDATE].p); // solution_time_increment = 0
+  launch_ins_assemble_ex(ctx, p, apply_nonzero, 1, assemble_system);
+  const int rc = imex_solve_impl(ctx, p, o, apply_nonzero, stats);
+  if (rc != 0) throw Error(rc, "FGMRES did not converge (SolverControl::NoConvergence)");
+  copy_owned(ctx, IFEM_VEC_PRESENT, IFEM_VEC_UPDATE, 1.0, 1.0); // present_solution += solution_time_increment
+  launch_update_stress(ctx, p->viscosity);
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+
 int ifem_solve(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats) {
   IFEM_API_BEGIN
   ifem_solver_opts def;

@@ -348,13 +348,21 @@ static void launch_t(ifem_ctx *ctx, const AsmArgs &A) {
 static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero);
 void launch_ins_assemble2_kernel(ifem_ctx *ctx, const AsmArgs &A);
 
-void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) {
+void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) { launch_ins_assemble_ex(ctx, p, use_nonzero, 0, 1); }
+
+// imex = 1: InsIMEX::assemble (mpi_insimex.cpp:150-355): every field comes from the present solution, the matrix has no
+// convective terms; assemble_system = 0 integrates the right-hand side only and leaves the matrices untouched
+void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero, int imex, int assemble_system) {
   hipStream_t s = ctx->stream;
   const int dim = ctx->dim;
-  { // state the matrix-free A_uu needs to reproduce this matrix (apply_mf.hip)
+  static const bool v1_env = [] { const char *e = getenv("IFEM_ASM"); return e && std::string(e) == "v1"; }();
+  if (imex && (v1_env || ctx->asm_rows)) throw Error(IFEM_E_BADPARAM, "InsIMEX assembly needs the default assembly kernel (unset IFEM_ASM)");
+  if (!assemble_system && !ctx->assembled) throw Error(IFEM_E_BADPARAM, "rhs-only assembly before any matrix assembly");
+  if (assemble_system) { // state the matrix-free A_uu needs to reproduce this matrix (apply_mf.hip)
     const size_t nu = size_t(dim) * size_t(ctx->nUl);
     if (ctx->mf_eval.n != nu) ctx->mf_eval.alloc(nu);
-    IFEM_HIP_CHECK(hipMemcpyAsync(ctx->mf_eval.p, ctx->vec[IFEM_VEC_EVAL].p, nu * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (imex) IFEM_HIP_CHECK(hipMemsetAsync(ctx->mf_eval.p, 0, nu * sizeof(double), s)); // no convection in the IMEX matrix
+    else IFEM_HIP_CHECK(hipMemcpyAsync(ctx->mf_eval.p, ctx->vec[IFEM_VEC_EVAL].p, nu * sizeof(double), hipMemcpyDeviceToDevice, s));
     ctx->mf_params = *p;
     ctx->mf_valid = true;
   }
@@ -364,12 +372,14 @@ void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzer
     return;
   }
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
-  IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
-  IFEM_HIP_CHECK(hipMemsetAsync(ctx->Bt.val.p, 0, ctx->Bt.val.n * sizeof(double), s));
-  IFEM_HIP_CHECK(hipMemsetAsync(ctx->B.val.p, 0, ctx->B.val.n * sizeof(double), s));
-  IFEM_HIP_CHECK(hipMemsetAsync(ctx->Mp.val.p, 0, ctx->Mp.val.n * sizeof(double), s));
-  IFEM_HIP_CHECK(hipMemsetAsync(ctx->diagMu.p, 0, ctx->diagMu.n * sizeof(double), s));
-  if (ctx->want_shat) {
+  if (assemble_system) {
+    IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
+    IFEM_HIP_CHECK(hipMemsetAsync(ctx->Bt.val.p, 0, ctx->Bt.val.n * sizeof(double), s));
+    IFEM_HIP_CHECK(hipMemsetAsync(ctx->B.val.p, 0, ctx->B.val.n * sizeof(double), s));
+    IFEM_HIP_CHECK(hipMemsetAsync(ctx->Mp.val.p, 0, ctx->Mp.val.n * sizeof(double), s));
+    IFEM_HIP_CHECK(hipMemsetAsync(ctx->diagMu.p, 0, ctx->diagMu.n * sizeof(double), s));
+  }
+  if (ctx->want_shat && assemble_system) {
     if (ctx->Shat.n != (size_t)ctx->Auu.nnzb) ctx->Shat.alloc((size_t)ctx->Auu.nnzb);
     IFEM_HIP_CHECK(hipMemsetAsync(ctx->Shat.p, 0, ctx->Shat.n * sizeof(double), s));
   }
@@ -389,7 +399,8 @@ void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzer
   A.cval = ctx->has_c[w] ? ctx->cval[w].p : nullptr;
   A.use_inhom = (use_nonzero && ctx->has_c[1]) ? 1 : 0;
   { const char *e = getenv("IFEM_ASM_SKIP"); A.debug_skip = e ? atoi(e) : 0; }
-  A.eval = ctx->vec[IFEM_VEC_EVAL].p; A.present = ctx->vec[IFEM_VEC_PRESENT].p;
+  A.eval = ctx->vec[imex ? IFEM_VEC_PRESENT : IFEM_VEC_EVAL].p; A.present = ctx->vec[IFEM_VEC_PRESENT].p;
+  A.imex = imex; A.rhs_only = assemble_system ? 0 : 1;
   A.fsi_acc = ctx->indicator.p ? ctx->vec[IFEM_VEC_FSI_ACC].p : nullptr;
   A.mu = p->viscosity; A.rho = p->rho; A.gamma = p->grad_div; A.inv_dt = 1.0 / p->dt;
   for (int i = 0; i < 3; ++i) A.g[i] = p->gravity[i];
@@ -404,7 +415,13 @@ void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzer
   else if (dim == 3 && ctx->kv == 2) launch_t<3, 2>(ctx, A);
   else throw Error(IFEM_E_BADPARAM, "unsupported (dim, kv)");
   IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
-  assemble_epilogue(ctx, use_nonzero);
+  if (assemble_system) assemble_epilogue(ctx, use_nonzero);
+  else {
+    IFEM_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    IFEM_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->timing.assemble_kernel_ms = ms;
+  }
 }
 
 static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero) {

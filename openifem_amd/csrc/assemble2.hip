@@ -292,12 +292,13 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
         tb[lane * TS + 1 + d] = t;
         ug += S.uq[q * DIM + d] * t;
       }
-      tb[lane * TS + 4] = ug;
+      tb[lane * TS + 4] = A.imex ? 0.0 : ug;
     }
     return tb;
   };
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; ++pass) {
+    if (A.rhs_only && pass > 0) break;
     const bool first = pass == 0;
     int oa[RP], ob[RP];
     bool pv[RP];
@@ -343,10 +344,10 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
       const double wmu = w * A.mu, wrho = w * A.rho, wrdt = w * rdt, wg = w * wgam;
       double gqs[DIM * DIM];
 #pragma unroll
-      for (int i = 0; i < DIM * DIM; ++i) gqs[i] = S.gqs[q * DIM * DIM + i];
+      for (int i = 0; i < DIM * DIM; ++i) gqs[i] = A.imex ? 0.0 : S.gqs[q * DIM * DIM + i];
 #pragma unroll
       for (int j = 0; j < RP; ++j) {
-        if (A.debug_skip == 2) continue;
+        if (A.debug_skip == 2 || A.rhs_only) continue;
         const double *pa = tb + oa[j], *pb = tb + ob[j];
         const double Na = pa[0], Nb = pb[0], ugb = pb[4];
         double ga[DIM], gb[DIM], gg = 0;
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
     // ---- scatter the velocity-velocity pairs of this pass
 #pragma unroll
     for (int j = 0; j < RP; ++j) {
-      if (!pbase[j] || A.debug_skip) continue; // no pair in this slot, inactive cell or row owned by another rank
+      if (!pbase[j] || A.debug_skip || A.rhs_only) continue; // no pair in this slot, inactive cell or row owned by another rank
       const int a = oa[j] / TS, b = ob[j] / TS;
       const int len = S.len_uu[a];
       double *base = pbase[j];
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
     }
     wsync2();
   }
-  { // ---- velocity-pressure blocks: -JxW psi_b grad N_a, own pass over the points
+  if (!A.rhs_only) { // ---- velocity-pressure blocks: -JxW psi_b grad N_a, own pass over the points
     double bacc[BROUNDS][DIM];
 #pragma unroll
     for (int k = 0; k < BROUNDS; ++k)
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
     wsync2();
   }
   // ---- pressure mass matrix M_p and diag(M_u)  (:274-276, only the (0,0) diagonal and (1,1) are used)
-  for (int t = lane; t < NP * NP; t += 64) {
+  for (int t = lane; t < (A.rhs_only ? 0 : NP * NP); t += 64) {
     const int pa = t / NP, pb = t - pa * NP;
     double m = 0;
 #pragma unroll 3
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
     if (!ra && !cb) gadd<ATOMIC>(dst, m);
     else if (ra && pa == pb) gadd<ATOMIC>(dst, fabs(m));
   }
-  if (lane < NU) {
+  if (lane < NU && !A.rhs_only) {
     double m = 0;
 #pragma unroll 1
     for (int q = 0; q < NQ; ++q) {

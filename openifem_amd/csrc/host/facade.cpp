@@ -24,13 +24,15 @@ std::unique_ptr<Fluid::MPI::FluidSolver<dim>> make_solver(const char *kind, Tria
   const std::string k = kind ? kind : "InsIM";
   if (k == "InsIM") return std::unique_ptr<Fluid::MPI::FluidSolver<dim>>(new Fluid::MPI::InsIM<dim>(t, params, device));
   if (k == "SCnsIM") return std::unique_ptr<Fluid::MPI::FluidSolver<dim>>(new Fluid::MPI::SCnsIM<dim>(t, params, device));
+  if (k == "InsIMEX") return std::unique_ptr<Fluid::MPI::FluidSolver<dim>>(new Fluid::MPI::InsIMEX<dim>(t, params, device));
   if (k == "SUPGInsIM") return std::unique_ptr<Fluid::MPI::FluidSolver<dim>>(new Fluid::MPI::SUPGInsIM<dim>(t, params, device));
-  throw std::invalid_argument("unknown fluid solver '" + k + "' (InsIM, SCnsIM, SUPGInsIM)");
+  throw std::invalid_argument("unknown fluid solver '" + k + "' (InsIM, InsIMEX, SCnsIM, SUPGInsIM)");
 }
 // assemble / solve / solver_opts live in the two solver families, not in FluidSolver (as in the reference)
 template <int dim, class FI, class FS>
 void with_family(Fluid::MPI::FluidSolver<dim> *s, FI fi, FS fs) {
   if (auto *a = dynamic_cast<Fluid::MPI::InsIM<dim> *>(s)) fi(*a);
+  else if (auto *x = dynamic_cast<Fluid::MPI::InsIMEX<dim> *>(s)) fi(*x);
   else if (auto *b = dynamic_cast<Fluid::MPI::SUPGFluidSolver<dim> *>(s)) fs(*b);
   else throw std::logic_error("unknown solver family");
 }
@@ -216,6 +218,13 @@ int ifemx_constraints(void *hv, int32_t *dof, double *val, int64_t *n) {
 int ifemx_run_one_step(void *hv, int apply_nonzero) {
   auto *h = static_cast<Handle *>(hv);
   return guard([&] { if (h->dim == 2) h->s2->run_one_step(apply_nonzero); else h->s3->run_one_step(apply_nonzero); });
+}
+// run_one_step(apply_nonzero_constraints, assemble_system): the second flag matters to InsIMEX only
+int ifemx_run_one_step2(void *hv, int apply_nonzero, int assemble_system) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) h->s2->run_one_step(apply_nonzero, assemble_system); else h->s3->run_one_step(apply_nonzero, assemble_system);
+  });
 }
 int ifemx_assemble(void *hv, int use_nonzero) {
   auto *h = static_cast<Handle *>(hv);

@@ -234,6 +234,74 @@ void InsIM<dim>::run() {
   while (time.end() - time.current() > 1e-12) run_one_step(false);
 }
 
+template <int dim>
+InsIMEX<dim>::InsIMEX(Triangulation<dim> &tria, const Parameters::AllParameters &parameters, int device)
+    : FluidSolver<dim>(tria, parameters, device) {
+  if (parameters.fluid_velocity_degree - parameters.fluid_pressure_degree != 1)
+    throw std::invalid_argument("Velocity finite element should be one order higher than pressure!");
+  ifem_default_solver_opts(&solver_opts);
+  solver_opts.inner_rel = 1e-4; // CG for A: max(1e-12, 1e-4 ||.||)  (mpi_insimex.cpp:117-118)
+}
+
+template <int dim>
+ifem_ins_params InsIMEX<dim>::ins_params() const {
+  ifem_ins_params p{};
+  p.viscosity = parameters.viscosity; p.rho = parameters.fluid_rho; p.grad_div = parameters.grad_div;
+  p.dt = time.get_delta_t();
+  for (int i = 0; i < dim; ++i) p.gravity[i] = parameters.gravity[i];
+  p.n_neumann = 0;
+  if (parameters.n_fluid_neumann_bcs != 0)
+    for (auto &kv : parameters.fluid_neumann_bcs) {
+      if (p.n_neumann >= 8) throw std::invalid_argument("at most 8 Neumann boundaries are supported");
+      p.neumann_id[p.n_neumann] = (int32_t)kv.first;
+      p.neumann_p[p.n_neumann++] = kv.second;
+    }
+  return p;
+}
+
+template <int dim>
+void InsIMEX<dim>::assemble(bool use_nonzero_constraints, bool assemble_system) {
+  const ifem_ins_params p = ins_params();
+  check(ifem_imex_assemble(ctx, &p, use_nonzero_constraints, assemble_system), "assemble");
+}
+
+template <int dim>
+std::pair<unsigned int, double> InsIMEX<dim>::solve(bool use_nonzero_constraints, bool assemble_system) {
+  static_cast<void>(assemble_system); // the preconditioner data (S_m) is cached by the context until the matrix changes
+  const ifem_ins_params p = ins_params();
+  check(ifem_imex_solve(ctx, &p, &solver_opts, use_nonzero_constraints, &last_stats), "solve");
+  return {last_stats.fgmres_iters, last_stats.fgmres_res};
+}
+
+template <int dim>
+void InsIMEX<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_system) {
+  time.increment();
+  if (this->pcout)
+    *this->pcout << std::string(96, '*') << std::endl
+                 << "Time step = " << time.get_timestep() << ", at t = " << std::scientific << time.current() << std::endl;
+  check(ifem_vec_zero(ctx, IFEM_VEC_UPDATE), "run_one_step"); // solution_time_increment = 0
+  // refinement is outside the path: the "|| time_to_refine()" of mpi_insimex.cpp:416-418 never fires here
+  assemble(apply_nonzero_constraints, assemble_system);
+  auto state = solve(apply_nonzero_constraints, assemble_system);
+  check(ifem_vec_axpy(ctx, 1.0, IFEM_VEC_UPDATE, IFEM_VEC_PRESENT), "run_one_step"); // present_solution += increment
+  if (this->pcout)
+    *this->pcout << std::scientific << std::left << " GMRES_ITR = " << std::setw(3) << state.first
+                 << " GMRES_RES = " << state.second << std::endl;
+  check(ifem_update_stress(ctx, parameters.viscosity, nullptr), "update_stress");
+}
+
+template <int dim>
+void InsIMEX<dim>::run() {
+  if (this->pcout) *this->pcout << "Running with HIP on " << this->proc_grid[0] * this->proc_grid[1] * this->proc_grid[2] << " MI355X rank(s)..." << std::endl;
+  this->triangulation.refine_global(parameters.global_refinements[0]);
+  this->setup_dofs();
+  this->make_constraints();
+  this->initialize_system();
+  while (time.end() - time.current() > 1e-12) run_one_step(time.get_timestep() == 0, time.get_timestep() < 2);
+}
+
+template class InsIMEX<2>;
+template class InsIMEX<3>;
 template class FluidSolver<2>;
 template class FluidSolver<3>;
 template class InsIM<2>;

@@ -130,6 +130,29 @@ private:
   using FluidSolver<dim>::check;
 };
 
+// Fluid::MPI::InsIMEX<dim> (include/mpi_insimex.h, source/mpi_insimex.cpp): implicit-explicit scheme, no Newton loop;
+// the matrix is assembled in the first two steps only (run(), :455-470) and the right-hand side every step
+template <int dim>
+class InsIMEX : public FluidSolver<dim> {
+public:
+  InsIMEX(Triangulation<dim> &, const Parameters::AllParameters &, int device = 0);
+  void run() override;
+  void run_one_step(bool apply_nonzero_constraints, bool assemble_system = true) override;
+  void assemble(bool use_nonzero_constraints, bool assemble_system);
+  std::pair<unsigned int, double> solve(bool use_nonzero_constraints, bool assemble_system);
+  void assemble(bool use_nonzero_constraints) { assemble(use_nonzero_constraints, true); }
+  std::pair<unsigned int, double> solve(bool use_nonzero_constraints) { return solve(use_nonzero_constraints, true); }
+  ifem_solver_opts solver_opts;
+  ifem_solve_stats last_stats{};
+  ifem_ins_params ins_params() const;
+
+private:
+  using FluidSolver<dim>::parameters;
+  using FluidSolver<dim>::time;
+  using FluidSolver<dim>::ctx;
+  using FluidSolver<dim>::check;
+};
+
 // Fluid::MPI::SUPGFluidSolver<dim> (include/mpi_supg_solver.h:39-104): Newton loop + FGMRES of the stabilised
 // solvers; assemble() is the hook of the derived formulation.
 template <int dim>

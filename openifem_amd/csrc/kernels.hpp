@@ -15,6 +15,7 @@ void launch_ins_assemble_rows(ifem_ctx *ctx, const ifem_ins_params *p, int use_n
 
 // assemble.hip
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
+void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero, int imex, int assemble_system);
 
 // assemble_scns.hip
 void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonzero);

@@ -35,6 +35,7 @@ def _lib():
     L.ifemx_run.argtypes = [C.c_void_p]
     L.ifemx_setup.argtypes = [C.c_void_p, C.c_int]
     L.ifemx_run_one_step.argtypes = [C.c_void_p, C.c_int]
+    L.ifemx_run_one_step2.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.ifemx_setup_host_only.argtypes = [C.c_void_p, C.c_int]
     L.ifemx_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     L.ifemx_assemble.argtypes = [C.c_void_p, C.c_int]
@@ -173,8 +174,8 @@ class FluidSolver:
         self._chk(self.L.ifemx_constraints(self.h, d.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), C.byref(n)))
         return d, v
 
-    def run_one_step(self, apply_nonzero):
-        self._chk(self.L.ifemx_run_one_step(self.h, int(apply_nonzero)))
+    def run_one_step(self, apply_nonzero, assemble_system=True):
+        self._chk(self.L.ifemx_run_one_step2(self.h, int(apply_nonzero), int(assemble_system)))
 
     def assemble(self, use_nonzero):
         self._chk(self.L.ifemx_assemble(self.h, int(use_nonzero)))
@@ -233,6 +234,10 @@ class FluidSolver:
 
 class InsIM(FluidSolver):
     KIND = "InsIM"
+
+
+class InsIMEX(FluidSolver):
+    KIND = "InsIMEX"
 
 
 class SCnsIM(FluidSolver):

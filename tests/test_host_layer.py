@@ -160,6 +160,12 @@ def test_scnsim_host_mirror_setup_and_errors():
         assert b.sizes()[0] == reps[0] * reps[1]
     with pytest.raises(host.HostError, match="same as pressure"):
         host.SCnsIM(host.channel_prm(2), (2, 2), (0, 0), (1, 1))
+    # Fluid::MPI::InsIMEX: Taylor-Hood only, the reference's cylinder parameter file
+    b = host.InsIMEX(open(os.path.join(gdir, "fluid_cylinder_mpi_insimex.prm")).read(), mesh="cylinder")
+    b.setup_host_only(1)
+    assert b.sizes()[0] == 368
+    with pytest.raises(host.HostError, match="one order higher"):
+        host.InsIMEX(open(os.path.join(gdir, "fluid_body_force_mpi.prm")).read(), (4, 4), (0, 0), (1, 1))
     # Fluid::MPI::SUPGInsIM with the reference's two parameter files
     for name, reps, p1 in (("fluid_pressure_driven_mpi_insim_supg.prm", (100, 10), (2.0, 0.2)),
                            ("fluid_plane_wall_driven_mpi_insim_supg.prm", (20, 16), (2.0, 0.4))):
