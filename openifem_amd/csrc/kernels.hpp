@@ -46,6 +46,7 @@ void spmv_bt_f32(ifem_ctx *ctx, const double *xp, double *yu); // (matrix-free S
 // y_p = A_pp x_p (SCnsIM pressure block on the M_p pattern); 1/diag(A_pp) for its Jacobi preconditioner
 void spmv_app(ifem_ctx *ctx, const double *xp, double *yp);
 void app_diag_setup(ifem_ctx *ctx);
+void scalar_diag(ifem_ctx *ctx, const PlanarCsr &M, const double *val, double *d);
 // y_p = M_p x_p
 void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp);
 // explicit S_m: numeric product B diag(1/diag M_u) B^T into ctx->Sm (pattern must exist), and y_p = S_m x_p

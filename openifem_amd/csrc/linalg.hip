@@ -322,6 +322,12 @@ void spmv_app(ifem_ctx *ctx, const double *xp, double *yp) {
                      ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->App.p, xp, yp);
 }
 
+// d = diag(M) of a scalar planar CSR matrix with owned rows (M_p, S_m): Jacobi preconditioner of their CG solves
+void scalar_diag(ifem_ctx *ctx, const PlanarCsr &M, const double *val, double *d) {
+  const int64_t n = M.n_rows;
+  if (n) hipLaunchKernelGGL(k_csr_diag, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, M.rowptr.p, M.col.p, val, d);
+}
+
 void app_diag_setup(ifem_ctx *ctx) {
   const int64_t n = ctx->Mp.n_rows;
   if (ctx->app_diag.n != (size_t)n) ctx->app_diag.alloc(n);

@@ -197,6 +197,36 @@ static int cg(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *b, double *
   return it;
 }
 
+// Jacobi-preconditioned CG, zero initial guess, same stopping rule (absolute tolerance on the TRUE residual ||r||_2).
+// r and z must be adjacent (z = r + ld) so that <r,r> and <z,r> come out of one fused reduction.
+static int pcg_jacobi(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *diag, const double *b, double *x, double tol,
+                      int maxit, double *r, int64_t ld, double *p, double *q,
+                      const std::function<void(int, const double *, int64_t, const double *, double *)> &mdot) {
+  double *z = r + ld;
+  v_zero(ctx, n, x);
+  v_copy(ctx, n, b, r);
+  vec_div(ctx, n, diag, r, z);
+  v_copy(ctx, n, z, p);
+  double d2[2];
+  mdot(2, r, ld, r, d2);
+  double rr = d2[0], rz = d2[1];
+  int it = 0;
+  while (std::sqrt(rr) > tol && it < maxit) {
+    A(p, q);
+    double pq;
+    mdot(1, p, n, q, &pq);
+    const double al = rz / pq;
+    v_axpy(ctx, n, al, p, x);
+    v_axpy(ctx, n, -al, q, r);
+    vec_div(ctx, n, diag, r, z);
+    mdot(2, r, ld, r, d2);
+    v_axpby(ctx, n, 1.0, z, d2[1] / rz, p);
+    rr = d2[0]; rz = d2[1];
+    ++it;
+  }
+  return it;
+}
+
 // leading dimension of a Krylov basis: a multiple of 64 doubles plus an odd number of 256-byte lines, so that the
 // K+1 streams of a fused multi-dot do not start on the same HBM channel
 static int64_t basis_ld(int64_t n) {
@@ -261,7 +291,19 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   Clock ck;
   // CG for Mp (:69-84)
   OpFn mp = [&](const double *x, double *y) { const double *xe; extend_p(S, x, &xe); spmv_mp(c, xe, y); };
-  S.st.cg_mp_iters += cg(c, S.npo, mp, src1, tmp, std::max(o->mp_abs, o->mp_rel * n1), (int)std::min<int64_t>(std::max<int64_t>(c->n_global_p, 1), 1 << 30), r, p, q, pdot);
+  // kinds 1 and 3 (approximate preconditioner) also put a Jacobi preconditioner on the two pressure CG solves: same
+  // stopping rule on the true residual, fewer iterations (the reference uses PreconditionNone; counts are no parity target)
+  const bool pjac = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF;
+  auto pmdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
+    v_mdot(c, S.npo, k, V, ld, w, out);
+    allreduce_sum(c, out, k);
+  };
+  const int pmax = (int)std::min<int64_t>(std::max<int64_t>(c->n_global_p, 1), 1 << 30);
+  if (pjac) {
+    scalar_diag(c, c->Mp, c->Mp.val.p, S.tp[5]);
+    S.st.cg_mp_iters += pcg_jacobi(c, S.npo, mp, S.tp[5], src1, tmp, std::max(o->mp_abs, o->mp_rel * n1), pmax, S.tp[1], c->nPl, S.tp[3], S.tp[4], pmdot); // r = tp[1], z = tp[2]
+  } else
+  S.st.cg_mp_iters += cg(c, S.npo, mp, src1, tmp, std::max(o->mp_abs, o->mp_rel * n1), pmax, r, p, q, pdot);
   v_scale(c, S.npo, -(P->viscosity + P->grad_div * P->rho), tmp);
   IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
   S.st.t_cg_mp_ms += ck.ms();
@@ -283,7 +325,8 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     const double *te; extend_u(S, S.tu, &te);
     if (lowp) spmv_b_f32(c, te, y); else spmv_b(c, te, y);
   };
-  S.st.cg_sm_iters += cg(c, S.npo, sm, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), (int)std::min<int64_t>(std::max<int64_t>(c->n_global_p, 1), 1 << 30), r, p, q, pdot);
+  // (Jacobi on S_m was measured too: 176 instead of 172 iterations -- its diagonal is nearly constant -- so CG stays plain)
+  S.st.cg_sm_iters += cg(c, S.npo, sm, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, r, p, q, pdot);
   v_axpby(c, S.npo, 1.0, tmp, -P->rho / P->dt, dst1);
   // utmp = src0 - B^T dst1 (:116-120)
   {
