@@ -69,6 +69,16 @@ typedef struct {
   const uint8_t *nccl_unique_id; /* 128 bytes from ifem_comm_unique_id(), identical on all ranks */
   void *local_world;             /* NULL for RCCL.  Validation transport: a handle from ifem_local_world_create()
                                     shared by several contexts (virtual ranks, one host thread each) of ONE process */
+  /* Optional (structured pressure lattices, i.e. box meshes): 2-deep pressure halo that lets several ranks keep
+   * mass_schur(1,1) = B diag(M_u)^-1 B^T explicit as the reference does (mpi_insim.cpp:44-49) -- its rows couple
+   * pressure nodes two cells apart.  Column space of the distributed S_m: [owned pressure nodes | the other nodes of
+   * the lattice box "owned range +-2", grouped by owner rank in global order].  sm_box_id == NULL: S_m is applied
+   * matrix-free (two SpMVs) on several ranks. */
+  int64_t p_lattice_n[3];        /* global pressure lattice (nodes per direction, 1 beyond dim) */
+  int64_t sm_box_lo[3], sm_box_n[3]; /* the box in lattice coordinates */
+  const int32_t *sm_box_id;      /* [sm_box_n[0]*sm_box_n[1]*sm_box_n[2]] (x fastest) S_m column id of every box node */
+  const int64_t *l2g_p;          /* [n_pnodes_owned] global lattice id ((z*Ny + y)*Nx + x) of the owned pressure nodes */
+  const int32_t *send_s_ptr, *send_s_idx, *recv_s_ptr; /* halo plan of that column space, same layout as send_p_* */
 } ifem_partition;
 
 /* Parameters::AllParameters subset used by InsIM::assemble (mpi_insim.cpp:157-161,240,272; parameters.cpp) */

@@ -57,7 +57,19 @@ void comm_init(ifem_ctx *ctx, const ifem_partition *part) {
     throw Error(IFEM_E_BADPARAM, "ifem_partition: receive counts do not match the number of ghost nodes");
   h.send_u_idx.upload(part->send_u_idx, h.send_u_ptr[nn], ctx->stream);
   h.send_p_idx.upload(part->send_p_idx, h.send_p_ptr[nn], ctx->stream);
-  h.sendbuf.alloc((size_t)ctx->dim * h.send_u_ptr[nn] + h.send_p_ptr[nn] + 8);
+  size_t n_send_s = 0;
+  if (part->sm_box_id && part->l2g_p && part->send_s_ptr && part->recv_s_ptr) {
+    h.send_s_ptr.assign(part->send_s_ptr, part->send_s_ptr + nn + 1);
+    h.recv_s_ptr.assign(part->recv_s_ptr, part->recv_s_ptr + nn + 1);
+    n_send_s = (size_t)h.send_s_ptr[nn];
+    h.send_s_idx.upload(part->send_s_idx, n_send_s, ctx->stream);
+    for (int d = 0; d < 3; ++d) { h.p_lattice_n[d] = part->p_lattice_n[d]; h.sm_box_lo[d] = part->sm_box_lo[d]; h.sm_box_n[d] = part->sm_box_n[d]; }
+    h.sm_box_id.upload(part->sm_box_id, (size_t)(h.sm_box_n[0] * h.sm_box_n[1] * h.sm_box_n[2]), ctx->stream);
+    h.own_p_gid.upload(part->l2g_p, (size_t)ctx->nPo, ctx->stream);
+    h.n_s_cols = ctx->nPo + h.recv_s_ptr[nn];
+    h.has_s = true;
+  }
+  h.sendbuf.alloc((size_t)ctx->dim * h.send_u_ptr[nn] + h.send_p_ptr[nn] + n_send_s + 8);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (part->local_world) {
     auto *w = static_cast<LocalWorld *>(part->local_world);
@@ -91,14 +103,20 @@ __global__ void k_pack(int64_t n, int bs, const int32_t *__restrict__ idx, const
 }
 
 // which: 0 = velocity nodes (bs = dim), 1 = pressure nodes (bs = 1)
+// which: 0 velocity halo, 1 pressure halo, 2 the 2-deep pressure halo of the distributed S_m
 static void exchange(ifem_ctx *ctx, double *x, int which) {
   Halo &h = ctx->halo;
   const int bs = which == 0 ? ctx->dim : 1;
   const int64_t n_owned = which == 0 ? ctx->nUo : ctx->nPo;
-  const std::vector<int32_t> &sptr = which == 0 ? h.send_u_ptr : h.send_p_ptr;
-  const std::vector<int32_t> &rptr = which == 0 ? h.recv_u_ptr : h.recv_p_ptr;
-  const DBuf<int32_t> &sidx = which == 0 ? h.send_u_idx : h.send_p_idx;
-  auto sendbuf_of = [&](ifem_ctx *c) { return c->halo.sendbuf.p + (which == 0 ? 0 : (size_t)c->dim * c->halo.send_u_ptr.back()); };
+  const std::vector<int32_t> &sptr = which == 0 ? h.send_u_ptr : (which == 1 ? h.send_p_ptr : h.send_s_ptr);
+  const std::vector<int32_t> &rptr = which == 0 ? h.recv_u_ptr : (which == 1 ? h.recv_p_ptr : h.recv_s_ptr);
+  const DBuf<int32_t> &sidx = which == 0 ? h.send_u_idx : (which == 1 ? h.send_p_idx : h.send_s_idx);
+  auto sendbuf_of = [&](ifem_ctx *c) {
+    size_t off = 0;
+    if (which >= 1) off += (size_t)c->dim * c->halo.send_u_ptr.back();
+    if (which >= 2) off += (size_t)c->halo.send_p_ptr.back();
+    return c->halo.sendbuf.p + off;
+  };
   double *sendbuf = sendbuf_of(ctx);
   const int nn = (int)h.nbr.size();
   const int64_t ns = sptr[nn];
@@ -118,7 +136,7 @@ static void exchange(ifem_ctx *ctx, double *x, int which) {
       int me = -1;
       for (size_t j = 0; j < ph.nbr.size(); ++j) if (ph.nbr[j] == h.rank) me = (int)j;
       if (me < 0) throw Error(IFEM_E_COMM, "local world: neighbour lists are not symmetric");
-      const std::vector<int32_t> &psptr = which == 0 ? ph.send_u_ptr : ph.send_p_ptr;
+      const std::vector<int32_t> &psptr = which == 0 ? ph.send_u_ptr : (which == 1 ? ph.send_p_ptr : ph.send_s_ptr);
       if (int64_t(psptr[me + 1] - psptr[me]) * bs != rc) throw Error(IFEM_E_COMM, "local world: send/recv count mismatch");
       IFEM_HIP_CHECK(hipMemcpyAsync(x + (n_owned + rptr[k]) * bs, sendbuf_of(peer) + int64_t(psptr[me]) * bs,
                                     rc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -139,6 +157,12 @@ static void exchange(ifem_ctx *ctx, double *x, int which) {
 void halo_exchange(ifem_ctx *ctx, double *xu_ext) {
   if (ctx->halo.nranks == 1) return;
   exchange(ctx, xu_ext, 0);
+}
+
+void halo_exchange_s(ifem_ctx *ctx, double *xs_ext) {
+  if (ctx->halo.nranks == 1) return;
+  if (!ctx->halo.has_s) throw Error(IFEM_E_BADPARAM, "no 2-deep pressure halo plan in this context");
+  exchange(ctx, xs_ext, 2);
 }
 
 void halo_exchange_p(ifem_ctx *ctx, double *xp_ext) {

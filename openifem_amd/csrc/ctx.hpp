@@ -87,6 +87,13 @@ struct Halo {
   std::vector<int> nbr;
   std::vector<int32_t> send_u_ptr, recv_u_ptr, send_p_ptr, recv_p_ptr;
   DBuf<int32_t> send_u_idx, send_p_idx;
+  // 2-deep pressure halo of the distributed explicit S_m (empty: not available)
+  std::vector<int32_t> send_s_ptr, recv_s_ptr;
+  DBuf<int32_t> send_s_idx, sm_box_id;
+  DBuf<int64_t> own_p_gid;
+  int64_t p_lattice_n[3] = {1, 1, 1}, sm_box_lo[3] = {0, 0, 0}, sm_box_n[3] = {0, 0, 0};
+  int64_t n_s_cols = 0; // nPo + far nodes
+  bool has_s = false;
   DBuf<double> sendbuf;
   void *comm = nullptr;  // ncclComm_t
   void *local = nullptr; // LocalWorld* (in-process virtual ranks, validation transport)
@@ -127,6 +134,7 @@ struct ifem_ctx {
   bool sm_valid = false;
   ifem::DBuf<float> B_f32, Bt_f32; // single-precision copies for the matrix-free S_m of the approximate-preconditioner kinds
   bool bbt_f32_valid = false;
+  ifem::DBuf<double> xs_ext; // [halo.n_s_cols] input of the distributed S_m SpMV: owned entries + 2-deep far nodes
   ifem::DBuf<float> Sm_f32; // single-precision copy of the S_m values for its SpMV (approximate-preconditioner kinds)
   bool sm_f32_valid = false;
   int64_t sm_key = -1, constraints_epoch = 0;

@@ -402,6 +402,63 @@ void distribute_dofs_box(const std::array<int, 3> &reps, const std::array<double
   if (part.recv_u_ptr.back() != out.n_unodes - out.n_unodes_owned || part.recv_p_ptr.back() != out.n_pnodes - out.n_pnodes_owned)
     throw std::logic_error("box partition: a ghost node has a non-adjacent owner");
 
+  // ---- 2-deep pressure halo plan (explicit S_m on several ranks)
+  part.p_lattice_n = {LP.N[0], LP.N[1], LP.N[2]};
+  part.sm_box_id.clear(); part.send_s_ptr.clear(); part.send_s_idx.clear(); part.recv_s_ptr.clear();
+  part.sm_box_n = {0, 0, 0};
+  {
+    bool wide = nranks > 1;
+    for (int d = 0; d < dim; ++d) if (n[d] < 2) wide = false;
+    if (wide) {
+      auto own_range = [&](const int *bb, int d, int64_t &lo, int64_t &hi) { // owned pressure nodes of block bb (inclusive)
+        if (d >= dim) { lo = hi = 0; return; }
+        lo = bb[d] == 0 ? 0 : int64_t(bb[d]) * n[d] + 1;
+        hi = int64_t(bb[d] + 1) * n[d];
+      };
+      auto s_box = [&](const int *bb, int64_t *lo, int64_t *hi) {
+        for (int d = 0; d < 3; ++d) {
+          int64_t a, c;
+          own_range(bb, d, a, c);
+          lo[d] = d < dim ? std::max<int64_t>(0, a - 2) : 0;
+          hi[d] = d < dim ? std::min<int64_t>(LP.N[d] - 1, c + 2) : 0;
+        }
+      };
+      int64_t slo[3], shi[3];
+      s_box(b, slo, shi);
+      for (int d = 0; d < 3; ++d) { part.sm_box_lo[d] = slo[d]; part.sm_box_n[d] = shi[d] - slo[d] + 1; }
+      const int64_t vol = part.sm_box_n[0] * part.sm_box_n[1] * part.sm_box_n[2];
+      part.sm_box_id.assign((size_t)vol, -1);
+      auto spos = [&](const int64_t *g) { return ((g[2] - slo[2]) * part.sm_box_n[1] + (g[1] - slo[1])) * part.sm_box_n[0] + (g[0] - slo[0]); };
+      struct G2 { int32_t owner; int64_t gid; int64_t pos; };
+      std::vector<G2> far;
+      int64_t g[3];
+      for (g[2] = slo[2]; g[2] <= shi[2]; ++g[2])
+        for (g[1] = slo[1]; g[1] <= shi[1]; ++g[1])
+          for (g[0] = slo[0]; g[0] <= shi[0]; ++g[0]) {
+            const int ow = owner_of(1, g);
+            if (ow == rank) part.sm_box_id[(size_t)spos(g)] = LP.local_id[(size_t)LP.lpos(g)];
+            else far.push_back({(int32_t)ow, LP.gid(g), spos(g)});
+          }
+      std::stable_sort(far.begin(), far.end(), [](const G2 &a, const G2 &c) { return a.owner != c.owner ? a.owner < c.owner : a.gid < c.gid; });
+      for (size_t i = 0; i < far.size(); ++i) part.sm_box_id[(size_t)far[i].pos] = (int32_t)(out.n_pnodes_owned + (int64_t)i);
+      part.send_s_ptr = {0}; part.recv_s_ptr = {0};
+      for (int32_t s : part.neighbors) { // same neighbour order as the other plans
+        int bb[3] = {s % Pd[0], (s / Pd[0]) % Pd[1], s / (Pd[0] * Pd[1])};
+        int64_t nlo[3], nhi[3];
+        s_box(bb, nlo, nhi);
+        for (g[2] = nlo[2]; g[2] <= nhi[2]; ++g[2])   // what the neighbour's box holds of my owned nodes, in global order
+          for (g[1] = nlo[1]; g[1] <= nhi[1]; ++g[1])
+            for (g[0] = nlo[0]; g[0] <= nhi[0]; ++g[0])
+              if (owner_of(1, g) == rank) part.send_s_idx.push_back(LP.local_id[(size_t)LP.lpos(g)]);
+        part.send_s_ptr.push_back((int32_t)part.send_s_idx.size());
+        int32_t cnt = 0;
+        for (auto &f : far) if (f.owner == s) ++cnt;
+        part.recv_s_ptr.push_back(part.recv_s_ptr.back() + cnt);
+      }
+      if (part.recv_s_ptr.back() != (int32_t)far.size()) throw std::logic_error("box partition: a 2-deep pressure neighbour is not an adjacent block");
+    }
+  }
+
   // ---- local cells (lexicographic over the local cell box)
   int c0[3], c1[3];
   for (int d = 0; d < 3; ++d) cell_range(b, d, c0[d], c1[d]);

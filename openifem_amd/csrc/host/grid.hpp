@@ -80,6 +80,13 @@ struct PartitionTables {
   std::vector<int32_t> send_p_ptr, send_p_idx, recv_p_ptr;
   std::vector<int64_t> l2g_u, l2g_p;                     // local node -> global lattice id
   int64_t n_unodes_global = 0, n_pnodes_global = 0, n_cells_global = 0;
+  // 2-deep pressure halo for an explicit S_m = B diag(M_u)^-1 B^T on several ranks (its rows couple pressure nodes two
+  // cells apart).  Column space: [owned pressure nodes | nodes of the box "owned range +-2" owned elsewhere, grouped by
+  // owner rank in global order].  Empty when a block is narrower than 2 cells.
+  std::array<int64_t, 3> p_lattice_n{1, 1, 1};           // global pressure lattice
+  std::array<int64_t, 3> sm_box_lo{0, 0, 0}, sm_box_n{0, 0, 0};
+  std::vector<int32_t> sm_box_id;                        // [box] lattice position -> S_m column id
+  std::vector<int32_t> send_s_ptr, send_s_idx, recv_s_ptr; // same layout as the pressure halo plan
 };
 
 // local tables of rank `rank` for the box mesh reps x [p0,p1] without ever building the global mesh

@@ -127,6 +127,12 @@ void FluidSolver<dim>::initialize_system() {
     ip.send_p_ptr = part.send_p_ptr.data(); ip.send_p_idx = part.send_p_idx.data(); ip.recv_p_ptr = part.recv_p_ptr.data();
     ip.nccl_unique_id = nccl_id.empty() ? nullptr : nccl_id.data();
     ip.local_world = local_world;
+    if (!part.sm_box_id.empty()) { // box meshes: 2-deep pressure halo for the explicit S_m
+      for (int d = 0; d < 3; ++d) { ip.p_lattice_n[d] = part.p_lattice_n[d]; ip.sm_box_lo[d] = part.sm_box_lo[d]; ip.sm_box_n[d] = part.sm_box_n[d]; }
+      ip.sm_box_id = part.sm_box_id.data();
+      ip.l2g_p = part.l2g_p.data();
+      ip.send_s_ptr = part.send_s_ptr.data(); ip.send_s_idx = part.send_s_idx.data(); ip.recv_s_ptr = part.recv_s_ptr.data();
+    }
   }
   check(ifem_ctx_create(&m, part.nranks > 1 ? &ip : nullptr, device, &ctx), "initialize_system");
   check(ifem_set_constraints(ctx, 1, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nonzero_values.data()), "initialize_system");

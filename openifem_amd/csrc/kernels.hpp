@@ -90,6 +90,10 @@ void local_world_destroy(void *w);
 // ghost refresh of a ghost-extended velocity buffer [dim*nUl] / pressure buffer [nPl] (RCCL send/recv over xGMI)
 void halo_exchange(ifem_ctx *ctx, double *xu_ext);
 void halo_exchange_p(ifem_ctx *ctx, double *xp_ext);
+void halo_exchange_s(ifem_ctx *ctx, double *xs_ext); // [n_s_cols]: owned pressure nodes, then the 2-deep far nodes
+void build_schur_pattern_box(ifem_ctx *ctx);          // distributed explicit S_m on a structured pressure lattice
+void schur_probe_fill(ifem_ctx *ctx, int color, const double *y); // S_m[i, j(color)] = y_i
+void schur_probe_vector(ifem_ctx *ctx, int color, double *x);     // x_i = [color(i) == color]
 void comm_init(ifem_ctx *ctx, const ifem_partition *part);
 void comm_destroy(ifem_ctx *ctx);
 

@@ -192,6 +192,115 @@ void build_incidence(ifem_ctx *ctx) {
     throw Error(IFEM_E_BADPARAM, "row assembly: a node belongs to more than 64 cells (set IFEM_ASM=atomic)");
 }
 
+// ---- distributed explicit S_m on a structured pressure lattice (box meshes on several ranks).  Row i couples the
+// lattice nodes within +-2 of it (clipped at the domain boundary) = pattern(M_p^2); columns are ids of the 2-deep column
+// space (owned | far nodes by owner).  Values come from probing the distributed matrix-free operator B diag(M_u)^-1 B^T
+// with the 5^dim vectors "nodes whose lattice coordinates are congruent to c mod 5": two columns of one colour never
+// meet in a row, so (S_m e_c)_i is exactly the entry S_m[i, j_c(i)].
+struct SBox {
+  int64_t N[3], lo[3], n[3];
+};
+__device__ inline void sbox_decode(const SBox &B, int64_t gid, int64_t *g) {
+  g[0] = gid % B.N[0];
+  g[1] = (gid / B.N[0]) % B.N[1];
+  g[2] = gid / (B.N[0] * B.N[1]);
+}
+__global__ void k_sbox_count(int64_t n_rows, SBox B, const int64_t *__restrict__ gid, int64_t *__restrict__ cnt) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t g[3], c = 1;
+    sbox_decode(B, gid[i], g);
+    for (int d = 0; d < 3; ++d) {
+      const int64_t lo = g[d] - 2 > 0 ? g[d] - 2 : 0, hi = g[d] + 2 < B.N[d] - 1 ? g[d] + 2 : B.N[d] - 1;
+      c *= hi - lo + 1;
+    }
+    cnt[i] = c;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) cnt[n_rows] = 0;
+}
+__global__ void k_sbox_fill(int64_t n_rows, SBox B, const int64_t *__restrict__ gid, const int32_t *__restrict__ box_id,
+                            const int64_t *__restrict__ rp, int32_t *__restrict__ col) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t g[3], lo[3], hi[3];
+    sbox_decode(B, gid[i], g);
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = g[d] - 2 > 0 ? g[d] - 2 : 0;
+      hi[d] = g[d] + 2 < B.N[d] - 1 ? g[d] + 2 : B.N[d] - 1;
+    }
+    int64_t o = rp[i];
+    for (int64_t z = lo[2]; z <= hi[2]; ++z)
+      for (int64_t y = lo[1]; y <= hi[1]; ++y)
+        for (int64_t x = lo[0]; x <= hi[0]; ++x)
+          col[o++] = box_id[((z - B.lo[2]) * B.n[1] + (y - B.lo[1])) * B.n[0] + (x - B.lo[0])];
+  }
+}
+__global__ void k_probe_vector(int64_t n_rows, SBox B, const int64_t *__restrict__ gid, int c0, int c1, int c2,
+                               double *__restrict__ x) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t g[3];
+    sbox_decode(B, gid[i], g);
+    x[i] = (g[0] % 5 == c0 && g[1] % 5 == c1 && g[2] % 5 == c2) ? 1.0 : 0.0;
+  }
+}
+__global__ void k_probe_fill(int64_t n_rows, SBox B, const int64_t *__restrict__ gid, int c0, int c1, int c2,
+                             const int64_t *__restrict__ rp, const double *__restrict__ y, double *__restrict__ val) {
+  const int c[3] = {c0, c1, c2};
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t g[3], lo[3], w[3], t[3];
+    sbox_decode(B, gid[i], g);
+    bool ok = true;
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = g[d] - 2 > 0 ? g[d] - 2 : 0;
+      const int64_t hi = g[d] + 2 < B.N[d] - 1 ? g[d] + 2 : B.N[d] - 1;
+      w[d] = hi - lo[d] + 1;
+      const int64_t a = g[d] - 2; // the unique node of [a, a+4] congruent to c[d] mod 5
+      t[d] = a + (((c[d] - a) % 5) + 5) % 5;
+      if (t[d] < lo[d] || t[d] > hi) ok = false;
+    }
+    if (ok) val[rp[i] + ((t[2] - lo[2]) * w[1] + (t[1] - lo[1])) * w[0] + (t[0] - lo[0])] = y[i];
+  }
+}
+static SBox sbox_of(const ifem_ctx *ctx) {
+  SBox B;
+  for (int d = 0; d < 3; ++d) { B.N[d] = ctx->halo.p_lattice_n[d]; B.lo[d] = ctx->halo.sm_box_lo[d]; B.n[d] = ctx->halo.sm_box_n[d]; }
+  return B;
+}
+void build_schur_pattern_box(ifem_ctx *ctx) {
+  if (!ctx->halo.has_s) throw Error(IFEM_E_BADPARAM, "explicit S_m on several ranks needs the 2-deep pressure halo plan");
+  hipStream_t s = ctx->stream;
+  const int64_t n = ctx->nPo;
+  const SBox B = sbox_of(ctx);
+  PlanarCsr &M = ctx->Sm;
+  DBuf<int64_t> cnt;
+  cnt.alloc(n + 1);
+  hipLaunchKernelGGL(k_sbox_count, dim3(grid_for(n > 0 ? n : 1)), dim3(256), 0, s, n, B, ctx->halo.own_p_gid.p, cnt.p);
+  M.rowptr.alloc(n + 1);
+  size_t tb = 0;
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, cnt.p, M.rowptr.p, int64_t(0), (size_t)(n + 1), rocprim::plus<int64_t>(), s));
+  DBuf<char> tmp;
+  tmp.alloc(tb + 16);
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(tmp.p, tb, cnt.p, M.rowptr.p, int64_t(0), (size_t)(n + 1), rocprim::plus<int64_t>(), s));
+  int64_t nnz = 0;
+  IFEM_HIP_CHECK(hipMemcpyAsync(&nnz, M.rowptr.p + n, 8, hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  M.n_rows = n; M.nnzb = nnz; M.bs = 1; M.max_row = ctx->dim == 3 ? 125 : 25;
+  M.col.alloc(nnz);
+  M.val.alloc(nnz);
+  IFEM_HIP_CHECK(hipMemsetAsync(M.val.p, 0, nnz * sizeof(double), s));
+  if (n) hipLaunchKernelGGL(k_sbox_fill, dim3(grid_for(n)), dim3(256), 0, s, n, B, ctx->halo.own_p_gid.p, ctx->halo.sm_box_id.p, M.rowptr.p, M.col.p);
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  IFEM_HIP_CHECK(hipGetLastError());
+}
+void schur_probe_vector(ifem_ctx *ctx, int color, double *x) {
+  const int64_t n = ctx->nPo;
+  if (n) hipLaunchKernelGGL(k_probe_vector, dim3(grid_for(n)), dim3(256), 0, ctx->stream, n, sbox_of(ctx), ctx->halo.own_p_gid.p,
+                            color % 5, (color / 5) % 5, color / 25, x);
+}
+void schur_probe_fill(ifem_ctx *ctx, int color, const double *y) {
+  const int64_t n = ctx->nPo;
+  if (n) hipLaunchKernelGGL(k_probe_fill, dim3(grid_for(n)), dim3(256), 0, ctx->stream, n, sbox_of(ctx), ctx->halo.own_p_gid.p,
+                            color % 5, (color / 5) % 5, color / 25, ctx->Sm.rowptr.p, y, ctx->Sm.val.p);
+}
+
 void build_schur_pattern(ifem_ctx *ctx) {
   if (ctx->halo.nranks != 1) throw Error(IFEM_E_BADPARAM, "explicit S_m needs a 2-deep pressure halo: single rank only");
   hipStream_t s = ctx->stream;

@@ -309,21 +309,46 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   S.st.t_cg_mp_ms += ck.ms();
   // CG for Sm (:86-112): S_m = B diag(M_u)^-1 B^T applied matrix-free
   Clock ck2;
-  const bool explicit_sm = c->halo.nranks == 1 && o->explicit_schur;
-  if (explicit_sm) { // BlockSchurPreconditioner ctor (:44-49): S_m assembled once per solve()
-    if (c->Sm.n_rows == 0) build_schur_pattern(c);
-    schur_numeric(c);
-  }
-  OpFn sm = [&](const double *x, double *y) {
-    // the approximate-preconditioner kinds (1, 3) also stream S_m in single precision: it only ever acts inside CG to
-    // 1e-3 ||v|| and the rounding (6e-8 relative) is far below the eigenvalue ratio of this Laplacian-like operator
-    if (explicit_sm) { spmv_sm(c, x, y, o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF); return; }
-    const bool lowp = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF;
+  const bool multi = c->halo.nranks > 1;
+  const bool explicit_sm = o->explicit_schur && (!multi || c->halo.has_s);
+  const bool lowp_all = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF;
+  // S_m = B diag(M_u)^-1 B^T applied with two SpMVs (ghost refreshes in between)
+  auto sm_matrix_free = [&](const double *x, double *y, bool lowp) {
     const double *xe; extend_p(S, x, &xe);
     if (lowp) spmv_bt_f32(c, xe, S.tu); else spmv_bt(c, xe, S.tu);
     vec_mul(c, S.nuo, c->dinvMu.p, S.tu, S.tu);
     const double *te; extend_u(S, S.tu, &te);
     if (lowp) spmv_b_f32(c, te, y); else spmv_b(c, te, y);
+  };
+  if (explicit_sm && !multi) { // BlockSchurPreconditioner ctor (:44-49): S_m assembled once per solve()
+    if (c->Sm.n_rows == 0) build_schur_pattern(c);
+    schur_numeric(c);
+  }
+  if (explicit_sm && multi) { // same matrix, distributed: pattern from the pressure lattice, values by probing
+    if (c->Sm.n_rows == 0 && c->nPo) build_schur_pattern_box(c);
+    if ((int64_t)c->xs_ext.n < c->halo.n_s_cols) c->xs_ext.alloc(c->halo.n_s_cols);
+    if (!c->sm_valid) {
+      const int ncol = c->dim == 3 ? 125 : 25;
+      for (int col = 0; col < ncol; ++col) {
+        schur_probe_vector(c, col, r);
+        sm_matrix_free(r, q, false);
+        schur_probe_fill(c, col, q);
+      }
+      c->sm_valid = true;
+      c->sm_f32_valid = false;
+    }
+  }
+  OpFn sm = [&](const double *x, double *y) {
+    if (explicit_sm && multi) {
+      v_copy(c, S.npo, x, c->xs_ext.p);
+      halo_exchange_s(c, c->xs_ext.p);
+      spmv_sm(c, c->xs_ext.p, y, lowp_all);
+      return;
+    }
+    // the approximate-preconditioner kinds (1, 3) also stream S_m in single precision: it only ever acts inside CG to
+    // 1e-3 ||v|| and the rounding (6e-8 relative) is far below the eigenvalue ratio of this Laplacian-like operator
+    if (explicit_sm) { spmv_sm(c, x, y, lowp_all); return; }
+    sm_matrix_free(x, y, lowp_all); // several ranks without the 2-deep halo plan (general meshes)
   };
   // (Jacobi on S_m was measured too: 176 instead of 172 iterations -- its diagonal is nearly constant -- so CG stays plain)
   S.st.cg_sm_iters += cg(c, S.npo, sm, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, r, p, q, pdot);

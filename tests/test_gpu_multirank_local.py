@@ -185,3 +185,66 @@ def test_scnsim_virtual_ranks_match_single_context():
             # update_stress: owned AND ghost nodes carry the global nodal average
             assert np.abs(st - sg[:, :, t["l2g_u"]]).max() <= 1e-6 * np.abs(sg).max()
         L.ifem_local_world_destroy(w)
+
+
+def _precond_case(reps, P, world_handle, rank, explicit, out, errs):
+    from openifem_amd import host, capi
+    try:
+        L = capi.load()
+        s = host.InsIM(host.channel_prm(3), reps, (0, 0, 0), (2.0, 0.2, 0.2))
+        if P is not None:
+            s.set_partition(P, rank, local_world=world_handle)
+        s.setup(0)
+        s.channel_state()
+        if P is not None:
+            assert L.ifem_halo_exchange(s.ctx, capi.VEC_EVAL) == 0
+        s.opts.mp_rel = s.opts.sm_rel = 1e-13
+        s.opts.inner_rel = 1e-11
+        s.opts.inner_maxit = 6000
+        s.opts.explicit_schur = int(explicit)
+        s.assemble(False)
+        t = s.partition_tables()
+        nuo, npo = t["n_unodes_owned"], t["n_pnodes_owned"]
+        gu = (t["l2g_u"][:nuo, None] * 3 + np.arange(3)[None, :]).ravel()
+        gp = 3 * t["n_unodes_global"] + t["l2g_p"][:npo]
+        gall = np.concatenate([gu, gp])
+        v = np.cos(0.37 * gall) + 0.1 * np.sin(1.3 * gall)  # the same global vector on every partition
+        assert L.ifem_vec_set(s.ctx, capi.VEC_TMP, v.ctypes.data_as(C.c_void_p)) == 0
+        P_ = s.L.ifemx_solver_opts  # noqa (keeps the opts alive)
+        ip = capi.make_params(mu=1.0, rho=1.0, gamma=0.1, dt=1e-3)
+        rc = L.ifem_precond_vmult(s.ctx, C.byref(ip), C.byref(s.opts), capi.VEC_UPDATE, capi.VEC_TMP)
+        assert rc == 0, L.ifem_last_error().decode()
+        z = np.zeros(3 * nuo + npo)
+        L.ifem_vec_get(s.ctx, capi.VEC_UPDATE, z.ctypes.data_as(C.c_void_p))
+        out[rank] = (gall, z)
+        s.close()
+    except Exception:  # noqa
+        import traceback
+        errs.append((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("P,reps", [((2, 1, 1), (8, 4, 4)), ((2, 2, 2), (6, 6, 6))])
+def test_distributed_explicit_schur_matches_single_context(P, reps):
+    # BlockSchurPreconditioner::vmult with the distributed explicit S_m (lattice pattern, values by probing, 2-deep
+    # pressure halo) against one context, all inner solves converged: a wrong S_m entry would change z_p
+    from openifem_amd import capi
+    L = capi.load()
+    single, errs = [None], []
+    _precond_case(reps, None, None, 0, True, single, errs)
+    assert not errs, errs
+    g1, z1 = single[0]
+    ref = np.zeros(g1.max() + 1)
+    ref[g1] = z1
+    for explicit in (True, False):  # False: the matrix-free S_m path stays available
+        world = int(np.prod(P))
+        w = C.c_void_p(L.ifem_local_world_create(world))
+        out, errs = [None] * world, []
+        th = [threading.Thread(target=_precond_case, args=(reps, P, w, r, explicit, out, errs)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+        assert not errs, errs
+        for g, z in out:
+            assert np.abs(z - ref[g]).max() <= 1e-7 * np.abs(ref).max(), explicit
+        L.ifem_local_world_destroy(w)
