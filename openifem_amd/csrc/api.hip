@@ -494,7 +494,7 @@ int ifem_export_csr(ifem_ctx *ctx, int which, int64_t *rowptr, int32_t *col, dou
       for (int64_t k = 0; k < len; ++k)
         for (int d = 0; d < dim; ++d) {
           col[o] = cA[rs + k] * dim + d;
-          if (which == 0) val[o] = vA[rs * dim * dim + (c * dim + d) * len + k];
+          if (which == 0) val[o] = vA[uu_base(rs, len, k, dim * dim) + (c * dim + d) * uu_estride(len)];
           else val[o] = (cA[rs + k] == A && c == d) ? dM[A * dim + c] : 0.0;
           ++o;
         }

@@ -200,10 +200,10 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble(AsmArgs A) {
     double old[DIM * DIM];
     if (row_here) {
       const uint16_t pos = A.posUU[(cc * NU + a) * NU + b];
-      base = A.v_uu + S.rs_uu[a] * (DIM * DIM) + pos;
+      base = A.v_uu + uu_base(S.rs_uu[a], len, pos, DIM * DIM);
       if constexpr (!ATOMIC) {
 #pragma unroll
-        for (int e = 0; e < DIM * DIM; ++e) old[e] = base[int64_t(e) * len];
+        for (int e = 0; e < DIM * DIM; ++e) old[e] = base[int64_t(e) * uu_estride(len)];
       }
     }
     double s = 0, acc[DIM * DIM];
@@ -221,13 +221,13 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble(AsmArgs A) {
     for (int c = 0; c < DIM; ++c) acc[c * DIM + c] += s;
     if (!row_here) continue;
     const int64_t row_dof0 = int64_t(DIM) * S.un[a];
-    if (A.v_s) gadd<ATOMIC>(A.v_s + (base - A.v_uu - S.rs_uu[a] * (DIM * DIM)) + S.rs_uu[a], s);
+    if (A.v_s) gadd<ATOMIC>(A.v_s + S.rs_uu[a] + A.posUU[(cc * NU + a) * NU + b], s);
     for (int c = 0; c < DIM; ++c) {
       const bool rc = S.cf[a * DIM + c];
       for (int d = 0; d < DIM; ++d) {
         const bool ccn = S.cf[b * DIM + d];
         const double v = acc[c * DIM + d];
-        double *dst = base + int64_t(c * DIM + d) * len;
+        double *dst = base + int64_t(c * DIM + d) * uu_estride(len);
         if (!rc && !ccn) {
           if constexpr (ATOMIC) unsafeAtomicAdd(dst, v); else *dst = old[c * DIM + d] + v;
         } else if (rc) {

@@ -38,7 +38,7 @@ struct Cell2 {
   using G_ = Geo<DIM, KV>;
   static constexpr int NU = G_::NU, NP = G_::NP, NQ = G_::NQ, ND = G_::ND;
   static constexpr int TS = 6; // node-table stride in doubles: {N, g[3], u.g, pad} (16-byte aligned pairs)
-  static constexpr int NODAL = 3 * NU * DIM + NP, TAB = 2 * NU * TS;
+  static constexpr int NODAL = 3 * NU * DIM + NP, TAB = 2 * NU * TS, STAGE = 64 * DIM * DIM + 64; // scatter staging
   double X[NP * DIM];
   double C[8 * DIM]; // monomial coefficients of the d-linear map
   // per quadrature point, uniform over the lanes
@@ -47,7 +47,8 @@ struct Cell2 {
   double Vc[NQ * DIM * DIM];  // JxW (-mu grad u_c + e_c (p - gamma rho div u))   . grad N_a  -> rhs
   double Sc[NQ * DIM];        // JxW rho (-(grad u u)_c - (u - u0)_c / dt + g_c [+ a_c]) N_a   -> rhs
   double divw[NQ];            // JxW div u
-  double scratch[NODAL > TAB ? NODAL : TAB]; // nodal values (phase 1) | node tables tab[2][NU][TS] (passes)
+  static constexpr int SCR0 = NODAL > TAB ? NODAL : TAB;
+  double scratch[SCR0 > STAGE ? SCR0 : STAGE]; // nodal values (phase 1) | node tables tab[2][NU][TS] (passes) | scatter staging
   double fe[ND], cv[ND];
   int64_t rs_uu[NU], rs_bt[NU], rs_b[NP], rs_mp[NP];
   int32_t len_uu[NU], len_bt[NU], len_b[NP], len_mp[NP];
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
   constexpr int NPAIR = NU * NU, ROUNDS = (NPAIR + 63) / 64, RP = ROUNDS < RPMAX ? ROUNDS : RPMAX;
   constexpr int NPASS = (ROUNDS + RP - 1) / RP;
   constexpr int NBP = NU * NP, BROUNDS = (NBP + 63) / 64; // velocity-pressure pairs
+  constexpr int BS = DIM * DIM;
   constexpr int FR = (ND + 63) / 64;                      // rhs items per lane
   extern __shared__ __align__(16) unsigned char smem[];
   Shared2 &T = *reinterpret_cast<Shared2 *>(smem);
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
   };
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; ++pass) {
-    if (A.rhs_only && pass > 0) break;
+    if ((A.rhs_only && pass > 0) || A.debug_skip >= 5) break;
     const bool first = pass == 0;
     int oa[RP], ob[RP];
     bool pv[RP];
@@ -324,11 +326,11 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
       pbase[j] = nullptr;
       const int a = oa[j] / TS, b = ob[j] / TS;
       if (pv[j] && active && S.len_uu[a] >= 0) {
-        pbase[j] = A.v_uu + S.rs_uu[a] * (DIM * DIM) + A.posUU[(cc * NU + a) * NU + b];
+        pbase[j] = A.v_uu + uu_base(S.rs_uu[a], S.len_uu[a], A.posUU[(cc * NU + a) * NU + b], DIM * DIM);
         if constexpr (!ATOMIC) {
           const int len = S.len_uu[a];
 #pragma unroll
-          for (int e = 0; e < DIM * DIM; ++e) old[j][e] = pbase[j][int64_t(e) * len];
+          for (int e = 0; e < DIM * DIM; ++e) old[j][e] = pbase[j][int64_t(e) * uu_estride(len)];
         }
       }
     }
@@ -336,10 +338,14 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
 #pragma unroll
     for (int k = 0; k < FR; ++k) fr[k] = 0;
 
+    // software pipeline: the table of point q+1 is written (other LDS buffer) before point q is consumed, so its
+    // LDS round trip hides behind ~190 FMAs instead of stalling the wave at every point
+    double *tb_next = build_tab(0);
+    wsync2();
 #pragma unroll 1
     for (int q = 0; q < NQ; ++q) {
-      double *tb = build_tab(q);
-      wsync2();
+      double *tb = tb_next;
+      if (q + 1 < NQ) tb_next = build_tab(q + 1);
       const double w = S.JxW[q];
       const double wmu = w * A.mu, wrho = w * A.rho, wrdt = w * rdt, wg = w * wgam;
       double gqs[DIM * DIM];
@@ -378,9 +384,59 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
           }
         }
       }
+      wsync2(); // table q+1 complete before the next iteration reads it; table q free for q+2
     }
     wsync2();
     // ---- scatter the velocity-velocity pairs of this pass
+#if IFEM_UU_INTERLEAVED
+    // Block-interleaved A_uu: the BS values of a pair are contiguous in memory.  Every lane settles the constraint
+    // logic of its pair, parks the BS contributions in LDS, then the wave re-reads them flat, lane = (pair, entry): one
+    // atomic instruction covers ~7 pairs x 9 consecutive doubles (~12 segments) instead of 64 pairs in 64 segments.
+    {
+      double *stage = S.scratch;                                          // [64][BS]
+      int64_t *soff = reinterpret_cast<int64_t *>(S.scratch + 64 * BS);   // [64] element offset of the block, -1: none
+#pragma unroll
+      for (int j = 0; j < RP; ++j) {
+        const bool have = pbase[j] && !A.debug_skip && !A.rhs_only;
+        soff[lane] = have ? int64_t(pbase[j] - A.v_uu) : int64_t(-1);
+        if (have) {
+          const int a = oa[j] / TS, b = ob[j] / TS;
+          const int64_t row_dof0 = int64_t(DIM) * S.un[a];
+          if (A.v_s) gadd<ATOMIC>(A.v_s + S.rs_uu[a] + A.posUU[(cc * NU + a) * NU + b], sacc[j]);
+#pragma unroll
+          for (int c = 0; c < DIM; ++c) {
+            const bool rc = S.cf[a * DIM + c];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) {
+              const bool ccn = S.cf[b * DIM + d];
+              const double v = acc[j][c * DIM + d] + (c == d ? sacc[j] : 0.0);
+              double w = 0.0;
+              if (!rc && !ccn) w = v;
+              else if (rc) {
+                if (a == b && c == d) { // |Ke(r,r)| on the diagonal, rhs so that the update equals the inhomogeneity
+                  w = fabs(v);
+                  if (A.use_inhom) gadd<ATOMIC>(&A.rhs[row_dof0 + c], S.cv[a * DIM + c] * fabs(v));
+                }
+              } else if (A.use_inhom) {
+                const double g = S.cv[b * DIM + d];
+                if (g != 0.0) unsafeAtomicAdd(&S.fe[a * DIM + c], -v * g);
+              }
+              stage[lane * BS + c * DIM + d] = w;
+            }
+          }
+        }
+        wsync2();
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+          const int t = lane + 64 * r, pl = t / BS, e = t - pl * BS;
+          const int64_t off = soff[pl];
+          const double w = stage[t];
+          if (off >= 0 && w != 0.0) gadd<ATOMIC>(A.v_uu + off + e, w);
+        }
+        wsync2();
+      }
+    }
+#else
 #pragma unroll
     for (int j = 0; j < RP; ++j) {
       if (!pbase[j] || A.debug_skip || A.rhs_only) continue; // no pair in this slot, inactive cell or row owned by another rank
@@ -388,7 +444,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
       const int len = S.len_uu[a];
       double *base = pbase[j];
       const int64_t row_dof0 = int64_t(DIM) * S.un[a];
-      if (A.v_s) gadd<ATOMIC>(A.v_s + S.rs_uu[a] + (base - (A.v_uu + S.rs_uu[a] * (DIM * DIM))), sacc[j]);
+      if (A.v_s) gadd<ATOMIC>(A.v_s + S.rs_uu[a] + A.posUU[(cc * NU + a) * NU + b], sacc[j]);
 #pragma unroll
       for (int c = 0; c < DIM; ++c) {
         const bool rc = S.cf[a * DIM + c];
@@ -396,7 +452,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
         for (int d = 0; d < DIM; ++d) {
           const bool ccn = S.cf[b * DIM + d];
           const double v = acc[j][c * DIM + d] + (c == d ? sacc[j] : 0.0);
-          double *dst = base + int64_t(c * DIM + d) * len;
+          double *dst = base + int64_t(c * DIM + d) * uu_estride(len);
           if (!rc && !ccn) { if constexpr (ATOMIC) unsafeAtomicAdd(dst, v); else *dst = old[j][c * DIM + d] + v; }
           else if (rc) {
             if (a == b && c == d) { // |Ke(r,r)| on the diagonal, rhs so that the update equals the inhomogeneity
@@ -410,6 +466,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
         }
       }
     }
+#endif
     if (first) {
 #pragma unroll
       for (int k = 0; k < FR; ++k) {
@@ -419,16 +476,18 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
     }
     wsync2();
   }
-  if (!A.rhs_only) { // ---- velocity-pressure blocks: -JxW psi_b grad N_a, own pass over the points
+  if (!A.rhs_only && A.debug_skip < 3) { // ---- velocity-pressure blocks: -JxW psi_b grad N_a, own pass over the points
     double bacc[BROUNDS][DIM];
 #pragma unroll
     for (int k = 0; k < BROUNDS; ++k)
 #pragma unroll
       for (int c = 0; c < DIM; ++c) bacc[k][c] = 0;
+    double *tb_next = build_tab(0);
+    wsync2();
 #pragma unroll 1
     for (int q = 0; q < NQ; ++q) {
-      double *tb = build_tab(q);
-      wsync2();
+      double *tb = tb_next;
+      if (q + 1 < NQ) tb_next = build_tab(q + 1);
       const double w = S.JxW[q];
       {
 #pragma unroll
@@ -443,6 +502,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
           }
         }
       }
+      wsync2();
     }
     wsync2();
     if (active) { // block (0,1) = B^T and block (1,0) = B
@@ -476,7 +536,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
     wsync2();
   }
   // ---- pressure mass matrix M_p and diag(M_u)  (:274-276, only the (0,0) diagonal and (1,1) are used)
-  for (int t = lane; t < (A.rhs_only ? 0 : NP * NP); t += 64) {
+  for (int t = lane; t < ((A.rhs_only || A.debug_skip >= 4) ? 0 : NP * NP); t += 64) {
     const int pa = t / NP, pb = t - pa * NP;
     double m = 0;
 #pragma unroll 3
@@ -487,7 +547,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
     if (!ra && !cb) gadd<ATOMIC>(dst, m);
     else if (ra && pa == pb) gadd<ATOMIC>(dst, fabs(m));
   }
-  if (lane < NU && !A.rhs_only) {
+  if (lane < NU && !A.rhs_only && A.debug_skip < 4) {
     double m = 0;
 #pragma unroll 1
     for (int q = 0; q < NQ; ++q) {

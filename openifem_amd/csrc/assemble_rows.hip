@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64 * WPB) void k_rows_u(RowArgs A) {
         if (rc[c]) { out = (J == I && c == d) ? fabs(v) : 0.0; if (J == I && c == d) dg[c] = fabs(v); }
         else if (cc_[d]) { out = 0.0; if (A.use_inhom) corr[c] -= v * cg[d]; }
         else out = v;
-        A.v_uu[rs * DD + int64_t(c * DIM + d) * len + k] = out;
+        A.v_uu[uu_base(rs, len, k, DD) + int64_t(c * DIM + d) * uu_estride(len)] = out;
       }
     if (A.v_s) A.v_s[rs + k] = sbuf[k];
   }

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64 * WPB) void k_scns_assemble(ScnsArgs A) {
     const int rlen = iu ? (ju ? S.len_uu[ai] : S.len_bt[ai]) : (ju ? S.len_b[ai] : S.len_pp[ai]);
     if (rlen < 0) continue; // row owned elsewhere
     double *dst;
-    if (iu && ju) dst = A.v_uu + S.rs_uu[ai] * (DIM * DIM) + int64_t(ci * DIM + cjj) * rlen + A.posUU[(cc * NU + ai) * NU + aj];
+    if (iu && ju) dst = A.v_uu + uu_base(S.rs_uu[ai], rlen, A.posUU[(cc * NU + ai) * NU + aj], DIM * DIM) + int64_t(ci * DIM + cjj) * uu_estride(rlen);
     else if (iu) dst = A.v_bt + S.rs_bt[ai] * DIM + int64_t(ci) * rlen + A.posUP[(cc * NU + ai) * NP + aj];
     else if (ju) dst = A.v_b + S.rs_b[ai] * DIM + int64_t(cjj) * rlen + A.posPU[(cc * NP + ai) * NU + aj];
     else dst = A.v_pp + S.rs_pp[ai] + A.posPP[(cc * NP + ai) * NP + aj];

@@ -58,6 +58,31 @@ struct DBuf { // owning device buffer
 // Row-planar block-CSR: row r owns blocks [rowptr[r], rowptr[r+1]); entry e (of BS per block) of the k-th
 // block of the row lives at val[BS*rowptr[r] + e*len_r + k].  Consecutive lanes (k) read consecutive
 // doubles for every e: fully coalesced without LDS staging.  BS = dim*dim (A_uu), dim (B, B^T) or 1.
+// Value layout of A_uu (bs = dim*dim entries per block).  Block-interleaved: the bs entries of a block are contiguous,
+// so the assembly scatters one node pair into one or two 64-byte segments (the f64 atomic unit retires ~24 G segments/s
+// whatever the number of lanes that hit a segment) instead of into bs planes.  B, B^T, M_p, S_m stay row-planar
+// (entry e of the k-th block of a row at val[bs*rowptr + e*len + k]).  IFEM_UU_INTERLEAVED=0 restores the planar A_uu.
+#ifndef IFEM_UU_INTERLEAVED
+#define IFEM_UU_INTERLEAVED 1
+#endif
+__host__ __device__ inline int64_t uu_base(int64_t rs, int64_t len, int64_t k, int bs) { // offset of entry 0 of block k
+#if IFEM_UU_INTERLEAVED
+  (void)len;
+  return (rs + k) * bs;
+#else
+  (void)len;
+  return rs * bs + k;
+#endif
+}
+__host__ __device__ inline int64_t uu_estride(int64_t len) { // distance between consecutive entries of one block
+#if IFEM_UU_INTERLEAVED
+  (void)len;
+  return 1;
+#else
+  return len;
+#endif
+}
+
 struct PlanarCsr {
   int64_t n_rows = 0, nnzb = 0;
   int bs = 1, max_row = 0;

@@ -30,6 +30,28 @@ __device__ inline void row_planar_dot(const int64_t rs, const int len, const int
   }
 }
 
+// A_uu block row in the block-interleaved layout: lane k reads the BR*BC entries of its block back to back (the lanes of
+// a group together cover one contiguous span of the row)
+template <int BR, int BC, int G, class VT>
+__device__ inline void row_interleaved_dot(const int64_t rs, const int len, const int32_t *__restrict__ col,
+                                           const VT *__restrict__ val, const double *__restrict__ x, const int lig,
+                                           double *acc) {
+  for (int k = lig; k < len; k += G) {
+    const int32_t c = col[rs + k];
+    const VT *b = val + (rs + k) * (BR * BC);
+    VT bv[BR * BC];
+#pragma unroll
+    for (int e = 0; e < BR * BC; ++e) bv[e] = b[e];
+    double xv[BC];
+#pragma unroll
+    for (int j = 0; j < BC; ++j) xv[j] = x[int64_t(c) * BC + j];
+#pragma unroll
+    for (int r = 0; r < BR; ++r)
+#pragma unroll
+      for (int j = 0; j < BC; ++j) acc[r] += double(bv[r * BC + j]) * xv[j];
+  }
+}
+
 template <int G>
 __device__ inline double group_sum(double v) {
 #pragma unroll
@@ -53,7 +75,11 @@ __global__ __launch_bounds__(256) void k_spmv_uu(int64_t n_rows, const int64_t *
   {
     const int64_t rs = rp_a[row];
     const int len = int(rp_a[row + 1] - rs);
+#if IFEM_UU_INTERLEAVED
+    row_interleaved_dot<DIM, DIM, G, VT>(rs, len, col_a, val_a, xu, lig, acc);
+#else
     row_planar_dot<DIM, DIM, G, true, VT>(rs, len, col_a, val_a, xu, lig, acc);
+#endif
   }
   if (xp) {
     const int64_t rs = rp_t[row];
@@ -749,7 +775,7 @@ __global__ void k_bjac_setup(int64_t n_rows, const int64_t *__restrict__ rp, con
     if (v < row) lo = mid + 1; else hi = mid - 1;
   }
   double D[DIM * DIM], Di[DIM * DIM];
-  for (int e = 0; e < DIM * DIM; ++e) D[e] = (pos >= 0) ? val[rs * DIM * DIM + int64_t(e) * len + pos] : ((e / DIM == e % DIM) ? 1.0 : 0.0);
+  for (int e = 0; e < DIM * DIM; ++e) D[e] = (pos >= 0) ? val[uu_base(rs, len, pos, DIM * DIM) + int64_t(e) * uu_estride(len)] : ((e / DIM == e % DIM) ? 1.0 : 0.0);
   if constexpr (DIM == 2) {
     const double r = 1.0 / (D[0] * D[3] - D[1] * D[2]);
     Di[0] = D[3] * r; Di[1] = -D[1] * r; Di[2] = -D[2] * r; Di[3] = D[0] * r;
