@@ -447,7 +447,14 @@ void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp, bool use_f32) {
     hipLaunchKernelGGL(k_to_f32, dim3(8192), dim3(256), 0, ctx->stream, nv, ctx->Sm.val.p, ctx->Sm_f32.p);
     ctx->sm_f32_valid = true;
   }
-  if (use_f32)
+  static const int Gs = [] { const char *e = getenv("IFEM_SM_G"); return e ? atoi(e) : 32; }();
+  if (use_f32 && Gs == 64)
+    hipLaunchKernelGGL((k_spmv_planar<1, 1, 64, float>), dim3(blocks_for_rows(n, 64)), dim3(256), 0, ctx->stream, n,
+                       ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm_f32.p, xp, yp);
+  else if (use_f32 && Gs == 16)
+    hipLaunchKernelGGL((k_spmv_planar<1, 1, 16, float>), dim3(blocks_for_rows(n, 16)), dim3(256), 0, ctx->stream, n,
+                       ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm_f32.p, xp, yp);
+  else if (use_f32)
     hipLaunchKernelGGL((k_spmv_planar<1, 1, 32, float>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n,
                        ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm_f32.p, xp, yp);
   else
