@@ -549,18 +549,24 @@ template <int DIM>
 __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc,
                             const double *__restrict__ ycell, const uint8_t *__restrict__ is_c,
                             const double *__restrict__ bjac, const double *__restrict__ x, double *__restrict__ y) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t nd = i / DIM;
-  const int c = int(i - nd * DIM);
-  if (is_c && is_c[i]) { y[i] = x[i] / bjac[nd * DIM * DIM + c * DIM + c]; return; }
-  double s = 0;
+  // one thread per node: the incidence list is walked once for the DIM components (24 contiguous bytes per entry)
+  const int64_t nd = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (nd * DIM >= n) return;
+  double s[DIM];
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) s[c] = 0;
   const int64_t k1 = inc_ptr[nd + 1];
   for (int64_t k = inc_ptr[nd]; k < k1; ++k) {
     const int32_t e = inc[k];
-    s += ycell[int64_t(e >> 5) * (DIM * nn) + (e & 31) * DIM + c];
+    const double *src = ycell + int64_t(e >> 5) * (DIM * nn) + (e & 31) * DIM;
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) s[c] += src[c];
   }
-  y[i] = s;
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) {
+    const int64_t i = nd * DIM + c;
+    y[i] = (is_c && is_c[i]) ? x[i] / bjac[nd * DIM * DIM + c * DIM + c] : s[c];
+  }
 }
 
 static void mf_tables(MfTables &t, int kv) {
@@ -641,10 +647,10 @@ void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu) {
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
   if (two_stage) {
     if (ctx->dim == 3)
-      hipLaunchKernelGGL((k_mf_gather<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
+      hipLaunchKernelGGL((k_mf_gather<3>), dim3(unsigned((n / 3 + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
                          ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu);
     else
-      hipLaunchKernelGGL((k_mf_gather<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
+      hipLaunchKernelGGL((k_mf_gather<2>), dim3(unsigned((n / 2 + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
                          ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu);
   } else
   if (a.is_c) {
