@@ -137,6 +137,30 @@ int ifemx_update_stress(void *hv, double *out) {
   });
 }
 
+// FluidSolver::output_results(index) into directory `dir` (must end with '/')
+int ifemx_output_results(void *hv, const char *dir, unsigned index) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) { h->s2->output_dir = dir; h->s2->output_results(index); }
+    else { h->s3->output_dir = dir; h->s3->output_results(index); }
+  });
+}
+// the .vtu writer on host data only (no device): solution [n_dofs], optional fsi_acc [n_dofs], stress [dim][dim][n_unodes]
+int ifemx_write_vtu(void *hv, const char *filename, const double *solution, const double *fsi_acc, const double *stress, int subdomain) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto run = [&](auto &s, auto dimtag) {
+      constexpr int D = decltype(dimtag)::value;
+      auto &d = s.dof_tables();
+      std::vector<double> sol(solution, solution + d.n_dofs()), acc, st;
+      if (fsi_acc) acc.assign(fsi_acc, fsi_acc + d.n_dofs());
+      if (stress) st.assign(stress, stress + (size_t)D * D * d.n_unodes);
+      Fluid::MPI::write_vtu_piece<D>(filename, d, sol, acc, st, {}, subdomain, nullptr);
+    };
+    if (h->dim == 2) run(*h->s2, std::integral_constant<int, 2>()); else run(*h->s3, std::integral_constant<int, 3>());
+  });
+}
+
 void ifemx_destroy(void *hv) { delete static_cast<Handle *>(hv); }
 
 // rank `rank` of a P[0] x P[1] x P[2] block partition; call before ifemx_setup.  Transport: nccl_unique_id (128 B)

@@ -199,6 +199,7 @@ std::pair<unsigned int, double> InsIM<dim>::solve(const bool use_nonzero_constra
 template <int dim>
 void InsIM<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_system) {
   static_cast<void>(assemble_system);
+  if (this->output_enabled && time.get_timestep() == 0) this->output_results(0);
   time.increment();
   if (this->pcout)
     *this->pcout << std::string(96, '*') << std::endl
@@ -226,7 +227,8 @@ void InsIM<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_syst
   check(ifem_vec_copy(ctx, IFEM_VEC_INCREMENT, IFEM_VEC_PRESENT), "run_one_step");
   check(ifem_vec_axpy(ctx, -1.0, IFEM_VEC_EVAL, IFEM_VEC_INCREMENT), "run_one_step");
   check(ifem_vec_copy(ctx, IFEM_VEC_PRESENT, IFEM_VEC_EVAL), "run_one_step");
-  // update_stress / save_checkpoint / output_results / refine_mesh: host plumbing, out of scope
+  if (this->output_enabled && time.time_to_output()) this->output_results(time.get_timestep()); // (:479-482)
+  // save_checkpoint / refine_mesh: outside the path
 }
 
 template <int dim>
@@ -294,6 +296,7 @@ void InsIMEX<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_sy
     *this->pcout << std::scientific << std::left << " GMRES_ITR = " << std::setw(3) << state.first
                  << " GMRES_RES = " << state.second << std::endl;
   check(ifem_update_stress(ctx, parameters.viscosity, nullptr), "update_stress");
+  if (this->output_enabled && time.time_to_output()) this->output_results(time.get_timestep());
 }
 
 template <int dim>

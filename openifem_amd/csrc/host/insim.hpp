@@ -40,10 +40,26 @@ private:
   double time_current, time_end, delta_t;
   const double output_interval, refinement_interval, save_interval;
 };
+// Utils::PVDWriter (include/utilities.h, source/utilities.cpp:38-81): the .pvd collection of the written time steps
+class PVDWriter {
+public:
+  PVDWriter(const Time &t, const std::string &filename = "solution.pvd");
+  void write_current_timestep(const std::string &pvtu_prefix, unsigned n_digits_for_counter);
+
+private:
+  const Time *time;
+  std::string name, entries;
+};
 } // namespace Utils
 
 namespace Fluid {
 namespace MPI {
+
+// one .vtu piece (linear patch per cell, the reference's field names); free function so that it is testable without a device
+template <int dim>
+void write_vtu_piece(const std::string &filename, const DoFTables<dim> &dofs, const std::vector<double> &solution,
+                     const std::vector<double> &fsi_acc, const std::vector<double> &stress, const std::vector<int32_t> &indicator,
+                     int subdomain, std::vector<std::string> *names_out);
 
 struct SolverFailure : std::runtime_error {
   int code;
@@ -65,6 +81,10 @@ public:
   void set_sigma_pml_field(const std::function<double(const Point &, const unsigned int)> &);
   // projected nodal viscous stress [dim][dim][n_unodes] of the present solution (mpi_fluid_solver.cpp:716-811)
   std::vector<double> update_stress();
+  // FluidSolver::output_results (mpi_fluid_solver.cpp:491-579): fluid_<index>.<rank>.vtu (+ .pvtu and fluid.pvd on rank 0)
+  void output_results(const unsigned int output_index);
+  std::string output_dir = "./";
+  bool output_enabled = false; // run_one_step writes results at step 0 and whenever time.time_to_output() (off by default)
   // block vector [velocity | pressure] (PETScWrappers::MPI::BlockVector get_current_solution())
   std::vector<double> get_current_solution() const;
   std::pair<size_t, size_t> dofs_per_block_sizes() const { return {(size_t)dofs.n_u(), (size_t)dofs.n_pnodes}; }
@@ -98,6 +118,7 @@ protected:
   // (mpi_insim.cpp:493-519), advanced by dt before every step of SUPGFluidSolver::run (mpi_supg_solver.cpp:438-480)
   double field_time = 0.0;
   Utils::Time time;
+  std::unique_ptr<Utils::PVDWriter> pvd_writer;
   ifem_ctx *ctx = nullptr;
   int device;
   std::vector<int32_t> constraint_dofs;

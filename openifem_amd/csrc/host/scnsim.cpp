@@ -86,6 +86,7 @@ void SUPGFluidSolver<dim>::run_one_step(bool apply_nonzero_constraints, bool ass
   // update_stress feeds the next assemble (mpi_scnsim.cpp:178-186); output / checkpoint / refinement are host
   // plumbing outside the path
   check(ifem_update_stress(ctx, parameters.viscosity, nullptr), "update_stress");
+  if (this->output_enabled && time.time_to_output()) this->output_results(time.get_timestep()); // (:413-416)
 }
 
 template <int dim>

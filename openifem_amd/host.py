@@ -29,6 +29,8 @@ def _lib():
     for f in (L.ifemx_set_body_force, L.ifemx_set_sigma_pml_field, L.ifemx_set_initial_condition):
         f.argtypes = [C.c_void_p, FIELD_FN]
     L.ifemx_update_stress.argtypes = [C.c_void_p, C.c_void_p]
+    L.ifemx_output_results.argtypes = [C.c_void_p, C.c_char_p, C.c_uint]
+    L.ifemx_write_vtu.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.ifemx_destroy.argtypes = [C.c_void_p]
     L.ifemx_insim_create_cylinder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.ifemx_add_hard_coded_boundary_condition.argtypes = [C.c_void_p, C.c_int, BC_FN]
@@ -122,6 +124,19 @@ class FluidSolver:
         out = np.zeros((self.dim, self.dim, n_u // self.dim))
         self._chk(self.L.ifemx_update_stress(self.h, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def output_results(self, directory, index):
+        """FluidSolver::output_results: fluid_<index>.<rank>.vtu (+ .pvtu, fluid.pvd) into `directory`"""
+        d = directory if directory.endswith("/") else directory + "/"
+        self._chk(self.L.ifemx_output_results(self.h, d.encode(), index))
+
+    def write_vtu(self, filename, solution, fsi_acc=None, stress=None, subdomain=0):
+        sol = np.ascontiguousarray(solution, float)
+        acc = None if fsi_acc is None else np.ascontiguousarray(fsi_acc, float)
+        st = None if stress is None else np.ascontiguousarray(stress, float)
+        self._chk(self.L.ifemx_write_vtu(self.h, filename.encode(), sol.ctypes.data_as(C.c_void_p),
+                                         None if acc is None else acc.ctypes.data_as(C.c_void_p),
+                                         None if st is None else st.ctypes.data_as(C.c_void_p), subdomain))
 
     def set_partition(self, P, rank, nccl_unique_id=None, local_world=None):
         """rank `rank` of a P[0] x P[1] x P[2] block partition; call before setup()."""

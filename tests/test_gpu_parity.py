@@ -344,3 +344,27 @@ def test_reference_driver_fluid_cylinder_mpi_through_host_mirror():
     v, p = flow.get_current_solution()
     assert abs(v.max() - 0.374235) / 0.374235 < 1e-3
     assert abs(p.max() - 46.5226) / 46.5226 < 1e-3
+
+
+def test_output_results_writes_vtu_pvtu_pvd(tmp_path):
+    # FluidSolver::output_results / Utils::PVDWriter through the host mirror after one step on the GPU
+    import xml.etree.ElementTree as ET
+    from openifem_amd import host
+    s = host.InsIM(host.channel_prm(3), (4, 4, 4), (0, 0, 0), (2.0, 0.2, 0.2))
+    s.setup(0)
+    s.run_one_step(True)
+    d = str(tmp_path)
+    s.output_results(d, 1)
+    root = ET.parse(d + "/fluid_000001.0.vtu").getroot()
+    piece = root.find("UnstructuredGrid/Piece")
+    assert int(piece.get("NumberOfCells")) == 64
+    arrays = {a.get("Name"): a for a in piece.find("PointData")}
+    v, p = s.get_current_solution()
+    vel = np.array(arrays["velocity"].text.split(), float).reshape(-1, 3)
+    assert abs(vel.max() - v.max()) < 1e-10 * max(1.0, abs(v.max()))
+    txy = np.array(arrays["Txy"].text.split(), float)
+    assert np.abs(txy).max() > 0  # the projected viscous stress of a Poiseuille-like start-up flow
+    pv = ET.parse(d + "/fluid_000001.pvtu").getroot()
+    assert [x.get("Source") for x in pv.iter("Piece")] == ["fluid_000001.0.vtu"]
+    pvd = ET.parse(d + "/fluid.pvd").getroot()
+    assert [x.get("file") for x in pvd.iter("DataSet")] == ["fluid_000001.pvtu"]

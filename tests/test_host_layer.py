@@ -176,3 +176,36 @@ def test_scnsim_host_mirror_setup_and_errors():
         class Bad(host.FluidSolver):
             KIND = "Stokes"
         Bad(host.channel_prm(2), (2, 2), (0, 0), (1, 1))
+
+
+def test_vtu_writer_matches_reference_field_layout(tmp_path):
+    # FluidSolver::output_results (mpi_fluid_solver.cpp:491-579): one linear patch per cell, the reference's field names;
+    # written from host data only, parsed back with the standard library
+    import xml.etree.ElementTree as ET
+    from openifem_amd import host
+    s = host.InsIM(host.channel_prm(3), (3, 2, 2), (0, 0, 0), (2.0, 0.2, 0.2))
+    s.set_node_order(False)
+    s.setup_host_only(0)
+    n_cells, n_u, n_p = s.sizes()
+    uc, pc = s.node_coords()
+    sol = np.concatenate([(uc * np.array([1.0, 2.0, 3.0])).ravel(), 10.0 * pc[:, 0]])  # u = (x, 2y, 3z), p = 10 x
+    stress = np.arange(9 * (n_u // 3), dtype=float).reshape(3, 3, -1)
+    f = str(tmp_path / "fluid_000001.0.vtu")
+    s.write_vtu(f, sol, stress=stress, subdomain=5)
+    root = ET.parse(f).getroot()
+    piece = root.find("UnstructuredGrid/Piece")
+    assert int(piece.get("NumberOfCells")) == n_cells and int(piece.get("NumberOfPoints")) == 8 * n_cells
+    pts = np.array(piece.find("Points/DataArray").text.split(), float).reshape(-1, 3)
+    arrays = {a.get("Name"): a for a in piece.find("PointData")}
+    assert list(arrays) == ["velocity", "pressure", "fsi_force", "dummy_fsi_force", "subdomain", "Indicator", "Txx", "Txy",
+                            "Tyy", "Txz", "Tyz", "Tzz"]
+    vel = np.array(arrays["velocity"].text.split(), float).reshape(-1, 3)
+    prs = np.array(arrays["pressure"].text.split(), float)
+    assert np.abs(vel - pts * np.array([1.0, 2.0, 3.0])).max() < 1e-11
+    assert np.abs(prs - 10.0 * pts[:, 0]).max() < 1e-11
+    assert set(np.array(arrays["subdomain"].text.split(), float)) == {5.0}
+    types = np.array(piece.find("Cells/DataArray[@Name='types']").text.split(), int)
+    assert set(types) == {12}
+    # VTK hexahedron vertex order: the first patch is a right-handed box
+    p = pts[:8]
+    assert np.dot(np.cross(p[1] - p[0], p[3] - p[0]), p[4] - p[0]) > 0
