@@ -73,8 +73,8 @@ int ifem_ctx_create(const ifem_mesh_desc *m, const ifem_partition *part, int dev
   ctx->scal.alloc(256);
   if (const char *e = getenv("IFEM_ASM")) ctx->asm_rows = std::string(e) == "rows";
   { // greedy cell colouring on the vertices (two cells share a node iff they share a vertex)
-    const char *e = getenv("IFEM_ASM");
-    if (!(e && std::string(e) == "atomic")) {
+    const char *e = getenv("IFEM_ASM_SCATTER"); // only the opt-in read-modify-write scatter needs the colouring
+    if (e && std::string(e) == "rmw") {
       std::vector<uint64_t> used((size_t)ctx->nPl, 0);
       std::vector<uint8_t> col((size_t)m->n_cells);
       int ncol = 0;

@@ -34,7 +34,7 @@ struct MfArgs {
   const double *x;     // ghost-extended input
   double *y;           // owned rows, zeroed by the caller
   double mu, rho, gamma, inv_dt;
-  int mode;
+  int mode, xcd;
   double *ycell;
   MfTables t;
 };
@@ -315,8 +315,12 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
     xi[d] = x_; wq *= w_;
   }
 
+  // every block owns one contiguous range of cell pairs (XCD-aware: neighbouring ranges run on the same XCD)
   const int64_t n_pairs = (A.n_cells + 1) / 2;
-  for (int64_t pair = int64_t(blockIdx.x) * WPB + wave; pair < n_pairs; pair += int64_t(gridDim.x) * WPB) {
+  const int64_t per_block = (n_pairs + gridDim.x - 1) / gridDim.x;
+  const int64_t vb = A.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int64_t p_end = (vb + 1) * per_block < n_pairs ? (vb + 1) * per_block : n_pairs;
+  for (int64_t pair = vb * per_block + wave; pair < p_end; pair += WPB) {
     const int64_t cell = 2 * pair + half;
     const bool active = cell < A.n_cells;
     const int64_t cc = active ? cell : 0;
@@ -611,6 +615,7 @@ void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu) {
   a.inv_dt = 1.0 / ctx->mf_params.dt;
   mf_tables(a.t, ctx->kv);
   { const char *e = getenv("IFEM_MF_MODE"); a.mode = e ? atoi(e) : 0; }
+  { static const int xcd = [] { const char *e = getenv("IFEM_XCD"); return e ? atoi(e) : 1; }(); a.xcd = xcd; }
   a.ycell = nullptr;
   if (a.mode == 3) {
     const size_t need = size_t(ctx->n_cells) * ctx->dim * ctx->nu;

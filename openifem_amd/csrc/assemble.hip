@@ -399,6 +399,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   A.cval = ctx->has_c[w] ? ctx->cval[w].p : nullptr;
   A.use_inhom = (use_nonzero && ctx->has_c[1]) ? 1 : 0;
   { const char *e = getenv("IFEM_ASM_SKIP"); A.debug_skip = e ? atoi(e) : 0; }
+  { const char *e = getenv("IFEM_XCD"); A.xcd_swizzle = e ? atoi(e) : 1; }
   A.eval = ctx->vec[imex ? IFEM_VEC_PRESENT : IFEM_VEC_EVAL].p; A.present = ctx->vec[IFEM_VEC_PRESENT].p;
   A.imex = imex; A.rhs_only = assemble_system ? 0 : 1;
   A.fsi_acc = ctx->indicator.p ? ctx->vec[IFEM_VEC_FSI_ACC].p : nullptr;

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
   }
   __syncthreads();
 
-  const int64_t idx = int64_t(blockIdx.x) * WPB + wave;
+  const int64_t idx = int64_t(A.xcd_swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * WPB + wave;
   const bool active = idx < A.count;
   const int64_t cc = active ? (A.order ? int64_t(A.order[A.first + idx]) : idx) : 0;
   const int64_t p_off = int64_t(DIM) * A.nUl;

@@ -39,6 +39,7 @@ struct AsmArgs {
   int use_inhom; // constraint set carries non-zero inhomogeneities
   int imex;     // InsIMEX (mpi_insimex.cpp:248-262): the matrix drops the two convective terms (explicit convection)
   int rhs_only; // InsIMEX with assemble_system = false: only the right-hand side is integrated and scattered (:343-346)
+  int xcd_swizzle; // contiguous cell ranges per XCD (IFEM_XCD=0 switches it off)
   int debug_skip; // measurement aid (IFEM_ASM_SKIP): 1 = skip the A_uu scatter, 2 = skip the pair contraction too
 };
 

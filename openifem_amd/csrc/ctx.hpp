@@ -58,6 +58,15 @@ struct DBuf { // owning device buffer
 // Row-planar block-CSR: row r owns blocks [rowptr[r], rowptr[r+1]); entry e (of BS per block) of the k-th
 // block of the row lives at val[BS*rowptr[r] + e*len_r + k].  Consecutive lanes (k) read consecutive
 // doubles for every e: fully coalesced without LDS staging.  BS = dim*dim (A_uu), dim (B, B^T) or 1.
+// XCD-aware block index: MI355X dispatches block b to XCD b % 8 (observed, not a contract -- only speed depends on it);
+// the remap hands every XCD one contiguous range of the Morton-ordered cells, so the nodes shared by neighbouring cells
+// are fetched into ONE private L2 instead of eight.  Bijective for any grid size.
+__device__ inline unsigned xcd_swizzle(unsigned bid, unsigned nwg) {
+  constexpr unsigned NX = 8;
+  const unsigned q = nwg / NX, r = nwg % NX, xcd = bid % NX, k = bid / NX;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // Value layout of A_uu (bs = dim*dim entries per block).  Block-interleaved: the bs entries of a block are contiguous,
 // so the assembly scatters one node pair into one or two 64-byte segments (the f64 atomic unit retires ~24 G segments/s
 // whatever the number of lanes that hit a segment) instead of into bs planes.  B, B^T, M_p, S_m stay row-planar
