@@ -347,6 +347,7 @@ static void launch_t(ifem_ctx *ctx, const AsmArgs &A) {
 
 static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero);
 void launch_ins_assemble2_kernel(ifem_ctx *ctx, const AsmArgs &A);
+bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A);
 
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) { launch_ins_assemble_ex(ctx, p, use_nonzero, 0, 1); }
 
@@ -409,7 +410,9 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   for (int i = 0; i < 8; ++i) { A.neumann_id[i] = p->neumann_id[i]; A.neumann_p[i] = p->neumann_p[i]; }
   IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s));
   static const bool v1 = [] { const char *e = getenv("IFEM_ASM"); return e && std::string(e) == "v1"; }();
-  if (!v1) launch_ins_assemble2_kernel(ctx, A); // assemble2.hip (quadrature-point-outer, register accumulators)
+  static const bool v2 = [] { const char *e = getenv("IFEM_ASM"); return e && std::string(e) == "v2"; }();
+  if (!v1 && !v2 && launch_ins_assemble3_kernel(ctx, A)) {} // assemble3.hip: 3D Q2/Q1 on the FP64 matrix cores
+  else if (!v1) launch_ins_assemble2_kernel(ctx, A);           // assemble2.hip (quadrature-point-outer, register accumulators)
   else if (dim == 2 && ctx->kv == 1) launch_t<2, 1>(ctx, A);
   else if (dim == 2 && ctx->kv == 2) launch_t<2, 2>(ctx, A);
   else if (dim == 3 && ctx->kv == 1) launch_t<3, 1>(ctx, A);

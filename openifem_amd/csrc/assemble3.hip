@@ -1,0 +1,453 @@
+// assemble3.hip -- InsIM::assemble for the 3D Q2/Q1 element on the FP64 matrix cores (reference:
+// source/mpi_insim.cpp:153-362; same mathematics, scatter and constraint handling as assemble2.hip).
+//
+// The velocity-velocity block of the element matrix is a sum over the 27 quadrature points of outer products,
+//   Ke[(a,c),(b,d)] = sum_q  (wg ga_c)(q,a) gb_d(q,b)  +  (N_a rho w d_d u_c)(q) N_b(q)           (grad-div, Newton term)
+//                 + d_cd sum_q [ sum_e (w mu ga_e) gb_e + (w rho N_a)(u.gb) + (w rho/dt N_a) N_b ]  (scalar part),
+// i.e. for every (c,d) a 27x27 GEMM with K = 54 (+ a shared 27x27 GEMM with K = 135).  One wavefront per cell runs them
+// as v_mfma_f64_16x16x4 on 2x2 tiles of 16x16 (27 padded to 32, K padded to 28): 644 MFMAs per cell.  FP64 MFMA has the
+// same peak as the vector FMA on MI355X -- the point is the instruction stream: an MFMA retires 2048 flops for two
+// 8-byte operands per lane, where the vector path of assemble2.hip issues ~47 instructions per 58 flops.
+// The operands come from per-cell LDS tables tabN[q][a], tabG[d][q][a] (23 KB), built once per cell; rhs, B/B^T, M_p
+// read the same tables.  Accumulator layout of the instruction (tools/microbench.hip): lane l supplies
+// A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15], register r of the result is D[(l>>4) + 4r][l&15].
+#include <hip/hip_runtime.h>
+#include "kernels.hpp"
+#include "assemble_common.hpp"
+
+namespace ifem {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct Cell3 {
+  static constexpr int DIM = 3, NU = 27, NP = 8, NQ = 27, ND = 89, BS = 9;
+  static constexpr int NODAL = 3 * NU * DIM + NP, STAGE = 64 * BS + 64;
+  double tabG[DIM][NQ][NU]; // physical shape gradients
+  double tabN[NQ][NU];      // shape values
+  double X[NP * DIM], C[8 * DIM];
+  double Ji[NQ * 9], JxW[NQ], uq[NQ * DIM];
+  double gqs[NQ * 9]; // rho JxW grad u
+  double Vc[NQ * 9], Sc[NQ * DIM], divw[NQ];
+  double scratch[STAGE > NODAL ? STAGE : NODAL]; // nodal values (phase 1) | scatter staging
+  double fe[ND], cv[ND];
+  int64_t rs_uu[NU], rs_bt[NU], rs_b[NP], rs_mp[NP];
+  int32_t len_uu[NU], len_bt[NU], len_b[NP], len_mp[NP];
+  int32_t un[NU], pn[NP];
+  uint8_t cf[ND + 7];
+};
+
+struct Shared3 {
+  Tab1D t;
+  double psi[27 * 8];
+};
+
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1) {
+  constexpr int DIM = 3, N1 = 3, NU = 27, NP = 8, NQ = 27, ND = 89, BS = 9;
+  constexpr int NBP = NU * NP, BROUNDS = (NBP + 63) / 64, FR = (ND + 63) / 64;
+  extern __shared__ __align__(16) unsigned char smem[];
+  Shared3 &T = *reinterpret_cast<Shared3 *>(smem);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  Cell3 &S = *reinterpret_cast<Cell3 *>(smem + ((sizeof(Shared3) + 15) & ~size_t(15)) + size_t(wave) * ((sizeof(Cell3) + 15) & ~size_t(15)));
+  if (threadIdx.x < 9) { T.t.N[threadIdx.x] = t1.N[threadIdx.x]; T.t.dN[threadIdx.x] = t1.dN[threadIdx.x]; }
+  if (threadIdx.x < 3) { T.t.xi[threadIdx.x] = t1.xi[threadIdx.x]; T.t.w[threadIdx.x] = t1.w[threadIdx.x]; }
+  for (int i = threadIdx.x; i < NQ * NP; i += blockDim.x) {
+    const int q = i / NP, b = i - q * NP;
+    double v = 1;
+    for (int d = 0; d < DIM; ++d) {
+      const int qd = d == 0 ? q % N1 : (d == 1 ? (q / N1) % N1 : q / (N1 * N1));
+      const double x = t1.xi[0] * (qd == 0) + t1.xi[1] * (qd == 1) + t1.xi[2] * (qd == 2);
+      v *= ((b >> d) & 1) ? x : 1.0 - x;
+    }
+    T.psi[i] = v;
+  }
+  __syncthreads();
+
+  const int64_t idx = int64_t(A.xcd_swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * WPB + wave;
+  const bool active = idx < A.count;
+  const int64_t cc = active ? (A.order ? int64_t(A.order[A.first + idx]) : idx) : 0;
+  const int64_t p_off = int64_t(DIM) * A.nUl;
+  double *ue = S.scratch, *u0e = S.scratch + NU * DIM, *ae = S.scratch + 2 * NU * DIM, *pe = S.scratch + 3 * NU * DIM;
+
+  // ---- phase 0: ids, coordinates, nodal values, row descriptors, constraint flags
+  for (int i = lane; i < NP * DIM; i += 64) S.X[i] = A.vcoords[cc * NP * DIM + i];
+  if (lane < NU) {
+    const int a = lane;
+    const int32_t nd = A.cell_unodes[cc * NU + a];
+    S.un[a] = nd;
+    const bool own = nd < A.nUo;
+    const int64_t r0 = own ? A.rp_uu[nd] : 0, r1 = own ? A.rp_uu[nd + 1] : 0;
+    S.rs_uu[a] = r0; S.len_uu[a] = own ? int32_t(r1 - r0) : -1;
+    const int64_t t0 = own ? A.rp_bt[nd] : 0, t1_ = own ? A.rp_bt[nd + 1] : 0;
+    S.rs_bt[a] = t0; S.len_bt[a] = own ? int32_t(t1_ - t0) : -1;
+    for (int c = 0; c < DIM; ++c) {
+      const int64_t dof = int64_t(DIM) * nd + c;
+      ue[a * DIM + c] = A.eval[dof];
+      u0e[a * DIM + c] = A.present[dof];
+      ae[a * DIM + c] = A.fsi_acc ? A.fsi_acc[dof] : 0.0;
+      S.cf[a * DIM + c] = A.is_c ? A.is_c[dof] : 0;
+      S.cv[a * DIM + c] = A.cval ? A.cval[dof] : 0.0;
+    }
+  }
+  if (lane < NP) {
+    const int b = lane;
+    const int32_t nd = A.cell_pnodes[cc * NP + b];
+    S.pn[b] = nd;
+    const bool own = nd < A.nPo;
+    const int64_t r0 = own ? A.rp_b[nd] : 0, r1 = own ? A.rp_b[nd + 1] : 0;
+    S.rs_b[b] = r0; S.len_b[b] = own ? int32_t(r1 - r0) : -1;
+    const int64_t m0 = own ? A.rp_mp[nd] : 0, m1 = own ? A.rp_mp[nd + 1] : 0;
+    S.rs_mp[b] = m0; S.len_mp[b] = own ? int32_t(m1 - m0) : -1;
+    pe[b] = A.eval[p_off + nd];
+    S.cf[NU * DIM + b] = A.is_c ? A.is_c[p_off + nd] : 0;
+    S.cv[NU * DIM + b] = A.cval ? A.cval[p_off + nd] : 0.0;
+  }
+  for (int i = lane; i < ND; i += 64) S.fe[i] = 0.0;
+  wsync2();
+  if (lane < NP * DIM) { // monomial coefficients of the trilinear map
+    const int k = lane / DIM, e = lane % DIM;
+    double acc = 0;
+#pragma unroll
+    for (int v = 0; v < NP; ++v) {
+      const bool sub = (v & ~k) == 0;
+      const int par = __builtin_popcount(k ^ v) & 1;
+      const double xv = S.X[v * DIM + e];
+      acc += sub ? (par ? -xv : xv) : 0.0;
+    }
+    S.C[k * DIM + e] = acc;
+  }
+  wsync2();
+  const int ind = (active && A.indicator) ? A.indicator[cc] : 0;
+
+  // ---- phase 1: per quadrature point (lane = q): Jacobian, fields of the evaluation point, rhs coefficients
+  if (lane < NQ) {
+    const int q = lane;
+    const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
+    double xi[3], wq = 1.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) { xi[d] = T.t.xi[qi[d]]; wq *= T.t.w[qi[d]]; }
+    double J[9], Ji[9];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const double c1 = S.C[1 * 3 + e], c2 = S.C[2 * 3 + e], c3 = S.C[3 * 3 + e], c4 = S.C[4 * 3 + e], c5 = S.C[5 * 3 + e],
+                   c6 = S.C[6 * 3 + e], c7 = S.C[7 * 3 + e];
+      J[e * 3 + 0] = c1 + c3 * xi[1] + c5 * xi[2] + c7 * (xi[1] * xi[2]);
+      J[e * 3 + 1] = c2 + c3 * xi[0] + c6 * xi[2] + c7 * (xi[0] * xi[2]);
+      J[e * 3 + 2] = c4 + c5 * xi[0] + c6 * xi[1] + c7 * (xi[0] * xi[1]);
+    }
+    const double det = inv_small<3>(J, Ji);
+    const double w = fabs(det) * wq;
+    double u[3] = {0, 0, 0}, u0[3] = {0, 0, 0}, ac[3] = {0, 0, 0}, gr[9], p = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gr[i] = 0;
+#pragma unroll 1
+    for (int a = 0; a < NU; ++a) {
+      const int ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
+      const double nx = T.t.N[qi[0] * N1 + ai[0]], ny = T.t.N[qi[1] * N1 + ai[1]], nz = T.t.N[qi[2] * N1 + ai[2]];
+      const double dx = T.t.dN[qi[0] * N1 + ai[0]], dy = T.t.dN[qi[1] * N1 + ai[1]], dz = T.t.dN[qi[2] * N1 + ai[2]];
+      const double N = nx * ny * nz, dr[3] = {dx * ny * nz, nx * dy * nz, nx * ny * dz};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double uv = ue[a * 3 + c];
+        u[c] += N * uv; u0[c] += N * u0e[a * 3 + c]; ac[c] += N * ae[a * 3 + c];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) gr[c * 3 + e] += uv * dr[e];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NP; ++b) p += T.psi[q * NP + b] * pe[b];
+    double g[9], dv = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        double t = 0;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) t += gr[c * 3 + e] * Ji[e * 3 + d];
+        g[c * 3 + d] = t;
+      }
+    dv = g[0] + g[4] + g[8];
+    S.JxW[q] = w;
+    S.divw[q] = w * dv;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { S.Ji[q * 9 + i] = Ji[i]; S.gqs[q * 9 + i] = A.imex ? 0.0 : A.rho * w * g[i]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      S.uq[q * 3 + c] = A.imex ? 0.0 : u[c]; // only the matrix reads uq (u . grad N_b): no convection in the IMEX matrix
+      double adv = 0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        adv += g[c * 3 + d] * u[d];
+        S.Vc[(q * 3 + c) * 3 + d] = w * (-A.mu * g[c * 3 + d] + (c == d ? p - A.gamma * A.rho * dv : 0.0));
+      }
+      double sc = -A.rho * adv - A.rho * A.inv_dt * (u[c] - u0[c]) + A.rho * A.g[c];
+      if (ind == 1) sc += A.rho * ac[c];
+      S.Sc[q * 3 + c] = w * sc;
+    }
+  }
+  wsync2();
+  // ---- node tables, once per cell: tabN[q][a], tabG[d][q][a]
+  for (int t = lane; t < NQ * NU; t += 64) {
+    const int q = t / NU, a = t - q * NU;
+    const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)}, ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
+    const double nx = T.t.N[qi[0] * N1 + ai[0]], ny = T.t.N[qi[1] * N1 + ai[1]], nz = T.t.N[qi[2] * N1 + ai[2]];
+    const double dx = T.t.dN[qi[0] * N1 + ai[0]], dy = T.t.dN[qi[1] * N1 + ai[1]], dz = T.t.dN[qi[2] * N1 + ai[2]];
+    const double dr[3] = {dx * ny * nz, nx * dy * nz, nx * ny * dz};
+    S.tabN[q][a] = nx * ny * nz;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) S.tabG[d][q][a] = dr[0] * S.Ji[q * 9 + d] + dr[1] * S.Ji[q * 9 + 3 + d] + dr[2] * S.Ji[q * 9 + 6 + d];
+  }
+  wsync2();
+  // ---- Neumann (pressure) boundary faces  (:313-341)
+  if (A.n_neumann != 0 && active) {
+    for (int f = 0; f < 2 * DIM; ++f) {
+      const int bid = A.cell_face_bid[cc * 2 * DIM + f];
+      if (bid < 0) continue;
+      double pbc = 0; bool hit = false;
+      for (int k = 0; k < A.n_neumann; ++k) if (A.neumann_id[k] == bid) { pbc = A.neumann_p[k]; hit = true; }
+      if (!hit) continue;
+      const int nd = f >> 1; const double sgn = (f & 1) ? 1.0 : -1.0;
+      for (int i = lane; i < NU * DIM; i += 64) {
+        const int a = i / DIM, c = i - a * DIM;
+        double acc = 0;
+#pragma unroll 1
+        for (int qf = 0; qf < A.fe->nqf; ++qf) {
+          double J[9], Ji[9];
+          for (int k = 0; k < 9; ++k) J[k] = 0;
+          const double *dps = &A.fe->fdpsi[(f * A.fe->nqf + qf) * NP * DIM];
+          for (int v = 0; v < NP; ++v)
+            for (int d = 0; d < DIM; ++d)
+              for (int e = 0; e < DIM; ++e) J[d * DIM + e] += S.X[v * DIM + d] * dps[v * DIM + e];
+          const double det = inv_small<3>(J, Ji);
+          double nv[3], nn = 0;
+          for (int d = 0; d < DIM; ++d) { nv[d] = sgn * Ji[nd * DIM + d]; nn += nv[d] * nv[d]; }
+          nn = sqrt(nn);
+          acc += A.fe->fphi[(f * A.fe->nqf + qf) * NU + a] * (nv[c] / nn) * pbc * fabs(det) * nn * A.fe->fw[qf];
+        }
+        S.fe[i] -= acc;
+      }
+    }
+  }
+  wsync2();
+  // ---- local rhs (:281-304) from the tables
+#pragma unroll
+  for (int k = 0; k < FR; ++k) {
+    const int i = lane + 64 * k;
+    double f = 0;
+    if (i < NU * DIM) {
+      const int a = i / DIM, c = i - a * DIM;
+#pragma unroll 3
+      for (int q = 0; q < NQ; ++q)
+        f += S.Sc[q * 3 + c] * S.tabN[q][a] + S.Vc[(q * 3 + c) * 3 + 0] * S.tabG[0][q][a] + S.Vc[(q * 3 + c) * 3 + 1] * S.tabG[1][q][a] +
+             S.Vc[(q * 3 + c) * 3 + 2] * S.tabG[2][q][a];
+    } else if (i < ND) {
+#pragma unroll 3
+      for (int q = 0; q < NQ; ++q) f += S.divw[q] * T.psi[q * NP + (i - NU * DIM)];
+    }
+    if (i < ND) unsafeAtomicAdd(&S.fe[i], f);
+  }
+
+  // most cells carry no constrained dof: a wave-uniform flag lets their scatter skip the per-entry constraint logic
+  bool any_c;
+  {
+    bool mine = false;
+    for (int i = lane; i < ND; i += 64) mine = mine || S.cf[i];
+    any_c = __any(mine);
+  }
+  const double wgam = A.gamma * A.rho, rdt = A.rho * A.inv_dt;
+  double *stage = S.scratch;
+  int64_t *soff = reinterpret_cast<int64_t *>(S.scratch + 64 * BS);
+  wsync2();
+  // ---- velocity-velocity block on the matrix cores, one 16x16 tile pair (ti, tj) at a time
+  if (!A.rhs_only && A.debug_skip < 5) {
+#pragma unroll 1
+    for (int tp = 0; tp < 4; ++tp) {
+      const int ti = tp >> 1, tj = tp & 1;
+      const int al = 16 * ti + (lane & 15), bl = 16 * tj + (lane & 15); // my A-row node, my B-column node
+      const bool av = al < NU, bv = bl < NU;
+      const int ac_ = av ? al : 0, bc_ = bv ? bl : 0;
+      d4 acc[BS], sac = {0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < BS; ++e) acc[e] = d4{0, 0, 0, 0};
+      if (A.debug_skip != 2) {
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+          const int q = 4 * ks + (lane >> 4);
+          const bool qv = q < NQ;
+          const int qq = qv ? q : 0;
+          const double ma = (av && qv) ? 1.0 : 0.0, mb = (bv && qv) ? 1.0 : 0.0; // padding rows / columns / points contribute 0
+          const double w = S.JxW[qq];
+          const double Na = ma * S.tabN[qq][ac_], Nb = mb * S.tabN[qq][bc_];
+          double ga[3], gb[3];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) { ga[d] = ma * S.tabG[d][qq][ac_]; gb[d] = mb * S.tabG[d][qq][bc_]; }
+          const double ugb = S.uq[qq * 3] * gb[0] + S.uq[qq * 3 + 1] * gb[1] + S.uq[qq * 3 + 2] * gb[2];
+          const double wmu = w * A.mu, wNa = w * Na;
+          // scalar part
+          sac = __builtin_amdgcn_mfma_f64_16x16x4f64(wmu * ga[0], gb[0], sac, 0, 0, 0);
+          // grad-div part of the nine blocks (independent accumulators between dependent MFMAs)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const double wga = w * wgam * ga[c];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) acc[c * 3 + d] = __builtin_amdgcn_mfma_f64_16x16x4f64(wga, gb[d], acc[c * 3 + d], 0, 0, 0);
+          }
+          sac = __builtin_amdgcn_mfma_f64_16x16x4f64(wmu * ga[1], gb[1], sac, 0, 0, 0);
+          if (!A.imex) { // Newton term rho N_a N_b d_d u_c
+#pragma unroll
+            for (int e = 0; e < BS; ++e) acc[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(Na * S.gqs[qq * 9 + e], Nb, acc[e], 0, 0, 0);
+          }
+          sac = __builtin_amdgcn_mfma_f64_16x16x4f64(wmu * ga[2], gb[2], sac, 0, 0, 0);
+          if (!A.imex) sac = __builtin_amdgcn_mfma_f64_16x16x4f64(A.rho * wNa, ugb, sac, 0, 0, 0);
+          sac = __builtin_amdgcn_mfma_f64_16x16x4f64(rdt * wNa, Nb, sac, 0, 0, 0);
+        }
+      }
+      // ---- scatter: register r of a tile holds the pair (a = 16 ti + (lane>>4) + 4 r, b = 16 tj + (lane&15))
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = 16 * ti + (lane >> 4) + 4 * r, b = bl;
+        const bool have = active && a < NU && b < NU && S.len_uu[a < NU ? a : 0] >= 0 && !A.debug_skip;
+        int64_t off = -1;
+        if (have) {
+          const uint16_t pos = A.posUU[(cc * NU + a) * NU + b];
+          off = uu_base(S.rs_uu[a], S.len_uu[a], pos, BS);
+          const double s = sac[r];
+          const int64_t row_dof0 = int64_t(DIM) * S.un[a];
+          if (A.v_s) unsafeAtomicAdd(A.v_s + S.rs_uu[a] + pos, s);
+          if (!any_c) {
+#pragma unroll
+            for (int e = 0; e < BS; ++e) stage[lane * BS + e] = acc[e][r] + ((e == 0 || e == 4 || e == 8) ? s : 0.0);
+          } else
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const bool rc = S.cf[a * 3 + c];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              const bool ccn = S.cf[b * 3 + d];
+              const double v = acc[c * 3 + d][r] + (c == d ? s : 0.0);
+              double w = 0.0;
+              if (!rc && !ccn) w = v;
+              else if (rc) {
+                if (a == b && c == d) { // |Ke(r,r)| on the diagonal, rhs so that the update equals the inhomogeneity
+                  w = fabs(v);
+                  if (A.use_inhom) unsafeAtomicAdd(&A.rhs[row_dof0 + c], S.cv[a * 3 + c] * fabs(v));
+                }
+              } else if (A.use_inhom) {
+                const double g = S.cv[b * 3 + d];
+                if (g != 0.0) unsafeAtomicAdd(&S.fe[a * 3 + c], -v * g);
+              }
+              stage[lane * BS + c * 3 + d] = w;
+            }
+          }
+        }
+        soff[lane] = off;
+        wsync2();
+#pragma unroll
+        for (int rr = 0; rr < BS; ++rr) {
+          const int t = lane + 64 * rr, pl = t / BS, e = t - pl * BS;
+          const int64_t o = soff[pl];
+          const double w = stage[t];
+          if (o >= 0 && w != 0.0) unsafeAtomicAdd(A.v_uu + o + e, w);
+        }
+        wsync2();
+      }
+    }
+  }
+  // ---- velocity-pressure blocks: -JxW psi_b grad N_a
+  if (!A.rhs_only && A.debug_skip < 3 && active) {
+#pragma unroll 1
+    for (int k = 0; k < BROUNDS; ++k) {
+      const int t = lane + 64 * k;
+      if (t >= NBP) continue;
+      const int a = t / NP, pb = t - a * NP;
+      double v[3] = {0, 0, 0};
+#pragma unroll 3
+      for (int q = 0; q < NQ; ++q) {
+        const double wpsi = S.JxW[q] * T.psi[q * NP + pb];
+        v[0] -= wpsi * S.tabG[0][q][a]; v[1] -= wpsi * S.tabG[1][q][a]; v[2] -= wpsi * S.tabG[2][q][a];
+      }
+      const bool pc = S.cf[NU * DIM + pb];
+      if (S.len_bt[a] >= 0) {
+        const int len = S.len_bt[a];
+        double *base = A.v_bt + S.rs_bt[a] * DIM + A.posUP[(cc * NU + a) * NP + pb];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+          if (S.cf[a * DIM + c]) continue;
+          if (!pc) unsafeAtomicAdd(base + int64_t(c) * len, v[c]);
+          else if (A.use_inhom && S.cv[NU * DIM + pb] != 0.0) unsafeAtomicAdd(&S.fe[a * DIM + c], -v[c] * S.cv[NU * DIM + pb]);
+        }
+      }
+      if (S.len_b[pb] >= 0 && !pc) {
+        const int len = S.len_b[pb];
+        double *base = A.v_b + S.rs_b[pb] * DIM + A.posPU[(cc * NP + pb) * NU + a];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+          if (!S.cf[a * DIM + c]) unsafeAtomicAdd(base + int64_t(c) * len, v[c]);
+          else if (A.use_inhom && S.cv[a * DIM + c] != 0.0) unsafeAtomicAdd(&S.fe[NU * DIM + pb], -v[c] * S.cv[a * DIM + c]);
+        }
+      }
+    }
+  }
+  // ---- pressure mass matrix M_p and diag(M_u)
+  if (!A.rhs_only && A.debug_skip < 4) {
+    if (lane < NP * NP) {
+      const int pa = lane / NP, pb = lane - pa * NP;
+      double m = 0;
+#pragma unroll 3
+      for (int q = 0; q < NQ; ++q) m += S.JxW[q] * T.psi[q * NP + pa] * T.psi[q * NP + pb];
+      if (active && S.len_mp[pa] >= 0) {
+        const bool ra = S.cf[NU * DIM + pa], cb = S.cf[NU * DIM + pb];
+        double *dst = A.v_mp + S.rs_mp[pa] + A.posPP[(cc * NP + pa) * NP + pb];
+        if (!ra && !cb) unsafeAtomicAdd(dst, m);
+        else if (ra && pa == pb) unsafeAtomicAdd(dst, fabs(m));
+      }
+    }
+    if (lane < NU) {
+      double m = 0;
+#pragma unroll 3
+      for (int q = 0; q < NQ; ++q) m += S.JxW[q] * S.tabN[q][lane] * S.tabN[q][lane];
+      if (active && S.len_uu[lane] >= 0)
+        for (int c = 0; c < DIM; ++c) unsafeAtomicAdd(&A.diagMu[int64_t(DIM) * S.un[lane] + c], m);
+    }
+  }
+  wsync2();
+  // ---- rhs scatter (unconstrained owned rows; constrained rows were handled with the diagonal)
+  if (active) {
+    for (int i = lane; i < ND; i += 64) {
+      if (S.cf[i]) continue;
+      if (i < NU * DIM) {
+        const int a = i / DIM, c = i - a * DIM;
+        if (S.len_uu[a] >= 0) unsafeAtomicAdd(&A.rhs[int64_t(DIM) * S.un[a] + c], S.fe[i]);
+      } else {
+        const int b = i - NU * DIM;
+        if (S.len_b[b] >= 0) unsafeAtomicAdd(&A.rhs[int64_t(DIM) * A.nUo + S.pn[b]], S.fe[i]);
+      }
+    }
+  }
+}
+
+// 3D Q2/Q1 only; the block-interleaved A_uu layout is assumed by the staged scatter
+bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A) {
+#if !IFEM_UU_INTERLEAVED
+  return false;
+#else
+  if (ctx->dim != 3 || ctx->kv != 2) return false;
+  constexpr int WPB = 4;
+  const size_t smem = ((sizeof(Shared3) + 15) & ~size_t(15)) + WPB * ((sizeof(Cell3) + 15) & ~size_t(15));
+  static bool attr_set = false;
+  if (!attr_set) {
+    IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ins_assemble3<WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  Tab1D t;
+  tab1d(t, 2);
+  AsmArgs B = A;
+  B.order = nullptr; B.first = 0; B.count = A.n_cells;
+  const int64_t nblk = (B.count + WPB - 1) / WPB;
+  hipLaunchKernelGGL((k_ins_assemble3<WPB>), dim3((unsigned)nblk), dim3(64 * WPB), smem, ctx->stream, B, t);
+  IFEM_HIP_CHECK(hipGetLastError());
+  return true;
+#endif
+}
+
+} // namespace ifem

@@ -3,6 +3,8 @@
 // accumulators).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
 #include "ctx.hpp"
 
 namespace ifem {
@@ -66,6 +68,48 @@ template <bool ATOMIC>
 __device__ inline void gadd(double *p, double v) {
   if constexpr (ATOMIC) unsafeAtomicAdd(p, v);
   else *p += v;
+}
+
+// 1D tensor factors of the Q_kv shape functions at the Gauss points (assemble2.hip, assemble3.hip)
+struct Tab1D {
+  double N[9];  // [q][i] 1D Lagrange shape i (equidistant nodes) at Gauss point q
+  double dN[9]; // its derivative
+  double xi[3], w[3];
+};
+
+__device__ inline void wsync2() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+inline void tab1d(Tab1D &t, int kv) {
+  const int n1 = kv + 1;
+  std::memset(&t, 0, sizeof(t));
+  if (n1 == 2) {
+    const double a = 0.5 / std::sqrt(3.0);
+    t.xi[0] = 0.5 - a; t.xi[1] = 0.5 + a; t.w[0] = t.w[1] = 0.5;
+  } else {
+    const double a = 0.5 * std::sqrt(0.6);
+    t.xi[0] = 0.5 - a; t.xi[1] = 0.5; t.xi[2] = 0.5 + a;
+    t.w[0] = t.w[2] = 5.0 / 18.0; t.w[1] = 8.0 / 18.0;
+  }
+  for (int q = 0; q < n1; ++q)
+    for (int i = 0; i < n1; ++i) {
+      const double xi_i = double(i) / kv;
+      double v = 1, d = 0;
+      for (int j = 0; j < n1; ++j)
+        if (j != i) v *= (t.xi[q] - double(j) / kv) / (xi_i - double(j) / kv);
+      for (int k = 0; k < n1; ++k) {
+        if (k == i) continue;
+        double p = 1.0 / (xi_i - double(k) / kv);
+        for (int j = 0; j < n1; ++j)
+          if (j != i && j != k) p *= (t.xi[q] - double(j) / kv) / (xi_i - double(j) / kv);
+        d += p;
+      }
+      t.N[q * n1 + i] = v;
+      t.dN[q * n1 + i] = d;
+    }
 }
 
 } // namespace ifem
