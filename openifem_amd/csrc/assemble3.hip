@@ -25,10 +25,11 @@ struct Cell3 {
   double tabG[DIM][NQ][NU]; // physical shape gradients
   double tabN[NQ][NU];      // shape values
   double X[NP * DIM], C[8 * DIM];
-  double Ji[NQ * 9], JxW[NQ], uq[NQ * DIM];
+  double JxW[NQ], uq[NQ * DIM];
   double gqs[NQ * 9]; // rho JxW grad u
-  double Vc[NQ * 9], Sc[NQ * DIM], divw[NQ];
-  double scratch[STAGE > NODAL ? STAGE : NODAL]; // nodal values (phase 1) | scatter staging
+  // Ji[243] | Vc[243] | Sc[81] | divw[27] until the rhs is integrated, then the scatter staging of the cell's second wave
+  double dead[STAGE];
+  double scratch[STAGE > NODAL ? STAGE : NODAL]; // nodal values (phase 1) | scatter staging of the cell's first wave
   double fe[ND], cv[ND];
   int64_t rs_uu[NU], rs_bt[NU], rs_b[NP], rs_mp[NP];
   int32_t len_uu[NU], len_bt[NU], len_b[NP], len_mp[NP];
@@ -41,14 +42,18 @@ struct Shared3 {
   double psi[27 * 8];
 };
 
-template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1) {
+// CPB cells per workgroup, TWO wavefronts per cell (h = 0, 1) sharing the cell's LDS tables: the tables cap the
+// workgroup at ~150 KB of LDS, and one wave per SIMD leaves every LDS / global round trip exposed; with two waves per
+// cell the SIMDs hold two waves each.  Phases are separated by workgroup barriers (uniform control flow).
+template <int CPB>
+__global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1) {
   constexpr int DIM = 3, N1 = 3, NU = 27, NP = 8, NQ = 27, ND = 89, BS = 9;
   constexpr int NBP = NU * NP, BROUNDS = (NBP + 63) / 64, FR = (ND + 63) / 64;
   extern __shared__ __align__(16) unsigned char smem[];
   Shared3 &T = *reinterpret_cast<Shared3 *>(smem);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  Cell3 &S = *reinterpret_cast<Cell3 *>(smem + ((sizeof(Shared3) + 15) & ~size_t(15)) + size_t(wave) * ((sizeof(Cell3) + 15) & ~size_t(15)));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = wave >> 1, h = wave & 1;
+  Cell3 &S = *reinterpret_cast<Cell3 *>(smem + ((sizeof(Shared3) + 15) & ~size_t(15)) + size_t(slot) * ((sizeof(Cell3) + 15) & ~size_t(15)));
+  double *const Ji_ = S.dead, *const Vc_ = S.dead + 243, *const Sc_ = S.dead + 486, *const divw_ = S.dead + 567;
   if (threadIdx.x < 9) { T.t.N[threadIdx.x] = t1.N[threadIdx.x]; T.t.dN[threadIdx.x] = t1.dN[threadIdx.x]; }
   if (threadIdx.x < 3) { T.t.xi[threadIdx.x] = t1.xi[threadIdx.x]; T.t.w[threadIdx.x] = t1.w[threadIdx.x]; }
   for (int i = threadIdx.x; i < NQ * NP; i += blockDim.x) {
@@ -63,15 +68,15 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1)
   }
   __syncthreads();
 
-  const int64_t idx = int64_t(A.xcd_swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * WPB + wave;
+  const int64_t idx = int64_t(A.xcd_swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * CPB + slot;
   const bool active = idx < A.count;
   const int64_t cc = active ? (A.order ? int64_t(A.order[A.first + idx]) : idx) : 0;
   const int64_t p_off = int64_t(DIM) * A.nUl;
   double *ue = S.scratch, *u0e = S.scratch + NU * DIM, *ae = S.scratch + 2 * NU * DIM, *pe = S.scratch + 3 * NU * DIM;
 
   // ---- phase 0: ids, coordinates, nodal values, row descriptors, constraint flags
-  for (int i = lane; i < NP * DIM; i += 64) S.X[i] = A.vcoords[cc * NP * DIM + i];
-  if (lane < NU) {
+  if (h == 1) for (int i = lane; i < NP * DIM; i += 64) S.X[i] = A.vcoords[cc * NP * DIM + i];
+  if (h == 0 && lane < NU) {
     const int a = lane;
     const int32_t nd = A.cell_unodes[cc * NU + a];
     S.un[a] = nd;
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1)
       S.cv[a * DIM + c] = A.cval ? A.cval[dof] : 0.0;
     }
   }
-  if (lane < NP) {
+  if (h == 1 && lane < NP) {
     const int b = lane;
     const int32_t nd = A.cell_pnodes[cc * NP + b];
     S.pn[b] = nd;
@@ -102,9 +107,9 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1)
     S.cf[NU * DIM + b] = A.is_c ? A.is_c[p_off + nd] : 0;
     S.cv[NU * DIM + b] = A.cval ? A.cval[p_off + nd] : 0.0;
   }
-  for (int i = lane; i < ND; i += 64) S.fe[i] = 0.0;
-  wsync2();
-  if (lane < NP * DIM) { // monomial coefficients of the trilinear map
+  if (h == 0) for (int i = lane; i < ND; i += 64) S.fe[i] = 0.0;
+  __syncthreads();
+  if (h == 0 && lane < NP * DIM) { // monomial coefficients of the trilinear map
     const int k = lane / DIM, e = lane % DIM;
     double acc = 0;
 #pragma unroll
@@ -116,11 +121,11 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1)
     }
     S.C[k * DIM + e] = acc;
   }
-  wsync2();
+  __syncthreads();
   const int ind = (active && A.indicator) ? A.indicator[cc] : 0;
 
   // ---- phase 1: per quadrature point (lane = q): Jacobian, fields of the evaluation point, rhs coefficients
-  if (lane < NQ) {
+  if (h == 0 && lane < NQ) {
     const int q = lane;
     const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
     double xi[3], wq = 1.0;
@@ -168,9 +173,9 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1)
       }
     dv = g[0] + g[4] + g[8];
     S.JxW[q] = w;
-    S.divw[q] = w * dv;
+    divw_[q] = w * dv;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { S.Ji[q * 9 + i] = Ji[i]; S.gqs[q * 9 + i] = A.imex ? 0.0 : A.rho * w * g[i]; }
+    for (int i = 0; i < 9; ++i) { Ji_[q * 9 + i] = Ji[i]; S.gqs[q * 9 + i] = A.imex ? 0.0 : A.rho * w * g[i]; }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       S.uq[q * 3 + c] = A.imex ? 0.0 : u[c]; // only the matrix reads uq (u . grad N_b): no convection in the IMEX matrix
@@ -178,16 +183,16 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1)
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         adv += g[c * 3 + d] * u[d];
-        S.Vc[(q * 3 + c) * 3 + d] = w * (-A.mu * g[c * 3 + d] + (c == d ? p - A.gamma * A.rho * dv : 0.0));
+        Vc_[(q * 3 + c) * 3 + d] = w * (-A.mu * g[c * 3 + d] + (c == d ? p - A.gamma * A.rho * dv : 0.0));
       }
       double sc = -A.rho * adv - A.rho * A.inv_dt * (u[c] - u0[c]) + A.rho * A.g[c];
       if (ind == 1) sc += A.rho * ac[c];
-      S.Sc[q * 3 + c] = w * sc;
+      Sc_[q * 3 + c] = w * sc;
     }
   }
-  wsync2();
-  // ---- node tables, once per cell: tabN[q][a], tabG[d][q][a]
-  for (int t = lane; t < NQ * NU; t += 64) {
+  __syncthreads();
+  // ---- node tables, once per cell: tabN[q][a], tabG[d][q][a] (both waves, interleaved rounds)
+  for (int t = lane + 64 * h; t < NQ * NU; t += 128) {
     const int q = t / NU, a = t - q * NU;
     const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)}, ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
     const double nx = T.t.N[qi[0] * N1 + ai[0]], ny = T.t.N[qi[1] * N1 + ai[1]], nz = T.t.N[qi[2] * N1 + ai[2]];
@@ -195,11 +200,11 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1)
     const double dr[3] = {dx * ny * nz, nx * dy * nz, nx * ny * dz};
     S.tabN[q][a] = nx * ny * nz;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) S.tabG[d][q][a] = dr[0] * S.Ji[q * 9 + d] + dr[1] * S.Ji[q * 9 + 3 + d] + dr[2] * S.Ji[q * 9 + 6 + d];
+    for (int d = 0; d < 3; ++d) S.tabG[d][q][a] = dr[0] * Ji_[q * 9 + d] + dr[1] * Ji_[q * 9 + 3 + d] + dr[2] * Ji_[q * 9 + 6 + d];
   }
-  wsync2();
+  __syncthreads();
   // ---- Neumann (pressure) boundary faces  (:313-341)
-  if (A.n_neumann != 0 && active) {
+  if (A.n_neumann != 0 && active && h == 0) {
     for (int f = 0; f < 2 * DIM; ++f) {
       const int bid = A.cell_face_bid[cc * 2 * DIM + f];
       if (bid < 0) continue;
@@ -224,12 +229,13 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1)
           nn = sqrt(nn);
           acc += A.fe->fphi[(f * A.fe->nqf + qf) * NU + a] * (nv[c] / nn) * pbc * fabs(det) * nn * A.fe->fw[qf];
         }
-        S.fe[i] -= acc;
+        unsafeAtomicAdd(&S.fe[i], -acc); // the cell's second wave adds to S.fe concurrently
       }
     }
   }
   wsync2();
-  // ---- local rhs (:281-304) from the tables
+  // ---- local rhs (:281-304) from the tables: first wave; the second wave integrates B / B^T and M_p meanwhile
+  if (h == 0)
 #pragma unroll
   for (int k = 0; k < FR; ++k) {
     const int i = lane + 64 * k;
@@ -238,15 +244,73 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1)
       const int a = i / DIM, c = i - a * DIM;
 #pragma unroll 3
       for (int q = 0; q < NQ; ++q)
-        f += S.Sc[q * 3 + c] * S.tabN[q][a] + S.Vc[(q * 3 + c) * 3 + 0] * S.tabG[0][q][a] + S.Vc[(q * 3 + c) * 3 + 1] * S.tabG[1][q][a] +
-             S.Vc[(q * 3 + c) * 3 + 2] * S.tabG[2][q][a];
+        f += Sc_[q * 3 + c] * S.tabN[q][a] + Vc_[(q * 3 + c) * 3 + 0] * S.tabG[0][q][a] + Vc_[(q * 3 + c) * 3 + 1] * S.tabG[1][q][a] +
+             Vc_[(q * 3 + c) * 3 + 2] * S.tabG[2][q][a];
     } else if (i < ND) {
 #pragma unroll 3
-      for (int q = 0; q < NQ; ++q) f += S.divw[q] * T.psi[q * NP + (i - NU * DIM)];
+      for (int q = 0; q < NQ; ++q) f += divw_[q] * T.psi[q * NP + (i - NU * DIM)];
     }
     if (i < ND) unsafeAtomicAdd(&S.fe[i], f);
   }
 
+  // ---- velocity-pressure blocks: -JxW psi_b grad N_a
+  if (!A.rhs_only && A.debug_skip < 3 && active && h == 1) {
+#pragma unroll 1
+    for (int k = 0; k < BROUNDS; ++k) {
+      const int t = lane + 64 * k;
+      if (t >= NBP) continue;
+      const int a = t / NP, pb = t - a * NP;
+      double v[3] = {0, 0, 0};
+#pragma unroll 3
+      for (int q = 0; q < NQ; ++q) {
+        const double wpsi = S.JxW[q] * T.psi[q * NP + pb];
+        v[0] -= wpsi * S.tabG[0][q][a]; v[1] -= wpsi * S.tabG[1][q][a]; v[2] -= wpsi * S.tabG[2][q][a];
+      }
+      const bool pc = S.cf[NU * DIM + pb];
+      if (S.len_bt[a] >= 0) {
+        const int len = S.len_bt[a];
+        double *base = A.v_bt + S.rs_bt[a] * DIM + A.posUP[(cc * NU + a) * NP + pb];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+          if (S.cf[a * DIM + c]) continue;
+          if (!pc) unsafeAtomicAdd(base + int64_t(c) * len, v[c]);
+          else if (A.use_inhom && S.cv[NU * DIM + pb] != 0.0) unsafeAtomicAdd(&S.fe[a * DIM + c], -v[c] * S.cv[NU * DIM + pb]);
+        }
+      }
+      if (S.len_b[pb] >= 0 && !pc) {
+        const int len = S.len_b[pb];
+        double *base = A.v_b + S.rs_b[pb] * DIM + A.posPU[(cc * NP + pb) * NU + a];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+          if (!S.cf[a * DIM + c]) unsafeAtomicAdd(base + int64_t(c) * len, v[c]);
+          else if (A.use_inhom && S.cv[a * DIM + c] != 0.0) unsafeAtomicAdd(&S.fe[NU * DIM + pb], -v[c] * S.cv[a * DIM + c]);
+        }
+      }
+    }
+  }
+  // ---- pressure mass matrix M_p and diag(M_u)
+  if (!A.rhs_only && A.debug_skip < 4) {
+    if (h == 1 && lane < NP * NP) {
+      const int pa = lane / NP, pb = lane - pa * NP;
+      double m = 0;
+#pragma unroll 3
+      for (int q = 0; q < NQ; ++q) m += S.JxW[q] * T.psi[q * NP + pa] * T.psi[q * NP + pb];
+      if (active && S.len_mp[pa] >= 0) {
+        const bool ra = S.cf[NU * DIM + pa], cb = S.cf[NU * DIM + pb];
+        double *dst = A.v_mp + S.rs_mp[pa] + A.posPP[(cc * NP + pa) * NP + pb];
+        if (!ra && !cb) unsafeAtomicAdd(dst, m);
+        else if (ra && pa == pb) unsafeAtomicAdd(dst, fabs(m));
+      }
+    }
+    if (h == 0 && lane < NU) {
+      double m = 0;
+#pragma unroll 3
+      for (int q = 0; q < NQ; ++q) m += S.JxW[q] * S.tabN[q][lane] * S.tabN[q][lane];
+      if (active && S.len_uu[lane] >= 0)
+        for (int c = 0; c < DIM; ++c) unsafeAtomicAdd(&A.diagMu[int64_t(DIM) * S.un[lane] + c], m);
+    }
+  }
+  __syncthreads(); // rhs, B / B^T and M_p are integrated: the dead zone may be reused, S.fe is complete up to the scatter corrections
   // most cells carry no constrained dof: a wave-uniform flag lets their scatter skip the per-entry constraint logic
   bool any_c;
   {
@@ -255,13 +319,12 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1)
     any_c = __any(mine);
   }
   const double wgam = A.gamma * A.rho, rdt = A.rho * A.inv_dt;
-  double *stage = S.scratch;
-  int64_t *soff = reinterpret_cast<int64_t *>(S.scratch + 64 * BS);
-  wsync2();
+  double *stage = h == 0 ? S.scratch : S.dead; // the second wave stages in the dead zone (Ji, Vc, Sc, divw are consumed)
+  int64_t *soff = reinterpret_cast<int64_t *>(stage + 64 * BS);
   // ---- velocity-velocity block on the matrix cores, one 16x16 tile pair (ti, tj) at a time
   if (!A.rhs_only && A.debug_skip < 5) {
 #pragma unroll 1
-    for (int tp = 0; tp < 4; ++tp) {
+    for (int tp = 2 * h; tp < 2 * h + 2; ++tp) {
       const int ti = tp >> 1, tj = tp & 1;
       const int al = 16 * ti + (lane & 15), bl = 16 * tj + (lane & 15); // my A-row node, my B-column node
       const bool av = al < NU, bv = bl < NU;
@@ -353,66 +416,9 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble3(AsmArgs A, Tab1D t1)
       }
     }
   }
-  // ---- velocity-pressure blocks: -JxW psi_b grad N_a
-  if (!A.rhs_only && A.debug_skip < 3 && active) {
-#pragma unroll 1
-    for (int k = 0; k < BROUNDS; ++k) {
-      const int t = lane + 64 * k;
-      if (t >= NBP) continue;
-      const int a = t / NP, pb = t - a * NP;
-      double v[3] = {0, 0, 0};
-#pragma unroll 3
-      for (int q = 0; q < NQ; ++q) {
-        const double wpsi = S.JxW[q] * T.psi[q * NP + pb];
-        v[0] -= wpsi * S.tabG[0][q][a]; v[1] -= wpsi * S.tabG[1][q][a]; v[2] -= wpsi * S.tabG[2][q][a];
-      }
-      const bool pc = S.cf[NU * DIM + pb];
-      if (S.len_bt[a] >= 0) {
-        const int len = S.len_bt[a];
-        double *base = A.v_bt + S.rs_bt[a] * DIM + A.posUP[(cc * NU + a) * NP + pb];
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-          if (S.cf[a * DIM + c]) continue;
-          if (!pc) unsafeAtomicAdd(base + int64_t(c) * len, v[c]);
-          else if (A.use_inhom && S.cv[NU * DIM + pb] != 0.0) unsafeAtomicAdd(&S.fe[a * DIM + c], -v[c] * S.cv[NU * DIM + pb]);
-        }
-      }
-      if (S.len_b[pb] >= 0 && !pc) {
-        const int len = S.len_b[pb];
-        double *base = A.v_b + S.rs_b[pb] * DIM + A.posPU[(cc * NP + pb) * NU + a];
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-          if (!S.cf[a * DIM + c]) unsafeAtomicAdd(base + int64_t(c) * len, v[c]);
-          else if (A.use_inhom && S.cv[a * DIM + c] != 0.0) unsafeAtomicAdd(&S.fe[NU * DIM + pb], -v[c] * S.cv[a * DIM + c]);
-        }
-      }
-    }
-  }
-  // ---- pressure mass matrix M_p and diag(M_u)
-  if (!A.rhs_only && A.debug_skip < 4) {
-    if (lane < NP * NP) {
-      const int pa = lane / NP, pb = lane - pa * NP;
-      double m = 0;
-#pragma unroll 3
-      for (int q = 0; q < NQ; ++q) m += S.JxW[q] * T.psi[q * NP + pa] * T.psi[q * NP + pb];
-      if (active && S.len_mp[pa] >= 0) {
-        const bool ra = S.cf[NU * DIM + pa], cb = S.cf[NU * DIM + pb];
-        double *dst = A.v_mp + S.rs_mp[pa] + A.posPP[(cc * NP + pa) * NP + pb];
-        if (!ra && !cb) unsafeAtomicAdd(dst, m);
-        else if (ra && pa == pb) unsafeAtomicAdd(dst, fabs(m));
-      }
-    }
-    if (lane < NU) {
-      double m = 0;
-#pragma unroll 3
-      for (int q = 0; q < NQ; ++q) m += S.JxW[q] * S.tabN[q][lane] * S.tabN[q][lane];
-      if (active && S.len_uu[lane] >= 0)
-        for (int c = 0; c < DIM; ++c) unsafeAtomicAdd(&A.diagMu[int64_t(DIM) * S.un[lane] + c], m);
-    }
-  }
-  wsync2();
+  __syncthreads();
   // ---- rhs scatter (unconstrained owned rows; constrained rows were handled with the diagonal)
-  if (active) {
+  if (active && h == 0) {
     for (int i = lane; i < ND; i += 64) {
       if (S.cf[i]) continue;
       if (i < NU * DIM) {
@@ -432,19 +438,19 @@ bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A) {
   return false;
 #else
   if (ctx->dim != 3 || ctx->kv != 2) return false;
-  constexpr int WPB = 4;
-  const size_t smem = ((sizeof(Shared3) + 15) & ~size_t(15)) + WPB * ((sizeof(Cell3) + 15) & ~size_t(15));
+  constexpr int CPB = 4; // cells per workgroup (two waves each)
+  const size_t smem = ((sizeof(Shared3) + 15) & ~size_t(15)) + CPB * ((sizeof(Cell3) + 15) & ~size_t(15));
   static bool attr_set = false;
   if (!attr_set) {
-    IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ins_assemble3<WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ins_assemble3<CPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
   Tab1D t;
   tab1d(t, 2);
   AsmArgs B = A;
   B.order = nullptr; B.first = 0; B.count = A.n_cells;
-  const int64_t nblk = (B.count + WPB - 1) / WPB;
-  hipLaunchKernelGGL((k_ins_assemble3<WPB>), dim3((unsigned)nblk), dim3(64 * WPB), smem, ctx->stream, B, t);
+  const int64_t nblk = (B.count + CPB - 1) / CPB;
+  hipLaunchKernelGGL((k_ins_assemble3<CPB>), dim3((unsigned)nblk), dim3(128 * CPB), smem, ctx->stream, B, t);
   IFEM_HIP_CHECK(hipGetLastError());
   return true;
 #endif
