@@ -438,7 +438,7 @@ bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A) {
   return false;
 #else
   if (ctx->dim != 3 || ctx->kv != 2) return false;
-  constexpr int CPB = 4; // cells per workgroup (two waves each)
+  constexpr int CPB = 2; // cells per workgroup (two waves each)
   const size_t smem = ((sizeof(Shared3) + 15) & ~size_t(15)) + CPB * ((sizeof(Cell3) + 15) & ~size_t(15));
   static bool attr_set = false;
   if (!attr_set) {
