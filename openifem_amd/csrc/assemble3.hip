@@ -146,7 +146,7 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
 #pragma unroll
     for (int i = 0; i < 9; ++i) gr[i] = 0;
 #pragma unroll 1
-    for (int a = 0; a < NU; ++a) {
+    for (int a = 0; a < (A.debug_skip == 6 ? 1 : NU); ++a) {
       const int ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
       const double nx = T.t.N[qi[0] * N1 + ai[0]], ny = T.t.N[qi[1] * N1 + ai[1]], nz = T.t.N[qi[2] * N1 + ai[2]];
       const double dx = T.t.dN[qi[0] * N1 + ai[0]], dy = T.t.dN[qi[1] * N1 + ai[1]], dz = T.t.dN[qi[2] * N1 + ai[2]];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
   }
   __syncthreads();
   // ---- node tables, once per cell: tabN[q][a], tabG[d][q][a] (both waves, interleaved rounds)
-  for (int t = lane + 64 * h; t < NQ * NU; t += 128) {
+  for (int t = lane + 64 * h; t < (A.debug_skip == 7 ? 128 : NQ * NU); t += 128) {
     const int q = t / NU, a = t - q * NU;
     const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)}, ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
     const double nx = T.t.N[qi[0] * N1 + ai[0]], ny = T.t.N[qi[1] * N1 + ai[1]], nz = T.t.N[qi[2] * N1 + ai[2]];
