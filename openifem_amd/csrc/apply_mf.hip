@@ -281,7 +281,9 @@ struct MfCell { // per-cell LDS scratch
   uint8_t flag[NN * DIM + 3];
 };
 
-template <int DIM, int KV, int WPB>
+// CONV = false: the evaluation point is zero (InsIMEX matrix: no convective / Newton terms) -- the second field group is
+// neither gathered nor interpolated
+template <int DIM, int KV, int WPB, bool CONV>
 __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
   constexpr int N1 = KV + 1, NN = MfGeo<DIM, N1>::NN, NV = 1 << DIM;
   constexpr int NP = NN / N1;        // pencils per field and direction
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
         S.flag[hl * DIM + c] = con;
         if (A.mode == 5) { S.V[c * NN + hl] = double(dof & 255); S.V[(DIM + c) * NN + hl] = double(dof & 127); } else {
         S.V[c * NN + hl] = con ? 0.0 : A.x[dof];
-        S.V[(DIM + c) * NN + hl] = A.eval[dof]; }
+        if constexpr (CONV) S.V[(DIM + c) * NN + hl] = A.eval[dof]; }
       }
     }
     if (hl < NV * DIM) S.X[hl] = A.vcoords[cc * NV * DIM + hl];
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
 #pragma unroll
       for (int d = 0; d < DIM; ++d) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < (CONV ? 2 : 1); ++r) {
           double *b = S.V + (r * DIM + comp) * NN + pbase[d];
           double in[N1];
 #pragma unroll
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
     for (int d = 0; d < DIM; ++d) {
       if (pen_lane) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < (CONV ? 2 : 1); ++r) {
           const int off = (r * DIM + comp) * NN + pbase[d];
           double in[N1];
 #pragma unroll
@@ -442,9 +444,14 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
       if (q_lane) {
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
-          const double rx = S.G[c * NN + q], ru = S.G[(DIM + c) * NN + q];
+          const double rx = S.G[c * NN + q];
 #pragma unroll
-          for (int e = 0; e < DIM; ++e) { gx[c][e] += Ji[d * DIM + e] * rx; gu[c][e] += Ji[d * DIM + e] * ru; }
+          for (int e = 0; e < DIM; ++e) gx[c][e] += Ji[d * DIM + e] * rx;
+          if constexpr (CONV) {
+            const double ru = S.G[(DIM + c) * NN + q];
+#pragma unroll
+            for (int e = 0; e < DIM; ++e) gu[c][e] += Ji[d * DIM + e] * ru;
+          }
         }
       }
       wsync();
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
     if (q_lane) {
       double xq[DIM], uq[DIM];
 #pragma unroll
-      for (int c = 0; c < DIM; ++c) { xq[c] = S.V[c * NN + q]; uq[c] = S.V[(DIM + c) * NN + q]; }
+      for (int c = 0; c < DIM; ++c) { xq[c] = S.V[c * NN + q]; uq[c] = CONV ? S.V[(DIM + c) * NN + q] : 0.0; }
       double divx = 0;
 #pragma unroll
       for (int c = 0; c < DIM; ++c) divx += gx[c][c];
@@ -640,10 +647,16 @@ void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu) {
   if (!v1 && (a.mode == 0 || a.mode >= 4)) {
     const int64_t n_pairs = (ctx->n_cells + 1) / 2;
     const dim3 g2(unsigned(std::min<int64_t>((n_pairs + WPB - 1) / WPB, 256 * 24)));
-    if (ctx->dim == 3 && ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf2<3, 2, WPB>), g2, block, 0, s, a);
-    else if (ctx->dim == 3) hipLaunchKernelGGL((k_apply_uu_mf2<3, 1, WPB>), g2, block, 0, s, a);
-    else if (ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf2<2, 2, WPB>), g2, block, 0, s, a);
-    else hipLaunchKernelGGL((k_apply_uu_mf2<2, 1, WPB>), g2, block, 0, s, a);
+    static const bool noconv_env = [] { const char *e = getenv("IFEM_MF_NOCONV"); return e && atoi(e); }(); // timing aid
+    const bool conv = !(ctx->mf_noconv || noconv_env);
+#define IFEM_MF2(D, K)                                                                                                 \
+  { if (conv) hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, true>), g2, block, 0, s, a);                                 \
+    else hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, false>), g2, block, 0, s, a); }
+    if (ctx->dim == 3 && ctx->kv == 2) IFEM_MF2(3, 2)
+    else if (ctx->dim == 3) IFEM_MF2(3, 1)
+    else if (ctx->kv == 2) IFEM_MF2(2, 2)
+    else IFEM_MF2(2, 1)
+#undef IFEM_MF2
   } else
   if (ctx->dim == 3 && ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf<3, 2, WPB>), grid, block, 0, s, a);
   else if (ctx->dim == 3) hipLaunchKernelGGL((k_apply_uu_mf<3, 1, WPB>), grid, block, 0, s, a);

@@ -366,6 +366,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
     else IFEM_HIP_CHECK(hipMemcpyAsync(ctx->mf_eval.p, ctx->vec[IFEM_VEC_EVAL].p, nu * sizeof(double), hipMemcpyDeviceToDevice, s));
     ctx->mf_params = *p;
     ctx->mf_valid = true;
+    ctx->mf_noconv = imex != 0;
   }
   if (ctx->asm_rows) {
     launch_ins_assemble_rows(ctx, p, use_nonzero);

@@ -182,6 +182,7 @@ struct ifem_ctx {
   ifem::DBuf<double> mf_eval;  // velocity part of the evaluation point, ghost-extended
   ifem_ins_params mf_params{};
   bool mf_valid = false;
+  bool mf_noconv = false; // the assembled matrix has no convective terms (InsIMEX): the operator skips the second field group
   double mf_ms_total = 0;
   ifem::DBuf<float> Auu_f32;   // single-precision copy of Auu.val for the inner (preconditioner-only) solver
   bool auu_f32_valid = false, last_spmv_f32 = false;
