@@ -222,6 +222,10 @@ typedef struct {
  * (set_sigma_pml_field evaluated at the quadrature points, mpi_scnsim.cpp:188-192), body_force [n_cells][n_q][dim]
  * (set_body_force, :193-197), fsi_stress [dim(dim+1)/2][n_unodes_local] (MPI::FSI, mpi_fsi.cpp:469-471) */
 int ifem_set_scns_fields(ifem_ctx *ctx, const double *sigma_pml, const double *body_force, const double *fsi_stress);
+/* nodal eddy viscosity of an attached turbulence model ([n_unodes_local] on the scalar Q_kv space, or NULL to detach):
+ * SCnsIM::assemble adds max(nu_t(q), 0) to the viscosity at every quadrature point (mpi_scnsim.cpp:198-216).  The
+ * turbulence model itself (Spalart-Allmaras, source/mpi_spalart_allmaras.cpp) is outside the path. */
+int ifem_set_eddy_viscosity(ifem_ctx *ctx, const double *nodal);
 /* FluidSolver::update_stress (mpi_fluid_solver.cpp:716-811) from IFEM_VEC_PRESENT into the context's nodal stress
  * (read by the next ifem_scns_assemble); host_out (may be NULL) receives [dim][dim][n_unodes_local] */
 int ifem_update_stress(ifem_ctx *ctx, double viscosity, double *host_out);

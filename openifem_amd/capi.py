@@ -73,7 +73,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_rhs_norm", "ifem_ins_newton_step", "ifem_system_vmult", "ifem_uu_vmult", "ifem_precond_vmult", "ifem_export_csr",
            "ifem_get_timing", "ifem_set_profiling", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
            "ifem_scns_assemble", "ifem_scns_solve", "ifem_scns_newton_step", "ifem_imex_assemble", "ifem_imex_solve",
-           "ifem_imex_step"]
+           "ifem_imex_step", "ifem_set_eddy_viscosity"]
 
 _lib = None
 
@@ -127,6 +127,7 @@ def load():
     L.ifem_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.ifem_set_ainv_kind.argtypes = [C.c_void_p, C.c_int]
     L.ifem_set_scns_fields.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifem_set_eddy_viscosity.argtypes = [C.c_void_p, C.c_void_p]
     L.ifem_update_stress.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
     L.ifem_scns_assemble.argtypes = [C.c_void_p, C.POINTER(ScnsParams), C.c_int]
     L.ifem_imex_assemble.argtypes = [C.c_void_p, C.POINTER(InsParams), C.c_int, C.c_int]
@@ -257,6 +258,10 @@ class Context:
         st = SolveStats()
         self._chk(self.L.ifem_imex_step(self.h, C.byref(params), C.byref(self.opts), int(apply_nonzero), int(assemble_system), C.byref(st)))
         return st
+
+    def set_eddy_viscosity(self, nodal):
+        a = None if nodal is None else np.ascontiguousarray(nodal, float)
+        self._chk(self.L.ifem_set_eddy_viscosity(self.h, None if a is None else a.ctypes.data_as(C.c_void_p)))
 
     def scns_assemble(self, params, use_nonzero):
         self._chk(self.L.ifem_scns_assemble(self.h, C.byref(params), int(use_nonzero)))

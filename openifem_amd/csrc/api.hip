@@ -372,6 +372,13 @@ int ifem_set_scns_fields(ifem_ctx *ctx, const double *sigma_pml, const double *b
   IFEM_API_END
 }
 
+int ifem_set_eddy_viscosity(ifem_ctx *ctx, const double *nodal) {
+  IFEM_API_BEGIN
+  if (nodal) ctx->eddy_viscosity.upload(nodal, (size_t)ctx->nUl, ctx->stream); else ctx->eddy_viscosity.release();
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+
 int ifem_update_stress(ifem_ctx *ctx, double viscosity, double *host_out) {
   IFEM_API_BEGIN
   launch_update_stress(ctx, viscosity);

@@ -39,6 +39,7 @@ struct ScnsArgs {
   const double *fsi_stress; // [NS][nUl] or nullptr
   const double *sigma_pml;  // [n_cells][NQ] or nullptr
   const double *body_force; // [n_cells][NQ][DIM] or nullptr
+  const double *eddy;       // [nUl] nodal eddy viscosity or nullptr
   double mu, rho_f, rho_s, dt;
   double g[3];
   int n_neumann;
@@ -82,7 +83,7 @@ struct ScnsScratch {
   double gP[G_::NQ * G_::NP * DIM];
   QPoint<DIM> qp[G_::NQ];
   double ue[G_::NU * DIM], u0e[G_::NU * DIM], ae[G_::NU * DIM], pe[G_::NP], p0e[G_::NP];
-  double se[DIM * DIM * G_::NU], fse[G_::NS * G_::NU];
+  double se[DIM * DIM * G_::NU], fse[G_::NS * G_::NU], eve[G_::NU];
   double fe[G_::ND], cv[G_::ND];
   int64_t rs_uu[G_::NU], rs_bt[G_::NU], rs_b[G_::NP], rs_pp[G_::NP];
   int32_t len_uu[G_::NU], len_bt[G_::NU], len_b[G_::NP], len_pp[G_::NP];
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(64 * WPB) void k_scns_assemble(ScnsArgs A) {
     }
     for (int k = 0; k < DIM * DIM; ++k) S.se[k * NU + a] = A.stress ? A.stress[int64_t(k) * A.nUl + nd] : 0.0;
     for (int k = 0; k < NS; ++k) S.fse[k * NU + a] = A.fsi_stress ? A.fsi_stress[int64_t(k) * A.nUl + nd] : 0.0;
+    S.eve[a] = (A.eddy && !inc) ? A.eddy[nd] : 0.0;
   }
   for (int b = lane; b < NP; b += 64) {
     const int32_t nd = A.cell_pnodes[cc * NP + b];
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(64 * WPB) void k_scns_assemble(ScnsArgs A) {
         S.gP[(q * NP + b) * DIM + d] = g;
       }
     double u[DIM], u0[DIM], acc[DIM], G[DIM * DIM], gp[DIM], sg[DIM * DIM * DIM], fs[NS];
-    double pr = 0, p0 = 0;
+    double pr = 0, p0 = 0, evq = 0;
     for (int c = 0; c < DIM; ++c) { u[c] = 0; u0[c] = 0; acc[c] = 0; gp[c] = 0; }
     for (int i = 0; i < DIM * DIM; ++i) G[i] = 0;
     for (int i = 0; i < DIM * DIM * DIM; ++i) sg[i] = 0;
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(64 * WPB) void k_scns_assemble(ScnsArgs A) {
       for (int k = 0; k < DIM * DIM; ++k)
         for (int d = 0; d < DIM; ++d) sg[k * DIM + d] += S.se[k * NU + a] * ga[d];
       for (int k = 0; k < NS; ++k) fs[k] += N * S.fse[k * NU + a];
+      evq += N * S.eve[a];
     }
     for (int b = 0; b < NP; ++b) {
       pr += T.psi[q * NP + b] * S.pe[b];
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(64 * WPB) void k_scns_assemble(ScnsArgs A) {
     }
     const double sigma = (A.sigma_pml && !inc) ? A.sigma_pml[cc * NQ + q] : 0.0;
     const double rho = inc ? A.rho_f : A.rho_f * (1 + p0 / atm) * (1 - ind) + ind * A.rho_s; // :210-213 | insim_supg :109
-    const double visc = (ind == 1 ? 1.0 : A.mu);                              // :214-216 (no turbulence model)
+    const double visc = (ind == 1 ? 1.0 : A.mu) + (evq > 0.0 ? evq : 0.0);    // :214-216
     // UGN length scale: first ND/(DIM+1) system shape functions in deal.II's vertex-major order (:252-258)
     double h = 0;
     for (int a = 0; a < ND / (DIM + 1); ++a) {
@@ -450,6 +453,7 @@ void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonz
   A.fsi_stress = ctx->fsi_stress.n ? ctx->fsi_stress.p : nullptr;
   A.sigma_pml = ctx->sigma_pml.n ? ctx->sigma_pml.p : nullptr;
   A.body_force = ctx->body_force.n ? ctx->body_force.p : nullptr;
+  A.eddy = ctx->eddy_viscosity.n ? ctx->eddy_viscosity.p : nullptr;
   A.mu = p->viscosity; A.rho_f = p->rho; A.rho_s = p->solid_rho; A.dt = p->dt;
   if (p->formulation != IFEM_FORM_SCNSIM && p->formulation != IFEM_FORM_SUPG_INSIM) throw Error(IFEM_E_BADPARAM, "ifem_scns_params.formulation");
   A.inc = p->formulation == IFEM_FORM_SUPG_INSIM;

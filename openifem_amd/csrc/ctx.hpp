@@ -154,7 +154,7 @@ struct ifem_ctx {
   ifem::PlanarCsr B;   // rows: owned pressure nodes, cols: local velocity nodes, bs = dim   (block (1,0))
   ifem::PlanarCsr Mp;  // rows: owned pressure nodes, cols: local pressure nodes, bs = 1     (mass (1,1))
   // SCnsIM (slightly compressible, SUPG): pressure-pressure block on the M_p pattern, nodal stress fields, cell fields
-  ifem::DBuf<double> App, app_diag, stress, fsi_stress, sigma_pml, body_force, xinv;
+  ifem::DBuf<double> App, app_diag, stress, fsi_stress, sigma_pml, body_force, xinv, eddy_viscosity;
   bool has_app = false, stress_valid = false;
   // cell colouring: cells of one colour share no node, so a launch over one colour scatters with plain read-modify-write
   // instead of atomics (gfx950 retires f64 atomics at ~24 G 64-byte segments/s whatever the scope; plain RMW is 2-5x faster)

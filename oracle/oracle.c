@@ -1010,8 +1010,9 @@ static void scns_cell(const orc_system *s, const orc_scns_params *P, int cell, c
     /* fields (:152-206) */
     double u[MAXD] = {0}, G[MAXD][MAXD] = {{0}}, pr = 0, gp[MAXD] = {0}, u0[MAXD] = {0}, p0 = 0, acc[MAXD] = {0};
     double sgrad[MAXD][MAXD][MAXD] = {{{0}}}; /* d_k sigma_ij */
-    double fsi_s[6] = {0};
+    double fsi_s[6] = {0}, evq = 0;
     for (int a = 0; a < nu; ++a) {
+      if (P->eddy_viscosity && !inc) evq += s->feu.phi[q][a] * P->eddy_viscosity[un[a]]; /* scalar_fe get_function_values (:198-203) */
       for (int c = 0; c < dim; ++c) {
         const double ue = eval[dim * un[a] + c];
         u[c] += s->feu.phi[q][a] * ue;
@@ -1038,7 +1039,7 @@ static void scns_cell(const orc_system *s, const orc_scns_params *P, int cell, c
     double bf[MAXD] = {0};
     if (P->body_force) for (int d = 0; d < dim; ++d) bf[d] = P->body_force[((size_t)cell * nq + q) * dim + d];
     const double rho = inc ? P->rho : P->rho * (1 + p0 / atm) * (1 - ind) + ind * P->solid_rho; /* :210-213 | insim_supg :109 */
-    const double viscosity = (ind == 1 ? 1 : P->mu);                              /* :214-216, no turbulence model */
+    const double viscosity = (ind == 1 ? 1 : P->mu) + (evq > 0.0 ? evq : 0.0);    /* :214-216 */
     for (int k = 0; k < nd; ++k) {
       for (int c = 0; c < dim; ++c) { phi_u[k][c] = 0; grad_phi_p[k][c] = 0; for (int d = 0; d < dim; ++d) grad_phi_u[k][c][d] = 0; }
       div_phi_u[k] = 0; phi_p[k] = 0;

@@ -132,6 +132,8 @@ typedef struct {
   const double *fsi_stress; /* [dim(dim+1)/2][n_unodes] nodal FSI stress or NULL */
   const double *sigma_pml;  /* [n_cells][n_q] or NULL */
   const double *body_force; /* [n_cells][n_q][dim] or NULL */
+  const double *eddy_viscosity; /* [n_unodes] nodal eddy viscosity of an attached turbulence model (mpi_scnsim.cpp:198-216:
+                                   viscosity_q += max(nu_t(q), 0)) or NULL */
   int32_t formulation;      /* 0: SCnsIM (source/mpi_scnsim.cpp:137-563); 1: SUPGInsIM, the incompressible SUPG/PSPG/LSIC
                                integrand of source/mpi_insim_supg.cpp:100-262 (constant density, div-free continuity, no
                                PML / stress / FSI terms).  Pinned by tests/fluid_pressure_driven_mpi_insim_supg (vmax

@@ -31,7 +31,8 @@ class ScnsParams(C.Structure):
     _fields_ = [("mu", C.c_double), ("rho", C.c_double), ("dt", C.c_double), ("solid_rho", C.c_double),
                 ("g", C.c_double * 3), ("n_neumann", C.c_int32), ("neumann_id", C.c_int32 * 8),
                 ("neumann_p", C.c_double * 8), ("stress", C.c_void_p), ("fsi_stress", C.c_void_p),
-                ("sigma_pml", C.c_void_p), ("body_force", C.c_void_p), ("formulation", C.c_int32)]
+                ("sigma_pml", C.c_void_p), ("body_force", C.c_void_p), ("eddy_viscosity", C.c_void_p),
+                ("formulation", C.c_int32)]
 
 
 FULL_SOLVE = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double),
@@ -111,7 +112,7 @@ def _ptr(a):
 
 
 def make_scns_params(mu, rho, dt, solid_rho=1.0, g=(0, 0, 0), neumann=None, stress=None, fsi_stress=None,
-                     sigma_pml=None, body_force=None, formulation=0):
+                     sigma_pml=None, body_force=None, formulation=0, eddy_viscosity=None):
     """formulation 0: SCnsIM, 1: SUPGInsIM (mpi_insim_supg.cpp)"""
     p = ScnsParams()
     p.formulation = formulation
@@ -123,8 +124,8 @@ def make_scns_params(mu, rho, dt, solid_rho=1.0, g=(0, 0, 0), neumann=None, stre
     for k, (bid, val) in enumerate(sorted(neumann.items())):
         p.neumann_id[k] = bid
         p.neumann_p[k] = val
-    p._keep = [None if a is None else np.ascontiguousarray(a, float) for a in (stress, fsi_stress, sigma_pml, body_force)]
-    p.stress, p.fsi_stress, p.sigma_pml, p.body_force = [_ptr(a) for a in p._keep]
+    p._keep = [None if a is None else np.ascontiguousarray(a, float) for a in (stress, fsi_stress, sigma_pml, body_force, eddy_viscosity)]
+    p.stress, p.fsi_stress, p.sigma_pml, p.body_force, p.eddy_viscosity = [_ptr(a) for a in p._keep]
     return p
 
 

@@ -38,6 +38,7 @@ def test_scns_assembly_matches_oracle_with_every_term(dim, kv, reps, use_nonzero
     sigma = rng.uniform(0, 3, (m.n_cells, nq))
     bf = rng.standard_normal((m.n_cells, nq, dim))
     fsi_stress = rng.standard_normal((dim * (dim + 1) // 2, m.n_unodes))
+    eddy = 0.02 * rng.standard_normal(m.n_unodes)  # both signs: only the positive part of nu_t(q) counts
     kw = dict(mu=0.03, rho=1.2, dt=0.01, solid_rho=3.0, g=(0.3, -9.8, 0.5)[:dim], neumann={1: 2.5})
     # projected stress of the present solution: oracle vs HIP
     S = orc.System(m)
@@ -52,7 +53,7 @@ def test_scns_assembly_matches_oracle_with_every_term(dim, kv, reps, use_nonzero
     S = orc.System(m)
     S.set_constraints(0, dofs, None)
     S.set_constraints(1, dofs, vals)
-    Po = orc.make_scns_params(stress=st_o, fsi_stress=fsi_stress, sigma_pml=sigma, body_force=bf, **kw)
+    Po = orc.make_scns_params(stress=st_o, fsi_stress=fsi_stress, sigma_pml=sigma, body_force=bf, eddy_viscosity=eddy, **kw)
     S.scns_assemble(Po, use_nonzero, ev, pr, acc)
     Ao, bo = S.csr("A"), S.rhs()
     ctx.set_constraints(0, dofs, None)
@@ -60,6 +61,7 @@ def test_scns_assembly_matches_oracle_with_every_term(dim, kv, reps, use_nonzero
     ctx.set_indicator(ind)
     ctx.vec_set(capi.VEC_FSI_ACC, acc)
     ctx.set_scns_fields(sigma, bf, fsi_stress)
+    ctx.set_eddy_viscosity(eddy)
     ctx.scns_assemble(capi.make_scns_params(**kw), use_nonzero)
     A, b = ctx.export_csr(0), ctx.vec_get(capi.VEC_RHS)
     assert abs(A - Ao).max() / abs(Ao).max() < 1e-11
