@@ -207,6 +207,32 @@ int ifemx_partition_tables(void *hv, int64_t *l2g_u, int64_t *l2g_p, int32_t *ne
   });
 }
 
+// 2-deep pressure halo plan of the distributed explicit S_m: out = [box_lo[3], box_n[3], lattice_n[3], n_send_s, n_far]
+// (all zero when the plan is not available); tables sized accordingly
+int ifemx_sm_plan_sizes(void *hv, int64_t *out) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto fill = [&](auto &s) {
+      auto &p = s.partition();
+      for (int d = 0; d < 3; ++d) { out[d] = p.sm_box_lo[d]; out[3 + d] = p.sm_box_n[d]; out[6 + d] = p.p_lattice_n[d]; }
+      out[9] = (int64_t)p.send_s_idx.size();
+      out[10] = p.recv_s_ptr.empty() ? 0 : p.recv_s_ptr.back();
+    };
+    if (h->dim == 2) fill(*h->s2); else fill(*h->s3);
+  });
+}
+int ifemx_sm_plan_tables(void *hv, int32_t *box_id, int32_t *send_s_ptr, int32_t *send_s_idx, int32_t *recv_s_ptr) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto fill = [&](auto &s) {
+      auto &p = s.partition();
+      auto cp = [](auto &v, auto *dst) { if (!v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+      cp(p.sm_box_id, box_id); cp(p.send_s_ptr, send_s_ptr); cp(p.send_s_idx, send_s_idx); cp(p.recv_s_ptr, recv_s_ptr);
+    };
+    if (h->dim == 2) fill(*h->s2); else fill(*h->s3);
+  });
+}
+
 #define DISPATCH(h, expr2, expr3) (static_cast<Handle *>(h)->dim == 2 ? (expr2) : (expr3))
 
 int ifemx_run(void *hv) {

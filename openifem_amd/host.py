@@ -54,6 +54,8 @@ def _lib():
     L.ifemx_set_node_order.argtypes = [C.c_void_p, C.c_int]
     L.ifemx_partition_sizes.argtypes = [C.c_void_p, C.c_void_p]
     L.ifemx_partition_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 9
+    L.ifemx_sm_plan_sizes.argtypes = [C.c_void_p, C.c_void_p]
+    L.ifemx_sm_plan_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     L.ifemx_channel_state.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_double]
     L._ifemx_bound = True
     return L
@@ -167,6 +169,20 @@ class FluidSolver:
                  "recv_p_ptr"]
         self._chk(self.L.ifemx_partition_tables(self.h, *[t[k].ctypes.data_as(C.c_void_p) for k in order]))
         t.update(z)
+        return t
+
+    def sm_plan(self):
+        """2-deep pressure halo plan of the distributed explicit S_m (None when a block is narrower than two cells)"""
+        z = np.zeros(11, np.int64)
+        self._chk(self.L.ifemx_sm_plan_sizes(self.h, z.ctypes.data_as(C.c_void_p)))
+        if z[3] == 0:
+            return None
+        nn = self.partition_sizes()["n_neighbors"]
+        t = dict(box_lo=z[0:3].copy(), box_n=z[3:6].copy(), lattice_n=z[6:9].copy(), n_far=int(z[10]),
+                 box_id=np.zeros(int(z[3] * z[4] * z[5]), np.int32), send_s_ptr=np.zeros(nn + 1, np.int32),
+                 send_s_idx=np.zeros(int(z[9]), np.int32), recv_s_ptr=np.zeros(nn + 1, np.int32))
+        self._chk(self.L.ifemx_sm_plan_tables(self.h, *[t[k].ctypes.data_as(C.c_void_p) for k in
+                                                        ("box_id", "send_s_ptr", "send_s_idx", "recv_s_ptr")]))
         return t
 
     def global_dofs(self):

@@ -60,6 +60,32 @@ def _worker(rank, world, port, P, reps, dim, q):
             for k, rbuf in bufs:
                 x[no + rp[k]:no + rp[k + 1]] = rbuf.numpy()
             assert np.abs(x - f(l2g)).max() == 0.0, f"halo {which}: ghost values differ from the owners'"
+        # (b2) the 2-deep pressure halo plan of the distributed explicit S_m: after the exchange every node of the lattice box
+        #      "owned range +-2" carries f(global id) at its S_m column id
+        sm = s.sm_plan()
+        if sm is not None:
+            lo, bn, N = sm["box_lo"], sm["box_n"], sm["lattice_n"]
+            zz, yy, xx = np.meshgrid(np.arange(bn[2]) + lo[2], np.arange(bn[1]) + lo[1], np.arange(bn[0]) + lo[0], indexing="ij")
+            gid = ((zz * N[1] + yy) * N[0] + xx).ravel()
+            f1 = lambda g: np.sin(0.37 * g)
+            xs = np.zeros(nPo + sm["n_far"])
+            xs[:nPo] = f1(t["l2g_p"][:nPo])
+            sp, si, rp = sm["send_s_ptr"], sm["send_s_idx"], sm["recv_s_ptr"]
+            reqs, bufs = [], []
+            for k, nb in enumerate(t["neighbors"]):
+                sbuf = torch.from_numpy(np.ascontiguousarray(xs[si[sp[k]:sp[k + 1]]]))
+                rbuf = torch.zeros(int(rp[k + 1] - rp[k]), dtype=torch.float64)
+                bufs.append((k, rbuf))
+                if sbuf.numel():
+                    reqs.append(dist.isend(sbuf, int(nb)))
+                if rbuf.numel():
+                    reqs.append(dist.irecv(rbuf, int(nb)))
+            for r in reqs:
+                r.wait()
+            for k, rbuf in bufs:
+                xs[nPo + rp[k]:nPo + rp[k + 1]] = rbuf.numpy()
+            assert sm["box_id"].min() >= 0 and len(np.unique(sm["box_id"])) == len(sm["box_id"]) == len(xs)
+            assert np.abs(xs[sm["box_id"]] - f1(gid)).max() == 0.0, "2-deep pressure halo: values differ from the owners'"
         # (c) local connectivity maps to the global lattice connectivity; every global cell touching an owned node is local
         from boxmesh import BoxMesh
         m = BoxMesh(reps, (0,) * dim, p1, kv=2)
@@ -87,7 +113,8 @@ def _worker(rank, world, port, P, reps, dim, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,P,reps,dim", [(2, (2, 1, 1), (4, 2, 2), 3), (4, (2, 2, 1), (4, 4, 2), 3), (2, (2, 1), (6, 3), 2)])
+@pytest.mark.parametrize("world,P,reps,dim", [(2, (2, 1, 1), (4, 2, 2), 3), (4, (2, 2, 1), (4, 4, 2), 3), (2, (2, 1), (6, 3), 2),
+                                               (4, (2, 2, 1), (8, 6, 3), 3)])
 def test_block_partition_over_gloo(world, P, reps, dim):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
