@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--inner-rel", type=float, default=1e-2)
     ap.add_argument("--ainv", type=int, default=3, help="IFEM_AINV_* kind of the A_uu^-1 replacement (3 = matrix-free inner operator, 1 = fp32 inner matrix, 0 = fp64 matrix)")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
+    ap.add_argument("--outer-mf", type=int, default=0, help="experiment: apply the u-u block of the OUTER operator matrix-free too")
     ap.add_argument("--solver", default="insim", choices=["insim", "insimex"],
                     help="insim (default, the BASELINE metric): one Newton iteration of MPI::InsIM; insimex: one steady-state "
                          "time step of MPI::InsIMEX (rhs-only assembly + solve), reported as a side measurement")
@@ -157,6 +158,7 @@ def main():
     n_dofs_global = solver.global_dofs() if world > 1 else n_u + n_p
     solver.opts.inner_rel = args.inner_rel
     solver.opts.ainv_kind = args.ainv
+    solver.opts.outer_matrix_free = args.outer_mf
     solver.opts.verbose = args.verbose if rank == 0 else 0
     solver.channel_state()
     solver.set_profiling(True)
@@ -236,7 +238,7 @@ def main():
                        "assemble_ms": t_asm / args.steps * 1e3, "solve_ms": t_solve / args.steps * 1e3,
                        "assemble_kernel_ms": tm.assemble_kernel_ms, "setup_s": t_setup,
                        "fgmres_iters": last.fgmres_iters, "cg_mp_iters": last.cg_mp_iters,
-                       "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "ainv_kind": args.ainv,
+                       "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "ainv_kind": args.ainv, "outer_matrix_free": args.outer_mf,
                        "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms,
                        "mf_apply_ms": mf_ms / max(mf_calls, 1), "mf_applies": mf_calls},
             "roofline": roof,

@@ -113,9 +113,12 @@ typedef struct {
   int32_t ainv_kind;          /* IFEM_AINV_* */
   int32_t inner_restart, inner_maxit;
   double  inner_rel;          /* relative residual target of the inner A_uu solve */
-  int32_t explicit_schur;     /* 1: form S_m = B diag(M_u)^-1 B^T explicitly like the reference (single GPU);
-                                 0 (and always on several GPUs): apply it matrix-free as two SpMVs */
+  int32_t explicit_schur;     /* 1: form S_m = B diag(M_u)^-1 B^T explicitly like the reference (on several GPUs this
+                                 needs the 2-deep pressure halo plan of ifem_partition); 0: apply it as two SpMVs */
   int32_t verbose;
+  int32_t outer_matrix_free;  /* 0 (default): the outer FGMRES operator is the assembled block matrix, as in the reference;
+                                 1: its velocity-velocity block is applied matrix-free (same operator to 1e-12, a
+                                 fifth of the time) -- an experiment switch, off by default */
 } ifem_solver_opts;
 
 /* counters of the last ifem_solve (the timer2 sections of mpi_insim.cpp:70,87,125) */

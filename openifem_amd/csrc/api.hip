@@ -35,6 +35,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
   o->mp_rel = 1e-6; o->mp_abs = 1e-10; o->sm_rel = 1e-3; o->sm_abs = 1e-10;
   o->ainv_kind = IFEM_AINV_GMRES_BJACOBI; o->inner_restart = 30; o->inner_maxit = 400; o->inner_rel = 1e-2;
   o->explicit_schur = 1;
+  o->outer_matrix_free = 0;
   o->verbose = 0;
 }
 

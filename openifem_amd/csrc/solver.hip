@@ -265,7 +265,12 @@ static void system_apply(SolveState &S, const double *x, double *y, bool time_it
   const double *xu, *xp;
   extend_u(S, x, &xu);
   extend_p(S, x + S.nuo, &xp);
-  spmv_uu(c, xu, xp, y, false);
+  if (S.o->outer_matrix_free && c->mf_valid && !c->has_app) { // experiment: A_uu x_u without the stored matrix
+    apply_uu_mf(c, xu, y);
+    spmv_bt(c, xp, S.tu);
+    v_axpy(c, S.nuo, 1.0, S.tu, y);
+  } else
+    spmv_uu(c, xu, xp, y, false);
   spmv_b(c, xu, y + S.nuo);
   if (c->has_app) { // SCnsIM: y_p += A_pp x_p
     spmv_app(c, xp, S.tp[5]);
