@@ -393,3 +393,39 @@ def test_assembly_matches_committed_golden_vectors(dim):
     b = ctx.vec_get(capi.VEC_RHS)
     assert np.abs(b - g[f"asm{dim}_rhs"]).max() / np.abs(g[f"asm{dim}_rhs"]).max() < 1e-11
     ctx.close()
+
+
+def test_config1_fluid_cavity_first_steps_match_oracle():
+    # BASELINE config 1 "tests/fluid_cavity": lid-driven cavity, hyper_cube refined 5 times (1024 cells, 9539 DoF), all
+    # velocity Dirichlet (pressure defined up to a constant), the reference's own .prm with the end time cut to 3 steps;
+    # the reference test asserts nothing, so the check is the oracle's velocity field and pressure range
+    import os
+    from openifem_amd import host
+    prm = open(os.path.join(os.path.dirname(__file__), "golden", "prm", "fluid_cavity.prm")).read()
+    prm = prm.replace("set End time = 3e0", "set End time = 3e-2")
+    flow = host.InsIM(prm, (1, 1), (0, 0), (1.0, 1.0))
+    flow.opts.inner_rel = 1e-3
+    flow.opts.inner_maxit = 4000
+    flow.run()
+    v, p = flow.get_current_solution()
+    uc, pc = flow.node_coords()
+    m = BoxMesh([32, 32], (0, 0), (1.0, 1.0), kv=2)
+    assert len(v) + len(p) == m.n_dofs == 9539
+    S = orc.System(m)
+    dofs, vals = m.dirichlet({0: (3, [0, 0]), 1: (3, [0, 0]), 2: (3, [0, 0]), 3: (3, [1, 0])})
+    S.set_constraints(1, dofs, vals)
+    S.set_constraints(0, dofs, None)
+    x = np.zeros(S.n)
+    P = orc.make_params(mu=0.01, rho=1, gamma=1.0, dt=1e-2)
+    ainv = orc.SpluAinv()
+    for step in range(3):
+        rc, _ = S.run_one_step(P, step == 0, x, ainv=ainv)
+        assert rc > 0
+    # match nodes by coordinates (the host mirror numbers along a Morton curve)
+    key = lambda c: np.lexsort((np.round(c[:, 0] * 4096).astype(int), np.round(c[:, 1] * 4096).astype(int)))
+    iu, ou = key(uc), key(m.unode_coords)
+    vg, vo = v.reshape(-1, 2)[iu], x[:S.n_u].reshape(-1, 2)[ou]
+    assert np.abs(vg - vo).max() < 1e-5 * np.abs(vo).max()
+    ip, op = key(pc), key(m.pnode_coords)
+    pg, po = p[ip], x[S.n_u:][op]
+    assert np.abs((pg - pg.mean()) - (po - po.mean())).max() < 1e-4 * (po.max() - po.min())
