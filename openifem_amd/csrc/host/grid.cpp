@@ -231,6 +231,107 @@ template void distribute_dofs_unstructured<2>(const Triangulation<2> &, int, DoF
 template void distribute_dofs_unstructured<3>(const Triangulation<3> &, int, DoFTables<3> &, PartitionTables &);
 
 template <int dim>
+void partition_unstructured(const DoFTables<dim> &g, int nranks, int rank, DoFTables<dim> &out, PartitionTables &part) {
+  constexpr int NV = 1 << dim;
+  const int nu = g.nu;
+  const size_t nc = g.cell_unodes.size() / nu;
+  if (nranks < 1 || rank < 0 || rank >= nranks) throw std::invalid_argument("partition_unstructured: bad rank");
+  // 1. strips of equal cell count along x (centroid), ties by y
+  std::vector<size_t> order(nc);
+  std::iota(order.begin(), order.end(), size_t(0));
+  auto centroid = [&](size_t c, int d) { double s = 0; for (int v = 0; v < NV; ++v) s += g.vcoords[(c * NV + v) * dim + d]; return s / NV; };
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+    const double xa = centroid(a, 0), xb = centroid(b, 0);
+    if (xa != xb) return xa < xb;
+    const double ya = centroid(a, 1), yb = centroid(b, 1);
+    return ya != yb ? ya < yb : a < b;
+  });
+  std::vector<int> cell_rank(nc);
+  for (size_t k = 0; k < nc; ++k) cell_rank[order[k]] = (int)std::min<size_t>(k * nranks / nc, nranks - 1);
+  // 2. node owners: lowest rank among the cells around the node
+  std::vector<int> uown((size_t)g.n_unodes, nranks), pown((size_t)g.n_pnodes, nranks);
+  for (size_t c = 0; c < nc; ++c) {
+    for (int a = 0; a < nu; ++a) { int &o = uown[g.cell_unodes[c * nu + a]]; o = std::min(o, cell_rank[c]); }
+    for (int v = 0; v < NV; ++v) { int &o = pown[g.cell_pnodes[c * NV + v]]; o = std::min(o, cell_rank[c]); }
+  }
+  // 3. local cells and local node numbering of ANY rank t (needed for t = rank and for the neighbours' ghost lists)
+  struct Local { std::vector<size_t> cells; std::vector<int64_t> lu, lp; int64_t nuo = 0, npo = 0; };
+  auto build = [&](int t) {
+    Local L;
+    std::vector<char> useu((size_t)g.n_unodes, 0), usep((size_t)g.n_pnodes, 0);
+    for (size_t c = 0; c < nc; ++c) {
+      bool touch = false;
+      for (int a = 0; a < nu && !touch; ++a) touch = uown[g.cell_unodes[c * nu + a]] == t;
+      if (!touch) continue;
+      L.cells.push_back(c);
+      for (int a = 0; a < nu; ++a) useu[g.cell_unodes[c * nu + a]] = 1;
+      for (int v = 0; v < NV; ++v) usep[g.cell_pnodes[c * NV + v]] = 1;
+    }
+    auto number = [&](const std::vector<char> &use, const std::vector<int> &own, std::vector<int64_t> &l2g, int64_t &n_owned) {
+      for (int64_t i = 0; i < (int64_t)use.size(); ++i) if (use[i] && own[i] == t) l2g.push_back(i);
+      n_owned = (int64_t)l2g.size();
+      std::vector<std::pair<int, int64_t>> gh;
+      for (int64_t i = 0; i < (int64_t)use.size(); ++i) if (use[i] && own[i] != t) gh.push_back({own[i], i});
+      std::sort(gh.begin(), gh.end());
+      for (auto &x : gh) l2g.push_back(x.second);
+    };
+    number(useu, uown, L.lu, L.nuo);
+    number(usep, pown, L.lp, L.npo);
+    return L;
+  };
+  const Local me = build(rank);
+  // 4. local tables
+  out = DoFTables<dim>();
+  out.kv = g.kv; out.nu = nu; out.np = NV; out.morton = g.morton;
+  out.n_unodes = (int64_t)me.lu.size(); out.n_pnodes = (int64_t)me.lp.size();
+  out.n_unodes_owned = me.nuo; out.n_pnodes_owned = me.npo;
+  std::vector<int32_t> gu2l((size_t)g.n_unodes, -1), gp2l((size_t)g.n_pnodes, -1);
+  for (size_t i = 0; i < me.lu.size(); ++i) gu2l[me.lu[i]] = (int32_t)i;
+  for (size_t i = 0; i < me.lp.size(); ++i) gp2l[me.lp[i]] = (int32_t)i;
+  out.unode_coords.resize(me.lu.size()); out.pnode_coords.resize(me.lp.size());
+  for (size_t i = 0; i < me.lu.size(); ++i) out.unode_coords[i] = g.unode_coords[me.lu[i]];
+  for (size_t i = 0; i < me.lp.size(); ++i) out.pnode_coords[i] = g.pnode_coords[me.lp[i]];
+  const size_t nl = me.cells.size();
+  out.vcoords.resize(nl * NV * dim); out.cell_face_bid.resize(nl * 2 * dim);
+  out.cell_unodes.resize(nl * nu); out.cell_pnodes.resize(nl * NV);
+  for (size_t k = 0; k < nl; ++k) {
+    const size_t c = me.cells[k];
+    for (int i = 0; i < NV * dim; ++i) out.vcoords[k * NV * dim + i] = g.vcoords[c * NV * dim + i];
+    for (int f = 0; f < 2 * dim; ++f) out.cell_face_bid[k * 2 * dim + f] = g.cell_face_bid[c * 2 * dim + f];
+    for (int a = 0; a < nu; ++a) out.cell_unodes[k * nu + a] = gu2l[g.cell_unodes[c * nu + a]];
+    for (int v = 0; v < NV; ++v) out.cell_pnodes[k * NV + v] = gp2l[g.cell_pnodes[c * NV + v]];
+  }
+  // 5. halo plans: my ghosts owned by s arrive in global order; I send to s what s holds of my owned nodes, same order
+  part = PartitionTables();
+  part.rank = rank; part.nranks = nranks; part.P = {nranks, 1, 1};
+  part.l2g_u = me.lu; part.l2g_p = me.lp;
+  part.n_unodes_global = g.n_unodes; part.n_pnodes_global = g.n_pnodes; part.n_cells_global = (int64_t)nc;
+  part.send_u_ptr = {0}; part.recv_u_ptr = {0}; part.send_p_ptr = {0}; part.recv_p_ptr = {0};
+  for (int s = 0; s < nranks; ++s) {
+    if (s == rank) continue;
+    const Local other = build(s);
+    std::vector<int32_t> su, sp;
+    for (size_t i = (size_t)other.nuo; i < other.lu.size(); ++i) if (uown[other.lu[i]] == rank) su.push_back(gu2l[other.lu[i]]);
+    for (size_t i = (size_t)other.npo; i < other.lp.size(); ++i) if (pown[other.lp[i]] == rank) sp.push_back(gp2l[other.lp[i]]);
+    int32_t ru = 0, rp = 0;
+    for (size_t i = (size_t)me.nuo; i < me.lu.size(); ++i) if (uown[me.lu[i]] == s) ++ru;
+    for (size_t i = (size_t)me.npo; i < me.lp.size(); ++i) if (pown[me.lp[i]] == s) ++rp;
+    if (su.empty() && sp.empty() && !ru && !rp) continue;
+    part.neighbors.push_back(s);
+    part.send_u_idx.insert(part.send_u_idx.end(), su.begin(), su.end());
+    part.send_p_idx.insert(part.send_p_idx.end(), sp.begin(), sp.end());
+    part.send_u_ptr.push_back((int32_t)part.send_u_idx.size());
+    part.send_p_ptr.push_back((int32_t)part.send_p_idx.size());
+    part.recv_u_ptr.push_back(part.recv_u_ptr.back() + ru);
+    part.recv_p_ptr.push_back(part.recv_p_ptr.back() + rp);
+  }
+  if (part.recv_u_ptr.back() != out.n_unodes - out.n_unodes_owned || part.recv_p_ptr.back() != out.n_pnodes - out.n_pnodes_owned)
+    throw std::logic_error("partition_unstructured: ghost bookkeeping is inconsistent");
+}
+template void partition_unstructured<2>(const DoFTables<2> &, int, int, DoFTables<2> &, PartitionTables &);
+template void partition_unstructured<3>(const DoFTables<3> &, int, int, DoFTables<3> &, PartitionTables &);
+
+template <int dim>
 static void map_point(const double *X /*[NV][dim]*/, const double *xi, double *out) {
   for (int d = 0; d < dim; ++d) out[d] = 0;
   for (int v = 0; v < (1 << dim); ++v) {

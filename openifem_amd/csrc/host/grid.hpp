@@ -100,6 +100,12 @@ void distribute_dofs(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out
 // general (unstructured, single rank) variant: vertices, edge midpoints, cell centres; 2D only in this build
 template <int dim>
 void distribute_dofs_unstructured(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out, PartitionTables &part);
+// Partition of an unstructured mesh given by its GLOBAL tables (every rank builds them: these meshes are small) into the
+// tables of rank `rank` of `nranks`: cells are cut into strips of equal count along x (p4est / METIS stand-in: results
+// do not depend on the partition), a node belongs to the lowest rank among the cells around it, the local cells are all
+// cells touching an owned node ("owner computes row"), ghosts are grouped by owner in global order.
+template <int dim>
+void partition_unstructured(const DoFTables<dim> &global, int nranks, int rank, DoFTables<dim> &out, PartitionTables &part);
 
 // Dirichlet lines (dof, value) in block numbering [u|p]; `bcs`: id -> (component flag 1..7, values);
 // `hard_coded`: id -> f(point, component) overriding the constant values (add_hard_coded_boundary_condition).

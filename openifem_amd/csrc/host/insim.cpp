@@ -83,8 +83,12 @@ void FluidSolver<dim>::set_partition(const std::array<int, 3> &P, int rank, cons
 template <int dim>
 void FluidSolver<dim>::setup_dofs() {
   if (!triangulation.is_box) {
-    if (proc_grid[0] * proc_grid[1] * proc_grid[2] != 1) throw std::runtime_error("setup_dofs: unstructured triangulations run on one rank in this build");
+    const int nranks = proc_grid[0] * proc_grid[1] * proc_grid[2];
     distribute_dofs_unstructured<dim>(triangulation, (int)parameters.fluid_velocity_degree, dofs, part);
+    if (nranks > 1) { // every rank builds the (small) global tables and keeps its strip
+      const DoFTables<dim> global = dofs;
+      partition_unstructured<dim>(global, nranks, part_rank, dofs, part);
+    }
   } else
   distribute_dofs_box<dim>(triangulation.reps, triangulation.p0, triangulation.p1, triangulation.colorized,
                            (int)parameters.fluid_velocity_degree, proc_grid, part_rank, dofs, part);

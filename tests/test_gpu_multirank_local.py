@@ -248,3 +248,50 @@ def test_distributed_explicit_schur_matches_single_context(P, reps):
         for g, z in out:
             assert np.abs(z - ref[g]).max() <= 1e-7 * np.abs(ref).max(), explicit
         L.ifem_local_world_destroy(w)
+
+
+def _cyl_case(kind, prm_name, world_handle, P, rank, out, errs):
+    import os
+    from openifem_amd import host
+    try:
+        prm = open(os.path.join(os.path.dirname(__file__), "golden", "prm", prm_name)).read()
+        cls = {"InsIM": host.InsIM, "SCnsIM": host.SCnsIM}[kind]
+        flow = cls(prm, mesh="cylinder")
+        if kind == "InsIM":
+            flow.add_hard_coded_boundary_condition(0, lambda p, c, t: 4 * 0.3 * p[1] * (0.41 - p[1]) / (0.41 * 0.41) if (c == 0 and abs(p[0]) < 1e-10) else 0.0)
+            flow.opts.inner_rel = 1e-3
+            flow.opts.inner_maxit = 4000
+        else:
+            flow.add_hard_coded_boundary_condition(0, lambda p, c, t: 4 * 4.5 * p[1] * (0.41 - p[1]) / (0.41 * 0.41) if (c == 0 and abs(p[0]) < 1e-10 and t < 2e-2) else 0.0)
+        flow.set_partition(P, rank, local_world=world_handle)
+        flow.run()
+        v, p = flow.get_current_solution()
+        t = flow.partition_tables()
+        out[rank] = (v[:2 * t["n_unodes_owned"]].max(), p[:t["n_pnodes_owned"]].max(), t["n_unodes_owned"], t["n_unodes_global"])
+        flow.close()
+    except Exception:  # noqa
+        import traceback
+        errs.append((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("kind,prm,world,vref,pref", [("InsIM", "fluid_cylinder_mpi.prm", 2, 0.374235, 46.5226),
+                                                     ("SCnsIM", "fluid_cylinder_mpi_scnsim.prm", 2, 4.5, 1.03544),
+                                                     ("InsIM", "fluid_cylinder_mpi.prm", 3, 0.374235, 46.5226)])
+def test_cylinder_known_answers_on_partitioned_unstructured_mesh(kind, prm, world, vref, pref):
+    # configs 2 and 4 ("fluid_cylinder_mpi", "fluid_cylinder_mpi_scnsim ... 2 x MI355X") the way the reference runs them
+    # under mpirun: the unstructured cylinder mesh cut into strips (partition_unstructured), virtual ranks on one GPU
+    from openifem_amd import capi
+    L = capi.load()
+    w = C.c_void_p(L.ifem_local_world_create(world))
+    out, errs = [None] * world, []
+    th = [threading.Thread(target=_cyl_case, args=(kind, prm, w, (world, 1, 1), r, out, errs)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=900)
+    assert not errs, errs
+    assert sum(o[2] for o in out) == out[0][3]  # the owned nodes partition the global set
+    vmax, pmax = max(o[0] for o in out), max(o[1] for o in out)
+    assert abs(vmax - vref) / vref < 1e-3
+    assert abs(pmax - pref) / pref < 1e-3
+    L.ifem_local_world_destroy(w)

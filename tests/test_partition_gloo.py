@@ -29,9 +29,16 @@ def _worker(rank, world, port, P, reps, dim, q):
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         p1 = (2.0, 0.2, 0.2)[:dim]
-        s = host.InsIM(host.channel_prm(dim), reps, (0,) * dim, p1)
-        s.set_partition(P, rank)
-        s.setup_host_only(0)
+        cylinder = reps == "cylinder"
+        if cylinder:  # unstructured mesh cut into strips (partition_unstructured)
+            prm = open(os.path.join(ROOT, "tests", "golden", "prm", "fluid_cylinder_mpi.prm")).read()
+            s = host.InsIM(prm, mesh="cylinder")
+            s.set_partition(P, rank)
+            s.setup_host_only(1)
+        else:
+            s = host.InsIM(host.channel_prm(dim), reps, (0,) * dim, p1)
+            s.set_partition(P, rank)
+            s.setup_host_only(0)
         t = s.partition_tables()
         nUo, nUl, nPo, nPl = t["n_unodes_owned"], t["n_unodes_local"], t["n_pnodes_owned"], t["n_pnodes_local"]
         # (a) every global node is owned by exactly one rank
@@ -86,6 +93,24 @@ def _worker(rank, world, port, P, reps, dim, q):
                 xs[nPo + rp[k]:nPo + rp[k + 1]] = rbuf.numpy()
             assert sm["box_id"].min() >= 0 and len(np.unique(sm["box_id"])) == len(sm["box_id"]) == len(xs)
             assert np.abs(xs[sm["box_id"]] - f1(gid)).max() == 0.0, "2-deep pressure halo: values differ from the owners'"
+        if cylinder:
+            # (c') every global cell appears on at least one rank, local tables reproduce the global geometry
+            from cylmesh import CylinderMesh
+            m = CylinderMesh(1)
+            cu, cp, fb, vc = s.cell_tables()
+            uc, pc = s.node_coords()
+            # the vertex nodes of every local cell sit on the cell's vertices (node numbering itself is an implementation detail)
+            assert np.abs(pc[cp] - vc).max() == 0.0 and np.abs(uc[cu][:, [0, 2, 6, 8]] - vc).max() == 0.0
+            key = {tuple(np.round(r, 12)): i for i, r in enumerate(m.vcoords.reshape(m.n_cells, -1))}
+            mine = torch.zeros(m.n_cells, dtype=torch.int64)
+            for r in vc.reshape(len(vc), -1):
+                mine[key[tuple(np.round(r, 12))]] = 1
+            dist.all_reduce(mine)
+            assert int(mine.min()) >= 1
+            dist.barrier()
+            dist.destroy_process_group()
+            q.put((rank, "ok"))
+            return
         # (c) local connectivity maps to the global lattice connectivity; every global cell touching an owned node is local
         from boxmesh import BoxMesh
         m = BoxMesh(reps, (0,) * dim, p1, kv=2)
@@ -114,7 +139,7 @@ def _worker(rank, world, port, P, reps, dim, q):
 
 
 @pytest.mark.parametrize("world,P,reps,dim", [(2, (2, 1, 1), (4, 2, 2), 3), (4, (2, 2, 1), (4, 4, 2), 3), (2, (2, 1), (6, 3), 2),
-                                               (4, (2, 2, 1), (8, 6, 3), 3)])
+                                               (4, (2, 2, 1), (8, 6, 3), 3), (2, (2, 1, 1), "cylinder", 2), (3, (3, 1, 1), "cylinder", 2)])
 def test_block_partition_over_gloo(world, P, reps, dim):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
