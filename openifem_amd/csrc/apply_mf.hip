@@ -34,8 +34,8 @@ struct MfArgs {
   const double *x;     // ghost-extended input
   double *y;           // owned rows, zeroed by the caller
   double mu, rho, gamma, inv_dt;
-  int mode, xcd;
-  double *ycell;
+  int xcd;
+  double *ycell; // per-cell results of the two-stage scatter, or nullptr (atomic scatter)
   MfTables t;
 };
 
@@ -230,27 +230,6 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf(MfArgs A) {
     R = W;
   }
   // ---- scatter into owned, unconstrained rows
-  if (A.mode == 1) return;
-  if (A.mode == 3) {
-    for (int t = lane; t < DIM * NN; t += 64) A.ycell[cell * (DIM * NN) + t] = R[(t % DIM) * NN + t / DIM];
-    return;
-  }
-  if (A.mode == 2) {
-    __shared__ int32_t nodes[WPB][NN];
-    __shared__ uint8_t cfl[WPB][NN * DIM];
-    if (lane < NN) {
-      nodes[wave][lane] = my_node;
-      for (int c = 0; c < DIM; ++c) cfl[wave][lane * DIM + c] = my_c[c];
-    }
-    __syncthreads();
-    if (active)
-      for (int t = lane; t < DIM * NN; t += 64) {
-        const int a = t / DIM, c = t % DIM;
-        const int32_t nd = nodes[wave][a];
-        if (nd < A.nUo && !cfl[wave][t]) unsafeAtomicAdd(&A.y[int64_t(DIM) * nd + c], R[c * NN + a]);
-      }
-    return;
-  }
   if (active && lane < NN && my_node < A.nUo) {
 #pragma unroll
     for (int c = 0; c < DIM; ++c)
@@ -335,9 +314,8 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
         const int64_t dof = int64_t(DIM) * nd + c;
         const bool con = A.is_c ? A.is_c[dof] != 0 : false;
         S.flag[hl * DIM + c] = con;
-        if (A.mode == 5) { S.V[c * NN + hl] = double(dof & 255); S.V[(DIM + c) * NN + hl] = double(dof & 127); } else {
         S.V[c * NN + hl] = con ? 0.0 : A.x[dof];
-        if constexpr (CONV) S.V[(DIM + c) * NN + hl] = A.eval[dof]; }
+        if constexpr (CONV) S.V[(DIM + c) * NN + hl] = A.eval[dof];
       }
     }
     if (hl < NV * DIM) S.X[hl] = A.vcoords[cc * NV * DIM + hl];
@@ -531,7 +509,7 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
           const int a = t / DIM, c = t - a * DIM;
           A.ycell[cell * (DIM * NN) + t] = S.V[c * NN + a];
         }
-    } else if (active && A.mode != 4) {
+    } else if (active) {
       for (int t = hl; t < DIM * NN; t += 32) {
         const int a = t / DIM, c = t - a * DIM;
         const int32_t nd = S.node[a];
@@ -621,18 +599,13 @@ void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu) {
   a.mu = ctx->mf_params.viscosity; a.rho = ctx->mf_params.rho; a.gamma = ctx->mf_params.grad_div;
   a.inv_dt = 1.0 / ctx->mf_params.dt;
   mf_tables(a.t, ctx->kv);
-  { const char *e = getenv("IFEM_MF_MODE"); a.mode = e ? atoi(e) : 0; }
   { static const int xcd = [] { const char *e = getenv("IFEM_XCD"); return e ? atoi(e) : 1; }(); a.xcd = xcd; }
   a.ycell = nullptr;
-  if (a.mode == 3) {
-    const size_t need = size_t(ctx->n_cells) * ctx->dim * ctx->nu;
-    if (ctx->qdata.n < need) ctx->qdata.alloc(need);
-    a.ycell = ctx->qdata.p;
-  }
   const bool time_it = ctx->profile;
   // scatter: two-stage (per-cell results + per-node gather; atomics-free, deterministic) unless IFEM_MF_SCATTER=atomic
   static const bool want_atomic = [] { const char *e = getenv("IFEM_MF_SCATTER"); return e && std::string(e) == "atomic"; }();
-  const bool two_stage = !want_atomic && a.mode == 0 && ctx->n_cells < (int64_t(1) << 26) && ctx->nu <= 32;
+  static const int v1 = [] { const char *e = getenv("IFEM_MF_V1"); return e ? atoi(e) : 0; }(); // first version (one item per lane, atomic scatter)
+  const bool two_stage = !want_atomic && !v1 && ctx->n_cells < (int64_t(1) << 26) && ctx->nu <= 32;
   if (two_stage) {
     if (ctx->uinc.n_rows == 0 && ctx->nUo) build_incidence(ctx);
     const size_t need = size_t(ctx->n_cells) * ctx->dim * ctx->nu;
@@ -643,12 +616,10 @@ void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu) {
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s)); // the cell kernel alone (what rocprofv3 reports for it)
   constexpr int WPB = 4;
   const dim3 grid(unsigned((ctx->n_cells + WPB - 1) / WPB)), block(64 * WPB);
-  static const int v1 = [] { const char *e = getenv("IFEM_MF_V1"); return e ? atoi(e) : 0; }();
-  if (!v1 && (a.mode == 0 || a.mode >= 4)) {
+  if (!v1) {
     const int64_t n_pairs = (ctx->n_cells + 1) / 2;
     const dim3 g2(unsigned(std::min<int64_t>((n_pairs + WPB - 1) / WPB, 256 * 24)));
-    static const bool noconv_env = [] { const char *e = getenv("IFEM_MF_NOCONV"); return e && atoi(e); }(); // timing aid
-    const bool conv = !(ctx->mf_noconv || noconv_env);
+    const bool conv = !ctx->mf_noconv;
 #define IFEM_MF2(D, K)                                                                                                 \
   { if (conv) hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, true>), g2, block, 0, s, a);                                 \
     else hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, false>), g2, block, 0, s, a); }

@@ -6,8 +6,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 s = host.InsIM(host.channel_prm(3), (n, n, n), (0, 0, 0), (2.0, 0.2, 0.2))
 s.setup(0); s.channel_state(); s.assemble(False)
 L = s.L; ctx = s.ctx
-for mode in sys.argv[2].split(","):
-    os.environ["IFEM_MF_MODE"] = mode
+for mode in sys.argv[2].split(","):  # "mf" (matrix-free), "f32", "f64" (stored matrix)
     var = 3
     if mode == "f32": var = 1
     if mode == "f64": var = 0
