@@ -116,6 +116,8 @@ typedef struct {
   int32_t explicit_schur;     /* 1: form S_m = B diag(M_u)^-1 B^T explicitly like the reference (on several GPUs this
                                  needs the 2-deep pressure halo plan of ifem_partition); 0: apply it as two SpMVs */
   int32_t verbose;
+  int32_t device_cg;          /* 1 (default): single-rank CG(M_p) / CG(S_m) keep their recurrence scalars on the device and
+                                 the host checks the residual every 4 iterations; 0: one host round trip per dot product */
   int32_t outer_matrix_free;  /* 0 (default): the outer FGMRES operator is the assembled block matrix, as in the reference;
                                  1: its velocity-velocity block is applied matrix-free (same operator to 1e-12, a
                                  fifth of the time) -- an experiment switch, off by default */

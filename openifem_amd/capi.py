@@ -49,7 +49,7 @@ class SolverOpts(C.Structure):
                 ("fgmres_abs", C.c_double), ("mp_rel", C.c_double), ("mp_abs", C.c_double),
                 ("sm_rel", C.c_double), ("sm_abs", C.c_double), ("ainv_kind", C.c_int32),
                 ("inner_restart", C.c_int32), ("inner_maxit", C.c_int32), ("inner_rel", C.c_double),
-                ("explicit_schur", C.c_int32), ("verbose", C.c_int32), ("outer_matrix_free", C.c_int32)]
+                ("explicit_schur", C.c_int32), ("verbose", C.c_int32), ("device_cg", C.c_int32), ("outer_matrix_free", C.c_int32)]
 
 
 class SolveStats(C.Structure):

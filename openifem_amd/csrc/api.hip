@@ -36,6 +36,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
   o->ainv_kind = IFEM_AINV_GMRES_BJACOBI; o->inner_restart = 30; o->inner_maxit = 400; o->inner_rel = 1e-2;
   o->explicit_schur = 1;
   o->outer_matrix_free = 0;
+  o->device_cg = 1;
   o->verbose = 0;
 }
 

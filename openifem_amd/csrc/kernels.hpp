@@ -76,6 +76,11 @@ void v_mdot_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, con
 void v_maxpy_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, const double *h_host, double *w, double *norm2_out);
 void v_scale_store_f32(ifem_ctx *ctx, int64_t n, double a, const double *w, float *v);
 void bjac_apply_f32(ifem_ctx *ctx, const float *x, double *y);
+// CG with device-resident recurrence scalars (single rank): init, alpha = rz / <p,q>, update of x, r, z, p; cgd_rr syncs
+void cgd_init(ifem_ctx *ctx, int64_t n, const double *b, const double *diag, double *x, double *r, double *z, double *p);
+void cgd_alpha(ifem_ctx *ctx, int64_t n, const double *p, const double *q);
+void cgd_update(ifem_ctx *ctx, int64_t n, const double *diag, double *p, const double *q, double *x, double *r, double *z);
+double cgd_rr(ifem_ctx *ctx);
 void v_minmax(ifem_ctx *ctx, int64_t n, const double *x, double *mn, double *mx);
 // x[dof] = value for constrained dofs (AffineConstraints::distribute, Dirichlet lines)
 void apply_constraints(ifem_ctx *ctx, int which, double *x);

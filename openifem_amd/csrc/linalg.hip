@@ -718,6 +718,84 @@ void v_scale_store_f32(ifem_ctx *ctx, int64_t n, double a, const double *w, floa
   if (n) hipLaunchKernelGGL(k_scale_store_f32, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, w, v);
 }
 
+// ---- CG with the recurrence scalars on the device: no host round trip per iteration (the host only looks at the
+// residual every few iterations).  Scalars live in ctx->scal[160..]: rr, rz, pq, alpha, beta.
+constexpr int CGD = 160;
+__global__ __launch_bounds__(256) void k_cgd_init(int64_t n, const double *__restrict__ b, const double *__restrict__ diag,
+                                                  double *__restrict__ x, double *__restrict__ r, double *__restrict__ z,
+                                                  double *__restrict__ p, double *__restrict__ part) {
+  double acc[2] = {0, 0};
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const double ri = b[i], zi = diag ? ri / (diag[i] != 0.0 ? diag[i] : 1.0) : ri;
+    x[i] = 0.0; r[i] = ri; p[i] = zi;
+    if (diag) z[i] = zi;
+    acc[0] += ri * ri; acc[1] += ri * zi;
+  }
+  block_reduce_store<2>(acc, part);
+}
+// one block: sums the partials of `nrow` dot products and advances the recurrence
+//   stage 0: rr, rz            stage 1: pq -> alpha = rz / pq            stage 2: rr', rz' -> beta = rz' / rz
+__global__ __launch_bounds__(256) void k_cgd_scalars(int nblk, const double *__restrict__ part, double *__restrict__ sc, int stage) {
+  __shared__ double sh[2][4];
+  double t[2] = {0, 0};
+  const int nrow = stage == 1 ? 1 : 2;
+  for (int k = 0; k < nrow; ++k)
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) t[k] += part[int64_t(k) * MDOT_MAXB + i];
+  for (int k = 0; k < 2; ++k) {
+    for (int off = 32; off > 0; off >>= 1) t[k] += __shfl_xor(t[k], off, 64);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = t[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double a = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], b = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    if (stage == 0) { sc[CGD + 0] = a; sc[CGD + 1] = b; }
+    else if (stage == 1) { sc[CGD + 2] = a; sc[CGD + 3] = a != 0.0 ? sc[CGD + 1] / a : 0.0; }
+    else { sc[CGD + 4] = sc[CGD + 1] != 0.0 ? b / sc[CGD + 1] : 0.0; sc[CGD + 0] = a; sc[CGD + 1] = b; }
+  }
+}
+__global__ __launch_bounds__(256) void k_cgd_update(int64_t n, const double *__restrict__ sc, const double *__restrict__ diag,
+                                                    const double *__restrict__ p, const double *__restrict__ q,
+                                                    double *__restrict__ x, double *__restrict__ r, double *__restrict__ z,
+                                                    double *__restrict__ part) {
+  const double al = sc[CGD + 3];
+  double acc[2] = {0, 0};
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    x[i] += al * p[i];
+    const double ri = r[i] - al * q[i];
+    r[i] = ri;
+    const double zi = diag ? ri / (diag[i] != 0.0 ? diag[i] : 1.0) : ri;
+    if (diag) z[i] = zi;
+    acc[0] += ri * ri; acc[1] += ri * zi;
+  }
+  block_reduce_store<2>(acc, part);
+}
+__global__ void k_cgd_p(int64_t n, const double *__restrict__ sc, const double *__restrict__ z, double *__restrict__ p) {
+  const double be = sc[CGD + 4];
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) p[i] = z[i] + be * p[i];
+}
+void cgd_init(ifem_ctx *ctx, int64_t n, const double *b, const double *diag, double *x, double *r, double *z, double *p) {
+  if (ctx->partials.n == 0) ctx->partials.alloc(size_t(64) * MDOT_MAXB);
+  const unsigned nblk = vgrid(n);
+  hipLaunchKernelGGL(k_cgd_init, dim3(nblk), dim3(256), 0, ctx->stream, n, b, diag, x, r, z, p, ctx->partials.p);
+  hipLaunchKernelGGL(k_cgd_scalars, dim3(1), dim3(256), 0, ctx->stream, (int)nblk, ctx->partials.p, ctx->scal.p, 0);
+}
+void cgd_alpha(ifem_ctx *ctx, int64_t n, const double *p, const double *q) {
+  const unsigned nblk = vgrid(n);
+  hipLaunchKernelGGL((k_mdot<1>), dim3(nblk), dim3(256), 0, ctx->stream, n, 0, p, n, q, ctx->partials.p);
+  hipLaunchKernelGGL(k_cgd_scalars, dim3(1), dim3(256), 0, ctx->stream, (int)nblk, ctx->partials.p, ctx->scal.p, 1);
+}
+void cgd_update(ifem_ctx *ctx, int64_t n, const double *diag, double *p, const double *q, double *x, double *r, double *z) {
+  const unsigned nblk = vgrid(n);
+  hipLaunchKernelGGL(k_cgd_update, dim3(nblk), dim3(256), 0, ctx->stream, n, ctx->scal.p, diag, p, q, x, r, z, ctx->partials.p);
+  hipLaunchKernelGGL(k_cgd_scalars, dim3(1), dim3(256), 0, ctx->stream, (int)nblk, ctx->partials.p, ctx->scal.p, 2);
+  hipLaunchKernelGGL(k_cgd_p, dim3(nblk), dim3(256), 0, ctx->stream, n, ctx->scal.p, diag ? z : r, p);
+}
+double cgd_rr(ifem_ctx *ctx) { // the only host synchronisation of the loop
+  IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal + 200, ctx->scal.p + CGD, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ctx->h_scal[200];
+}
+
 double v_dot(ifem_ctx *ctx, int64_t n, const double *x, const double *y) {
   double out = 0;
   v_mdot(ctx, n, 1, x, n, y, &out);

@@ -197,6 +197,28 @@ static int cg(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *b, double *
   return it;
 }
 
+// CG / Jacobi-PCG whose recurrence scalars stay on the device: five launches and no host round trip per iteration; the
+// host reads ||r||^2 every `chk` iterations, so up to chk - 1 iterations run beyond the tolerance (harmless: they only
+// tighten the solve).  Same iterates as cg() / pcg_jacobi() up to that point.  Single rank (the dots are not all-reduced).
+static int cg_device(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *diag, const double *b, double *x, double tol,
+                     int maxit, double *r, double *z, double *p, double *q, int chk) {
+  cgd_init(ctx, n, b, diag, x, r, z, p);
+  int it = 0;
+  double rr = cgd_rr(ctx);
+  while (std::sqrt(rr) > tol && it < maxit) {
+    const int burst = std::min(chk, maxit - it);
+    for (int k = 0; k < burst; ++k) {
+      A(p, q);
+      cgd_alpha(ctx, n, p, q);
+      cgd_update(ctx, n, diag, p, q, x, r, z);
+    }
+    it += burst;
+    rr = cgd_rr(ctx);
+    if (!(rr == rr)) break; // NaN guard
+  }
+  return it;
+}
+
 // Jacobi-preconditioned CG, zero initial guess, same stopping rule (absolute tolerance on the TRUE residual ||r||_2).
 // r and z must be adjacent (z = r + ld) so that <r,r> and <z,r> come out of one fused reduction.
 static int pcg_jacobi(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *diag, const double *b, double *x, double tol,
@@ -293,6 +315,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   double *tmp = S.tp[0], *r = S.tp[1], *p = S.tp[2], *q = S.tp[3];
   auto pdot = [&](const double *a, const double *b) { return dot_all(S, S.npo, a, b); };
   const double n1 = std::sqrt(pdot(src1, src1));
+  const bool multi_early = c->halo.nranks > 1;
   Clock ck;
   // CG for Mp (:69-84)
   OpFn mp = [&](const double *x, double *y) { const double *xe; extend_p(S, x, &xe); spmv_mp(c, xe, y); };
@@ -304,7 +327,12 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     allreduce_sum(c, out, k);
   };
   const int pmax = (int)std::min<int64_t>(std::max<int64_t>(c->n_global_p, 1), 1 << 30);
-  if (pjac) {
+  const bool dev_cg = !multi_early && o->device_cg;
+  if (dev_cg) {
+    if (pjac) scalar_diag(c, c->Mp, c->Mp.val.p, S.tp[5]);
+    S.st.cg_mp_iters += cg_device(c, S.npo, mp, pjac ? S.tp[5] : nullptr, src1, tmp, std::max(o->mp_abs, o->mp_rel * n1), pmax,
+                                  S.tp[1], S.tp[2], S.tp[3], S.tp[4], 4);
+  } else if (pjac) {
     scalar_diag(c, c->Mp, c->Mp.val.p, S.tp[5]);
     S.st.cg_mp_iters += pcg_jacobi(c, S.npo, mp, S.tp[5], src1, tmp, std::max(o->mp_abs, o->mp_rel * n1), pmax, S.tp[1], c->nPl, S.tp[3], S.tp[4], pmdot); // r = tp[1], z = tp[2]
   } else
@@ -356,6 +384,10 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     sm_matrix_free(x, y, lowp_all); // several ranks without the 2-deep halo plan (general meshes)
   };
   // (Jacobi on S_m was measured too: 176 instead of 172 iterations -- its diagonal is nearly constant -- so CG stays plain)
+  if (dev_cg)
+    S.st.cg_sm_iters += cg_device(c, S.npo, sm, nullptr, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, S.tp[1], S.tp[2],
+                                  S.tp[3], S.tp[4], 4);
+  else
   S.st.cg_sm_iters += cg(c, S.npo, sm, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, r, p, q, pdot);
   v_axpby(c, S.npo, 1.0, tmp, -P->rho / P->dt, dst1);
   // utmp = src0 - B^T dst1 (:116-120)
