@@ -243,7 +243,7 @@ def main():
                        "mf_apply_ms": mf_ms / max(mf_calls, 1), "mf_applies": mf_calls},
             "roofline": roof,
         }
-        if args.cpu_n > 0:
+        if args.cpu_n > 0 and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, os.cpu_count() or 1)
         print(json.dumps(out), flush=True)
     if dist:
