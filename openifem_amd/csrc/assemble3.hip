@@ -125,6 +125,54 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
   const int ind = (active && A.indicator) ? A.indicator[cc] : 0;
 
   // ---- phase 1: per quadrature point (lane = q): Jacobian, fields of the evaluation point, rhs coefficients
+  // the nodal sums are split over the two waves of the cell: the second wave handles nodes 14..26 and parks its partial
+  // sums in the (not yet built) gradient table
+  double *const part1 = &S.tabG[0][0][0]; // [27 lanes][18]
+  if (h == 1 && lane < NQ) {
+    const int q = lane;
+    const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
+    double u[3] = {0, 0, 0}, u0[3] = {0, 0, 0}, ac[3] = {0, 0, 0}, gr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gr[i] = 0;
+#pragma unroll 1
+    for (int a = 14; a < (A.debug_skip == 6 ? 15 : NU); ++a) {
+      const int ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
+      const double nx = T.t.N[qi[0] * N1 + ai[0]], ny = T.t.N[qi[1] * N1 + ai[1]], nz = T.t.N[qi[2] * N1 + ai[2]];
+      const double dx = T.t.dN[qi[0] * N1 + ai[0]], dy = T.t.dN[qi[1] * N1 + ai[1]], dz = T.t.dN[qi[2] * N1 + ai[2]];
+      const double N = nx * ny * nz, dr[3] = {dx * ny * nz, nx * dy * nz, nx * ny * dz};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double uv = ue[a * 3 + c];
+        u[c] += N * uv; u0[c] += N * u0e[a * 3 + c]; ac[c] += N * ae[a * 3 + c];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) gr[c * 3 + e] += uv * dr[e];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { part1[q * 18 + c] = u[c]; part1[q * 18 + 3 + c] = u0[c]; part1[q * 18 + 6 + c] = ac[c]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) part1[q * 18 + 9 + i] = gr[i];
+  }
+  double u_[3] = {0, 0, 0}, u0_[3] = {0, 0, 0}, ac_[3] = {0, 0, 0}, gr_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (h == 0 && lane < NQ) { // first half of the nodes, in registers across the barrier
+    const int q = lane;
+    const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
+#pragma unroll 1
+    for (int a = 0; a < (A.debug_skip == 6 ? 1 : 14); ++a) {
+      const int ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
+      const double nx = T.t.N[qi[0] * N1 + ai[0]], ny = T.t.N[qi[1] * N1 + ai[1]], nz = T.t.N[qi[2] * N1 + ai[2]];
+      const double dx = T.t.dN[qi[0] * N1 + ai[0]], dy = T.t.dN[qi[1] * N1 + ai[1]], dz = T.t.dN[qi[2] * N1 + ai[2]];
+      const double N = nx * ny * nz, dr[3] = {dx * ny * nz, nx * dy * nz, nx * ny * dz};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double uv = ue[a * 3 + c];
+        u_[c] += N * uv; u0_[c] += N * u0e[a * 3 + c]; ac_[c] += N * ae[a * 3 + c];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) gr_[c * 3 + e] += uv * dr[e];
+      }
+    }
+  }
+  __syncthreads();
   if (h == 0 && lane < NQ) {
     const int q = lane;
     const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
@@ -142,23 +190,11 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
     }
     const double det = inv_small<3>(J, Ji);
     const double w = fabs(det) * wq;
-    double u[3] = {0, 0, 0}, u0[3] = {0, 0, 0}, ac[3] = {0, 0, 0}, gr[9], p = 0;
+    double u[3], u0[3], ac[3], gr[9], p = 0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) gr[i] = 0;
-#pragma unroll 1
-    for (int a = 0; a < (A.debug_skip == 6 ? 1 : NU); ++a) {
-      const int ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
-      const double nx = T.t.N[qi[0] * N1 + ai[0]], ny = T.t.N[qi[1] * N1 + ai[1]], nz = T.t.N[qi[2] * N1 + ai[2]];
-      const double dx = T.t.dN[qi[0] * N1 + ai[0]], dy = T.t.dN[qi[1] * N1 + ai[1]], dz = T.t.dN[qi[2] * N1 + ai[2]];
-      const double N = nx * ny * nz, dr[3] = {dx * ny * nz, nx * dy * nz, nx * ny * dz};
+    for (int c = 0; c < 3; ++c) { u[c] = u_[c] + part1[q * 18 + c]; u0[c] = u0_[c] + part1[q * 18 + 3 + c]; ac[c] = ac_[c] + part1[q * 18 + 6 + c]; }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double uv = ue[a * 3 + c];
-        u[c] += N * uv; u0[c] += N * u0e[a * 3 + c]; ac[c] += N * ae[a * 3 + c];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) gr[c * 3 + e] += uv * dr[e];
-      }
-    }
+    for (int i = 0; i < 9; ++i) gr[i] = gr_[i] + part1[q * 18 + 9 + i];
 #pragma unroll
     for (int b = 0; b < NP; ++b) p += T.psi[q * NP + b] * pe[b];
     double g[9], dv = 0;
