@@ -18,14 +18,19 @@
 
 namespace ifem {
 
-struct MfTables {
-  double N[9];  // [q][i]  1D Lagrange shape i (equidistant nodes) at Gauss point q
-  double D[9];  // [q][q'] derivative at Gauss point q of the Lagrange polynomial of Gauss point q'
-  double xi[3]; // Gauss points on [0,1]
-  double w[3];
+template <typename R>
+struct MfTablesT {
+  R N[9];  // [q][i]  1D Lagrange shape i (equidistant nodes) at Gauss point q
+  R D[9];  // [q][q'] derivative at Gauss point q of the Lagrange polynomial of Gauss point q'
+  R xi[3]; // Gauss points on [0,1]
+  R w[3];
 };
+using MfTables = MfTablesT<double>;
 
-struct MfArgs {
+// R = arithmetic type of the cell kernel: double for the operator of an outer solve, float for the preconditioner-only
+// inner Krylov solve (tolerance 1e-2; its basis is single precision already).  Vectors in HBM stay double either way.
+template <typename R>
+struct MfArgsT {
   int64_t n_cells, nUo;
   const double *vcoords;
   const int32_t *cell_unodes;
@@ -33,11 +38,12 @@ struct MfArgs {
   const double *eval;  // evaluation point of the assembled matrix, velocity part, ghost-extended
   const double *x;     // ghost-extended input
   double *y;           // owned rows, zeroed by the caller
-  double mu, rho, gamma, inv_dt;
+  R mu, rho, gamma, inv_dt;
   int xcd;
-  double *ycell; // per-cell results of the two-stage scatter, or nullptr (atomic scatter)
-  MfTables t;
+  R *ycell; // per-cell results of the two-stage scatter, or nullptr (atomic scatter)
+  MfTablesT<R> t;
 };
+using MfArgs = MfArgsT<double>;
 
 template <int DIM, int N1>
 struct MfGeo {
@@ -249,27 +255,27 @@ __device__ inline void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int DIM, int N1>
+template <int DIM, int N1, typename R>
 struct MfCell { // per-cell LDS scratch
   static constexpr int NN = MfGeo<DIM, N1>::NN;
-  double V[2 * DIM * NN];  // nodal values -> values at the Gauss points -> integrand -> nodal result, in place
-  double G[2 * DIM * NN];  // one reference-gradient direction at a time
-  double C[8 * DIM];       // monomial coefficients of the d-linear map
-  double X[(1 << DIM) * DIM];
+  R V[2 * DIM * NN];  // nodal values -> values at the Gauss points -> integrand -> nodal result, in place
+  R G[2 * DIM * NN];  // one reference-gradient direction at a time
+  R C[8 * DIM];       // monomial coefficients of the d-linear map
+  R X[(1 << DIM) * DIM];
   int32_t node[NN];
   uint8_t flag[NN * DIM + 3];
 };
 
 // CONV = false: the evaluation point is zero (InsIMEX matrix: no convective / Newton terms) -- the second field group is
 // neither gathered nor interpolated
-template <int DIM, int KV, int WPB, bool CONV>
-__global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
+template <int DIM, int KV, int WPB, bool CONV, typename R>
+__global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
   constexpr int N1 = KV + 1, NN = MfGeo<DIM, N1>::NN, NV = 1 << DIM;
   constexpr int NP = NN / N1;        // pencils per field and direction
   constexpr int NPL = DIM * NP;      // pencil lanes per round (one field group of DIM components)
-  __shared__ MfCell<DIM, N1> SS[2 * WPB];
+  __shared__ MfCell<DIM, N1, R> SS[2 * WPB];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
-  MfCell<DIM, N1> &S = SS[2 * wave + half];
+  MfCell<DIM, N1, R> &S = SS[2 * wave + half];
   // ---- per-lane roles (fixed for the life of the wave)
   const bool pen_lane = hl < NPL;
   const int comp = pen_lane ? hl / NP : 0, pen = pen_lane ? hl % NP : 0;
@@ -286,11 +292,11 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
   const bool q_lane = hl < NN;
   const int q = q_lane ? hl : 0;
   const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
-  double xi[3] = {0, 0, 0}, wq = 1.0;
+  R xi[3] = {0, 0, 0}, wq = 1;
 #pragma unroll
   for (int d = 0; d < DIM; ++d) {
     // select from the wave-uniform tables without dynamic indexing of kernel arguments
-    double x_ = A.t.xi[0], w_ = A.t.w[0];
+    R x_ = A.t.xi[0], w_ = A.t.w[0];
 #pragma unroll
     for (int k = 1; k < N1; ++k) { x_ = qi[d] == k ? A.t.xi[k] : x_; w_ = qi[d] == k ? A.t.w[k] : w_; }
     xi[d] = x_; wq *= w_;
@@ -314,22 +320,22 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
         const int64_t dof = int64_t(DIM) * nd + c;
         const bool con = A.is_c ? A.is_c[dof] != 0 : false;
         S.flag[hl * DIM + c] = con;
-        S.V[c * NN + hl] = con ? 0.0 : A.x[dof];
-        if constexpr (CONV) S.V[(DIM + c) * NN + hl] = A.eval[dof];
+        S.V[c * NN + hl] = con ? R(0) : R(A.x[dof]);
+        if constexpr (CONV) S.V[(DIM + c) * NN + hl] = R(A.eval[dof]);
       }
     }
-    if (hl < NV * DIM) S.X[hl] = A.vcoords[cc * NV * DIM + hl];
+    if (hl < NV * DIM) S.X[hl] = R(A.vcoords[cc * NV * DIM + hl]);
     wsync();
     // monomial coefficients of x(xi) = sum_k C_k prod_{d in k} xi_d:  C_k = sum_{v subset of k} (-1)^{|k|-|v|} X_v
     if (hl < NV * DIM) {
       const int k = hl / DIM, e = hl % DIM;
-      double acc = 0;
+      R acc = 0;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const bool sub = (v & ~k) == 0;
         const int par = __builtin_popcount(k ^ v) & 1;
-        const double xv = S.X[v * DIM + e];
-        acc += sub ? (par ? -xv : xv) : 0.0;
+        const R xv = S.X[v * DIM + e];
+        acc += sub ? (par ? -xv : xv) : R(0);
       }
       S.C[k * DIM + e] = acc;
     }
@@ -339,13 +345,13 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
       for (int d = 0; d < DIM; ++d) {
 #pragma unroll
         for (int r = 0; r < (CONV ? 2 : 1); ++r) {
-          double *b = S.V + (r * DIM + comp) * NN + pbase[d];
-          double in[N1];
+          R *b = S.V + (r * DIM + comp) * NN + pbase[d];
+          R in[N1];
 #pragma unroll
           for (int i = 0; i < N1; ++i) in[i] = b[i * pstride[d]];
 #pragma unroll
           for (int o = 0; o < N1; ++o) {
-            double acc = 0;
+            R acc = 0;
 #pragma unroll
             for (int i = 0; i < N1; ++i) acc += A.t.N[o * N1 + i] * in[i];
             b[o * pstride[d]] = acc;
@@ -358,14 +364,14 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
       for (int d = 0; d < DIM; ++d) wsync();
     }
     // ---- geometry at the quadrature point
-    double Ji[DIM * DIM], JxW = 0;
+    R Ji[DIM * DIM], JxW = 0;
     {
-      double J[DIM * DIM];
+      R J[DIM * DIM];
       if constexpr (DIM == 3) {
-        const double e_ = xi[1], z_ = xi[2], x_ = xi[0];
+        const R e_ = xi[1], z_ = xi[2], x_ = xi[0];
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-          const double c1 = S.C[1 * 3 + e], c2 = S.C[2 * 3 + e], c3 = S.C[3 * 3 + e], c4 = S.C[4 * 3 + e],
+          const R c1 = S.C[1 * 3 + e], c2 = S.C[2 * 3 + e], c3 = S.C[3 * 3 + e], c4 = S.C[4 * 3 + e],
                        c5 = S.C[5 * 3 + e], c6 = S.C[6 * 3 + e], c7 = S.C[7 * 3 + e];
           J[e * 3 + 0] = c1 + c3 * e_ + c5 * z_ + c7 * (e_ * z_);
           J[e * 3 + 1] = c2 + c3 * x_ + c6 * z_ + c7 * (x_ * z_);
@@ -374,20 +380,20 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
       } else {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const double c1 = S.C[1 * 2 + e], c2 = S.C[2 * 2 + e], c3 = S.C[3 * 2 + e];
+          const R c1 = S.C[1 * 2 + e], c2 = S.C[2 * 2 + e], c3 = S.C[3 * 2 + e];
           J[e * 2 + 0] = c1 + c3 * xi[1];
           J[e * 2 + 1] = c2 + c3 * xi[0];
         }
       }
-      double det;
+      R det;
       if constexpr (DIM == 2) {
         det = J[0] * J[3] - J[1] * J[2];
-        const double r = 1.0 / det;
+        const R r = R(1) / det;
         Ji[0] = J[3] * r; Ji[1] = -J[1] * r; Ji[2] = -J[2] * r; Ji[3] = J[0] * r;
       } else {
-        const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+        const R c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
         det = J[0] * c00 + J[1] * c01 + J[2] * c02;
-        const double r = 1.0 / det;
+        const R r = R(1) / det;
         Ji[0] = c00 * r; Ji[3] = c01 * r; Ji[6] = c02 * r;
         Ji[1] = (J[2] * J[7] - J[1] * J[8]) * r; Ji[4] = (J[0] * J[8] - J[2] * J[6]) * r; Ji[7] = (J[1] * J[6] - J[0] * J[7]) * r;
         Ji[2] = (J[1] * J[5] - J[2] * J[4]) * r; Ji[5] = (J[2] * J[3] - J[0] * J[5]) * r; Ji[8] = (J[0] * J[4] - J[1] * J[3]) * r;
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
       JxW = fabs(det) * wq;
     }
     // ---- physical gradients: one reference direction at a time through G
-    double gx[DIM][DIM], gu[DIM][DIM];
+    R gx[DIM][DIM], gu[DIM][DIM];
 #pragma unroll
     for (int c = 0; c < DIM; ++c)
 #pragma unroll
@@ -406,12 +412,12 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
 #pragma unroll
         for (int r = 0; r < (CONV ? 2 : 1); ++r) {
           const int off = (r * DIM + comp) * NN + pbase[d];
-          double in[N1];
+          R in[N1];
 #pragma unroll
           for (int i = 0; i < N1; ++i) in[i] = S.V[off + i * pstride[d]];
 #pragma unroll
           for (int o = 0; o < N1; ++o) {
-            double acc = 0;
+            R acc = 0;
 #pragma unroll
             for (int i = 0; i < N1; ++i) acc += A.t.D[o * N1 + i] * in[i];
             S.G[off + o * pstride[d]] = acc;
@@ -422,11 +428,11 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
       if (q_lane) {
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
-          const double rx = S.G[c * NN + q];
+          const R rx = S.G[c * NN + q];
 #pragma unroll
           for (int e = 0; e < DIM; ++e) gx[c][e] += Ji[d * DIM + e] * rx;
           if constexpr (CONV) {
-            const double ru = S.G[(DIM + c) * NN + q];
+            const R ru = S.G[(DIM + c) * NN + q];
 #pragma unroll
             for (int e = 0; e < DIM; ++e) gu[c][e] += Ji[d * DIM + e] * ru;
           }
@@ -435,26 +441,26 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
       wsync();
     }
     // ---- weak form at the quadrature point
-    double That[DIM][DIM]; // [comp][ref dir]
+    R That[DIM][DIM]; // [comp][ref dir]
     if (q_lane) {
-      double xq[DIM], uq[DIM];
+      R xq[DIM], uq[DIM];
 #pragma unroll
-      for (int c = 0; c < DIM; ++c) { xq[c] = S.V[c * NN + q]; uq[c] = CONV ? S.V[(DIM + c) * NN + q] : 0.0; }
-      double divx = 0;
+      for (int c = 0; c < DIM; ++c) { xq[c] = S.V[c * NN + q]; uq[c] = CONV ? S.V[(DIM + c) * NN + q] : R(0); }
+      R divx = 0;
 #pragma unroll
       for (int c = 0; c < DIM; ++c) divx += gx[c][c];
 #pragma unroll
       for (int c = 0; c < DIM; ++c) {
-        double conv = 0, newt = 0;
+        R conv = 0, newt = 0;
 #pragma unroll
         for (int e = 0; e < DIM; ++e) { conv += uq[e] * gx[c][e]; newt += xq[e] * gu[c][e]; }
         S.V[c * NN + q] = JxW * A.rho * (conv + A.inv_dt * xq[c] + newt);
-        double tp[DIM];
+        R tp[DIM];
 #pragma unroll
-        for (int e = 0; e < DIM; ++e) tp[e] = JxW * (A.mu * gx[c][e] + (e == c ? A.gamma * A.rho * divx : 0.0));
+        for (int e = 0; e < DIM; ++e) tp[e] = JxW * (A.mu * gx[c][e] + (e == c ? A.gamma * A.rho * divx : R(0)));
 #pragma unroll
         for (int d = 0; d < DIM; ++d) {
-          double t = 0;
+          R t = 0;
 #pragma unroll
           for (int e = 0; e < DIM; ++e) t += Ji[d * DIM + e] * tp[e];
           That[c][d] = t;
@@ -471,12 +477,12 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
       wsync();
       if (pen_lane) {
         const int off = comp * NN + pbase[d];
-        double t[N1];
+        R t[N1];
 #pragma unroll
         for (int i = 0; i < N1; ++i) t[i] = S.G[off + i * pstride[d]];
 #pragma unroll
         for (int o = 0; o < N1; ++o) {
-          double acc = S.V[off + o * pstride[d]];
+          R acc = S.V[off + o * pstride[d]];
 #pragma unroll
           for (int i = 0; i < N1; ++i) acc += A.t.D[i * N1 + o] * t[i];
           S.V[off + o * pstride[d]] = acc;
@@ -488,13 +494,13 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
       if (pen_lane) {
-        double *b = S.V + comp * NN + pbase[d];
-        double in[N1];
+        R *b = S.V + comp * NN + pbase[d];
+        R in[N1];
 #pragma unroll
         for (int i = 0; i < N1; ++i) in[i] = b[i * pstride[d]];
 #pragma unroll
         for (int o = 0; o < N1; ++o) {
-          double acc = 0;
+          R acc = 0;
 #pragma unroll
           for (int i = 0; i < N1; ++i) acc += A.t.N[i * N1 + o] * in[i];
           b[o * pstride[d]] = acc;
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgs A) {
       for (int t = hl; t < DIM * NN; t += 32) {
         const int a = t / DIM, c = t - a * DIM;
         const int32_t nd = S.node[a];
-        if (nd < A.nUo && !S.flag[t]) unsafeAtomicAdd(&A.y[int64_t(DIM) * nd + c], S.V[c * NN + a]);
+        if (nd < A.nUo && !S.flag[t]) unsafeAtomicAdd(&A.y[int64_t(DIM) * nd + c], double(S.V[c * NN + a]));
       }
     }
     wsync();
@@ -534,9 +540,9 @@ __global__ void k_mf_constrained_rows(int64_t n, const uint8_t *__restrict__ is_
 
 // second stage of the atomics-free scatter: y_i = sum over the cells touching node(i) of the cell's local result (fixed
 // order: deterministic), constrained rows y_r = d_r x_r as above
-template <int DIM>
+template <int DIM, typename R>
 __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc,
-                            const double *__restrict__ ycell, const uint8_t *__restrict__ is_c,
+                            const R *__restrict__ ycell, const uint8_t *__restrict__ is_c,
                             const double *__restrict__ bjac, const double *__restrict__ x, double *__restrict__ y) {
   // one thread per node: the incidence list is walked once for the DIM components (24 contiguous bytes per entry)
   const int64_t nd = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -547,7 +553,7 @@ __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_p
   const int64_t k1 = inc_ptr[nd + 1];
   for (int64_t k = inc_ptr[nd]; k < k1; ++k) {
     const int32_t e = inc[k];
-    const double *src = ycell + int64_t(e >> 5) * (DIM * nn) + (e & 31) * DIM;
+    const R *src = ycell + int64_t(e >> 5) * (DIM * nn) + (e & 31) * DIM;
 #pragma unroll
     for (int c = 0; c < DIM; ++c) s[c] += src[c];
   }
@@ -556,6 +562,12 @@ __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_p
     const int64_t i = nd * DIM + c;
     y[i] = (is_c && is_c[i]) ? x[i] / bjac[nd * DIM * DIM + c * DIM + c] : s[c];
   }
+}
+
+template <typename R>
+static void mf_tables_to(MfTablesT<R> &o, const MfTables &t) {
+  for (int i = 0; i < 9; ++i) { o.N[i] = R(t.N[i]); o.D[i] = R(t.D[i]); }
+  for (int i = 0; i < 3; ++i) { o.xi[i] = R(t.xi[i]); o.w[i] = R(t.w[i]); }
 }
 
 static void mf_tables(MfTables &t, int kv) {
@@ -587,59 +599,53 @@ static void mf_tables(MfTables &t, int kv) {
     }
 }
 
-void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu) {
+template <typename R>
+static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu) {
   if (!ctx->mf_valid) throw Error(IFEM_E_BADPARAM, "matrix-free A_uu: no assembled state (call ifem_ins_assemble first)");
   const int64_t n = int64_t(ctx->dim) * ctx->nUo;
   hipStream_t s = ctx->stream;
-  MfArgs a{};
+  MfArgsT<R> a{};
   a.n_cells = ctx->n_cells; a.nUo = ctx->nUo;
   a.vcoords = ctx->vcoords.p; a.cell_unodes = ctx->cell_unodes.p;
   a.is_c = ctx->has_c[ctx->asm_constraint_set] ? ctx->is_c[ctx->asm_constraint_set].p : nullptr;
   a.eval = ctx->mf_eval.p; a.x = xu; a.y = yu;
-  a.mu = ctx->mf_params.viscosity; a.rho = ctx->mf_params.rho; a.gamma = ctx->mf_params.grad_div;
-  a.inv_dt = 1.0 / ctx->mf_params.dt;
-  mf_tables(a.t, ctx->kv);
+  a.mu = R(ctx->mf_params.viscosity); a.rho = R(ctx->mf_params.rho); a.gamma = R(ctx->mf_params.grad_div);
+  a.inv_dt = R(1.0 / ctx->mf_params.dt);
+  { MfTables t; mf_tables(t, ctx->kv); mf_tables_to(a.t, t); }
   { static const int xcd = [] { const char *e = getenv("IFEM_XCD"); return e ? atoi(e) : 1; }(); a.xcd = xcd; }
   a.ycell = nullptr;
   const bool time_it = ctx->profile;
   // scatter: two-stage (per-cell results + per-node gather; atomics-free, deterministic) unless IFEM_MF_SCATTER=atomic
   static const bool want_atomic = [] { const char *e = getenv("IFEM_MF_SCATTER"); return e && std::string(e) == "atomic"; }();
-  static const int v1 = [] { const char *e = getenv("IFEM_MF_V1"); return e ? atoi(e) : 0; }(); // first version (one item per lane, atomic scatter)
-  const bool two_stage = !want_atomic && !v1 && ctx->n_cells < (int64_t(1) << 26) && ctx->nu <= 32;
+  const bool two_stage = !want_atomic && ctx->n_cells < (int64_t(1) << 26) && ctx->nu <= 32;
   if (two_stage) {
     if (ctx->uinc.n_rows == 0 && ctx->nUo) build_incidence(ctx);
-    const size_t need = size_t(ctx->n_cells) * ctx->dim * ctx->nu;
+    const size_t need = size_t(ctx->n_cells) * ctx->dim * ctx->nu; // in doubles: the float variant uses half of it
     if (ctx->mf_ycell.n < need) ctx->mf_ycell.alloc(need);
-    a.ycell = ctx->mf_ycell.p;
+    a.ycell = reinterpret_cast<R *>(ctx->mf_ycell.p);
   } else
     IFEM_HIP_CHECK(hipMemsetAsync(yu, 0, size_t(n) * sizeof(double), s));
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s)); // the cell kernel alone (what rocprofv3 reports for it)
   constexpr int WPB = 4;
-  const dim3 grid(unsigned((ctx->n_cells + WPB - 1) / WPB)), block(64 * WPB);
-  if (!v1) {
-    const int64_t n_pairs = (ctx->n_cells + 1) / 2;
-    const dim3 g2(unsigned(std::min<int64_t>((n_pairs + WPB - 1) / WPB, 256 * 24)));
-    const bool conv = !ctx->mf_noconv;
+  const dim3 block(64 * WPB);
+  const int64_t n_pairs = (ctx->n_cells + 1) / 2;
+  const dim3 g2(unsigned(std::min<int64_t>((n_pairs + WPB - 1) / WPB, 256 * 24)));
+  const bool conv = !ctx->mf_noconv;
 #define IFEM_MF2(D, K)                                                                                                 \
-  { if (conv) hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, true>), g2, block, 0, s, a);                                 \
-    else hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, false>), g2, block, 0, s, a); }
-    if (ctx->dim == 3 && ctx->kv == 2) IFEM_MF2(3, 2)
-    else if (ctx->dim == 3) IFEM_MF2(3, 1)
-    else if (ctx->kv == 2) IFEM_MF2(2, 2)
-    else IFEM_MF2(2, 1)
+  { if (conv) hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, true, R>), g2, block, 0, s, a);                              \
+    else hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, false, R>), g2, block, 0, s, a); }
+  if (ctx->dim == 3 && ctx->kv == 2) IFEM_MF2(3, 2)
+  else if (ctx->dim == 3) IFEM_MF2(3, 1)
+  else if (ctx->kv == 2) IFEM_MF2(2, 2)
+  else IFEM_MF2(2, 1)
 #undef IFEM_MF2
-  } else
-  if (ctx->dim == 3 && ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf<3, 2, WPB>), grid, block, 0, s, a);
-  else if (ctx->dim == 3) hipLaunchKernelGGL((k_apply_uu_mf<3, 1, WPB>), grid, block, 0, s, a);
-  else if (ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf<2, 2, WPB>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((k_apply_uu_mf<2, 1, WPB>), grid, block, 0, s, a);
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
   if (two_stage) {
     if (ctx->dim == 3)
-      hipLaunchKernelGGL((k_mf_gather<3>), dim3(unsigned((n / 3 + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
+      hipLaunchKernelGGL((k_mf_gather<3, R>), dim3(unsigned((n / 3 + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
                          ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu);
     else
-      hipLaunchKernelGGL((k_mf_gather<2>), dim3(unsigned((n / 2 + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
+      hipLaunchKernelGGL((k_mf_gather<2, R>), dim3(unsigned((n / 2 + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
                          ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu);
   } else
   if (a.is_c) {
@@ -653,6 +659,41 @@ void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu) {
     ctx->mf_ms_total += ms;
     ctx->timing.mf_calls++;
   }
+}
+
+// first version of the cell kernel (one item per lane, atomic scatter), kept behind IFEM_MF_V1=1 for comparison
+static void apply_uu_mf_v1(ifem_ctx *ctx, const double *xu, double *yu) {
+  if (!ctx->mf_valid) throw Error(IFEM_E_BADPARAM, "matrix-free A_uu: no assembled state (call ifem_ins_assemble first)");
+  const int64_t n = int64_t(ctx->dim) * ctx->nUo;
+  hipStream_t s = ctx->stream;
+  MfArgs a{};
+  a.n_cells = ctx->n_cells; a.nUo = ctx->nUo;
+  a.vcoords = ctx->vcoords.p; a.cell_unodes = ctx->cell_unodes.p;
+  a.is_c = ctx->has_c[ctx->asm_constraint_set] ? ctx->is_c[ctx->asm_constraint_set].p : nullptr;
+  a.eval = ctx->mf_eval.p; a.x = xu; a.y = yu;
+  a.mu = ctx->mf_params.viscosity; a.rho = ctx->mf_params.rho; a.gamma = ctx->mf_params.grad_div;
+  a.inv_dt = 1.0 / ctx->mf_params.dt;
+  mf_tables(a.t, ctx->kv);
+  IFEM_HIP_CHECK(hipMemsetAsync(yu, 0, size_t(n) * sizeof(double), s));
+  constexpr int WPB = 4;
+  const dim3 grid(unsigned((ctx->n_cells + WPB - 1) / WPB)), block(64 * WPB);
+  if (ctx->dim == 3 && ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf<3, 2, WPB>), grid, block, 0, s, a);
+  else if (ctx->dim == 3) hipLaunchKernelGGL((k_apply_uu_mf<3, 1, WPB>), grid, block, 0, s, a);
+  else if (ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf<2, 2, WPB>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_apply_uu_mf<2, 1, WPB>), grid, block, 0, s, a);
+  if (a.is_c) {
+    if (ctx->dim == 3) hipLaunchKernelGGL((k_mf_constrained_rows<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, a.is_c, ctx->bjac.p, xu, yu);
+    else hipLaunchKernelGGL((k_mf_constrained_rows<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, a.is_c, ctx->bjac.p, xu, yu);
+  }
+}
+
+// single = true: single-precision cell arithmetic (the inner, preconditioner-only solve); IFEM_MF_F32=0 forces double
+void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single) {
+  static const int v1 = [] { const char *e = getenv("IFEM_MF_V1"); return e ? atoi(e) : 0; }();
+  static const int f32 = [] { const char *e = getenv("IFEM_MF_F32"); return e ? atoi(e) : 1; }();
+  if (v1) apply_uu_mf_v1(ctx, xu, yu);
+  else if (single && f32) apply_uu_mf_t<float>(ctx, xu, yu);
+  else apply_uu_mf_t<double>(ctx, xu, yu);
 }
 
 } // namespace ifem

@@ -32,7 +32,7 @@ inline VecLayout layout_of(const ifem_ctx *c) { return {c->dim * c->nUo, c->dim 
 // y_u = A_uu x_u (+ B^T x_p when xp != nullptr)
 void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool use_f32);
 // apply_mf.hip: y_u = A_uu x_u without the stored matrix (sum-factorised cell kernel on the state of the last assemble)
-void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu);
+void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single = false);
 // scalar velocity operator S^ (IFEM_AINV_SCALAR_GMRES): auxiliary data, SpMV on all components, Jacobi
 void shat_refresh(ifem_ctx *ctx, bool f32);
 void spmv_shat(ifem_ctx *ctx, const double *xu, double *yu, bool f32);

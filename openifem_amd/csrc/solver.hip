@@ -403,7 +403,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   const bool f32 = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32;
   OpFn Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_uu(c, xe, nullptr, y, f32); };
   if (o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF)
-    Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); apply_uu_mf(c, xe, y); };
+    Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); apply_uu_mf(c, xe, y, true); };
   const bool scalar_op = o->ainv_kind == IFEM_AINV_SCALAR_GMRES;
   if (scalar_op) shat_refresh(c, true);
   if (scalar_op) Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_shat(c, xe, y, true); };
