@@ -169,8 +169,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if dist:
-        dist.barrier()
+    import torch
+    torch.cuda.set_device(local_rank)
+
+    def fence():  # barrier + device idle: the library's own stream, and torch's for good measure
+        if dist:
+            dist.barrier()
+        solver.synchronize()
+        torch.cuda.synchronize()
+
+    fence()
     t0 = time.time()
     t_asm = t_solve = 0.0
     spmv_ms, spmv_calls = 0.0, 0
@@ -189,9 +197,10 @@ def main():
         spmv_calls += tm.spmv_uu_calls
         mf_ms += tm.mf_ms_avg * tm.mf_calls
         mf_calls += tm.mf_calls
+    solver.synchronize()
+    torch.cuda.synchronize()
     elapsed = time.time() - t0
     if dist:
-        import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])

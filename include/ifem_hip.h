@@ -266,6 +266,9 @@ typedef struct {
 int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t);
 /* on != 0: time every A_uu SpMV launch with HIP events on the context stream (one sync per launch) */
 int ifem_set_profiling(ifem_ctx *ctx, int on);
+/* block until everything queued on the context's stream (and on its halo-exchange stream) has finished: the bracket of
+   a timed region.  The reference needs no counterpart (its PETSc calls are synchronous). */
+int ifem_synchronize(ifem_ctx *ctx);
 
 #ifdef __cplusplus
 }

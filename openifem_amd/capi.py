@@ -71,7 +71,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_set_cell_fields", "ifem_vec_set", "ifem_vec_get", "ifem_vec_copy", "ifem_vec_zero", "ifem_vec_axpy",
            "ifem_vec_norm2", "ifem_vec_minmax", "ifem_halo_exchange", "ifem_ins_assemble", "ifem_solve",
            "ifem_rhs_norm", "ifem_ins_newton_step", "ifem_system_vmult", "ifem_uu_vmult", "ifem_precond_vmult", "ifem_export_csr",
-           "ifem_get_timing", "ifem_set_profiling", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
+           "ifem_get_timing", "ifem_set_profiling", "ifem_synchronize", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
            "ifem_scns_assemble", "ifem_scns_solve", "ifem_scns_newton_step", "ifem_imex_assemble", "ifem_imex_solve",
            "ifem_imex_step", "ifem_set_eddy_viscosity"]
 
@@ -125,6 +125,7 @@ def load():
     L.ifem_local_world_create.argtypes = [C.c_int]
     L.ifem_local_world_destroy.argtypes = [C.c_void_p]
     L.ifem_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.ifem_synchronize.argtypes = [C.c_void_p]
     L.ifem_set_ainv_kind.argtypes = [C.c_void_p, C.c_int]
     L.ifem_set_scns_fields.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifem_set_eddy_viscosity.argtypes = [C.c_void_p, C.c_void_p]

@@ -540,6 +540,12 @@ int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t) {
 
 int ifem_set_ainv_kind(ifem_ctx *ctx, int kind) { ctx->want_shat = kind == IFEM_AINV_SCALAR_GMRES; return IFEM_OK; }
 int ifem_set_profiling(ifem_ctx *ctx, int on) { ctx->profile = on != 0; return IFEM_OK; }
+int ifem_synchronize(ifem_ctx *ctx) {
+  IFEM_API_BEGIN
+  IFEM_HIP_CHECK(hipSetDevice(ctx->device));
+  IFEM_HIP_CHECK(hipDeviceSynchronize());
+  IFEM_API_END
+}
 
 int ifem_comm_unique_id(uint8_t out[128]) { return ifem::comm_unique_id(out); }
 int ifem_comm_selftest(int device) {

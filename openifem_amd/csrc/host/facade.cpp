@@ -145,6 +145,38 @@ int ifemx_output_results(void *hv, const char *dir, unsigned index) {
     else { h->s3->output_dir = dir; h->s3->output_results(index); }
   });
 }
+// FluidSolver::save_checkpoint(index) / load_checkpoint() in directory `dir` (must end with '/'); *found = 0 when the
+// directory holds no checkpoint (the solver is then untouched: set it up as for a fresh start)
+int ifemx_save_checkpoint(void *hv, const char *dir, int index) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) { h->s2->output_dir = dir; h->s2->save_checkpoint(index); }
+    else { h->s3->output_dir = dir; h->s3->save_checkpoint(index); }
+  });
+}
+int ifemx_load_checkpoint(void *hv, const char *dir, int *found) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) { h->s2->output_dir = dir; *found = h->s2->load_checkpoint(); }
+    else { h->s3->output_dir = dir; *found = h->s3->load_checkpoint(); }
+  });
+}
+// directory of output_results / checkpoints for run() (the reference uses the working directory)
+int ifemx_set_output_dir(void *hv, const char *dir, int enable_output) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) { h->s2->output_dir = dir; h->s2->output_enabled = enable_output != 0; }
+    else { h->s3->output_dir = dir; h->s3->output_enabled = enable_output != 0; }
+  });
+}
+// Utils::Time of the solver: current step and time
+int ifemx_time(void *hv, unsigned *timestep, double *current) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (h->dim == 2) { *timestep = h->s2->current_timestep(); *current = h->s2->current_time(); }
+    else { *timestep = h->s3->current_timestep(); *current = h->s3->current_time(); }
+  });
+}
 // the .vtu writer on host data only (no device): solution [n_dofs], optional fsi_acc [n_dofs], stress [dim][dim][n_unodes]
 int ifemx_write_vtu(void *hv, const char *filename, const double *solution, const double *fsi_acc, const double *stress, int subdomain) {
   auto *h = static_cast<Handle *>(hv);

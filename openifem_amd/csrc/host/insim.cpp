@@ -231,17 +231,21 @@ void InsIM<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_syst
   check(ifem_vec_copy(ctx, IFEM_VEC_INCREMENT, IFEM_VEC_PRESENT), "run_one_step");
   check(ifem_vec_axpy(ctx, -1.0, IFEM_VEC_EVAL, IFEM_VEC_INCREMENT), "run_one_step");
   check(ifem_vec_copy(ctx, IFEM_VEC_PRESENT, IFEM_VEC_EVAL), "run_one_step");
-  if (this->output_enabled && time.time_to_output()) this->output_results(time.get_timestep()); // (:479-482)
-  // save_checkpoint / refine_mesh: outside the path
+  if (parameters.simulation_type == "Fluid" && time.time_to_save()) this->save_checkpoint((int)time.get_timestep()); // (:477-480)
+  if (this->output_enabled && time.time_to_output()) this->output_results(time.get_timestep()); // (:481-484)
+  // refine_mesh: outside the path
 }
 
 template <int dim>
 void InsIM<dim>::run() {
   if (this->pcout) *this->pcout << "Running with HIP on " << this->proc_grid[0] * this->proc_grid[1] * this->proc_grid[2] << " MI355X rank(s)..." << std::endl;
-  this->triangulation.refine_global(parameters.global_refinements[0]);
-  this->setup_dofs();
-  this->make_constraints();
-  this->initialize_system();
+  const bool success_load = this->load_checkpoint(); // try load from previous computation (:499-507)
+  if (!success_load) {
+    this->triangulation.refine_global(parameters.global_refinements[0]);
+    this->setup_dofs();
+    this->make_constraints();
+    this->initialize_system();
+  }
   run_one_step(true);
   while (time.end() - time.current() > 1e-12) run_one_step(false);
 }
@@ -300,17 +304,22 @@ void InsIMEX<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_sy
     *this->pcout << std::scientific << std::left << " GMRES_ITR = " << std::setw(3) << state.first
                  << " GMRES_RES = " << state.second << std::endl;
   check(ifem_update_stress(ctx, parameters.viscosity, nullptr), "update_stress");
+  if (parameters.simulation_type == "Fluid" && time.time_to_save()) this->save_checkpoint((int)time.get_timestep()); // (mpi_insimex.cpp:433-436)
   if (this->output_enabled && time.time_to_output()) this->output_results(time.get_timestep());
 }
 
 template <int dim>
 void InsIMEX<dim>::run() {
   if (this->pcout) *this->pcout << "Running with HIP on " << this->proc_grid[0] * this->proc_grid[1] * this->proc_grid[2] << " MI355X rank(s)..." << std::endl;
-  this->triangulation.refine_global(parameters.global_refinements[0]);
-  this->setup_dofs();
-  this->make_constraints();
-  this->initialize_system();
-  while (time.end() - time.current() > 1e-12) run_one_step(time.get_timestep() == 0, time.get_timestep() < 2);
+  const bool success_load = this->load_checkpoint(); // (mpi_insimex.cpp:455-463)
+  if (!success_load) {
+    this->triangulation.refine_global(parameters.global_refinements[0]);
+    this->setup_dofs();
+    this->make_constraints();
+    this->initialize_system();
+  }
+  // the left-hand side is assembled in the first two steps, and again after a restart (:466-472)
+  while (time.end() - time.current() > 1e-12) run_one_step(time.get_timestep() == 0, time.get_timestep() < 2 || success_load);
 }
 
 template class InsIMEX<2>;

@@ -83,6 +83,10 @@ public:
   std::vector<double> update_stress();
   // FluidSolver::output_results (mpi_fluid_solver.cpp:491-579): fluid_<index>.<rank>.vtu (+ .pvtu and fluid.pvd on rank 0)
   void output_results(const unsigned int output_index);
+  // FluidSolver::save_checkpoint / load_checkpoint (mpi_fluid_solver.cpp:582-713): <step>.fluid_checkpoint (+ .info,
+  // _fixed.data) in output_dir; run() tries load_checkpoint() first and run_one_step saves whenever time.time_to_save()
+  void save_checkpoint(const int output_index);
+  bool load_checkpoint();
   std::string output_dir = "./";
   bool output_enabled = false; // run_one_step writes results at step 0 and whenever time.time_to_output() (off by default)
   // block vector [velocity | pressure] (PETScWrappers::MPI::BlockVector get_current_solution())
@@ -96,6 +100,8 @@ public:
   // node/cell ordering used by setup_dofs: Morton curve (default, cache-friendly) or lexicographic
   void set_node_order(bool morton) { dofs.morton = morton; }
   ifem_ctx *context() const { return ctx; }
+  unsigned int current_timestep() const { return time.get_timestep(); }
+  double current_time() const { return time.current(); }
   const DoFTables<dim> &dof_tables() const { return dofs; }
   void constraint_lines(std::vector<int32_t> &d, std::vector<double> &v) const { d = constraint_dofs; v = nonzero_values; }
   std::ostream *pcout = &std::cout; // ConditionalOStream on rank 0; nullptr silences

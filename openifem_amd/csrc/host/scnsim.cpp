@@ -83,22 +83,25 @@ void SUPGFluidSolver<dim>::run_one_step(bool apply_nonzero_constraints, bool ass
   check(ifem_vec_copy(ctx, IFEM_VEC_INCREMENT, IFEM_VEC_PRESENT), "run_one_step");
   check(ifem_vec_axpy(ctx, -1.0, IFEM_VEC_EVAL, IFEM_VEC_INCREMENT), "run_one_step");
   check(ifem_vec_copy(ctx, IFEM_VEC_PRESENT, IFEM_VEC_EVAL), "run_one_step");
-  // update_stress feeds the next assemble (mpi_scnsim.cpp:178-186); output / checkpoint / refinement are host
-  // plumbing outside the path
+  // update_stress feeds the next assemble (mpi_scnsim.cpp:178-186); refinement is host plumbing outside the path
   check(ifem_update_stress(ctx, parameters.viscosity, nullptr), "update_stress");
-  if (this->output_enabled && time.time_to_output()) this->output_results(time.get_timestep()); // (:413-416)
+  if (parameters.simulation_type == "Fluid" && time.time_to_save()) this->save_checkpoint((int)time.get_timestep()); // (:416-419)
+  if (this->output_enabled && time.time_to_output()) this->output_results(time.get_timestep());
 }
 
 template <int dim>
 void SUPGFluidSolver<dim>::run() {
   if (this->pcout) *this->pcout << "Running with HIP on 1 MI355X rank(s)..." << std::endl;
   // hard coded boundary Fields are advanced by dt before the first and every later step (:438-444, :470-480)
-  if (!this->hard_coded_boundary_values.empty()) this->field_time += time.get_delta_t();
-  this->triangulation.refine_global(parameters.global_refinements[0]);
-  this->setup_dofs();
-  this->make_constraints();
-  this->initialize_system();
-  run_one_step(true);
+  const bool success_load = this->load_checkpoint(); // (:434-450); a restarted run goes straight into the time loop
+  if (!success_load) {
+    if (!this->hard_coded_boundary_values.empty()) this->field_time += time.get_delta_t();
+    this->triangulation.refine_global(parameters.global_refinements[0]);
+    this->setup_dofs();
+    this->make_constraints();
+    this->initialize_system();
+    run_one_step(true);
+  }
   while (time.end() - time.current() > 1e-12) {
     if (!this->hard_coded_boundary_values.empty()) {
       this->field_time += time.get_delta_t();

@@ -30,6 +30,10 @@ def _lib():
         f.argtypes = [C.c_void_p, FIELD_FN]
     L.ifemx_update_stress.argtypes = [C.c_void_p, C.c_void_p]
     L.ifemx_output_results.argtypes = [C.c_void_p, C.c_char_p, C.c_uint]
+    L.ifemx_save_checkpoint.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.ifemx_load_checkpoint.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
+    L.ifemx_set_output_dir.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.ifemx_time.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_double)]
     L.ifemx_write_vtu.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.ifemx_destroy.argtypes = [C.c_void_p]
     L.ifemx_insim_create_cylinder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -131,6 +135,29 @@ class FluidSolver:
         """FluidSolver::output_results: fluid_<index>.<rank>.vtu (+ .pvtu, fluid.pvd) into `directory`"""
         d = directory if directory.endswith("/") else directory + "/"
         self._chk(self.L.ifemx_output_results(self.h, d.encode(), index))
+
+    def save_checkpoint(self, directory, index):
+        """FluidSolver::save_checkpoint: <index>.fluid_checkpoint (+ .info, _fixed.data) into `directory`"""
+        d = directory if directory.endswith("/") else directory + "/"
+        self._chk(self.L.ifemx_save_checkpoint(self.h, d.encode(), index))
+
+    def load_checkpoint(self, directory):
+        """FluidSolver::load_checkpoint: restore the newest checkpoint of `directory` (sets the system up); False if none"""
+        d = directory if directory.endswith("/") else directory + "/"
+        found = C.c_int(0)
+        self._chk(self.L.ifemx_load_checkpoint(self.h, d.encode(), C.byref(found)))
+        return bool(found.value)
+
+    def set_output_dir(self, directory, enable_output=False):
+        """directory of run()'s results and checkpoints (the reference's working directory)"""
+        d = directory if directory.endswith("/") else directory + "/"
+        self._chk(self.L.ifemx_set_output_dir(self.h, d.encode(), int(enable_output)))
+
+    def time(self):
+        """(time step, current time) of the solver's Utils::Time"""
+        n, t = C.c_uint(0), C.c_double(0)
+        self._chk(self.L.ifemx_time(self.h, C.byref(n), C.byref(t)))
+        return n.value, t.value
 
     def write_vtu(self, filename, solution, fsi_acc=None, stress=None, subdomain=0):
         sol = np.ascontiguousarray(solution, float)
@@ -254,6 +281,11 @@ class FluidSolver:
 
     def set_profiling(self, on=True):
         self.L.ifem_set_profiling(self.ctx, int(on))
+
+    def synchronize(self):
+        rc = self.L.ifem_synchronize(self.ctx)
+        if rc < 0:
+            raise HostError(rc, self.L.ifem_last_error().decode())
 
     def timing(self):
         t = capi.Timing()

@@ -209,3 +209,16 @@ def test_vtu_writer_matches_reference_field_layout(tmp_path):
     # VTK hexahedron vertex order: the first patch is a right-handed box
     p = pts[:8]
     assert np.dot(np.cross(p[1] - p[0], p[3] - p[0]), p[4] - p[0]) > 0
+
+
+def test_load_checkpoint_without_files_starts_from_the_beginning(tmp_path):
+    # FluidSolver::load_checkpoint (mpi_fluid_solver.cpp:643-665): no *.fluid_checkpoint in the directory -> false, and
+    # the solver is left untouched (no device needed up to here)
+    from openifem_amd import host
+    s = host.InsIM(host.channel_prm(2), (4, 2), (0, 0), (2.0, 0.2))
+    assert s.load_checkpoint(str(tmp_path)) is False
+    assert s.time() == (0, 0.0)
+    # a marker without its .info file is a broken checkpoint: reported, not silently skipped
+    open(tmp_path / "000003.fluid_checkpoint", "w").write("x\n")
+    with pytest.raises(host.HostError):
+        s.load_checkpoint(str(tmp_path))
