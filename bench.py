@@ -169,14 +169,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    import torch
-    torch.cuda.set_device(local_rank)
 
-    def fence():  # barrier + device idle: the library's own stream, and torch's for good measure
+    def fence():
+        # barrier + device idle.  The device work runs on the library's own HIP runtime and stream, so the library's
+        # hipDeviceSynchronize is the device fence; torch holds no device state in this process (torch.cuda is never
+        # initialised: it would bring up a second HIP runtime next to the library's).
         if dist:
             dist.barrier()
         solver.synchronize()
-        torch.cuda.synchronize()
 
     fence()
     t0 = time.time()
@@ -198,9 +198,9 @@ def main():
         mf_ms += tm.mf_ms_avg * tm.mf_calls
         mf_calls += tm.mf_calls
     solver.synchronize()
-    torch.cuda.synchronize()
     elapsed = time.time() - t0
     if dist:
+        import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])

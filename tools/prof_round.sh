@@ -1,14 +1,14 @@
 set -x
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r01d
+mkdir -p $R/gpurun_out/r01e
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r01d/kt -o kt -- python $R/bench.py --steps 2 --warmup 1 --cpu-cells 0 > $R/gpurun_out/r01d/bench_under_rocprof.jsonl 2> $R/gpurun_out/r01d/kt.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/r01d/fetch -o f -- python $R/bench.py --steps 1 --warmup 0 --cpu-cells 0 > /dev/null 2> $R/gpurun_out/r01d/fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/r01d/write -o w -- python $R/bench.py --steps 1 --warmup 0 --cpu-cells 0 > /dev/null 2> $R/gpurun_out/r01d/write.err
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r01e/kt -o kt -- python $R/bench.py --steps 2 --warmup 1 --cpu-cells 0 > $R/gpurun_out/r01e/bench_under_rocprof.jsonl 2> $R/gpurun_out/r01e/kt.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/r01e/fetch -o f -- python $R/bench.py --steps 1 --warmup 0 --cpu-cells 0 > /dev/null 2> $R/gpurun_out/r01e/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/r01e/write -o w -- python $R/bench.py --steps 1 --warmup 0 --cpu-cells 0 > /dev/null 2> $R/gpurun_out/r01e/write.err
 cd $R
-find gpurun_out/r01d -name "*.db" | head
-for d in kt fetch write; do db=$(find gpurun_out/r01d/$d -name "*.db" | head -1); python tools/rocpd_summary.py $db gpurun_out/r01d/$d; done
-python bench.py > gpurun_out/r01d/bench_default.jsonl 2> gpurun_out/r01d/bench_default.err
-tail -1 gpurun_out/r01d/bench_default.jsonl | cut -c1-600
-find gpurun_out/r01d -name "*.db" -delete
-ls -la gpurun_out/r01d
+find gpurun_out/r01e -name "*.db" | head
+for d in kt fetch write; do db=$(find gpurun_out/r01e/$d -name "*.db" | head -1); python tools/rocpd_summary.py $db gpurun_out/r01e/$d; done
+python bench.py > gpurun_out/r01e/bench_default.jsonl 2> gpurun_out/r01e/bench_default.err
+tail -1 gpurun_out/r01e/bench_default.jsonl | cut -c1-600
+find gpurun_out/r01e -name "*.db" -delete
+ls -la gpurun_out/r01e
