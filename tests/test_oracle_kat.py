@@ -275,3 +275,58 @@ def test_fluid_cylinder_insimex_serial_time_loop_constants():
     vmax, pmax = x[:S.n_u].max(), x[S.n_u:].max()
     assert abs(vmax - 0.4081072) / 0.4081072 < 1e-3
     assert abs(pmax - 0.1539) / 0.1539 < 1e-3
+
+
+def _acoustic_run(m, n_steps, dt, t0, width, sigma_of_x=None):
+    """tests/acoustic_duct_wave_mpi/*.cpp:33-59 and tests/acoustic_pml_mpi/*.cpp:33-79: MPI::SCnsIM<2>, Q1/Q1, air
+    (mu 1.8e-4, rho 1.3e-3), Gaussian velocity pulse 6 exp(-((t - t0)/width)^2 / 2) on the inlet as a hard-coded,
+    time-dependent Dirichlet field; u_x = 0 at the outlet, u_y = 0 on the walls.  The Field returns the INCREMENT over
+    the step (the Newton update is what the nonzero constraints act on); SUPGFluidSolver::run advances the Field time by
+    dt before every step and re-makes the constraints (mpi_supg_solver.cpp:438-480), update_stress feeds the next step."""
+    mu, rho = 1.8e-4, 1.3e-3
+    S = orc.System(m)
+    sigma = None
+    if sigma_of_x is not None:  # PML damping at the quadrature points [n_cells][n_q]
+        import ctypes as C
+        nq1 = m.kv + 1
+        qp = np.zeros((nq1 ** 2, 2))
+        scratch = np.zeros(4096)
+        orc.lib().orc_fe_tables(2, m.kv, nq1, scratch.ctypes.data_as(C.c_void_p), scratch.ctypes.data_as(C.c_void_p),
+                                scratch.ctypes.data_as(C.c_void_p), qp.ctypes.data_as(C.c_void_p))
+        x0, hx = m.vcoords[:, 0, 0], m.vcoords[:, 1, 0] - m.vcoords[:, 0, 0]
+        sigma = sigma_of_x(x0[:, None] + qp[None, :, 0] * hx[:, None])
+    pulse = lambda t: 6.0 * np.exp(-0.5 * ((t - t0) / width) ** 2)  # noqa: E731
+    unit = {0: lambda p, c: 1.0 if (c == 0 and abs(p[0]) < 1e-10) else 0.0}
+    dofs, shape = m.dirichlet({0: (1, [100]), 1: (1, [0]), 2: (2, [0]), 3: (2, [0])}, unit)
+    S.set_constraints(0, dofs, None)
+    x = np.zeros(S.n)
+    stress = None
+    for k in range(1, n_steps + 1):
+        t = k * dt
+        inc = pulse(t) - (0.0 if k < 2 else pulse(t - dt))
+        S.set_constraints(1, dofs, shape * inc)
+        P = orc.make_scns_params(mu=mu, rho=rho, dt=dt, stress=stress, sigma_pml=sigma)
+        rc, _ = S.scns_run_one_step(P, True, x)
+        assert rc > 0
+        stress = S.update_stress(mu, x)
+    return S, x
+
+
+def test_acoustic_duct_wave_mpi_regression_constant():
+    # tests/acoustic_duct_wave_mpi/acoustic_duct_wave_mpi.cpp:52-68: 8 x 2 cells of [0,4] x [0,1] refined 3 times, 1000
+    # steps of 1e-7: the pulse travels down the duct at the isentropic speed of sound; max velocity 5.93 (the peak 6 with
+    # the scheme's dispersion) at 1e-3 -- pins the compressibility terms of the SCnsIM integrand
+    m = BoxMesh([64, 16], (0, 0), (4.0, 1.0), kv=1)
+    S, x = _acoustic_run(m, 1000, 1e-7, 0.5e-4, 0.15e-4)
+    vmax = x[:S.n_u].max()
+    assert abs(vmax - 5.93) / 5.93 < 1e-3
+
+
+def test_acoustic_pml_mpi_known_answer():
+    # tests/acoustic_pml_mpi/acoustic_pml_mpi.cpp:33-84: 7 x 2 cells of [0,1.4] x [0,0.4] refined 3 times, quartic PML
+    # sigma = 340000 ((x - 0.2) / 1.2)^4 for x > 0.2, 500 steps of 1e-7: the pulse is absorbed, |vmax| < 5e-2
+    m = BoxMesh([56, 16], (0, 0), (1.4, 0.4), kv=1)
+    S, x = _acoustic_run(m, 500, 1e-7, 0.5e-6, 0.15e-6,
+                         sigma_of_x=lambda xq: np.where(xq > 0.2, 340000.0 * ((xq - 0.2) / 1.2) ** 4, 0.0))
+    assert abs(x[:S.n_u].max()) < 5e-2
+    assert np.abs(x[:S.n_u]).max() > 0  # the run did move the fluid
