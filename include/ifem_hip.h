@@ -163,6 +163,16 @@ int64_t ifem_nnz(const ifem_ctx *ctx, int block); /* 0: A_uu blocks, 1: B blocks
 /* FluidSolver::make_constraints result (mpi_fluid_solver.cpp:165-280): which = 0 zero_constraints,
  * 1 nonzero_constraints; Dirichlet lines (local dof, inhomogeneity). */
 int ifem_set_constraints(ifem_ctx *ctx, int which, int32_t n, const int32_t *dof, const double *inhom);
+/* Hanging-node lines of both AffineConstraints objects (DoFTools::make_hanging_node_constraints,
+ * mpi_fluid_solver.cpp:182-184; consumed by distribute_local_to_global, mpi_insim.cpp:343-355, and by
+ * constraints.distribute, :390):  x[dof[i]] = sum_{k in [ptr[i], ptr[i+1])} weight[k] * x[master[k]],  local dof ids as in
+ * ifem_set_constraints (velocity dofs, then n_u + pressure node).  The lines must be closed with respect to each other
+ * (no master is itself a hanging dof); masters may be Dirichlet-constrained (their inhomogeneity is inherited, as
+ * AffineConstraints::close() does).  A hanging dof must not also be listed in ifem_set_constraints
+ * (interpolate_boundary_values skips constrained dofs).  Assemble, solve and the *_step calls then work on the condensed
+ * system; the returned update has its hanging entries interpolated.  n = 0 removes the lines.  Single-rank contexts. */
+int ifem_set_hanging_constraints(ifem_ctx *ctx, int32_t n, const int32_t *dof, const int32_t *ptr, const int32_t *master,
+                                 const double *weight);
 /* cell_property[*].indicator written by MPI::FSI::update_indicator (mpi_fsi.cpp:291-321); NULL = all 0 */
 int ifem_set_cell_fields(ifem_ctx *ctx, const int32_t *indicator);
 

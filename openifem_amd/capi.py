@@ -71,7 +71,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_set_cell_fields", "ifem_vec_set", "ifem_vec_get", "ifem_vec_copy", "ifem_vec_zero", "ifem_vec_axpy",
            "ifem_vec_norm2", "ifem_vec_minmax", "ifem_halo_exchange", "ifem_ins_assemble", "ifem_solve",
            "ifem_rhs_norm", "ifem_ins_newton_step", "ifem_system_vmult", "ifem_uu_vmult", "ifem_precond_vmult", "ifem_export_csr",
-           "ifem_get_timing", "ifem_set_profiling", "ifem_synchronize", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
+           "ifem_get_timing", "ifem_set_profiling", "ifem_synchronize", "ifem_set_hanging_constraints", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
            "ifem_scns_assemble", "ifem_scns_solve", "ifem_scns_newton_step", "ifem_imex_assemble", "ifem_imex_solve",
            "ifem_imex_step", "ifem_set_eddy_viscosity"]
 
@@ -126,6 +126,7 @@ def load():
     L.ifem_local_world_destroy.argtypes = [C.c_void_p]
     L.ifem_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.ifem_synchronize.argtypes = [C.c_void_p]
+    L.ifem_set_hanging_constraints.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifem_set_ainv_kind.argtypes = [C.c_void_p, C.c_int]
     L.ifem_set_scns_fields.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifem_set_eddy_viscosity.argtypes = [C.c_void_p, C.c_void_p]
@@ -212,6 +213,12 @@ class Context:
         dofs = np.ascontiguousarray(dofs, np.int32)
         vals = None if vals is None else np.ascontiguousarray(vals, float)
         self._chk(self.L.ifem_set_constraints(self.h, which, len(dofs), _ptr(dofs), _ptr(vals)))
+
+    def set_hanging_constraints(self, dof, ptr, master, weight):
+        """hanging-node lines x[dof[i]] = sum_k weight[k] x[master[k]] (ifem_set_hanging_constraints); empty dof clears"""
+        dof, ptr = np.ascontiguousarray(dof, np.int32), np.ascontiguousarray(ptr, np.int32)
+        master, weight = np.ascontiguousarray(master, np.int32), np.ascontiguousarray(weight, float)
+        self._chk(self.L.ifem_set_hanging_constraints(self.h, len(dof), _ptr(dof), _ptr(ptr), _ptr(master), _ptr(weight)))
 
     def set_indicator(self, ind):
         ind = None if ind is None else np.ascontiguousarray(ind, np.int32)

@@ -170,6 +170,13 @@ int ifem_set_constraints(ifem_ctx *ctx, int which, int32_t n, const int32_t *dof
   IFEM_API_END
 }
 
+int ifem_set_hanging_constraints(ifem_ctx *ctx, int32_t n, const int32_t *dof, const int32_t *ptr, const int32_t *master,
+                                 const double *weight) {
+  IFEM_API_BEGIN
+  ifem::hanging_set(ctx, n, dof, ptr, master, weight);
+  IFEM_API_END
+}
+
 int ifem_set_cell_fields(ifem_ctx *ctx, const int32_t *indicator) {
   IFEM_API_BEGIN
   if (indicator) {

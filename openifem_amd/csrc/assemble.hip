@@ -371,6 +371,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   if (ctx->asm_rows) {
     launch_ins_assemble_rows(ctx, p, use_nonzero);
     assemble_epilogue(ctx, use_nonzero);
+    hanging_condense_rhs(ctx, use_nonzero);
     return;
   }
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
@@ -427,6 +428,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
     IFEM_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->timing.assemble_kernel_ms = ms;
   }
+  hanging_condense_rhs(ctx, use_nonzero);
 }
 
 static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero) {

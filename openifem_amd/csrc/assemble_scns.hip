@@ -475,6 +475,7 @@ void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonz
   ctx->sm_valid = false; ctx->sm_key = -1;
   ctx->shat_valid = false;
   ctx->asm_constraint_set = use_nonzero ? 1 : 0;
+  hanging_condense_rhs(ctx, use_nonzero);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -135,6 +135,17 @@ struct Halo {
 
 } // namespace ifem
 
+namespace ifem {
+// hanging-node constraint lines x[dof_i] = sum_k w_k x[master_k] (closed), see hanging.hip
+struct Hanging {
+  int32_t n = 0;
+  DBuf<int32_t> dof, ptr, master;
+  DBuf<double> w, d, x, c0; // weights, diagonal of the hanging rows, scratch input vector, inhomogeneity vector
+  DBuf<int> flag;
+  std::vector<int32_t> host_dof;
+};
+} // namespace ifem
+
 struct ifem_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -177,6 +188,7 @@ struct ifem_ctx {
   ifem::DBuf<float> Shat_f32;
   bool want_shat = false, shat_valid = false, shat_aux_valid = false;
   int asm_constraint_set = 0;
+  ifem::Hanging hang; // hanging-node lines (hanging.hip)
   // matrix-free A_uu (IFEM_AINV_GMRES_BJACOBI_MF): state of the last ifem_ins_assemble
   ifem::DBuf<double> mf_ycell; // per-cell results of the matrix-free apply [n_cells][nu][dim] (two-stage scatter)
   ifem::DBuf<double> mf_eval;  // velocity part of the evaluation point, ghost-extended

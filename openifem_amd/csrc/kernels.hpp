@@ -84,6 +84,14 @@ double cgd_rr(ifem_ctx *ctx);
 void v_minmax(ifem_ctx *ctx, int64_t n, const double *x, double *mn, double *mx);
 // x[dof] = value for constrained dofs (AffineConstraints::distribute, Dirichlet lines)
 void apply_constraints(ifem_ctx *ctx, int which, double *x);
+// hanging-node lines (hanging.hip): C x on a copy of x, C^T and the hanging rows on y, distribute, set-up
+void hanging_set(ifem_ctx *ctx, int32_t n, const int32_t *dof, const int32_t *ptr, const int32_t *master, const double *weight);
+const double *hanging_input(ifem_ctx *ctx, const double *x);
+void hanging_output(ifem_ctx *ctx, const double *x, double *y);
+void hanging_distribute(ifem_ctx *ctx, double *x);
+void hanging_refresh_diag(ifem_ctx *ctx);
+bool hanging_offset(ifem_ctx *ctx, int use_nonzero);
+void hanging_condense_rhs(ifem_ctx *ctx, int use_nonzero); // solver.hip: b = C^T (b^ - A^ c0), hanging rows d c0
 
 // all-reduce helpers (identity for a single rank)
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n);

@@ -282,7 +282,18 @@ static void extend_p(SolveState &S, const double *xp, const double **out) {
   *out = S.xp_ext;
 }
 
+// the assembled operator A^ = [A_uu B^T; B A_pp] on compact owned vectors
+static void system_apply_raw(SolveState &S, const double *x, double *y, bool time_it);
+
+// operator of the outer Krylov solver: A^, or C^T A^ C with the hanging rows replaced by their diagonal (hanging.hip)
 static void system_apply(SolveState &S, const double *x, double *y, bool time_it) {
+  ifem_ctx *c = S.ctx;
+  if (!c->hang.n) { system_apply_raw(S, x, y, time_it); return; }
+  system_apply_raw(S, hanging_input(c, x), y, time_it);
+  hanging_output(c, x, y);
+}
+
+static void system_apply_raw(SolveState &S, const double *x, double *y, bool time_it) {
   ifem_ctx *c = S.ctx;
   const double *xu, *xp;
   extend_u(S, x, &xu);
@@ -461,6 +472,25 @@ void ins_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solve
   precond_vmult(S, src, dst);
 }
 
+// right-hand side of the condensed system after an assembly that treated the hanging dofs as ordinary ones:
+// b = C^T (b^ - A^ c0) on the regular rows, d_h c0_h on the hanging rows (distribute_local_to_global semantics)
+void hanging_condense_rhs(ifem_ctx *ctx, int use_nonzero) {
+  if (!ctx->hang.n) return;
+  ifem_solver_opts o;
+  ifem_default_solver_opts(&o);
+  SolveState S{ctx, nullptr, &o};
+  carve_workspace(S);
+  hanging_refresh_diag(ctx);
+  double *rhs = ctx->vec[IFEM_VEC_RHS].p;
+  const bool inhom = hanging_offset(ctx, use_nonzero);
+  if (inhom) {
+    system_apply_raw(S, ctx->hang.c0.p, S.outer_w, false);
+    v_axpy(ctx, S.n, -1.0, S.outer_w, rhs);
+  } else
+    v_zero(ctx, S.n, ctx->hang.c0.p);
+  hanging_output(ctx, ctx->hang.c0.p, rhs);
+}
+
 void ins_system_vmult(ifem_ctx *ctx, const double *src, double *dst) {
   ifem_solver_opts o;
   ifem_default_solver_opts(&o);
@@ -530,6 +560,7 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
   const int it = gmres(ctx, S.n, basis_ld(S.n), true, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p,
                        ctx->krylovZ.p, S.outer_w, &res, mdot);
   apply_constraints(ctx, use_nonzero ? 1 : 0, upd);
+  hanging_distribute(ctx, upd);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   S.st.fgmres_iters = it; S.st.fgmres_res = res; S.st.t_total_ms = total.ms();
   if (stats) *stats = S.st;
@@ -566,6 +597,7 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   const int it = gmres(ctx, S.n, basis_ld(S.n), /*reorth=*/true, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p, ctx->krylovZ.p,
                        S.outer_w, &res, mdot);
   apply_constraints(ctx, use_nonzero ? 1 : 0, upd); // constraints_used.distribute(newton_update)
+  hanging_distribute(ctx, upd);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   S.st.fgmres_iters = it;
   S.st.fgmres_res = res;

@@ -450,6 +450,74 @@ void orc_ins_assemble(orc_system *s, const orc_params *P, int32_t use_nonzero, c
   }
 }
 
+/* InsIM assembly through AffineConstraints that also hold hanging-node lines
+ * (DoFTools::make_hanging_node_constraints, mpi_fluid_solver.cpp:182-184, then interpolate_boundary_values which skips
+ * dofs that are already constrained, :185-271, then close()).  distribute_local_to_global(Ke, fe, idx, A, rhs, true)
+ * [3P deal.II, SURVEY A.4]: an unconstrained local dof goes to its own row/column; a constrained one is replaced by its
+ * masters with their weights (none for a Dirichlet line), receives |Ke_ii| (or the mean |diagonal| of Ke when that is
+ * zero) on its own diagonal and that value times its inhomogeneity on the right-hand side; every row target gets
+ * fe_i - sum_{j constrained} Ke_ij b_j.  close() turns a Dirichlet master of a hanging line into inhomogeneity.
+ * Output: dense n x n matrix (row-major) and rhs -- for the small meshes of the hanging-node parity tests. */
+void orc_ins_assemble_affine_dense(orc_system *s, const orc_params *P, int32_t use_nonzero, const double *eval,
+                                   const double *present, const double *fsi_acc, int32_t n_lines, const int32_t *dof,
+                                   const int32_t *ptr, const int32_t *master, const double *weight, double *A, double *rhs) {
+  const int nd = s->ndof_cell, n = s->n;
+  const unsigned char *isc = s->is_c[use_nonzero ? 1 : 0];
+  const double *cv = s->cval[use_nonzero ? 1 : 0];
+  /* closed lines: line_of[g] = -1 unconstrained, -2 Dirichlet, >= 0 hanging line index */
+  int *line_of = (int *)malloc(sizeof(int) * (size_t)n);
+  double *inhom = (double *)calloc((size_t)n, sizeof(double));
+  for (int g = 0; g < n; ++g) { line_of[g] = isc[g] ? -2 : -1; if (isc[g]) inhom[g] = cv[g]; }
+  for (int l = 0; l < n_lines; ++l) {
+    line_of[dof[l]] = l; /* hanging lines come first: a boundary value never overrides them */
+    inhom[dof[l]] = 0;
+  }
+  for (int l = 0; l < n_lines; ++l)
+    for (int k = ptr[l]; k < ptr[l + 1]; ++k)
+      if (line_of[master[k]] == -2) inhom[dof[l]] += weight[k] * cv[master[k]];
+  memset(A, 0, sizeof(double) * (size_t)n * n);
+  memset(rhs, 0, sizeof(double) * (size_t)n);
+  double *Ke = (double *)malloc(sizeof(double) * (size_t)nd * nd);
+  double *Me = (double *)malloc(sizeof(double) * (size_t)nd * nd);
+  double fe[MAXDOF]; int32_t idx[MAXDOF];
+  for (int cell = 0; cell < s->m.n_cells; ++cell) {
+    cell_integrals(s, P, cell, eval, present, fsi_acc, Ke, Me, fe);
+    cell_dofs(s, cell, idx);
+    double avgK = 0;
+    for (int i = 0; i < nd; ++i) avgK += fabs(Ke[i * nd + i]);
+    avgK /= nd;
+    for (int i = 0; i < nd; ++i) {
+      const int gi = idx[i], li = line_of[gi];
+      if (li != -1) {
+        const double kd = fabs(Ke[i * nd + i]) != 0 ? fabs(Ke[i * nd + i]) : avgK;
+        A[(size_t)gi * n + gi] += kd;
+        rhs[gi] += kd * inhom[gi];
+      }
+      double val = fe[i];
+      for (int j = 0; j < nd; ++j) if (line_of[idx[j]] != -1) val -= Ke[i * nd + j] * inhom[idx[j]];
+      /* row targets of local dof i */
+      const int nti = li == -1 ? 1 : (li == -2 ? 0 : ptr[li + 1] - ptr[li]);
+      for (int a = 0; a < nti; ++a) {
+        int r; double wr;
+        if (li == -1) { r = gi; wr = 1.0; }
+        else { r = master[ptr[li] + a]; wr = weight[ptr[li] + a]; if (line_of[r] != -1) continue; /* Dirichlet master: closed away */ }
+        rhs[r] += wr * val;
+        for (int j = 0; j < nd; ++j) {
+          const int gj = idx[j], lj = line_of[gj];
+          const int ntj = lj == -1 ? 1 : (lj == -2 ? 0 : ptr[lj + 1] - ptr[lj]);
+          for (int b = 0; b < ntj; ++b) {
+            int c; double wc;
+            if (lj == -1) { c = gj; wc = 1.0; }
+            else { c = master[ptr[lj] + b]; wc = weight[ptr[lj] + b]; if (line_of[c] != -1) continue; }
+            A[(size_t)r * n + c] += wr * wc * Ke[i * nd + j];
+          }
+        }
+      }
+    }
+  }
+  free(Ke); free(Me); free(line_of); free(inhom);
+}
+
 /* ------------------------------------------------------------------ vector helpers */
 static int g_max_threads = 0;
 static int nthr(long n, long grain) {

@@ -89,6 +89,11 @@ double *orc_rhs(orc_system *s);
 
 void orc_ins_assemble(orc_system *s, const orc_params *p, int32_t use_nonzero, const double *eval,
                       const double *present, const double *fsi_acc);
+/* the same assembly through constraints that also hold hanging-node lines x[dof[l]] = sum_k weight[k] x[master[k]],
+ * k in [ptr[l], ptr[l+1]); dense n x n output (row-major) for small meshes; Dirichlet lines from orc_set_constraints */
+void orc_ins_assemble_affine_dense(orc_system *s, const orc_params *p, int32_t use_nonzero, const double *eval,
+                                   const double *present, const double *fsi_acc, int32_t n_lines, const int32_t *dof,
+                                   const int32_t *ptr, const int32_t *master, const double *weight, double *A, double *rhs);
 /* single-cell dense Ke/Me/fe (ndof x ndof row-major, local dof = [a*dim+c | p]) before constraints */
 void orc_ins_cell(const orc_mesh *m, const orc_params *p, int32_t cell, const double *eval,
                   const double *present, const double *fsi_acc, double *Ke, double *Me, double *fe);

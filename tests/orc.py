@@ -70,6 +70,8 @@ def _bind(L):
         getattr(L, f).restype = C.POINTER(t)
         getattr(L, f).argtypes = [C.c_void_p]
     L.orc_ins_assemble.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_ins_assemble_affine_dense.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_ins_cell.argtypes = [C.POINTER(_Mesh), C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_ins_solve.restype = C.c_int32
@@ -200,6 +202,14 @@ class System:
 
     def assemble(self, params, use_nonzero, evalp, present, fsi_acc=None):
         self.L.orc_ins_assemble(self.h, C.byref(params), int(use_nonzero), _ptr(evalp), _ptr(present), _ptr(fsi_acc))
+
+    def assemble_affine_dense(self, params, use_nonzero, evalp, present, mesh, fsi_acc=None):
+        """assembly through constraints that also hold the hanging lines of `mesh` (tests/hangmesh.py): dense (A, rhs)"""
+        A, b = np.zeros((self.n, self.n)), np.zeros(self.n)
+        self.L.orc_ins_assemble_affine_dense(self.h, C.byref(params), int(use_nonzero), _ptr(evalp), _ptr(present), _ptr(fsi_acc),
+                                             len(mesh.hang_dof), _ptr(mesh.hang_dof), _ptr(mesh.hang_ptr), _ptr(mesh.hang_master),
+                                             _ptr(mesh.hang_weight), _ptr(A), _ptr(b))
+        return A, b
 
     def csr(self, which="A"):
         import scipy.sparse as sp
