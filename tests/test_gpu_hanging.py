@@ -176,3 +176,50 @@ def test_scnsim_with_hanging_nodes(dim, form):
     assert np.abs(upd - xo).max() <= 1e-4 * np.abs(xo).max()
     assert np.abs(upd - Cm @ upd).max() <= 1e-12 * np.abs(upd).max()
     ctx.close()
+
+
+def test_insimex_with_hanging_nodes():
+    # InsIMEX (mpi_insimex.cpp:150-355): matrix assembled once, then right-hand-side-only assemblies; both go through the
+    # same condensation.  Reference here: the oracle's ordinary IMEX assembly condensed in numpy (see the SCnsIM test)
+    capi = _capi()
+    m = _mesh(2, 2)
+    rng = np.random.default_rng(77)
+    dofs, vals = m.dirichlet({0: (3, [0.3, -0.2]), 2: (3, [0.0, 0.0])}, {0: lambda p, c: 0.3 + 0.5 * p[1] if c == 0 else 0.1 * p[1]})
+    pr = 0.3 * rng.standard_normal(m.n_dofs)
+    kw = dict(mu=0.7, rho=1.3, gamma=0.1, dt=0.05, g=(0.2, -9.8), neumann={1: 2.0})
+    Cm = m.prolongation()
+    isc = np.zeros(m.n_dofs, bool)
+    isc[dofs] = True
+    cv = np.zeros(m.n_dofs)
+    cv[dofs] = vals
+    Cc, c0 = Cm.copy(), np.zeros(m.n_dofs)
+    for d in m.hang_dof:
+        c0[d] = Cm[d, isc] @ cv[isc]
+        Cc[d, isc] = 0
+    reg = np.setdiff1d(np.arange(m.n_dofs), m.hang_dof)
+    S = orc.System(m)
+    S.set_constraints(0, dofs, None)
+    S.set_constraints(1, dofs, vals)
+    ctx = capi.Context(m.dim, m.kv, m.vcoords, m.cell_unodes, m.cell_pnodes, m.cell_face_bid, m.n_unodes, m.n_pnodes)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.set_hanging_constraints(m.hang_dof, m.hang_ptr, m.hang_master, m.hang_weight)
+    ctx.vec_set(capi.VEC_PRESENT, pr)
+    for use_nonzero, assemble_system in ((True, True), (False, True), (False, False)):
+        S.imex_assemble(orc.make_params(**kw), use_nonzero, assemble_system, pr)
+        Ah, bh = S.csr("A").toarray(), S.rhs()
+        off = c0 if use_nonzero else 0 * c0
+        Ao, bo = Cc.T @ Ah @ Cc, Cc.T @ (bh - Ah @ off)
+        ctx.imex_assemble(capi.make_params(**kw), use_nonzero, assemble_system)
+        b = ctx.vec_get(capi.VEC_RHS)
+        assert np.abs(b[reg] - bo[reg]).max() <= 1e-11 * np.abs(bo).max()
+        x = rng.standard_normal(m.n_dofs)
+        y, yo = ctx.system_vmult(x), Ao @ x
+        assert np.abs(y[reg] - yo[reg]).max() <= 1e-11 * np.abs(yo).max()
+    ctx.imex_solve(capi.make_params(**kw), False)
+    upd = ctx.vec_get(capi.VEC_UPDATE)
+    xo = np.zeros(m.n_dofs)
+    xo[reg] = np.linalg.solve(Ao[np.ix_(reg, reg)], bo[reg])
+    xo = Cm @ xo
+    assert np.abs(upd - xo).max() <= 1e-6 * np.abs(xo).max()
+    ctx.close()
