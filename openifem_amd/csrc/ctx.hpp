@@ -189,6 +189,11 @@ struct ifem_ctx {
   bool want_shat = false, shat_valid = false, shat_aux_valid = false;
   int asm_constraint_set = 0;
   ifem::Hanging hang; // hanging-node lines (hanging.hip)
+  // explicit T_pp = A_pp - A_pv Binv A_vp on the pattern of Sm and its dense LU (tpp.hip)
+  ifem::DBuf<double> Tpp, tpp_diag, tpp_dense;
+  ifem::DBuf<int> tpp_ipiv;
+  bool tpp_valid = false, tpp_dense_valid = false, tpp_prefer_dense = false;
+  void *rocblas = nullptr;
   // matrix-free A_uu (IFEM_AINV_GMRES_BJACOBI_MF): state of the last ifem_ins_assemble
   ifem::DBuf<double> mf_ycell; // per-cell results of the matrix-free apply [n_cells][nu][dim] (two-stage scatter)
   ifem::DBuf<double> mf_eval;  // velocity part of the evaluation point, ghost-extended

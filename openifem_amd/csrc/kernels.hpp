@@ -84,6 +84,14 @@ double cgd_rr(ifem_ctx *ctx);
 void v_minmax(ifem_ctx *ctx, int64_t n, const double *x, double *mn, double *mx);
 // x[dof] = value for constrained dofs (AffineConstraints::distribute, Dirichlet lines)
 void apply_constraints(ifem_ctx *ctx, int which, double *x);
+void spmv_planar_scalar(ifem_ctx *ctx, const PlanarCsr &M, const double *val, const double *xp, double *yp);
+// explicit pressure Schur complement of the SUPG block preconditioner (tpp.hip)
+void tpp_numeric(ifem_ctx *ctx);
+void spmv_tpp(ifem_ctx *ctx, const double *xp, double *yp);
+bool tpp_dense_setup(ifem_ctx *ctx);
+int64_t tpp_dense_max();
+void tpp_dense_solve(ifem_ctx *ctx, const double *x, double *y);
+void tpp_release(ifem_ctx *ctx);
 // hanging-node lines (hanging.hip): C x on a copy of x, C^T and the hanging rows on y, distribute, set-up
 void hanging_set(ifem_ctx *ctx, int32_t n, const int32_t *dof, const int32_t *ptr, const int32_t *master, const double *weight);
 const double *hanging_input(ifem_ctx *ctx, const double *x);

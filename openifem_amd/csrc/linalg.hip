@@ -438,6 +438,14 @@ void schur_numeric(ifem_ctx *ctx) {
   ctx->sm_f32_valid = false;
 }
 
+// y = M x for a scalar matrix on the pattern of `M` with the values `val` (explicit T_pp on the pattern of S_m)
+void spmv_planar_scalar(ifem_ctx *ctx, const PlanarCsr &M, const double *val, const double *xp, double *yp) {
+  const int64_t n = M.n_rows;
+  if (n == 0) return;
+  hipLaunchKernelGGL((k_spmv_planar<1, 1, 32>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n, M.rowptr.p, M.col.p,
+                     val, xp, yp);
+}
+
 void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp, bool use_f32) {
   const int64_t n = ctx->Sm.n_rows;
   if (n == 0) return;

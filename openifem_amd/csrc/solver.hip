@@ -539,6 +539,20 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
     v_axpy(ctx, S.npo, -1.0, S.tp[4], y);
   };
   OpFn Jpp = [&](const double *x, double *y) { vec_div(ctx, S.npo, ctx->app_diag.p, x, y); };
+  // one rank: T_pp as an explicit matrix (tpp.hip) -- exact dense solve on small pressure spaces, else one SpMV per inner
+  // iteration and the Jacobi preconditioner of T_pp itself.  IFEM_TPP=operator keeps the operator form.
+  static const bool tpp_operator = [] { const char *e = getenv("IFEM_TPP"); return e && std::string(e) == "operator"; }();
+  const bool tpp_explicit = ctx->halo.nranks == 1 && !tpp_operator;
+  // The dense LU costs one factorisation per Newton iteration: it is switched on (for the life of the context) the first
+  // time an inner solve does not converge within `tpp_switch_its` iterations -- acoustics with dt ~ 1e-7 never get there.
+  const int tpp_switch_its = 100;
+  bool tpp_dense = false;
+  if (tpp_explicit) {
+    tpp_numeric(ctx);
+    if (ctx->tpp_prefer_dense) tpp_dense = tpp_dense_setup(ctx);
+    Tpp = [&](const double *x, double *y) { spmv_tpp(ctx, x, y); };
+    Jpp = [&](const double *x, double *y) { vec_div(ctx, S.npo, ctx->tpp_diag.p, x, y); };
+  }
   OpFn Pop = [&](const double *src, double *dst) {
     const double *src0 = src, *src1 = src + S.nuo;
     double *dst0 = dst, *dst1 = dst + S.nuo;
@@ -548,8 +562,20 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
     double pn;
     mdot_p(1, S.tp[0], S.npo, S.tp[0], &pn);
     double res = 0;
-    S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.npo), /*reorth=*/true, Tpp, Jpp, false, S.tp[0], dst1, mt, 100000,
-                              1e-3 * std::sqrt(pn), ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p);
+    const double inner_tol = 1e-3 * std::sqrt(pn);
+    if (!tpp_dense) {
+      const bool may_switch = tpp_explicit && !ctx->tpp_prefer_dense && S.npo <= tpp_dense_max();
+      S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.npo), /*reorth=*/true, Tpp, Jpp, false, S.tp[0], dst1, mt,
+                                may_switch ? tpp_switch_its : 100000, inner_tol, ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p);
+      if (may_switch && res > inner_tol) { // too slow for this system: factorise instead
+        ctx->tpp_prefer_dense = true;
+        tpp_dense = tpp_dense_setup(ctx);
+        if (!tpp_dense) // no rocSOLVER: carry on iteratively
+          S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.npo), true, Tpp, Jpp, false, S.tp[0], dst1, mt, 100000, inner_tol,
+                                    ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p);
+      }
+    }
+    if (tpp_dense) tpp_dense_solve(ctx, S.tp[0], dst1);
     bt_apply(dst1, S.tu);                          // A_vp dst1
     bjac_apply(ctx, S.tu, S.utmp);
     v_copy(ctx, S.nuo, S.inner_w, dst0);
