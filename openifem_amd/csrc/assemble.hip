@@ -374,13 +374,23 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
     hanging_condense_rhs(ctx, use_nonzero);
     return;
   }
+  // B, B^T, M_p and diag(M_u) depend on the mesh and on WHICH dofs are constrained, not on the solution or the
+  // parameters: an assembly with the constraint set of the previous one keeps them (bit-identical to re-integrating
+  // them) and integrates A_uu and the right-hand side only.  MFMA kernel only; IFEM_GEO_CACHE=0 switches it off.
+  static const bool geo_cache_on = [] { const char *e = getenv("IFEM_GEO_CACHE"); return !e || atoi(e) != 0; }();
+  static const bool other_kernel = [] { const char *e = getenv("IFEM_ASM"); return e && (std::string(e) == "v1" || std::string(e) == "v2"); }();
+  const int64_t geo_key = ctx->constraints_epoch * 2 + (use_nonzero ? 1 : 0);
+  const bool mfma_kernel = dim == 3 && ctx->kv == 2 && !other_kernel;
+  const bool skip_geo = geo_cache_on && assemble_system && mfma_kernel && ctx->geo_valid && ctx->geo_key == geo_key;
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
   if (assemble_system) {
     IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
-    IFEM_HIP_CHECK(hipMemsetAsync(ctx->Bt.val.p, 0, ctx->Bt.val.n * sizeof(double), s));
-    IFEM_HIP_CHECK(hipMemsetAsync(ctx->B.val.p, 0, ctx->B.val.n * sizeof(double), s));
-    IFEM_HIP_CHECK(hipMemsetAsync(ctx->Mp.val.p, 0, ctx->Mp.val.n * sizeof(double), s));
-    IFEM_HIP_CHECK(hipMemsetAsync(ctx->diagMu.p, 0, ctx->diagMu.n * sizeof(double), s));
+    if (!skip_geo) {
+      IFEM_HIP_CHECK(hipMemsetAsync(ctx->Bt.val.p, 0, ctx->Bt.val.n * sizeof(double), s));
+      IFEM_HIP_CHECK(hipMemsetAsync(ctx->B.val.p, 0, ctx->B.val.n * sizeof(double), s));
+      IFEM_HIP_CHECK(hipMemsetAsync(ctx->Mp.val.p, 0, ctx->Mp.val.n * sizeof(double), s));
+      IFEM_HIP_CHECK(hipMemsetAsync(ctx->diagMu.p, 0, ctx->diagMu.n * sizeof(double), s));
+    }
   }
   if (ctx->want_shat && assemble_system) {
     if (ctx->Shat.n != (size_t)ctx->Auu.nnzb) ctx->Shat.alloc((size_t)ctx->Auu.nnzb);
@@ -401,6 +411,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   A.is_c = ctx->has_c[w] ? ctx->is_c[w].p : nullptr;
   A.cval = ctx->has_c[w] ? ctx->cval[w].p : nullptr;
   A.use_inhom = (use_nonzero && ctx->has_c[1]) ? 1 : 0;
+  A.skip_geo = skip_geo ? 1 : 0;
   { const char *e = getenv("IFEM_ASM_SKIP"); A.debug_skip = e ? atoi(e) : 0; }
   { const char *e = getenv("IFEM_XCD"); A.xcd_swizzle = e ? atoi(e) : 1; }
   A.eval = ctx->vec[imex ? IFEM_VEC_PRESENT : IFEM_VEC_EVAL].p; A.present = ctx->vec[IFEM_VEC_PRESENT].p;
@@ -421,6 +432,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   else if (dim == 3 && ctx->kv == 2) launch_t<3, 2>(ctx, A);
   else throw Error(IFEM_E_BADPARAM, "unsupported (dim, kv)");
   IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+  if (assemble_system) { ctx->geo_valid = true; ctx->geo_key = geo_key; }
   if (assemble_system) assemble_epilogue(ctx, use_nonzero);
   else {
     IFEM_HIP_CHECK(hipEventSynchronize(ctx->ev1));

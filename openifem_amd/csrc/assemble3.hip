@@ -290,7 +290,12 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
   }
 
   // ---- velocity-pressure blocks: -JxW psi_b grad N_a
-  if (!A.rhs_only && A.debug_skip < 3 && active && h == 1) {
+  bool need_b = !A.rhs_only && A.debug_skip < 3 && active && h == 1;
+  if (need_b && A.skip_geo) { // cached blocks: only a cell with an inhomogeneous constrained dof still needs the entries
+    const bool mine = (lane < ND && S.cf[lane] && S.cv[lane] != 0.0) || (lane + 64 < ND && S.cf[lane + 64] && S.cv[lane + 64] != 0.0);
+    need_b = A.use_inhom && __any(mine);
+  }
+  if (need_b) {
 #pragma unroll 1
     for (int k = 0; k < BROUNDS; ++k) {
       const int t = lane + 64 * k;
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
           if (S.cf[a * DIM + c]) continue;
-          if (!pc) unsafeAtomicAdd(base + int64_t(c) * len, v[c]);
+          if (!pc) { if (!A.skip_geo) unsafeAtomicAdd(base + int64_t(c) * len, v[c]); }
           else if (A.use_inhom && S.cv[NU * DIM + pb] != 0.0) unsafeAtomicAdd(&S.fe[a * DIM + c], -v[c] * S.cv[NU * DIM + pb]);
         }
       }
@@ -318,14 +323,14 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
         double *base = A.v_b + S.rs_b[pb] * DIM + A.posPU[(cc * NP + pb) * NU + a];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
-          if (!S.cf[a * DIM + c]) unsafeAtomicAdd(base + int64_t(c) * len, v[c]);
+          if (!S.cf[a * DIM + c]) { if (!A.skip_geo) unsafeAtomicAdd(base + int64_t(c) * len, v[c]); }
           else if (A.use_inhom && S.cv[a * DIM + c] != 0.0) unsafeAtomicAdd(&S.fe[NU * DIM + pb], -v[c] * S.cv[a * DIM + c]);
         }
       }
     }
   }
   // ---- pressure mass matrix M_p and diag(M_u)
-  if (!A.rhs_only && A.debug_skip < 4) {
+  if (!A.rhs_only && !A.skip_geo && A.debug_skip < 4) {
     if (h == 1 && lane < NP * NP) {
       const int pa = lane / NP, pb = lane - pa * NP;
       double m = 0;

@@ -42,6 +42,8 @@ struct AsmArgs {
   int imex;     // InsIMEX (mpi_insimex.cpp:248-262): the matrix drops the two convective terms (explicit convection)
   int rhs_only; // InsIMEX with assemble_system = false: only the right-hand side is integrated and scattered (:343-346)
   int xcd_swizzle; // contiguous cell ranges per XCD (IFEM_XCD=0 switches it off)
+  int skip_geo;   // B, B^T, M_p and diag(M_u) of the previous assembly are still valid (same mesh, same constraint set):
+                  // integrate them only where a constrained dof needs their entries for the right-hand side
   int debug_skip; // measurement aid (IFEM_ASM_SKIP): 1 = skip the A_uu scatter, 2 = skip the pair contraction too
 };
 

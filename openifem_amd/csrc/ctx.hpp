@@ -188,6 +188,8 @@ struct ifem_ctx {
   ifem::DBuf<float> Shat_f32;
   bool want_shat = false, shat_valid = false, shat_aux_valid = false;
   int asm_constraint_set = 0;
+  bool geo_valid = false; // B, B^T, M_p, diag(M_u) hold the blocks of constraint set geo_key (assemble.hip)
+  int64_t geo_key = -1;
   ifem::Hanging hang; // hanging-node lines (hanging.hip)
   // explicit T_pp = A_pp - A_pv Binv A_vp on the pattern of Sm and its dense LU (tpp.hip)
   ifem::DBuf<double> Tpp, tpp_diag, tpp_dense;

@@ -429,3 +429,43 @@ def test_config1_fluid_cavity_first_steps_match_oracle():
     ip, op = key(pc), key(m.pnode_coords)
     pg, po = p[ip], x[S.n_u:][op]
     assert np.abs((pg - pg.mean()) - (po - po.mean())).max() < 1e-4 * (po.max() - po.min())
+
+
+def test_cached_geometry_blocks_stay_identical_across_assemblies():
+    # B, B^T, M_p and diag(M_u) do not depend on the solution: the MFMA assembly keeps them while the constraint set is
+    # unchanged and re-integrates them when it changes.  Every assembly of the sequence must match the oracle in full.
+    capi = _capi()
+    rng = np.random.default_rng(99)
+    m = BoxMesh((3, 2, 2), (0, 0, 0), (1.0, 0.6, 0.4), kv=2)
+    m.vcoords = m.vcoords + 0.02 * rng.standard_normal(m.vcoords.shape)
+    kw = dict(mu=0.7, rho=1.3, gamma=0.1, dt=0.05, g=(0.2, -9.8, 0.4), neumann={1: 2.0})
+    bc1 = m.dirichlet({0: (7, [0.3, -0.2, 0.1]), 2: (7, [0.0, 0.0, 0.0])})
+    bc2 = m.dirichlet({0: (7, [0.3, -0.2, 0.1]), 3: (5, [0.4, 0.0])})
+    ctx = _ctx(m)
+    S = orc.System(m)
+    n_u = m.dim * m.n_unodes
+
+    def check(use_nonzero, tag):
+        ev, pr = _rand_state(m, rng)
+        ctx.vec_set(capi.VEC_PRESENT, pr)
+        ctx.vec_set(capi.VEC_EVAL, ev)
+        ctx.assemble(capi.make_params(**kw), use_nonzero)
+        S.assemble(orc.make_params(**kw), use_nonzero, ev, pr)
+        A, M, b = ctx.export_csr(0), ctx.export_csr(1), ctx.vec_get(capi.VEC_RHS)
+        Ao, Mo, bo = S.csr("A"), S.csr("M"), S.rhs()
+        assert abs(A - Ao).max() / abs(Ao).max() < 1e-11, tag
+        assert np.abs(b - bo).max() / np.abs(bo).max() < 1e-11, tag
+        assert np.abs(M.diagonal()[:n_u] - Mo.diagonal()[:n_u]).max() / Mo.diagonal()[:n_u].max() < 1e-12, tag
+        assert abs(M[n_u:, n_u:] - Mo[n_u:, n_u:]).max() / abs(Mo[n_u:, n_u:]).max() < 1e-12, tag
+
+    for (dofs, vals), name in ((bc1, "first set"), (bc2, "second set")):
+        ctx.set_constraints(0, dofs, None)
+        ctx.set_constraints(1, dofs, vals)
+        S.set_constraints(0, dofs, None)
+        S.set_constraints(1, dofs, vals)
+        check(True, name + ": nonzero constraints, fresh")
+        check(True, name + ": nonzero constraints, cached blocks (inhomogeneous rows still read B)")
+        check(False, name + ": zero constraints, fresh")
+        check(False, name + ": zero constraints, cached blocks")
+        check(False, name + ": zero constraints, cached again")
+    ctx.close()
