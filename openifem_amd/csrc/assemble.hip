@@ -376,12 +376,12 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   }
   // B, B^T, M_p and diag(M_u) depend on the mesh and on WHICH dofs are constrained, not on the solution or the
   // parameters: an assembly with the constraint set of the previous one keeps them (bit-identical to re-integrating
-  // them) and integrates A_uu and the right-hand side only.  MFMA kernel only; IFEM_GEO_CACHE=0 switches it off.
+  // them) and integrates A_uu and the right-hand side only (not the first-generation kernel IFEM_ASM=v1).  IFEM_GEO_CACHE=0
+  // switches it off.
   static const bool geo_cache_on = [] { const char *e = getenv("IFEM_GEO_CACHE"); return !e || atoi(e) != 0; }();
-  static const bool other_kernel = [] { const char *e = getenv("IFEM_ASM"); return e && (std::string(e) == "v1" || std::string(e) == "v2"); }();
+  static const bool other_kernel = [] { const char *e = getenv("IFEM_ASM"); return e && std::string(e) == "v1"; }();
   const int64_t geo_key = ctx->constraints_epoch * 2 + (use_nonzero ? 1 : 0);
-  const bool mfma_kernel = dim == 3 && ctx->kv == 2 && !other_kernel;
-  const bool skip_geo = geo_cache_on && assemble_system && mfma_kernel && ctx->geo_valid && ctx->geo_key == geo_key;
+  const bool skip_geo = geo_cache_on && assemble_system && !other_kernel && ctx->geo_valid && ctx->geo_key == geo_key;
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
   if (assemble_system) {
     IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));

@@ -464,7 +464,13 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
     }
     wsync2();
   }
-  if (!A.rhs_only && A.debug_skip < 3) { // ---- velocity-pressure blocks: -JxW psi_b grad N_a, own pass over the points
+  bool need_b = !A.rhs_only && A.debug_skip < 3;
+  if (need_b && A.skip_geo) { // cached blocks: only a cell with an inhomogeneous constrained dof still needs the entries
+    bool mine = false;
+    for (int i = lane; i < ND; i += 64) mine = mine || (S.cf[i] && S.cv[i] != 0.0);
+    need_b = A.use_inhom && __any(mine);
+  }
+  if (need_b) { // ---- velocity-pressure blocks: -JxW psi_b grad N_a, own pass over the points
     double bacc[BROUNDS][DIM];
 #pragma unroll
     for (int k = 0; k < BROUNDS; ++k)
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
 #pragma unroll
           for (int c = 0; c < DIM; ++c) {
             if (S.cf[a * DIM + c]) continue;
-            if (!pc) gadd<ATOMIC>(base + int64_t(c) * len, bacc[k][c]);
+            if (!pc) { if (!A.skip_geo) gadd<ATOMIC>(base + int64_t(c) * len, bacc[k][c]); }
             else if (A.use_inhom && S.cv[NU * DIM + pb] != 0.0) unsafeAtomicAdd(&S.fe[a * DIM + c], -bacc[k][c] * S.cv[NU * DIM + pb]);
           }
         }
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
           double *base = A.v_b + S.rs_b[pb] * DIM + A.posPU[(cc * NP + pb) * NU + a];
 #pragma unroll
           for (int c = 0; c < DIM; ++c) {
-            if (!S.cf[a * DIM + c]) gadd<ATOMIC>(base + int64_t(c) * len, bacc[k][c]);
+            if (!S.cf[a * DIM + c]) { if (!A.skip_geo) gadd<ATOMIC>(base + int64_t(c) * len, bacc[k][c]); }
             else if (A.use_inhom && S.cv[a * DIM + c] != 0.0) unsafeAtomicAdd(&S.fe[NU * DIM + pb], -bacc[k][c] * S.cv[a * DIM + c]);
           }
         }
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
     wsync2();
   }
   // ---- pressure mass matrix M_p and diag(M_u)  (:274-276, only the (0,0) diagonal and (1,1) are used)
-  for (int t = lane; t < ((A.rhs_only || A.debug_skip >= 4) ? 0 : NP * NP); t += 64) {
+  for (int t = lane; t < ((A.rhs_only || A.skip_geo || A.debug_skip >= 4) ? 0 : NP * NP); t += 64) {
     const int pa = t / NP, pb = t - pa * NP;
     double m = 0;
 #pragma unroll 3
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
     if (!ra && !cb) gadd<ATOMIC>(dst, m);
     else if (ra && pa == pb) gadd<ATOMIC>(dst, fabs(m));
   }
-  if (lane < NU && !A.rhs_only && A.debug_skip < 4) {
+  if (lane < NU && !A.rhs_only && !A.skip_geo && A.debug_skip < 4) {
     double m = 0;
 #pragma unroll 1
     for (int q = 0; q < NQ; ++q) {

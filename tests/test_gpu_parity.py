@@ -431,16 +431,18 @@ def test_config1_fluid_cavity_first_steps_match_oracle():
     assert np.abs((pg - pg.mean()) - (po - po.mean())).max() < 1e-4 * (po.max() - po.min())
 
 
-def test_cached_geometry_blocks_stay_identical_across_assemblies():
+@pytest.mark.parametrize("dim,kv,reps", [(3, 2, (3, 2, 2)), (2, 2, (4, 3)), (3, 1, (3, 3, 2)), (2, 1, (5, 4))])
+def test_cached_geometry_blocks_stay_identical_across_assemblies(dim, kv, reps):
     # B, B^T, M_p and diag(M_u) do not depend on the solution: the MFMA assembly keeps them while the constraint set is
     # unchanged and re-integrates them when it changes.  Every assembly of the sequence must match the oracle in full.
     capi = _capi()
     rng = np.random.default_rng(99)
-    m = BoxMesh((3, 2, 2), (0, 0, 0), (1.0, 0.6, 0.4), kv=2)
+    m = BoxMesh(reps, (0,) * dim, (1.0, 0.6, 0.4)[:dim], kv=kv)
     m.vcoords = m.vcoords + 0.02 * rng.standard_normal(m.vcoords.shape)
-    kw = dict(mu=0.7, rho=1.3, gamma=0.1, dt=0.05, g=(0.2, -9.8, 0.4), neumann={1: 2.0})
-    bc1 = m.dirichlet({0: (7, [0.3, -0.2, 0.1]), 2: (7, [0.0, 0.0, 0.0])})
-    bc2 = m.dirichlet({0: (7, [0.3, -0.2, 0.1]), 3: (5, [0.4, 0.0])})
+    kw = dict(mu=0.7, rho=1.3, gamma=0.1, dt=0.05, g=(0.2, -9.8, 0.4)[:dim], neumann={1: 2.0})
+    full = 7 if dim == 3 else 3
+    bc1 = m.dirichlet({0: (full, [0.3, -0.2, 0.1][:dim]), 2: (full, [0.0] * dim)})
+    bc2 = m.dirichlet({0: (full, [0.3, -0.2, 0.1][:dim]), 3: (1, [0.4])})
     ctx = _ctx(m)
     S = orc.System(m)
     n_u = m.dim * m.n_unodes
