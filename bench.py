@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--ainv", type=int, default=3, help="IFEM_AINV_* kind of the A_uu^-1 replacement (3 = matrix-free inner operator, 1 = fp32 inner matrix, 0 = fp64 matrix)")
     ap.add_argument("--sm-rel", type=float, default=None, help="experiment: relative tolerance of CG(S_m) inside the preconditioner (reference and default: 1e-3)")
     ap.add_argument("--mp-rel", type=float, default=None, help="experiment: relative tolerance of CG(M_p) inside the preconditioner (reference and default: 1e-6)")
+    ap.add_argument("--inner-restart", type=int, default=0, help="experiment: restart length of the inner GMRES (default: the library's 30)")
     ap.add_argument("--tuned", type=int, default=1, help="also time the relaxed-preconditioner variant (reported as tuned_preconditioner, N = 1 only)")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
     ap.add_argument("--outer-mf", type=int, default=0, help="experiment: apply the u-u block of the OUTER operator matrix-free too")
@@ -166,6 +167,8 @@ def main():
     n_cells, n_u, n_p = solver.sizes()
     n_dofs_global = solver.global_dofs() if world > 1 else n_u + n_p
     solver.opts.inner_rel = args.inner_rel
+    if args.inner_restart:
+        solver.opts.inner_restart = args.inner_restart
     if args.sm_rel is not None:
         solver.opts.sm_rel = args.sm_rel
     if args.mp_rel is not None:
