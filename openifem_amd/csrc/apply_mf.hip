@@ -550,12 +550,26 @@ __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_p
   double s[DIM];
 #pragma unroll
   for (int c = 0; c < DIM; ++c) s[c] = 0;
-  const int64_t k1 = inc_ptr[nd + 1];
-  for (int64_t k = inc_ptr[nd]; k < k1; ++k) {
-    const int32_t e = inc[k];
-    const R *src = ycell + int64_t(e >> 5) * (DIM * nn) + (e & 31) * DIM;
+  const int64_t k0 = inc_ptr[nd], k1 = inc_ptr[nd + 1];
+  // up to 8 incident cells per trip (a vertex node of a hexahedral mesh has 8): all incidence entries are loaded before
+  // the dependent loads of the cell results; slots past the end re-read the first entry with weight 0
+  for (int64_t k = k0; k < k1; k += 8) {
+    int32_t e[8];
 #pragma unroll
-    for (int c = 0; c < DIM; ++c) s[c] += src[c];
+    for (int u = 0; u < 8; ++u) e[u] = inc[k + u < k1 ? k + u : k0];
+    R v[8][DIM];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const R *src = ycell + int64_t(e[u] >> 5) * (DIM * nn) + (e[u] & 31) * DIM;
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) v[u][c] = src[c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k + u < k1) {
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) s[c] += v[u][c];
+      }
   }
 #pragma unroll
   for (int c = 0; c < DIM; ++c) {

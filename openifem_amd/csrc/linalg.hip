@@ -13,42 +13,79 @@ namespace ifem {
 // Row-planar block SpMV.  G lanes cooperate on one row; lane k walks blocks k, k+G, ... of the row and
 // reads the BS = BR*BC planes of its block with stride len (coalesced across lanes), gathers BC values of x
 // and accumulates BR partial sums that are reduced over the G lanes with DPP-free shuffles.
+#ifndef IFEM_SPMV_UNROLL
+#define IFEM_SPMV_UNROLL 4
+#endif
 template <int BR, int BC, int G, bool ACC, class VT = double>
 __device__ inline void row_planar_dot(const int64_t rs, const int len, const int32_t *__restrict__ col,
                                       const VT *__restrict__ val, const double *__restrict__ x, const int lig,
                                       double *acc) {
   const VT *vbase = val + rs * (BR * BC);
-  for (int k = lig; k < len; k += G) {
-    const int32_t c = col[rs + k];
-    double xv[BC];
+  // U entries per lane and trip with all index / value loads issued before the dependent gathers of x: the loop is
+  // latency-bound otherwise (one 12-byte load pair in flight per lane).  Out-of-range slots re-read entry 0 with weight 0.
+  constexpr int U = IFEM_SPMV_UNROLL;
+  for (int k0 = lig; k0 < len; k0 += G * U) {
+    int32_t c[U];
+    VT v[U][BR * BC];
 #pragma unroll
-    for (int j = 0; j < BC; ++j) xv[j] = x[int64_t(c) * BC + j];
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * G;
+      const bool ok = k < len;
+      const int ks = ok ? k : 0;
+      c[u] = col[rs + ks];
 #pragma unroll
-    for (int r = 0; r < BR; ++r)
+      for (int e = 0; e < BR * BC; ++e) { const VT t = vbase[int64_t(e) * len + ks]; v[u][e] = ok ? t : VT(0); }
+    }
+    double xv[U][BC];
 #pragma unroll
-      for (int j = 0; j < BC; ++j) acc[r] += vbase[int64_t(r * BC + j) * len + k] * xv[j];
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < BC; ++j) xv[u][j] = x[int64_t(c[u]) * BC + j];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < BR; ++r)
+#pragma unroll
+        for (int j = 0; j < BC; ++j) acc[r] += v[u][r * BC + j] * xv[u][j];
   }
 }
 
 // A_uu block row in the block-interleaved layout: lane k reads the BR*BC entries of its block back to back (the lanes of
 // a group together cover one contiguous span of the row)
+#ifndef IFEM_SPMV_UU_UNROLL
+#define IFEM_SPMV_UU_UNROLL 1
+#endif
 template <int BR, int BC, int G, class VT>
 __device__ inline void row_interleaved_dot(const int64_t rs, const int len, const int32_t *__restrict__ col,
                                            const VT *__restrict__ val, const double *__restrict__ x, const int lig,
                                            double *acc) {
-  for (int k = lig; k < len; k += G) {
-    const int32_t c = col[rs + k];
-    const VT *b = val + (rs + k) * (BR * BC);
-    VT bv[BR * BC];
+  // U blocks per lane and trip as in row_planar_dot; 72-byte blocks already keep enough bytes in flight: U = 2 measured
+  // no faster (k_spmv_uu 21.0 vs 19.8 ms at 128^3), so U = 1
+  constexpr int U = IFEM_SPMV_UU_UNROLL;
+  for (int k0 = lig; k0 < len; k0 += G * U) {
+    int32_t c[U];
+    VT bv[U][BR * BC];
 #pragma unroll
-    for (int e = 0; e < BR * BC; ++e) bv[e] = b[e];
-    double xv[BC];
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * G;
+      const bool ok = k < len;
+      const int ks = ok ? k : 0;
+      c[u] = col[rs + ks];
+      const VT *b = val + (rs + ks) * (BR * BC);
 #pragma unroll
-    for (int j = 0; j < BC; ++j) xv[j] = x[int64_t(c) * BC + j];
+      for (int e = 0; e < BR * BC; ++e) { const VT t = b[e]; bv[u][e] = ok ? t : VT(0); }
+    }
+    double xv[U][BC];
 #pragma unroll
-    for (int r = 0; r < BR; ++r)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int j = 0; j < BC; ++j) acc[r] += double(bv[r * BC + j]) * xv[j];
+      for (int j = 0; j < BC; ++j) xv[u][j] = x[int64_t(c[u]) * BC + j];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < BR; ++r)
+#pragma unroll
+        for (int j = 0; j < BC; ++j) acc[r] += double(bv[u][r * BC + j]) * xv[u][j];
   }
 }
 
