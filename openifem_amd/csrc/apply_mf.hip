@@ -307,21 +307,44 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
   const int64_t per_block = (n_pairs + gridDim.x - 1) / gridDim.x;
   const int64_t vb = A.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
   const int64_t p_end = (vb + 1) * per_block < n_pairs ? (vb + 1) * per_block : n_pairs;
-  for (int64_t pair = vb * per_block + wave; pair < p_end; pair += WPB) {
+  // The gather of a cell is a chain of two dependent HBM accesses (node id, then the nodal values): it is software-
+  // pipelined over the cells of the wave -- ids two cells ahead, values one cell ahead, both held in registers across the
+  // ~800 instructions of the current cell -- so that the chain is off the critical path.
+  const int64_t p_first = vb * per_block + wave;
+  // 32-bit index arithmetic in the prefetch (cells * nodes-per-cell and dim * nodes are below 2^31 by the int32 node ids)
+  auto cell_of = [&](int64_t pr) { const int64_t c = 2 * pr + half; return (pr < p_end && c < A.n_cells) ? uint32_t(c) : 0u; };
+  struct Pre { int32_t nd; R x[DIM], u[DIM]; } pre;
+  auto load_id = [&](int64_t pr) -> int32_t { return q_lane ? A.cell_unodes[cell_of(pr) * uint32_t(NN) + uint32_t(hl)] : 0; };
+  auto load_vals = [&](int64_t pr, int32_t nd, Pre &o) {
+    o.nd = nd;
+    if (q_lane) {
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) {
+        const uint32_t dof = uint32_t(DIM) * uint32_t(nd) + uint32_t(c);
+        o.x[c] = R(A.x[dof]);
+        if constexpr (CONV) o.u[c] = R(A.eval[dof]);
+      }
+    }
+  };
+  int32_t nd_ahead = load_id(p_first + WPB);
+  load_vals(p_first, load_id(p_first), pre);
+  for (int64_t pair = p_first; pair < p_end; pair += WPB) {
     const int64_t cell = 2 * pair + half;
     const bool active = cell < A.n_cells;
     const int64_t cc = active ? cell : 0;
-    // ---- gather
+    // ---- gather: this cell's values are in registers; start the loads of the next ones
+    const Pre cur = pre;
+    const int32_t nd_next = nd_ahead;
+    nd_ahead = load_id(pair + 2 * WPB);
+    load_vals(pair + WPB, nd_next, pre);
     if (q_lane) {
-      const int32_t nd = A.cell_unodes[cc * NN + hl];
-      S.node[hl] = nd;
+      S.node[hl] = cur.nd;
 #pragma unroll
       for (int c = 0; c < DIM; ++c) {
-        const int64_t dof = int64_t(DIM) * nd + c;
-        const bool con = A.is_c ? A.is_c[dof] != 0 : false;
+        const bool con = A.is_c ? A.is_c[int64_t(DIM) * cur.nd + c] != 0 : false; // one byte per dof: stays in L2
         S.flag[hl * DIM + c] = con;
-        S.V[c * NN + hl] = con ? R(0) : R(A.x[dof]);
-        if constexpr (CONV) S.V[(DIM + c) * NN + hl] = R(A.eval[dof]);
+        S.V[c * NN + hl] = con ? R(0) : cur.x[c];
+        if constexpr (CONV) S.V[(DIM + c) * NN + hl] = cur.u[c];
       }
     }
     if (hl < NV * DIM) S.X[hl] = R(A.vcoords[cc * NV * DIM + hl]);
