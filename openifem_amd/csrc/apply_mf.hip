@@ -666,11 +666,21 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu) {
   constexpr int WPB = 4;
   const dim3 block(64 * WPB);
   const int64_t n_pairs = (ctx->n_cells + 1) / 2;
-  const dim3 g2(unsigned(std::min<int64_t>((n_pairs + WPB - 1) / WPB, 256 * 24)));
   const bool conv = !ctx->mf_noconv;
+  // every block walks one contiguous range of cell pairs: the grid is a whole number of resident rounds (4 per CU slot)
+  // so that no round runs partly empty
+  auto grid_for_kernel = [&](const void *fn) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WPB, 0) != hipSuccess || per_cu < 1) per_cu = 6;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return unsigned(cus) * unsigned(per_cu) * 4u;
+  };
+  const unsigned g_all = unsigned(std::min<int64_t>((n_pairs + WPB - 1) / WPB, int64_t(1) << 30));
 #define IFEM_MF2(D, K)                                                                                                 \
-  { if (conv) hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, true, R>), g2, block, 0, s, a);                              \
-    else hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, false, R>), g2, block, 0, s, a); }
+  { if (conv) { static const unsigned cap = grid_for_kernel(reinterpret_cast<const void *>(&k_apply_uu_mf2<D, K, WPB, true, R>));  \
+                hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, true, R>), dim3(std::min(cap, g_all)), block, 0, s, a); }       \
+    else { static const unsigned cap = grid_for_kernel(reinterpret_cast<const void *>(&k_apply_uu_mf2<D, K, WPB, false, R>));     \
+           hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, false, R>), dim3(std::min(cap, g_all)), block, 0, s, a); } }
   if (ctx->dim == 3 && ctx->kv == 2) IFEM_MF2(3, 2)
   else if (ctx->dim == 3) IFEM_MF2(3, 1)
   else if (ctx->kv == 2) IFEM_MF2(2, 2)
