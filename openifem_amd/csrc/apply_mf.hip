@@ -308,12 +308,13 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
   const int64_t vb = A.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
   const int64_t p_end = (vb + 1) * per_block < n_pairs ? (vb + 1) * per_block : n_pairs;
   // The gather of a cell is a chain of two dependent HBM accesses (node id, then the nodal values): it is software-
-  // pipelined over the cells of the wave -- ids two cells ahead, values one cell ahead, both held in registers across the
-  // ~800 instructions of the current cell -- so that the chain is off the critical path.
+  // pipelined over the cells of the wave -- ids two cells ahead (issued at the top of a cell), values, constraint flags and
+  // vertex coordinates one cell ahead (issued after the quadrature-point stage, where few registers are live) -- and
+  // everything is kept RAW (double / byte) until it is consumed, so that no conversion forces a wait next to a load.
   const int64_t p_first = vb * per_block + wave;
   // 32-bit index arithmetic in the prefetch (cells * nodes-per-cell and dim * nodes are below 2^31 by the int32 node ids)
   auto cell_of = [&](int64_t pr) { const int64_t c = 2 * pr + half; return (pr < p_end && c < A.n_cells) ? uint32_t(c) : 0u; };
-  struct Pre { int32_t nd; R x[DIM], u[DIM]; } pre;
+  struct Pre { int32_t nd; double x[DIM], u[DIM], vc; uint8_t f[DIM]; } pre;
   auto load_id = [&](int64_t pr) -> int32_t { return q_lane ? A.cell_unodes[cell_of(pr) * uint32_t(NN) + uint32_t(hl)] : 0; };
   auto load_vals = [&](int64_t pr, int32_t nd, Pre &o) {
     o.nd = nd;
@@ -321,33 +322,33 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
 #pragma unroll
       for (int c = 0; c < DIM; ++c) {
         const uint32_t dof = uint32_t(DIM) * uint32_t(nd) + uint32_t(c);
-        o.x[c] = R(A.x[dof]);
-        if constexpr (CONV) o.u[c] = R(A.eval[dof]);
+        o.x[c] = A.x[dof];
+        if constexpr (CONV) o.u[c] = A.eval[dof];
+        o.f[c] = A.is_c ? A.is_c[dof] : uint8_t(0); // one byte per dof: stays in L2
       }
     }
+    if (hl < NV * DIM) o.vc = A.vcoords[int64_t(cell_of(pr)) * (NV * DIM) + hl];
   };
   int32_t nd_ahead = load_id(p_first + WPB);
   load_vals(p_first, load_id(p_first), pre);
   for (int64_t pair = p_first; pair < p_end; pair += WPB) {
     const int64_t cell = 2 * pair + half;
     const bool active = cell < A.n_cells;
-    const int64_t cc = active ? cell : 0;
-    // ---- gather: this cell's values are in registers; start the loads of the next ones
+    // ---- gather: this cell's values are in registers; start the id load of the cell after the next
     const Pre cur = pre;
     const int32_t nd_next = nd_ahead;
     nd_ahead = load_id(pair + 2 * WPB);
-    load_vals(pair + WPB, nd_next, pre);
     if (q_lane) {
       S.node[hl] = cur.nd;
 #pragma unroll
       for (int c = 0; c < DIM; ++c) {
-        const bool con = A.is_c ? A.is_c[int64_t(DIM) * cur.nd + c] != 0 : false; // one byte per dof: stays in L2
+        const bool con = cur.f[c] != 0;
         S.flag[hl * DIM + c] = con;
-        S.V[c * NN + hl] = con ? R(0) : cur.x[c];
-        if constexpr (CONV) S.V[(DIM + c) * NN + hl] = cur.u[c];
+        S.V[c * NN + hl] = con ? R(0) : R(cur.x[c]);
+        if constexpr (CONV) S.V[(DIM + c) * NN + hl] = R(cur.u[c]);
       }
     }
-    if (hl < NV * DIM) S.X[hl] = R(A.vcoords[cc * NV * DIM + hl]);
+    if (hl < NV * DIM) S.X[hl] = R(cur.vc);
     wsync();
     // monomial coefficients of x(xi) = sum_k C_k prod_{d in k} xi_d:  C_k = sum_{v subset of k} (-1)^{|k|-|v|} X_v
     if (hl < NV * DIM) {
@@ -490,6 +491,8 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
         }
       }
     }
+    // ---- the next cell's values: their latency hides behind the transposed passes below
+    load_vals(pair + WPB, nd_next, pre);
     // ---- V_c += D_d^T T^_{c,d}, one direction at a time
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
@@ -533,11 +536,14 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
     }
     // ---- scatter into owned, unconstrained rows: consecutive lanes hit consecutive doubles of a node
     if (A.ycell) { // two-stage scatter: coalesced plain stores per cell, summed per node by k_mf_gather
-      if (active)
-        for (int t = hl; t < DIM * NN; t += 32) {
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < (DIM * NN + 31) / 32; ++k) { // unrolled: a loop here makes the compiler drain the prefetch first
+          const int t = hl + 32 * k;
           const int a = t / DIM, c = t - a * DIM;
-          A.ycell[cell * (DIM * NN) + t] = S.V[c * NN + a];
+          if (t < DIM * NN) A.ycell[cell * (DIM * NN) + t] = S.V[c * NN + a];
         }
+      }
     } else if (active) {
       for (int t = hl; t < DIM * NN; t += 32) {
         const int a = t / DIM, c = t - a * DIM;
