@@ -255,6 +255,13 @@ def main():
                          "algorithmic_bytes": nb, "algorithmic_flops": nf, "hbm_frac": gbs / HBM_PEAK_GBS, "compute_frac": tfs / peak_tf,
                          "compute_peak": "FP64 MFMA" if dom == "asm" else "FP32 vector FMA",
                          "kernel_ms_per_step": totals})
+            if dom == "asm":
+                # what actually bounds this kernel: the rate of the f64 atomic unit.  One atomic per (cell, dof pair) of the
+                # velocity-velocity block; peak = the contiguous-footprint rate measured by tools/microbench.hip
+                # (profiles/r01_microbench.txt: 188 Gatom/s; 72-byte strided footprints reach 24 Gatom/s)
+                n_atom = float(n_cells) * (27 * 3) ** 2
+                roof.update({"atomic_adds": n_atom, "atomic_rate_gatom_s": n_atom / (ms * 1e-3) / 1e9, "atomic_peak_gatom_s": 188.0,
+                             "atomic_frac": n_atom / (ms * 1e-3) / 1e9 / 188.0})
         out = {
             "metric": "DoF/s per Newton step (assemble+solve), 3D INS Q2/Q1",
             "value": n_dofs_global / (elapsed / args.steps),

@@ -580,6 +580,9 @@ __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_p
 #pragma unroll
   for (int c = 0; c < DIM; ++c) s[c] = 0;
   const int64_t k0 = inc_ptr[nd], k1 = inc_ptr[nd + 1];
+  uint8_t fl[DIM]; // constraint flags: requested now, looked at after the sums
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) fl[c] = is_c ? is_c[nd * DIM + c] : uint8_t(0);
   // up to 8 incident cells per trip (a vertex node of a hexahedral mesh has 8): all incidence entries are loaded before
   // the dependent loads of the cell results; slots past the end re-read the first entry with weight 0
   for (int64_t k = k0; k < k1; k += 8) {
@@ -603,7 +606,7 @@ __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_p
 #pragma unroll
   for (int c = 0; c < DIM; ++c) {
     const int64_t i = nd * DIM + c;
-    y[i] = (is_c && is_c[i]) ? x[i] / bjac[nd * DIM * DIM + c * DIM + c] : s[c];
+    y[i] = fl[c] ? x[i] / bjac[nd * DIM * DIM + c * DIM + c] : s[c];
   }
 }
 

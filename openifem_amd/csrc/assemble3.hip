@@ -34,6 +34,7 @@ struct Cell3 {
   int64_t rs_uu[NU], rs_bt[NU], rs_b[NP], rs_mp[NP];
   int32_t len_uu[NU], len_bt[NU], len_b[NP], len_mp[NP];
   int32_t un[NU], pn[NP];
+  int32_t bid[6], ind; // boundary ids of the faces (only read with Neumann conditions), FSI indicator of the cell
   uint8_t cf[ND + 7];
 };
 
@@ -74,40 +75,64 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
   const int64_t p_off = int64_t(DIM) * A.nUl;
   double *ue = S.scratch, *u0e = S.scratch + NU * DIM, *ae = S.scratch + 2 * NU * DIM, *pe = S.scratch + 3 * NU * DIM;
 
-  // ---- phase 0: ids, coordinates, nodal values, row descriptors, constraint flags
-  if (h == 1) for (int i = lane; i < NP * DIM; i += 64) S.X[i] = A.vcoords[cc * NP * DIM + i];
-  if (h == 0 && lane < NU) {
-    const int a = lane;
+  // ---- phase 0: ids, coordinates, nodal values, row descriptors, constraint flags.  One workgroup fills a CU's LDS, so
+  // nothing hides a global round trip: every wave issues ALL its loads (two dependent rounds: ids, then everything keyed
+  // by the id) before the first LDS store that needs one.  Optional arrays fall back to a valid address + select.
+  if (h == 0) {
+    const int a = lane < NU ? lane : 0;
     const int32_t nd = A.cell_unodes[cc * NU + a];
-    S.un[a] = nd;
+    int32_t bid = -1;
+    if (A.n_neumann != 0 && lane < 2 * DIM) bid = A.cell_face_bid[cc * 2 * DIM + lane];
     const bool own = nd < A.nUo;
-    const int64_t r0 = own ? A.rp_uu[nd] : 0, r1 = own ? A.rp_uu[nd + 1] : 0;
-    S.rs_uu[a] = r0; S.len_uu[a] = own ? int32_t(r1 - r0) : -1;
-    const int64_t t0 = own ? A.rp_bt[nd] : 0, t1_ = own ? A.rp_bt[nd + 1] : 0;
-    S.rs_bt[a] = t0; S.len_bt[a] = own ? int32_t(t1_ - t0) : -1;
+    const int64_t ndr = own ? nd : 0;
+    const int64_t r0 = A.rp_uu[ndr], r1 = A.rp_uu[ndr + 1], t0 = A.rp_bt[ndr], t1_ = A.rp_bt[ndr + 1];
+    const int64_t dof = int64_t(DIM) * nd;
+    const double *fa = A.fsi_acc ? A.fsi_acc : A.eval, *cvp = A.cval ? A.cval : A.eval;
+    const uint8_t *icp = A.is_c ? A.is_c : reinterpret_cast<const uint8_t *>(A.eval);
+    double ev[DIM], pv[DIM], av[DIM], cvv[DIM];
+    uint8_t cfv[DIM];
+#pragma unroll
     for (int c = 0; c < DIM; ++c) {
-      const int64_t dof = int64_t(DIM) * nd + c;
-      ue[a * DIM + c] = A.eval[dof];
-      u0e[a * DIM + c] = A.present[dof];
-      ae[a * DIM + c] = A.fsi_acc ? A.fsi_acc[dof] : 0.0;
-      S.cf[a * DIM + c] = A.is_c ? A.is_c[dof] : 0;
-      S.cv[a * DIM + c] = A.cval ? A.cval[dof] : 0.0;
+      ev[c] = A.eval[dof + c]; pv[c] = A.present[dof + c]; av[c] = fa[dof + c]; cvv[c] = cvp[dof + c]; cfv[c] = icp[dof + c];
+    }
+    if (lane < NU) {
+      S.un[a] = nd;
+      S.rs_uu[a] = own ? r0 : 0; S.len_uu[a] = own ? int32_t(r1 - r0) : -1;
+      S.rs_bt[a] = own ? t0 : 0; S.len_bt[a] = own ? int32_t(t1_ - t0) : -1;
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) {
+        ue[a * DIM + c] = ev[c];
+        u0e[a * DIM + c] = pv[c];
+        ae[a * DIM + c] = A.fsi_acc ? av[c] : 0.0;
+        S.cf[a * DIM + c] = A.is_c ? cfv[c] : uint8_t(0);
+        S.cv[a * DIM + c] = A.cval ? cvv[c] : 0.0;
+      }
+    }
+    if (lane < 2 * DIM) S.bid[lane] = bid;
+    for (int i = lane; i < ND; i += 64) S.fe[i] = 0.0;
+  } else {
+    const int b = lane < NP ? lane : 0;
+    const int32_t nd = A.cell_pnodes[cc * NP + b];
+    const double xv = A.vcoords[cc * NP * DIM + (lane < NP * DIM ? lane : 0)];
+    const int32_t indv = (A.indicator && lane == 0) ? A.indicator[cc] : 0;
+    const bool own = nd < A.nPo;
+    const int64_t ndr = own ? nd : 0;
+    const int64_t r0 = A.rp_b[ndr], r1 = A.rp_b[ndr + 1], m0 = A.rp_mp[ndr], m1 = A.rp_mp[ndr + 1];
+    const double *cvp = A.cval ? A.cval : A.eval;
+    const uint8_t *icp = A.is_c ? A.is_c : reinterpret_cast<const uint8_t *>(A.eval);
+    const double pev = A.eval[p_off + nd], cvv = cvp[p_off + nd];
+    const uint8_t cfv = icp[p_off + nd];
+    if (lane < NP * DIM) S.X[lane] = xv;
+    if (lane == 0) S.ind = indv;
+    if (lane < NP) {
+      S.pn[b] = nd;
+      S.rs_b[b] = own ? r0 : 0; S.len_b[b] = own ? int32_t(r1 - r0) : -1;
+      S.rs_mp[b] = own ? m0 : 0; S.len_mp[b] = own ? int32_t(m1 - m0) : -1;
+      pe[b] = pev;
+      S.cf[NU * DIM + b] = A.is_c ? cfv : uint8_t(0);
+      S.cv[NU * DIM + b] = A.cval ? cvv : 0.0;
     }
   }
-  if (h == 1 && lane < NP) {
-    const int b = lane;
-    const int32_t nd = A.cell_pnodes[cc * NP + b];
-    S.pn[b] = nd;
-    const bool own = nd < A.nPo;
-    const int64_t r0 = own ? A.rp_b[nd] : 0, r1 = own ? A.rp_b[nd + 1] : 0;
-    S.rs_b[b] = r0; S.len_b[b] = own ? int32_t(r1 - r0) : -1;
-    const int64_t m0 = own ? A.rp_mp[nd] : 0, m1 = own ? A.rp_mp[nd + 1] : 0;
-    S.rs_mp[b] = m0; S.len_mp[b] = own ? int32_t(m1 - m0) : -1;
-    pe[b] = A.eval[p_off + nd];
-    S.cf[NU * DIM + b] = A.is_c ? A.is_c[p_off + nd] : 0;
-    S.cv[NU * DIM + b] = A.cval ? A.cval[p_off + nd] : 0.0;
-  }
-  if (h == 0) for (int i = lane; i < ND; i += 64) S.fe[i] = 0.0;
   __syncthreads();
   if (h == 0 && lane < NP * DIM) { // monomial coefficients of the trilinear map
     const int k = lane / DIM, e = lane % DIM;
@@ -122,7 +147,7 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
     S.C[k * DIM + e] = acc;
   }
   __syncthreads();
-  const int ind = (active && A.indicator) ? A.indicator[cc] : 0;
+  const int ind = active ? S.ind : 0;
 
   // ---- phase 1: per quadrature point (lane = q): Jacobian, fields of the evaluation point, rhs coefficients
   // the nodal sums are split over the two waves of the cell: the second wave handles nodes 14..26 and parks its partial
@@ -242,7 +267,7 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
   // ---- Neumann (pressure) boundary faces  (:313-341)
   if (A.n_neumann != 0 && active && h == 0) {
     for (int f = 0; f < 2 * DIM; ++f) {
-      const int bid = A.cell_face_bid[cc * 2 * DIM + f];
+      const int bid = S.bid[f];
       if (bid < 0) continue;
       double pbc = 0; bool hit = false;
       for (int k = 0; k < A.n_neumann; ++k) if (A.neumann_id[k] == bid) { pbc = A.neumann_p[k]; hit = true; }
@@ -373,6 +398,13 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
       d4 acc[BS], sac = {0, 0, 0, 0};
 #pragma unroll
       for (int e = 0; e < BS; ++e) acc[e] = d4{0, 0, 0, 0};
+      // scatter positions of my four pairs: loaded now, needed after the contraction
+      uint16_t posr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = 16 * ti + (lane >> 4) + 4 * r;
+        posr[r] = A.posUU[(cc * NU + (a < NU ? a : 0)) * NU + bc_]; // unconditional (clamped): no branch, no wait here
+      }
       if (A.debug_skip != 2) {
 #pragma unroll
         for (int ks = 0; ks < 7; ++ks) {
@@ -413,7 +445,7 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
         const bool have = active && a < NU && b < NU && S.len_uu[a < NU ? a : 0] >= 0 && !A.debug_skip;
         int64_t off = -1;
         if (have) {
-          const uint16_t pos = A.posUU[(cc * NU + a) * NU + b];
+          const uint16_t pos = posr[r];
           off = uu_base(S.rs_uu[a], S.len_uu[a], pos, BS);
           const double s = sac[r];
           const int64_t row_dof0 = int64_t(DIM) * S.un[a];

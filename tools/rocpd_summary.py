@@ -22,7 +22,7 @@ def main(db_path, prefix):
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
+        w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent"])
         for name, calls, tot, avg, pct in rows:
             w.writerow([short(name), calls, f"{tot / 1e3:.3f}", f"{avg / 1e3:.3f}", f"{pct:.2f}"])
     try:
