@@ -135,6 +135,9 @@ void ifem_ctx_destroy(ifem_ctx *ctx) {
   comm_destroy(ctx);
   ifem::tpp_release(ctx);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
+  if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+  if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
+  if (ctx->ev_spare) (void)hipEventDestroy(ctx->ev_spare);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   hipStream_t s = ctx->stream;

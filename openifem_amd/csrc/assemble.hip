@@ -352,6 +352,29 @@ bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A);
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) { launch_ins_assemble_ex(ctx, p, use_nonzero, 0, 1); }
 
 // imex = 1: InsIMEX::assemble (mpi_insimex.cpp:150-355): every field comes from the present solution, the matrix has no
+// Zeroing the 78 GB of A_uu values (128^3 Q2) in front of the scatter costs 12 ms of an otherwise idle stream.  With a
+// second value buffer the fill runs on a side stream and the next assembly swaps the buffers.  Measured at 128^3: the
+// fill then runs underneath the assembly kernel, which slows from 112.6 to 124 ms (it competes for the same write path),
+// so the step only goes from 514 to 509 ms -- not worth 78 GB by default.  Opt-in: IFEM_AUU_SPARE=1 (when the matrix is
+// large enough to matter and free memory >= 2 x the buffer), =2 always (tests).
+static bool spare_buffer_ready(ifem_ctx *ctx) {
+  if (ctx->spare_state) return ctx->spare_state > 0;
+  const char *e = getenv("IFEM_AUU_SPARE");
+  const int mode = e ? atoi(e) : 0;
+  const size_t bytes = ctx->Auu.val.n * sizeof(double);
+  size_t free_b = 0, total_b = 0;
+  bool ok = mode != 0 && bytes > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+  if (ok && mode != 2) ok = bytes >= (size_t(256) << 20) && free_b >= 2 * bytes;
+  if (ok) ok = hipMalloc((void **)&ctx->Auu_spare.p, bytes) == hipSuccess;
+  if (!ok) { (void)hipGetLastError(); ctx->spare_state = -1; return false; }
+  ctx->Auu_spare.n = ctx->Auu.val.n;
+  IFEM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+  IFEM_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+  IFEM_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_spare, hipEventDisableTiming));
+  ctx->spare_state = 1;
+  return true;
+}
+
 // convective terms; assemble_system = 0 integrates the right-hand side only and leaves the matrices untouched
 void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero, int imex, int assemble_system) {
   hipStream_t s = ctx->stream;
@@ -384,6 +407,19 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   const bool skip_geo = geo_cache_on && assemble_system && !other_kernel && ctx->geo_valid && ctx->geo_key == geo_key;
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
   if (assemble_system) {
+    if (spare_buffer_ready(ctx)) { // the other buffer was zeroed while the previous matrix was in use
+      IFEM_HIP_CHECK(hipEventRecord(ctx->ev_main, s)); // everything that reads the present matrix is in front of this
+      if (ctx->spare_zeroing) {
+        IFEM_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_spare, 0));
+        std::swap(ctx->Auu.val.p, ctx->Auu_spare.p);
+      } else
+        IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
+      IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_main, 0));
+      IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu_spare.p, 0, ctx->Auu_spare.n * sizeof(double), ctx->side_stream));
+      IFEM_HIP_CHECK(hipEventRecord(ctx->ev_spare, ctx->side_stream));
+      ctx->spare_zeroing = true;
+      ctx->auu_f32_valid = false;
+    } else
     IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
     if (!skip_geo) {
       IFEM_HIP_CHECK(hipMemsetAsync(ctx->Bt.val.p, 0, ctx->Bt.val.n * sizeof(double), s));

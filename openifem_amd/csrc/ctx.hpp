@@ -210,6 +210,13 @@ struct ifem_ctx {
   ifem::DBuf<double> bjac;     // inverse diagonal node blocks of A_uu [nUo][dim*dim]
   ifem::DBuf<float> bjac_f32;  // single-precision copy for the inner solver (built on first use after bjac_setup)
   bool bjac_f32_valid = false;
+  // second value buffer of A_uu: zeroed on a side stream while the previous matrix is still in use, swapped in by the
+  // next assembly instead of a memset in front of the scatter (assemble.hip; IFEM_AUU_SPARE)
+  ifem::DBuf<double> Auu_spare;
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_main = nullptr, ev_spare = nullptr;
+  int spare_state = 0; // 0 undecided, -1 unavailable, 1 allocated; spare_zeroing: a zero-fill of the spare is enqueued
+  bool spare_zeroing = false;
   // scatter maps: position of the column inside the row, 0xFFFF = row not owned here
   ifem::DBuf<uint16_t> posUU, posUP, posPU, posPP;
   // constraints (local dof numbering), sets 0 = zero, 1 = nonzero
