@@ -352,11 +352,12 @@ bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A);
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) { launch_ins_assemble_ex(ctx, p, use_nonzero, 0, 1); }
 
 // imex = 1: InsIMEX::assemble (mpi_insimex.cpp:150-355): every field comes from the present solution, the matrix has no
-// Zeroing the 78 GB of A_uu values (128^3 Q2) in front of the scatter costs 12 ms of an otherwise idle stream.  With a
-// second value buffer the fill runs on a side stream and the next assembly swaps the buffers.  Measured at 128^3: the
-// fill then runs underneath the assembly kernel, which slows from 112.6 to 124 ms (it competes for the same write path),
-// so the step only goes from 514 to 509 ms -- not worth 78 GB by default.  Opt-in: IFEM_AUU_SPARE=1 (when the matrix is
-// large enough to matter and free memory >= 2 x the buffer), =2 always (tests).
+// Zeroing the 78 GB of A_uu values (128^3 Q2) in front of the scatter costs 12 ms.  With a second value buffer the fill
+// runs on a side stream and the next assembly swaps the buffers.  Measured at 128^3: underneath the cell kernel the fill
+// competes for the write path of the atomics (112.6 -> 124 ms); started behind the cell kernel it slows the block-Jacobi
+// set-up and the first pressure solves by about what it saves (step 513 -> 509..515 ms) -- 12 ms of HBM writes cost 12 ms
+// wherever they run in this pipeline.  Not worth 78 GB: opt-in only, IFEM_AUU_SPARE=1 (when the matrix is large enough to
+// matter and free memory >= 2 x the buffer), =2 always (tests).
 static bool spare_buffer_ready(ifem_ctx *ctx) {
   if (ctx->spare_state) return ctx->spare_state > 0;
   const char *e = getenv("IFEM_AUU_SPARE");
@@ -406,19 +407,15 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   const int64_t geo_key = ctx->constraints_epoch * 2 + (use_nonzero ? 1 : 0);
   const bool skip_geo = geo_cache_on && assemble_system && !other_kernel && ctx->geo_valid && ctx->geo_key == geo_key;
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
+  bool refill_spare = false;
   if (assemble_system) {
     if (spare_buffer_ready(ctx)) { // the other buffer was zeroed while the previous matrix was in use
-      IFEM_HIP_CHECK(hipEventRecord(ctx->ev_main, s)); // everything that reads the present matrix is in front of this
       if (ctx->spare_zeroing) {
         IFEM_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_spare, 0));
         std::swap(ctx->Auu.val.p, ctx->Auu_spare.p);
       } else
         IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
-      IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_main, 0));
-      IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu_spare.p, 0, ctx->Auu_spare.n * sizeof(double), ctx->side_stream));
-      IFEM_HIP_CHECK(hipEventRecord(ctx->ev_spare, ctx->side_stream));
-      ctx->spare_zeroing = true;
-      ctx->auu_f32_valid = false;
+      refill_spare = true; // enqueued behind the cell kernel below
     } else
     IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
     if (!skip_geo) {
@@ -468,6 +465,15 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   else if (dim == 3 && ctx->kv == 2) launch_t<3, 2>(ctx, A);
   else throw Error(IFEM_E_BADPARAM, "unsupported (dim, kv)");
   IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+  if (refill_spare) {
+    // the previous matrix (now the spare buffer) lost its last reader before this assembly; its fill starts when the cell
+    // kernel is done
+    IFEM_HIP_CHECK(hipEventRecord(ctx->ev_main, s));
+    IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_main, 0));
+    IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu_spare.p, 0, ctx->Auu_spare.n * sizeof(double), ctx->side_stream));
+    IFEM_HIP_CHECK(hipEventRecord(ctx->ev_spare, ctx->side_stream));
+    ctx->spare_zeroing = true;
+  }
   if (assemble_system) { ctx->geo_valid = true; ctx->geo_key = geo_key; }
   if (assemble_system) assemble_epilogue(ctx, use_nonzero);
   else {
