@@ -19,6 +19,7 @@ steps = 3
 def configure(s):
     s.opts.ainv_kind = 3
     s.opts.inner_rel = 1e-2
+    s.opts.inner_restart = 16  # as bench.py
     s.channel_state()
 
 
