@@ -20,11 +20,23 @@ def main(db_path, prefix):
     db = sqlite3.connect(db_path)
     cur = db.cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    # per-dispatch durations for the median / minimum (a kernel whose first launch does extra work -- the assembly
+    # integrates the cached blocks once -- has a mean that no single launch shows)
+    per = {}
+    try:
+        for name, dur in cur.execute('select name, ("end" - start) from kernels'):
+            per.setdefault(name, []).append(dur)
+    except sqlite3.Error as e:
+        print("no per-dispatch view:", e)
+        print("objects:", [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")][:60])
     with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent"])
+        w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent", "median_ms", "min_ms"])
         for name, calls, tot, avg, pct in rows:
-            w.writerow([short(name), calls, f"{tot / 1e3:.3f}", f"{avg / 1e3:.3f}", f"{pct:.2f}"])
+            d = sorted(per.get(name, []))
+            med = f"{d[len(d) // 2] / 1e6:.3f}" if d else ""
+            mn = f"{d[0] / 1e6:.3f}" if d else ""
+            w.writerow([short(name), calls, f"{tot / 1e3:.3f}", f"{avg / 1e3:.3f}", f"{pct:.2f}", med, mn])
     try:
         q = ("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
              "group by kernel_name, counter_name")
