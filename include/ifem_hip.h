@@ -123,6 +123,23 @@ typedef struct {
                                  fifth of the time) -- an experiment switch, off by default */
 } ifem_solver_opts;
 
+/* Tuning / measurement knobs of one context (defaults = the measured best; nothing here changes results beyond fp64
+ * rounding).  Replaces the environment switches of the first round: the library reads no environment variable. */
+typedef struct {
+  int32_t geo_cache;     /* 1: B, B^T, M_p, diag(M_u) are kept across assemblies with an unchanged constraint set; 0:
+                            re-integrated by every assembly as the reference does (mpi_insim.cpp:163-165) */
+  int32_t xcd_swizzle;   /* 1: cell kernels hand every XCD one contiguous range of the (Morton-ordered) cells */
+  int32_t asm_skip;      /* 0; measurement only: drop parts of the 3D Q2/Q1 assembly kernel (results invalid) */
+  int32_t spmv_lanes;    /* 32: lanes per block row of the A_uu SpMV (8/16/32/64) */
+  int32_t sm_lanes;      /* 32: lanes per row of the S_m SpMV */
+  int32_t mf_f32;        /* 1: single-precision cell arithmetic in the matrix-free A_uu of the INNER solve */
+  int32_t tpp_operator;  /* 0; 1: SCnsIM preconditioner applies T_pp as an operator instead of the explicit matrix */
+  int64_t tpp_dense_max; /* 12288: largest pressure space whose T_pp may be factorised densely (0 = never) */
+  int64_t basis_pad;     /* 32*33 doubles of padding between Krylov basis columns (HBM channel spread) */
+} ifem_tuning;
+void ifem_default_tuning(ifem_tuning *t);
+int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t);
+
 /* counters of the last ifem_solve (the timer2 sections of mpi_insim.cpp:70,87,125) */
 typedef struct {
   uint32_t fgmres_iters; double fgmres_res;
@@ -143,6 +160,10 @@ enum {
 };
 
 const char *ifem_last_error(void);
+/* sizeof of the structs above as this library was compiled, for a binding to check its mirror against:
+ * 0 ifem_mesh_desc, 1 ifem_partition, 2 ifem_ins_params, 3 ifem_solver_opts, 4 ifem_solve_stats, 5 ifem_scns_params,
+ * 6 ifem_timing, 7 ifem_tuning; -1 for anything else */
+int64_t ifem_abi_sizeof(int which);
 int ifem_device_count(void);
 void ifem_default_solver_opts(ifem_solver_opts *o);
 /* RCCL bootstrap: rank 0 calls this and ships the 128 bytes to the other ranks by any channel */

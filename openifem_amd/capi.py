@@ -23,10 +23,28 @@ class MeshDesc(C.Structure):
 
 
 class Partition(C.Structure):
+    """ifem_partition, member for member (tests/test_host_layer.py checks the size against ifem_abi_sizeof)"""
     _fields_ = [("rank", C.c_int32), ("nranks", C.c_int32), ("n_neighbors", C.c_int32),
                 ("neighbor_rank", C.c_void_p), ("send_u_ptr", C.c_void_p), ("send_u_idx", C.c_void_p),
                 ("recv_u_ptr", C.c_void_p), ("send_p_ptr", C.c_void_p), ("send_p_idx", C.c_void_p),
-                ("recv_p_ptr", C.c_void_p), ("nccl_unique_id", C.c_void_p), ("local_world", C.c_void_p)]
+                ("recv_p_ptr", C.c_void_p), ("nccl_unique_id", C.c_void_p), ("local_world", C.c_void_p),
+                ("p_lattice_n", C.c_int64 * 3), ("sm_box_lo", C.c_int64 * 3), ("sm_box_n", C.c_int64 * 3),
+                ("sm_box_id", C.c_void_p), ("l2g_p", C.c_void_p),
+                ("send_s_ptr", C.c_void_p), ("send_s_idx", C.c_void_p), ("recv_s_ptr", C.c_void_p)]
+
+
+def make_partition(rank, nranks, neighbors, send_u_ptr, send_u_idx, recv_u_ptr, send_p_ptr, send_p_idx, recv_p_ptr,
+                   nccl_unique_id=None, local_world=None):
+    """ifem_partition from numpy tables (general meshes: no 2-deep pressure halo).  Returns (struct, keep-alive list)."""
+    keep = [np.ascontiguousarray(a, np.int32) for a in (neighbors, send_u_ptr, send_u_idx, recv_u_ptr, send_p_ptr,
+                                                        send_p_idx, recv_p_ptr)]
+    uid = None if nccl_unique_id is None else np.ascontiguousarray(nccl_unique_id, np.uint8)
+    P = Partition()
+    P.rank, P.nranks, P.n_neighbors = rank, nranks, len(keep[0])
+    (P.neighbor_rank, P.send_u_ptr, P.send_u_idx, P.recv_u_ptr, P.send_p_ptr, P.send_p_idx, P.recv_p_ptr) = [_ptr(a) for a in keep]
+    P.nccl_unique_id = _ptr(uid)
+    P.local_world = local_world
+    return P, keep + [uid]
 
 
 class InsParams(C.Structure):
@@ -59,6 +77,12 @@ class SolveStats(C.Structure):
                 ("t_ainv_ms", C.c_double), ("t_spmv_ms", C.c_double), ("t_total_ms", C.c_double)]
 
 
+class Tuning(C.Structure):
+    _fields_ = [("geo_cache", C.c_int32), ("xcd_swizzle", C.c_int32), ("asm_skip", C.c_int32), ("spmv_lanes", C.c_int32),
+                ("sm_lanes", C.c_int32), ("mf_f32", C.c_int32), ("tpp_operator", C.c_int32),
+                ("tpp_dense_max", C.c_int64), ("basis_pad", C.c_int64)]
+
+
 class Timing(C.Structure):
     _fields_ = [("assemble_ms", C.c_double), ("assemble_kernel_ms", C.c_double), ("spmv_uu_ms_avg", C.c_double),
                 ("spmv_uu_calls", C.c_uint64), ("spmv_uu_bytes", C.c_double), ("mf_ms_avg", C.c_double),
@@ -73,7 +97,10 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_rhs_norm", "ifem_ins_newton_step", "ifem_system_vmult", "ifem_uu_vmult", "ifem_precond_vmult", "ifem_export_csr",
            "ifem_get_timing", "ifem_set_profiling", "ifem_synchronize", "ifem_set_hanging_constraints", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
            "ifem_scns_assemble", "ifem_scns_solve", "ifem_scns_newton_step", "ifem_imex_assemble", "ifem_imex_solve",
-           "ifem_imex_step", "ifem_set_eddy_viscosity"]
+           "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof"]
+
+# ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
+ABI_STRUCTS = None  # filled below (needs every class defined)
 
 _lib = None
 
@@ -138,12 +165,19 @@ def load():
     L.ifem_scns_solve.argtypes = [C.c_void_p, C.POINTER(SolverOpts), C.c_int, C.POINTER(SolveStats)]
     L.ifem_scns_newton_step.argtypes = [C.c_void_p, C.POINTER(ScnsParams), C.POINTER(SolverOpts), C.c_int, C.c_double,
                                         C.c_int, C.c_void_p]
+    L.ifem_default_tuning.argtypes = [C.POINTER(Tuning)]
+    L.ifem_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
+    L.ifem_abi_sizeof.argtypes = [C.c_int]
+    L.ifem_abi_sizeof.restype = C.c_int64
     _lib = L
     return L
 
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+ABI_STRUCTS = [MeshDesc, Partition, InsParams, SolverOpts, SolveStats, ScnsParams, Timing, Tuning]
 
 
 def make_params(mu=1.0, rho=1.0, gamma=0.1, dt=1e-3, g=(0, 0, 0), neumann=None):
@@ -186,7 +220,7 @@ class Context:
                      n_pnodes if n_pnodes_owned is None else n_pnodes_owned, n_pnodes, *[_ptr(a) for a in self._keep])
         self.dim, self.kv = dim, kv
         self.h = C.c_void_p()
-        self._chk(self.L.ifem_ctx_create(C.byref(m), partition, device, C.byref(self.h)))
+        self._chk(self.L.ifem_ctx_create(C.byref(m), None if partition is None else C.byref(partition), device, C.byref(self.h)))
         self.n_local = self.L.ifem_n_local_dofs(self.h)
         self.n_u = dim * m.n_unodes_local
         self.n_owned = dim * m.n_unodes_owned + m.n_pnodes_owned
@@ -208,6 +242,19 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_tuning(self, **kw):
+        """ifem_set_tuning: e.g. set_tuning(geo_cache=0)"""
+        t = Tuning()
+        self.L.ifem_default_tuning(C.byref(t))
+        if getattr(self, "_tuning", None) is not None:
+            t = self._tuning
+        for k, v in kw.items():
+            if not hasattr(t, k):
+                raise AttributeError(k)
+            setattr(t, k, v)
+        self._chk(self.L.ifem_set_tuning(self.h, C.byref(t)))
+        self._tuning = t
 
     def set_constraints(self, which, dofs, vals=None):
         dofs = np.ascontiguousarray(dofs, np.int32)

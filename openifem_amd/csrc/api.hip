@@ -24,6 +24,20 @@ extern "C" {
 
 const char *ifem_last_error(void) { return g_err.c_str(); }
 
+int64_t ifem_abi_sizeof(int which) {
+  switch (which) {
+  case 0: return sizeof(ifem_mesh_desc);
+  case 1: return sizeof(ifem_partition);
+  case 2: return sizeof(ifem_ins_params);
+  case 3: return sizeof(ifem_solver_opts);
+  case 4: return sizeof(ifem_solve_stats);
+  case 5: return sizeof(ifem_scns_params);
+  case 6: return sizeof(ifem_timing);
+  case 7: return sizeof(ifem_tuning);
+  default: return -1;
+  }
+}
+
 int ifem_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -40,6 +54,22 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
   o->verbose = 0;
 }
 
+void ifem_default_tuning(ifem_tuning *t) {
+  t->geo_cache = 1; t->xcd_swizzle = 1; t->asm_skip = 0; t->spmv_lanes = 32; t->sm_lanes = 32; t->mf_f32 = 1;
+  t->tpp_operator = 0; t->tpp_dense_max = 12288; t->basis_pad = 32 * 33;
+}
+
+int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
+  IFEM_API_BEGIN
+  if (!t) throw Error(IFEM_E_BADPARAM, "null tuning");
+  const int g[2] = {t->spmv_lanes, t->sm_lanes};
+  for (int v : g)
+    if (v != 8 && v != 16 && v != 32 && v != 64) throw Error(IFEM_E_BADPARAM, "lanes per row must be 8, 16, 32 or 64");
+  if (t->basis_pad < 0 || t->tpp_dense_max < 0) throw Error(IFEM_E_BADPARAM, "negative size in ifem_tuning");
+  ctx->tune = *t;
+  IFEM_API_END
+}
+
 int ifem_ctx_create(const ifem_mesh_desc *m, const ifem_partition *part, int device, ifem_ctx **out) {
   ifem_ctx *ctx = nullptr;
   IFEM_API_BEGIN
@@ -49,6 +79,7 @@ int ifem_ctx_create(const ifem_mesh_desc *m, const ifem_partition *part, int dev
   IFEM_HIP_CHECK(hipSetDevice(device));
   ctx = new ifem_ctx();
   ctx->device = device;
+  ifem_default_tuning(&ctx->tune);
   IFEM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   IFEM_HIP_CHECK(hipEventCreate(&ctx->ev0));
   IFEM_HIP_CHECK(hipEventCreate(&ctx->ev1));
@@ -71,37 +102,8 @@ int ifem_ctx_create(const ifem_mesh_desc *m, const ifem_partition *part, int dev
     ctx->cell_face_bid.upload(none.data(), none.size(), s);
     IFEM_HIP_CHECK(hipStreamSynchronize(s));
   }
-  IFEM_HIP_CHECK(hipHostMalloc((void **)&ctx->h_scal, 256 * sizeof(double)));
-  ctx->scal.alloc(256);
-  if (const char *e = getenv("IFEM_ASM")) ctx->asm_rows = std::string(e) == "rows";
-  { // greedy cell colouring on the vertices (two cells share a node iff they share a vertex)
-    const char *e = getenv("IFEM_ASM_SCATTER"); // only the opt-in read-modify-write scatter needs the colouring
-    if (e && std::string(e) == "rmw") {
-      std::vector<uint64_t> used((size_t)ctx->nPl, 0);
-      std::vector<uint8_t> col((size_t)m->n_cells);
-      int ncol = 0;
-      bool ok = true;
-      for (int64_t c = 0; c < m->n_cells && ok; ++c) {
-        uint64_t msk = 0;
-        for (int v = 0; v < np; ++v) msk |= used[m->cell_pnodes[c * np + v]];
-        if (~msk == 0) { ok = false; break; }
-        const int k = __builtin_ctzll(~msk);
-        col[c] = (uint8_t)k;
-        ncol = std::max(ncol, k + 1);
-        for (int v = 0; v < np; ++v) used[m->cell_pnodes[c * np + v]] |= uint64_t(1) << k;
-      }
-      if (ok && m->n_cells > 0) {
-        ctx->color_ptr.assign((size_t)ncol + 1, 0);
-        for (int64_t c = 0; c < m->n_cells; ++c) ctx->color_ptr[col[c] + 1]++;
-        for (int k = 0; k < ncol; ++k) ctx->color_ptr[k + 1] += ctx->color_ptr[k];
-        std::vector<int64_t> next(ctx->color_ptr.begin(), ctx->color_ptr.end() - 1);
-        std::vector<int32_t> order((size_t)m->n_cells);
-        for (int64_t c = 0; c < m->n_cells; ++c) order[next[col[c]]++] = (int32_t)c;
-        ctx->color_order.upload(order.data(), order.size(), s);
-        IFEM_HIP_CHECK(hipStreamSynchronize(s));
-      }
-    }
-  }
+  IFEM_HIP_CHECK(hipHostMalloc((void **)&ctx->h_scal, kScalSlots * sizeof(double)));
+  ctx->scal.alloc(kScalSlots);
   comm_init(ctx, part);
   {
     double g[2] = {double(ctx->dim * ctx->nUo), double(ctx->nPo)};
@@ -135,9 +137,6 @@ void ifem_ctx_destroy(ifem_ctx *ctx) {
   comm_destroy(ctx);
   ifem::tpp_release(ctx);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
-  if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
-  if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
-  if (ctx->ev_spare) (void)hipEventDestroy(ctx->ev_spare);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   hipStream_t s = ctx->stream;

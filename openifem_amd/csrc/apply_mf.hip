@@ -37,13 +37,12 @@ struct MfArgsT {
   const uint8_t *is_c; // constraint flags of the set the matrix was assembled with (local dofs) or nullptr
   const double *eval;  // evaluation point of the assembled matrix, velocity part, ghost-extended
   const double *x;     // ghost-extended input
-  double *y;           // owned rows, zeroed by the caller
+  double *y;           // owned rows
   R mu, rho, gamma, inv_dt;
   int xcd;
-  R *ycell; // per-cell results of the two-stage scatter, or nullptr (atomic scatter)
+  R *ycell; // per-cell results of the two-stage scatter
   MfTablesT<R> t;
 };
-using MfArgs = MfArgsT<double>;
 
 template <int DIM, int N1>
 struct MfGeo {
@@ -51,204 +50,12 @@ struct MfGeo {
   static constexpr int NV = 1 << DIM;
 };
 
-// per-wave scratch in LDS
-template <int DIM, int N1>
-struct MfScratch {
-  static constexpr int NN = MfGeo<DIM, N1>::NN;
-  double A[2 * DIM * NN];       // ping
-  double B[2 * DIM * NN];       // pong: values at the Gauss points [field][q], fields = x_0..x_{dim-1}, u_0..u_{dim-1}
-  double G[DIM * 2 * DIM * NN]; // reference gradients [dir][field][q]; reused for T^ [dir][comp][q]
-  double X[MfGeo<DIM, N1>::NV * DIM];
-};
-
-// out[f][..o..] = sum_i M(o,i) in[f][..i..] along direction dir; M(o,i) = T ? m[i*N1+o] : m[o*N1+i]
-template <int DIM, int N1, int NF, bool T>
-__device__ inline void mf_pass(const double *__restrict__ in, double *__restrict__ out, const double *__restrict__ m,
-                               int dir, int lane) {
-  constexpr int NN = MfGeo<DIM, N1>::NN;
-  const int stride = dir == 0 ? 1 : (dir == 1 ? N1 : N1 * N1);
-  for (int t = lane; t < NF * NN; t += 64) {
-    const int r = t % NN;
-    const int o = (r / stride) % N1;
-    const int base = t - o * stride;
-    double acc = 0;
-#pragma unroll
-    for (int i = 0; i < N1; ++i) acc += (T ? m[i * N1 + o] : m[o * N1 + i]) * in[base + i * stride];
-    out[t] = acc;
-  }
-}
-
-template <int DIM, int KV, int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf(MfArgs A) {
-  constexpr int N1 = KV + 1, NN = MfGeo<DIM, N1>::NN, NV = 1 << DIM, NF = 2 * DIM;
-  __shared__ MfTables T;
-  __shared__ MfScratch<DIM, N1> SS[WPB];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (threadIdx.x < 9) { T.N[threadIdx.x] = A.t.N[threadIdx.x]; T.D[threadIdx.x] = A.t.D[threadIdx.x]; }
-  if (threadIdx.x < 3) { T.xi[threadIdx.x] = A.t.xi[threadIdx.x]; T.w[threadIdx.x] = A.t.w[threadIdx.x]; }
-  MfScratch<DIM, N1> &S = SS[wave];
-  const int64_t cell = int64_t(blockIdx.x) * WPB + wave;
-  const bool active = cell < A.n_cells;
-  const int64_t cc = active ? cell : 0;
-
-  // ---- gather: nodal x (constrained columns are eliminated: x = 0 there) and evaluation point
-  int32_t my_node = 0;
-  bool my_c[DIM];
-  for (int a = lane; a < NN; a += 64) { // NN <= 27 < 64: one trip
-    const int32_t nd = A.cell_unodes[cc * NN + a];
-    my_node = nd;
-#pragma unroll
-    for (int c = 0; c < DIM; ++c) {
-      const int64_t dof = int64_t(DIM) * nd + c;
-      const bool con = A.is_c ? A.is_c[dof] != 0 : false;
-      my_c[c] = con;
-      S.A[c * NN + a] = con ? 0.0 : A.x[dof];
-      S.A[(DIM + c) * NN + a] = A.eval[dof];
-    }
-  }
-  for (int i = lane; i < NV * DIM; i += 64) S.X[i] = A.vcoords[cc * NV * DIM + i];
-  __syncthreads();
-
-  // ---- nodal values -> Gauss points, one direction at a time
-  mf_pass<DIM, N1, NF, false>(S.A, S.B, T.N, 0, lane);
-  __syncthreads();
-  mf_pass<DIM, N1, NF, false>(S.B, S.A, T.N, 1, lane);
-  __syncthreads();
-  if constexpr (DIM == 3) {
-    mf_pass<DIM, N1, NF, false>(S.A, S.B, T.N, 2, lane);
-    __syncthreads();
-  }
-  double *V = (DIM == 3) ? S.B : S.A; // values at the Gauss points
-  double *W = (DIM == 3) ? S.A : S.B; // free buffer
-  // ---- reference gradients by collocation
-#pragma unroll
-  for (int d = 0; d < DIM; ++d) mf_pass<DIM, N1, NF, false>(V, S.G + d * NF * NN, T.D, d, lane);
-  __syncthreads();
-
-  // ---- weak form at the quadrature point (lane = q)
-  if (lane < NN) {
-    const int q = lane;
-    int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
-    // MappingQ1: J[e][d] = sum_v X[v][e] d_d N1_v(xi_q)
-    double L[3][2], J[DIM * DIM], Ji[DIM * DIM];
-#pragma unroll
-    for (int d = 0; d < DIM; ++d) { L[d][1] = T.xi[qi[d]]; L[d][0] = 1.0 - L[d][1]; }
-#pragma unroll
-    for (int i = 0; i < DIM * DIM; ++i) J[i] = 0;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int b[3] = {v & 1, (v >> 1) & 1, (v >> 2) & 1};
-#pragma unroll
-      for (int d = 0; d < DIM; ++d) {
-        double g = b[d] ? 1.0 : -1.0;
-#pragma unroll
-        for (int o = 0; o < DIM; ++o)
-          if (o != d) g *= L[o][b[o]];
-#pragma unroll
-        for (int e = 0; e < DIM; ++e) J[e * DIM + d] += S.X[v * DIM + e] * g;
-      }
-    }
-    double det;
-    if constexpr (DIM == 2) {
-      det = J[0] * J[3] - J[1] * J[2];
-      const double r = 1.0 / det;
-      Ji[0] = J[3] * r; Ji[1] = -J[1] * r; Ji[2] = -J[2] * r; Ji[3] = J[0] * r;
-    } else {
-      const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
-      det = J[0] * c00 + J[1] * c01 + J[2] * c02;
-      const double r = 1.0 / det;
-      Ji[0] = c00 * r; Ji[3] = c01 * r; Ji[6] = c02 * r;
-      Ji[1] = (J[2] * J[7] - J[1] * J[8]) * r; Ji[4] = (J[0] * J[8] - J[2] * J[6]) * r; Ji[7] = (J[1] * J[6] - J[0] * J[7]) * r;
-      Ji[2] = (J[1] * J[5] - J[2] * J[4]) * r; Ji[5] = (J[2] * J[3] - J[0] * J[5]) * r; Ji[8] = (J[0] * J[4] - J[1] * J[3]) * r;
-    }
-    double wq = T.w[qi[0]] * T.w[qi[1]];
-    if constexpr (DIM == 3) wq *= T.w[qi[2]];
-    const double JxW = fabs(det) * wq;
-    double xq[DIM], uq[DIM], gx[DIM][DIM], gu[DIM][DIM];
-#pragma unroll
-    for (int c = 0; c < DIM; ++c) {
-      xq[c] = V[c * NN + q];
-      uq[c] = V[(DIM + c) * NN + q];
-      double rx[DIM], ru[DIM];
-#pragma unroll
-      for (int d = 0; d < DIM; ++d) {
-        rx[d] = S.G[(d * NF + c) * NN + q];
-        ru[d] = S.G[(d * NF + DIM + c) * NN + q];
-      }
-      // physical gradient: (g f)_e = sum_d Ji[d][e] d^_d f
-#pragma unroll
-      for (int e = 0; e < DIM; ++e) {
-        double sx = 0, su = 0;
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) { sx += Ji[d * DIM + e] * rx[d]; su += Ji[d * DIM + e] * ru[d]; }
-        gx[c][e] = sx; gu[c][e] = su;
-      }
-    }
-    double divx = 0;
-#pragma unroll
-    for (int c = 0; c < DIM; ++c) divx += gx[c][c];
-#pragma unroll
-    for (int c = 0; c < DIM; ++c) {
-      double conv = 0, newt = 0;
-#pragma unroll
-      for (int e = 0; e < DIM; ++e) { conv += uq[e] * gx[c][e]; newt += xq[e] * gu[c][e]; }
-      const double s = JxW * A.rho * (conv + A.inv_dt * xq[c] + newt);
-      double tp[DIM];
-#pragma unroll
-      for (int e = 0; e < DIM; ++e) tp[e] = JxW * (A.mu * gx[c][e] + (e == c ? A.gamma * A.rho * divx : 0.0));
-      W[c * NN + q] = s;
-      // back to reference directions: T^_d = sum_e Ji[d][e] tp[e]
-#pragma unroll
-      for (int d = 0; d < DIM; ++d) {
-        double t = 0;
-#pragma unroll
-        for (int e = 0; e < DIM; ++e) t += Ji[d * DIM + e] * tp[e];
-        S.G[(d * DIM + c) * NN + q] = t; // [dir][comp][q]
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- W += sum_d D_d^T T^_d  (fused, one item per (comp, q))
-  for (int t = lane; t < DIM * NN; t += 64) {
-    const int r = t % NN;
-    double acc = W[t];
-#pragma unroll
-    for (int d = 0; d < DIM; ++d) {
-      const int stride = d == 0 ? 1 : (d == 1 ? N1 : N1 * N1);
-      const int o = (r / stride) % N1;
-      const double *src = S.G + d * DIM * NN + (t - o * stride);
-#pragma unroll
-      for (int i = 0; i < N1; ++i) acc += T.D[i * N1 + o] * src[i * stride];
-    }
-    V[t] = acc; // V is free now (the q stage consumed it)
-  }
-  __syncthreads();
-  // ---- transposed interpolation back to the nodes
-  mf_pass<DIM, N1, DIM, true>(V, W, T.N, 0, lane);
-  __syncthreads();
-  mf_pass<DIM, N1, DIM, true>(W, V, T.N, 1, lane);
-  __syncthreads();
-  const double *R = V;
-  if constexpr (DIM == 3) {
-    mf_pass<DIM, N1, DIM, true>(V, W, T.N, 2, lane);
-    __syncthreads();
-    R = W;
-  }
-  // ---- scatter into owned, unconstrained rows
-  if (active && lane < NN && my_node < A.nUo) {
-#pragma unroll
-    for (int c = 0; c < DIM; ++c)
-      if (!my_c[c]) unsafeAtomicAdd(&A.y[int64_t(DIM) * my_node + c], R[c * NN + lane]);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// v2: half a wavefront (32 lanes) per cell, two cells per wave.  Every 1D pass is an in-register "pencil" operation
+// Half a wavefront (32 lanes) per cell, two cells per wave.  Every 1D pass is an in-register "pencil" operation
 // (one lane owns the N1 values of a grid line: N1 LDS reads, N1^2 FMAs against wave-uniform table entries that live in
 // SGPRs, N1 LDS writes, in place), the quadrature-point stage runs on 27 of 32 lanes, the trilinear geometry comes
 // from 8 monomial coefficients, and the only synchronisation is wave-local (LDS operations of one wave execute in
-// order).  ~330 wave instructions per 3D Q2 cell instead of ~1200 for the item-per-lane version above.
+// order).  ~330 wave instructions per 3D Q2 cell (the first, item-per-lane version of round 1 needed ~1200).
 __device__ inline void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -535,38 +342,21 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
       wsync();
     }
     // ---- scatter into owned, unconstrained rows: consecutive lanes hit consecutive doubles of a node
-    if (A.ycell) { // two-stage scatter: coalesced plain stores per cell, summed per node by k_mf_gather
-      if (active) {
+    // two-stage scatter: coalesced plain stores per cell, summed per node by k_mf_gather (atomics-free, deterministic)
+    if (active) {
 #pragma unroll
-        for (int k = 0; k < (DIM * NN + 31) / 32; ++k) { // unrolled: a loop here makes the compiler drain the prefetch first
-          const int t = hl + 32 * k;
-          const int a = t / DIM, c = t - a * DIM;
-          if (t < DIM * NN) A.ycell[cell * (DIM * NN) + t] = S.V[c * NN + a];
-        }
-      }
-    } else if (active) {
-      for (int t = hl; t < DIM * NN; t += 32) {
+      for (int k = 0; k < (DIM * NN + 31) / 32; ++k) { // unrolled: a loop here makes the compiler drain the prefetch first
+        const int t = hl + 32 * k;
         const int a = t / DIM, c = t - a * DIM;
-        const int32_t nd = S.node[a];
-        if (nd < A.nUo && !S.flag[t]) unsafeAtomicAdd(&A.y[int64_t(DIM) * nd + c], double(S.V[c * NN + a]));
+        if (t < DIM * NN) A.ycell[cell * (DIM * NN) + t] = S.V[c * NN + a];
       }
     }
     wsync();
   }
 }
 
-// constrained rows of the assembled matrix carry only their diagonal: y_r = d_r x_r, d_r recovered from
-// the inverse node block (row and column r of the block are zero apart from d_r, so its inverse has 1/d_r there)
-template <int DIM>
-__global__ void k_mf_constrained_rows(int64_t n, const uint8_t *__restrict__ is_c, const double *__restrict__ bjac,
-                                      const double *__restrict__ x, double *__restrict__ y) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n || !is_c[i]) return;
-  const int64_t nd = i / DIM;
-  const int c = int(i - nd * DIM);
-  y[i] = x[i] / bjac[nd * DIM * DIM + c * DIM + c];
-}
-
+// Constrained rows of the assembled matrix carry only their diagonal: y_r = d_r x_r, d_r recovered from the
+// inverse node block (row and column r of the block are zero apart from d_r, so its inverse has 1/d_r there).
 // second stage of the atomics-free scatter: y_i = sum over the cells touching node(i) of the cell's local result (fixed
 // order: deterministic), constrained rows y_r = d_r x_r as above
 template <int DIM, typename R>
@@ -658,19 +448,13 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu) {
   a.mu = R(ctx->mf_params.viscosity); a.rho = R(ctx->mf_params.rho); a.gamma = R(ctx->mf_params.grad_div);
   a.inv_dt = R(1.0 / ctx->mf_params.dt);
   { MfTables t; mf_tables(t, ctx->kv); mf_tables_to(a.t, t); }
-  { static const int xcd = [] { const char *e = getenv("IFEM_XCD"); return e ? atoi(e) : 1; }(); a.xcd = xcd; }
-  a.ycell = nullptr;
+  a.xcd = ctx->tune.xcd_swizzle;
   const bool time_it = ctx->profile;
-  // scatter: two-stage (per-cell results + per-node gather; atomics-free, deterministic) unless IFEM_MF_SCATTER=atomic
-  static const bool want_atomic = [] { const char *e = getenv("IFEM_MF_SCATTER"); return e && std::string(e) == "atomic"; }();
-  const bool two_stage = !want_atomic && ctx->n_cells < (int64_t(1) << 26) && ctx->nu <= 32;
-  if (two_stage) {
-    if (ctx->uinc.n_rows == 0 && ctx->nUo) build_incidence(ctx);
-    const size_t need = size_t(ctx->n_cells) * ctx->dim * ctx->nu; // in doubles: the float variant uses half of it
-    if (ctx->mf_ycell.n < need) ctx->mf_ycell.alloc(need);
-    a.ycell = reinterpret_cast<R *>(ctx->mf_ycell.p);
-  } else
-    IFEM_HIP_CHECK(hipMemsetAsync(yu, 0, size_t(n) * sizeof(double), s));
+  if (ctx->n_cells >= (int64_t(1) << 26) || ctx->nu > 32) throw Error(IFEM_E_BADPARAM, "matrix-free A_uu: incidence entries hold 26 cell bits and 5 node bits");
+  if (ctx->uinc.n_rows == 0 && ctx->nUo) build_incidence(ctx);
+  const size_t need = size_t(ctx->n_cells) * ctx->dim * ctx->nu; // in doubles: the float variant uses half of it
+  if (ctx->mf_ycell.n < need) ctx->mf_ycell.alloc(need);
+  a.ycell = reinterpret_cast<R *>(ctx->mf_ycell.p);
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s)); // the cell kernel alone (what rocprofv3 reports for it)
   constexpr int WPB = 4;
   const dim3 block(64 * WPB);
@@ -696,18 +480,12 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu) {
   else IFEM_MF2(2, 1)
 #undef IFEM_MF2
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
-  if (two_stage) {
-    if (ctx->dim == 3)
-      hipLaunchKernelGGL((k_mf_gather<3, R>), dim3(unsigned((n / 3 + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
-                         ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu);
-    else
-      hipLaunchKernelGGL((k_mf_gather<2, R>), dim3(unsigned((n / 2 + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
-                         ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu);
-  } else
-  if (a.is_c) {
-    if (ctx->dim == 3) hipLaunchKernelGGL((k_mf_constrained_rows<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, a.is_c, ctx->bjac.p, xu, yu);
-    else hipLaunchKernelGGL((k_mf_constrained_rows<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, a.is_c, ctx->bjac.p, xu, yu);
-  }
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_mf_gather<3, R>), dim3(unsigned((n / 3 + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
+                       ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu);
+  else
+    hipLaunchKernelGGL((k_mf_gather<2, R>), dim3(unsigned((n / 2 + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
+                       ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu);
   if (time_it) {
     IFEM_HIP_CHECK(hipEventSynchronize(ctx->ev1));
     float ms = 0;
@@ -717,38 +495,9 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu) {
   }
 }
 
-// first version of the cell kernel (one item per lane, atomic scatter), kept behind IFEM_MF_V1=1 for comparison
-static void apply_uu_mf_v1(ifem_ctx *ctx, const double *xu, double *yu) {
-  if (!ctx->mf_valid) throw Error(IFEM_E_BADPARAM, "matrix-free A_uu: no assembled state (call ifem_ins_assemble first)");
-  const int64_t n = int64_t(ctx->dim) * ctx->nUo;
-  hipStream_t s = ctx->stream;
-  MfArgs a{};
-  a.n_cells = ctx->n_cells; a.nUo = ctx->nUo;
-  a.vcoords = ctx->vcoords.p; a.cell_unodes = ctx->cell_unodes.p;
-  a.is_c = ctx->has_c[ctx->asm_constraint_set] ? ctx->is_c[ctx->asm_constraint_set].p : nullptr;
-  a.eval = ctx->mf_eval.p; a.x = xu; a.y = yu;
-  a.mu = ctx->mf_params.viscosity; a.rho = ctx->mf_params.rho; a.gamma = ctx->mf_params.grad_div;
-  a.inv_dt = 1.0 / ctx->mf_params.dt;
-  mf_tables(a.t, ctx->kv);
-  IFEM_HIP_CHECK(hipMemsetAsync(yu, 0, size_t(n) * sizeof(double), s));
-  constexpr int WPB = 4;
-  const dim3 grid(unsigned((ctx->n_cells + WPB - 1) / WPB)), block(64 * WPB);
-  if (ctx->dim == 3 && ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf<3, 2, WPB>), grid, block, 0, s, a);
-  else if (ctx->dim == 3) hipLaunchKernelGGL((k_apply_uu_mf<3, 1, WPB>), grid, block, 0, s, a);
-  else if (ctx->kv == 2) hipLaunchKernelGGL((k_apply_uu_mf<2, 2, WPB>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((k_apply_uu_mf<2, 1, WPB>), grid, block, 0, s, a);
-  if (a.is_c) {
-    if (ctx->dim == 3) hipLaunchKernelGGL((k_mf_constrained_rows<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, a.is_c, ctx->bjac.p, xu, yu);
-    else hipLaunchKernelGGL((k_mf_constrained_rows<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, a.is_c, ctx->bjac.p, xu, yu);
-  }
-}
-
-// single = true: single-precision cell arithmetic (the inner, preconditioner-only solve); IFEM_MF_F32=0 forces double
+// single = true: single-precision cell arithmetic (the inner, preconditioner-only solve); ifem_tuning::mf_f32 = 0 forces double
 void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single) {
-  static const int v1 = [] { const char *e = getenv("IFEM_MF_V1"); return e ? atoi(e) : 0; }();
-  static const int f32 = [] { const char *e = getenv("IFEM_MF_F32"); return e ? atoi(e) : 1; }();
-  if (v1) apply_uu_mf_v1(ctx, xu, yu);
-  else if (single && f32) apply_uu_mf_t<float>(ctx, xu, yu);
+  if (single && ctx->tune.mf_f32) apply_uu_mf_t<float>(ctx, xu, yu);
   else apply_uu_mf_t<double>(ctx, xu, yu);
 }
 

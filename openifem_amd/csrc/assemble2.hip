@@ -572,36 +572,21 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
 template <int DIM, int KV>
 static void launch2_t(ifem_ctx *ctx, const AsmArgs &A) {
   constexpr int WPB = 4, RPMAX = IFEM_ASM2_RP; // pairs per lane and pass: atomic scatter
-  constexpr int RPRMW = 2;                     // plain read-modify-write scatter (old values prefetched into registers)
   using C2 = Cell2<DIM, KV>;
   const size_t smem = ((sizeof(Shared2) + 15) & ~size_t(15)) + WPB * ((sizeof(C2) + 15) & ~size_t(15));
   static bool attr_set = false;
   if (!attr_set) {
     IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ins_assemble2<DIM, KV, WPB, true, RPMAX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ins_assemble2<DIM, KV, WPB, false, RPRMW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
   Tab1D t;
   tab1d(t, KV);
-  // Measured at 128^3 (MI355X): atomics 224 ms, coloured plain read-modify-write 247-253 ms (its loads sit on the
-  // critical path of a kernel that runs at 2 waves/SIMD), so atomics are the default and IFEM_ASM_SCATTER=rmw opts in.
-  static const bool use_rmw = [] { const char *e = getenv("IFEM_ASM_SCATTER"); return e && std::string(e) == "rmw"; }();
-  if (ctx->color_ptr.empty() || !use_rmw) { // one launch, hardware atomics
-    AsmArgs B = A;
-    B.order = nullptr; B.first = 0; B.count = A.n_cells;
-    const int64_t nblk = (B.count + WPB - 1) / WPB;
-    hipLaunchKernelGGL((k_ins_assemble2<DIM, KV, WPB, true, RPMAX>), dim3((unsigned)nblk), dim3(64 * WPB), smem, ctx->stream, B, t);
-  } else { // one launch per colour (stream order separates them): conflict-free plain read-modify-write
-    for (size_t k = 0; k + 1 < ctx->color_ptr.size(); ++k) {
-      AsmArgs B = A;
-      B.order = ctx->color_order.p; B.first = ctx->color_ptr[k]; B.count = ctx->color_ptr[k + 1] - ctx->color_ptr[k];
-      if (B.count == 0) continue;
-      const int64_t nblk = (B.count + WPB - 1) / WPB;
-      hipLaunchKernelGGL((k_ins_assemble2<DIM, KV, WPB, false, RPRMW>), dim3((unsigned)nblk), dim3(64 * WPB), smem, ctx->stream, B, t);
-    }
-  }
+  // (a coloured plain read-modify-write scatter was measured in round 1: 247-253 ms against 224 ms with atomics at 128^3)
+  AsmArgs B = A;
+  B.order = nullptr; B.first = 0; B.count = A.n_cells;
+  const int64_t nblk = (B.count + WPB - 1) / WPB;
+  hipLaunchKernelGGL((k_ins_assemble2<DIM, KV, WPB, true, RPMAX>), dim3((unsigned)nblk), dim3(64 * WPB), smem, ctx->stream, B, t);
   IFEM_HIP_CHECK(hipGetLastError());
 }
 

@@ -191,14 +191,19 @@ static void allreduce(ifem_ctx *ctx, double *host_vals, int n, bool is_max) {
     std::memcpy(host_vals, out.data(), n * sizeof(double));
     return;
   }
+  // the staging slots hold kScalStage doubles (scal / h_scal[kScalStageOff...]): longer lists (the 200-column inner GMRES of
+  // scns_solve, a user fgmres_restart >= 128) go through in chunks
   hipStream_t s = ctx->stream;
-  double *d = ctx->scal.p + 128;
-  std::memcpy(ctx->h_scal + 128, host_vals, n * sizeof(double));
-  IFEM_HIP_CHECK(hipMemcpyAsync(d, ctx->h_scal + 128, n * sizeof(double), hipMemcpyHostToDevice, s));
-  IFEM_NCCL_CHECK(ncclAllReduce(d, d, n, ncclDouble, is_max ? ncclMax : ncclSum, (ncclComm_t)h.comm, s));
-  IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal + 128, d, n * sizeof(double), hipMemcpyDeviceToHost, s));
-  IFEM_HIP_CHECK(hipStreamSynchronize(s));
-  std::memcpy(host_vals, ctx->h_scal + 128, n * sizeof(double));
+  double *d = ctx->scal.p + kScalStageOff;
+  for (int first = 0; first < n; first += kScalStage) {
+    const int m = std::min(kScalStage, n - first);
+    std::memcpy(ctx->h_scal + kScalStageOff, host_vals + first, m * sizeof(double));
+    IFEM_HIP_CHECK(hipMemcpyAsync(d, ctx->h_scal + kScalStageOff, m * sizeof(double), hipMemcpyHostToDevice, s));
+    IFEM_NCCL_CHECK(ncclAllReduce(d, d, m, ncclDouble, is_max ? ncclMax : ncclSum, (ncclComm_t)h.comm, s));
+    IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal + kScalStageOff, d, m * sizeof(double), hipMemcpyDeviceToHost, s));
+    IFEM_HIP_CHECK(hipStreamSynchronize(s));
+    std::memcpy(host_vals + first, ctx->h_scal + kScalStageOff, m * sizeof(double));
+  }
 }
 
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, host_vals, n, false); }

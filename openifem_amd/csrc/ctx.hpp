@@ -23,6 +23,10 @@ struct Error : std::runtime_error {
                                           __FILE__ + ":" + std::to_string(__LINE__));               \
   } while (0)
 
+// ctx->scal / ctx->h_scal slots: [0,64) fused dot products, [64,128) multi-axpy coefficients, [128,256) recurrence scalars
+// of the device-resident CG (linalg.hip), [kScalStageOff, +kScalStage) staging of the RCCL all-reduce (comm.hip)
+constexpr int kScalSlots = 512, kScalStageOff = 256, kScalStage = 256;
+
 template <class T>
 struct DBuf { // owning device buffer
   T *p = nullptr;
@@ -167,14 +171,8 @@ struct ifem_ctx {
   // SCnsIM (slightly compressible, SUPG): pressure-pressure block on the M_p pattern, nodal stress fields, cell fields
   ifem::DBuf<double> App, app_diag, stress, fsi_stress, sigma_pml, body_force, xinv, eddy_viscosity;
   bool has_app = false, stress_valid = false;
-  // cell colouring: cells of one colour share no node, so a launch over one colour scatters with plain read-modify-write
-  // instead of atomics (gfx950 retires f64 atomics at ~24 G 64-byte segments/s whatever the scope; plain RMW is 2-5x faster)
-  ifem::DBuf<int32_t> color_order; // cells sorted by colour (stable: Morton order inside a colour)
-  std::vector<int64_t> color_ptr;  // [n_colors + 1]; empty = colouring unavailable, atomics are used
-  ifem::PlanarCsr uinc, pinc;  // node -> (cell << 5 | local index) incidence lists (row-owner assembly)
-  ifem::DBuf<double> qdata;    // per cell, per quadrature point geometry + evaluation-point fields
-  bool asm_rows = false;       // true (IFEM_ASM=rows): atomics-free row-owner assembly (assemble_rows.hip): bit-reproducible,
-                               // ~3x slower at 128^3 (2.2x the VALU work: per-row recomputation of the cell gradients)
+  ifem::PlanarCsr uinc;  // velocity node -> (cell << 5 | local index) incidence lists (gather stage of the matrix-free apply)
+  ifem_tuning tune{};    // ifem_set_tuning
   ifem::PlanarCsr Sm;  // mass_schur(1,1) = B diag(M_u)^-1 B^T, explicit (single rank only; empty otherwise)
   bool sm_valid = false;
   ifem::DBuf<float> B_f32, Bt_f32; // single-precision copies for the matrix-free S_m of the approximate-preconditioner kinds
@@ -210,13 +208,6 @@ struct ifem_ctx {
   ifem::DBuf<double> bjac;     // inverse diagonal node blocks of A_uu [nUo][dim*dim]
   ifem::DBuf<float> bjac_f32;  // single-precision copy for the inner solver (built on first use after bjac_setup)
   bool bjac_f32_valid = false;
-  // second value buffer of A_uu: zeroed on a side stream while the previous matrix is still in use, swapped in by the
-  // next assembly instead of a memset in front of the scatter (assemble.hip; IFEM_AUU_SPARE)
-  ifem::DBuf<double> Auu_spare;
-  hipStream_t side_stream = nullptr;
-  hipEvent_t ev_main = nullptr, ev_spare = nullptr;
-  int spare_state = 0; // 0 undecided, -1 unavailable, 1 allocated; spare_zeroing: a zero-fill of the spare is enqueued
-  bool spare_zeroing = false;
   // scatter maps: position of the column inside the row, 0xFFFF = row not owned here
   ifem::DBuf<uint16_t> posUU, posUP, posPU, posPP;
   // constraints (local dof numbering), sets 0 = zero, 1 = nonzero

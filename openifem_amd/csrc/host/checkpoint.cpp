@@ -64,8 +64,12 @@ void FluidSolver<dim>::save_checkpoint(const int output_index) {
       std::error_code ec;
       fs::remove(old, ec);
       fs::remove(stem + ".fluid_checkpoint.info", ec);
-      for (int r = 0; r < std::max(nranks, 1); ++r) fs::remove(data_name(stem, r, nranks), ec);
-      fs::remove(data_name(stem, 0, 1), ec);
+      // every piece of the old checkpoint, whatever rank count wrote it: <stem>.fluid_checkpoint_fixed.data[.<rank>]
+      const std::string piece = old.stem().string() + ".fluid_checkpoint_fixed.data";
+      std::vector<fs::path> pieces;
+      for (const auto &q : fs::directory_iterator(dir))
+        if (q.path().filename().string().compare(0, piece.size(), piece) == 0) pieces.push_back(q.path());
+      for (const auto &q : pieces) fs::remove(q, ec);
       checkpoints.erase(checkpoints.begin());
     }
   }
@@ -147,6 +151,11 @@ bool FluidSolver<dim>::load_checkpoint() {
     if (!in) throw std::runtime_error("load_checkpoint: missing " + data_name(stem, r, h.nranks));
     int64_t counts[2];
     get(in, counts, 2);
+    // validate the header before anything is sized or indexed by it (a stale or corrupt piece must not write out of bounds)
+    if (same_layout && (counts[0] != nuo || counts[1] != npo))
+      throw std::runtime_error("load_checkpoint: piece size differs from this rank's owned range");
+    if (counts[0] < 0 || counts[1] < 0 || counts[0] > h.n_unodes_global || counts[1] > h.n_pnodes_global)
+      throw std::runtime_error("load_checkpoint: corrupt piece header in " + data_name(stem, r, h.nranks));
     std::vector<int64_t> gid((size_t)counts[0]);
     std::vector<double> val((size_t)counts[0] * dim);
     get(in, gid.data(), gid.size());
@@ -156,7 +165,7 @@ bool FluidSolver<dim>::load_checkpoint() {
       if (same_layout) l = i;
       else { auto it = mu->find(gid[(size_t)i]); if (it != mu->end()) l = it->second; }
       if (l < 0) continue;
-      if (same_layout && l < nuo && (keyed ? part.l2g_u[(size_t)l] : l) != gid[(size_t)i])
+      if (same_layout && (keyed ? part.l2g_u[(size_t)l] : l) != gid[(size_t)i])
         throw std::runtime_error("load_checkpoint: node numbering of the checkpoint differs from this run");
       for (int c = 0; c < dim; ++c) sol[(size_t)l * dim + c] = val[(size_t)i * dim + c];
       seen_u[(size_t)l] = 1;
@@ -170,13 +179,11 @@ bool FluidSolver<dim>::load_checkpoint() {
       if (same_layout) l = i;
       else { auto it = mp->find(gid[(size_t)i]); if (it != mp->end()) l = it->second; }
       if (l < 0) continue;
-      if (same_layout && l < npo && (keyed ? part.l2g_p[(size_t)l] : l) != gid[(size_t)i])
+      if (same_layout && (keyed ? part.l2g_p[(size_t)l] : l) != gid[(size_t)i])
         throw std::runtime_error("load_checkpoint: node numbering of the checkpoint differs from this run");
       sol[(size_t)dofs.n_u() + (size_t)l] = val[(size_t)i];
       seen_p[(size_t)l] = 1;
     }
-    if (same_layout && (counts[0] != nuo || counts[1] != npo))
-      throw std::runtime_error("load_checkpoint: piece size differs from this rank's owned range");
   };
   if (h.nranks == nranks) // same partition: this rank's own piece, position by position
     read_piece(part_rank, true, nullptr, nullptr);

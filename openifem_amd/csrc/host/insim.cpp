@@ -41,6 +41,15 @@ void FluidSolver<dim>::check(int rc, const char *what) const {
 }
 
 template <int dim>
+void FluidSolver<dim>::refine_mesh_not_supported() const {
+  if (parameters.simulation_type == "Fluid" && time.time_to_refine())
+    throw std::runtime_error("refine_mesh: the reference refines the fluid mesh at this step (Refinement interval reached); "
+                             "adaptive refinement is not supported by the HIP host mirror -- raise 'Refinement interval' "
+                             "above 'End time' (hanging-node lines of an externally refined mesh go through "
+                             "ifem_set_hanging_constraints)");
+}
+
+template <int dim>
 void FluidSolver<dim>::add_hard_coded_boundary_condition(
     const int id, const std::function<double(const Point &, const unsigned int, const double)> &value_function) {
   if (parameters.fluid_dirichlet_bcs.find(id) == parameters.fluid_dirichlet_bcs.end())
@@ -233,7 +242,7 @@ void InsIM<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_syst
   check(ifem_vec_copy(ctx, IFEM_VEC_PRESENT, IFEM_VEC_EVAL), "run_one_step");
   if (parameters.simulation_type == "Fluid" && time.time_to_save()) this->save_checkpoint((int)time.get_timestep()); // (:477-480)
   if (this->output_enabled && time.time_to_output()) this->output_results(time.get_timestep()); // (:481-484)
-  // refine_mesh: outside the path
+  this->refine_mesh_not_supported(); // (:485-489)
 }
 
 template <int dim>
@@ -291,12 +300,12 @@ std::pair<unsigned int, double> InsIMEX<dim>::solve(bool use_nonzero_constraints
 
 template <int dim>
 void InsIMEX<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_system) {
+  if (this->output_enabled && time.get_timestep() == 0) this->output_results(0); // (mpi_insimex.cpp:402-405)
   time.increment();
   if (this->pcout)
     *this->pcout << std::string(96, '*') << std::endl
                  << "Time step = " << time.get_timestep() << ", at t = " << std::scientific << time.current() << std::endl;
   check(ifem_vec_zero(ctx, IFEM_VEC_UPDATE), "run_one_step"); // solution_time_increment = 0
-  // refinement is outside the path: the "|| time_to_refine()" of mpi_insimex.cpp:416-418 never fires here
   assemble(apply_nonzero_constraints, assemble_system);
   auto state = solve(apply_nonzero_constraints, assemble_system);
   check(ifem_vec_axpy(ctx, 1.0, IFEM_VEC_UPDATE, IFEM_VEC_PRESENT), "run_one_step"); // present_solution += increment
@@ -306,6 +315,7 @@ void InsIMEX<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_sy
   check(ifem_update_stress(ctx, parameters.viscosity, nullptr), "update_stress");
   if (parameters.simulation_type == "Fluid" && time.time_to_save()) this->save_checkpoint((int)time.get_timestep()); // (mpi_insimex.cpp:433-436)
   if (this->output_enabled && time.time_to_output()) this->output_results(time.get_timestep());
+  this->refine_mesh_not_supported(); // (mpi_insimex.cpp:438-442; the reference also re-assembles on that trigger, :416-418)
 }
 
 template <int dim>

@@ -113,6 +113,9 @@ public:
 
 protected:
   void check(int rc, const char *what) const;
+  // refine_mesh (mpi_fluid_solver.cpp:418-488, called from run_one_step when time_to_refine() fires in a pure-fluid run,
+  // mpi_insim.cpp:485-489) is not part of the host mirror: stop with a message instead of computing on another mesh
+  void refine_mesh_not_supported() const;
   Triangulation<dim> &triangulation;
   Parameters::AllParameters parameters;
   DoFTables<dim> dofs;

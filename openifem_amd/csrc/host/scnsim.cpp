@@ -83,10 +83,11 @@ void SUPGFluidSolver<dim>::run_one_step(bool apply_nonzero_constraints, bool ass
   check(ifem_vec_copy(ctx, IFEM_VEC_INCREMENT, IFEM_VEC_PRESENT), "run_one_step");
   check(ifem_vec_axpy(ctx, -1.0, IFEM_VEC_EVAL, IFEM_VEC_INCREMENT), "run_one_step");
   check(ifem_vec_copy(ctx, IFEM_VEC_PRESENT, IFEM_VEC_EVAL), "run_one_step");
-  // update_stress feeds the next assemble (mpi_scnsim.cpp:178-186); refinement is host plumbing outside the path
+  // update_stress feeds the next assemble (mpi_scnsim.cpp:178-186); 
   check(ifem_update_stress(ctx, parameters.viscosity, nullptr), "update_stress");
   if (parameters.simulation_type == "Fluid" && time.time_to_save()) this->save_checkpoint((int)time.get_timestep()); // (:416-419)
   if (this->output_enabled && time.time_to_output()) this->output_results(time.get_timestep());
+  this->refine_mesh_not_supported(); // (mpi_supg_solver.cpp:420-424)
 }
 
 template <int dim>

@@ -10,8 +10,6 @@ void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, in
 
 void build_schur_pattern(ifem_ctx *ctx);
 void build_incidence(ifem_ctx *ctx);
-// assemble_rows.hip: atomics-free row-owner assembly (records ev0/ev1 around its kernels)
-void launch_ins_assemble_rows(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
 
 // assemble.hip
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
@@ -89,7 +87,6 @@ void spmv_planar_scalar(ifem_ctx *ctx, const PlanarCsr &M, const double *val, co
 void tpp_numeric(ifem_ctx *ctx);
 void spmv_tpp(ifem_ctx *ctx, const double *xp, double *yp);
 bool tpp_dense_setup(ifem_ctx *ctx);
-int64_t tpp_dense_max();
 void tpp_dense_solve(ifem_ctx *ctx, const double *x, double *y);
 void tpp_release(ifem_ctx *ctx);
 // hanging-node lines (hanging.hip): C x on a copy of x, C^T and the hanging rows on y, distribute, set-up

@@ -177,7 +177,7 @@ void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool
   if (use_f32) auu_f32_refresh(ctx);
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s));
   if (ctx->dim == 3) {
-    static const int Gsel = [] { const char *e = getenv("IFEM_SPMV_G"); return e ? atoi(e) : 32; }();
+    const int Gsel = ctx->tune.spmv_lanes;
 #define IFEM_SPMV3(G)                                                                                                  \
   if (use_f32)                                                                                                         \
     hipLaunchKernelGGL((k_spmv_uu<3, G, float>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,    \
@@ -492,7 +492,7 @@ void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp, bool use_f32) {
     hipLaunchKernelGGL(k_to_f32, dim3(8192), dim3(256), 0, ctx->stream, nv, ctx->Sm.val.p, ctx->Sm_f32.p);
     ctx->sm_f32_valid = true;
   }
-  static const int Gs = [] { const char *e = getenv("IFEM_SM_G"); return e ? atoi(e) : 32; }();
+  const int Gs = ctx->tune.sm_lanes;
   if (use_f32 && Gs == 64)
     hipLaunchKernelGGL((k_spmv_planar<1, 1, 64, float>), dim3(blocks_for_rows(n, 64)), dim3(256), 0, ctx->stream, n,
                        ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm_f32.p, xp, yp);

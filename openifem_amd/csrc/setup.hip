@@ -177,7 +177,7 @@ __global__ void k_gen_inc_keys(int64_t n_cells, int R, const int32_t *__restrict
 }
 
 void build_incidence(ifem_ctx *ctx) {
-  if (ctx->n_cells >= (int64_t(1) << 26)) throw Error(IFEM_E_BADPARAM, "row assembly: too many local cells");
+  if (ctx->n_cells >= (int64_t(1) << 26)) throw Error(IFEM_E_BADPARAM, "incidence lists: too many local cells");
   hipStream_t s = ctx->stream;
   auto one = [&](PlanarCsr &M, int64_t n_rows, int R, const int32_t *rows) {
     const int64_t N = ctx->n_cells * R;
@@ -187,9 +187,6 @@ void build_incidence(ifem_ctx *ctx) {
     pattern_from_keys(ctx, M, 0, n_rows, keys, N);
   };
   one(ctx->uinc, ctx->nUo, ctx->nu, ctx->cell_unodes.p);
-  one(ctx->pinc, ctx->nPo, ctx->np, ctx->cell_pnodes.p);
-  if (ctx->uinc.max_row > 64 || ctx->pinc.max_row > 64)
-    throw Error(IFEM_E_BADPARAM, "row assembly: a node belongs to more than 64 cells (set IFEM_ASM=atomic)");
 }
 
 // ---- distributed explicit S_m on a structured pressure lattice (box meshes on several ranks).  Row i couples the

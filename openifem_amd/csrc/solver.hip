@@ -251,10 +251,7 @@ static int pcg_jacobi(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *dia
 
 // leading dimension of a Krylov basis: a multiple of 64 doubles plus an odd number of 256-byte lines, so that the
 // K+1 streams of a fused multi-dot do not start on the same HBM channel
-static int64_t basis_ld(int64_t n) {
-  static const int64_t pad = [] { const char *e = getenv("IFEM_LD_PAD"); return e ? atoll(e) : 32 * 33; }();
-  return ((n + 63) / 64) * 64 + pad;
-}
+static int64_t basis_ld(const ifem_ctx *ctx, int64_t n) { return ((n + 63) / 64) * 64 + ctx->tune.basis_pad; }
 
 struct SolveState {
   ifem_ctx *ctx;
@@ -430,15 +427,24 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   const bool f32_basis = (f32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF) && o->inner_restart + 6 <= 64;
   if (f32_basis) { // columns 0..m: basis, m+1: scratch for V y, up to the next multiple of 4: padding read by the fused kernels
     OpF32 Pf = [&](const float *x, double *y) { bjac_apply_f32(c, x, y); };
-    S.st.inner_iters += gmres_f32basis(c, S.nuo, basis_ld(S.nuo), Auu, Pf, S.utmp, dst0, o->inner_restart, o->inner_maxit,
+    S.st.inner_iters += gmres_f32basis(c, S.nuo, basis_ld(S.ctx, S.nuo), Auu, Pf, S.utmp, dst0, o->inner_restart, o->inner_maxit,
                                        o->inner_rel * un, reinterpret_cast<float *>(c->innerV.p), S.inner_z, S.inner_w, &res,
                                        [&](double *v, int k) { allreduce_sum(c, v, k); });
   } else
-  S.st.inner_iters += gmres(c, S.nuo, basis_ld(S.nuo), /*reorth=*/false, Auu, Pj, false, S.utmp, dst0, o->inner_restart,
+  S.st.inner_iters += gmres(c, S.nuo, basis_ld(S.ctx, S.nuo), /*reorth=*/false, Auu, Pj, false, S.utmp, dst0, o->inner_restart,
                             o->inner_maxit, o->inner_rel * un, c->innerV.p, S.inner_z, S.inner_w, &res, mdot);
   IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
   S.st.t_ainv_ms += ck3.ms();
   S.st.precond_applies++;
+}
+
+// The inner Krylov basis is shared by every solver of the context.  The single-precision-basis kernels read (with zero
+// coefficients) up to 3 columns past the ones in use, so the buffer is zero-filled whenever it is (re)allocated: 0 * NaN
+// from uninitialised memory would poison the preconditioner.
+static void grow_inner_basis(ifem_ctx *c, int64_t need) {
+  if ((int64_t)c->innerV.n >= need) return;
+  c->innerV.alloc((size_t)need);
+  IFEM_HIP_CHECK(hipMemsetAsync(c->innerV.p, 0, c->innerV.n * sizeof(double), c->stream));
 }
 
 static void carve_workspace(SolveState &S) {
@@ -457,13 +463,9 @@ static void carve_workspace(SolveState &S) {
   for (int i = 0; i < 6; ++i) { S.tp[i] = p; p += npl; }
   S.outer_w = p;
   const int m = S.o->fgmres_restart, mi = S.o->inner_restart;
-  if ((int64_t)c->krylovV.n < (int64_t)(m + 1) * basis_ld(S.n)) c->krylovV.alloc((int64_t)(m + 1) * basis_ld(S.n));
-  if ((int64_t)c->krylovZ.n < (int64_t)m * basis_ld(S.n)) c->krylovZ.alloc((int64_t)m * basis_ld(S.n));
-  if ((int64_t)c->innerV.n < (int64_t)(mi + 1) * basis_ld(S.nuo)) {
-    c->innerV.alloc((int64_t)(mi + 1) * basis_ld(S.nuo));
-    // the single-precision basis reads (with zero coefficients) up to 3 columns past the ones in use: keep them finite
-    IFEM_HIP_CHECK(hipMemsetAsync(c->innerV.p, 0, c->innerV.n * sizeof(double), c->stream));
-  }
+  if ((int64_t)c->krylovV.n < (int64_t)(m + 1) * basis_ld(S.ctx, S.n)) c->krylovV.alloc((int64_t)(m + 1) * basis_ld(S.ctx, S.n));
+  if ((int64_t)c->krylovZ.n < (int64_t)m * basis_ld(S.ctx, S.n)) c->krylovZ.alloc((int64_t)m * basis_ld(S.ctx, S.n));
+  grow_inner_basis(c, (int64_t)(mi + 1) * basis_ld(S.ctx, S.nuo));
 }
 
 void ins_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, const double *src, double *dst) {
@@ -510,7 +512,7 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
   Clock total;
   app_diag_setup(ctx);
   const int mt = 200;
-  if ((int64_t)ctx->innerV.n < (int64_t)(mt + 1) * basis_ld(S.npo)) ctx->innerV.alloc((int64_t)(mt + 1) * basis_ld(S.npo));
+  grow_inner_basis(ctx, (int64_t)(mt + 1) * basis_ld(S.ctx, S.npo));
   double *rhs = ctx->vec[IFEM_VEC_RHS].p, *upd = ctx->vec[IFEM_VEC_UPDATE].p;
   auto mdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
     v_mdot(ctx, S.n, k, V, ld, w, out);
@@ -540,9 +542,8 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
   };
   OpFn Jpp = [&](const double *x, double *y) { vec_div(ctx, S.npo, ctx->app_diag.p, x, y); };
   // one rank: T_pp as an explicit matrix (tpp.hip) -- exact dense solve on small pressure spaces, else one SpMV per inner
-  // iteration and the Jacobi preconditioner of T_pp itself.  IFEM_TPP=operator keeps the operator form.
-  static const bool tpp_operator = [] { const char *e = getenv("IFEM_TPP"); return e && std::string(e) == "operator"; }();
-  const bool tpp_explicit = ctx->halo.nranks == 1 && !tpp_operator;
+  // iteration and the Jacobi preconditioner of T_pp itself.  ifem_tuning::tpp_operator keeps the operator form.
+  const bool tpp_explicit = ctx->halo.nranks == 1 && !ctx->tune.tpp_operator;
   // The dense LU costs one factorisation per Newton iteration: it is switched on (for the life of the context) the first
   // time an inner solve does not converge within `tpp_switch_its` iterations -- acoustics with dt ~ 1e-7 never get there.
   const int tpp_switch_its = 100;
@@ -564,14 +565,14 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
     double res = 0;
     const double inner_tol = 1e-3 * std::sqrt(pn);
     if (!tpp_dense) {
-      const bool may_switch = tpp_explicit && !ctx->tpp_prefer_dense && S.npo <= tpp_dense_max();
-      S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.npo), /*reorth=*/true, Tpp, Jpp, false, S.tp[0], dst1, mt,
+      const bool may_switch = tpp_explicit && !ctx->tpp_prefer_dense && S.npo <= ctx->tune.tpp_dense_max;
+      S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.ctx, S.npo), /*reorth=*/true, Tpp, Jpp, false, S.tp[0], dst1, mt,
                                 may_switch ? tpp_switch_its : 100000, inner_tol, ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p);
       if (may_switch && res > inner_tol) { // too slow for this system: factorise instead
         ctx->tpp_prefer_dense = true;
         tpp_dense = tpp_dense_setup(ctx);
         if (!tpp_dense) // no rocSOLVER: carry on iteratively
-          S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.npo), true, Tpp, Jpp, false, S.tp[0], dst1, mt, 100000, inner_tol,
+          S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.ctx, S.npo), true, Tpp, Jpp, false, S.tp[0], dst1, mt, 100000, inner_tol,
                                     ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p);
       }
     }
@@ -583,7 +584,7 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
     S.st.precond_applies++;
   };
   double res = 0;
-  const int it = gmres(ctx, S.n, basis_ld(S.n), true, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p,
+  const int it = gmres(ctx, S.n, basis_ld(S.ctx, S.n), true, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p,
                        ctx->krylovZ.p, S.outer_w, &res, mdot);
   apply_constraints(ctx, use_nonzero ? 1 : 0, upd);
   hanging_distribute(ctx, upd);
@@ -620,7 +621,7 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   OpFn Aop = [&](const double *x, double *y) { system_apply(S, x, y, true); };
   OpFn Pop = [&](const double *x, double *y) { precond_vmult(S, x, y); };
   double res = 0;
-  const int it = gmres(ctx, S.n, basis_ld(S.n), /*reorth=*/true, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p, ctx->krylovZ.p,
+  const int it = gmres(ctx, S.n, basis_ld(S.ctx, S.n), /*reorth=*/true, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p, ctx->krylovZ.p,
                        S.outer_w, &res, mdot);
   apply_constraints(ctx, use_nonzero ? 1 : 0, upd); // constraints_used.distribute(newton_update)
   hanging_distribute(ctx, upd);

@@ -4,7 +4,7 @@
 // Here P_vv^-1 is the node-block Jacobi of A_vv, so T_pp itself has the sparsity of A_pv A_vp (= the pattern of
 // mass_schur) and is assembled once per Newton iteration:  T~[i,j] = A_pp[i,j] - sum_k A_pv[i,k] Binv_k A_vp[k,j].
 // Its inverse is then applied exactly where the pressure space is small (dense LU through rocSOLVER, up to
-// IFEM_TPP_DENSE_MAX rows: the 2D benchmark meshes of the reference), and by Jacobi-preconditioned GMRES on one SpMV per
+// ifem_tuning::tpp_dense_max rows: the 2D benchmark meshes of the reference), and by Jacobi-preconditioned GMRES on one SpMV per
 // iteration beyond.  Only the preconditioner is affected.  Single-rank contexts (the pattern needs a 2-deep halo).
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
@@ -128,10 +128,6 @@ void spmv_tpp(ifem_ctx *ctx, const double *xp, double *yp) {
   spmv_planar_scalar(ctx, ctx->Sm, ctx->Tpp.p, xp, yp);
 }
 
-int64_t tpp_dense_max() {
-  static const int64_t v = [] { const char *e = getenv("IFEM_TPP_DENSE_MAX"); return e ? atoll(e) : 12288; }();
-  return v;
-}
 
 static rocblas_handle handle_of(ifem_ctx *ctx) {
   if (!ctx->rocblas) {
@@ -150,7 +146,7 @@ void tpp_release(ifem_ctx *ctx) {
 // LU factors of the dense copy of T~ (partial pivoting); false when the pressure space is too large for this path
 bool tpp_dense_setup(ifem_ctx *ctx) {
   const int64_t n = ctx->Sm.n_rows;
-  if (n == 0 || n > tpp_dense_max()) return false;
+  if (n == 0 || n > ctx->tune.tpp_dense_max) return false;
   if (ctx->tpp_dense_valid) return true;
   rocblas_handle h = handle_of(ctx);
   if (ctx->tpp_dense.n != size_t(n) * size_t(n)) ctx->tpp_dense.alloc(size_t(n) * size_t(n));

@@ -471,20 +471,3 @@ def test_cached_geometry_blocks_stay_identical_across_assemblies(dim, kv, reps):
         check(False, name + ": zero constraints, cached blocks")
         check(False, name + ": zero constraints, cached again")
     ctx.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("dim,kv,reps", [(3, 2, (3, 2, 2)), (2, 2, (4, 3))])
-def test_spare_value_buffer_of_auu_is_invisible(dim, kv, reps, monkeypatch):
-    # Large matrices are zeroed on a side stream in a second value buffer that the next assembly swaps in
-    # (assemble.hip::spare_buffer_ready).  IFEM_AUU_SPARE=2 forces that path on a small mesh: the sequence of assemblies
-    # (cached and fresh blocks, both constraint sets, different states) must still match the oracle every time.
-    monkeypatch.setenv("IFEM_AUU_SPARE", "2")
-    test_cached_geometry_blocks_stay_identical_across_assemblies(dim, kv, reps)
-
-
-def test_newton_loop_with_spare_value_buffer(monkeypatch):
-    # the same through a whole Newton loop (several assemble / solve pairs on swapped buffers)
-    monkeypatch.setenv("IFEM_AUU_SPARE", "2")
-    test_newton_step_matches_oracle_2d_poiseuille_start()
-    test_kat_poiseuille_3d_on_gpu()
