@@ -60,10 +60,19 @@ def kernel_models(L, ctx, n_cells, n_u, n_p, dim=3, nu=27, npn=8, cached_blocks=
     return {"asm": (asm_bytes, asm_flops), "mf": (mf_bytes, mf_flops)}
 
 
-def cpu_baseline(n_cpu, threads):
-    """The CPU oracle (a port of the reference algorithm, oracle/oracle.c) on a bounded sample of the same workload:
-    one assemble + solve of the n_cpu^3 channel with the same inner-solver settings, on the host cores."""
-    import numpy as np
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def _cpu_step(n_cpu, threads):
+    """One assemble + solve of the n_cpu^3 channel on the CPU oracle; returns (n_dofs, assemble s, solve s, FGMRES its)."""
     import orc
     from boxmesh import BoxMesh
     from cases import channel3d_state
@@ -85,9 +94,33 @@ def cpu_baseline(n_cpu, threads):
     t1 = time.time()
     rc, upd, it, res = S.solve(P, False)
     t2 = time.time()
-    return {"value": m.n_dofs / (t2 - t0), "unit": "DoF/s", "cores": threads, "kind": "port",
-            "sample": f"1 Newton step (assemble {t1 - t0:.2f}s + solve {t2 - t1:.2f}s, FGMRES its {it}) of the "
-                      f"{n_cpu}^3 Q2/Q1 channel ({m.n_dofs} DoF), oracle/oracle.c with OpenMP"}
+    return m.n_dofs, t1 - t0, t2 - t1, it
+
+
+def cpu_baseline(sizes, sweep_n=12):
+    """The CPU oracle (a port of the reference algorithm, oracle/oracle.c: dense per-cell Ke, CSR scatter, FGMRES with the
+    block Schur preconditioner, same inner-solver settings as the GPU run) on a bounded sample of the same workload:
+    one Newton step of the n^3 channel for every n in `sizes` (BASELINE.md section 3 plans n = 32 and 64; the default run
+    does n = 32 to stay within a few minutes, `--cpu-cells 32,64` does both), on the host cores.  The thread count is
+    picked by a short sweep on a sweep_n^3 mesh (the oracle's OpenMP loops stop scaling long before 256 threads)."""
+    ncpu = os.cpu_count() or 1
+    cand = sorted({max(1, ncpu // d) for d in (1, 2, 4, 8, 16)})
+    sweep = {}
+    for t in cand:
+        nd, ta, ts, _ = _cpu_step(sweep_n, t)
+        sweep[t] = ta + ts
+    best = min(sweep, key=sweep.get)
+    runs = []
+    for n in sizes:
+        nd, ta, ts, it = _cpu_step(n, best)
+        runs.append({"n": n, "n_dofs": nd, "assemble_s": ta, "solve_s": ts, "fgmres_iters": it, "dofs_per_s": nd / (ta + ts),
+                     "assemble_dofs_per_s": nd / ta, "solve_dofs_per_s": nd / ts})
+    big = runs[-1]
+    return {"value": big["dofs_per_s"], "unit": "DoF/s", "cores": best, "kind": "port", "cpu_model": _cpu_model(),
+            "host_threads_available": ncpu, "thread_sweep_s": {str(k): v for k, v in sweep.items()}, "runs": runs,
+            "sample": f"1 Newton step (assemble {big['assemble_s']:.2f}s + solve {big['solve_s']:.2f}s, FGMRES its "
+                      f"{big['fgmres_iters']}) of the {big['n']}^3 Q2/Q1 channel ({big['n_dofs']} DoF), oracle/oracle.c with "
+                      f"OpenMP on {best} threads of {_cpu_model()}"}
 
 
 def bench_insimex(args, host):
@@ -118,13 +151,67 @@ def bench_insimex(args, host):
                                  "ainv_kind": args.ainv, "inner_rel": args.inner_rel}}), flush=True)
 
 
+def extras(solver, capi, n_dofs, warm_ms):
+    """N = 1 side measurements next to the warm `value`:
+    cold_step -- one Newton iteration with nothing kept from the previous one: B, B^T, M_p, diag(M_u) re-integrated and
+      S_m = B diag(M_u)^-1 B^T re-formed, which is what the reference does in EVERY iteration (assemble() zeroes all blocks,
+      mpi_insim.cpp:163-165; solve() rebuilds the preconditioner, :369 and :44-49).  Here it is the cost of the first
+      iteration after the set of constrained dofs changed (every FSI step), ifem_tuning::geo_cache = 0.
+    time_step -- a whole InsIM::run_one_step(apply_nonzero_constraints = true) Newton loop (mpi_insim.cpp:416-473,
+      tolerance 1e-6, first iteration with nonzero_constraints, the others with zero_constraints) from the bench state.
+      Both AffineConstraints objects of make_constraints list the same dofs, so the cached blocks survive the switch."""
+    import numpy as np
+    from cases import CHANNEL_KW
+    out = {}
+    L, ctx = solver.L, solver.ctx
+    tun = capi.Tuning()
+    L.ifem_default_tuning(C.byref(tun))
+    tun.geo_cache = 0
+    assert L.ifem_set_tuning(ctx, C.byref(tun)) == 0
+    solver.assemble(False)
+    solver.solve(False)  # state: previous iteration done, nothing cached
+    solver.synchronize()
+    t0 = time.time()
+    solver.assemble(False)
+    t1 = time.time()
+    st = solver.solve(False)
+    solver.synchronize()
+    t2 = time.time()
+    out["cold_step"] = {"ms_per_step": (t2 - t0) * 1e3, "value": n_dofs / (t2 - t0), "unit": "DoF/s",
+                        "assemble_ms": (t1 - t0) * 1e3, "solve_ms": (t2 - t1) * 1e3, "fgmres_iters": st.fgmres_iters,
+                        "vs_warm": (t2 - t0) * 1e3 / warm_ms,
+                        "note": "geometry blocks re-integrated and S_m re-formed inside the step, as the reference does every "
+                                "Newton iteration; `value` above keeps them (same constrained-dof set)"}
+    tun.geo_cache = 1
+    assert L.ifem_set_tuning(ctx, C.byref(tun)) == 0
+    solver.channel_state()
+    # present := perturbed state, so that the Newton loop has something to converge from
+    assert L.ifem_vec_copy(ctx, capi.VEC_PRESENT, capi.VEC_EVAL) == 0
+    log = np.zeros((16, 4))
+    P = capi.make_params(**CHANNEL_KW)  # the parameters of host.channel_prm
+    solver.synchronize()
+    t0 = time.time()
+    its = L.ifem_ins_newton_step(ctx, C.byref(P), C.byref(solver.opts), 1, 1e-6, 8, log.ctypes.data_as(C.c_void_p))
+    solver.synchronize()
+    dt = time.time() - t0
+    if its > 0:
+        out["time_step"] = {"ms": dt * 1e3, "newton_iterations": int(its), "ms_per_newton_iteration": dt * 1e3 / its,
+                            "dofs_per_s_per_iteration": n_dofs * its / dt, "rel_residuals": [float(v) for v in log[:its, 1]],
+                            "fgmres_iters": [int(v) for v in log[:its, 2]],
+                            "note": "InsIM::run_one_step(true): Newton loop to 1e-6 from the bench state"}
+    else:
+        out["time_step"] = {"error": L.ifem_last_error().decode()}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", dest="n", type=int, default=128, help="cells per direction per GPU")
-    ap.add_argument("--cpu-cells", dest="cpu_n", type=int, default=24, help="cells per direction of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-cells", dest="cpu_n", default="32", help="cells per direction of the CPU baseline sample(s), comma separated (0 = skip; BASELINE.md plans 32,64 -- 64 takes several minutes)")
+    ap.add_argument("--extras", type=int, default=1, help="N = 1 only: also measure cold_step (geometry blocks and S_m rebuilt, as the reference does every iteration) and time_step (a whole run_one_step Newton loop)")
     ap.add_argument("--inner-rel", type=float, default=1e-2)
     ap.add_argument("--ainv", type=int, default=3, help="IFEM_AINV_* kind of the A_uu^-1 replacement (3 = matrix-free inner operator, 1 = fp32 inner matrix, 0 = fp64 matrix)")
     ap.add_argument("--sm-rel", type=float, default=None, help="experiment: relative tolerance of CG(S_m) inside the preconditioner (reference and default: 1e-3)")
@@ -177,7 +264,6 @@ def main():
     solver.opts.outer_matrix_free = args.outer_mf
     solver.opts.verbose = args.verbose if rank == 0 else 0
     solver.channel_state()
-    solver.set_profiling(True)
 
     def step():
         solver.assemble(False)
@@ -194,11 +280,10 @@ def main():
             dist.barrier()
         solver.synchronize()
 
+    # ---- the timed region: K steps, no per-kernel profiling (its event synchronisations would drain the queue)
     fence()
     t0 = time.time()
-    t_asm = t_solve = 0.0
-    spmv_ms, spmv_calls = 0.0, 0
-    mf_ms, mf_calls = 0.0, 0
+    t_asm = t_solve = asm_kernel_ms = 0.0
     last = None
     for _ in range(args.steps):
         ta = time.time()
@@ -208,27 +293,32 @@ def main():
         tc = time.time()
         t_asm += tb - ta
         t_solve += tc - tb
-        tm = solver.timing()
-        spmv_ms += tm.spmv_uu_ms_avg * tm.spmv_uu_calls
-        spmv_calls += tm.spmv_uu_calls
-        mf_ms += tm.mf_ms_avg * tm.mf_calls
-        mf_calls += tm.mf_calls
-    solver.synchronize()
+        asm_kernel_ms += solver.timing().assemble_kernel_ms  # HIP events around the cell kernel on the context stream
+    fence()
     elapsed = time.time() - t0
     if dist:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-    tm = solver.timing()
+    asm_kernel_ms /= max(args.steps, 1)
     ms_per_step = elapsed / args.steps * 1e3
+    # ---- per-kernel pass (outside the timed region): one more step with HIP events around every matrix-free application
+    # and every A_uu SpMV on the context stream
+    solver.set_profiling(True)
+    step()
+    tm = solver.timing()
+    solver.set_profiling(False)
+    spmv_ms, spmv_calls = tm.spmv_uu_ms_avg * tm.spmv_uu_calls, tm.spmv_uu_calls
+    mf_ms, mf_calls = tm.mf_ms_avg * tm.mf_calls, tm.mf_calls
+    prof_steps = 1
     if rank == 0:
         spmv_avg_ms = spmv_ms / max(spmv_calls, 1)
         mf_avg_ms = mf_ms / max(mf_calls, 1)
         # dominant kernel = largest total time per step among the three heavy kernels, each timed live with HIP events
-        totals = {"asm": tm.assemble_kernel_ms, "mf": mf_ms / args.steps, "spmv": spmv_ms / args.steps}
+        totals = {"asm": asm_kernel_ms, "mf": mf_ms / prof_steps, "spmv": spmv_ms / prof_steps}
         dom = max(totals, key=totals.get)
-        cached = args.warmup >= 1 and os.environ.get("IFEM_GEO_CACHE", "1") != "0"
+        cached = args.warmup >= 1  # the timed steps keep B, B^T, M_p, diag(M_u), S_m of the warm-up (same constrained-dof set)
         models = kernel_models(solver.L, solver.ctx, n_cells, n_u, n_p, cached_blocks=cached)
         if dom == "spmv":
             achieved = tm.spmv_uu_bytes / (spmv_avg_ms * 1e-3) / 1e9
@@ -238,7 +328,7 @@ def main():
                     "launch_ms": spmv_avg_ms, "launches_timed": spmv_calls, "algorithmic_bytes": tm.spmv_uu_bytes}
         else:
             name = {"asm": "k_ins_assemble3 (cell integration on the FP64 matrix cores + scatter)", "mf": "k_apply_uu_mf2<3,2,float> (matrix-free A_uu of the inner solver, fp32 cell arithmetic)"}[dom]
-            ms = tm.assemble_kernel_ms if dom == "asm" else mf_avg_ms
+            ms = asm_kernel_ms if dom == "asm" else mf_avg_ms
             nb, nf = models[dom]
             gbs, tfs = nb / (ms * 1e-3) / 1e9, nf / (ms * 1e-3) / 1e12
             # compute ceiling: FP64 matrix cores for the assembly, FP32 vector FMA for the single-precision matrix-free
@@ -274,7 +364,7 @@ def main():
                                    f"(plane Poiseuille + seeded 1e-3 perturbation), {n}^3 cells per GPU",
                        "n_dofs": n_dofs_global, "cells_per_gpu": n_cells, "parallelism": f"dd{world}",
                        "assemble_ms": t_asm / args.steps * 1e3, "solve_ms": t_solve / args.steps * 1e3,
-                       "assemble_kernel_ms": tm.assemble_kernel_ms, "setup_s": t_setup,
+                       "assemble_kernel_ms": asm_kernel_ms, "setup_s": t_setup,
                        "fgmres_iters": last.fgmres_iters, "cg_mp_iters": last.cg_mp_iters,
                        "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "ainv_kind": args.ainv, "outer_matrix_free": args.outer_mf,
                        "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms,
@@ -297,8 +387,11 @@ def main():
             out["tuned_preconditioner"] = {"ms_per_step": dt_t * 1e3, "value": n_dofs_global / dt_t, "unit": "DoF/s",
                                            "fgmres_iters": st.fgmres_iters, "cg_mp_rel": 1e-2, "cg_sm_rel": 1e-1, "outer_matrix_free": 1,
                                            "note": "side measurement; `value` above uses the reference's tolerances"}
-        if args.cpu_n > 0 and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n, os.cpu_count() or 1)
+        if world == 1 and args.extras:
+            out.update(extras(solver, capi, n_dofs_global, ms_per_step))
+        cpu_sizes = [int(v) for v in str(args.cpu_n).split(",") if int(v) > 0]
+        if cpu_sizes and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
+            out["cpu_baseline"] = cpu_baseline(cpu_sizes)
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

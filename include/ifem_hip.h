@@ -276,6 +276,9 @@ int ifem_scns_newton_step(ifem_ctx *ctx, const ifem_scns_params *p, const ifem_s
 
 /* y = [A Bt; B 0] x on context vectors (system_matrix.vmult) -- test / bench hook */
 int ifem_system_vmult(ifem_ctx *ctx, int dst, int src);
+/* y = [diag(M_u) x_u ; M_p x_p] on context vectors: the two blocks of mass_matrix the reference's preconditioner reads
+ * (mpi_insim.cpp:27-49: diag of block (0,0), block (1,1)) -- test hook */
+int ifem_mass_vmult(ifem_ctx *ctx, int dst, int src);
 /* y_u = A_uu x_u on the velocity part of two context vectors -- test / bench hook.  variant: IFEM_AINV_GMRES_BJACOBI
  * (stored fp64 matrix), _F32 (its single-precision copy) or _MF (matrix-free) */
 int ifem_uu_vmult(ifem_ctx *ctx, int dst, int src, int variant);

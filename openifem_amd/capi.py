@@ -97,7 +97,8 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_rhs_norm", "ifem_ins_newton_step", "ifem_system_vmult", "ifem_uu_vmult", "ifem_precond_vmult", "ifem_export_csr",
            "ifem_get_timing", "ifem_set_profiling", "ifem_synchronize", "ifem_set_hanging_constraints", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
            "ifem_scns_assemble", "ifem_scns_solve", "ifem_scns_newton_step", "ifem_imex_assemble", "ifem_imex_solve",
-           "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof"]
+           "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof",
+           "ifem_mass_vmult"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -144,6 +145,7 @@ def load():
                                        C.c_int, C.c_void_p]
     L.ifem_system_vmult.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.ifem_uu_vmult.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.ifem_mass_vmult.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.ifem_precond_vmult.argtypes = [C.c_void_p, C.POINTER(InsParams), C.POINTER(SolverOpts), C.c_int, C.c_int]
     L.ifem_export_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifem_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
@@ -357,6 +359,12 @@ class Context:
         """y_u = A_uu x_u; variant 0 stored fp64, 1 fp32 copy, 3 matrix-free"""
         self.vec_set(VEC_TMP, x)
         self._chk(self.L.ifem_uu_vmult(self.h, VEC_UPDATE, VEC_TMP, variant))
+        return self.vec_get(VEC_UPDATE)
+
+    def mass_vmult(self, x):
+        """[diag(M_u) x_u ; M_p x_p]"""
+        self.vec_set(VEC_TMP, x)
+        self._chk(self.L.ifem_mass_vmult(self.h, VEC_UPDATE, VEC_TMP))
         return self.vec_get(VEC_UPDATE)
 
     def precond_vmult(self, params, x):

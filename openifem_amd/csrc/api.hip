@@ -169,7 +169,13 @@ int ifem_set_constraints(ifem_ctx *ctx, int which, int32_t n, const int32_t *dof
   ctx->cval[which].upload(v.data(), v.size(), ctx->stream);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   ctx->has_c[which] = n > 0;
-  ctx->constraints_epoch++;
+  { // identity of the constrained-dof set (ctx.hpp): decided over ALL ranks, since a stale cache triggers collective work
+    const int other = 1 - which;
+    double differs[2] = {ctx->h_flags[which] != f ? 1.0 : 0.0, ctx->h_flags[other] != f ? 1.0 : 0.0};
+    allreduce_max(ctx, differs, 2);
+    if (differs[0] != 0.0) ctx->flag_id[which] = differs[1] == 0.0 ? ctx->flag_id[other] : ++ctx->flag_counter;
+    ctx->h_flags[which] = std::move(f);
+  }
   IFEM_API_END
 }
 
@@ -456,6 +462,21 @@ int ifem_system_vmult(ifem_ctx *ctx, int dst, int src) {
   IFEM_API_BEGIN
   if (!vec_ok(dst) || !vec_ok(src) || is_ext(dst) || is_ext(src)) throw Error(IFEM_E_BADPARAM, "use non-ghosted vectors");
   ins_system_vmult(ctx, ctx->vec[src].p, ctx->vec[dst].p);
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+
+int ifem_mass_vmult(ifem_ctx *ctx, int dst, int src) {
+  IFEM_API_BEGIN
+  if (!vec_ok(dst) || !vec_ok(src) || is_ext(dst) || is_ext(src) || dst == src) throw Error(IFEM_E_BADPARAM, "use two non-ghosted vectors");
+  if (!ctx->assembled) throw Error(IFEM_E_BADPARAM, "ifem_mass_vmult called before an assembly");
+  const int64_t nuo = int64_t(ctx->dim) * ctx->nUo;
+  vec_mul(ctx, nuo, ctx->diagMu.p, ctx->vec[src].p, ctx->vec[dst].p);
+  if ((int64_t)ctx->work.n < ctx->nPl) ctx->work.alloc(ctx->nPl);
+  double *xe = ctx->work.p; // ghost-extended copy of the pressure part
+  v_copy(ctx, ctx->nPo, ctx->vec[src].p + nuo, xe);
+  if (ctx->halo.nranks > 1) halo_exchange_p(ctx, xe);
+  spmv_mp(ctx, xe, ctx->vec[dst].p + nuo);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   IFEM_API_END
 }

@@ -37,10 +37,11 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
     ctx->mf_valid = true;
     ctx->mf_noconv = imex != 0;
   }
-  // B, B^T, M_p and diag(M_u) depend on the mesh and on WHICH dofs are constrained, not on the solution or the
-  // parameters: an assembly with the constraint set of the previous one keeps them (bit-identical to re-integrating
+  // B, B^T, M_p and diag(M_u) depend on the mesh and on WHICH dofs are constrained, not on the solution, the parameters
+  // or the inhomogeneities: an assembly whose constrained-dof set equals that of the previous one (zero_ and
+  // nonzero_constraints of make_constraints list the same dofs) keeps them (bit-identical to re-integrating
   // them) and integrates A_uu and the right-hand side only.  ifem_tuning::geo_cache = 0 switches it off.
-  const int64_t geo_key = ctx->constraints_epoch * 2 + (use_nonzero ? 1 : 0);
+  const int64_t geo_key = ctx->flag_id[use_nonzero ? 1 : 0];
   const bool skip_geo = ctx->tune.geo_cache && assemble_system && ctx->geo_valid && ctx->geo_key == geo_key;
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
   if (assemble_system) {
@@ -110,8 +111,8 @@ static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero) {
   // S_m = B diag(M_u)^-1 B^T depends only on the mesh and on WHICH dofs are constrained (not on the solution):
   // keep it across assemblies until the constraint set changes (the reference rebuilds it every solve(); same values)
   {
-    const int64_t key = ctx->constraints_epoch * 2 + (use_nonzero ? 1 : 0);
-    if (key != ctx->sm_key) { ctx->sm_valid = false; ctx->sm_key = key; }
+    const int64_t key = ctx->flag_id[use_nonzero ? 1 : 0];
+    if (key != ctx->sm_key || !ctx->tune.geo_cache) { ctx->sm_valid = false; ctx->sm_key = key; }
   }
   ctx->shat_valid = ctx->want_shat;
   ctx->shat_aux_valid = false;

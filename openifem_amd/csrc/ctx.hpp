@@ -180,7 +180,12 @@ struct ifem_ctx {
   ifem::DBuf<double> xs_ext; // [halo.n_s_cols] input of the distributed S_m SpMV: owned entries + 2-deep far nodes
   ifem::DBuf<float> Sm_f32; // single-precision copy of the S_m values for its SpMV (approximate-preconditioner kinds)
   bool sm_f32_valid = false;
-  int64_t sm_key = -1, constraints_epoch = 0;
+  int64_t sm_key = -1;
+  // identity of the constrained-dof SET of each AffineConstraints object (which dofs, not their values): B, B^T, M_p,
+  // diag(M_u) and S_m depend on nothing else, so zero_ / nonzero_constraints with the same lines share one cache entry and
+  // re-making identical constraints (time-dependent boundary values) keeps it
+  std::vector<uint8_t> h_flags[2];
+  int64_t flag_id[2] = {0, 0}, flag_counter = 0;
   // scalar velocity operator S^ = mu K + rho C(u) + rho/dt M on the A_uu block pattern (IFEM_AINV_SCALAR_*)
   ifem::DBuf<double> Shat, shat_dinv;
   ifem::DBuf<float> Shat_f32;
