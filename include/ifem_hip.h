@@ -191,7 +191,11 @@ int ifem_set_constraints(ifem_ctx *ctx, int which, int32_t n, const int32_t *dof
  * (no master is itself a hanging dof); masters may be Dirichlet-constrained (their inhomogeneity is inherited, as
  * AffineConstraints::close() does).  A hanging dof must not also be listed in ifem_set_constraints
  * (interpolate_boundary_values skips constrained dofs).  Assemble, solve and the *_step calls then work on the condensed
- * system; the returned update has its hanging entries interpolated.  n = 0 removes the lines.  Single-rank contexts. */
+ * system; the returned update has its hanging entries interpolated.  n = 0 removes the lines.
+ * Partitioned contexts (collective call; a rank without hanging nodes passes n = 0): list the lines of every LOCAL hanging
+ * dof, owned or ghost, with local master ids -- the ghost layer of the rank must therefore hold the masters of its ghost
+ * hanging nodes (p4est's ghost layer plus DoFTools::extract_locally_relevant_dofs does the same for the reference,
+ * mpi_fluid_solver.cpp:140-152,182-184). */
 int ifem_set_hanging_constraints(ifem_ctx *ctx, int32_t n, const int32_t *dof, const int32_t *ptr, const int32_t *master,
                                  const double *weight);
 /* cell_property[*].indicator written by MPI::FSI::update_indicator (mpi_fsi.cpp:291-321); NULL = all 0 */

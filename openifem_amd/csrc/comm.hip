@@ -154,6 +154,73 @@ static void exchange(ifem_ctx *ctx, double *x, int which) {
   IFEM_NCCL_CHECK(ncclGroupEnd());
 }
 
+__global__ void k_unpack_add(int64_t n, int bs, const int32_t *__restrict__ idx, const double *__restrict__ buf,
+                             double *__restrict__ x) {
+  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < n * bs; t += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t i = t / bs;
+    const int c = int(t - i * bs);
+    unsafeAtomicAdd(&x[int64_t(idx[i]) * bs + c], buf[t]); // a node may be a ghost of several neighbours
+  }
+}
+
+// Transpose of the halo exchange: the ghost entries of x_ext travel back to their owners and are ADDED to the owned
+// entries (PETSc VecScatter in reverse / ADD_VALUES mode; deal.II compress(VectorOperation::add)).  Used by C^T of the
+// hanging-node lines whose masters live on another rank.  which: 0 velocity nodes (bs = dim), 1 pressure nodes.
+static void reverse_add(ifem_ctx *ctx, double *x, int which) {
+  Halo &h = ctx->halo;
+  const int bs = which == 0 ? ctx->dim : 1;
+  const int64_t n_owned = which == 0 ? ctx->nUo : ctx->nPo;
+  const std::vector<int32_t> &sptr = which == 0 ? h.send_u_ptr : h.send_p_ptr;
+  const std::vector<int32_t> &rptr = which == 0 ? h.recv_u_ptr : h.recv_p_ptr;
+  const DBuf<int32_t> &sidx = which == 0 ? h.send_u_idx : h.send_p_idx;
+  double *buf = h.sendbuf.p + (which == 0 ? 0 : (size_t)ctx->dim * h.send_u_ptr.back()); // the forward send region, now receiving
+  const int nn = (int)h.nbr.size();
+  const int64_t ns = sptr[nn];
+  if (h.local) {
+    auto *w = static_cast<LocalWorld *>(h.local);
+    h.rev_src = x;
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // my ghost entries are complete
+    w->barrier();
+    for (int k = 0; k < nn; ++k) {
+      const int64_t sc = int64_t(sptr[k + 1] - sptr[k]) * bs;
+      if (!sc) continue;
+      ifem_ctx *peer = w->ctx[h.nbr[k]];
+      const Halo &ph = peer->halo;
+      int me = -1;
+      for (size_t j = 0; j < ph.nbr.size(); ++j) if (ph.nbr[j] == h.rank) me = (int)j;
+      if (me < 0) throw Error(IFEM_E_COMM, "local world: neighbour lists are not symmetric");
+      const std::vector<int32_t> &prptr = which == 0 ? ph.recv_u_ptr : ph.recv_p_ptr;
+      const int64_t pn_owned = which == 0 ? peer->nUo : peer->nPo;
+      if (int64_t(prptr[me + 1] - prptr[me]) * bs != sc) throw Error(IFEM_E_COMM, "local world: send/recv count mismatch");
+      IFEM_HIP_CHECK(hipMemcpyAsync(buf + int64_t(sptr[k]) * bs, ph.rev_src + (pn_owned + prptr[me]) * bs, sc * sizeof(double),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    w->barrier(); // peers may now reuse their ghost entries
+  } else {
+    IFEM_NCCL_CHECK(ncclGroupStart());
+    for (int k = 0; k < nn; ++k) {
+      const int64_t sc = int64_t(sptr[k + 1] - sptr[k]) * bs, rc = int64_t(rptr[k + 1] - rptr[k]) * bs;
+      if (rc) IFEM_NCCL_CHECK(ncclSend(x + (n_owned + rptr[k]) * bs, rc, ncclDouble, h.nbr[k], (ncclComm_t)h.comm, ctx->stream));
+      if (sc) IFEM_NCCL_CHECK(ncclRecv(buf + int64_t(sptr[k]) * bs, sc, ncclDouble, h.nbr[k], (ncclComm_t)h.comm, ctx->stream));
+    }
+    IFEM_NCCL_CHECK(ncclGroupEnd());
+  }
+  if (ns) {
+    int64_t g = (ns * bs + 255) / 256;
+    hipLaunchKernelGGL(k_unpack_add, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, ctx->stream, ns, bs, sidx.p, buf, x);
+  }
+}
+
+void halo_reverse_add(ifem_ctx *ctx, double *xu_ext) {
+  if (ctx->halo.nranks == 1) return;
+  reverse_add(ctx, xu_ext, 0);
+}
+void halo_reverse_add_p(ifem_ctx *ctx, double *xp_ext) {
+  if (ctx->halo.nranks == 1) return;
+  reverse_add(ctx, xp_ext, 1);
+}
+
 void halo_exchange(ifem_ctx *ctx, double *xu_ext) {
   if (ctx->halo.nranks == 1) return;
   exchange(ctx, xu_ext, 0);

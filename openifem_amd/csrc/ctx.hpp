@@ -135,6 +135,7 @@ struct Halo {
   DBuf<double> sendbuf;
   void *comm = nullptr;  // ncclComm_t
   void *local = nullptr; // LocalWorld* (in-process virtual ranks, validation transport)
+  const double *rev_src = nullptr; // local world only: the extended vector whose ghosts the peers fetch in a reverse exchange
 };
 
 } // namespace ifem
@@ -143,10 +144,11 @@ namespace ifem {
 // hanging-node constraint lines x[dof_i] = sum_k w_k x[master_k] (closed), see hanging.hip
 struct Hanging {
   int32_t n = 0;
-  DBuf<int32_t> dof, ptr, master;
-  DBuf<double> w, d, x, c0; // weights, diagonal of the hanging rows, scratch input vector, inhomogeneity vector
+  DBuf<int32_t> dof, ptr, master; // local (ghost-extended) dof ids; lines of owned AND ghost hanging dofs
+  DBuf<double> w, d, x, c0, y; // weights, diagonal of the hanging rows, extended scratch input / inhomogeneity / output
   DBuf<int> flag;
   std::vector<int32_t> host_dof;
+  bool active = false; // some rank holds hanging lines: every rank takes part in their exchanges
 };
 } // namespace ifem
 

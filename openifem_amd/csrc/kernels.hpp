@@ -91,8 +91,8 @@ void tpp_dense_solve(ifem_ctx *ctx, const double *x, double *y);
 void tpp_release(ifem_ctx *ctx);
 // hanging-node lines (hanging.hip): C x on a copy of x, C^T and the hanging rows on y, distribute, set-up
 void hanging_set(ifem_ctx *ctx, int32_t n, const int32_t *dof, const int32_t *ptr, const int32_t *master, const double *weight);
-const double *hanging_input(ifem_ctx *ctx, const double *x);
-void hanging_output(ifem_ctx *ctx, const double *x, double *y);
+const double *hanging_input(ifem_ctx *ctx, const double *x); // ghost-extended [u_l | p_l] copy of x with C applied
+void hanging_output(ifem_ctx *ctx, const double *x, bool x_extended, double *y);
 void hanging_distribute(ifem_ctx *ctx, double *x);
 void hanging_refresh_diag(ifem_ctx *ctx);
 bool hanging_offset(ifem_ctx *ctx, int use_nonzero);
@@ -108,6 +108,9 @@ void local_world_destroy(void *w);
 // ghost refresh of a ghost-extended velocity buffer [dim*nUl] / pressure buffer [nPl] (RCCL send/recv over xGMI)
 void halo_exchange(ifem_ctx *ctx, double *xu_ext);
 void halo_exchange_p(ifem_ctx *ctx, double *xp_ext);
+// transpose: ghost entries are sent back to their owners and added there (C^T of hanging lines across ranks)
+void halo_reverse_add(ifem_ctx *ctx, double *xu_ext);
+void halo_reverse_add_p(ifem_ctx *ctx, double *xp_ext);
 void halo_exchange_s(ifem_ctx *ctx, double *xs_ext); // [n_s_cols]: owned pressure nodes, then the 2-deep far nodes
 void build_schur_pattern_box(ifem_ctx *ctx);          // distributed explicit S_m on a structured pressure lattice
 void schur_probe_fill(ifem_ctx *ctx, int color, const double *y); // S_m[i, j(color)] = y_i

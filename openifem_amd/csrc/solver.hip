@@ -279,22 +279,28 @@ static void extend_p(SolveState &S, const double *xp, const double **out) {
   *out = S.xp_ext;
 }
 
-// the assembled operator A^ = [A_uu B^T; B A_pp] on compact owned vectors
-static void system_apply_raw(SolveState &S, const double *x, double *y, bool time_it);
+// the assembled operator A^ = [A_uu B^T; B A_pp]: ghost-extended input (xu [dim*nUl], xp [nPl]), compact owned output
+static void system_apply_ext(SolveState &S, const double *xu, const double *xp, double *y, bool time_it);
+
+// the same on a compact owned vector (ghosts refreshed here)
+static void system_apply_raw(SolveState &S, const double *x, double *y, bool time_it) {
+  const double *xu, *xp;
+  extend_u(S, x, &xu);
+  extend_p(S, x + S.nuo, &xp);
+  system_apply_ext(S, xu, xp, y, time_it);
+}
 
 // operator of the outer Krylov solver: A^, or C^T A^ C with the hanging rows replaced by their diagonal (hanging.hip)
 static void system_apply(SolveState &S, const double *x, double *y, bool time_it) {
   ifem_ctx *c = S.ctx;
-  if (!c->hang.n) { system_apply_raw(S, x, y, time_it); return; }
-  system_apply_raw(S, hanging_input(c, x), y, time_it);
-  hanging_output(c, x, y);
+  if (!c->hang.active) { system_apply_raw(S, x, y, time_it); return; }
+  const double *xe = hanging_input(c, x); // ghost-extended, hanging entries interpolated
+  system_apply_ext(S, xe, xe + int64_t(c->dim) * c->nUl, y, time_it);
+  hanging_output(c, x, false, y);
 }
 
-static void system_apply_raw(SolveState &S, const double *x, double *y, bool time_it) {
+static void system_apply_ext(SolveState &S, const double *xu, const double *xp, double *y, bool time_it) {
   ifem_ctx *c = S.ctx;
-  const double *xu, *xp;
-  extend_u(S, x, &xu);
-  extend_p(S, x + S.nuo, &xp);
   if (S.o->outer_matrix_free && c->mf_valid && !c->has_app) { // experiment: A_uu x_u without the stored matrix
     apply_uu_mf(c, xu, y);
     spmv_bt(c, xp, S.tu);
@@ -477,20 +483,19 @@ void ins_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solve
 // right-hand side of the condensed system after an assembly that treated the hanging dofs as ordinary ones:
 // b = C^T (b^ - A^ c0) on the regular rows, d_h c0_h on the hanging rows (distribute_local_to_global semantics)
 void hanging_condense_rhs(ifem_ctx *ctx, int use_nonzero) {
-  if (!ctx->hang.n) return;
+  if (!ctx->hang.active) return;
   ifem_solver_opts o;
   ifem_default_solver_opts(&o);
   SolveState S{ctx, nullptr, &o};
   carve_workspace(S);
   hanging_refresh_diag(ctx);
   double *rhs = ctx->vec[IFEM_VEC_RHS].p;
-  const bool inhom = hanging_offset(ctx, use_nonzero);
+  const bool inhom = hanging_offset(ctx, use_nonzero); // c0: ghost-extended, zero away from the hanging entries
   if (inhom) {
-    system_apply_raw(S, ctx->hang.c0.p, S.outer_w, false);
+    system_apply_ext(S, ctx->hang.c0.p, ctx->hang.c0.p + int64_t(ctx->dim) * ctx->nUl, S.outer_w, false);
     v_axpy(ctx, S.n, -1.0, S.outer_w, rhs);
-  } else
-    v_zero(ctx, S.n, ctx->hang.c0.p);
-  hanging_output(ctx, ctx->hang.c0.p, rhs);
+  }
+  hanging_output(ctx, ctx->hang.c0.p, true, rhs);
 }
 
 void ins_system_vmult(ifem_ctx *ctx, const double *src, double *dst) {

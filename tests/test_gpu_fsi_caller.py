@@ -1,0 +1,244 @@
+"""The FSI caller's contract with the fluid step (BASELINE config 5, tests/fsi_leaflet_mpi: SCnsIM<2> Q1/Q1 on a locally
+refined, distributed mesh driven by MPI::FSI), exercised through the C ABI.
+
+MPI::FSI::run (source/mpi_fsi.cpp:1186-1212) does, EVERY time step, on the fluid side:
+  update_indicator()                (:291-321)   cell indicator = all vertices inside the solid
+  fluid_solver.make_constraints()   (:1192)      boundary lines re-made; after the first step nonzero_ := copy of zero_ (:1193-1198)
+  find_fluid_bc()                   (:323-663)   nodal fsi_stress[k] = fluid stress - solid stress at the nodes inside the solid
+                                                 of indicator cells (:469-471, persistent elsewhere); use_dirichlet_bc = false:
+                                                 fsi_acceleration = (v_s - v)/dt + ... - a_s at those velocity dofs (:548-556);
+                                                 use_dirichlet_bc = true (fsi_leaflet_mpi.cpp:91): Dirichlet lines
+                                                 v_s - present on the velocity dofs inside the solid, merged with
+                                                 left_object_wins into both AffineConstraints (:615-650)
+  fluid_solver.run_one_step(true)   (:1208)      Newton loop with apply_nonzero_constraints = true, then update_stress
+The solid solver, the point location and the interpolation are the FSI side (outside the path): a rigid disc
+with prescribed motion and an analytic stress field stands in for them here; both sides of the comparison receive the
+same numbers.  What is under test is the fluid side of that loop: per-step changes of the constrained-dof set, of the
+indicator, of fsi_acceleration and of the nodal fsi_stress TOGETHER, on a hanging-node mesh, on one context and on four
+virtual ranks, against the oracle running the same loop (oracle assembly of SCnsIM::assemble + the condensation that
+tests/test_oracle_hanging.py shows to be distribute_local_to_global + an exact sparse solve).
+"""
+import threading
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+import orc
+from hangmesh import HangingMesh
+from partmesh import local_dirichlet, partition_mesh, run_virtual_ranks
+
+pytestmark = pytest.mark.gpu
+
+L_, H_, HC = 4.0, 1.0, 0.125  # channel, coarse cell size
+A_ = 0.25                    # "leaflet" scale of fsi_leaflet_mpi.cpp:66-76: cells with centre in [L/4 - 2a, L/4 + 3a] are refined
+KW = dict(mu=0.1, rho=1.0, dt=0.01, solid_rho=2.5, g=(0.0, 0.0), neumann={})
+R_DISC, C0, AS = 0.3, np.array([0.72, 0.52]), np.array([0.3, -0.2])
+V_PATH = np.array([9.0, 1.0])   # the disc crosses 1.5 fine cells per step (its path is prescribed, not integrated from V_S)
+V_S = np.array([1.2, 0.15])     # rigid-body velocity handed to the fluid
+OMEGA = 0.8
+NEWTON_TOL, NEWTON_MAXIT = 1e-8, 10
+
+
+def _mesh():
+    reps = (int(L_ / HC), int(H_ / HC))
+    refine = {(i, j) for i in range(reps[0]) for j in range(reps[1])
+              if L_ / 4 - 2 * A_ <= (i + 0.5) * HC <= L_ / 4 + 3 * A_}
+    m = HangingMesh(reps, (0, 0), (L_, H_), refine, kv=1)
+    assert len(m.hang_dof) > 0
+    return m
+
+
+def _solid(step):
+    """rigid disc: centre, velocity / acceleration / stress fields at points x [n, 2]"""
+    t = step * KW["dt"]
+    c = C0 + V_PATH * t
+    def vel(x):
+        r = x - c
+        return V_S + OMEGA * np.stack([-r[:, 1], r[:, 0]], axis=1)
+    def acc(x):
+        return np.broadcast_to(AS, x.shape) - OMEGA ** 2 * (x - c)
+    def stress(x):  # symmetric, components ordered (0,0), (1,0), (1,1) as the loops of mpi_fsi.cpp:459-474
+        return np.stack([0.4 + 0.3 * x[:, 0], 0.05 * x[:, 1] - 0.1 * x[:, 0], -0.2 + 0.1 * x[:, 1] * x[:, 0]], axis=0)
+    inside = lambda x: ((x - c) ** 2).sum(axis=1) <= R_DISC ** 2  # noqa: E731
+    return inside, vel, acc, stress
+
+
+def fsi_inputs(m, step, present, stress, fsi_stress, boundary, use_dirichlet_bc):
+    """what MPI::FSI hands to the fluid solver before run_one_step(true) of time step `step` (0-based): indicator per cell,
+    fsi_acceleration (global block vector), fsi_stress (updated IN PLACE where the reference assigns it), and the two
+    constraint sets (dofs, nonzero values)."""
+    dim, n_u = 2, m.n_u
+    inside, vel, acc, sstress = _solid(step)
+    v_in = inside(m.vcoords.reshape(-1, dim)).reshape(m.n_cells, -1)
+    indicator = v_in.all(axis=1).astype(np.int32)
+    assert indicator.sum() > 0, "the solid covers no fluid cell: the test exercises nothing"
+    node_in = inside(m.unode_coords)
+    in_ind_cell = np.zeros(m.n_unodes, bool)
+    in_ind_cell[np.unique(m.cell_unodes[indicator == 1])] = True
+    # nodal fsi_stress (scalar Q_k space = the velocity nodes): fluid stress - solid stress (:469-471)
+    sel = in_ind_cell & node_in
+    fl = np.stack([stress[0, 0], stress[1, 0], stress[1, 1]], axis=0)
+    fsi_stress[:, sel] = fl[:, sel] - sstress(m.unode_coords)[:, sel]
+    fsi_acc = np.zeros(m.n_dofs)
+    bdofs, bvals = boundary
+    taken = set(int(d) for d in bdofs) | set(int(d) for d in m.hang_dof)
+    dofs, vals = list(bdofs), list(bvals if step == 0 else np.zeros(len(bvals)))  # nonzero_ := zero_ after the first step
+    v = present[:n_u].reshape(-1, dim)
+    if not use_dirichlet_bc:  # (:489-556) only dofs of indicator cells; the convective part grad_v v needs FE gradients at
+        nodes = np.nonzero(sel)[0]  # the support points (FSI-side code): the test feeds (v_s - v)/dt - a_s
+        a = (vel(m.unode_coords[nodes]) - v[nodes]) / KW["dt"] - acc(m.unode_coords[nodes])
+        for c in range(dim):
+            fsi_acc[dim * nodes + c] = a[:, c]
+    else:  # (:569-650) every non-artificial cell; Q1: every support point is a vertex, none is skipped as in-cell
+        nodes = np.nonzero(node_in)[0]
+        vs = vel(m.unode_coords[nodes])
+        for k, nd in enumerate(nodes):
+            for c in range(dim):
+                dof = dim * int(nd) + c
+                if dof in taken:  # left_object_wins: boundary and hanging lines stay
+                    continue
+                dofs.append(dof)
+                vals.append(vs[k, c] - present[dof])
+    return indicator, fsi_acc, np.array(dofs, np.int32), np.array(vals, float)
+
+
+def _boundary(m):
+    inflow = lambda p, c: 6.0 * p[1] * (H_ - p[1]) / H_ ** 2 if c == 0 else 0.0  # noqa: E731
+    return m.dirichlet({0: (3, [0, 0]), 2: (3, [0, 0]), 3: (3, [0, 0])}, {0: inflow})
+
+
+def oracle_loop(m, n_steps, use_dirichlet_bc):
+    """the same loop on the CPU oracle; returns [(present, newton iterations)] per step"""
+    n = m.n_dofs
+    Cm = sp.csr_matrix(m.prolongation())
+    hang = m.hang_dof
+    reg = np.setdiff1d(np.arange(n), hang)
+    m.indicator = np.zeros(m.n_cells, np.int32)
+    S = orc.System(m)  # borrows m.indicator: updated in place below
+    ind_buf = S._keep[4]
+    present = np.zeros(n)
+    stress = np.zeros((2, 2, m.n_unodes))
+    fsi_stress = np.zeros((3, m.n_unodes))
+    boundary = _boundary(m)
+    out = []
+    for step in range(n_steps):
+        indicator, fsi_acc, dofs, vals = fsi_inputs(m, step, present, stress, fsi_stress, boundary, use_dirichlet_bc)
+        ind_buf[:] = indicator
+        S.set_constraints(0, dofs, None)
+        S.set_constraints(1, dofs, vals)
+        isc = np.zeros(n, bool)
+        isc[dofs] = True
+        cv = np.zeros(n)
+        cv[dofs] = vals
+        # C with the Dirichlet masters closed away, and their inhomogeneity c0 (AffineConstraints::close)
+        Cc = Cm.tolil(copy=True)
+        c0 = np.zeros(n)
+        for d in hang:
+            row = Cm.getrow(d)
+            for k, w in zip(row.indices, row.data):
+                if isc[k]:
+                    c0[d] += w * cv[k]
+                    Cc[d, k] = 0.0
+        Cc = Cc.tocsr()
+        evalp = present.copy()
+        cur = init = rel = 1.0
+        it = 0
+        while rel > NEWTON_TOL and cur > 1e-14:
+            assert it < NEWTON_MAXIT, "oracle Newton loop does not converge"
+            nz = it == 0
+            P = orc.make_scns_params(stress=stress, fsi_stress=fsi_stress, **KW)
+            S.scns_assemble(P, nz, evalp, present, fsi_acc)
+            Ah, bh = S.csr("A"), S.rhs()
+            off = c0 if nz else np.zeros(n)
+            Ao = (Cc.T @ Ah @ Cc).tocsr()
+            bo = Cc.T @ (bh - Ah @ off)
+            x = np.zeros(n)
+            x[reg] = spl.spsolve(Ao[reg][:, reg].tocsc(), bo[reg])
+            x = Cm @ x  # constraints.distribute: hanging entries from all masters (Dirichlet masters hold their values)
+            # system_rhs.l2_norm(): regular rows + the hanging rows, which carry diag * inhomogeneity
+            hrow = np.abs(Ah.diagonal()[hang]) * off[hang]
+            cur = np.sqrt((bo[reg] ** 2).sum() + (hrow ** 2).sum())
+            evalp += x
+            if it == 0:
+                init = cur
+            rel = cur / init
+            it += 1
+        present = evalp
+        stress = S.update_stress(KW["mu"], present)
+        out.append((present.copy(), it))
+    m.indicator = None
+    return out
+
+
+def hip_loop(m, nranks, n_steps, use_dirichlet_bc):
+    from openifem_amd import capi
+    c = m.vcoords.mean(axis=1)
+    if nranks == 1:
+        cell_rank = np.zeros(m.n_cells, int)
+    else:  # 2 x 2 blocks cutting through the refined band and through the path of the disc
+        cell_rank = (c[:, 0] > 1.02).astype(int) + 2 * (c[:, 1] > 0.5).astype(int)
+    parts = partition_mesh(m, cell_rank, nranks)
+    n = m.n_dofs
+    shared = {"present": np.zeros(n), "stress": np.zeros((2, 2, m.n_unodes))}
+    fsi_stress = [np.zeros((3, m.n_unodes)) for _ in range(nranks)]  # every rank keeps its own (identical) copy
+    barrier = threading.Barrier(nranks)
+    boundary = _boundary(m)
+    out = [[] for _ in range(nranks)]
+
+    def work(rank, P, ctx):
+        ctx.set_hanging_constraints(P.hang_dof, P.hang_ptr, P.hang_master, P.hang_weight)
+        ctx.vec_set(capi.VEC_PRESENT, np.zeros(P.n_local))
+        prm = capi.make_scns_params(**KW)
+        nuo, nul = P.n_unodes_owned, P.n_unodes
+        for step in range(n_steps):
+            # the FSI side works on localized (global) vectors, as the reference does (Vector<double> localized_*, :350-362)
+            indicator, fsi_acc, dofs, vals = fsi_inputs(m, step, shared["present"], shared["stress"], fsi_stress[rank], boundary,
+                                                        use_dirichlet_bc)
+            barrier.wait()  # everybody has read the shared state of the previous step
+            ctx.set_indicator(indicator[P.cells])
+            ctx.vec_set(capi.VEC_FSI_ACC, fsi_acc[P.ext_gdof])
+            ctx.set_scns_fields(fsi_stress=fsi_stress[rank][:, P.l2g_u])
+            ld, lv = local_dirichlet(P, dofs, vals)
+            ctx.set_constraints(1, ld, lv)
+            ctx.set_constraints(0, ld, None)
+            its, log = ctx.scns_newton_step(prm, True, tol=NEWTON_TOL, maxit=NEWTON_MAXIT)
+            x = ctx.vec_get(capi.VEC_PRESENT)
+            st = ctx.update_stress(KW["mu"])  # the projected stress the step left behind (FluidSolver::update_stress)
+            shared["present"][P.own_gdof] = np.concatenate([x[:2 * nuo], x[2 * nul:2 * nul + P.n_pnodes_owned]])
+            shared["stress"][:, :, P.owned_u] = st[:, :, :nuo]
+            barrier.wait()
+            out[rank].append((shared["present"].copy() if rank == 0 else None, its))
+        return None
+
+    run_virtual_ranks(capi, parts, work)
+    assert all([o[1] for o in out[r]] == [o[1] for o in out[0]] for r in range(nranks)), "ranks disagree on Newton counts"
+    return out[0]
+
+
+@pytest.mark.parametrize("use_dirichlet_bc", [True, False])
+@pytest.mark.parametrize("nranks", [1, 4])
+def test_fsi_caller_loop_matches_oracle(nranks, use_dirichlet_bc):
+    m = _mesh()
+    n_steps = 4
+    ref = oracle_loop(m, n_steps, use_dirichlet_bc)
+    got = hip_loop(m, nranks, n_steps, use_dirichlet_bc)
+    # the set of constrained dofs and the indicator really change from step to step
+    sets = [set(int(d) for d in fsi_inputs(m, s, ref[max(s - 1, 0)][0], np.zeros((2, 2, m.n_unodes)), np.zeros((3, m.n_unodes)),
+                                           _boundary(m), use_dirichlet_bc)[2]) for s in range(n_steps)]
+    inds = [fsi_inputs(m, s, ref[0][0], np.zeros((2, 2, m.n_unodes)), np.zeros((3, m.n_unodes)), _boundary(m), False)[0]
+            for s in range(n_steps)]
+    assert any((inds[s] != inds[s + 1]).any() for s in range(n_steps - 1))
+    if use_dirichlet_bc:
+        assert any(sets[s] != sets[s + 1] for s in range(n_steps - 1))
+    n_u = m.n_u
+    for s in range(n_steps):
+        xr, itr = ref[s]
+        xg, itg = got[s]
+        # velocity and pressure separately, relative to their own scale; 1e-6 = what Newton to 1e-8 on an FGMRES solve to
+        # 1e-6 ||rhs|| (mpi_supg_solver.cpp:311-312) leaves against the oracle's exact linear solves
+        ev = np.abs(xg[:n_u] - xr[:n_u]).max() / np.abs(xr[:n_u]).max()
+        ep = np.abs(xg[n_u:] - xr[n_u:]).max() / max(np.abs(xr[n_u:]).max(), 1e-300)
+        assert ev < 1e-6 and ep < 1e-6, (s, ev, ep, itr, itg)
+        assert abs(itg - itr) <= 1, (s, itr, itg)

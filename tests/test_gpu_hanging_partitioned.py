@@ -1,0 +1,110 @@
+"""Hanging-node lines on PARTITIONED contexts (ifem_set_hanging_constraints on several ranks): the condensed operator, the
+condensed right-hand side and the Newton update of 2 / 4 virtual ranks (one host thread and one ifem_ctx each, in-process
+transport) against the single context, which tests/test_gpu_hanging.py ties to the oracle's literal
+distribute_local_to_global.  Reference: the fluid mesh of tests/fsi_leaflet_mpi is adaptively refined and distributed
+over 4 ranks (fsi_leaflet_mpi.cpp:66-76; hanging lines: mpi_fluid_solver.cpp:182-184, consumed in mpi_insim.cpp:343-355,390).
+The partitions below cut through the refinement interfaces, so that hanging nodes have masters on other ranks (ghost
+masters, reverse scatter-add of C^T) and ghost hanging nodes are interpolated locally."""
+import numpy as np
+import pytest
+
+from hangmesh import HangingMesh
+from partmesh import gather_owned, local_dirichlet, partition_mesh, run_virtual_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+def _capi():
+    from openifem_amd import capi
+    return capi
+
+
+def _mesh(dim, kv):
+    if dim == 2:
+        return HangingMesh((6, 4), (0, 0), (3.0, 1.6), {(1, 1), (2, 1), (2, 2), (4, 0), (3, 3)}, kv=kv)
+    return HangingMesh((3, 2, 2), (0, 0, 0), (1.5, 0.8, 0.6), {(0, 0, 0), (2, 1, 1)}, kv=kv)
+
+
+def _cell_ranks(m, nranks):
+    c = m.vcoords.mean(axis=1)
+    mid = 0.5 * (c.min(axis=0) + c.max(axis=0))
+    r = (c[:, 0] > mid[0]).astype(int)
+    if nranks == 4:
+        r += 2 * (c[:, 1] > mid[1]).astype(int)
+    return r
+
+
+def _case(dim, kv, seed):
+    m = _mesh(dim, kv)
+    rng = np.random.default_rng(seed)
+    flag = 3 if dim == 2 else 7
+    dofs, vals = m.dirichlet({0: (flag, [0.3, -0.2, 0.1][:dim]), 2: (flag, [0.0] * dim)},
+                             {0: lambda p, c: 0.3 + 0.5 * p[1] if c == 0 else 0.1 * p[1]})
+    ev, pr = 0.3 * rng.standard_normal(m.n_dofs), 0.3 * rng.standard_normal(m.n_dofs)
+    xs = [rng.standard_normal(m.n_dofs) for _ in range(2)]
+    return m, dofs, vals, ev, pr, xs
+
+
+def _run(m, nranks, dofs, vals, ev, pr, xs, solver, use_nonzero, tight):
+    capi = _capi()
+    parts = partition_mesh(m, _cell_ranks(m, nranks) if nranks > 1 else np.zeros(m.n_cells, int), nranks)
+    if nranks > 1:  # the partition must separate some hanging dof from one of its masters
+        own = np.full(m.n_dofs, -1)
+        for P in parts:
+            own[P.own_gdof] = P.rank
+        split = any((own[m.hang_master[m.hang_ptr[i]:m.hang_ptr[i + 1]]] != own[d]).any() for i, d in enumerate(m.hang_dof))
+        assert split, "test mesh: no hanging line crosses a rank boundary"
+    kw_ins = dict(mu=0.7, rho=1.3, gamma=0.1, dt=0.05, g=(0.2, -9.8, 0.4)[:m.dim], neumann={1: 2.0})
+    kw_scns = dict(mu=0.05, rho=1.2, dt=0.01, g=(0.3, -9.8, 0.5)[:m.dim], neumann={1: 2.5})
+
+    def work(rank, P, ctx):
+        ld, lv = local_dirichlet(P, dofs, vals)
+        ctx.set_constraints(0, ld, None)
+        ctx.set_constraints(1, ld, lv)
+        ctx.set_hanging_constraints(P.hang_dof, P.hang_ptr, P.hang_master, P.hang_weight)
+        ctx.vec_set(capi.VEC_PRESENT, pr[P.ext_gdof])
+        ctx.vec_set(capi.VEC_EVAL, ev[P.ext_gdof])
+        if tight:
+            ctx.opts.fgmres_rel = 1e-10
+            ctx.opts.inner_rel = 1e-3
+        if solver == "ins":
+            Pm = capi.make_params(**kw_ins)
+            ctx.assemble(Pm, use_nonzero)
+        else:
+            ctx.update_stress(kw_scns["mu"])
+            ctx.scns_assemble(capi.make_scns_params(**kw_scns), use_nonzero)
+        out = {"rhs": ctx.vec_get(capi.VEC_RHS), "y": [ctx.system_vmult(x[P.own_gdof]) for x in xs]}
+        if solver == "ins" and m.kv == 1:  # Q1/Q1 without stabilisation is not inf-sup stable: operator and rhs only
+            out["upd"] = np.zeros(P.n_owned)
+            return out
+        if solver == "ins":
+            ctx.solve(Pm, use_nonzero)
+        else:
+            ctx.scns_solve(use_nonzero)
+        out["upd"] = ctx.vec_get(capi.VEC_UPDATE)
+        return out
+
+    res = run_virtual_ranks(capi, parts, work)
+    g = lambda key: gather_owned(parts, [r[key] for r in res], m.n_dofs)  # noqa: E731
+    return g("rhs"), [gather_owned(parts, [r["y"][k] for r in res], m.n_dofs) for k in range(len(xs))], g("upd")
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("dim,kv,solver", [(2, 2, "ins"), (2, 1, "ins"), (3, 2, "ins"), (2, 1, "scns")])
+@pytest.mark.parametrize("use_nonzero", [True, False])
+def test_condensed_system_on_virtual_ranks_equals_single_context(nranks, dim, kv, solver, use_nonzero):
+    if dim == 3 and nranks == 4 and not use_nonzero:
+        pytest.skip("covered by the other 3D cases")
+    m, dofs, vals, ev, pr, xs = _case(dim, kv, 100 + dim + kv)
+    b1, y1, u1 = _run(m, 1, dofs, vals, ev, pr, xs, solver, use_nonzero, tight=True)
+    bN, yN, uN = _run(m, nranks, dofs, vals, ev, pr, xs, solver, use_nonzero, tight=True)
+    assert np.abs(bN - b1).max() <= 1e-11 * np.abs(b1).max()
+    for a, b in zip(yN, y1):
+        assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max()
+    # Newton update incl. constraints.distribute of the hanging entries (masters on other ranks)
+    tol = 1e-6 if solver == "ins" else 1e-4  # the SUPG solve stops at the reference's 1e-6 ||rhs|| (mpi_supg_solver.cpp:311)
+    if solver == "ins" and kv == 1:
+        return
+    assert np.abs(uN - u1).max() <= tol * np.abs(u1).max()
+    Cm = m.prolongation()
+    assert np.abs(uN - Cm @ uN).max() <= 1e-12 * np.abs(uN).max()
