@@ -218,6 +218,7 @@ def main():
     ap.add_argument("--mp-rel", type=float, default=None, help="experiment: relative tolerance of CG(M_p) inside the preconditioner (reference and default: 1e-6)")
     ap.add_argument("--inner-restart", type=int, default=16, help="restart length of the inner GMRES of the A_uu^-1 replacement (measured at 128^3: 8/10/12/15/20/30/45 -> 557/533/537/518/522/531/543 ms per step; 16 = one multi-dot pass of the single-precision basis; the library default is 30)")
     ap.add_argument("--tuned", type=int, default=1, help="also time the relaxed-preconditioner variant (reported as tuned_preconditioner, N = 1 only)")
+    ap.add_argument("--mg", type=int, default=1, help="1 (default): attach the chain of coarser (semi-coarsened) box meshes so that CG(S_m) inside the preconditioner is multigrid-preconditioned; 0: plain CG as in the reference")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
     ap.add_argument("--outer-mf", type=int, default=0, help="experiment: apply the u-u block of the OUTER operator matrix-free too")
     ap.add_argument("--solver", default="insim", choices=["insim", "insimex"],
@@ -242,15 +243,8 @@ def main():
     if args.solver == "insimex":
         return bench_insimex(args, host)
     n = args.n
-    if world == 1:
-        reps = (n, n, n)
-        solver = host.InsIM(host.channel_prm(3), reps, (0, 0, 0), (2.0, 0.2, 0.2), device=local_rank, verbose=False)
-        t_setup = time.time()
-        solver.setup(0)
-        t_setup = time.time() - t_setup
-    else:
-        from openifem_amd import multigpu
-        solver, reps, t_setup = multigpu.make_channel_solver(n, rank, world, local_rank, dist)
+    from openifem_amd import multigpu
+    solver, reps, t_setup = multigpu.make_channel_solver(n, rank, world, local_rank, dist, multigrid=bool(args.mg))
     n_cells, n_u, n_p = solver.sizes()
     n_dofs_global = solver.global_dofs() if world > 1 else n_u + n_p
     solver.opts.inner_rel = args.inner_rel
@@ -368,7 +362,9 @@ def main():
                        "fgmres_iters": last.fgmres_iters, "cg_mp_iters": last.cg_mp_iters,
                        "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "ainv_kind": args.ainv, "outer_matrix_free": args.outer_mf,
                        "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms,
-                       "mf_apply_ms": mf_ms / max(mf_calls, 1), "mf_applies": mf_calls},
+                       "mf_apply_ms": mf_ms / max(mf_calls, 1), "mf_applies": mf_calls,
+                       "sm_multigrid_levels": int(last.sm_mg_levels),
+                       "coarse_levels": [list(s.reps) for s in getattr(solver, "_levels", [])]},
             "roofline": roof,
         }
         out["config"].update({"cg_mp_rel": solver.opts.mp_rel, "cg_sm_rel": solver.opts.sm_rel})

@@ -121,6 +121,11 @@ typedef struct {
   int32_t outer_matrix_free;  /* 0 (default): the outer FGMRES operator is the assembled block matrix, as in the reference;
                                  1: its velocity-velocity block is applied matrix-free (same operator to 1e-12, a
                                  fifth of the time) -- an experiment switch, off by default */
+  int32_t sm_mg;              /* 1 (default): when coarser levels are attached (ifem_mg_attach) and S_m is explicit, the
+                                 S_m solve of the preconditioner (mpi_insim.cpp:86-112) is CG preconditioned by one multigrid
+                                 V-cycle, same stopping rule on the true residual; 0: plain CG as in the reference */
+  int32_t mg_smooth;          /* 2: Chebyshev-Jacobi smoothing steps before and after the coarse correction */
+  double  mg_cheb_ratio;      /* 4: the smoother targets the eigenvalues of D^-1 S_m in [lambda_max / ratio, lambda_max] */
 } ifem_solver_opts;
 
 /* Tuning / measurement knobs of one context (defaults = the measured best; nothing here changes results beyond fp64
@@ -145,6 +150,7 @@ typedef struct {
   uint32_t fgmres_iters; double fgmres_res;
   uint32_t precond_applies, cg_mp_iters, cg_sm_iters, inner_iters;
   double t_schur_setup_ms, t_cg_mp_ms, t_cg_sm_ms, t_ainv_ms, t_spmv_ms, t_total_ms;
+  uint32_t sm_mg_levels; /* levels used by the multigrid-preconditioned CG(S_m) of the last solve (0: plain CG) */
 } ifem_solve_stats;
 
 /* context-resident block vectors (reference members of FluidSolver / InsIM) */
@@ -162,7 +168,7 @@ enum {
 const char *ifem_last_error(void);
 /* sizeof of the structs above as this library was compiled, for a binding to check its mirror against:
  * 0 ifem_mesh_desc, 1 ifem_partition, 2 ifem_ins_params, 3 ifem_solver_opts, 4 ifem_solve_stats, 5 ifem_scns_params,
- * 6 ifem_timing, 7 ifem_tuning; -1 for anything else */
+ * 6 ifem_timing, 7 ifem_tuning, 8 ifem_mg_transfer; -1 for anything else */
 int64_t ifem_abi_sizeof(int which);
 int ifem_device_count(void);
 void ifem_default_solver_opts(ifem_solver_opts *o);
@@ -211,6 +217,26 @@ int ifem_vec_norm2(ifem_ctx *ctx, int vec, double *out);  /* l2_norm(), all-redu
 /* Utils::PETScVectorMax/Min over one block (source/utilities.cpp:635-651): block 0 velocity, 1 pressure */
 int ifem_vec_minmax(ifem_ctx *ctx, int vec, int block, double *vmin, double *vmax);
 int ifem_halo_exchange(ifem_ctx *ctx, int vec);           /* ghosted-vector assignment */
+
+/* ---- Geometric multigrid levels for the preconditioner's inner solves.  The reference gets mesh-independent inner solves
+ * from MUMPS (mpi_insim.cpp:124-127); its CG(S_m) (:86-112) is unpreconditioned.  Here the caller may attach a chain of
+ * coarser contexts -- the same problem (domain, boundary ids, constraint sets, partition over the same ranks) on coarser
+ * meshes, e.g. the levels a Triangulation passes through under refine_global, or semi-coarsened box meshes for stretched
+ * cells -- with the nodal prolongation between neighbouring levels.  Coarse operators are REDISCRETISED on those contexts
+ * (S_m: geometry blocks + the same B diag(M_u)^-1 B^T), nothing is assembled by Galerkin products.  Only the
+ * preconditioner changes: the outer FGMRES operator and stopping rules stay the reference's.
+ * P_p: pressure-node prolongation, rows = the OWNED pressure nodes of `fine`, columns = LOCAL (owned + ghost) pressure
+ * nodes of `coarse` on the same rank; R_p = P_p^T, rows = LOCAL pressure nodes of `coarse`, columns = owned pressure
+ * nodes of `fine` (ghost rows are sent to their owners and added, like a PETSc reverse scatter).  The caller keeps
+ * `coarse` alive and keeps its constraint sets in step with those of `fine`; the tables are copied. */
+typedef struct {
+  int64_t n_fine_p_owned, n_coarse_p_local;
+  const int64_t *pp_ptr; const int32_t *pp_col; const double *pp_w; /* CSR of P_p */
+  const int64_t *rp_ptr; const int32_t *rp_col; const double *rp_w; /* CSR of R_p = P_p^T */
+} ifem_mg_transfer;
+int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t);
+/* number of levels below ctx (0: none attached) */
+int ifem_mg_depth(const ifem_ctx *ctx);
 
 /* Tells the next ifem_ins_assemble which extra operators the chosen A_uu^-1 replacement needs (IFEM_AINV_*). */
 int ifem_set_ainv_kind(ifem_ctx *ctx, int kind);

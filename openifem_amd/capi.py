@@ -67,14 +67,22 @@ class SolverOpts(C.Structure):
                 ("fgmres_abs", C.c_double), ("mp_rel", C.c_double), ("mp_abs", C.c_double),
                 ("sm_rel", C.c_double), ("sm_abs", C.c_double), ("ainv_kind", C.c_int32),
                 ("inner_restart", C.c_int32), ("inner_maxit", C.c_int32), ("inner_rel", C.c_double),
-                ("explicit_schur", C.c_int32), ("verbose", C.c_int32), ("device_cg", C.c_int32), ("outer_matrix_free", C.c_int32)]
+                ("explicit_schur", C.c_int32), ("verbose", C.c_int32), ("device_cg", C.c_int32), ("outer_matrix_free", C.c_int32),
+                ("sm_mg", C.c_int32), ("mg_smooth", C.c_int32), ("mg_cheb_ratio", C.c_double)]
 
 
 class SolveStats(C.Structure):
     _fields_ = [("fgmres_iters", C.c_uint32), ("fgmres_res", C.c_double), ("precond_applies", C.c_uint32),
                 ("cg_mp_iters", C.c_uint32), ("cg_sm_iters", C.c_uint32), ("inner_iters", C.c_uint32),
                 ("t_schur_setup_ms", C.c_double), ("t_cg_mp_ms", C.c_double), ("t_cg_sm_ms", C.c_double),
-                ("t_ainv_ms", C.c_double), ("t_spmv_ms", C.c_double), ("t_total_ms", C.c_double)]
+                ("t_ainv_ms", C.c_double), ("t_spmv_ms", C.c_double), ("t_total_ms", C.c_double),
+                ("sm_mg_levels", C.c_uint32)]
+
+
+class MgTransfer(C.Structure):
+    _fields_ = [("n_fine_p_owned", C.c_int64), ("n_coarse_p_local", C.c_int64),
+                ("pp_ptr", C.c_void_p), ("pp_col", C.c_void_p), ("pp_w", C.c_void_p),
+                ("rp_ptr", C.c_void_p), ("rp_col", C.c_void_p), ("rp_w", C.c_void_p)]
 
 
 class Tuning(C.Structure):
@@ -98,7 +106,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_get_timing", "ifem_set_profiling", "ifem_synchronize", "ifem_set_hanging_constraints", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
            "ifem_scns_assemble", "ifem_scns_solve", "ifem_scns_newton_step", "ifem_imex_assemble", "ifem_imex_solve",
            "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof",
-           "ifem_mass_vmult"]
+           "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -169,6 +177,8 @@ def load():
                                         C.c_int, C.c_void_p]
     L.ifem_default_tuning.argtypes = [C.POINTER(Tuning)]
     L.ifem_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
+    L.ifem_mg_attach.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(MgTransfer)]
+    L.ifem_mg_depth.argtypes = [C.c_void_p]
     L.ifem_abi_sizeof.argtypes = [C.c_int]
     L.ifem_abi_sizeof.restype = C.c_int64
     _lib = L
@@ -179,7 +189,7 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-ABI_STRUCTS = [MeshDesc, Partition, InsParams, SolverOpts, SolveStats, ScnsParams, Timing, Tuning]
+ABI_STRUCTS = [MeshDesc, Partition, InsParams, SolverOpts, SolveStats, ScnsParams, Timing, Tuning, MgTransfer]
 
 
 def make_params(mu=1.0, rho=1.0, gamma=0.1, dt=1e-3, g=(0, 0, 0), neumann=None):
@@ -207,6 +217,83 @@ def make_scns_params(mu, rho, dt, solid_rho=1.0, g=(0, 0, 0), neumann=None, form
         p.neumann_id[k] = bid
         p.neumann_p[k] = val
     return p
+
+
+def mg_attach(L, fine_h, coarse_h, P_p):
+    """ifem_mg_attach from a scipy.sparse prolongation (rows: owned fine pressure nodes, columns: local coarse pressure nodes)"""
+    Pm = P_p.tocsr()
+    Pm.sort_indices()
+    Rm = Pm.T.tocsr()
+    Rm.sort_indices()
+    keep = [np.ascontiguousarray(Pm.indptr, np.int64), np.ascontiguousarray(Pm.indices, np.int32), np.ascontiguousarray(Pm.data, float),
+            np.ascontiguousarray(Rm.indptr, np.int64), np.ascontiguousarray(Rm.indices, np.int32), np.ascontiguousarray(Rm.data, float)]
+    t = MgTransfer(Pm.shape[0], Pm.shape[1], *[_ptr(a) for a in keep])
+    rc = L.ifem_mg_attach(fine_h, coarse_h, C.byref(t))
+    if rc < 0:
+        raise IfemError(rc, L.ifem_last_error().decode())
+
+
+def lattice_prolongation_1d(n_fine, n_coarse, degree):
+    """1D nodal interpolation between nested uniform lattices of Q_degree nodes: n_fine cells <- n_coarse cells,
+    n_fine = n_coarse (identity) or 2 n_coarse.  Returns (idx [N_f, degree + 1], w [N_f, degree + 1]) with zero-weight
+    padding: fine lattice point i = sum_k w[i, k] * coarse point idx[i, k]."""
+    k = degree
+    Nf = k * n_fine + 1
+    i = np.arange(Nf)
+    idx = np.zeros((Nf, k + 1), np.int64)
+    w = np.zeros((Nf, k + 1))
+    if n_fine == n_coarse:
+        idx[:, 0], w[:, 0] = i, 1.0
+        return idx, w
+    assert n_fine == 2 * n_coarse, "levels must be nested with ratio 1 or 2 per direction"
+    cell = np.minimum(i // (2 * k), n_coarse - 1)        # coarse cell holding the point (2k fine steps per coarse cell)
+    t = (i - 2 * k * cell) / (2.0 * k)                   # position in the coarse cell, in [0, 1]
+    nodes = np.arange(k + 1) / k
+    for a in range(k + 1):                               # Lagrange polynomial a on the coarse cell's nodes
+        la = np.ones(Nf)
+        for b in range(k + 1):
+            if b != a:
+                la *= (t - nodes[b]) / (nodes[a] - nodes[b])
+        idx[:, a] = k * cell + a
+        w[:, a] = np.where(np.abs(la) < 1e-14, 0.0, la)
+    return idx, w
+
+
+def box_prolongation(reps_fine, reps_coarse, degree, l2g_fine_owned, l2g_coarse_local):
+    """scipy CSR prolongation between two box meshes of the same domain (nested, ratio 1 or 2 per direction) on the Q_degree
+    node lattice: rows = the given fine nodes (global lattice ids, x fastest), columns = positions in l2g_coarse_local."""
+    import scipy.sparse as sp
+    dim = len(reps_fine)
+    Nf = [degree * r + 1 for r in reps_fine]
+    Nc = [degree * r + 1 for r in reps_coarse]
+    g = np.asarray(l2g_fine_owned, np.int64)
+    coords, rem = [], g.copy()
+    for d in range(dim):
+        coords.append(rem % Nf[d])
+        rem //= Nf[d]
+    one = [lattice_prolongation_1d(reps_fine[d], reps_coarse[d], degree) for d in range(dim)]
+    n_glob_c = int(np.prod(Nc))
+    g2l = -np.ones(n_glob_c, np.int64)
+    g2l[np.asarray(l2g_coarse_local, np.int64)] = np.arange(len(l2g_coarse_local))
+    rows, cols, vals = [], [], []
+    import itertools
+    for combo in itertools.product(range(degree + 1), repeat=dim):
+        wgt = np.ones(len(g))
+        cid = np.zeros(len(g), np.int64)
+        stride = 1
+        for d in range(dim):
+            idx, w = one[d]
+            wgt = wgt * w[coords[d], combo[d]]
+            cid = cid + idx[coords[d], combo[d]] * stride
+            stride *= Nc[d]
+        sel = wgt != 0.0
+        lc = g2l[cid[sel]]
+        assert (lc >= 0).all(), "a coarse node of the interpolation stencil is not local on this rank"
+        rows.append(np.nonzero(sel)[0])
+        cols.append(lc)
+        vals.append(wgt[sel])
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                         shape=(len(g), len(l2g_coarse_local)))
 
 
 class Context:

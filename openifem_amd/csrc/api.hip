@@ -34,6 +34,7 @@ int64_t ifem_abi_sizeof(int which) {
   case 5: return sizeof(ifem_scns_params);
   case 6: return sizeof(ifem_timing);
   case 7: return sizeof(ifem_tuning);
+  case 8: return sizeof(ifem_mg_transfer);
   default: return -1;
   }
 }
@@ -52,6 +53,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
   o->outer_matrix_free = 0;
   o->device_cg = 1;
   o->verbose = 0;
+  o->sm_mg = 1; o->mg_smooth = 2; o->mg_cheb_ratio = 4.0;
 }
 
 void ifem_default_tuning(ifem_tuning *t) {
@@ -133,13 +135,14 @@ int ifem_ctx_create(const ifem_mesh_desc *m, const ifem_partition *part, int dev
 void ifem_ctx_destroy(ifem_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream && ctx->owns_stream) (void)hipStreamSynchronize(ctx->stream);
+  else (void)hipDeviceSynchronize(); // a multigrid level on a borrowed stream (which may be gone already)
   comm_destroy(ctx);
   ifem::tpp_release(ctx);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->owns_stream ? ctx->stream : nullptr;
   delete ctx;
   if (s) (void)hipStreamDestroy(s);
 }
@@ -184,6 +187,50 @@ int ifem_set_hanging_constraints(ifem_ctx *ctx, int32_t n, const int32_t *dof, c
   IFEM_API_BEGIN
   ifem::hanging_set(ctx, n, dof, ptr, master, weight);
   IFEM_API_END
+}
+
+int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t) {
+  IFEM_API_BEGIN
+  if (!fine || !coarse || !t || fine == coarse) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: two contexts and a transfer table");
+  if (fine->dim != coarse->dim || fine->halo.nranks != coarse->halo.nranks || fine->device != coarse->device)
+    throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: the levels must share dimension, device and rank count");
+  if (t->n_fine_p_owned != fine->nPo || t->n_coarse_p_local != coarse->nPl)
+    throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: P_p needs one row per owned fine pressure node, R_p one per local coarse pressure node");
+  if (!t->pp_ptr || !t->pp_col || !t->pp_w || !t->rp_ptr || !t->rp_col || !t->rp_w) throw Error(IFEM_E_BADPARAM, "null transfer table");
+  const int64_t nnz = t->pp_ptr[fine->nPo];
+  if (t->pp_ptr[0] != 0 || t->rp_ptr[0] != 0 || t->rp_ptr[coarse->nPl] != nnz) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: R_p is not the transpose of P_p");
+  for (int64_t k = 0; k < nnz; ++k) {
+    if (t->pp_col[k] < 0 || t->pp_col[k] >= coarse->nPl) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: P_p column out of range");
+    if (t->rp_col[k] < 0 || t->rp_col[k] >= fine->nPo) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: R_p column out of range");
+  }
+  hipStream_t s = fine->stream;
+  fine->mg_Pp.n_rows = fine->nPo;
+  fine->mg_Pp.ptr.upload(t->pp_ptr, (size_t)fine->nPo + 1, s);
+  fine->mg_Pp.col.upload(t->pp_col, (size_t)nnz, s);
+  fine->mg_Pp.w.upload(t->pp_w, (size_t)nnz, s);
+  fine->mg_Rp.n_rows = coarse->nPl;
+  fine->mg_Rp.ptr.upload(t->rp_ptr, (size_t)coarse->nPl + 1, s);
+  fine->mg_Rp.col.upload(t->rp_col, (size_t)nnz, s);
+  fine->mg_Rp.w.upload(t->rp_w, (size_t)nnz, s);
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  fine->mg_coarse = coarse;
+  fine->sm_mg_version = -1;
+  // one stream for the whole chain: the V-cycle walks up and down the levels and every launch must stay in order
+  for (ifem_ctx *c = coarse; c; c = c->mg_coarse) {
+    if (c->stream == s) continue;
+    IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+    c->stream = s;
+    c->owns_stream = false;
+    if (c->rocblas) ifem::tpp_release(c);
+  }
+  IFEM_API_END
+}
+
+int ifem_mg_depth(const ifem_ctx *ctx) {
+  int d = 0;
+  for (const ifem_ctx *c = ctx ? ctx->mg_coarse : nullptr; c; c = c->mg_coarse) ++d;
+  return d;
 }
 
 int ifem_set_cell_fields(ifem_ctx *ctx, const int32_t *indicator) {

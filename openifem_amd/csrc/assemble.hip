@@ -21,14 +21,22 @@ void launch_ins_assemble2_kernel(ifem_ctx *ctx, const AsmArgs &A);
 bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A);
 
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) { launch_ins_assemble_ex(ctx, p, use_nonzero, 0, 1); }
+void launch_ins_assemble_geometry(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) { launch_ins_assemble_ex(ctx, p, use_nonzero, 0, 2); }
 
 // imex = 1: InsIMEX::assemble (mpi_insimex.cpp:150-355): every field comes from the present solution, the matrix has no
-// convective terms; assemble_system = 0 integrates the right-hand side only and leaves the matrices untouched
+// convective terms; assemble_system = 0 integrates the right-hand side only and leaves the matrices untouched;
+// assemble_system = 2 (internal): B, B^T, M_p, diag(M_u) only -- a multigrid level of the pressure Schur complement
 void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero, int imex, int assemble_system) {
   hipStream_t s = ctx->stream;
   const int dim = ctx->dim;
+  const bool geo_only = assemble_system == 2;
+  if (geo_only) {
+    const int64_t key = ctx->flag_id[use_nonzero ? 1 : 0];
+    if (ctx->geo_valid && ctx->geo_key == key) return; // still the blocks of this constrained-dof set
+  } else if (assemble_system)
+    ensure_auu_values(ctx);
   if (!assemble_system && !ctx->assembled) throw Error(IFEM_E_BADPARAM, "rhs-only assembly before any matrix assembly");
-  if (assemble_system) { // state the matrix-free A_uu needs to reproduce this matrix (apply_mf.hip)
+  if (assemble_system == 1) { // state the matrix-free A_uu needs to reproduce this matrix (apply_mf.hip)
     const size_t nu = size_t(dim) * size_t(ctx->nUl);
     if (ctx->mf_eval.n != nu) ctx->mf_eval.alloc(nu);
     if (imex) IFEM_HIP_CHECK(hipMemsetAsync(ctx->mf_eval.p, 0, nu * sizeof(double), s)); // no convection in the IMEX matrix
@@ -45,7 +53,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   const bool skip_geo = ctx->tune.geo_cache && assemble_system && ctx->geo_valid && ctx->geo_key == geo_key;
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
   if (assemble_system) {
-    IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
+    if (!geo_only) IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
     if (!skip_geo) {
       IFEM_HIP_CHECK(hipMemsetAsync(ctx->Bt.val.p, 0, ctx->Bt.val.n * sizeof(double), s));
       IFEM_HIP_CHECK(hipMemsetAsync(ctx->B.val.p, 0, ctx->B.val.n * sizeof(double), s));
@@ -73,6 +81,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   A.cval = ctx->has_c[w] ? ctx->cval[w].p : nullptr;
   A.use_inhom = (use_nonzero && ctx->has_c[1]) ? 1 : 0;
   A.skip_geo = skip_geo ? 1 : 0;
+  A.skip_uu = geo_only ? 1 : 0;
   A.debug_skip = ctx->tune.asm_skip;
   A.xcd_swizzle = ctx->tune.xcd_swizzle;
   A.eval = ctx->vec[imex ? IFEM_VEC_PRESENT : IFEM_VEC_EVAL].p; A.present = ctx->vec[IFEM_VEC_PRESENT].p;
@@ -87,6 +96,13 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
     launch_ins_assemble2_kernel(ctx, A);    // assemble2.hip (quadrature-point-outer, register accumulators)
   IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
   if (assemble_system) { ctx->geo_valid = true; ctx->geo_key = geo_key; }
+  if (geo_only) { // what the Schur complement of this level needs: 1/diag(M_u); S_m is stale if the blocks were re-integrated
+    dinv_setup(ctx);
+    ctx->bbt_f32_valid = false;
+    ctx->sm_valid = false; ctx->sm_key = geo_key;
+    ctx->asm_constraint_set = use_nonzero ? 1 : 0;
+    return;
+  }
   if (assemble_system) assemble_epilogue(ctx, use_nonzero);
   else {
     IFEM_HIP_CHECK(hipEventSynchronize(ctx->ev1));

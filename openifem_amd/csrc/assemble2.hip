@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
   };
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; ++pass) {
-    if ((A.rhs_only && pass > 0) || A.debug_skip >= 5) break;
+    if (((A.rhs_only || A.skip_uu) && pass > 0) || A.debug_skip >= 5) break;
     const bool first = pass == 0;
     int oa[RP], ob[RP];
     bool pv[RP];
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
       for (int i = 0; i < DIM * DIM; ++i) gqs[i] = A.imex ? 0.0 : S.gqs[q * DIM * DIM + i];
 #pragma unroll
       for (int j = 0; j < RP; ++j) {
-        if (A.debug_skip == 2 || A.rhs_only) continue;
+        if (A.debug_skip == 2 || A.rhs_only || A.skip_uu) continue;
         const double *pa = tb + oa[j], *pb = tb + ob[j];
         const double Na = pa[0], Nb = pb[0], ugb = pb[4];
         double ga[DIM], gb[DIM], gg = 0;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
       int64_t *soff = reinterpret_cast<int64_t *>(S.scratch + 64 * BS);   // [64] element offset of the block, -1: none
 #pragma unroll
       for (int j = 0; j < RP; ++j) {
-        const bool have = pbase[j] && !A.debug_skip && !A.rhs_only;
+        const bool have = pbase[j] && !A.debug_skip && !A.rhs_only && !A.skip_uu;
         soff[lane] = have ? int64_t(pbase[j] - A.v_uu) : int64_t(-1);
         if (have) {
           const int a = oa[j] / TS, b = ob[j] / TS;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * WPB) void k_ins_assemble2(AsmArgs A, Tab1D t1)
 #else
 #pragma unroll
     for (int j = 0; j < RP; ++j) {
-      if (!pbase[j] || A.debug_skip || A.rhs_only) continue; // no pair in this slot, inactive cell or row owned by another rank
+      if (!pbase[j] || A.debug_skip || A.rhs_only || A.skip_uu) continue; // no pair in this slot, inactive cell or row owned by another rank
       const int a = oa[j] / TS, b = ob[j] / TS;
       const int len = S.len_uu[a];
       double *base = pbase[j];

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
   double *stage = h == 0 ? S.scratch : S.dead; // the second wave stages in the dead zone (Ji, Vc, Sc, divw are consumed)
   int64_t *soff = reinterpret_cast<int64_t *>(stage + 64 * BS);
   // ---- velocity-velocity block on the matrix cores, one 16x16 tile pair (ti, tj) at a time
-  if (!A.rhs_only && A.debug_skip < 5) {
+  if (!A.rhs_only && !A.skip_uu && A.debug_skip < 5) {
 #pragma unroll 1
     for (int tp = 2 * h; tp < 2 * h + 2; ++tp) {
       const int ti = tp >> 1, tj = tp & 1;

@@ -44,6 +44,7 @@ struct AsmArgs {
   int xcd_swizzle; // contiguous cell ranges per XCD (IFEM_XCD=0 switches it off)
   int skip_geo;   // B, B^T, M_p and diag(M_u) of the previous assembly are still valid (same mesh, same constraint set):
                   // integrate them only where a constrained dof needs their entries for the right-hand side
+  int skip_uu;    // geometry-only assembly (multigrid levels): the velocity-velocity block is neither integrated nor scattered
   int debug_skip; // measurement aid (IFEM_ASM_SKIP): 1 = skip the A_uu scatter, 2 = skip the pair contraction too
 };
 

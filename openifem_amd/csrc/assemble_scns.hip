@@ -429,6 +429,7 @@ static void launch_scns_t(ifem_ctx *ctx, const ScnsArgs &A) {
 void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonzero) {
   hipStream_t s = ctx->stream;
   if (ctx->App.n != ctx->Mp.val.n) ctx->App.alloc(ctx->Mp.val.n);
+  ensure_auu_values(ctx);
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->Bt.val.p, 0, ctx->Bt.val.n * sizeof(double), s));
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->B.val.p, 0, ctx->B.val.n * sizeof(double), s));

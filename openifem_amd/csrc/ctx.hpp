@@ -152,9 +152,20 @@ struct Hanging {
 };
 } // namespace ifem
 
+namespace ifem {
+// one CSR transfer table of the multigrid hierarchy (row-parallel gather on the device)
+struct MgCsr {
+  int64_t n_rows = 0;
+  DBuf<int64_t> ptr;
+  DBuf<int32_t> col;
+  DBuf<double> w;
+};
+} // namespace ifem
+
 struct ifem_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool owns_stream = true; // false: a coarse multigrid level running on the stream of the finest level (ifem_mg_attach)
   int dim = 0, kv = 0, nu = 0, np = 0, nq = 0;
   int64_t n_cells = 0;
   int64_t nUo = 0, nUl = 0, nPo = 0, nPl = 0; // velocity / pressure nodes owned / local
@@ -196,6 +207,13 @@ struct ifem_ctx {
   bool geo_valid = false; // B, B^T, M_p, diag(M_u) hold the blocks of constraint set geo_key (assemble.hip)
   int64_t geo_key = -1;
   ifem::Hanging hang; // hanging-node lines (hanging.hip)
+  // multigrid (ifem_mg_attach): the next coarser level (not owned) and the pressure transfers to it; per-level state of
+  // the S_m V-cycle: 1/diag(S_m), largest eigenvalue of D^-1 S_m, scratch vectors [nPl]
+  ifem_ctx *mg_coarse = nullptr;
+  ifem::MgCsr mg_Pp, mg_Rp;
+  ifem::DBuf<double> sm_dinv, mg_vec[6];
+  double sm_lmax = 0;
+  int64_t sm_version = 0, sm_mg_version = -1; // S_m values rebuilt / the version the V-cycle data belong to
   // explicit T_pp = A_pp - A_pv Binv A_vp on the pattern of Sm and its dense LU (tpp.hip)
   ifem::DBuf<double> Tpp, tpp_diag, tpp_dense;
   ifem::DBuf<int> tpp_ipiv;

@@ -8,12 +8,15 @@ namespace ifem {
 void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, int R, const int32_t *d_rows, int C,
                    const int32_t *d_cols, DBuf<uint16_t> &pos);
 
+void ensure_auu_values(ifem_ctx *ctx);
 void build_schur_pattern(ifem_ctx *ctx);
 void build_incidence(ifem_ctx *ctx);
 
 // assemble.hip
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
 void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero, int imex, int assemble_system);
+// B, B^T, M_p, diag(M_u) only (multigrid levels of the pressure Schur complement): no A_uu, no right-hand side state
+void launch_ins_assemble_geometry(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
 
 // assemble_scns.hip
 void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonzero);
@@ -97,6 +100,13 @@ void hanging_distribute(ifem_ctx *ctx, double *x);
 void hanging_refresh_diag(ifem_ctx *ctx);
 bool hanging_offset(ifem_ctx *ctx, int use_nonzero);
 void hanging_condense_rhs(ifem_ctx *ctx, int use_nonzero); // solver.hip: b = C^T (b^ - A^ c0), hanging rows d c0
+
+// mg.hip: transfers and smoother updates of the multigrid inside the preconditioner
+void mg_csr_apply(ifem_ctx *ctx, const MgCsr &M, const double *x, double *y, bool add);
+void cheb_init(ifem_ctx *ctx, int64_t n, double c0, const double *dinv, const double *r, double *d);
+void cheb_step(ifem_ctx *ctx, int64_t n, double a, double b, const double *dinv, const double *t, double *x, double *r, double *d);
+void vec_recip(ifem_ctx *ctx, int64_t n, double *d);
+void vec_rough(ifem_ctx *ctx, int64_t n, int64_t offset, double *x);
 
 // all-reduce helpers (identity for a single rank)
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n);

@@ -473,6 +473,7 @@ void schur_numeric(ifem_ctx *ctx) {
   IFEM_HIP_CHECK(hipGetLastError());
   ctx->sm_valid = true;
   ctx->sm_f32_valid = false;
+  ctx->sm_version++;
 }
 
 // y = M x for a scalar matrix on the pattern of `M` with the values `val` (explicit T_pp on the pattern of S_m)

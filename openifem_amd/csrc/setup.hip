@@ -118,11 +118,21 @@ static void pattern_from_keys(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_row
     if (mx >= 0xFFFF) throw Error(IFEM_E_BADPARAM, "row longer than 65534 blocks");
     M.max_row = (int)mx;
   }
-  if (bs > 0) { // bs == 0: pattern only (incidence lists)
+  if (bs > 0 && &M != &ctx->Auu) { // bs == 0: pattern only (incidence lists); A_uu values: see ensure_auu_values
     M.val.alloc((size_t)nnzb * bs);
     IFEM_HIP_CHECK(hipMemsetAsync(M.val.p, 0, (size_t)nnzb * bs * sizeof(double), s));
   }
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// The values of A_uu (78 GB at 128^3 Q2) are allocated by the first assembly that writes them: coarse multigrid levels
+// keep the pattern but never assemble the velocity block.
+void ensure_auu_values(ifem_ctx *ctx) {
+  PlanarCsr &M = ctx->Auu;
+  const size_t n = (size_t)M.nnzb * M.bs;
+  if (M.val.n == n) return;
+  M.val.alloc(n);
+  IFEM_HIP_CHECK(hipMemsetAsync(M.val.p, 0, n * sizeof(double), ctx->stream));
 }
 
 // Builds the sorted pattern of {(row, col)} pairs coupled through a common cell, plus the scatter map.

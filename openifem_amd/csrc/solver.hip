@@ -320,6 +320,201 @@ static double dot_all(SolveState &S, int64_t n, const double *a, const double *b
   return d;
 }
 
+// ---- the pressure Schur complement S_m = B diag(M_u)^-1 B^T of one level (mass_schur(1,1), mpi_insim.cpp:44-49)
+// S_m applied with two SpMVs (ghost refreshes in between): several ranks without the 2-deep halo plan, and the probing
+static void sm_matrix_free(SolveState &S, const double *x, double *y, bool lowp) {
+  ifem_ctx *c = S.ctx;
+  const double *xe; extend_p(S, x, &xe);
+  if (lowp) spmv_bt_f32(c, xe, S.tu); else spmv_bt(c, xe, S.tu);
+  vec_mul(c, S.nuo, c->dinvMu.p, S.tu, S.tu);
+  const double *te; extend_u(S, S.tu, &te);
+  if (lowp) spmv_b_f32(c, te, y); else spmv_b(c, te, y);
+}
+
+static bool sm_is_explicit(const SolveState &S) {
+  const ifem_ctx *c = S.ctx;
+  return S.o->explicit_schur && (c->halo.nranks == 1 || c->halo.has_s);
+}
+
+// BlockSchurPreconditioner ctor (:44-49): S_m formed explicitly, once per constrained-dof set
+static void sm_ensure(SolveState &S) {
+  ifem_ctx *c = S.ctx;
+  if (!sm_is_explicit(S)) return;
+  if (c->halo.nranks == 1) {
+    if (c->Sm.n_rows == 0) build_schur_pattern(c);
+    schur_numeric(c);
+    return;
+  }
+  // same matrix, distributed: pattern from the pressure lattice, values by probing
+  if (c->Sm.n_rows == 0 && c->nPo) build_schur_pattern_box(c);
+  if ((int64_t)c->xs_ext.n < c->halo.n_s_cols) c->xs_ext.alloc(c->halo.n_s_cols);
+  if (!c->sm_valid) {
+    const int ncol = c->dim == 3 ? 125 : 25;
+    for (int col = 0; col < ncol; ++col) {
+      schur_probe_vector(c, col, S.tp[1]);
+      sm_matrix_free(S, S.tp[1], S.tp[3], false);
+      schur_probe_fill(c, col, S.tp[3]);
+    }
+    c->sm_valid = true;
+    c->sm_f32_valid = false;
+    c->sm_version++;
+  }
+}
+
+// y = S_m x on compact owned pressure vectors
+static void sm_apply(SolveState &S, const double *x, double *y, bool lowp) {
+  ifem_ctx *c = S.ctx;
+  if (sm_is_explicit(S) && c->halo.nranks > 1) {
+    v_copy(c, S.npo, x, c->xs_ext.p);
+    halo_exchange_s(c, c->xs_ext.p);
+    spmv_sm(c, c->xs_ext.p, y, lowp);
+    return;
+  }
+  // the approximate-preconditioner kinds (1, 3) also stream S_m in single precision: it only ever acts inside CG to
+  // 1e-3 ||v|| and the rounding (6e-8 relative) is far below the eigenvalue ratio of this Laplacian-like operator
+  if (sm_is_explicit(S)) { spmv_sm(c, x, y, lowp); return; }
+  sm_matrix_free(S, x, y, lowp);
+}
+
+// ---- multigrid V-cycle for S_m over the levels attached with ifem_mg_attach (geometric, rediscretised coarse operators).
+// Smoother: Chebyshev iteration on D^-1 S_m (D = diag S_m) over [lambda_max / ratio, 1.1 lambda_max]: no inner products, a
+// fixed polynomial, so the V-cycle (same polynomial before and after the coarse correction) is a fixed SPD operator and
+// CG may use it as its preconditioner.  Level vectors (ctx->mg_vec, nPl + 8 each): 0 right-hand side / residual,
+// 1 solution, 2 Chebyshev direction, 3 operator product, 4 prolongated correction.  Compact owned entries come first, so
+// the same buffers serve as ghost-extended pressure vectors for the transfers.
+struct MgSm {
+  std::vector<SolveState> L; // level 0 = the context being solved
+  bool lowp = false;
+  int nu = 2;
+  double ratio = 4.0;
+};
+
+// geometry blocks, S_m, its diagonal and the eigenvalue bound of every level; cheap when nothing changed
+static void mg_sm_setup(MgSm &M, int use_nonzero) {
+  for (size_t l = 0; l < M.L.size(); ++l) {
+    SolveState &S = M.L[l];
+    ifem_ctx *c = S.ctx;
+    if (l > 0) { // coarse levels are rediscretised: B, B^T, M_p, diag(M_u) of the level's own mesh and constraint set
+      launch_ins_assemble_geometry(c, S.P, use_nonzero);
+      sm_ensure(S);
+    }
+    for (auto &v : c->mg_vec)
+      if ((int64_t)v.n < c->nPl + 8) { v.alloc((size_t)c->nPl + 8); IFEM_HIP_CHECK(hipMemsetAsync(v.p, 0, v.n * sizeof(double), c->stream)); }
+    if (c->sm_mg_version == c->sm_version && c->sm_lmax > 0) continue;
+    if ((int64_t)c->sm_dinv.n != c->nPo) c->sm_dinv.alloc((size_t)c->nPo);
+    scalar_diag(c, c->Sm, c->Sm.val.p, c->sm_dinv.p); // owned rows; the diagonal entry has a local column id on every layout
+    vec_recip(c, S.npo, c->sm_dinv.p);
+    // largest eigenvalue of D^-1 S_m: power iteration from a fixed rough vector (set-up only: host-synchronised norms)
+    double *x = c->mg_vec[1].p, *y = c->mg_vec[3].p;
+    vec_rough(c, S.npo, int64_t(c->halo.rank) * 1000003, x);
+    double lam = 0;
+    for (int it = 0; it < 14; ++it) {
+      double nx = v_dot(c, S.npo, x, x);
+      allreduce_sum(c, &nx, 1);
+      if (!(nx > 0)) break;
+      v_scale(c, S.npo, 1.0 / std::sqrt(nx), x);
+      sm_apply(S, x, y, false);
+      vec_mul(c, S.npo, c->sm_dinv.p, y, y);
+      double ny = v_dot(c, S.npo, y, y);
+      allreduce_sum(c, &ny, 1);
+      lam = std::sqrt(ny);
+      v_copy(c, S.npo, y, x);
+    }
+    c->sm_lmax = lam > 0 ? lam : 1.0;
+    c->sm_mg_version = c->sm_version;
+  }
+}
+
+// nsteps Chebyshev steps on S x = b from the pair (x, r = b - S x); with keep_r the residual is kept up to date on exit
+// (one operator product per step), without it the last product is skipped.  lo / hi: target interval of D^-1 S.
+static void mg_sm_smooth(MgSm &M, size_t l, int nsteps, double lo, double hi, double *x, double *r, bool keep_r) {
+  SolveState &S = M.L[l];
+  ifem_ctx *c = S.ctx;
+  double *d = c->mg_vec[2].p, *t = c->mg_vec[3].p;
+  const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+  double rho_old = 1.0 / sigma;
+  cheb_init(c, S.npo, 1.0 / theta, c->sm_dinv.p, r, d);
+  for (int k = 0; k < nsteps; ++k) {
+    const bool last = k == nsteps - 1;
+    if (last && !keep_r) { v_axpy(c, S.npo, 1.0, d, x); break; }
+    sm_apply(S, d, t, M.lowp);
+    const double rho_new = 1.0 / (2.0 * sigma - rho_old);
+    // x += d; r -= S d; d = rho_new rho_old d + (2 rho_new / delta) D^-1 r   (the new d is unused after the last step)
+    cheb_step(c, S.npo, rho_new * rho_old, 2.0 * rho_new / delta, c->sm_dinv.p, t, x, r, d);
+    rho_old = rho_new;
+  }
+}
+
+// level l: mg_vec[1] = V(mg_vec[0]); mg_vec[0] is overwritten by the residual
+static void mg_sm_vcycle(MgSm &M, size_t l) {
+  SolveState &S = M.L[l];
+  ifem_ctx *c = S.ctx;
+  double *r = c->mg_vec[0].p, *x = c->mg_vec[1].p;
+  const double hi = 1.1 * c->sm_lmax;
+  v_zero(c, S.npo, x);
+  if (l + 1 == M.L.size()) { // coarsest level: a longer polynomial over a wide interval stands in for a direct solve
+    mg_sm_smooth(M, l, 30, hi / 900.0, hi, x, r, false);
+    return;
+  }
+  const double lo = hi / M.ratio;
+  mg_sm_smooth(M, l, M.nu, lo, hi, x, r, true);
+  // restriction r_c = P^T r: gather per LOCAL coarse node from the owned fine nodes, ghost rows travel to their owners
+  SolveState &Sc = M.L[l + 1];
+  ifem_ctx *cc = Sc.ctx;
+  mg_csr_apply(c, c->mg_Rp, r, cc->mg_vec[0].p, false);
+  halo_reverse_add_p(cc, cc->mg_vec[0].p);
+  mg_sm_vcycle(M, l + 1);
+  // prolongation e = P x_c from the ghost-extended coarse correction, then x += e, r -= S e
+  halo_exchange_p(cc, cc->mg_vec[1].p);
+  double *e = c->mg_vec[4].p, *t = c->mg_vec[3].p;
+  mg_csr_apply(c, c->mg_Pp, cc->mg_vec[1].p, e, false);
+  sm_apply(S, e, t, M.lowp);
+  v_axpy(c, S.npo, 1.0, e, x);
+  v_axpy(c, S.npo, -1.0, t, r);
+  mg_sm_smooth(M, l, M.nu, lo, hi, x, r, false);
+}
+
+// CG preconditioned by one V-cycle, zero initial guess, absolute tolerance on the true residual ||b - S x||_2 (the
+// reference's stopping rule for CG(S_m), mpi_insim.cpp:88-89)
+static int pcg_mg_sm(MgSm &M, const double *b, double *x, double tol, int maxit, double *r, double *p, double *q) {
+  SolveState &S = M.L[0];
+  ifem_ctx *c = S.ctx;
+  auto dot2 = [&](const double *a1, const double *b1, const double *a2, const double *b2, double *out) {
+    out[0] = v_dot(c, S.npo, a1, b1);
+    out[1] = v_dot(c, S.npo, a2, b2);
+    allreduce_sum(c, out, 2);
+  };
+  double *zin = c->mg_vec[0].p, *z = c->mg_vec[1].p;
+  v_zero(c, S.npo, x);
+  v_copy(c, S.npo, b, r);
+  double d2[2];
+  dot2(r, r, r, r, d2);
+  double rr = d2[0], rz = 0;
+  int it = 0;
+  while (std::sqrt(rr) > tol && it < maxit) {
+    v_copy(c, S.npo, r, zin);
+    mg_sm_vcycle(M, 0);
+    double rz_new[2];
+    dot2(r, z, r, z, rz_new);
+    if (it == 0) v_copy(c, S.npo, z, p);
+    else v_axpby(c, S.npo, 1.0, z, rz_new[0] / rz, p);
+    rz = rz_new[0];
+    sm_apply(S, p, q, M.lowp);
+    double pq[2];
+    dot2(p, q, p, q, pq);
+    const double al = rz / pq[0];
+    v_axpy(c, S.npo, al, p, x);
+    v_axpy(c, S.npo, -al, q, r);
+    dot2(r, r, r, r, d2);
+    rr = d2[0];
+    ++it;
+    if (!(rr == rr)) break; // NaN guard
+  }
+  return it;
+}
+
+static void carve_workspace(SolveState &S, bool krylov = true);
+
 static void precond_vmult(SolveState &S, const double *src, double *dst) {
   ifem_ctx *c = S.ctx;
   const ifem_ins_params *P = S.P;
@@ -354,55 +549,33 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   v_scale(c, S.npo, -(P->viscosity + P->grad_div * P->rho), tmp);
   IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
   S.st.t_cg_mp_ms += ck.ms();
-  // CG for Sm (:86-112): S_m = B diag(M_u)^-1 B^T applied matrix-free
+  // CG for Sm (:86-112)
   Clock ck2;
-  const bool multi = c->halo.nranks > 1;
-  const bool explicit_sm = o->explicit_schur && (!multi || c->halo.has_s);
   const bool lowp_all = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF;
-  // S_m = B diag(M_u)^-1 B^T applied with two SpMVs (ghost refreshes in between)
-  auto sm_matrix_free = [&](const double *x, double *y, bool lowp) {
-    const double *xe; extend_p(S, x, &xe);
-    if (lowp) spmv_bt_f32(c, xe, S.tu); else spmv_bt(c, xe, S.tu);
-    vec_mul(c, S.nuo, c->dinvMu.p, S.tu, S.tu);
-    const double *te; extend_u(S, S.tu, &te);
-    if (lowp) spmv_b_f32(c, te, y); else spmv_b(c, te, y);
-  };
-  if (explicit_sm && !multi) { // BlockSchurPreconditioner ctor (:44-49): S_m assembled once per solve()
-    if (c->Sm.n_rows == 0) build_schur_pattern(c);
-    schur_numeric(c);
-  }
-  if (explicit_sm && multi) { // same matrix, distributed: pattern from the pressure lattice, values by probing
-    if (c->Sm.n_rows == 0 && c->nPo) build_schur_pattern_box(c);
-    if ((int64_t)c->xs_ext.n < c->halo.n_s_cols) c->xs_ext.alloc(c->halo.n_s_cols);
-    if (!c->sm_valid) {
-      const int ncol = c->dim == 3 ? 125 : 25;
-      for (int col = 0; col < ncol; ++col) {
-        schur_probe_vector(c, col, r);
-        sm_matrix_free(r, q, false);
-        schur_probe_fill(c, col, q);
-      }
-      c->sm_valid = true;
-      c->sm_f32_valid = false;
+  sm_ensure(S);
+  OpFn sm = [&](const double *x, double *y) { sm_apply(S, x, y, lowp_all); };
+  // multigrid-preconditioned CG when coarser levels are attached (every level needs its S_m explicitly: Jacobi smoothing)
+  bool use_mg = o->sm_mg && c->mg_coarse && sm_is_explicit(S);
+  MgSm M;
+  if (use_mg) {
+    M.lowp = lowp_all; M.nu = std::max(1, o->mg_smooth); M.ratio = std::max(1.5, o->mg_cheb_ratio);
+    M.L.push_back(S);
+    for (ifem_ctx *cc = c->mg_coarse; cc; cc = cc->mg_coarse) {
+      SolveState Sc{cc, P, o};
+      carve_workspace(Sc, false);
+      if (!sm_is_explicit(Sc)) { use_mg = false; break; }
+      M.L.push_back(Sc);
     }
   }
-  OpFn sm = [&](const double *x, double *y) {
-    if (explicit_sm && multi) {
-      v_copy(c, S.npo, x, c->xs_ext.p);
-      halo_exchange_s(c, c->xs_ext.p);
-      spmv_sm(c, c->xs_ext.p, y, lowp_all);
-      return;
-    }
-    // the approximate-preconditioner kinds (1, 3) also stream S_m in single precision: it only ever acts inside CG to
-    // 1e-3 ||v|| and the rounding (6e-8 relative) is far below the eigenvalue ratio of this Laplacian-like operator
-    if (explicit_sm) { spmv_sm(c, x, y, lowp_all); return; }
-    sm_matrix_free(x, y, lowp_all); // several ranks without the 2-deep halo plan (general meshes)
-  };
-  // (Jacobi on S_m was measured too: 176 instead of 172 iterations -- its diagonal is nearly constant -- so CG stays plain)
-  if (dev_cg)
+  if (use_mg) {
+    mg_sm_setup(M, c->asm_constraint_set);
+    S.st.cg_sm_iters += pcg_mg_sm(M, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, S.tp[1], S.tp[2], S.tp[3]);
+    S.st.sm_mg_levels = (uint32_t)M.L.size();
+  } else if (dev_cg) // (Jacobi on S_m was measured too: 176 instead of 172 iterations -- its diagonal is nearly constant)
     S.st.cg_sm_iters += cg_device(c, S.npo, sm, nullptr, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, S.tp[1], S.tp[2],
                                   S.tp[3], S.tp[4], 4);
   else
-  S.st.cg_sm_iters += cg(c, S.npo, sm, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, r, p, q, pdot);
+    S.st.cg_sm_iters += cg(c, S.npo, sm, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, r, p, q, pdot);
   v_axpby(c, S.npo, 1.0, tmp, -P->rho / P->dt, dst1);
   // utmp = src0 - B^T dst1 (:116-120)
   {
@@ -453,7 +626,7 @@ static void grow_inner_basis(ifem_ctx *c, int64_t need) {
   IFEM_HIP_CHECK(hipMemsetAsync(c->innerV.p, 0, c->innerV.n * sizeof(double), c->stream));
 }
 
-static void carve_workspace(SolveState &S) {
+static void carve_workspace(SolveState &S, bool krylov) {
   ifem_ctx *c = S.ctx;
   const int64_t nul = c->dim * c->nUl, npl = c->nPl;
   S.nuo = c->dim * c->nUo; S.npo = c->nPo; S.n = S.nuo + S.npo;
@@ -468,6 +641,7 @@ static void carve_workspace(SolveState &S) {
   S.inner_z = p; p += nul;
   for (int i = 0; i < 6; ++i) { S.tp[i] = p; p += npl; }
   S.outer_w = p;
+  if (!krylov) return; // a coarse multigrid level: vector scratch only
   const int m = S.o->fgmres_restart, mi = S.o->inner_restart;
   if ((int64_t)c->krylovV.n < (int64_t)(m + 1) * basis_ld(S.ctx, S.n)) c->krylovV.alloc((int64_t)(m + 1) * basis_ld(S.ctx, S.n));
   if ((int64_t)c->krylovZ.n < (int64_t)m * basis_ld(S.ctx, S.n)) c->krylovZ.alloc((int64_t)m * basis_ld(S.ctx, S.n));

@@ -80,6 +80,7 @@ class FluidSolver:
                                                           C.byref(self.h)))
             return
         self.dim = len(reps)
+        self.reps = tuple(int(v) for v in reps)
         r = np.ascontiguousarray(reps, np.uint32)
         a, b = np.ascontiguousarray(p0, float), np.ascontiguousarray(p1, float)
         self.h = C.c_void_p()
@@ -173,6 +174,14 @@ class FluidSolver:
         idbuf = None if nccl_unique_id is None else np.ascontiguousarray(nccl_unique_id, np.uint8)
         self._chk(self.L.ifemx_set_partition(self.h, Pa.ctypes.data_as(C.c_void_p), rank,
                                              None if idbuf is None else idbuf.ctypes.data_as(C.c_void_p), local_world))
+
+    def attach_coarse(self, coarse):
+        """ifem_mg_attach: `coarse` is the same problem on a coarser box mesh (nested, ratio 1 or 2 per direction, same
+        partition).  Builds the pressure-node prolongation from the two lattices and keeps `coarse` alive."""
+        tf, tc = self.partition_tables(), coarse.partition_tables()
+        Pp = capi.box_prolongation(self.reps, coarse.reps, 1, tf["l2g_p"][:tf["n_pnodes_owned"]], tc["l2g_p"])
+        capi.mg_attach(self.L, self.ctx, coarse.ctx, Pp)
+        self._coarse = coarse
 
     def set_node_order(self, morton=True):
         self._chk(self.L.ifemx_set_node_order(self.h, int(morton)))
