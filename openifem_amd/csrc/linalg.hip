@@ -260,6 +260,9 @@ __global__ void k_csr_diag(int64_t n_rows, const int64_t *__restrict__ rp, const
     if (v == row) { out = val[rs + mid]; break; }
     if (v < row) lo = mid + 1; else hi = mid - 1;
   }
+  if (lo > hi) // not found by bisection: the distributed S_m keeps its columns in lattice-window order, not sorted by id
+    for (int64_t k = rs; k < rp[row + 1]; ++k)
+      if (col[k] == row) { out = val[k]; break; }
   d[row] = out;
 }
 

@@ -76,3 +76,166 @@ void vec_rough(ifem_ctx *ctx, int64_t n, int64_t offset, double *x) {
 }
 
 } // namespace ifem
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Node-block diagonal of A_uu without the assembled matrix: the dim x dim blocks Ke[(a,.),(a,.)] of every cell summed per
+// node, with the constraint rule of the assembly (a constrained dof keeps |Ke_rr| on its diagonal, its row and
+// column vanish), then inverted: the block-Jacobi data of a COARSE multigrid level, where nothing is assembled.  Same
+// integrand as apply_mf.hip / assemble*.hip at the evaluation point ctx->mf_eval.  One wavefront per cell.
+#include "assemble_common.hpp"
+
+namespace ifem {
+
+struct DiagArgs {
+  int64_t n_cells, nUo;
+  const double *vcoords;
+  const int32_t *cell_unodes;
+  const uint8_t *is_c;
+  const double *eval;
+  double *out; // [nUo][DIM*DIM], zeroed
+  double mu, rho, gamma, inv_dt;
+  int conv;
+  Tab1D t;
+};
+
+template <int DIM, int KV>
+__global__ __launch_bounds__(256) void k_uu_diag(DiagArgs A) {
+  constexpr int N1 = KV + 1, NN = (DIM == 2) ? N1 * N1 : N1 * N1 * N1, NV = 1 << DIM;
+  __shared__ double sX[4][NV * DIM], sJi[4][NN * DIM * DIM], sW[4][NN], sU[4][NN * DIM], sGu[4][NN * DIM * DIM], sE[4][NN * DIM];
+  __shared__ int32_t sNode[4][NN];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t cell = int64_t(blockIdx.x) * 4 + wave;
+  const bool active = cell < A.n_cells;
+  const int64_t cc = active ? cell : 0;
+  if (lane < NN) {
+    const int32_t nd = A.cell_unodes[cc * NN + lane];
+    sNode[wave][lane] = nd;
+    for (int c = 0; c < DIM; ++c) sE[wave][lane * DIM + c] = A.conv ? A.eval[int64_t(DIM) * nd + c] : 0.0;
+  }
+  if (lane < NV * DIM) sX[wave][lane] = A.vcoords[cc * NV * DIM + lane];
+  __syncthreads();
+  auto shape = [&](int q, int a, double &N, double *dr) { // value and reference gradient of node a at Gauss point q
+    int qi[3], ai[3];
+    qi[0] = q % N1; qi[1] = (q / N1) % N1; qi[2] = q / (N1 * N1);
+    ai[0] = a % N1; ai[1] = (a / N1) % N1; ai[2] = a / (N1 * N1);
+    double n[3] = {1, 1, 1}, d[3] = {0, 0, 0};
+    for (int e = 0; e < DIM; ++e) { n[e] = A.t.N[qi[e] * N1 + ai[e]]; d[e] = A.t.dN[qi[e] * N1 + ai[e]]; }
+    N = n[0] * n[1] * n[2];
+    dr[0] = d[0] * n[1] * n[2]; dr[1] = n[0] * d[1] * n[2]; dr[2] = n[0] * n[1] * d[2];
+  };
+  if (lane < NN) { // lane = quadrature point: Jacobian of the d-linear map, fields of the evaluation point
+    const int q = lane;
+    int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
+    double L[3][2], J[DIM * DIM], Ji[DIM * DIM], wq = 1;
+    for (int d = 0; d < DIM; ++d) { L[d][1] = A.t.xi[qi[d]]; L[d][0] = 1.0 - L[d][1]; wq *= A.t.w[qi[d]]; }
+    for (int i = 0; i < DIM * DIM; ++i) J[i] = 0;
+    for (int v = 0; v < NV; ++v) {
+      const int b[3] = {v & 1, (v >> 1) & 1, (v >> 2) & 1};
+      for (int d = 0; d < DIM; ++d) {
+        double g = b[d] ? 1.0 : -1.0;
+        for (int o = 0; o < DIM; ++o) if (o != d) g *= L[o][b[o]];
+        for (int e = 0; e < DIM; ++e) J[e * DIM + d] += sX[wave][v * DIM + e] * g;
+      }
+    }
+    const double det = inv_small<DIM>(J, Ji);
+    sW[wave][q] = fabs(det) * wq;
+    for (int i = 0; i < DIM * DIM; ++i) sJi[wave][q * DIM * DIM + i] = Ji[i];
+    double u[DIM], gr[DIM * DIM];
+    for (int c = 0; c < DIM; ++c) u[c] = 0;
+    for (int i = 0; i < DIM * DIM; ++i) gr[i] = 0;
+    for (int a = 0; a < NN; ++a) {
+      double N, dr[3];
+      shape(q, a, N, dr);
+      for (int c = 0; c < DIM; ++c) {
+        const double uv = sE[wave][a * DIM + c];
+        u[c] += N * uv;
+        for (int e = 0; e < DIM; ++e) gr[c * DIM + e] += uv * dr[e];
+      }
+    }
+    for (int c = 0; c < DIM; ++c) {
+      sU[wave][q * DIM + c] = u[c];
+      for (int d = 0; d < DIM; ++d) { // physical gradient d_d u_c = sum_e (d^_e u_c) Ji[e][d]
+        double t = 0;
+        for (int e = 0; e < DIM; ++e) t += gr[c * DIM + e] * Ji[e * DIM + d];
+        sGu[wave][q * DIM * DIM + c * DIM + d] = t;
+      }
+    }
+  }
+  __syncthreads();
+  if (lane < NN && active) { // lane = node a: its diagonal block
+    const int a = lane;
+    double s = 0, D[DIM * DIM];
+    for (int i = 0; i < DIM * DIM; ++i) D[i] = 0;
+    for (int q = 0; q < NN; ++q) {
+      double N, dr[3], ga[DIM];
+      shape(q, a, N, dr);
+      const double *Ji = &sJi[wave][q * DIM * DIM];
+      for (int d = 0; d < DIM; ++d) {
+        double t = 0;
+        for (int e = 0; e < DIM; ++e) t += dr[e] * Ji[e * DIM + d];
+        ga[d] = t;
+      }
+      const double w = sW[wave][q];
+      double gg = 0, ug = 0;
+      for (int d = 0; d < DIM; ++d) { gg += ga[d] * ga[d]; ug += sU[wave][q * DIM + d] * ga[d]; }
+      s += w * (A.mu * gg + A.rho * N * ug + A.rho * A.inv_dt * N * N);
+      for (int c = 0; c < DIM; ++c)
+        for (int d = 0; d < DIM; ++d)
+          D[c * DIM + d] += w * (A.rho * N * N * sGu[wave][q * DIM * DIM + c * DIM + d] + A.gamma * A.rho * ga[c] * ga[d]);
+    }
+    for (int c = 0; c < DIM; ++c) D[c * DIM + c] += s;
+    const int32_t nd = sNode[wave][a];
+    if (nd < A.nUo) {
+      for (int c = 0; c < DIM; ++c)
+        for (int d = 0; d < DIM; ++d) {
+          const bool rc = A.is_c && A.is_c[int64_t(DIM) * nd + c], cd = A.is_c && A.is_c[int64_t(DIM) * nd + d];
+          double v = D[c * DIM + d];
+          if (rc || cd) v = (c == d) ? fabs(v) : 0.0;
+          if (v != 0.0) unsafeAtomicAdd(&A.out[int64_t(nd) * DIM * DIM + c * DIM + d], v);
+        }
+    }
+  }
+}
+
+template <int DIM>
+__global__ void k_block_invert(int64_t n, double *__restrict__ b) {
+  const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  double D[DIM * DIM], Di[DIM * DIM];
+  for (int e = 0; e < DIM * DIM; ++e) D[e] = b[row * DIM * DIM + e];
+  bool zero = true;
+  for (int e = 0; e < DIM * DIM; ++e) zero = zero && D[e] == 0.0;
+  if (zero) for (int c = 0; c < DIM; ++c) D[c * DIM + c] = 1.0;
+  inv_small<DIM>(D, Di);
+  for (int e = 0; e < DIM * DIM; ++e) b[row * DIM * DIM + e] = Di[e];
+}
+
+// ctx->bjac := inverse node blocks of the matrix-free A_uu of this level (state: mf_eval, mf_params, active constraint set)
+void uu_block_diag_mf(ifem_ctx *ctx) {
+  if (!ctx->mf_valid) throw Error(IFEM_E_BADPARAM, "matrix-free block diagonal: no operator state on this level");
+  const int64_t n = ctx->nUo;
+  const int dim = ctx->dim;
+  if ((int64_t)ctx->bjac.n != n * dim * dim) ctx->bjac.alloc((size_t)n * dim * dim);
+  ctx->bjac_f32_valid = false;
+  if (!n) return;
+  hipStream_t s = ctx->stream;
+  IFEM_HIP_CHECK(hipMemsetAsync(ctx->bjac.p, 0, ctx->bjac.n * sizeof(double), s));
+  DiagArgs a{};
+  a.n_cells = ctx->n_cells; a.nUo = ctx->nUo;
+  a.vcoords = ctx->vcoords.p; a.cell_unodes = ctx->cell_unodes.p;
+  a.is_c = ctx->has_c[ctx->asm_constraint_set] ? ctx->is_c[ctx->asm_constraint_set].p : nullptr;
+  a.eval = ctx->mf_eval.p; a.out = ctx->bjac.p;
+  a.mu = ctx->mf_params.viscosity; a.rho = ctx->mf_params.rho; a.gamma = ctx->mf_params.grad_div; a.inv_dt = 1.0 / ctx->mf_params.dt;
+  a.conv = ctx->mf_noconv ? 0 : 1;
+  tab1d(a.t, ctx->kv);
+  const dim3 grid(unsigned((ctx->n_cells + 3) / 4)), block(256);
+  if (dim == 3 && ctx->kv == 2) hipLaunchKernelGGL((k_uu_diag<3, 2>), grid, block, 0, s, a);
+  else if (dim == 3) hipLaunchKernelGGL((k_uu_diag<3, 1>), grid, block, 0, s, a);
+  else if (ctx->kv == 2) hipLaunchKernelGGL((k_uu_diag<2, 2>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_uu_diag<2, 1>), grid, block, 0, s, a);
+  if (dim == 3) hipLaunchKernelGGL((k_block_invert<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, ctx->bjac.p);
+  else hipLaunchKernelGGL((k_block_invert<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, ctx->bjac.p);
+  IFEM_HIP_CHECK(hipGetLastError());
+}
+
+} // namespace ifem

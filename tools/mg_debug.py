@@ -1,0 +1,54 @@
+"""debug aid: CG(S_m) counts with / without multigrid on one context and on virtual ranks"""
+import ctypes as C
+import sys
+import threading
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from openifem_amd import capi, host, multigpu
+
+EXTENT = (2.0, 0.2, 0.2)
+
+
+def make(reps, P, rank, worlds, level):
+    s = host.InsIM(host.channel_prm(3), reps, (0, 0, 0), EXTENT)
+    if worlds is not None:
+        s.set_partition(P, rank, local_world=worlds[level])
+    s.setup(0)
+    return s
+
+
+def run(n, P, mg, nu=2, ratio=4.0):
+    L = capi.load()
+    world = int(np.prod(P))
+    depth = len(multigpu.coarse_level_chain(n, P, EXTENT))
+    worlds = [C.c_void_p(L.ifem_local_world_create(world)) for _ in range(depth + 1)] if world > 1 else None
+    out = [None] * world
+
+    def work(rank):
+        reps = tuple(n[d] * P[d] for d in range(3))
+        s = make(reps, P, rank, worlds, 0)
+        s._levels = multigpu.attach_levels(lambda r, lev: make(r, P, rank, worlds, lev), s, n, P, EXTENT)
+        s.channel_state()
+        if world > 1:
+            L.ifem_halo_exchange(s.ctx, capi.VEC_EVAL)
+        s.opts.ainv_kind = 3
+        s.opts.sm_mg = mg
+        s.opts.mg_smooth = nu
+        s.opts.mg_cheb_ratio = ratio
+        s.assemble(False)
+        st = s.solve(False)
+        out[rank] = (st.fgmres_iters, st.precond_applies, st.cg_sm_iters, st.sm_mg_levels, st.cg_mp_iters, st.inner_iters)
+        s.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    return out[0]
+
+
+if __name__ == "__main__":
+    for n, P in (((16, 8, 8), (1, 1, 1)), ((8, 8, 8), (2, 1, 1)), ((16, 4, 8), (1, 2, 1)), ((16, 16, 16), (1, 1, 1)), ((8, 16, 16), (2, 1, 1)), ((8, 8, 8), (2, 2, 2))):
+        for mg in (0, 1):
+            print(n, P, "mg", mg, "fgmres, applies, cg_sm, levels, cg_mp, inner =", run(n, P, mg), flush=True)
