@@ -213,12 +213,15 @@ def main():
     ap.add_argument("--cpu-cells", dest="cpu_n", default="32", help="cells per direction of the CPU baseline sample(s), comma separated (0 = skip; BASELINE.md plans 32,64 -- 64 takes several minutes)")
     ap.add_argument("--extras", type=int, default=1, help="N = 1 only: also measure cold_step (geometry blocks and S_m rebuilt, as the reference does every iteration) and time_step (a whole run_one_step Newton loop)")
     ap.add_argument("--inner-rel", type=float, default=1e-2)
-    ap.add_argument("--ainv", type=int, default=3, help="IFEM_AINV_* kind of the A_uu^-1 replacement (3 = matrix-free inner operator, 1 = fp32 inner matrix, 0 = fp64 matrix)")
+    ap.add_argument("--ainv", type=int, default=4, help="IFEM_AINV_* kind of the A_uu^-1 replacement (4 = matrix-free operator + geometric multigrid V-cycle, 3 = matrix-free inner operator + block Jacobi, 1 = fp32 inner matrix, 0 = fp64 matrix)")
     ap.add_argument("--sm-rel", type=float, default=None, help="experiment: relative tolerance of CG(S_m) inside the preconditioner (reference and default: 1e-3)")
     ap.add_argument("--mp-rel", type=float, default=None, help="experiment: relative tolerance of CG(M_p) inside the preconditioner (reference and default: 1e-6)")
     ap.add_argument("--inner-restart", type=int, default=16, help="restart length of the inner GMRES of the A_uu^-1 replacement (measured at 128^3: 8/10/12/15/20/30/45 -> 557/533/537/518/522/531/543 ms per step; 16 = one multi-dot pass of the single-precision basis; the library default is 30)")
     ap.add_argument("--tuned", type=int, default=1, help="also time the relaxed-preconditioner variant (reported as tuned_preconditioner, N = 1 only)")
     ap.add_argument("--mg", type=int, default=1, help="1 (default): attach the chain of coarser (semi-coarsened) box meshes so that CG(S_m) inside the preconditioner is multigrid-preconditioned; 0: plain CG as in the reference")
+    ap.add_argument("--inner-maxit", type=int, default=None, help="cap of the inner A_uu iterations (--ainv 4: 0 = exactly one V-cycle)")
+    ap.add_argument("--mg-smooth-u", type=int, default=None, help="smoothing steps of the A_uu V-cycle (--ainv 4)")
+    ap.add_argument("--mg-ratio-u", type=float, default=None, help="Chebyshev interval ratio of the A_uu V-cycle (--ainv 4)")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
     ap.add_argument("--outer-mf", type=int, default=0, help="experiment: apply the u-u block of the OUTER operator matrix-free too")
     ap.add_argument("--solver", default="insim", choices=["insim", "insimex"],
@@ -255,6 +258,12 @@ def main():
     if args.mp_rel is not None:
         solver.opts.mp_rel = args.mp_rel
     solver.opts.ainv_kind = args.ainv
+    if args.inner_maxit is not None:
+        solver.opts.inner_maxit = args.inner_maxit
+    if args.mg_smooth_u is not None:
+        solver.opts.mg_smooth_u = args.mg_smooth_u
+    if args.mg_ratio_u is not None:
+        solver.opts.mg_cheb_ratio_u = args.mg_ratio_u
     solver.opts.outer_matrix_free = args.outer_mf
     solver.opts.verbose = args.verbose if rank == 0 else 0
     solver.channel_state()

@@ -103,6 +103,10 @@ typedef struct {
                                          kernel on the evaluation point of the last ifem_ins_assemble): same operator
                                          as kind 0 up to fp64 rounding, ~2 kB instead of ~40 kB of HBM traffic per cell */
 
+#define IFEM_AINV_MG 4                /* inner GMRES(m) on the matrix-free A_uu (as kind 3) preconditioned by one geometric multigrid
+                                         V-cycle over the levels of ifem_mg_attach: matrix-free rediscretised operators at
+                                         the injected evaluation point, Chebyshev / node-block-Jacobi smoothing */
+
 typedef struct {
   int32_t fgmres_restart;     /* 30: deal.II SolverFGMRES default */
   int32_t fgmres_maxit;       /* 0 -> n_dofs (mpi_insim.cpp:379-380) */
@@ -111,7 +115,7 @@ typedef struct {
   double  mp_rel, mp_abs;     /* CG(M_p) 1e-6, 1e-10 (mpi_insim.cpp:73-74) */
   double  sm_rel, sm_abs;     /* CG(S_m) 1e-3, 1e-10 (mpi_insim.cpp:88-89) */
   int32_t ainv_kind;          /* IFEM_AINV_* */
-  int32_t inner_restart, inner_maxit;
+  int32_t inner_restart, inner_maxit; /* IFEM_AINV_MG: inner_maxit <= 0 makes A~^-1 exactly one V-cycle (no inner Krylov loop) */
   double  inner_rel;          /* relative residual target of the inner A_uu solve */
   int32_t explicit_schur;     /* 1: form S_m = B diag(M_u)^-1 B^T explicitly like the reference (on several GPUs this
                                  needs the 2-deep pressure halo plan of ifem_partition); 0: apply it as two SpMVs */
@@ -126,6 +130,8 @@ typedef struct {
                                  V-cycle, same stopping rule on the true residual; 0: plain CG as in the reference */
   int32_t mg_smooth;          /* 2: Chebyshev-Jacobi smoothing steps before and after the coarse correction */
   double  mg_cheb_ratio;      /* 4: the smoother targets the eigenvalues of D^-1 S_m in [lambda_max / ratio, lambda_max] */
+  int32_t mg_smooth_u;        /* 2: smoothing steps of the A_uu V-cycle (IFEM_AINV_MG) */
+  double  mg_cheb_ratio_u;    /* 4: its Chebyshev interval [lambda_max / ratio, lambda_max] of (block D)^-1 A_uu */
 } ifem_solver_opts;
 
 /* Tuning / measurement knobs of one context (defaults = the measured best; nothing here changes results beyond fp64
@@ -233,6 +239,14 @@ typedef struct {
   int64_t n_fine_p_owned, n_coarse_p_local;
   const int64_t *pp_ptr; const int32_t *pp_col; const double *pp_w; /* CSR of P_p */
   const int64_t *rp_ptr; const int32_t *rp_col; const double *rp_w; /* CSR of R_p = P_p^T */
+  /* optional (all NULL: pressure levels only): the same for the velocity NODES (applied to the dim components of a node),
+   * rows of P_u = owned velocity nodes of `fine`, columns = local velocity nodes of `coarse`, R_u = P_u^T; inj_u
+   * [n_unodes_owned of coarse]: the owned velocity node of `fine` at the same point (nested meshes: the coarse evaluation
+   * point is the fine one restricted by injection) -- enables IFEM_AINV_MG */
+  int64_t n_fine_u_owned, n_coarse_u_local;
+  const int64_t *pu_ptr; const int32_t *pu_col; const double *pu_w;
+  const int64_t *ru_ptr; const int32_t *ru_col; const double *ru_w;
+  const int32_t *inj_u;
 } ifem_mg_transfer;
 int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t);
 /* number of levels below ctx (0: none attached) */
@@ -309,6 +323,10 @@ int ifem_system_vmult(ifem_ctx *ctx, int dst, int src);
 /* y = [diag(M_u) x_u ; M_p x_p] on context vectors: the two blocks of mass_matrix the reference's preconditioner reads
  * (mpi_insim.cpp:27-49: diag of block (0,0), block (1,1)) -- test hook */
 int ifem_mass_vmult(ifem_ctx *ctx, int dst, int src);
+/* inverse dim x dim diagonal node blocks of A_uu [n_unodes_owned][dim*dim] -- test hook.  which = 0: from the assembled
+ * matrix (the block-Jacobi data of the last assembly); 1: recomputed matrix-free from the operator state of the last assembly
+ * (what a coarse multigrid level uses, mg.hip::k_uu_diag) */
+int ifem_uu_block_diag(ifem_ctx *ctx, int which, double *host_out);
 /* y_u = A_uu x_u on the velocity part of two context vectors -- test / bench hook.  variant: IFEM_AINV_GMRES_BJACOBI
  * (stored fp64 matrix), _F32 (its single-precision copy) or _MF (matrix-free) */
 int ifem_uu_vmult(ifem_ctx *ctx, int dst, int src, int variant);

@@ -68,7 +68,8 @@ class SolverOpts(C.Structure):
                 ("sm_rel", C.c_double), ("sm_abs", C.c_double), ("ainv_kind", C.c_int32),
                 ("inner_restart", C.c_int32), ("inner_maxit", C.c_int32), ("inner_rel", C.c_double),
                 ("explicit_schur", C.c_int32), ("verbose", C.c_int32), ("device_cg", C.c_int32), ("outer_matrix_free", C.c_int32),
-                ("sm_mg", C.c_int32), ("mg_smooth", C.c_int32), ("mg_cheb_ratio", C.c_double)]
+                ("sm_mg", C.c_int32), ("mg_smooth", C.c_int32), ("mg_cheb_ratio", C.c_double),
+                ("mg_smooth_u", C.c_int32), ("mg_cheb_ratio_u", C.c_double)]
 
 
 class SolveStats(C.Structure):
@@ -82,7 +83,10 @@ class SolveStats(C.Structure):
 class MgTransfer(C.Structure):
     _fields_ = [("n_fine_p_owned", C.c_int64), ("n_coarse_p_local", C.c_int64),
                 ("pp_ptr", C.c_void_p), ("pp_col", C.c_void_p), ("pp_w", C.c_void_p),
-                ("rp_ptr", C.c_void_p), ("rp_col", C.c_void_p), ("rp_w", C.c_void_p)]
+                ("rp_ptr", C.c_void_p), ("rp_col", C.c_void_p), ("rp_w", C.c_void_p),
+                ("n_fine_u_owned", C.c_int64), ("n_coarse_u_local", C.c_int64),
+                ("pu_ptr", C.c_void_p), ("pu_col", C.c_void_p), ("pu_w", C.c_void_p),
+                ("ru_ptr", C.c_void_p), ("ru_col", C.c_void_p), ("ru_w", C.c_void_p), ("inj_u", C.c_void_p)]
 
 
 class Tuning(C.Structure):
@@ -106,7 +110,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_get_timing", "ifem_set_profiling", "ifem_synchronize", "ifem_set_hanging_constraints", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
            "ifem_scns_assemble", "ifem_scns_solve", "ifem_scns_newton_step", "ifem_imex_assemble", "ifem_imex_solve",
            "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof",
-           "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth"]
+           "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -179,6 +183,7 @@ def load():
     L.ifem_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
     L.ifem_mg_attach.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(MgTransfer)]
     L.ifem_mg_depth.argtypes = [C.c_void_p]
+    L.ifem_uu_block_diag.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.ifem_abi_sizeof.argtypes = [C.c_int]
     L.ifem_abi_sizeof.restype = C.c_int64
     _lib = L
@@ -219,15 +224,27 @@ def make_scns_params(mu, rho, dt, solid_rho=1.0, g=(0, 0, 0), neumann=None, form
     return p
 
 
-def mg_attach(L, fine_h, coarse_h, P_p):
-    """ifem_mg_attach from a scipy.sparse prolongation (rows: owned fine pressure nodes, columns: local coarse pressure nodes)"""
-    Pm = P_p.tocsr()
+def _csr_pair(Pm):
+    Pm = Pm.tocsr()
     Pm.sort_indices()
     Rm = Pm.T.tocsr()
     Rm.sort_indices()
-    keep = [np.ascontiguousarray(Pm.indptr, np.int64), np.ascontiguousarray(Pm.indices, np.int32), np.ascontiguousarray(Pm.data, float),
+    return [np.ascontiguousarray(Pm.indptr, np.int64), np.ascontiguousarray(Pm.indices, np.int32), np.ascontiguousarray(Pm.data, float),
             np.ascontiguousarray(Rm.indptr, np.int64), np.ascontiguousarray(Rm.indices, np.int32), np.ascontiguousarray(Rm.data, float)]
-    t = MgTransfer(Pm.shape[0], Pm.shape[1], *[_ptr(a) for a in keep])
+
+
+def mg_attach(L, fine_h, coarse_h, P_p, P_u=None, inj_u=None):
+    """ifem_mg_attach from scipy.sparse prolongations (rows: owned fine nodes, columns: local coarse nodes); P_u / inj_u
+    (velocity nodes, coincident fine node of every owned coarse node) are optional"""
+    keep = _csr_pair(P_p)
+    t = MgTransfer()
+    t.n_fine_p_owned, t.n_coarse_p_local = P_p.shape
+    (t.pp_ptr, t.pp_col, t.pp_w, t.rp_ptr, t.rp_col, t.rp_w) = [_ptr(a) for a in keep]
+    if P_u is not None:
+        ku = _csr_pair(P_u) + [np.ascontiguousarray(inj_u, np.int32)]
+        t.n_fine_u_owned, t.n_coarse_u_local = P_u.shape
+        (t.pu_ptr, t.pu_col, t.pu_w, t.ru_ptr, t.ru_col, t.ru_w, t.inj_u) = [_ptr(a) for a in ku]
+        keep += ku
     rc = L.ifem_mg_attach(fine_h, coarse_h, C.byref(t))
     if rc < 0:
         raise IfemError(rc, L.ifem_last_error().decode())
@@ -294,6 +311,25 @@ def box_prolongation(reps_fine, reps_coarse, degree, l2g_fine_owned, l2g_coarse_
         vals.append(wgt[sel])
     return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
                          shape=(len(g), len(l2g_coarse_local)))
+
+
+def box_injection(reps_fine, reps_coarse, degree, l2g_coarse_owned, l2g_fine_owned):
+    """for every given coarse lattice node the position in l2g_fine_owned of the fine node at the same point"""
+    dim = len(reps_fine)
+    Nf = [degree * r + 1 for r in reps_fine]
+    Nc = [degree * r + 1 for r in reps_coarse]
+    rem = np.asarray(l2g_coarse_owned, np.int64).copy()
+    gid, stride = np.zeros(len(rem), np.int64), 1
+    for d in range(dim):
+        ratio = reps_fine[d] // reps_coarse[d]
+        gid += (rem % Nc[d]) * ratio * stride
+        rem //= Nc[d]
+        stride *= Nf[d]
+    g2l = -np.ones(int(np.prod(Nf)), np.int64)
+    g2l[np.asarray(l2g_fine_owned, np.int64)] = np.arange(len(l2g_fine_owned))
+    out = g2l[gid]
+    assert (out >= 0).all(), "the fine node under an owned coarse node is not owned by the same rank"
+    return out.astype(np.int32)
 
 
 class Context:
@@ -447,6 +483,13 @@ class Context:
         self.vec_set(VEC_TMP, x)
         self._chk(self.L.ifem_uu_vmult(self.h, VEC_UPDATE, VEC_TMP, variant))
         return self.vec_get(VEC_UPDATE)
+
+    def uu_block_diag(self, which):
+        """inverse diagonal node blocks of A_uu [n_unodes_owned, dim, dim]: 0 from the assembled matrix, 1 matrix-free"""
+        n_own = (self.n_owned - (self.n_local - self.n_u)) // self.dim if self.n_owned != self.n_local else self.n_u // self.dim
+        out = np.zeros((n_own, self.dim, self.dim))
+        self._chk(self.L.ifem_uu_block_diag(self.h, which, _ptr(out)))
+        return out
 
     def mass_vmult(self, x):
         """[diag(M_u) x_u ; M_p x_p]"""

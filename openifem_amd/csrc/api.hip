@@ -54,6 +54,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
   o->device_cg = 1;
   o->verbose = 0;
   o->sm_mg = 1; o->mg_smooth = 2; o->mg_cheb_ratio = 4.0;
+  o->mg_smooth_u = 2; o->mg_cheb_ratio_u = 4.0;
 }
 
 void ifem_default_tuning(ifem_tuning *t) {
@@ -212,9 +213,33 @@ int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t) 
   fine->mg_Rp.ptr.upload(t->rp_ptr, (size_t)coarse->nPl + 1, s);
   fine->mg_Rp.col.upload(t->rp_col, (size_t)nnz, s);
   fine->mg_Rp.w.upload(t->rp_w, (size_t)nnz, s);
+  fine->mg_Pu.n_rows = fine->mg_Ru.n_rows = 0;
+  if (t->pu_ptr) { // velocity-node transfers: optional
+    if (!t->pu_col || !t->pu_w || !t->ru_ptr || !t->ru_col || !t->ru_w || !t->inj_u) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: incomplete velocity transfer tables");
+    if (t->n_fine_u_owned != fine->nUo || t->n_coarse_u_local != coarse->nUl)
+      throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: P_u needs one row per owned fine velocity node, R_u one per local coarse velocity node");
+    const int64_t nu = t->pu_ptr[fine->nUo];
+    if (t->pu_ptr[0] != 0 || t->ru_ptr[0] != 0 || t->ru_ptr[coarse->nUl] != nu) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: R_u is not the transpose of P_u");
+    for (int64_t k = 0; k < nu; ++k) {
+      if (t->pu_col[k] < 0 || t->pu_col[k] >= coarse->nUl) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: P_u column out of range");
+      if (t->ru_col[k] < 0 || t->ru_col[k] >= fine->nUo) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: R_u column out of range");
+    }
+    for (int64_t i = 0; i < coarse->nUo; ++i)
+      if (t->inj_u[i] < 0 || t->inj_u[i] >= fine->nUo) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: inj_u must name owned fine nodes");
+    fine->mg_Pu.n_rows = fine->nUo;
+    fine->mg_Pu.ptr.upload(t->pu_ptr, (size_t)fine->nUo + 1, s);
+    fine->mg_Pu.col.upload(t->pu_col, (size_t)nu, s);
+    fine->mg_Pu.w.upload(t->pu_w, (size_t)nu, s);
+    fine->mg_Ru.n_rows = coarse->nUl;
+    fine->mg_Ru.ptr.upload(t->ru_ptr, (size_t)coarse->nUl + 1, s);
+    fine->mg_Ru.col.upload(t->ru_col, (size_t)nu, s);
+    fine->mg_Ru.w.upload(t->ru_w, (size_t)nu, s);
+    fine->mg_inj_u.upload(t->inj_u, (size_t)coarse->nUo, s);
+  }
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
   fine->mg_coarse = coarse;
   fine->sm_mg_version = -1;
+  fine->uu_mg_version = -1;
   // one stream for the whole chain: the V-cycle walks up and down the levels and every launch must stay in order
   for (ifem_ctx *c = coarse; c; c = c->mg_coarse) {
     if (c->stream == s) continue;
@@ -525,6 +550,26 @@ int ifem_mass_vmult(ifem_ctx *ctx, int dst, int src) {
   if (ctx->halo.nranks > 1) halo_exchange_p(ctx, xe);
   spmv_mp(ctx, xe, ctx->vec[dst].p + nuo);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+
+int ifem_uu_block_diag(ifem_ctx *ctx, int which, double *host_out) {
+  IFEM_API_BEGIN
+  if (!ctx->assembled || !host_out) throw Error(IFEM_E_BADPARAM, "ifem_uu_block_diag after an assembly, with an output buffer");
+  const size_t n = (size_t)ctx->nUo * ctx->dim * ctx->dim;
+  if (which == 1) {
+    std::vector<double> keep(n);
+    IFEM_HIP_CHECK(hipMemcpyAsync(keep.data(), ctx->bjac.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    uu_block_diag_mf(ctx);
+    IFEM_HIP_CHECK(hipMemcpyAsync(host_out, ctx->bjac.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    IFEM_HIP_CHECK(hipMemcpyAsync(ctx->bjac.p, keep.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->bjac_f32_valid = false;
+  } else {
+    IFEM_HIP_CHECK(hipMemcpyAsync(host_out, ctx->bjac.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
   IFEM_API_END
 }
 

@@ -44,6 +44,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
     ctx->mf_params = *p;
     ctx->mf_valid = true;
     ctx->mf_noconv = imex != 0;
+    ctx->asm_version++;
   }
   // B, B^T, M_p and diag(M_u) depend on the mesh and on WHICH dofs are constrained, not on the solution, the parameters
   // or the inhomogeneities: an assembly whose constrained-dof set equals that of the previous one (zero_ and

@@ -210,9 +210,12 @@ struct ifem_ctx {
   // multigrid (ifem_mg_attach): the next coarser level (not owned) and the pressure transfers to it; per-level state of
   // the S_m V-cycle: 1/diag(S_m), largest eigenvalue of D^-1 S_m, scratch vectors [nPl]
   ifem_ctx *mg_coarse = nullptr;
-  ifem::MgCsr mg_Pp, mg_Rp;
-  ifem::DBuf<double> sm_dinv, mg_vec[6];
-  double sm_lmax = 0;
+  ifem::MgCsr mg_Pp, mg_Rp, mg_Pu, mg_Ru;
+  ifem::DBuf<int32_t> mg_inj_u; // [nUo of the coarse level] coincident owned velocity node of this level
+  ifem::DBuf<double> sm_dinv, mg_vec[6], mgu_vec[5];
+  double sm_lmax = 0, uu_lmax = 0;
+  int64_t asm_version = 0, uu_mg_version = -1; // full assemblies done / the assembly the A_uu V-cycle data belong to
+  double uu_lmax_key[6] = {0, 0, 0, 0, 0, -1};  // (mu, rho, gamma, dt, noconv, constrained-dof set) of the cached eigenvalue bound
   int64_t sm_version = 0, sm_mg_version = -1; // S_m values rebuilt / the version the V-cycle data belong to
   // explicit T_pp = A_pp - A_pv Binv A_vp on the pattern of Sm and its dense LU (tpp.hip)
   ifem::DBuf<double> Tpp, tpp_diag, tpp_dense;
@@ -242,7 +245,7 @@ struct ifem_ctx {
   // vectors
   ifem::DBuf<double> vec[IFEM_N_VECS];
   // Krylov workspace
-  ifem::DBuf<double> krylovV, krylovZ, innerV, work;
+  ifem::DBuf<double> krylovV, krylovZ, innerV, innerZ, work;
   ifem::DBuf<double> scal; // device scalars for reductions
   ifem::DBuf<double> partials; // per-block partial sums of the fused dot products [64][4096]
   double *h_scal = nullptr; // pinned host mirror

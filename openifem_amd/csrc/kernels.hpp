@@ -107,6 +107,11 @@ void cheb_init(ifem_ctx *ctx, int64_t n, double c0, const double *dinv, const do
 void cheb_step(ifem_ctx *ctx, int64_t n, double a, double b, const double *dinv, const double *t, double *x, double *r, double *d);
 void vec_recip(ifem_ctx *ctx, int64_t n, double *d);
 void vec_rough(ifem_ctx *ctx, int64_t n, int64_t offset, double *x);
+void uu_block_diag_mf(ifem_ctx *ctx); // ctx->bjac := inverse node blocks of the matrix-free A_uu (coarse multigrid levels)
+void mg_csr_apply_nodes(ifem_ctx *ctx, const MgCsr &M, const double *x, const uint8_t *flag_in, const uint8_t *flag_out, double *y);
+void mg_inject_nodes(ifem_ctx *ctx, int64_t n_nodes, const int32_t *inj, const double *fine, double *coarse);
+void cheb_init_block(ifem_ctx *ctx, double c0, const double *r, double *d);
+void cheb_step_block(ifem_ctx *ctx, double a, double b, const double *t, double *x, double *r, double *d);
 
 // all-reduce helpers (identity for a single rank)
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n);

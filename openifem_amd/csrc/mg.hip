@@ -239,3 +239,107 @@ void uu_block_diag_mf(ifem_ctx *ctx) {
 }
 
 } // namespace ifem
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Velocity-space pieces of the A_uu V-cycle: node-based CSR transfers acting on the dim components of a node, masked by
+// the Dirichlet flags of the two levels (a constrained dof is a decoupled 1 x 1 equation on its level: it neither sends
+// nor receives corrections), injection of the evaluation point, and the Chebyshev updates with the inverse node blocks.
+namespace ifem {
+
+// y[row][c] = flag_out ? 0 : sum_k w_k (flag_in[col_k][c] ? 0 : x[col_k][c])
+template <int DIM>
+__global__ __launch_bounds__(256) void k_mg_csr_nodes(int64_t n_rows, const int64_t *__restrict__ ptr, const int32_t *__restrict__ col,
+                                                      const double *__restrict__ w, const double *__restrict__ x,
+                                                      const uint8_t *__restrict__ flag_in, const uint8_t *__restrict__ flag_out,
+                                                      double *__restrict__ y) {
+  for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n_rows; r += int64_t(gridDim.x) * blockDim.x) {
+    double s[DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) s[c] = 0;
+    for (int64_t k = ptr[r]; k < ptr[r + 1]; ++k) {
+      const int64_t j = int64_t(col[k]) * DIM;
+      const double wk = w[k];
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) s[c] += (flag_in && flag_in[j + c]) ? 0.0 : wk * x[j + c];
+    }
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) y[r * DIM + c] = (flag_out && flag_out[r * DIM + c]) ? 0.0 : s[c];
+  }
+}
+
+void mg_csr_apply_nodes(ifem_ctx *ctx, const MgCsr &M, const double *x, const uint8_t *flag_in, const uint8_t *flag_out, double *y) {
+  if (!M.n_rows) return;
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_mg_csr_nodes<3>), dim3(mgrid(M.n_rows)), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, M.w.p, x, flag_in, flag_out, y);
+  else
+    hipLaunchKernelGGL((k_mg_csr_nodes<2>), dim3(mgrid(M.n_rows)), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, M.w.p, x, flag_in, flag_out, y);
+}
+
+__global__ void k_mg_inject(int64_t n_nodes, int dim, const int32_t *__restrict__ inj, const double *__restrict__ fine,
+                            double *__restrict__ coarse) {
+  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < n_nodes * dim; t += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t i = t / dim;
+    const int c = int(t - i * dim);
+    coarse[t] = fine[int64_t(inj[i]) * dim + c];
+  }
+}
+void mg_inject_nodes(ifem_ctx *ctx, int64_t n_nodes, const int32_t *inj, const double *fine, double *coarse) {
+  if (n_nodes) hipLaunchKernelGGL(k_mg_inject, dim3(mgrid(n_nodes * ctx->dim)), dim3(256), 0, ctx->stream, n_nodes, ctx->dim, inj, fine, coarse);
+}
+
+// d = c0 B r per node (B = inverse diagonal block)
+template <int DIM>
+__global__ void k_cheb_init_block(int64_t n_nodes, double c0, const double *__restrict__ bj, const double *__restrict__ r,
+                                  double *__restrict__ d) {
+  const int64_t nd = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (nd >= n_nodes) return;
+  double rv[DIM];
+#pragma unroll
+  for (int j = 0; j < DIM; ++j) rv[j] = r[nd * DIM + j];
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) {
+    double t = 0;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) t += bj[nd * DIM * DIM + i * DIM + j] * rv[j];
+    d[nd * DIM + i] = c0 * t;
+  }
+}
+// x += d; r -= t; d = a d + b B r
+template <int DIM>
+__global__ void k_cheb_step_block(int64_t n_nodes, double a, double b, const double *__restrict__ bj, const double *__restrict__ t,
+                                  double *__restrict__ x, double *__restrict__ r, double *__restrict__ d) {
+  const int64_t nd = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (nd >= n_nodes) return;
+  double rv[DIM], dv[DIM];
+#pragma unroll
+  for (int j = 0; j < DIM; ++j) {
+    const int64_t i = nd * DIM + j;
+    dv[j] = d[i];
+    rv[j] = r[i] - t[i];
+    x[i] += dv[j];
+    r[i] = rv[j];
+  }
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) {
+    double z = 0;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) z += bj[nd * DIM * DIM + i * DIM + j] * rv[j];
+    d[nd * DIM + i] = a * dv[i] + b * z;
+  }
+}
+void cheb_init_block(ifem_ctx *ctx, double c0, const double *r, double *d) {
+  const int64_t n = ctx->nUo;
+  if (!n) return;
+  const dim3 g(unsigned((n + 255) / 256)), b(256);
+  if (ctx->dim == 3) hipLaunchKernelGGL((k_cheb_init_block<3>), g, b, 0, ctx->stream, n, c0, ctx->bjac.p, r, d);
+  else hipLaunchKernelGGL((k_cheb_init_block<2>), g, b, 0, ctx->stream, n, c0, ctx->bjac.p, r, d);
+}
+void cheb_step_block(ifem_ctx *ctx, double a, double bb, const double *t, double *x, double *r, double *d) {
+  const int64_t n = ctx->nUo;
+  if (!n) return;
+  const dim3 g(unsigned((n + 255) / 256)), b(256);
+  if (ctx->dim == 3) hipLaunchKernelGGL((k_cheb_step_block<3>), g, b, 0, ctx->stream, n, a, bb, ctx->bjac.p, t, x, r, d);
+  else hipLaunchKernelGGL((k_cheb_step_block<2>), g, b, 0, ctx->stream, n, a, bb, ctx->bjac.p, t, x, r, d);
+}
+
+} // namespace ifem

@@ -515,6 +515,118 @@ static int pcg_mg_sm(MgSm &M, const double *b, double *x, double tol, int maxit,
 
 static void carve_workspace(SolveState &S, bool krylov = true);
 
+// ---- multigrid V-cycle for A_uu (IFEM_AINV_MG): stands where the reference has MUMPS (mpi_insim.cpp:124-127).  Every level
+// applies its own matrix-free A_uu (apply_mf.hip, single-precision cell arithmetic) at the evaluation point injected from
+// the level above; smoother = Chebyshev iteration on (node-block diagonal)^-1 A_uu.  The coarse block diagonals are
+// integrated matrix-free (mg.hip::k_uu_diag), the finest level uses the blocks of the assembled matrix.  Level vectors
+// (ctx->mgu_vec, dim * nUl + 8 each): 0 right-hand side / residual, 1 solution, 2 direction, 3 operator product,
+// 4 prolongated correction; compact owned entries first, so the buffers double as ghost-extended velocity vectors.
+struct MgUu {
+  std::vector<SolveState> L;
+  int nu = 3;
+  double ratio = 8.0;
+};
+
+static void uu_apply_level(SolveState &S, const double *x, double *y) {
+  const double *xe; extend_u(S, x, &xe);
+  apply_uu_mf(S.ctx, xe, y, true);
+}
+static const uint8_t *level_flags(const ifem_ctx *c) {
+  return c->has_c[c->asm_constraint_set] ? c->is_c[c->asm_constraint_set].p : nullptr;
+}
+
+static void mg_uu_setup(MgUu &M) {
+  ifem_ctx *f0 = M.L[0].ctx;
+  for (size_t l = 0; l < M.L.size(); ++l) {
+    SolveState &S = M.L[l];
+    ifem_ctx *c = S.ctx;
+    const int64_t nv = int64_t(c->dim) * c->nUl + 8;
+    for (auto &v : c->mgu_vec)
+      if ((int64_t)v.n < nv) { v.alloc((size_t)nv); IFEM_HIP_CHECK(hipMemsetAsync(v.p, 0, v.n * sizeof(double), c->stream)); }
+    if (l > 0 && c->uu_mg_version != f0->asm_version) { // operator state of a coarse level: rediscretisation at the injected point
+      ifem_ctx *p = M.L[l - 1].ctx;
+      c->mf_params = f0->mf_params;
+      c->mf_noconv = f0->mf_noconv;
+      c->asm_constraint_set = f0->asm_constraint_set;
+      const size_t ne = size_t(c->dim) * size_t(c->nUl);
+      if (c->mf_eval.n != ne) c->mf_eval.alloc(ne);
+      mg_inject_nodes(c, c->nUo, p->mg_inj_u.p, p->mf_eval.p, c->mf_eval.p);
+      halo_exchange(c, c->mf_eval.p);
+      c->mf_valid = true;
+      uu_block_diag_mf(c);
+      c->uu_mg_version = f0->asm_version;
+    }
+    // eigenvalue bound of (block D)^-1 A_uu: depends on the parameters and the constrained-dof set, hardly on the evaluation
+    // point (the viscous and mass terms carry the top of the spectrum): estimated once per such state
+    const double key[6] = {f0->mf_params.viscosity, f0->mf_params.rho, f0->mf_params.grad_div, f0->mf_params.dt,
+                           double(f0->mf_noconv), double(c->flag_id[c->asm_constraint_set])};
+    bool same = c->uu_lmax > 0;
+    for (int i = 0; i < 6; ++i) same = same && key[i] == c->uu_lmax_key[i];
+    if (same) continue;
+    double *x = c->mgu_vec[1].p, *y = c->mgu_vec[3].p, *z = c->mgu_vec[2].p;
+    vec_rough(c, S.nuo, int64_t(c->halo.rank) * 7000003, x);
+    double lam = 0;
+    for (int it = 0; it < 12; ++it) {
+      double nx = v_dot(c, S.nuo, x, x);
+      allreduce_sum(c, &nx, 1);
+      if (!(nx > 0)) break;
+      v_scale(c, S.nuo, 1.0 / std::sqrt(nx), x);
+      uu_apply_level(S, x, y);
+      bjac_apply(c, y, z);
+      double nz = v_dot(c, S.nuo, z, z);
+      allreduce_sum(c, &nz, 1);
+      lam = std::sqrt(nz);
+      v_copy(c, S.nuo, z, x);
+    }
+    c->uu_lmax = lam > 0 ? lam : 1.0;
+    for (int i = 0; i < 6; ++i) c->uu_lmax_key[i] = key[i];
+  }
+}
+
+static void mg_uu_smooth(MgUu &M, size_t l, int nsteps, double lo, double hi, double *x, double *r, bool keep_r) {
+  SolveState &S = M.L[l];
+  ifem_ctx *c = S.ctx;
+  double *d = c->mgu_vec[2].p, *t = c->mgu_vec[3].p;
+  const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+  double rho_old = 1.0 / sigma;
+  cheb_init_block(c, 1.0 / theta, r, d);
+  for (int k = 0; k < nsteps; ++k) {
+    const bool last = k == nsteps - 1;
+    if (last && !keep_r) { v_axpy(c, S.nuo, 1.0, d, x); break; }
+    uu_apply_level(S, d, t);
+    const double rho_new = 1.0 / (2.0 * sigma - rho_old);
+    cheb_step_block(c, rho_new * rho_old, 2.0 * rho_new / delta, t, x, r, d);
+    rho_old = rho_new;
+  }
+}
+
+// level l: mgu_vec[1] = V(mgu_vec[0]); mgu_vec[0] is overwritten by the residual
+static void mg_uu_vcycle(MgUu &M, size_t l) {
+  SolveState &S = M.L[l];
+  ifem_ctx *c = S.ctx;
+  double *r = c->mgu_vec[0].p, *x = c->mgu_vec[1].p;
+  const double hi = 1.1 * c->uu_lmax;
+  v_zero(c, S.nuo, x);
+  if (l + 1 == M.L.size()) {
+    mg_uu_smooth(M, l, 24, hi / 400.0, hi, x, r, false);
+    return;
+  }
+  const double lo = hi / M.ratio;
+  mg_uu_smooth(M, l, M.nu, lo, hi, x, r, true);
+  SolveState &Sc = M.L[l + 1];
+  ifem_ctx *cc = Sc.ctx;
+  mg_csr_apply_nodes(c, c->mg_Ru, r, level_flags(c), level_flags(cc), cc->mgu_vec[0].p);
+  halo_reverse_add(cc, cc->mgu_vec[0].p);
+  mg_uu_vcycle(M, l + 1);
+  halo_exchange(cc, cc->mgu_vec[1].p);
+  double *e = c->mgu_vec[4].p, *t = c->mgu_vec[3].p;
+  mg_csr_apply_nodes(c, c->mg_Pu, cc->mgu_vec[1].p, level_flags(cc), level_flags(c), e);
+  uu_apply_level(S, e, t);
+  v_axpy(c, S.nuo, 1.0, e, x);
+  v_axpy(c, S.nuo, -1.0, t, r);
+  mg_uu_smooth(M, l, M.nu, lo, hi, x, r, false);
+}
+
 static void precond_vmult(SolveState &S, const double *src, double *dst) {
   ifem_ctx *c = S.ctx;
   const ifem_ins_params *P = S.P;
@@ -603,6 +715,38 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   mdot(1, S.utmp, S.nuo, S.utmp, &un);
   un = std::sqrt(un);
   double res = 0;
+  if (o->ainv_kind == IFEM_AINV_MG) { // inner GMRES on the matrix-free operator, one V-cycle as its preconditioner
+    MgUu Mu;
+    Mu.nu = std::max(1, o->mg_smooth_u); Mu.ratio = std::max(1.5, o->mg_cheb_ratio_u);
+    Mu.L.push_back(S);
+    for (ifem_ctx *p = c; p->mg_coarse && p->mg_Pu.n_rows == p->nUo && p->nUo > 0; p = p->mg_coarse) {
+      SolveState Sc{p->mg_coarse, P, o};
+      carve_workspace(Sc, false);
+      Mu.L.push_back(Sc);
+    }
+    if (!c->mf_valid) throw Error(IFEM_E_BADPARAM, "IFEM_AINV_MG needs the operator state of ifem_ins_assemble / ifem_imex_assemble");
+    mg_uu_setup(Mu);
+    OpFn Amf = [&](const double *x, double *y) { uu_apply_level(S, x, y); };
+    OpFn Vc = [&](const double *x, double *y) {
+      v_copy(c, S.nuo, x, c->mgu_vec[0].p);
+      mg_uu_vcycle(Mu, 0);
+      v_copy(c, S.nuo, c->mgu_vec[1].p, y);
+    };
+    if (o->inner_maxit <= 0) { // A~^-1 := one V-cycle, no inner Krylov iteration (the outer solver is flexible)
+      Vc(S.utmp, dst0);
+      S.st.inner_iters += 1;
+    } else { // flexible GMRES: the preconditioned directions are kept, so the update needs no extra V-cycle
+      const int64_t ld = basis_ld(S.ctx, S.nuo);
+      const int mi = std::max(1, o->inner_restart);
+      if ((int64_t)c->innerZ.n < int64_t(mi) * ld) c->innerZ.alloc(size_t(mi) * size_t(ld));
+      S.st.inner_iters += gmres(c, S.nuo, ld, /*reorth=*/false, Amf, Vc, true, S.utmp, dst0, mi, o->inner_maxit, o->inner_rel * un,
+                                c->innerV.p, c->innerZ.p, S.inner_w, &res, mdot);
+    }
+    IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    S.st.t_ainv_ms += ck3.ms();
+    S.st.precond_applies++;
+    return;
+  }
   const bool f32_basis = (f32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF) && o->inner_restart + 6 <= 64;
   if (f32_basis) { // columns 0..m: basis, m+1: scratch for V y, up to the next multiple of 4: padding read by the fused kernels
     OpF32 Pf = [&](const float *x, double *y) { bjac_apply_f32(c, x, y); };

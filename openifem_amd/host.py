@@ -175,12 +175,18 @@ class FluidSolver:
         self._chk(self.L.ifemx_set_partition(self.h, Pa.ctypes.data_as(C.c_void_p), rank,
                                              None if idbuf is None else idbuf.ctypes.data_as(C.c_void_p), local_world))
 
-    def attach_coarse(self, coarse):
+    def attach_coarse(self, coarse, velocity=True):
         """ifem_mg_attach: `coarse` is the same problem on a coarser box mesh (nested, ratio 1 or 2 per direction, same
         partition).  Builds the pressure-node prolongation from the two lattices and keeps `coarse` alive."""
         tf, tc = self.partition_tables(), coarse.partition_tables()
         Pp = capi.box_prolongation(self.reps, coarse.reps, 1, tf["l2g_p"][:tf["n_pnodes_owned"]], tc["l2g_p"])
-        capi.mg_attach(self.L, self.ctx, coarse.ctx, Pp)
+        Pu, inj = None, None
+        if velocity:
+            kv = 2 if tf["n_unodes_global"] != tf["n_pnodes_global"] else 1
+            fo = tf["l2g_u"][:tf["n_unodes_owned"]]
+            Pu = capi.box_prolongation(self.reps, coarse.reps, kv, fo, tc["l2g_u"])
+            inj = capi.box_injection(self.reps, coarse.reps, kv, tc["l2g_u"][:tc["n_unodes_owned"]], fo)
+        capi.mg_attach(self.L, self.ctx, coarse.ctx, Pp, Pu, inj)
         self._coarse = coarse
 
     def set_node_order(self, morton=True):

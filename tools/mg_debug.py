@@ -19,7 +19,7 @@ def make(reps, P, rank, worlds, level):
     return s
 
 
-def run(n, P, mg, nu=2, ratio=4.0):
+def run(n, P, mg, nu=2, ratio=4.0, ainv=3, nu_u=3, ratio_u=8.0, restart=16):
     L = capi.load()
     world = int(np.prod(P))
     depth = len(multigpu.coarse_level_chain(n, P, EXTENT))
@@ -33,13 +33,20 @@ def run(n, P, mg, nu=2, ratio=4.0):
         s.channel_state()
         if world > 1:
             L.ifem_halo_exchange(s.ctx, capi.VEC_EVAL)
-        s.opts.ainv_kind = 3
+        s.opts.ainv_kind = ainv
+        s.opts.mg_smooth_u = nu_u
+        s.opts.mg_cheb_ratio_u = ratio_u
+        s.opts.inner_restart = restart
         s.opts.sm_mg = mg
         s.opts.mg_smooth = nu
         s.opts.mg_cheb_ratio = ratio
         s.assemble(False)
         st = s.solve(False)
-        out[rank] = (st.fgmres_iters, st.precond_applies, st.cg_sm_iters, st.sm_mg_levels, st.cg_mp_iters, st.inner_iters)
+        import time
+        t0 = time.time()
+        st = s.solve(False)
+        out[rank] = (st.fgmres_iters, st.precond_applies, st.cg_sm_iters, st.sm_mg_levels, st.cg_mp_iters, st.inner_iters,
+                     round(st.t_ainv_ms, 1), round((time.time() - t0) * 1e3, 1))
         s.close()
 
     th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
@@ -49,6 +56,13 @@ def run(n, P, mg, nu=2, ratio=4.0):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "uu":
+        n = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+        print("n", n, "kind 3:", run((n, n, n), (1, 1, 1), 1), flush=True)
+        for nu_u in (2, 3, 4):
+            for ratio_u in (4.0, 8.0, 16.0):
+                print("n", n, "kind 4 nu_u", nu_u, "ratio_u", ratio_u, run((n, n, n), (1, 1, 1), 1, ainv=4, nu_u=nu_u, ratio_u=ratio_u), flush=True)
+        sys.exit(0)
     for n, P in (((16, 8, 8), (1, 1, 1)), ((8, 8, 8), (2, 1, 1)), ((16, 4, 8), (1, 2, 1)), ((16, 16, 16), (1, 1, 1)), ((8, 16, 16), (2, 1, 1)), ((8, 8, 8), (2, 2, 2))):
         for mg in (0, 1):
             print(n, P, "mg", mg, "fgmres, applies, cg_sm, levels, cg_mp, inner =", run(n, P, mg), flush=True)
