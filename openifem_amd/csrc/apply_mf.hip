@@ -359,10 +359,14 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
 // inverse node block (row and column r of the block are zero apart from d_r, so its inverse has 1/d_r there).
 // second stage of the atomics-free scatter: y_i = sum over the cells touching node(i) of the cell's local result (fixed
 // order: deterministic), constrained rows y_r = d_r x_r as above
-template <int DIM, typename R>
+// FUSE (the multigrid smoother, solver.hip::mg_uu_smooth): the product t = (A x)_node is not stored but consumed on the
+// spot -- fuse.mode 1: xs += x, r -= t (residual update after the coarse correction); mode 2: the Chebyshev step
+// xs += x, r -= t, x <- a x + b B r with the inverse node block B (x is the smoother's direction vector and is updated in
+// place: the cell kernel that read it has completed, and a thread only touches the entries of its own node).
+template <int DIM, typename R, bool FUSE>
 __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc,
                             const R *__restrict__ ycell, const uint8_t *__restrict__ is_c,
-                            const double *__restrict__ bjac, const double *__restrict__ x, double *__restrict__ y) {
+                            const double *__restrict__ bjac, const double *x, double *y, MfFuse fuse) {
   // one thread per node: the incidence list is walked once for the DIM components (24 contiguous bytes per entry)
   const int64_t nd = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (nd * DIM >= n) return;
@@ -393,10 +397,34 @@ __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_p
         for (int c = 0; c < DIM; ++c) s[c] += v[u][c];
       }
   }
+  if constexpr (!FUSE) {
 #pragma unroll
-  for (int c = 0; c < DIM; ++c) {
-    const int64_t i = nd * DIM + c;
-    y[i] = fl[c] ? x[i] / bjac[nd * DIM * DIM + c * DIM + c] : s[c];
+    for (int c = 0; c < DIM; ++c) {
+      const int64_t i = nd * DIM + c;
+      y[i] = fl[c] ? x[i] / bjac[nd * DIM * DIM + c * DIM + c] : s[c];
+    }
+  } else {
+    double xv[DIM], rv[DIM], bj[DIM * DIM];
+#pragma unroll
+    for (int e = 0; e < DIM * DIM; ++e) bj[e] = bjac[nd * DIM * DIM + e];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+      const int64_t i = nd * DIM + c;
+      xv[c] = x[i];
+      const double t = fl[c] ? xv[c] / bj[c * DIM + c] : s[c];
+      rv[c] = fuse.r[i] - t;
+      fuse.xs[i] += xv[c];
+      fuse.r[i] = rv[c];
+    }
+    if (fuse.mode == 2) {
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) {
+        double z = 0;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) z += bj[c * DIM + j] * rv[j];
+        fuse.d[nd * DIM + c] = fuse.a * xv[c] + fuse.b * z;
+      }
+    }
   }
 }
 
@@ -436,7 +464,7 @@ static void mf_tables(MfTables &t, int kv) {
 }
 
 template <typename R>
-static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu) {
+static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu, const MfFuse *fuse) {
   if (!ctx->mf_valid) throw Error(IFEM_E_BADPARAM, "matrix-free A_uu: no assembled state (call ifem_ins_assemble first)");
   const int64_t n = int64_t(ctx->dim) * ctx->nUo;
   hipStream_t s = ctx->stream;
@@ -480,12 +508,13 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu) {
   else IFEM_MF2(2, 1)
 #undef IFEM_MF2
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
-  if (ctx->dim == 3)
-    hipLaunchKernelGGL((k_mf_gather<3, R>), dim3(unsigned((n / 3 + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
-                       ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu);
-  else
-    hipLaunchKernelGGL((k_mf_gather<2, R>), dim3(unsigned((n / 2 + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p,
-                       ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu);
+  const MfFuse f0 = fuse ? *fuse : MfFuse{};
+#define IFEM_MFG(D, F)                                                                                                 \
+  hipLaunchKernelGGL((k_mf_gather<D, R, F>), dim3(unsigned((n / D + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p, \
+                     ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu, f0)
+  if (ctx->dim == 3) { if (fuse) IFEM_MFG(3, true); else IFEM_MFG(3, false); }
+  else { if (fuse) IFEM_MFG(2, true); else IFEM_MFG(2, false); }
+#undef IFEM_MFG
   if (time_it) {
     IFEM_HIP_CHECK(hipEventSynchronize(ctx->ev1));
     float ms = 0;
@@ -496,9 +525,9 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu) {
 }
 
 // single = true: single-precision cell arithmetic (the inner, preconditioner-only solve); ifem_tuning::mf_f32 = 0 forces double
-void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single) {
-  if (single && ctx->tune.mf_f32) apply_uu_mf_t<float>(ctx, xu, yu);
-  else apply_uu_mf_t<double>(ctx, xu, yu);
+void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single, const MfFuse *fuse) {
+  if (single && ctx->tune.mf_f32) apply_uu_mf_t<float>(ctx, xu, yu, fuse);
+  else apply_uu_mf_t<double>(ctx, xu, yu, fuse);
 }
 
 } // namespace ifem

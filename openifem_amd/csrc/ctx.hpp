@@ -212,6 +212,8 @@ struct ifem_ctx {
   ifem_ctx *mg_coarse = nullptr;
   ifem::MgCsr mg_Pp, mg_Rp, mg_Pu, mg_Ru;
   ifem::DBuf<int32_t> mg_inj_u; // [nUo of the coarse level] coincident owned velocity node of this level
+  ifem::DBuf<uint8_t> mg_Pu_mask, mg_Ru_mask; // per weight: components dropped by the Dirichlet flags of the two levels
+  int64_t mg_mask_key[2] = {-1, -1};          // constrained-dof sets (flag ids of this level and the coarser one) of the masks
   ifem::DBuf<double> sm_dinv, mg_vec[6], mgu_vec[5];
   double sm_lmax = 0, uu_lmax = 0;
   int64_t asm_version = 0, uu_mg_version = -1; // full assemblies done / the assembly the A_uu V-cycle data belong to

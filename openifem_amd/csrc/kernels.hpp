@@ -33,7 +33,15 @@ inline VecLayout layout_of(const ifem_ctx *c) { return {c->dim * c->nUo, c->dim 
 // y_u = A_uu x_u (+ B^T x_p when xp != nullptr)
 void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool use_f32);
 // apply_mf.hip: y_u = A_uu x_u without the stored matrix (sum-factorised cell kernel on the state of the last assemble)
-void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single = false);
+// optional epilogue of the matrix-free product t = A_uu x (owned rows), see apply_mf.hip::k_mf_gather: t is consumed instead of
+// stored.  mode 1: xs += x, r -= t; mode 2 additionally d = a x + b (inverse node block) r -- the Chebyshev step of the
+// multigrid smoother, d being the owned part of x itself
+struct MfFuse {
+  int mode = 0;
+  double a = 0, b = 0;
+  double *xs = nullptr, *r = nullptr, *d = nullptr;
+};
+void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single = false, const MfFuse *fuse = nullptr);
 // scalar velocity operator S^ (IFEM_AINV_SCALAR_GMRES): auxiliary data, SpMV on all components, Jacobi
 void shat_refresh(ifem_ctx *ctx, bool f32);
 void spmv_shat(ifem_ctx *ctx, const double *xu, double *yu, bool f32);
@@ -108,10 +116,10 @@ void cheb_step(ifem_ctx *ctx, int64_t n, double a, double b, const double *dinv,
 void vec_recip(ifem_ctx *ctx, int64_t n, double *d);
 void vec_rough(ifem_ctx *ctx, int64_t n, int64_t offset, double *x);
 void uu_block_diag_mf(ifem_ctx *ctx); // ctx->bjac := inverse node blocks of the matrix-free A_uu (coarse multigrid levels)
-void mg_csr_apply_nodes(ifem_ctx *ctx, const MgCsr &M, const double *x, const uint8_t *flag_in, const uint8_t *flag_out, double *y);
+void mg_csr_mask(ifem_ctx *ctx, const MgCsr &M, const uint8_t *flag_in, const uint8_t *flag_out, DBuf<uint8_t> &mask);
+void mg_csr_apply_nodes(ifem_ctx *ctx, const MgCsr &M, const double *x, const DBuf<uint8_t> &mask, double *y);
 void mg_inject_nodes(ifem_ctx *ctx, int64_t n_nodes, const int32_t *inj, const double *fine, double *coarse);
 void cheb_init_block(ifem_ctx *ctx, double c0, const double *r, double *d);
-void cheb_step_block(ifem_ctx *ctx, double a, double b, const double *t, double *x, double *r, double *d);
 
 // all-reduce helpers (identity for a single rank)
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n);

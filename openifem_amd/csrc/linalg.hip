@@ -410,10 +410,18 @@ void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp) {
 
 // ---------------------------------------------------------------------------------------------------
 // mass_schur(1,1) = B diag(1/diag M_u) B^T (mpi_insim.cpp:44-49, PETSc MatMatMult in the reference): one wave per
-// pressure row i; lanes walk the blocks k of B's row i, then the (short) row k of B^T, and accumulate into the
-// row's LDS copy through a binary search of the column.
+// pressure row i.  The row's column ids go into a small open-addressing hash table in LDS (column -> position), the
+// blocks k of B's row i (scaled by 1/diag M_u) into LDS arrays; then each half of the wave walks one (short) row k of B^T
+// with consecutive lanes on consecutive entries (coalesced), looks the position up with ~1 probe and adds into the row's
+// LDS accumulators.  (First version: one lane per block k, a serial walk of row k with a 7-step bisection per entry --
+// 102 ms at 128^3, bound by the uncoalesced loads and the dependent LDS reads.)
+__device__ inline void wsync() { // LDS operations of one wave execute in order: a wave-local barrier is enough
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <int DIM>
-__global__ __launch_bounds__(256) void k_schur_numeric(int64_t n_rows, int maxlen, const int64_t *__restrict__ rpS,
+__global__ __launch_bounds__(256) void k_schur_numeric(int64_t n_rows, int maxlen, int maxb, int hsize, const int64_t *__restrict__ rpS,
                                                        const int32_t *__restrict__ colS, double *__restrict__ valS,
                                                        const int64_t *__restrict__ rpB, const int32_t *__restrict__ colB,
                                                        const double *__restrict__ valB, const int64_t *__restrict__ rpT,
@@ -421,40 +429,67 @@ __global__ __launch_bounds__(256) void k_schur_numeric(int64_t n_rows, int maxle
                                                        const double *__restrict__ dinv) {
   extern __shared__ __align__(16) unsigned char smem_s[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double *acc = reinterpret_cast<double *>(smem_s) + size_t(wave) * maxlen;
-  int32_t *cols = reinterpret_cast<int32_t *>(reinterpret_cast<double *>(smem_s) + size_t(4) * maxlen) + size_t(wave) * maxlen;
+  // per wave: acc[maxlen] | bd[maxb][DIM] | ts[maxb] (int64) | hkey[hsize] | tlen[maxb] | hpos[hsize] (uint16)
+  const size_t per_wave = size_t(maxlen) * 8 + size_t(maxb) * DIM * 8 + size_t(maxb) * 8 + size_t(hsize) * 4 + size_t(maxb) * 4 + size_t(hsize) * 2;
+  unsigned char *base = smem_s + size_t(wave) * ((per_wave + 15) & ~size_t(15));
+  double *acc = reinterpret_cast<double *>(base);
+  double *bdl = acc + maxlen;
+  int64_t *tsl = reinterpret_cast<int64_t *>(bdl + size_t(maxb) * DIM);
+  int32_t *hkey = reinterpret_cast<int32_t *>(tsl + maxb);
+  int32_t *tll = hkey + hsize;
+  uint16_t *hpos = reinterpret_cast<uint16_t *>(tll + maxb);
   const int64_t row = int64_t(blockIdx.x) * 4 + wave;
   const bool active = row < n_rows;
   const int64_t rs = active ? rpS[row] : 0;
   const int len = active ? int(rpS[row + 1] - rs) : 0;
-  for (int i = lane; i < len; i += 64) { cols[i] = colS[rs + i]; acc[i] = 0.0; }
-  __syncthreads();
-  if (active) {
-    const int64_t bs = rpB[row];
-    const int blen = int(rpB[row + 1] - bs);
-    for (int kb = lane; kb < blen; kb += 64) {
-      const int32_t k = colB[bs + kb];
-      double bd[DIM];
+  const unsigned hmask = unsigned(hsize - 1);
+  for (int i = lane; i < hsize; i += 64) hkey[i] = -1;
+  for (int i = lane; i < len; i += 64) acc[i] = 0.0;
+  wsync();
+  for (int i = lane; i < len; i += 64) { // insert (column -> position)
+    const int32_t j = colS[rs + i];
+    unsigned h = (unsigned(j) * 2654435761u >> 8) & hmask;
+    while (true) {
+      const int32_t old = atomicCAS(&hkey[h], -1, j);
+      if (old == -1) { hpos[h] = uint16_t(i); break; }
+      h = (h + 1) & hmask;
+    }
+  }
+  const int64_t bs = active ? rpB[row] : 0;
+  const int blen = active ? int(rpB[row + 1] - bs) : 0;
+  for (int kb = lane; kb < blen; kb += 64) {
+    const int32_t k = colB[bs + kb];
 #pragma unroll
-      for (int c = 0; c < DIM; ++c) bd[c] = valB[bs * DIM + int64_t(c) * blen + kb] * dinv[int64_t(k) * DIM + c];
-      const int64_t ts = rpT[k];
-      const int tlen = int(rpT[k + 1] - ts);
-      for (int t = 0; t < tlen; ++t) {
-        const int32_t j = colT[ts + t];
-        double v = 0;
+    for (int c = 0; c < DIM; ++c) bdl[kb * DIM + c] = valB[bs * DIM + int64_t(c) * blen + kb] * dinv[int64_t(k) * DIM + c];
+    const int64_t ts = rpT[k];
+    tsl[kb] = ts;
+    tll[kb] = int32_t(rpT[k + 1] - ts);
+  }
+  wsync();
+  const int half = lane >> 5, tl = lane & 31;
+  for (int kb0 = 0; kb0 < blen; kb0 += 2) {
+    const int kb = kb0 + half;
+    if (kb >= blen) continue;
+    const int64_t ts = tsl[kb];
+    const int tlen = tll[kb];
+    double bd[DIM];
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) v += bd[c] * valT[ts * DIM + int64_t(c) * tlen + t];
-        int lo = 0, hi = len - 1;
-        while (lo <= hi) {
-          const int mid = (lo + hi) >> 1;
-          const int32_t cv = cols[mid];
-          if (cv == j) { unsafeAtomicAdd(&acc[mid], v); break; }
-          if (cv < j) lo = mid + 1; else hi = mid - 1;
-        }
+    for (int c = 0; c < DIM; ++c) bd[c] = bdl[kb * DIM + c];
+    for (int t = tl; t < tlen; t += 32) {
+      const int32_t j = colT[ts + t];
+      double v = 0;
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) v += bd[c] * valT[ts * DIM + int64_t(c) * tlen + t];
+      unsigned h = (unsigned(j) * 2654435761u >> 8) & hmask;
+      while (true) { // every column of B^T's row k is a column of S_m's row i (pattern(S_m) = pattern(B B^T))
+        const int32_t key = hkey[h];
+        if (key == j) { unsafeAtomicAdd(&acc[hpos[h]], v); break; }
+        if (key == -1) break;
+        h = (h + 1) & hmask;
       }
     }
   }
-  __syncthreads();
+  wsync();
   for (int i = lane; i < len; i += 64) valS[rs + i] = acc[i];
 }
 
@@ -462,15 +497,25 @@ void schur_numeric(ifem_ctx *ctx) {
   if (ctx->sm_valid) return;
   const int64_t n = ctx->Sm.n_rows;
   if (n == 0) return;
-  const int maxlen = (ctx->Sm.max_row + 1) & ~1;
-  const size_t smem = size_t(4) * maxlen * (sizeof(double) + sizeof(int32_t));
+  const int maxlen = (ctx->Sm.max_row + 1) & ~1, maxb = (ctx->B.max_row + 1) & ~1;
+  int hsize = 64;
+  while (hsize < 2 * maxlen) hsize *= 2;
+  const size_t per_wave = size_t(maxlen) * 8 + size_t(maxb) * ctx->dim * 8 + size_t(maxb) * 8 + size_t(hsize) * 4 + size_t(maxb) * 4 + size_t(hsize) * 2;
+  const size_t smem = 4 * ((per_wave + 15) & ~size_t(15));
+  if (smem > 160 * 1024) throw Error(IFEM_E_BADPARAM, "explicit S_m: a pressure row is too long for the LDS row buffers");
   const unsigned blocks = unsigned((n + 3) / 4);
+  static bool attr_set[2] = {false, false};
+  if (smem > 48 * 1024 && !attr_set[ctx->dim == 3]) {
+    if (ctx->dim == 3) IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_schur_numeric<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_schur_numeric<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set[ctx->dim == 3] = true;
+  }
   if (ctx->dim == 3)
-    hipLaunchKernelGGL((k_schur_numeric<3>), dim3(blocks), dim3(256), smem, ctx->stream, n, maxlen, ctx->Sm.rowptr.p,
+    hipLaunchKernelGGL((k_schur_numeric<3>), dim3(blocks), dim3(256), smem, ctx->stream, n, maxlen, maxb, hsize, ctx->Sm.rowptr.p,
                        ctx->Sm.col.p, ctx->Sm.val.p, ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, ctx->Bt.rowptr.p,
                        ctx->Bt.col.p, ctx->Bt.val.p, ctx->dinvMu.p);
   else
-    hipLaunchKernelGGL((k_schur_numeric<2>), dim3(blocks), dim3(256), smem, ctx->stream, n, maxlen, ctx->Sm.rowptr.p,
+    hipLaunchKernelGGL((k_schur_numeric<2>), dim3(blocks), dim3(256), smem, ctx->stream, n, maxlen, maxb, hsize, ctx->Sm.rowptr.p,
                        ctx->Sm.col.p, ctx->Sm.val.p, ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, ctx->Bt.rowptr.p,
                        ctx->Bt.col.p, ctx->Bt.val.p, ctx->dinvMu.p);
   IFEM_HIP_CHECK(hipGetLastError());

@@ -246,33 +246,83 @@ void uu_block_diag_mf(ifem_ctx *ctx) {
 // nor receives corrections), injection of the evaluation point, and the Chebyshev updates with the inverse node blocks.
 namespace ifem {
 
-// y[row][c] = flag_out ? 0 : sum_k w_k (flag_in[col_k][c] ? 0 : x[col_k][c])
+// y[row][c] = flag_out ? 0 : sum_k w_k (flag_in[col_k][c] ? 0 : x[col_k][c]).  G lanes share a row (prolongation rows hold
+// 1..27 weights, restriction rows up to 125): index / weight reads are contiguous per group, the partial sums meet by
+// shuffles.  G is chosen from the mean row length at launch.  The two flag tests are folded into one byte per weight
+// (bit c: component c of this weight is dropped), rebuilt when the constrained-dof set of either level changes.
 template <int DIM>
+__global__ void k_mg_mask(int64_t n_rows, const int64_t *__restrict__ ptr, const int32_t *__restrict__ col,
+                          const uint8_t *__restrict__ flag_in, const uint8_t *__restrict__ flag_out, uint8_t *__restrict__ mask) {
+  for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n_rows; r += int64_t(gridDim.x) * blockDim.x) {
+    uint8_t mo = 0;
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) mo |= uint8_t((flag_out && flag_out[r * DIM + c]) ? (1 << c) : 0);
+    for (int64_t k = ptr[r]; k < ptr[r + 1]; ++k) {
+      uint8_t m = mo;
+      const int64_t j = int64_t(col[k]) * DIM;
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) m |= uint8_t((flag_in && flag_in[j + c]) ? (1 << c) : 0);
+      mask[k] = m;
+    }
+  }
+}
+void mg_csr_mask(ifem_ctx *ctx, const MgCsr &M, const uint8_t *flag_in, const uint8_t *flag_out, DBuf<uint8_t> &mask) {
+  if (!M.n_rows) return;
+  if (mask.n != M.col.n) mask.alloc(M.col.n);
+  if (ctx->dim == 3) hipLaunchKernelGGL((k_mg_mask<3>), dim3(mgrid(M.n_rows)), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, flag_in, flag_out, mask.p);
+  else hipLaunchKernelGGL((k_mg_mask<2>), dim3(mgrid(M.n_rows)), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, flag_in, flag_out, mask.p);
+}
+
+template <int DIM, int G>
 __global__ __launch_bounds__(256) void k_mg_csr_nodes(int64_t n_rows, const int64_t *__restrict__ ptr, const int32_t *__restrict__ col,
                                                       const double *__restrict__ w, const double *__restrict__ x,
-                                                      const uint8_t *__restrict__ flag_in, const uint8_t *__restrict__ flag_out,
-                                                      double *__restrict__ y) {
-  for (int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n_rows; r += int64_t(gridDim.x) * blockDim.x) {
-    double s[DIM];
+                                                      const uint8_t *__restrict__ mask, double *__restrict__ y) {
+  const int lig = threadIdx.x % G;
+  const int64_t r = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  const bool live = r < n_rows;
+  double s[DIM];
 #pragma unroll
-    for (int c = 0; c < DIM; ++c) s[c] = 0;
-    for (int64_t k = ptr[r]; k < ptr[r + 1]; ++k) {
+  for (int c = 0; c < DIM; ++c) s[c] = 0;
+  if (live) {
+    const int64_t k1 = ptr[r + 1];
+    for (int64_t k = ptr[r] + lig; k < k1; k += G) {
       const int64_t j = int64_t(col[k]) * DIM;
       const double wk = w[k];
+      const unsigned m = mask[k];
+      double xv[DIM];
 #pragma unroll
-      for (int c = 0; c < DIM; ++c) s[c] += (flag_in && flag_in[j + c]) ? 0.0 : wk * x[j + c];
+      for (int c = 0; c < DIM; ++c) xv[c] = x[j + c];
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) s[c] += ((m >> c) & 1u) ? 0.0 : wk * xv[c];
     }
+  }
 #pragma unroll
-    for (int c = 0; c < DIM; ++c) y[r * DIM + c] = (flag_out && flag_out[r * DIM + c]) ? 0.0 : s[c];
+  for (int c = 0; c < DIM; ++c)
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) s[c] += __shfl_xor(s[c], o, G);
+  if (live && lig < DIM) {
+    double v = s[0];
+#pragma unroll
+    for (int c = 1; c < DIM; ++c) v = lig == c ? s[c] : v;
+    y[r * DIM + lig] = v;
   }
 }
 
-void mg_csr_apply_nodes(ifem_ctx *ctx, const MgCsr &M, const double *x, const uint8_t *flag_in, const uint8_t *flag_out, double *y) {
+template <int DIM>
+static void launch_csr_nodes(ifem_ctx *ctx, const MgCsr &M, const double *x, const uint8_t *mask, double *y) {
+  const double mean = double(M.col.n) / double(M.n_rows);
+  const int g = mean <= 6 ? 4 : (mean <= 12 ? 8 : (mean <= 24 ? 16 : 32));
+  const unsigned blocks = unsigned((M.n_rows * g + 255) / 256);
+#define IFEM_CSRN(G) hipLaunchKernelGGL((k_mg_csr_nodes<DIM, G>), dim3(blocks), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, M.w.p, x, mask, y)
+  if (g == 4) IFEM_CSRN(4); else if (g == 8) IFEM_CSRN(8); else if (g == 16) IFEM_CSRN(16); else IFEM_CSRN(32);
+#undef IFEM_CSRN
+}
+
+void mg_csr_apply_nodes(ifem_ctx *ctx, const MgCsr &M, const double *x, const DBuf<uint8_t> &mask, double *y) {
   if (!M.n_rows) return;
-  if (ctx->dim == 3)
-    hipLaunchKernelGGL((k_mg_csr_nodes<3>), dim3(mgrid(M.n_rows)), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, M.w.p, x, flag_in, flag_out, y);
-  else
-    hipLaunchKernelGGL((k_mg_csr_nodes<2>), dim3(mgrid(M.n_rows)), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, M.w.p, x, flag_in, flag_out, y);
+  if (mask.n != M.col.n) throw Error(IFEM_E_BADPARAM, "multigrid transfer without its constraint mask");
+  if (ctx->dim == 3) launch_csr_nodes<3>(ctx, M, x, mask.p, y);
+  else launch_csr_nodes<2>(ctx, M, x, mask.p, y);
 }
 
 __global__ void k_mg_inject(int64_t n_nodes, int dim, const int32_t *__restrict__ inj, const double *__restrict__ fine,
@@ -304,29 +354,6 @@ __global__ void k_cheb_init_block(int64_t n_nodes, double c0, const double *__re
     d[nd * DIM + i] = c0 * t;
   }
 }
-// x += d; r -= t; d = a d + b B r
-template <int DIM>
-__global__ void k_cheb_step_block(int64_t n_nodes, double a, double b, const double *__restrict__ bj, const double *__restrict__ t,
-                                  double *__restrict__ x, double *__restrict__ r, double *__restrict__ d) {
-  const int64_t nd = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (nd >= n_nodes) return;
-  double rv[DIM], dv[DIM];
-#pragma unroll
-  for (int j = 0; j < DIM; ++j) {
-    const int64_t i = nd * DIM + j;
-    dv[j] = d[i];
-    rv[j] = r[i] - t[i];
-    x[i] += dv[j];
-    r[i] = rv[j];
-  }
-#pragma unroll
-  for (int i = 0; i < DIM; ++i) {
-    double z = 0;
-#pragma unroll
-    for (int j = 0; j < DIM; ++j) z += bj[nd * DIM * DIM + i * DIM + j] * rv[j];
-    d[nd * DIM + i] = a * dv[i] + b * z;
-  }
-}
 void cheb_init_block(ifem_ctx *ctx, double c0, const double *r, double *d) {
   const int64_t n = ctx->nUo;
   if (!n) return;
@@ -334,12 +361,4 @@ void cheb_init_block(ifem_ctx *ctx, double c0, const double *r, double *d) {
   if (ctx->dim == 3) hipLaunchKernelGGL((k_cheb_init_block<3>), g, b, 0, ctx->stream, n, c0, ctx->bjac.p, r, d);
   else hipLaunchKernelGGL((k_cheb_init_block<2>), g, b, 0, ctx->stream, n, c0, ctx->bjac.p, r, d);
 }
-void cheb_step_block(ifem_ctx *ctx, double a, double bb, const double *t, double *x, double *r, double *d) {
-  const int64_t n = ctx->nUo;
-  if (!n) return;
-  const dim3 g(unsigned((n + 255) / 256)), b(256);
-  if (ctx->dim == 3) hipLaunchKernelGGL((k_cheb_step_block<3>), g, b, 0, ctx->stream, n, a, bb, ctx->bjac.p, t, x, r, d);
-  else hipLaunchKernelGGL((k_cheb_step_block<2>), g, b, 0, ctx->stream, n, a, bb, ctx->bjac.p, t, x, r, d);
-}
-
 } // namespace ifem

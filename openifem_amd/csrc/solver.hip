@@ -527,12 +527,9 @@ struct MgUu {
   double ratio = 8.0;
 };
 
-static void uu_apply_level(SolveState &S, const double *x, double *y) {
+static void uu_apply_level(SolveState &S, const double *x, double *y, const MfFuse *fuse = nullptr) {
   const double *xe; extend_u(S, x, &xe);
-  apply_uu_mf(S.ctx, xe, y, true);
-}
-static const uint8_t *level_flags(const ifem_ctx *c) {
-  return c->has_c[c->asm_constraint_set] ? c->is_c[c->asm_constraint_set].p : nullptr;
+  apply_uu_mf(S.ctx, xe, y, true, fuse);
 }
 
 static void mg_uu_setup(MgUu &M) {
@@ -555,6 +552,17 @@ static void mg_uu_setup(MgUu &M) {
       c->mf_valid = true;
       uu_block_diag_mf(c);
       c->uu_mg_version = f0->asm_version;
+    }
+    if (l + 1 < M.L.size()) { // transfer masks towards the next level: functions of the two constrained-dof sets
+      ifem_ctx *cc = M.L[l + 1].ctx;
+      const int cs = f0->asm_constraint_set;
+      const int64_t key[2] = {c->flag_id[cs], cc->flag_id[cs]};
+      if (c->mg_Pu_mask.n != c->mg_Pu.col.n || c->mg_mask_key[0] != key[0] || c->mg_mask_key[1] != key[1]) {
+        const uint8_t *ff = c->has_c[cs] ? c->is_c[cs].p : nullptr, *fc = cc->has_c[cs] ? cc->is_c[cs].p : nullptr;
+        mg_csr_mask(c, c->mg_Ru, ff, fc, c->mg_Ru_mask); // rows: local coarse nodes, columns: owned fine nodes
+        mg_csr_mask(c, c->mg_Pu, fc, ff, c->mg_Pu_mask); // rows: owned fine nodes, columns: local coarse nodes
+        c->mg_mask_key[0] = key[0]; c->mg_mask_key[1] = key[1];
+      }
     }
     // eigenvalue bound of (block D)^-1 A_uu: depends on the parameters and the constrained-dof set, hardly on the evaluation
     // point (the viscous and mass terms carry the top of the spectrum): estimated once per such state
@@ -593,9 +601,11 @@ static void mg_uu_smooth(MgUu &M, size_t l, int nsteps, double lo, double hi, do
   for (int k = 0; k < nsteps; ++k) {
     const bool last = k == nsteps - 1;
     if (last && !keep_r) { v_axpy(c, S.nuo, 1.0, d, x); break; }
-    uu_apply_level(S, d, t);
     const double rho_new = 1.0 / (2.0 * sigma - rho_old);
-    cheb_step_block(c, rho_new * rho_old, 2.0 * rho_new / delta, t, x, r, d);
+    // x += d; r -= A d; d = rho_new rho_old d + (2 rho_new / delta) B r, fused into the node gather of the product
+    MfFuse f;
+    f.mode = 2; f.a = rho_new * rho_old; f.b = 2.0 * rho_new / delta; f.xs = x; f.r = r; f.d = d;
+    uu_apply_level(S, d, t, &f);
     rho_old = rho_new;
   }
 }
@@ -615,15 +625,15 @@ static void mg_uu_vcycle(MgUu &M, size_t l) {
   mg_uu_smooth(M, l, M.nu, lo, hi, x, r, true);
   SolveState &Sc = M.L[l + 1];
   ifem_ctx *cc = Sc.ctx;
-  mg_csr_apply_nodes(c, c->mg_Ru, r, level_flags(c), level_flags(cc), cc->mgu_vec[0].p);
+  mg_csr_apply_nodes(c, c->mg_Ru, r, c->mg_Ru_mask, cc->mgu_vec[0].p);
   halo_reverse_add(cc, cc->mgu_vec[0].p);
   mg_uu_vcycle(M, l + 1);
   halo_exchange(cc, cc->mgu_vec[1].p);
   double *e = c->mgu_vec[4].p, *t = c->mgu_vec[3].p;
-  mg_csr_apply_nodes(c, c->mg_Pu, cc->mgu_vec[1].p, level_flags(cc), level_flags(c), e);
-  uu_apply_level(S, e, t);
-  v_axpy(c, S.nuo, 1.0, e, x);
-  v_axpy(c, S.nuo, -1.0, t, r);
+  mg_csr_apply_nodes(c, c->mg_Pu, cc->mgu_vec[1].p, c->mg_Pu_mask, e);
+  MfFuse f;
+  f.mode = 1; f.xs = x; f.r = r; // x += e; r -= A e
+  uu_apply_level(S, e, t, &f);
   mg_uu_smooth(M, l, M.nu, lo, hi, x, r, false);
 }
 
@@ -663,7 +673,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   S.st.t_cg_mp_ms += ck.ms();
   // CG for Sm (:86-112)
   Clock ck2;
-  const bool lowp_all = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF;
+  const bool lowp_all = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF || o->ainv_kind == IFEM_AINV_MG;
   sm_ensure(S);
   OpFn sm = [&](const double *x, double *y) { sm_apply(S, x, y, lowp_all); };
   // multigrid-preconditioned CG when coarser levels are attached (every level needs its S_m explicitly: Jacobi smoothing)
@@ -957,8 +967,8 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   ctx->timing.spmv_uu_ms_avg = ctx->timing.spmv_uu_calls ? ctx->spmv_uu_ms_total / ctx->timing.spmv_uu_calls : 0;
   if (stats) *stats = S.st;
   if (o->verbose)
-    fprintf(stderr, "[ifem] solve: fgmres %d its res %.3e (tol %.3e) | P applies %u CG(Mp) %u CG(Sm) %u inner %u | %.1f ms\n",
-            it, res, tol, S.st.precond_applies, S.st.cg_mp_iters, S.st.cg_sm_iters, S.st.inner_iters, S.st.t_total_ms);
+    fprintf(stderr, "[ifem] solve: fgmres %d its res %.3e (tol %.3e) | P applies %u CG(Mp) %u (%.1f ms) CG(Sm) %u (%.1f ms) inner %u (%.1f ms) | %.1f ms\n",
+            it, res, tol, S.st.precond_applies, S.st.cg_mp_iters, S.st.t_cg_mp_ms, S.st.cg_sm_iters, S.st.t_cg_sm_ms, S.st.inner_iters, S.st.t_ainv_ms, S.st.t_total_ms);
   return res <= tol ? 0 : IFEM_E_KRYLOV_NOCONV;
 }
 

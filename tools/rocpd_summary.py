@@ -37,6 +37,25 @@ def main(db_path, prefix):
             med = f"{d[len(d) // 2] / 1e6:.3f}" if d else ""
             mn = f"{d[0] / 1e6:.3f}" if d else ""
             w.writerow([short(name), calls, f"{tot / 1e3:.3f}", f"{avg / 1e3:.3f}", f"{pct:.2f}", med, mn])
+    # per (kernel, grid size): the same kernel runs on every multigrid level
+    try:
+        cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+        gcol = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else ("grid_size" if "grid_size" in cols else None))
+        if gcol is None:
+            print("kernels view columns:", cols)
+        else:
+            g = {}
+            for name, grid, dur in cur.execute(f'select name, {gcol}, ("end" - start) from kernels'):
+                g.setdefault((name, grid), []).append(dur)
+            with open(prefix + "_by_grid.csv", "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(["kernel", "grid", "calls", "total_ms", "avg_ms"])
+                for (name, grid), d in sorted(g.items(), key=lambda kv: -sum(kv[1])):
+                    if sum(d) / 1e6 < 0.5:
+                        continue
+                    w.writerow([short(name)[:90], grid, len(d), f"{sum(d) / 1e6:.3f}", f"{sum(d) / len(d) / 1e6:.4f}"])
+    except sqlite3.Error as e:
+        print("no per-grid view:", e)
     try:
         q = ("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
              "group by kernel_name, counter_name")
