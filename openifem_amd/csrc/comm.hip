@@ -11,8 +11,10 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <algorithm>
+#include <array>
 #include <condition_variable>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include "ctx.hpp"
 #include "kernels.hpp"
@@ -42,6 +44,13 @@ struct LocalWorld {
     else cv.wait(lk, [&] { return generation != gen; });
   }
 };
+
+// Communicators are shared by the contexts of one process that were given the same unique id (the levels of a multigrid
+// chain: same ranks, same neighbours, one stream): ncclCommInitRank is collective and allocates its channel buffers per
+// communicator, one per level would multiply both.  Reference-counted; the last context destroys it.
+struct SharedComm { ncclComm_t comm; int refs; };
+static std::mutex g_comm_mu;
+static std::map<std::array<uint8_t, 128>, SharedComm> g_comms;
 
 void comm_init(ifem_ctx *ctx, const ifem_partition *part) {
   Halo &h = ctx->halo;
@@ -82,14 +91,35 @@ void comm_init(ifem_ctx *ctx, const ifem_partition *part) {
     ncclUniqueId id;
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
     std::memcpy(&id, part->nccl_unique_id, 128);
-    ncclComm_t comm;
-    IFEM_NCCL_CHECK(ncclCommInitRank(&comm, h.nranks, id, h.rank));
-    h.comm = comm;
+    std::array<uint8_t, 128> key;
+    std::memcpy(key.data(), part->nccl_unique_id, 128);
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    auto it = g_comms.find(key);
+    if (it != g_comms.end()) {
+      int cr = -1, cn = -1;
+      IFEM_NCCL_CHECK(ncclCommUserRank(it->second.comm, &cr));
+      IFEM_NCCL_CHECK(ncclCommCount(it->second.comm, &cn));
+      if (cr != h.rank || cn != h.nranks) throw Error(IFEM_E_BADPARAM, "ifem_partition: this unique id already names a communicator of another rank / size");
+      it->second.refs++;
+      h.comm = it->second.comm;
+    } else {
+      ncclComm_t comm;
+      IFEM_NCCL_CHECK(ncclCommInitRank(&comm, h.nranks, id, h.rank));
+      g_comms[key] = SharedComm{comm, 1};
+      h.comm = comm;
+    }
   }
 }
 
 void comm_destroy(ifem_ctx *ctx) {
-  if (ctx->halo.comm) ncclCommDestroy((ncclComm_t)ctx->halo.comm);
+  if (ctx->halo.comm) {
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    for (auto it = g_comms.begin(); it != g_comms.end(); ++it)
+      if (it->second.comm == (ncclComm_t)ctx->halo.comm) {
+        if (--it->second.refs == 0) { ncclCommDestroy(it->second.comm); g_comms.erase(it); }
+        break;
+      }
+  }
   ctx->halo.comm = nullptr;
 }
 
@@ -274,6 +304,24 @@ static void allreduce(ifem_ctx *ctx, double *host_vals, int n, bool is_max) {
 }
 
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, host_vals, n, false); }
+
+// Sum of n DEVICE-resident scalars over the ranks, in place, ordered on the context stream and without a host round trip
+// (RCCL): what the device-resident CG recurrences use between their partial reductions and the scalar update.  The
+// validation transport has no device-side collective: it synchronises and goes through the host path.
+void allreduce_sum_dev(ifem_ctx *ctx, double *dev_vals, int n) {
+  Halo &h = ctx->halo;
+  if (h.nranks == 1 || n <= 0) return;
+  if (h.local) {
+    std::vector<double> tmp(n);
+    IFEM_HIP_CHECK(hipMemcpyAsync(tmp.data(), dev_vals, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    allreduce(ctx, tmp.data(), n, false);
+    IFEM_HIP_CHECK(hipMemcpyAsync(dev_vals, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // tmp leaves scope
+    return;
+  }
+  IFEM_NCCL_CHECK(ncclAllReduce(dev_vals, dev_vals, n, ncclDouble, ncclSum, (ncclComm_t)h.comm, ctx->stream));
+}
 void allreduce_max(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, host_vals, n, true); }
 
 // One-rank RCCL round trip (communicator, all-reduce, grouped send/recv to self) on `device`: checks on a

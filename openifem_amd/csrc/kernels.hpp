@@ -124,6 +124,7 @@ void cheb_init_block(ifem_ctx *ctx, double c0, const double *r, double *d);
 // all-reduce helpers (identity for a single rank)
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n);
 void allreduce_max(ifem_ctx *ctx, double *host_vals, int n);
+void allreduce_sum_dev(ifem_ctx *ctx, double *dev_vals, int n); // device scalars, in place, stream-ordered
 int comm_unique_id(uint8_t out[128]);
 int comm_selftest(int device);
 void *local_world_create(int nranks);

@@ -829,23 +829,41 @@ __global__ __launch_bounds__(256) void k_cgd_init(int64_t n, const double *__res
 }
 // one block: sums the partials of `nrow` dot products and advances the recurrence
 //   stage 0: rr, rz            stage 1: pq -> alpha = rz / pq            stage 2: rr', rz' -> beta = rz' / rz
-__global__ __launch_bounds__(256) void k_cgd_scalars(int nblk, const double *__restrict__ part, double *__restrict__ sc, int stage) {
+// part 0: both in one launch (single rank); part 1: sums only, left in sc[CGD + 8..9] for the all-reduce over the ranks;
+// part 2: the scalar update from those sums
+__global__ __launch_bounds__(256) void k_cgd_scalars(int nblk, const double *__restrict__ part, double *__restrict__ sc, int stage, int piece) {
   __shared__ double sh[2][4];
-  double t[2] = {0, 0};
-  const int nrow = stage == 1 ? 1 : 2;
-  for (int k = 0; k < nrow; ++k)
-    for (int i = threadIdx.x; i < nblk; i += blockDim.x) t[k] += part[int64_t(k) * MDOT_MAXB + i];
-  for (int k = 0; k < 2; ++k) {
-    for (int off = 32; off > 0; off >>= 1) t[k] += __shfl_xor(t[k], off, 64);
-    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = t[k];
+  double a = 0, b = 0;
+  if (piece != 2) {
+    double t[2] = {0, 0};
+    const int nrow = stage == 1 ? 1 : 2;
+    for (int k = 0; k < nrow; ++k)
+      for (int i = threadIdx.x; i < nblk; i += blockDim.x) t[k] += part[int64_t(k) * MDOT_MAXB + i];
+    for (int k = 0; k < 2; ++k) {
+      for (int off = 32; off > 0; off >>= 1) t[k] += __shfl_xor(t[k], off, 64);
+      if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = t[k];
+    }
+    __syncthreads();
+    a = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]; b = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
   }
-  __syncthreads();
   if (threadIdx.x == 0) {
-    const double a = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], b = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    if (piece == 1) { sc[CGD + 8] = a; sc[CGD + 9] = b; return; }
+    if (piece == 2) { a = sc[CGD + 8]; b = sc[CGD + 9]; }
     if (stage == 0) { sc[CGD + 0] = a; sc[CGD + 1] = b; }
     else if (stage == 1) { sc[CGD + 2] = a; sc[CGD + 3] = a != 0.0 ? sc[CGD + 1] / a : 0.0; }
     else { sc[CGD + 4] = sc[CGD + 1] != 0.0 ? b / sc[CGD + 1] : 0.0; sc[CGD + 0] = a; sc[CGD + 1] = b; }
   }
+}
+// the scalar step of one stage: on several ranks the local sums are all-reduced on the stream between the two pieces
+static void cgd_scalars(ifem_ctx *ctx, unsigned nblk, int stage) {
+  hipStream_t s = ctx->stream;
+  if (ctx->halo.nranks == 1) {
+    hipLaunchKernelGGL(k_cgd_scalars, dim3(1), dim3(256), 0, s, (int)nblk, ctx->partials.p, ctx->scal.p, stage, 0);
+    return;
+  }
+  hipLaunchKernelGGL(k_cgd_scalars, dim3(1), dim3(256), 0, s, (int)nblk, ctx->partials.p, ctx->scal.p, stage, 1);
+  allreduce_sum_dev(ctx, ctx->scal.p + CGD + 8, stage == 1 ? 1 : 2);
+  hipLaunchKernelGGL(k_cgd_scalars, dim3(1), dim3(64), 0, s, (int)nblk, ctx->partials.p, ctx->scal.p, stage, 2);
 }
 __global__ __launch_bounds__(256) void k_cgd_update(int64_t n, const double *__restrict__ sc, const double *__restrict__ diag,
                                                     const double *__restrict__ p, const double *__restrict__ q,
@@ -871,17 +889,17 @@ void cgd_init(ifem_ctx *ctx, int64_t n, const double *b, const double *diag, dou
   if (ctx->partials.n == 0) ctx->partials.alloc(size_t(64) * MDOT_MAXB);
   const unsigned nblk = vgrid(n);
   hipLaunchKernelGGL(k_cgd_init, dim3(nblk), dim3(256), 0, ctx->stream, n, b, diag, x, r, z, p, ctx->partials.p);
-  hipLaunchKernelGGL(k_cgd_scalars, dim3(1), dim3(256), 0, ctx->stream, (int)nblk, ctx->partials.p, ctx->scal.p, 0);
+  cgd_scalars(ctx, nblk, 0);
 }
 void cgd_alpha(ifem_ctx *ctx, int64_t n, const double *p, const double *q) {
   const unsigned nblk = vgrid(n);
   hipLaunchKernelGGL((k_mdot<1>), dim3(nblk), dim3(256), 0, ctx->stream, n, 0, p, n, q, ctx->partials.p);
-  hipLaunchKernelGGL(k_cgd_scalars, dim3(1), dim3(256), 0, ctx->stream, (int)nblk, ctx->partials.p, ctx->scal.p, 1);
+  cgd_scalars(ctx, nblk, 1);
 }
 void cgd_update(ifem_ctx *ctx, int64_t n, const double *diag, double *p, const double *q, double *x, double *r, double *z) {
   const unsigned nblk = vgrid(n);
   hipLaunchKernelGGL(k_cgd_update, dim3(nblk), dim3(256), 0, ctx->stream, n, ctx->scal.p, diag, p, q, x, r, z, ctx->partials.p);
-  hipLaunchKernelGGL(k_cgd_scalars, dim3(1), dim3(256), 0, ctx->stream, (int)nblk, ctx->partials.p, ctx->scal.p, 2);
+  cgd_scalars(ctx, nblk, 2);
   hipLaunchKernelGGL(k_cgd_p, dim3(nblk), dim3(256), 0, ctx->stream, n, ctx->scal.p, diag ? z : r, p);
 }
 double cgd_rr(ifem_ctx *ctx) { // the only host synchronisation of the loop

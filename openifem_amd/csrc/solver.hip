@@ -199,7 +199,8 @@ static int cg(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *b, double *
 
 // CG / Jacobi-PCG whose recurrence scalars stay on the device: five launches and no host round trip per iteration; the
 // host reads ||r||^2 every `chk` iterations, so up to chk - 1 iterations run beyond the tolerance (harmless: they only
-// tighten the solve).  Same iterates as cg() / pcg_jacobi() up to that point.  Single rank (the dots are not all-reduced).
+// tighten the solve).  Same iterates as cg() / pcg_jacobi() up to that point.  On several ranks the partial sums are
+// all-reduced on the stream (RCCL) between the reduction and the scalar update: still no host round trip per iteration.
 static int cg_device(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *diag, const double *b, double *x, double tol,
                      int maxit, double *r, double *z, double *p, double *q, int chk) {
   cgd_init(ctx, n, b, diag, x, r, z, p);
@@ -646,19 +647,19 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   double *tmp = S.tp[0], *r = S.tp[1], *p = S.tp[2], *q = S.tp[3];
   auto pdot = [&](const double *a, const double *b) { return dot_all(S, S.npo, a, b); };
   const double n1 = std::sqrt(pdot(src1, src1));
-  const bool multi_early = c->halo.nranks > 1;
   Clock ck;
   // CG for Mp (:69-84)
   OpFn mp = [&](const double *x, double *y) { const double *xe; extend_p(S, x, &xe); spmv_mp(c, xe, y); };
   // kinds 1 and 3 (approximate preconditioner) also put a Jacobi preconditioner on the two pressure CG solves: same
   // stopping rule on the true residual, fewer iterations (the reference uses PreconditionNone; counts are no parity target)
-  const bool pjac = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF;
+  const bool pjac = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF || o->ainv_kind == IFEM_AINV_MG;
   auto pmdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
     v_mdot(c, S.npo, k, V, ld, w, out);
     allreduce_sum(c, out, k);
   };
   const int pmax = (int)std::min<int64_t>(std::max<int64_t>(c->n_global_p, 1), 1 << 30);
-  const bool dev_cg = !multi_early && o->device_cg;
+  // device-resident recurrences on any number of ranks: the dot products are all-reduced on the stream (comm.hip::allreduce_sum_dev)
+  const bool dev_cg = o->device_cg != 0;
   if (dev_cg) {
     if (pjac) scalar_diag(c, c->Mp, c->Mp.val.p, S.tp[5]);
     S.st.cg_mp_iters += cg_device(c, S.npo, mp, pjac ? S.tp[5] : nullptr, src1, tmp, std::max(o->mp_abs, o->mp_rel * n1), pmax,

@@ -58,16 +58,18 @@ def _unique_id(rank, dist):
 
 def make_channel_solver(n, rank, world, local_rank, dist, multigrid=True):
     """the bench's channel on `world` ranks (n^3 cells per rank) and, with multigrid, its chain of coarser levels: every
-    level is a context of its own with its own communicator (one more unique id per level)"""
+    level is a context of its own; all of them name the same unique id and therefore share one RCCL communicator
+    (comm.hip keeps one per id and process)"""
     if world not in PROC_GRIDS:
         raise SystemExit(f"--gpus must be one of {sorted(PROC_GRIDS)}")
     P = PROC_GRIDS[world]
     extent = (2.0, 0.2, 0.2)
+    uid = _unique_id(rank, dist) if world > 1 else None
 
     def make(reps, level):
         s = host.InsIM(host.channel_prm(3), reps, (0, 0, 0), extent, device=local_rank, verbose=False)
         if world > 1:
-            s.set_partition(P, rank, nccl_unique_id=_unique_id(rank, dist))
+            s.set_partition(P, rank, nccl_unique_id=uid)
         s.setup(0)
         return s
 
