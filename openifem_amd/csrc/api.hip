@@ -59,7 +59,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
 
 void ifem_default_tuning(ifem_tuning *t) {
   t->geo_cache = 1; t->xcd_swizzle = 1; t->asm_skip = 0; t->spmv_lanes = 32; t->sm_lanes = 32; t->mf_f32 = 1;
-  t->tpp_operator = 0; t->tpp_dense_max = 12288; t->basis_pad = 32 * 33;
+  t->tpp_operator = 0; t->halo_overlap = 1; t->tpp_dense_max = 12288; t->basis_pad = 32 * 33;
 }
 
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
@@ -248,6 +248,13 @@ int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t) 
     c->stream = s;
     c->owns_stream = false;
     if (c->rocblas) ifem::tpp_release(c);
+    // likewise one halo stream (the levels share the communicators, comm.hip)
+    if (fine->halo.hstream && c->halo.hstream && c->halo.hstream != fine->halo.hstream) {
+      IFEM_HIP_CHECK(hipStreamSynchronize(c->halo.hstream));
+      if (c->halo.owns_hstream) (void)hipStreamDestroy(c->halo.hstream);
+      c->halo.hstream = fine->halo.hstream;
+      c->halo.owns_hstream = false;
+    }
   }
   IFEM_API_END
 }

@@ -31,7 +31,8 @@ using MfTables = MfTablesT<double>;
 // inner Krylov solve (tolerance 1e-2; its basis is single precision already).  Vectors in HBM stay double either way.
 template <typename R>
 struct MfArgsT {
-  int64_t n_cells, nUo;
+  int64_t n_cells, nUo; // n_cells: one past the last cell of this launch
+  int64_t first_cell;   // first cell of this launch
   const double *vcoords;
   const int32_t *cell_unodes;
   const uint8_t *is_c; // constraint flags of the set the matrix was assembled with (local dofs) or nullptr
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
   }
 
   // every block owns one contiguous range of cell pairs (XCD-aware: neighbouring ranges run on the same XCD)
-  const int64_t n_pairs = (A.n_cells + 1) / 2;
+  const int64_t n_pairs = (A.n_cells - A.first_cell + 1) / 2;
   const int64_t per_block = (n_pairs + gridDim.x - 1) / gridDim.x;
   const int64_t vb = A.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
   const int64_t p_end = (vb + 1) * per_block < n_pairs ? (vb + 1) * per_block : n_pairs;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
   // everything is kept RAW (double / byte) until it is consumed, so that no conversion forces a wait next to a load.
   const int64_t p_first = vb * per_block + wave;
   // 32-bit index arithmetic in the prefetch (cells * nodes-per-cell and dim * nodes are below 2^31 by the int32 node ids)
-  auto cell_of = [&](int64_t pr) { const int64_t c = 2 * pr + half; return (pr < p_end && c < A.n_cells) ? uint32_t(c) : 0u; };
+  auto cell_of = [&](int64_t pr) { const int64_t c = A.first_cell + 2 * pr + half; return (pr < p_end && c < A.n_cells) ? uint32_t(c) : 0u; };
   struct Pre { int32_t nd; double x[DIM], u[DIM], vc; uint8_t f[DIM]; } pre;
   auto load_id = [&](int64_t pr) -> int32_t { return q_lane ? A.cell_unodes[cell_of(pr) * uint32_t(NN) + uint32_t(hl)] : 0; };
   auto load_vals = [&](int64_t pr, int32_t nd, Pre &o) {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
   int32_t nd_ahead = load_id(p_first + WPB);
   load_vals(p_first, load_id(p_first), pre);
   for (int64_t pair = p_first; pair < p_end; pair += WPB) {
-    const int64_t cell = 2 * pair + half;
+    const int64_t cell = A.first_cell + 2 * pair + half;
     const bool active = cell < A.n_cells;
     // ---- gather: this cell's values are in registers; start the id load of the cell after the next
     const Pre cur = pre;
@@ -464,13 +465,18 @@ static void mf_tables(MfTables &t, int kv) {
 }
 
 template <typename R>
-static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu, const MfFuse *fuse) {
+static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu, const MfFuse *fuse, int part) {
   if (!ctx->mf_valid) throw Error(IFEM_E_BADPARAM, "matrix-free A_uu: no assembled state (call ifem_ins_assemble first)");
   const int64_t n = int64_t(ctx->dim) * ctx->nUo;
   hipStream_t s = ctx->stream;
   MfArgsT<R> a{};
-  a.n_cells = ctx->n_cells; a.nUo = ctx->nUo;
-  a.vcoords = ctx->vcoords.p; a.cell_unodes = ctx->cell_unodes.p;
+  // cell range of this launch; with the interior-first tables (several ranks) every part uses them, part 0 included
+  if (part != 0 && ctx->mf_n_interior < 0) throw Error(IFEM_E_BADPARAM, "matrix-free A_uu: cell split not built");
+  const bool perm = ctx->mf_n_interior >= 0;
+  a.first_cell = part == 2 ? ctx->mf_n_interior : 0;
+  a.n_cells = part == 1 ? ctx->mf_n_interior : ctx->n_cells;
+  a.nUo = ctx->nUo;
+  a.vcoords = perm ? ctx->mf_vcoords.p : ctx->vcoords.p; a.cell_unodes = perm ? ctx->mf_cell_unodes.p : ctx->cell_unodes.p;
   a.is_c = ctx->has_c[ctx->asm_constraint_set] ? ctx->is_c[ctx->asm_constraint_set].p : nullptr;
   a.eval = ctx->mf_eval.p; a.x = xu; a.y = yu;
   a.mu = R(ctx->mf_params.viscosity); a.rho = R(ctx->mf_params.rho); a.gamma = R(ctx->mf_params.grad_div);
@@ -486,7 +492,7 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu, const MfF
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s)); // the cell kernel alone (what rocprofv3 reports for it)
   constexpr int WPB = 4;
   const dim3 block(64 * WPB);
-  const int64_t n_pairs = (ctx->n_cells + 1) / 2;
+  const int64_t n_pairs = (a.n_cells - a.first_cell + 1) / 2;
   const bool conv = !ctx->mf_noconv;
   // every block walks one contiguous range of cell pairs: the grid is a whole number of resident rounds (4 per CU slot)
   // so that no round runs partly empty
@@ -502,11 +508,14 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu, const MfF
                 hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, true, R>), dim3(std::min(cap, g_all)), block, 0, s, a); }       \
     else { static const unsigned cap = grid_for_kernel(reinterpret_cast<const void *>(&k_apply_uu_mf2<D, K, WPB, false, R>));     \
            hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, false, R>), dim3(std::min(cap, g_all)), block, 0, s, a); } }
-  if (ctx->dim == 3 && ctx->kv == 2) IFEM_MF2(3, 2)
-  else if (ctx->dim == 3) IFEM_MF2(3, 1)
-  else if (ctx->kv == 2) IFEM_MF2(2, 2)
-  else IFEM_MF2(2, 1)
+  if (n_pairs > 0) {
+    if (ctx->dim == 3 && ctx->kv == 2) IFEM_MF2(3, 2)
+    else if (ctx->dim == 3) IFEM_MF2(3, 1)
+    else if (ctx->kv == 2) IFEM_MF2(2, 2)
+    else IFEM_MF2(2, 1)
+  }
 #undef IFEM_MF2
+  if (part == 1) return; // the node gather follows the boundary cells
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
   const MfFuse f0 = fuse ? *fuse : MfFuse{};
 #define IFEM_MFG(D, F)                                                                                                 \
@@ -525,9 +534,9 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu, const MfF
 }
 
 // single = true: single-precision cell arithmetic (the inner, preconditioner-only solve); ifem_tuning::mf_f32 = 0 forces double
-void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single, const MfFuse *fuse) {
-  if (single && ctx->tune.mf_f32) apply_uu_mf_t<float>(ctx, xu, yu, fuse);
-  else apply_uu_mf_t<double>(ctx, xu, yu, fuse);
+void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single, const MfFuse *fuse, int part) {
+  if (single && ctx->tune.mf_f32) apply_uu_mf_t<float>(ctx, xu, yu, fuse, part);
+  else apply_uu_mf_t<double>(ctx, xu, yu, fuse, part);
 }
 
 } // namespace ifem

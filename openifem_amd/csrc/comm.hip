@@ -48,7 +48,7 @@ struct LocalWorld {
 // Communicators are shared by the contexts of one process that were given the same unique id (the levels of a multigrid
 // chain: same ranks, same neighbours, one stream): ncclCommInitRank is collective and allocates its channel buffers per
 // communicator, one per level would multiply both.  Reference-counted; the last context destroys it.
-struct SharedComm { ncclComm_t comm; int refs; };
+struct SharedComm { ncclComm_t comm, comm2; int refs; };
 static std::mutex g_comm_mu;
 static std::map<std::array<uint8_t, 128>, SharedComm> g_comms;
 
@@ -102,21 +102,43 @@ void comm_init(ifem_ctx *ctx, const ifem_partition *part) {
       if (cr != h.rank || cn != h.nranks) throw Error(IFEM_E_BADPARAM, "ifem_partition: this unique id already names a communicator of another rank / size");
       it->second.refs++;
       h.comm = it->second.comm;
+      h.comm2 = it->second.comm2;
     } else {
-      ncclComm_t comm;
+      ncclComm_t comm, comm2 = nullptr;
       IFEM_NCCL_CHECK(ncclCommInitRank(&comm, h.nranks, id, h.rank));
-      g_comms[key] = SharedComm{comm, 1};
+      // the halo traffic gets a communicator of its own: its groups run on another stream than the all-reduces of `comm`.
+      // Without it (an RCCL that cannot split) the exchanges simply stay on the context stream.
+      if (ncclCommSplit(comm, 0, h.rank, &comm2, nullptr) != ncclSuccess) comm2 = nullptr;
+      g_comms[key] = SharedComm{comm, comm2, 1};
       h.comm = comm;
+      h.comm2 = comm2;
+    }
+    if (h.comm2) {
+      int lo = 0, hi = 0;
+      IFEM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi)); // hi = numerically lowest = highest priority
+      IFEM_HIP_CHECK(hipStreamCreateWithPriority(&h.hstream, hipStreamNonBlocking, hi));
+      h.owns_hstream = true;
+      IFEM_HIP_CHECK(hipEventCreateWithFlags(&h.ev_pack, hipEventDisableTiming));
+      IFEM_HIP_CHECK(hipEventCreateWithFlags(&h.ev_done, hipEventDisableTiming));
     }
   }
 }
 
 void comm_destroy(ifem_ctx *ctx) {
+  Halo &hh = ctx->halo;
+  if (hh.ev_pack) (void)hipEventDestroy(hh.ev_pack);
+  if (hh.ev_done) (void)hipEventDestroy(hh.ev_done);
+  if (hh.hstream && hh.owns_hstream) (void)hipStreamDestroy(hh.hstream);
+  hh.ev_pack = hh.ev_done = nullptr; hh.hstream = nullptr; hh.comm2 = nullptr;
   if (ctx->halo.comm) {
     std::lock_guard<std::mutex> lk(g_comm_mu);
     for (auto it = g_comms.begin(); it != g_comms.end(); ++it)
       if (it->second.comm == (ncclComm_t)ctx->halo.comm) {
-        if (--it->second.refs == 0) { ncclCommDestroy(it->second.comm); g_comms.erase(it); }
+        if (--it->second.refs == 0) {
+          if (it->second.comm2) ncclCommDestroy(it->second.comm2);
+          ncclCommDestroy(it->second.comm);
+          g_comms.erase(it);
+        }
         break;
       }
   }
@@ -134,7 +156,9 @@ __global__ void k_pack(int64_t n, int bs, const int32_t *__restrict__ idx, const
 
 // which: 0 = velocity nodes (bs = dim), 1 = pressure nodes (bs = 1)
 // which: 0 velocity halo, 1 pressure halo, 2 the 2-deep pressure halo of the distributed S_m
-static void exchange(ifem_ctx *ctx, double *x, int which) {
+// async: the send/recv group goes to the halo stream (second communicator) behind an event recorded after the packing
+// kernel, and leaves an event for halo_wait; otherwise everything is ordered on the context stream
+static void exchange(ifem_ctx *ctx, double *x, int which, bool async = false) {
   Halo &h = ctx->halo;
   const int bs = which == 0 ? ctx->dim : 1;
   const int64_t n_owned = which == 0 ? ctx->nUo : ctx->nPo;
@@ -175,13 +199,40 @@ static void exchange(ifem_ctx *ctx, double *x, int which) {
     w->barrier(); // peers may now overwrite their send buffers
     return;
   }
+  async = async && h.comm2 && h.hstream;
+  hipStream_t st = async ? h.hstream : ctx->stream;
+  ncclComm_t cm = (ncclComm_t)(async ? h.comm2 : h.comm);
+  if (async) { // the halo stream picks up behind the packing kernel (and everything before it on the context stream)
+    IFEM_HIP_CHECK(hipEventRecord(h.ev_pack, ctx->stream));
+    IFEM_HIP_CHECK(hipStreamWaitEvent(st, h.ev_pack, 0));
+  }
   IFEM_NCCL_CHECK(ncclGroupStart());
   for (int k = 0; k < nn; ++k) {
     const int64_t sc = int64_t(sptr[k + 1] - sptr[k]) * bs, rc = int64_t(rptr[k + 1] - rptr[k]) * bs;
-    if (sc) IFEM_NCCL_CHECK(ncclSend(sendbuf + int64_t(sptr[k]) * bs, sc, ncclDouble, h.nbr[k], (ncclComm_t)h.comm, ctx->stream));
-    if (rc) IFEM_NCCL_CHECK(ncclRecv(x + (n_owned + rptr[k]) * bs, rc, ncclDouble, h.nbr[k], (ncclComm_t)h.comm, ctx->stream));
+    if (sc) IFEM_NCCL_CHECK(ncclSend(sendbuf + int64_t(sptr[k]) * bs, sc, ncclDouble, h.nbr[k], cm, st));
+    if (rc) IFEM_NCCL_CHECK(ncclRecv(x + (n_owned + rptr[k]) * bs, rc, ncclDouble, h.nbr[k], cm, st));
   }
   IFEM_NCCL_CHECK(ncclGroupEnd());
+  if (async) IFEM_HIP_CHECK(hipEventRecord(h.ev_done, st));
+}
+
+// Overlapped halo exchange: halo_start packs on the context stream and lets the transfers run on the halo stream;
+// kernels launched on the context stream up to halo_wait must not read ghost entries of x (nor write its owned ones).
+// which: 0 velocity, 1 pressure, 2 the 2-deep pressure halo of S_m.  The validation transport exchanges synchronously
+// in halo_start (the split of the consumers is exercised all the same).
+bool halo_overlap_ok(const ifem_ctx *ctx) {
+  const Halo &h = ctx->halo;
+  return h.nranks > 1 && ctx->tune.halo_overlap && (h.local || (h.comm2 && h.hstream));
+}
+void halo_start(ifem_ctx *ctx, double *x_ext, int which) {
+  if (ctx->halo.nranks == 1) return;
+  if (which == 2 && !ctx->halo.has_s) throw Error(IFEM_E_BADPARAM, "no 2-deep pressure halo plan in this context");
+  exchange(ctx, x_ext, which, true);
+}
+void halo_wait(ifem_ctx *ctx) {
+  Halo &h = ctx->halo;
+  if (h.nranks == 1 || h.local || !h.comm2 || !h.hstream) return;
+  IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, h.ev_done, 0));
 }
 
 __global__ void k_unpack_add(int64_t n, int bs, const int32_t *__restrict__ idx, const double *__restrict__ buf,
@@ -347,8 +398,38 @@ int comm_selftest(int device) {
   std::vector<double> out(64);
   IFEM_HIP_CHECK(hipMemcpyAsync(out.data(), b.p, 64 * 8, hipMemcpyDeviceToHost, s));
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  // the overlapped exchange's plumbing (comm_init / exchange(async)): split communicator, high-priority stream, the
+  // event pair, a send/recv group on the second stream and a stream-ordered all-reduce of device scalars
+  ncclComm_t comm2 = nullptr;
+  IFEM_NCCL_CHECK(ncclCommSplit(comm, 0, 0, &comm2, nullptr));
+  int lo = 0, hi = 0;
+  IFEM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  hipStream_t hs;
+  IFEM_HIP_CHECK(hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, hi));
+  hipEvent_t e0, e1;
+  IFEM_HIP_CHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+  IFEM_HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+  DBuf<double> c2;
+  c2.alloc(64);
+  IFEM_HIP_CHECK(hipMemsetAsync(c2.p, 0, 64 * 8, s));
+  IFEM_HIP_CHECK(hipEventRecord(e0, s));
+  IFEM_HIP_CHECK(hipStreamWaitEvent(hs, e0, 0));
+  IFEM_NCCL_CHECK(ncclGroupStart());
+  IFEM_NCCL_CHECK(ncclSend(b.p, 64, ncclDouble, 0, comm2, hs));
+  IFEM_NCCL_CHECK(ncclRecv(c2.p, 64, ncclDouble, 0, comm2, hs));
+  IFEM_NCCL_CHECK(ncclGroupEnd());
+  IFEM_HIP_CHECK(hipEventRecord(e1, hs));
+  IFEM_NCCL_CHECK(ncclAllReduce(a.p, a.p, 2, ncclDouble, ncclSum, comm, s)); // meanwhile on the first communicator
+  IFEM_HIP_CHECK(hipStreamWaitEvent(s, e1, 0));
+  std::vector<double> out2(64);
+  IFEM_HIP_CHECK(hipMemcpyAsync(out2.data(), c2.p, 64 * 8, hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  ncclCommDestroy(comm2);
   ncclCommDestroy(comm);
+  (void)hipStreamDestroy(hs);
   (void)hipStreamDestroy(s);
+  for (int i = 0; i < 64; ++i) if (out2[i] != h[i]) throw Error(IFEM_E_COMM, "RCCL self-test: wrong data on the halo stream");
   for (int i = 0; i < 64; ++i) if (out[i] != h[i]) throw Error(IFEM_E_COMM, "RCCL self-test: wrong data");
   return IFEM_OK;
 }

@@ -102,6 +102,10 @@ struct PlanarCsr {
   DBuf<int64_t> rowptr;
   DBuf<int32_t> col;
   DBuf<double> val;
+  // several ranks: rows whose columns are all owned (they can be multiplied while the halo is in flight) listed first,
+  // then the rows that read a ghost column; built on first use (setup.hip::build_row_split)
+  DBuf<int32_t> split_rows;
+  int64_t n_interior = -1, n_boundary = 0;
 };
 
 // FE tables for one (dim, kv): reference-cell shape values/gradients at the volume quadrature points.
@@ -134,6 +138,12 @@ struct Halo {
   bool has_s = false;
   DBuf<double> sendbuf;
   void *comm = nullptr;  // ncclComm_t
+  // overlapped exchanges (halo_start / halo_wait): a second communicator (ncclCommSplit of `comm`) whose send/recv groups
+  // run on `hstream` (high priority) while the context stream works on the rows / cells that need no ghost value
+  void *comm2 = nullptr;
+  hipStream_t hstream = nullptr;
+  bool owns_hstream = false;
+  hipEvent_t ev_pack = nullptr, ev_done = nullptr;
   void *local = nullptr; // LocalWorld* (in-process virtual ranks, validation transport)
   const double *rev_src = nullptr; // local world only: the extended vector whose ghosts the peers fetch in a reverse exchange
 };
@@ -185,6 +195,11 @@ struct ifem_ctx {
   ifem::DBuf<double> App, app_diag, stress, fsi_stress, sigma_pml, body_force, xinv, eddy_viscosity;
   bool has_app = false, stress_valid = false;
   ifem::PlanarCsr uinc;  // velocity node -> (cell << 5 | local index) incidence lists (gather stage of the matrix-free apply)
+  // several ranks: the matrix-free apply keeps its own copy of the cell tables with the cells whose nodes are all owned
+  // first (they are processed while the halo is in flight); the incidence lists then refer to this numbering
+  ifem::DBuf<int32_t> mf_cell_unodes;
+  ifem::DBuf<double> mf_vcoords;
+  int64_t mf_n_interior = -1;
   ifem_tuning tune{};    // ifem_set_tuning
   ifem::PlanarCsr Sm;  // mass_schur(1,1) = B diag(M_u)^-1 B^T, explicit (single rank only; empty otherwise)
   bool sm_valid = false;

@@ -11,6 +11,7 @@ void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, in
 void ensure_auu_values(ifem_ctx *ctx);
 void build_schur_pattern(ifem_ctx *ctx);
 void build_incidence(ifem_ctx *ctx);
+void build_mf_cell_split(ifem_ctx *ctx); // several ranks: interior-first copy of the cell tables for the matrix-free apply
 
 // assemble.hip
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
@@ -31,7 +32,7 @@ struct VecLayout {
 inline VecLayout layout_of(const ifem_ctx *c) { return {c->dim * c->nUo, c->dim * c->nUl, c->nPo}; }
 
 // y_u = A_uu x_u (+ B^T x_p when xp != nullptr)
-void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool use_f32);
+void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool use_f32, int part = 0);
 // apply_mf.hip: y_u = A_uu x_u without the stored matrix (sum-factorised cell kernel on the state of the last assemble)
 // optional epilogue of the matrix-free product t = A_uu x (owned rows), see apply_mf.hip::k_mf_gather: t is consumed instead of
 // stored.  mode 1: xs += x, r -= t; mode 2 additionally d = a x + b (inverse node block) r -- the Chebyshev step of the
@@ -41,13 +42,18 @@ struct MfFuse {
   double a = 0, b = 0;
   double *xs = nullptr, *r = nullptr, *d = nullptr;
 };
-void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single = false, const MfFuse *fuse = nullptr);
+// part (several ranks, build_mf_cell_split): 0 every cell, then the node gather; 1 only the cells whose nodes are all owned
+// (no ghost entry of xu is read: the halo may still be in flight); 2 the remaining cells, then the gather
+void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single = false, const MfFuse *fuse = nullptr, int part = 0);
 // scalar velocity operator S^ (IFEM_AINV_SCALAR_GMRES): auxiliary data, SpMV on all components, Jacobi
 void shat_refresh(ifem_ctx *ctx, bool f32);
 void spmv_shat(ifem_ctx *ctx, const double *xu, double *yu, bool f32);
 void shat_jacobi(ifem_ctx *ctx, const double *x, double *y);
 // y_p = B x_u
-void spmv_b(ifem_ctx *ctx, const double *xu, double *yp);
+// `part` of the row-parallel products below: 0 all rows, 1 the rows that read owned columns only, 2 the others (several
+// ranks: 1 runs while the halo of x is in flight, 2 after halo_wait; see PlanarCsr::split_rows)
+void build_row_split(ifem_ctx *ctx, PlanarCsr &M, int64_t n_owned_cols, const PlanarCsr *M2 = nullptr, int64_t n_owned_cols2 = 0);
+void spmv_b(ifem_ctx *ctx, const double *xu, double *yp, int part = 0);
 // y_u = B^T x_p
 void spmv_bt(ifem_ctx *ctx, const double *xp, double *yu);
 void spmv_b_f32(ifem_ctx *ctx, const double *xu, double *yp);  // same with single-precision copies of the values
@@ -57,10 +63,10 @@ void spmv_app(ifem_ctx *ctx, const double *xp, double *yp);
 void app_diag_setup(ifem_ctx *ctx);
 void scalar_diag(ifem_ctx *ctx, const PlanarCsr &M, const double *val, double *d);
 // y_p = M_p x_p
-void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp);
+void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp, int part = 0);
 // explicit S_m: numeric product B diag(1/diag M_u) B^T into ctx->Sm (pattern must exist), and y_p = S_m x_p
 void schur_numeric(ifem_ctx *ctx);
-void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp, bool use_f32);
+void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp, bool use_f32, int part = 0);
 // y_u = d .* x_u (diagonal scaling with 1/diag(M_u))
 void vec_mul(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y);
 void vec_div(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y); // y = x ./ d (d == 0 -> 1)
@@ -135,6 +141,10 @@ void halo_exchange_p(ifem_ctx *ctx, double *xp_ext);
 // transpose: ghost entries are sent back to their owners and added there (C^T of hanging lines across ranks)
 void halo_reverse_add(ifem_ctx *ctx, double *xu_ext);
 void halo_reverse_add_p(ifem_ctx *ctx, double *xp_ext);
+// overlapped form: halo_start (pack + transfers on the halo stream), work that reads no ghost entry, halo_wait
+bool halo_overlap_ok(const ifem_ctx *ctx);
+void halo_start(ifem_ctx *ctx, double *x_ext, int which); // which: 0 velocity, 1 pressure, 2 the 2-deep halo of S_m
+void halo_wait(ifem_ctx *ctx);
 void halo_exchange_s(ifem_ctx *ctx, double *xs_ext); // [n_s_cols]: owned pressure nodes, then the 2-deep far nodes
 void build_schur_pattern_box(ifem_ctx *ctx);          // distributed explicit S_m on a structured pressure lattice
 void schur_probe_fill(ifem_ctx *ctx, int color, const double *y); // S_m[i, j(color)] = y_i

@@ -102,10 +102,12 @@ __global__ __launch_bounds__(256) void k_spmv_uu(int64_t n_rows, const int64_t *
                                                  const int32_t *__restrict__ col_a, const VT *__restrict__ val_a,
                                                  const int64_t *__restrict__ rp_t, const int32_t *__restrict__ col_t,
                                                  const double *__restrict__ val_t, const double *__restrict__ xu,
-                                                 const double *__restrict__ xp, double *__restrict__ yu) {
-  const int64_t row = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+                                                 const double *__restrict__ xp, double *__restrict__ yu,
+                                                 const int32_t *__restrict__ rows) {
+  const int64_t ridx = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
   const int lig = threadIdx.x & (G - 1);
-  if (row >= n_rows) return; // whole groups exit together
+  if (ridx >= n_rows) return; // whole groups exit together
+  const int64_t row = rows ? int64_t(rows[ridx]) : ridx; // a row list: n_rows counts its entries
   double acc[DIM];
 #pragma unroll
   for (int r = 0; r < DIM; ++r) acc[r] = 0;
@@ -135,10 +137,12 @@ __global__ __launch_bounds__(256) void k_spmv_uu(int64_t n_rows, const int64_t *
 template <int BR, int BC, int G, class VT = double>
 __global__ __launch_bounds__(256) void k_spmv_planar(int64_t n_rows, const int64_t *__restrict__ rp,
                                                      const int32_t *__restrict__ col, const VT *__restrict__ val,
-                                                     const double *__restrict__ x, double *__restrict__ y) {
-  const int64_t row = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+                                                     const double *__restrict__ x, double *__restrict__ y,
+                                                     const int32_t *__restrict__ rows = nullptr) {
+  const int64_t ridx = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
   const int lig = threadIdx.x & (G - 1);
-  if (row >= n_rows) return;
+  if (ridx >= n_rows) return;
+  const int64_t row = rows ? int64_t(rows[ridx]) : ridx; // a row list: n_rows counts its entries
   double acc[BR];
 #pragma unroll
   for (int r = 0; r < BR; ++r) acc[r] = 0;
@@ -154,6 +158,14 @@ __global__ __launch_bounds__(256) void k_spmv_planar(int64_t n_rows, const int64
 }
 
 static inline unsigned blocks_for_rows(int64_t n_rows, int G) { return unsigned((n_rows * G + 255) / 256); }
+// rows of `part` (kernels.hpp): count and list (nullptr = all rows in natural order)
+struct RowPart { int64_t n; const int32_t *rows; };
+static inline RowPart row_part(const PlanarCsr &M, int part) {
+  if (part == 0) return {M.n_rows, nullptr};
+  if (M.n_interior < 0) throw Error(IFEM_E_BADPARAM, "row split not built");
+  if (part == 1) return {M.n_interior, M.split_rows.p};
+  return {M.n_boundary, M.split_rows.p + M.n_interior};
+}
 static inline unsigned vgrid(int64_t n);
 
 __global__ void k_to_f32(int64_t n, const double *__restrict__ a, float *__restrict__ b) {
@@ -169,8 +181,10 @@ void auu_f32_refresh(ifem_ctx *ctx) {
   ctx->auu_f32_valid = true;
 }
 
-void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool use_f32) {
-  const int64_t n = ctx->Auu.n_rows;
+void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool use_f32, int part) {
+  const RowPart rp_ = row_part(ctx->Auu, part);
+  const int64_t n = rp_.n;
+  const int32_t *rows = rp_.rows;
   if (n == 0) return;
   hipStream_t s = ctx->stream;
   const bool time_it = ctx->profile && xp == nullptr; // the A_uu-only launches of the inner solver: the dominant kernel
@@ -181,20 +195,20 @@ void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool
 #define IFEM_SPMV3(G)                                                                                                  \
   if (use_f32)                                                                                                         \
     hipLaunchKernelGGL((k_spmv_uu<3, G, float>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,    \
-                       ctx->Auu.col.p, ctx->Auu_f32.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);   \
+                       ctx->Auu.col.p, ctx->Auu_f32.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu, rows); \
   else                                                                                                                 \
     hipLaunchKernelGGL((k_spmv_uu<3, G, double>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,   \
-                       ctx->Auu.col.p, ctx->Auu.val.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
+                       ctx->Auu.col.p, ctx->Auu.val.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu, rows);
     if (Gsel == 16) { IFEM_SPMV3(16) } else if (Gsel == 64) { IFEM_SPMV3(64) } else if (Gsel == 8) { IFEM_SPMV3(8) } else { IFEM_SPMV3(32) }
 #undef IFEM_SPMV3
   } else {
     constexpr int G = 16;
     if (use_f32)
       hipLaunchKernelGGL((k_spmv_uu<2, G, float>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
-                         ctx->Auu.col.p, ctx->Auu_f32.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
+                         ctx->Auu.col.p, ctx->Auu_f32.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu, rows);
     else
       hipLaunchKernelGGL((k_spmv_uu<2, G, double>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
-                         ctx->Auu.col.p, ctx->Auu.val.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu);
+                         ctx->Auu.col.p, ctx->Auu.val.p, ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xu, xp, yu, rows);
   }
   ctx->last_spmv_f32 = use_f32;
   if (time_it) {
@@ -325,15 +339,16 @@ void shat_jacobi(ifem_ctx *ctx, const double *x, double *y) {
   else hipLaunchKernelGGL((k_node_scale<2>), dim3(vgrid(n * 2)), dim3(256), 0, ctx->stream, n, ctx->shat_dinv.p, x, y);
 }
 
-void spmv_b(ifem_ctx *ctx, const double *xu, double *yp) {
-  const int64_t n = ctx->B.n_rows;
+void spmv_b(ifem_ctx *ctx, const double *xu, double *yp, int part) {
+  const RowPart rp_ = row_part(ctx->B, part);
+  const int64_t n = rp_.n;
   if (n == 0) return;
   if (ctx->dim == 3)
     hipLaunchKernelGGL((k_spmv_planar<1, 3, 32>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n,
-                       ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, xu, yp);
+                       ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, xu, yp, rp_.rows);
   else
     hipLaunchKernelGGL((k_spmv_planar<1, 2, 16>), dim3(blocks_for_rows(n, 16)), dim3(256), 0, ctx->stream, n,
-                       ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, xu, yp);
+                       ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, xu, yp, rp_.rows);
 }
 
 void spmv_bt(ifem_ctx *ctx, const double *xp, double *yu) {
@@ -401,11 +416,12 @@ void app_diag_setup(ifem_ctx *ctx) {
                             ctx->Mp.col.p, ctx->App.p, ctx->app_diag.p);
 }
 
-void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp) {
-  const int64_t n = ctx->Mp.n_rows;
+void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp, int part) {
+  const RowPart rp_ = row_part(ctx->Mp, part);
+  const int64_t n = rp_.n;
   if (n == 0) return;
   hipLaunchKernelGGL((k_spmv_planar<1, 1, 8>), dim3(blocks_for_rows(n, 8)), dim3(256), 0, ctx->stream, n,
-                     ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->Mp.val.p, xp, yp);
+                     ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->Mp.val.p, xp, yp, rp_.rows);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -532,28 +548,30 @@ void spmv_planar_scalar(ifem_ctx *ctx, const PlanarCsr &M, const double *val, co
                      val, xp, yp);
 }
 
-void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp, bool use_f32) {
-  const int64_t n = ctx->Sm.n_rows;
-  if (n == 0) return;
+void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp, bool use_f32, int part) {
+  if (ctx->Sm.n_rows == 0) return;
   if (use_f32 && !ctx->sm_f32_valid) {
     const int64_t nv = (int64_t)ctx->Sm.val.n;
     if (ctx->Sm_f32.n != (size_t)nv) ctx->Sm_f32.alloc(nv);
     hipLaunchKernelGGL(k_to_f32, dim3(8192), dim3(256), 0, ctx->stream, nv, ctx->Sm.val.p, ctx->Sm_f32.p);
     ctx->sm_f32_valid = true;
   }
+  const RowPart rp_ = row_part(ctx->Sm, part);
+  const int64_t n = rp_.n;
+  if (n == 0) return;
   const int Gs = ctx->tune.sm_lanes;
   if (use_f32 && Gs == 64)
     hipLaunchKernelGGL((k_spmv_planar<1, 1, 64, float>), dim3(blocks_for_rows(n, 64)), dim3(256), 0, ctx->stream, n,
-                       ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm_f32.p, xp, yp);
+                       ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm_f32.p, xp, yp, rp_.rows);
   else if (use_f32 && Gs == 16)
     hipLaunchKernelGGL((k_spmv_planar<1, 1, 16, float>), dim3(blocks_for_rows(n, 16)), dim3(256), 0, ctx->stream, n,
-                       ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm_f32.p, xp, yp);
+                       ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm_f32.p, xp, yp, rp_.rows);
   else if (use_f32)
     hipLaunchKernelGGL((k_spmv_planar<1, 1, 32, float>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n,
-                       ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm_f32.p, xp, yp);
+                       ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm_f32.p, xp, yp, rp_.rows);
   else
     hipLaunchKernelGGL((k_spmv_planar<1, 1, 32>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n,
-                       ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm.val.p, xp, yp);
+                       ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm.val.p, xp, yp, rp_.rows);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -153,6 +153,55 @@ void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, in
 }
 
 
+// ---- interior / boundary rows of a matrix on several ranks: a row is "boundary" when it reads a ghost column (column id
+// >= n_owned_cols) of its own pattern or of the optional second pattern M2 (A_uu rows also carry the B^T block); the
+// list keeps the row order inside both groups.
+__global__ void k_row_flag(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col, int32_t n_owned_cols,
+                           const int64_t *__restrict__ rp2, const int32_t *__restrict__ col2, int32_t n_owned_cols2,
+                           int64_t *__restrict__ flag) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+    bool b = false;
+    for (int64_t k = rp[r]; k < rp[r + 1] && !b; ++k) b = col[k] >= n_owned_cols;
+    if (rp2)
+      for (int64_t k = rp2[r]; k < rp2[r + 1] && !b; ++k) b = col2[k] >= n_owned_cols2;
+    flag[r] = b ? 1 : 0;
+  }
+}
+__global__ void k_row_split(int64_t n_rows, const int64_t *__restrict__ flag, const int64_t *__restrict__ before, int64_t n_interior,
+                            int32_t *__restrict__ rows) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+    if (flag[r]) rows[n_interior + before[r]] = int32_t(r);
+    else rows[r - before[r]] = int32_t(r);
+  }
+}
+void build_row_split(ifem_ctx *ctx, PlanarCsr &M, int64_t n_owned_cols, const PlanarCsr *M2, int64_t n_owned_cols2) {
+  if (M.n_interior >= 0) return;
+  hipStream_t s = ctx->stream;
+  const int64_t n = M.n_rows;
+  M.n_interior = 0; M.n_boundary = 0;
+  if (n == 0) return;
+  if (M2 && M2->n_rows != n) throw Error(IFEM_E_BADPARAM, "row split: the two patterns differ in their row count");
+  DBuf<int64_t> flag, before;
+  flag.alloc(n); before.alloc(n);
+  hipLaunchKernelGGL(k_row_flag, dim3(grid_for(n)), dim3(256), 0, s, n, M.rowptr.p, M.col.p, int32_t(n_owned_cols),
+                     M2 ? M2->rowptr.p : nullptr, M2 ? M2->col.p : nullptr, int32_t(n_owned_cols2), flag.p);
+  size_t tb = 0;
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, flag.p, before.p, int64_t(0), (size_t)n, rocprim::plus<int64_t>(), s));
+  DBuf<char> tmp;
+  tmp.alloc(tb + 16);
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(tmp.p, tb, flag.p, before.p, int64_t(0), (size_t)n, rocprim::plus<int64_t>(), s));
+  int64_t last_before = 0, last_flag = 0;
+  IFEM_HIP_CHECK(hipMemcpyAsync(&last_before, before.p + (n - 1), 8, hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipMemcpyAsync(&last_flag, flag.p + (n - 1), 8, hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  M.n_boundary = last_before + last_flag;
+  M.n_interior = n - M.n_boundary;
+  M.split_rows.alloc(n);
+  hipLaunchKernelGGL(k_row_split, dim3(grid_for(n)), dim3(256), 0, s, n, flag.p, before.p, M.n_interior, M.split_rows.p);
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  IFEM_HIP_CHECK(hipGetLastError());
+}
+
 // ---- mass_schur(1,1) pattern (compute_mmult_pattern(B, B^T), mpi_fluid_solver.cpp:326-329).  For the Q1 pressure space
 // pattern(B B^T) = pattern(M_p^2): p-nodes i, j couple iff cells c1 with i and c2 with j share a vertex.
 __global__ void k_sq_count(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
@@ -196,7 +245,58 @@ void build_incidence(ifem_ctx *ctx) {
     hipLaunchKernelGGL(k_gen_inc_keys, dim3(grid_for(N)), dim3(256), 0, s, ctx->n_cells, R, rows, n_rows, keys.p);
     pattern_from_keys(ctx, M, 0, n_rows, keys, N);
   };
-  one(ctx->uinc, ctx->nUo, ctx->nu, ctx->cell_unodes.p);
+  one(ctx->uinc, ctx->nUo, ctx->nu, ctx->mf_n_interior >= 0 ? ctx->mf_cell_unodes.p : ctx->cell_unodes.p);
+}
+
+// ---- cell tables of the matrix-free apply on several ranks: interior cells (all nodes owned) first, then the cells that
+// touch a ghost node; order kept inside both groups (the Morton locality survives)
+__global__ void k_cell_flag(int64_t n_cells, int nu, const int32_t *__restrict__ cell_unodes, int32_t n_owned, int64_t *__restrict__ flag) {
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n_cells; c += (int64_t)gridDim.x * blockDim.x) {
+    bool b = false;
+    for (int a = 0; a < nu; ++a) b = b || cell_unodes[c * nu + a] >= n_owned;
+    flag[c] = b ? 1 : 0;
+  }
+}
+__global__ void k_cell_permute(int64_t n_cells, int nu, int nvd, const int64_t *__restrict__ flag, const int64_t *__restrict__ before,
+                               int64_t n_interior, const int32_t *__restrict__ cu, const double *__restrict__ vc,
+                               int32_t *__restrict__ cu_out, double *__restrict__ vc_out) {
+  const int per = nu + nvd;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_cells * per; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = t / per;
+    const int k = int(t - c * per);
+    const int64_t dst = flag[c] ? n_interior + before[c] : c - before[c];
+    if (k < nu) cu_out[dst * nu + k] = cu[c * nu + k];
+    else vc_out[dst * nvd + (k - nu)] = vc[c * nvd + (k - nu)];
+  }
+}
+void build_mf_cell_split(ifem_ctx *ctx) {
+  if (ctx->mf_n_interior >= 0) return;
+  hipStream_t s = ctx->stream;
+  const int64_t n = ctx->n_cells;
+  if (n == 0) { ctx->mf_n_interior = 0; return; }
+  const int nu = ctx->nu, nvd = ctx->np * ctx->dim; // np = 2^dim vertices
+  DBuf<int64_t> flag, before;
+  flag.alloc(n); before.alloc(n);
+  hipLaunchKernelGGL(k_cell_flag, dim3(grid_for(n)), dim3(256), 0, s, n, nu, ctx->cell_unodes.p, int32_t(ctx->nUo), flag.p);
+  size_t tb = 0;
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, flag.p, before.p, int64_t(0), (size_t)n, rocprim::plus<int64_t>(), s));
+  DBuf<char> tmp;
+  tmp.alloc(tb + 16);
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(tmp.p, tb, flag.p, before.p, int64_t(0), (size_t)n, rocprim::plus<int64_t>(), s));
+  int64_t lb = 0, lf = 0;
+  IFEM_HIP_CHECK(hipMemcpyAsync(&lb, before.p + (n - 1), 8, hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipMemcpyAsync(&lf, flag.p + (n - 1), 8, hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  const int64_t n_int = n - (lb + lf);
+  ctx->mf_cell_unodes.alloc((size_t)n * nu);
+  ctx->mf_vcoords.alloc((size_t)n * nvd);
+  hipLaunchKernelGGL(k_cell_permute, dim3(grid_for(n * (nu + nvd))), dim3(256), 0, s, n, nu, nvd, flag.p, before.p, n_int,
+                     ctx->cell_unodes.p, ctx->vcoords.p, ctx->mf_cell_unodes.p, ctx->mf_vcoords.p);
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  IFEM_HIP_CHECK(hipGetLastError());
+  ctx->mf_n_interior = n_int;
+  ctx->uinc.n_rows = 0; // incidence lists of the natural numbering (if any) are stale
+  ctx->uinc.n_interior = -1;
 }
 
 // ---- distributed explicit S_m on a structured pressure lattice (box meshes on several ranks).  Row i couples the

@@ -283,8 +283,24 @@ static void extend_p(SolveState &S, const double *xp, const double **out) {
 // the assembled operator A^ = [A_uu B^T; B A_pp]: ghost-extended input (xu [dim*nUl], xp [nPl]), compact owned output
 static void system_apply_ext(SolveState &S, const double *xu, const double *xp, double *y, bool time_it);
 
-// the same on a compact owned vector (ghosts refreshed here)
+// the same on a compact owned vector (ghosts refreshed here).  Several ranks: both halos travel on the halo stream while the
+// rows without a ghost column are multiplied (comm.hip::halo_start / halo_wait, PlanarCsr::split_rows)
 static void system_apply_raw(SolveState &S, const double *x, double *y, bool time_it) {
+  ifem_ctx *c = S.ctx;
+  if (halo_overlap_ok(c) && !c->has_app && !(S.o->outer_matrix_free && c->mf_valid)) {
+    build_row_split(c, c->Auu, c->nUo, &c->Bt, c->nPo);
+    build_row_split(c, c->B, c->nUo);
+    v_copy(c, S.nuo, x, S.xu_ext);
+    v_copy(c, S.npo, x + S.nuo, S.xp_ext);
+    halo_start(c, S.xu_ext, 0);
+    halo_start(c, S.xp_ext, 1);
+    spmv_uu(c, S.xu_ext, S.xp_ext, y, false, 1);
+    spmv_b(c, S.xu_ext, y + S.nuo, 1);
+    halo_wait(c);
+    spmv_uu(c, S.xu_ext, S.xp_ext, y, false, 2);
+    spmv_b(c, S.xu_ext, y + S.nuo, 2);
+    return;
+  }
   const double *xu, *xp;
   extend_u(S, x, &xu);
   extend_p(S, x + S.nuo, &xp);
@@ -367,6 +383,14 @@ static void sm_apply(SolveState &S, const double *x, double *y, bool lowp) {
   ifem_ctx *c = S.ctx;
   if (sm_is_explicit(S) && c->halo.nranks > 1) {
     v_copy(c, S.npo, x, c->xs_ext.p);
+    if (halo_overlap_ok(c)) { // rows of S_m without a far column while the 2-deep halo travels
+      build_row_split(c, c->Sm, c->nPo);
+      halo_start(c, c->xs_ext.p, 2);
+      spmv_sm(c, c->xs_ext.p, y, lowp, 1);
+      halo_wait(c);
+      spmv_sm(c, c->xs_ext.p, y, lowp, 2);
+      return;
+    }
     halo_exchange_s(c, c->xs_ext.p);
     spmv_sm(c, c->xs_ext.p, y, lowp);
     return;
@@ -528,9 +552,21 @@ struct MgUu {
   double ratio = 8.0;
 };
 
+// matrix-free A_uu of one level on a compact owned vector.  Several ranks: the cells whose nodes are all owned are
+// processed while the velocity halo travels, the cells of the ghost layer and the node gather after it has arrived
 static void uu_apply_level(SolveState &S, const double *x, double *y, const MfFuse *fuse = nullptr) {
+  ifem_ctx *c = S.ctx;
+  if (halo_overlap_ok(c)) {
+    build_mf_cell_split(c);
+    v_copy(c, S.nuo, x, S.xu_ext);
+    halo_start(c, S.xu_ext, 0);
+    apply_uu_mf(c, S.xu_ext, y, true, fuse, 1);
+    halo_wait(c);
+    apply_uu_mf(c, S.xu_ext, y, true, fuse, 2);
+    return;
+  }
   const double *xe; extend_u(S, x, &xe);
-  apply_uu_mf(S.ctx, xe, y, true, fuse);
+  apply_uu_mf(c, xe, y, true, fuse);
 }
 
 static void mg_uu_setup(MgUu &M) {
@@ -649,7 +685,18 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   const double n1 = std::sqrt(pdot(src1, src1));
   Clock ck;
   // CG for Mp (:69-84)
-  OpFn mp = [&](const double *x, double *y) { const double *xe; extend_p(S, x, &xe); spmv_mp(c, xe, y); };
+  OpFn mp = [&](const double *x, double *y) {
+    if (halo_overlap_ok(c)) {
+      build_row_split(c, c->Mp, c->nPo);
+      v_copy(c, S.npo, x, S.xp_ext);
+      halo_start(c, S.xp_ext, 1);
+      spmv_mp(c, S.xp_ext, y, 1);
+      halo_wait(c);
+      spmv_mp(c, S.xp_ext, y, 2);
+      return;
+    }
+    const double *xe; extend_p(S, x, &xe); spmv_mp(c, xe, y);
+  };
   // kinds 1 and 3 (approximate preconditioner) also put a Jacobi preconditioner on the two pressure CG solves: same
   // stopping rule on the true residual, fewer iterations (the reference uses PreconditionNone; counts are no parity target)
   const bool pjac = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF || o->ainv_kind == IFEM_AINV_MG;
@@ -713,7 +760,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   const bool f32 = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32;
   OpFn Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_uu(c, xe, nullptr, y, f32); };
   if (o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF)
-    Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); apply_uu_mf(c, xe, y, true); };
+    Auu = [&](const double *x, double *y) { uu_apply_level(S, x, y); };
   const bool scalar_op = o->ainv_kind == IFEM_AINV_SCALAR_GMRES;
   if (scalar_op) shat_refresh(c, true);
   if (scalar_op) Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_shat(c, xe, y, true); };
