@@ -127,8 +127,8 @@ def bench_insimex(args, host):
     """Side measurement: steady-state InsIMEX time step = rhs-only assembly + FGMRES to
     min(1e-9, 1e-8 ||rhs||) on the same channel; the matrix is assembled in the two warm-up steps as InsIMEX::run does."""
     n = args.n
-    solver = host.InsIMEX(host.channel_prm(3), (n, n, n), (0, 0, 0), (2.0, 0.2, 0.2), verbose=False)
-    solver.setup(0)
+    from openifem_amd import multigpu
+    solver, _, _ = multigpu.make_channel_solver(n, 0, 1, int(os.environ.get("LOCAL_RANK", "0")), None, multigrid=bool(args.mg), kind="InsIMEX")
     n_cells, n_u, n_p = solver.sizes()
     solver.opts.ainv_kind = args.ainv
     solver.opts.inner_rel = args.inner_rel  # the host class defaults to the reference's 1e-4 (CG for A); 1e-2 is the measured optimum
@@ -144,11 +144,14 @@ def bench_insimex(args, host):
     for _ in range(args.steps):
         solver.run_one_step(False, False)
     dt = (time.time() - t0) / args.steps
+    st = solver.last_stats()
     print(json.dumps({"metric": "DoF/s per InsIMEX time step (rhs assembly + solve), 3D Q2/Q1", "value": (n_u + n_p) / dt,
                       "unit": "DoF/s", "n_gpus": 1, "steps": args.steps, "warmup": 2, "ms_per_step": dt * 1e3,
                       "higher_is_better": True, "dtype": "f64", "data": "synthetic",
                       "config": {"workload": f"3D channel flow {n}^3 Q2/Q1, mpi_insimex steady-state time step", "n_dofs": n_u + n_p,
-                                 "ainv_kind": args.ainv, "inner_rel": args.inner_rel}}), flush=True)
+                                 "ainv_kind": args.ainv, "inner_rel": args.inner_rel, "multigrid_levels": 1 + len(solver._levels),
+                                 "fgmres_iters": st.fgmres_iters, "cg_mp_iters": st.cg_mp_iters, "cg_sm_iters": st.cg_sm_iters,
+                                 "inner_iters": st.inner_iters}}), flush=True)
 
 
 def extras(solver, capi, n_dofs, warm_ms):
@@ -210,7 +213,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", dest="n", type=int, default=128, help="cells per direction per GPU")
-    ap.add_argument("--cpu-cells", dest="cpu_n", default="32", help="cells per direction of the CPU baseline sample(s), comma separated (0 = skip; BASELINE.md plans 32,64 -- 64 takes several minutes)")
+    ap.add_argument("--cpu-cells", dest="cpu_n", default="32,64", help="cells per direction of the CPU baseline sample(s), comma separated (0 = skip; BASELINE.md section 3 plans 32 and 64: 14 s and 63 s on the 64 threads the sweep picks)")
     ap.add_argument("--extras", type=int, default=1, help="N = 1 only: also measure cold_step (geometry blocks and S_m rebuilt, as the reference does every iteration) and time_step (a whole run_one_step Newton loop)")
     ap.add_argument("--inner-rel", type=float, default=1e-2)
     ap.add_argument("--ainv", type=int, default=4, help="IFEM_AINV_* kind of the A_uu^-1 replacement (4 = matrix-free operator + geometric multigrid V-cycle, 3 = matrix-free inner operator + block Jacobi, 1 = fp32 inner matrix, 0 = fp64 matrix)")

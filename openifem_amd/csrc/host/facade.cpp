@@ -308,6 +308,15 @@ int ifemx_run_one_step2(void *hv, int apply_nonzero, int assemble_system) {
     if (h->dim == 2) h->s2->run_one_step(apply_nonzero, assemble_system); else h->s3->run_one_step(apply_nonzero, assemble_system);
   });
 }
+// counters of the solver's most recent solve (also the one inside run_one_step)
+int ifemx_last_stats(void *hv, ifem_solve_stats *st) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (!st) throw std::runtime_error("ifemx_last_stats: null output");
+    auto get = [&](auto &s) { *st = s.last_stats; };
+    if (h->dim == 2) with_family<2>(h->s2.get(), get, get); else with_family<3>(h->s3.get(), get, get);
+  });
+}
 int ifemx_assemble(void *hv, int use_nonzero) {
   auto *h = static_cast<Handle *>(hv);
   return guard([&] {

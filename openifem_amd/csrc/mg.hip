@@ -98,95 +98,141 @@ struct DiagArgs {
   Tab1D t;
 };
 
+// Half a wavefront per cell (8 cells per block), 1D tables in LDS, every loop over nodes / points / components unrolled (the
+// node or point index of the inner loops is a compile-time constant, the lane's own index selects the LDS table row).
 template <int DIM, int KV>
 __global__ __launch_bounds__(256) void k_uu_diag(DiagArgs A) {
-  constexpr int N1 = KV + 1, NN = (DIM == 2) ? N1 * N1 : N1 * N1 * N1, NV = 1 << DIM;
-  __shared__ double sX[4][NV * DIM], sJi[4][NN * DIM * DIM], sW[4][NN], sU[4][NN * DIM], sGu[4][NN * DIM * DIM], sE[4][NN * DIM];
-  __shared__ int32_t sNode[4][NN];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t cell = int64_t(blockIdx.x) * 4 + wave;
+  constexpr int N1 = KV + 1, NN = (DIM == 2) ? N1 * N1 : N1 * N1 * N1, NV = 1 << DIM, CPB = 8;
+  __shared__ double sX[CPB][NV * DIM], sJi[CPB][NN * DIM * DIM], sW[CPB][NN], sU[CPB][NN * DIM], sGu[CPB][NN * DIM * DIM], sE[CPB][NN * DIM];
+  __shared__ double tN[9], tD[9];
+  __shared__ int32_t sNode[CPB][NN];
+  const int slot = threadIdx.x >> 5, hl = threadIdx.x & 31;
+  const int64_t cell = int64_t(blockIdx.x) * CPB + slot;
   const bool active = cell < A.n_cells;
   const int64_t cc = active ? cell : 0;
-  if (lane < NN) {
-    const int32_t nd = A.cell_unodes[cc * NN + lane];
-    sNode[wave][lane] = nd;
-    for (int c = 0; c < DIM; ++c) sE[wave][lane * DIM + c] = A.conv ? A.eval[int64_t(DIM) * nd + c] : 0.0;
+  if (threadIdx.x < 9) { tN[threadIdx.x] = A.t.N[threadIdx.x]; tD[threadIdx.x] = A.t.dN[threadIdx.x]; }
+  if (hl < NN) {
+    const int32_t nd = A.cell_unodes[cc * NN + hl];
+    sNode[slot][hl] = nd;
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) sE[slot][hl * DIM + c] = A.conv ? A.eval[int64_t(DIM) * nd + c] : 0.0;
   }
-  if (lane < NV * DIM) sX[wave][lane] = A.vcoords[cc * NV * DIM + lane];
+  if (hl < NV * DIM) sX[slot][hl] = A.vcoords[cc * NV * DIM + hl];
   __syncthreads();
-  auto shape = [&](int q, int a, double &N, double *dr) { // value and reference gradient of node a at Gauss point q
-    int qi[3], ai[3];
-    qi[0] = q % N1; qi[1] = (q / N1) % N1; qi[2] = q / (N1 * N1);
-    ai[0] = a % N1; ai[1] = (a / N1) % N1; ai[2] = a / (N1 * N1);
-    double n[3] = {1, 1, 1}, d[3] = {0, 0, 0};
-    for (int e = 0; e < DIM; ++e) { n[e] = A.t.N[qi[e] * N1 + ai[e]]; d[e] = A.t.dN[qi[e] * N1 + ai[e]]; }
-    N = n[0] * n[1] * n[2];
-    dr[0] = d[0] * n[1] * n[2]; dr[1] = n[0] * d[1] * n[2]; dr[2] = n[0] * n[1] * d[2];
-  };
-  if (lane < NN) { // lane = quadrature point: Jacobian of the d-linear map, fields of the evaluation point
-    const int q = lane;
-    int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
+  const int li = hl < NN ? hl : 0; // my point (first stage) / my node (second stage)
+  const int l0 = li % N1, l1 = (li / N1) % N1, l2 = DIM == 3 ? li / (N1 * N1) : 0;
+  if (hl < NN) { // lane = quadrature point: Jacobian of the d-linear map, fields of the evaluation point
+    const int q = hl;
+    const int qi[3] = {l0, l1, l2};
     double L[3][2], J[DIM * DIM], Ji[DIM * DIM], wq = 1;
-    for (int d = 0; d < DIM; ++d) { L[d][1] = A.t.xi[qi[d]]; L[d][0] = 1.0 - L[d][1]; wq *= A.t.w[qi[d]]; }
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      double x_ = A.t.xi[0], w_ = A.t.w[0];
+#pragma unroll
+      for (int k = 1; k < N1; ++k) { x_ = qi[d] == k ? A.t.xi[k] : x_; w_ = qi[d] == k ? A.t.w[k] : w_; }
+      L[d][1] = x_; L[d][0] = 1.0 - x_; wq *= w_;
+    }
+#pragma unroll
     for (int i = 0; i < DIM * DIM; ++i) J[i] = 0;
+#pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int b[3] = {v & 1, (v >> 1) & 1, (v >> 2) & 1};
+#pragma unroll
       for (int d = 0; d < DIM; ++d) {
         double g = b[d] ? 1.0 : -1.0;
+#pragma unroll
         for (int o = 0; o < DIM; ++o) if (o != d) g *= L[o][b[o]];
-        for (int e = 0; e < DIM; ++e) J[e * DIM + d] += sX[wave][v * DIM + e] * g;
+#pragma unroll
+        for (int e = 0; e < DIM; ++e) J[e * DIM + d] += sX[slot][v * DIM + e] * g;
       }
     }
     const double det = inv_small<DIM>(J, Ji);
-    sW[wave][q] = fabs(det) * wq;
-    for (int i = 0; i < DIM * DIM; ++i) sJi[wave][q * DIM * DIM + i] = Ji[i];
+    sW[slot][q] = fabs(det) * wq;
+#pragma unroll
+    for (int i = 0; i < DIM * DIM; ++i) sJi[slot][q * DIM * DIM + i] = Ji[i];
     double u[DIM], gr[DIM * DIM];
+#pragma unroll
     for (int c = 0; c < DIM; ++c) u[c] = 0;
+#pragma unroll
     for (int i = 0; i < DIM * DIM; ++i) gr[i] = 0;
-    for (int a = 0; a < NN; ++a) {
-      double N, dr[3];
-      shape(q, a, N, dr);
-      for (int c = 0; c < DIM; ++c) {
-        const double uv = sE[wave][a * DIM + c];
-        u[c] += N * uv;
-        for (int e = 0; e < DIM; ++e) gr[c * DIM + e] += uv * dr[e];
+    // node loop: x index unrolled, the two slower indices walk the LDS tables
+#pragma unroll 1
+    for (int a21 = 0; a21 < NN / N1; ++a21) {
+      const int a1 = a21 % N1, a2 = a21 / N1;
+      const double n1v = tN[l1 * N1 + a1], d1v = tD[l1 * N1 + a1];
+      const double n2v = DIM == 3 ? tN[l2 * N1 + a2] : 1.0, d2v = DIM == 3 ? tD[l2 * N1 + a2] : 0.0;
+#pragma unroll
+      for (int a0 = 0; a0 < N1; ++a0) {
+        const int a = a21 * N1 + a0;
+        const double n0v = tN[l0 * N1 + a0], d0v = tD[l0 * N1 + a0];
+        const double N = n0v * n1v * n2v;
+        const double dr[3] = {d0v * n1v * n2v, n0v * d1v * n2v, n0v * n1v * d2v};
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+          const double uv = sE[slot][a * DIM + c];
+          u[c] += N * uv;
+#pragma unroll
+          for (int e = 0; e < DIM; ++e) gr[c * DIM + e] += uv * dr[e];
+        }
       }
     }
+#pragma unroll
     for (int c = 0; c < DIM; ++c) {
-      sU[wave][q * DIM + c] = u[c];
+      sU[slot][q * DIM + c] = u[c];
+#pragma unroll
       for (int d = 0; d < DIM; ++d) { // physical gradient d_d u_c = sum_e (d^_e u_c) Ji[e][d]
         double t = 0;
+#pragma unroll
         for (int e = 0; e < DIM; ++e) t += gr[c * DIM + e] * Ji[e * DIM + d];
-        sGu[wave][q * DIM * DIM + c * DIM + d] = t;
+        sGu[slot][q * DIM * DIM + c * DIM + d] = t;
       }
     }
   }
   __syncthreads();
-  if (lane < NN && active) { // lane = node a: its diagonal block
-    const int a = lane;
+  if (hl < NN && active) { // lane = node a: its diagonal block
+    const int a = hl;
     double s = 0, D[DIM * DIM];
+#pragma unroll
     for (int i = 0; i < DIM * DIM; ++i) D[i] = 0;
-    for (int q = 0; q < NN; ++q) {
-      double N, dr[3], ga[DIM];
-      shape(q, a, N, dr);
-      const double *Ji = &sJi[wave][q * DIM * DIM];
-      for (int d = 0; d < DIM; ++d) {
-        double t = 0;
-        for (int e = 0; e < DIM; ++e) t += dr[e] * Ji[e * DIM + d];
-        ga[d] = t;
+#pragma unroll 1
+    for (int q21 = 0; q21 < NN / N1; ++q21) {
+      const int q1 = q21 % N1, q2 = q21 / N1;
+      const double n1v = tN[q1 * N1 + l1], d1v = tD[q1 * N1 + l1];
+      const double n2v = DIM == 3 ? tN[q2 * N1 + l2] : 1.0, d2v = DIM == 3 ? tD[q2 * N1 + l2] : 0.0;
+#pragma unroll
+      for (int q0 = 0; q0 < N1; ++q0) {
+        const int q = q21 * N1 + q0;
+        const double n0v = tN[q0 * N1 + l0], d0v = tD[q0 * N1 + l0];
+        const double N = n0v * n1v * n2v;
+        const double dr[3] = {d0v * n1v * n2v, n0v * d1v * n2v, n0v * n1v * d2v};
+        double ga[DIM];
+        const double *Ji = &sJi[slot][q * DIM * DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+          double t = 0;
+#pragma unroll
+          for (int e = 0; e < DIM; ++e) t += dr[e] * Ji[e * DIM + d];
+          ga[d] = t;
+        }
+        const double w = sW[slot][q];
+        double gg = 0, ug = 0;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) { gg += ga[d] * ga[d]; ug += sU[slot][q * DIM + d] * ga[d]; }
+        s += w * (A.mu * gg + A.rho * N * ug + A.rho * A.inv_dt * N * N);
+#pragma unroll
+        for (int c = 0; c < DIM; ++c)
+#pragma unroll
+          for (int d = 0; d < DIM; ++d)
+            D[c * DIM + d] += w * (A.rho * N * N * sGu[slot][q * DIM * DIM + c * DIM + d] + A.gamma * A.rho * ga[c] * ga[d]);
       }
-      const double w = sW[wave][q];
-      double gg = 0, ug = 0;
-      for (int d = 0; d < DIM; ++d) { gg += ga[d] * ga[d]; ug += sU[wave][q * DIM + d] * ga[d]; }
-      s += w * (A.mu * gg + A.rho * N * ug + A.rho * A.inv_dt * N * N);
-      for (int c = 0; c < DIM; ++c)
-        for (int d = 0; d < DIM; ++d)
-          D[c * DIM + d] += w * (A.rho * N * N * sGu[wave][q * DIM * DIM + c * DIM + d] + A.gamma * A.rho * ga[c] * ga[d]);
     }
+#pragma unroll
     for (int c = 0; c < DIM; ++c) D[c * DIM + c] += s;
-    const int32_t nd = sNode[wave][a];
+    const int32_t nd = sNode[slot][a];
     if (nd < A.nUo) {
+#pragma unroll
       for (int c = 0; c < DIM; ++c)
+#pragma unroll
         for (int d = 0; d < DIM; ++d) {
           const bool rc = A.is_c && A.is_c[int64_t(DIM) * nd + c], cd = A.is_c && A.is_c[int64_t(DIM) * nd + d];
           double v = D[c * DIM + d];
@@ -228,7 +274,7 @@ void uu_block_diag_mf(ifem_ctx *ctx) {
   a.mu = ctx->mf_params.viscosity; a.rho = ctx->mf_params.rho; a.gamma = ctx->mf_params.grad_div; a.inv_dt = 1.0 / ctx->mf_params.dt;
   a.conv = ctx->mf_noconv ? 0 : 1;
   tab1d(a.t, ctx->kv);
-  const dim3 grid(unsigned((ctx->n_cells + 3) / 4)), block(256);
+  const dim3 grid(unsigned((ctx->n_cells + 7) / 8)), block(256); // 8 cells per block
   if (dim == 3 && ctx->kv == 2) hipLaunchKernelGGL((k_uu_diag<3, 2>), grid, block, 0, s, a);
   else if (dim == 3) hipLaunchKernelGGL((k_uu_diag<3, 1>), grid, block, 0, s, a);
   else if (ctx->kv == 2) hipLaunchKernelGGL((k_uu_diag<2, 2>), grid, block, 0, s, a);

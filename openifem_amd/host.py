@@ -46,6 +46,7 @@ def _lib():
     L.ifemx_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     L.ifemx_assemble.argtypes = [C.c_void_p, C.c_int]
     L.ifemx_solve.argtypes = [C.c_void_p, C.c_int, C.POINTER(capi.SolveStats)]
+    L.ifemx_last_stats.argtypes = [C.c_void_p, C.POINTER(capi.SolveStats)]
     L.ifemx_solver_opts.restype = C.POINTER(capi.SolverOpts)
     L.ifemx_solver_opts.argtypes = [C.c_void_p]
     L.ifemx_ctx.restype = C.c_void_p
@@ -249,6 +250,12 @@ class FluidSolver:
 
     def run_one_step(self, apply_nonzero, assemble_system=True):
         self._chk(self.L.ifemx_run_one_step2(self.h, int(apply_nonzero), int(assemble_system)))
+
+    def last_stats(self):
+        """counters of the most recent solve (the one inside run_one_step included)"""
+        st = capi.SolveStats()
+        self._chk(self.L.ifemx_last_stats(self.h, C.byref(st)))
+        return st
 
     def assemble(self, use_nonzero):
         self._chk(self.L.ifemx_assemble(self.h, int(use_nonzero)))

@@ -56,7 +56,7 @@ def _unique_id(rank, dist):
     return uid
 
 
-def make_channel_solver(n, rank, world, local_rank, dist, multigrid=True):
+def make_channel_solver(n, rank, world, local_rank, dist, multigrid=True, kind="InsIM"):
     """the bench's channel on `world` ranks (n^3 cells per rank) and, with multigrid, its chain of coarser levels: every
     level is a context of its own; all of them name the same unique id and therefore share one RCCL communicator
     (comm.hip keeps one per id and process)"""
@@ -67,7 +67,7 @@ def make_channel_solver(n, rank, world, local_rank, dist, multigrid=True):
     uid = _unique_id(rank, dist) if world > 1 else None
 
     def make(reps, level):
-        s = host.InsIM(host.channel_prm(3), reps, (0, 0, 0), extent, device=local_rank, verbose=False)
+        s = getattr(host, kind)(host.channel_prm(3), reps, (0, 0, 0), extent, device=local_rank, verbose=False)
         if world > 1:
             s.set_partition(P, rank, nccl_unique_id=uid)
         s.setup(0)

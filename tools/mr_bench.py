@@ -1,25 +1,49 @@
 """Cost of the partitioned code path, measured on ONE GPU: a Newton step of the 2n x n x n channel in one context, and
 the same problem cut into two virtual ranks (in-process transport; both ranks share the GPU, so the total work is the
-same).  The difference is the overhead of the multi-rank path: ghost cell layer, halo packing, host-synchronised dots,
-the distributed S_m."""
+same), both in the bench configuration (multigrid levels attached, IFEM_AINV_MG).  The difference is the overhead of the
+multi-rank path: ghost cell layer, halo packing, split launches, the distributed S_m -- plus what only the validation
+transport pays (host barriers and synchronous copies where RCCL runs stream-ordered).
+
+    python tools/mr_bench.py [n] [halo_overlap 0|1]"""
 import ctypes as C
 import sys
 import threading
 import time
 
-import numpy as np
-
 sys.path.insert(0, ".")
-from openifem_amd import host, capi  # noqa
+from openifem_amd import host, capi, multigpu  # noqa
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+overlap = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 steps = 3
+EXTENT = (2.0, 0.2, 0.2)
+L = capi.load()
+
+
+def make(reps, P, rank, worlds, level):
+    s = host.InsIM(host.channel_prm(3), reps, (0, 0, 0), EXTENT, verbose=False)
+    if P is not None:
+        s.set_partition(P, rank, local_world=worlds[level])
+    s.setup(0)
+    return s
+
+
+def hierarchy(cells, P, rank, worlds):
+    reps = tuple(cells[d] * (P[d] if P else 1) for d in range(3))
+    fine = make(reps, P, rank, worlds, 0)
+    fine._levels = multigpu.attach_levels(lambda r, lev: make(r, P, rank, worlds, lev), fine, cells, P or (1, 1, 1), EXTENT)
+    return fine
 
 
 def configure(s):
-    s.opts.ainv_kind = 3
+    s.opts.ainv_kind = 4
     s.opts.inner_rel = 1e-2
     s.opts.inner_restart = 16  # as bench.py
+    tun = capi.Tuning()
+    L.ifem_default_tuning(C.byref(tun))
+    tun.halo_overlap = overlap
+    for c in [s] + list(s._levels):
+        assert L.ifem_set_tuning(c.ctx, C.byref(tun)) == 0
     s.channel_state()
 
 
@@ -35,23 +59,20 @@ def timed(s, sync=None):
     return (time.time() - t0) / steps, its
 
 
-s = host.InsIM(host.channel_prm(3), (2 * n, n, n), (0, 0, 0), (2.0, 0.2, 0.2))
-s.setup(0)
+s = hierarchy((2 * n, n, n), None, 0, None)
 configure(s)
 t1, st = timed(s)
-print(f"one context, {2*n}x{n}x{n}: {t1*1e3:.1f} ms/step, fgmres {st.fgmres_iters} cg_mp {st.cg_mp_iters} cg_sm {st.cg_sm_iters} inner {st.inner_iters}")
+print(f"one context, {2*n}x{n}x{n}: {t1*1e3:.1f} ms/step, fgmres {st.fgmres_iters} cg_mp {st.cg_mp_iters} cg_sm {st.cg_sm_iters} inner {st.inner_iters}", flush=True)
+depth = L.ifem_mg_depth(s.ctx)
 s.close()
 
-L = capi.load()
-w = C.c_void_p(L.ifem_local_world_create(2))
+worlds = [C.c_void_p(L.ifem_local_world_create(2)) for _ in range(depth + 1)]
 bar = threading.Barrier(2)
 res = [None, None]
 
 
 def work(rank):
-    s = host.InsIM(host.channel_prm(3), (2 * n, n, n), (0, 0, 0), (2.0, 0.2, 0.2))
-    s.set_partition((2, 1, 1), rank, local_world=w)
-    s.setup(0)
+    s = hierarchy((n, n, n), (2, 1, 1), rank, worlds)
     configure(s)
     L.ifem_halo_exchange(s.ctx, capi.VEC_EVAL)
     res[rank] = timed(s, bar.wait)
@@ -62,4 +83,5 @@ th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
 for t in th: t.start()
 for t in th: t.join()
 t2, st = res[0]
-print(f"two virtual ranks of {n}^3 on one GPU: {t2*1e3:.1f} ms/step (one context: {t1*1e3:.1f}), fgmres {st.fgmres_iters} cg_mp {st.cg_mp_iters} cg_sm {st.cg_sm_iters} inner {st.inner_iters}")
+print(f"two virtual ranks of {n}^3 on one GPU (halo_overlap {overlap}): {t2*1e3:.1f} ms/step (one context: {t1*1e3:.1f}, {100*(t2/t1-1):+.1f} %), "
+      f"fgmres {st.fgmres_iters} cg_mp {st.cg_mp_iters} cg_sm {st.cg_sm_iters} inner {st.inner_iters}")
