@@ -229,18 +229,26 @@ __global__ __launch_bounds__(256) void k_uu_diag(DiagArgs A) {
 #pragma unroll
     for (int c = 0; c < DIM; ++c) D[c * DIM + c] += s;
     const int32_t nd = sNode[slot][a];
-    if (nd < A.nUo) {
+    const bool own = nd < A.nUo;
 #pragma unroll
-      for (int c = 0; c < DIM; ++c)
+    for (int c = 0; c < DIM; ++c)
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) {
-          const bool rc = A.is_c && A.is_c[int64_t(DIM) * nd + c], cd = A.is_c && A.is_c[int64_t(DIM) * nd + d];
-          double v = D[c * DIM + d];
-          if (rc || cd) v = (c == d) ? fabs(v) : 0.0;
-          if (v != 0.0) unsafeAtomicAdd(&A.out[int64_t(nd) * DIM * DIM + c * DIM + d], v);
-        }
-    }
+      for (int d = 0; d < DIM; ++d) {
+        const bool rc = own && A.is_c && A.is_c[int64_t(DIM) * nd + c], cd = own && A.is_c && A.is_c[int64_t(DIM) * nd + d];
+        double v = D[c * DIM + d];
+        if (rc || cd) v = (c == d) ? fabs(v) : 0.0;
+        sGu[slot][a * DIM * DIM + c * DIM + d] = own ? v : 0.0; // staged: the gradient table is consumed (same index range)
+      }
   }
+  __syncthreads();
+  // scatter with lane = (node, entry): consecutive lanes add to consecutive doubles of a node block (the f64 atomic unit
+  // works per 64-byte segment: one lane per node block costs 9 segments per block, this costs ~1.5)
+  if (active)
+    for (int t = hl; t < NN * DIM * DIM; t += 32) {
+      const int a = t / (DIM * DIM), e = t - a * (DIM * DIM);
+      const double v = sGu[slot][t];
+      if (v != 0.0) unsafeAtomicAdd(&A.out[int64_t(sNode[slot][a]) * DIM * DIM + e], v);
+    }
 }
 
 template <int DIM>
