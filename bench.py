@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--mg", type=int, default=1, help="1 (default): attach the chain of coarser (semi-coarsened) box meshes so that CG(S_m) inside the preconditioner is multigrid-preconditioned; 0: plain CG as in the reference")
     ap.add_argument("--inner-maxit", type=int, default=None, help="cap of the inner A_uu iterations (--ainv 4: 0 = exactly one V-cycle)")
     ap.add_argument("--mg-smooth-u", type=int, default=None, help="smoothing steps of the A_uu V-cycle (--ainv 4)")
+    ap.add_argument("--mg-post-u", type=int, default=None, help="smoothing steps after the coarse correction of the A_uu V-cycle (default: as before it)")
     ap.add_argument("--mg-ratio-u", type=float, default=None, help="Chebyshev interval ratio of the A_uu V-cycle (--ainv 4)")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
     ap.add_argument("--outer-mf", type=int, default=0, help="experiment: apply the u-u block of the OUTER operator matrix-free too")
@@ -265,6 +266,8 @@ def main():
         solver.opts.inner_maxit = args.inner_maxit
     if args.mg_smooth_u is not None:
         solver.opts.mg_smooth_u = args.mg_smooth_u
+    if args.mg_post_u is not None:
+        solver.opts.mg_smooth_u_post = args.mg_post_u
     if args.mg_ratio_u is not None:
         solver.opts.mg_cheb_ratio_u = args.mg_ratio_u
     solver.opts.outer_matrix_free = args.outer_mf

@@ -131,6 +131,8 @@ typedef struct {
   int32_t mg_smooth;          /* 2: Chebyshev-Jacobi smoothing steps before and after the coarse correction */
   double  mg_cheb_ratio;      /* 4: the smoother targets the eigenvalues of D^-1 S_m in [lambda_max / ratio, lambda_max] */
   int32_t mg_smooth_u;        /* 2: smoothing steps of the A_uu V-cycle (IFEM_AINV_MG) */
+  int32_t mg_smooth_u_post;   /* 0: as many after the coarse correction as before it; > 0: that many (the cycle is then no
+                                 longer symmetric, which the flexible inner GMRES does not need) */
   double  mg_cheb_ratio_u;    /* 4: its Chebyshev interval [lambda_max / ratio, lambda_max] of (block D)^-1 A_uu */
 } ifem_solver_opts;
 

@@ -54,6 +54,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   const bool skip_geo = ctx->tune.geo_cache && assemble_system && ctx->geo_valid && ctx->geo_key == geo_key;
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
   if (assemble_system) {
+    // (a hand-written fill kernel with 16-byte non-temporal stores measures the same 15 ms for the 78 GB at 128^3)
     if (!geo_only) IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
     if (!skip_geo) {
       IFEM_HIP_CHECK(hipMemsetAsync(ctx->Bt.val.p, 0, ctx->Bt.val.n * sizeof(double), s));

@@ -548,7 +548,7 @@ static void carve_workspace(SolveState &S, bool krylov = true);
 // 4 prolongated correction; compact owned entries first, so the buffers double as ghost-extended velocity vectors.
 struct MgUu {
   std::vector<SolveState> L;
-  int nu = 3;
+  int nu = 3, nu_post = 3;
   double ratio = 8.0;
 };
 
@@ -671,7 +671,7 @@ static void mg_uu_vcycle(MgUu &M, size_t l) {
   MfFuse f;
   f.mode = 1; f.xs = x; f.r = r; // x += e; r -= A e
   uu_apply_level(S, e, t, &f);
-  mg_uu_smooth(M, l, M.nu, lo, hi, x, r, false);
+  mg_uu_smooth(M, l, M.nu_post, lo, hi, x, r, false);
 }
 
 static void precond_vmult(SolveState &S, const double *src, double *dst) {
@@ -775,7 +775,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   double res = 0;
   if (o->ainv_kind == IFEM_AINV_MG) { // inner GMRES on the matrix-free operator, one V-cycle as its preconditioner
     MgUu Mu;
-    Mu.nu = std::max(1, o->mg_smooth_u); Mu.ratio = std::max(1.5, o->mg_cheb_ratio_u);
+    Mu.nu = std::max(1, o->mg_smooth_u); Mu.nu_post = o->mg_smooth_u_post > 0 ? o->mg_smooth_u_post : Mu.nu; Mu.ratio = std::max(1.5, o->mg_cheb_ratio_u);
     Mu.L.push_back(S);
     for (ifem_ctx *p = c; p->mg_coarse && p->mg_Pu.n_rows == p->nUo && p->nUo > 0; p = p->mg_coarse) {
       SolveState Sc{p->mg_coarse, P, o};

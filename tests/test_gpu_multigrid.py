@@ -267,6 +267,16 @@ def test_multigrid_ainv_keeps_the_reference_stopping_rule(n):
         out[kind] = (st.fgmres_iters, st.inner_iters)
     assert out[4][0] <= out[3][0] + 1
     assert out[4][1] * 2 <= out[3][1], out
+    # an asymmetric cycle (fewer smoothing steps after the coarse correction) is admissible under the flexible inner GMRES
+    s.opts.ainv_kind = 4
+    s.opts.mg_smooth_u, s.opts.mg_smooth_u_post = 3, 1
+    st = s.solve(False)
+    x = _get(s, capi.VEC_UPDATE, nt)
+    assert s.L.ifem_vec_set(s.ctx, capi.VEC_TMP, x.ctypes.data_as(C.c_void_p)) == 0
+    assert s.L.ifem_system_vmult(s.ctx, capi.VEC_UPDATE, capi.VEC_TMP) == 0
+    r = b - _get(s, capi.VEC_UPDATE, nt)
+    r[cd] = 0
+    assert np.linalg.norm(r) <= 1.05e-4 * np.linalg.norm(b)
     s.close()
 
 
