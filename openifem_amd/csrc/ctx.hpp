@@ -208,6 +208,8 @@ struct ifem_ctx {
   ifem::DBuf<double> xs_ext; // [halo.n_s_cols] input of the distributed S_m SpMV: owned entries + 2-deep far nodes
   ifem::DBuf<float> Sm_f32; // single-precision copy of the S_m values for its SpMV (approximate-preconditioner kinds)
   bool sm_f32_valid = false;
+  ifem::DBuf<float> Mp_f32; // the same for M_p (CG(M_p) of the preconditioner)
+  bool mp_f32_valid = false;
   int64_t sm_key = -1;
   // identity of the constrained-dof SET of each AffineConstraints object (which dofs, not their values): B, B^T, M_p,
   // diag(M_u) and S_m depend on nothing else, so zero_ / nonzero_constraints with the same lines share one cache entry and

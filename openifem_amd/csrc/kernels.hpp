@@ -63,7 +63,7 @@ void spmv_app(ifem_ctx *ctx, const double *xp, double *yp);
 void app_diag_setup(ifem_ctx *ctx);
 void scalar_diag(ifem_ctx *ctx, const PlanarCsr &M, const double *val, double *d);
 // y_p = M_p x_p
-void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp, int part = 0);
+void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp, int part = 0, bool use_f32 = false);
 // explicit S_m: numeric product B diag(1/diag M_u) B^T into ctx->Sm (pattern must exist), and y_p = S_m x_p
 void schur_numeric(ifem_ctx *ctx);
 void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp, bool use_f32, int part = 0);

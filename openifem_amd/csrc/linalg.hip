@@ -416,12 +416,20 @@ void app_diag_setup(ifem_ctx *ctx) {
                             ctx->Mp.col.p, ctx->App.p, ctx->app_diag.p);
 }
 
-void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp, int part) {
+// use_f32: single-precision copy of the values (the preconditioner's CG(M_p) only; refreshed when M_p is re-integrated)
+void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp, int part, bool use_f32) {
   const RowPart rp_ = row_part(ctx->Mp, part);
   const int64_t n = rp_.n;
   if (n == 0) return;
-  hipLaunchKernelGGL((k_spmv_planar<1, 1, 8>), dim3(blocks_for_rows(n, 8)), dim3(256), 0, ctx->stream, n,
-                     ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->Mp.val.p, xp, yp, rp_.rows);
+  if (use_f32 && !ctx->mp_f32_valid) {
+    const int64_t nv = (int64_t)ctx->Mp.val.n;
+    if (ctx->Mp_f32.n != (size_t)nv) ctx->Mp_f32.alloc(nv);
+    hipLaunchKernelGGL(k_to_f32, dim3(8192), dim3(256), 0, ctx->stream, nv, ctx->Mp.val.p, ctx->Mp_f32.p);
+    ctx->mp_f32_valid = true;
+  }
+  const unsigned nb = blocks_for_rows(n, 8);
+  if (use_f32) hipLaunchKernelGGL((k_spmv_planar<1, 1, 8, float>), dim3(nb), dim3(256), 0, ctx->stream, n, ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->Mp_f32.p, xp, yp, rp_.rows);
+  else hipLaunchKernelGGL((k_spmv_planar<1, 1, 8>), dim3(nb), dim3(256), 0, ctx->stream, n, ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->Mp.val.p, xp, yp, rp_.rows);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -685,17 +685,22 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   const double n1 = std::sqrt(pdot(src1, src1));
   Clock ck;
   // CG for Mp (:69-84)
+  // the approximate-preconditioner kinds stream M_p in single precision like S_m (the solve is to 1e-6, the rounding of the
+  // values 6e-8).  (p.q fused into this SpMV was measured: a block reduction in each of its 67 k small blocks costs more
+  // than the separate pass over the two vectors.)
+  const bool mp_f32 = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF || o->ainv_kind == IFEM_AINV_MG;
   OpFn mp = [&](const double *x, double *y) {
     if (halo_overlap_ok(c)) {
       build_row_split(c, c->Mp, c->nPo);
       v_copy(c, S.npo, x, S.xp_ext);
       halo_start(c, S.xp_ext, 1);
-      spmv_mp(c, S.xp_ext, y, 1);
+      spmv_mp(c, S.xp_ext, y, 1, mp_f32);
       halo_wait(c);
-      spmv_mp(c, S.xp_ext, y, 2);
+      spmv_mp(c, S.xp_ext, y, 2, mp_f32);
       return;
     }
-    const double *xe; extend_p(S, x, &xe); spmv_mp(c, xe, y);
+    const double *xe; extend_p(S, x, &xe);
+    spmv_mp(c, xe, y, 0, mp_f32);
   };
   // kinds 1 and 3 (approximate preconditioner) also put a Jacobi preconditioner on the two pressure CG solves: same
   // stopping rule on the true residual, fewer iterations (the reference uses PreconditionNone; counts are no parity target)
