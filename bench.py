@@ -97,7 +97,12 @@ def _cpu_step(n_cpu, threads):
     return m.n_dofs, t1 - t0, t2 - t1, it
 
 
-def cpu_baseline(sizes, sweep_n=12):
+def np_log2(x):
+    import math
+    return math.log2(x)
+
+
+def cpu_baseline(sizes, sweep_n=12, budget_s=75.0):
     """The CPU oracle (a port of the reference algorithm, oracle/oracle.c: dense per-cell Ke, CSR scatter, FGMRES with the
     block Schur preconditioner, same inner-solver settings as the GPU run) on a bounded sample of the same workload:
     one Newton step of the n^3 channel for every n in `sizes` (BASELINE.md section 3 plans n = 32 and 64; the default run
@@ -110,14 +115,22 @@ def cpu_baseline(sizes, sweep_n=12):
         nd, ta, ts, _ = _cpu_step(sweep_n, t)
         sweep[t] = ta + ts
     best = min(sweep, key=sweep.get)
-    runs = []
-    for n in sizes:
+    runs, skipped = [], []
+    for n in sorted(sizes):
+        # keep the default run bounded: a sample is skipped when the previous (smaller) one predicts more than `budget_s`
+        # for it (cost grows ~ 4.6x per doubling of n on this oracle: 13.6 s -> 63 s measured)
+        if runs and budget_s > 0:
+            prev = runs[-1]
+            predicted = (prev["assemble_s"] + prev["solve_s"]) * 4.6 ** (np_log2(n / prev["n"]))
+            if predicted > budget_s:
+                skipped.append({"n": n, "predicted_s": predicted, "budget_s": budget_s})
+                continue
         nd, ta, ts, it = _cpu_step(n, best)
         runs.append({"n": n, "n_dofs": nd, "assemble_s": ta, "solve_s": ts, "fgmres_iters": it, "dofs_per_s": nd / (ta + ts),
                      "assemble_dofs_per_s": nd / ta, "solve_dofs_per_s": nd / ts})
     big = runs[-1]
     return {"value": big["dofs_per_s"], "unit": "DoF/s", "cores": best, "kind": "port", "cpu_model": _cpu_model(),
-            "host_threads_available": ncpu, "thread_sweep_s": {str(k): v for k, v in sweep.items()}, "runs": runs,
+            "host_threads_available": ncpu, "thread_sweep_s": {str(k): v for k, v in sweep.items()}, "runs": runs, "skipped": skipped,
             "sample": f"1 Newton step (assemble {big['assemble_s']:.2f}s + solve {big['solve_s']:.2f}s, FGMRES its "
                       f"{big['fgmres_iters']}) of the {big['n']}^3 Q2/Q1 channel ({big['n_dofs']} DoF), oracle/oracle.c with "
                       f"OpenMP on {best} threads of {_cpu_model()}"}
@@ -387,6 +400,7 @@ def main():
         # (pressure CG solves to 1e-2 / 1e-1 instead of the reference's 1e-6 / 1e-3) and the u-u block of the outer operator
         # applied matrix-free.  The outer FGMRES still stops at the reference's 1e-4 ||rhs|| on the same operator.
         if world == 1 and args.tuned and args.sm_rel is None and args.mp_rel is None and not args.outer_mf:
+            keep = (solver.opts.mp_rel, solver.opts.sm_rel, solver.opts.outer_matrix_free)
             solver.opts.mp_rel, solver.opts.sm_rel, solver.opts.outer_matrix_free = 1e-2, 1e-1, 1
             step()
             fence()
@@ -398,6 +412,7 @@ def main():
             out["tuned_preconditioner"] = {"ms_per_step": dt_t * 1e3, "value": n_dofs_global / dt_t, "unit": "DoF/s",
                                            "fgmres_iters": st.fgmres_iters, "cg_mp_rel": 1e-2, "cg_sm_rel": 1e-1, "outer_matrix_free": 1,
                                            "note": "side measurement; `value` above uses the reference's tolerances"}
+            solver.opts.mp_rel, solver.opts.sm_rel, solver.opts.outer_matrix_free = keep  # the legs below use the reference's again
         if world == 1 and args.extras:
             out.update(extras(solver, capi, n_dofs_global, ms_per_step))
         cpu_sizes = [int(v) for v in str(args.cpu_n).split(",") if int(v) > 0]
