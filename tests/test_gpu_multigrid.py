@@ -280,11 +280,14 @@ def test_multigrid_ainv_keeps_the_reference_stopping_rule(n):
     s.close()
 
 
-def test_multigrid_ainv_on_virtual_ranks():
+@pytest.mark.parametrize("P", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
+def test_multigrid_ainv_on_virtual_ranks(P):
+    """the bench configuration (IFEM_AINV_MG + multigrid CG(S_m), halo overlap on) on the partitions bench.py uses for 2, 4 and
+    8 GPUs: face, edge and corner neighbours on every level, transfers across rank boundaries"""
     from openifem_amd import capi
     L = capi.load()
-    n, P, world = (8, 8, 8), (2, 1, 1), 2
-    s1 = _hierarchy((16, 8, 8))
+    n, world = (8, 8, 8), int(np.prod(P))
+    s1 = _hierarchy(tuple(n[d] * P[d] for d in range(3)))
     s1.channel_state()
     s1.opts.ainv_kind = 4
     s1.opts.fgmres_rel = 1e-9
@@ -331,6 +334,7 @@ def test_multigrid_ainv_on_virtual_ranks():
         xN[(t["l2g_u"][:nuo, None] * 3 + np.arange(3)[None, :]).ravel()] = u[:3 * nuo]
         xN[3 * t["n_unodes_global"] + t["l2g_p"][:npo]] = u[3 * nuo:]
     assert np.linalg.norm(xN - x1) <= 1e-6 * np.linalg.norm(x1)
-    assert out[0][2] == out[1][2] and abs(out[0][2] - st1.inner_iters) <= max(3, st1.inner_iters // 4), (out[0][2], st1.inner_iters)
+    assert len({o[2] for o in out}) == 1 and len({o[3] for o in out}) == 1, "ranks disagree on the iteration counts"
+    assert abs(out[0][2] - st1.inner_iters) <= max(3, st1.inner_iters // 4), (out[0][2], st1.inner_iters)
     for w in worlds:
         L.ifem_local_world_destroy(w)
