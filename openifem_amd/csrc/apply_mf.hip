@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
 template <int DIM, typename R, bool FUSE>
 __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc,
                             const R *__restrict__ ycell, const uint8_t *__restrict__ is_c,
-                            const double *__restrict__ bjac, const double *x, double *y, MfFuse fuse) {
+                            const double *__restrict__ bjac, const float *__restrict__ bjf, const double *x, double *y, MfFuse fuse) {
   // one thread per node: the incidence list is walked once for the DIM components (24 contiguous bytes per entry)
   const int64_t nd = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (nd * DIM >= n) return;
@@ -407,7 +407,7 @@ __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_p
   } else {
     double xv[DIM], rv[DIM], bj[DIM * DIM];
 #pragma unroll
-    for (int e = 0; e < DIM * DIM; ++e) bj[e] = bjac[nd * DIM * DIM + e];
+    for (int e = 0; e < DIM * DIM; ++e) bj[e] = double(bjf[nd * DIM * DIM + e]);
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
       const int64_t i = nd * DIM + c;
@@ -417,13 +417,14 @@ __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_p
       fuse.xs[i] += xv[c];
       fuse.r[i] = rv[c];
     }
-    if (fuse.mode == 2) {
+    if (fuse.mode >= 2) {
+      const double a = fuse.mode == 2 ? fuse.a : 0.0;
 #pragma unroll
       for (int c = 0; c < DIM; ++c) {
         double z = 0;
 #pragma unroll
         for (int j = 0; j < DIM; ++j) z += bj[c * DIM + j] * rv[j];
-        fuse.d[nd * DIM + c] = fuse.a * xv[c] + fuse.b * z;
+        fuse.d[nd * DIM + c] = a * xv[c] + fuse.b * z;
       }
     }
   }
@@ -520,7 +521,7 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu, const MfF
   const MfFuse f0 = fuse ? *fuse : MfFuse{};
 #define IFEM_MFG(D, F)                                                                                                 \
   hipLaunchKernelGGL((k_mf_gather<D, R, F>), dim3(unsigned((n / D + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p, \
-                     ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, xu, yu, f0)
+                     ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, fuse ? bjac_f32_ptr(ctx) : nullptr, xu, yu, f0)
   if (ctx->dim == 3) { if (fuse) IFEM_MFG(3, true); else IFEM_MFG(3, false); }
   else { if (fuse) IFEM_MFG(2, true); else IFEM_MFG(2, false); }
 #undef IFEM_MFG

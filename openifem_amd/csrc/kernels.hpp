@@ -35,8 +35,9 @@ inline VecLayout layout_of(const ifem_ctx *c) { return {c->dim * c->nUo, c->dim 
 void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool use_f32, int part = 0);
 // apply_mf.hip: y_u = A_uu x_u without the stored matrix (sum-factorised cell kernel on the state of the last assemble)
 // optional epilogue of the matrix-free product t = A_uu x (owned rows), see apply_mf.hip::k_mf_gather: t is consumed instead of
-// stored.  mode 1: xs += x, r -= t; mode 2 additionally d = a x + b (inverse node block) r -- the Chebyshev step of the
-// multigrid smoother, d being the owned part of x itself
+// stored.  mode 1: xs += x, r -= t; mode 2 additionally d = a x + b B r (B = inverse node block, single-precision copy) -- the
+// Chebyshev step of the multigrid smoother, d being the owned part of x itself; mode 3: mode 1, then d = b B r into another
+// vector d -- the first direction of the smoothing sweep that follows the coarse correction
 struct MfFuse {
   int mode = 0;
   double a = 0, b = 0;
@@ -72,6 +73,7 @@ void vec_mul(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double 
 void vec_div(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y); // y = x ./ d (d == 0 -> 1)
 // y = bjac * x  (node-block Jacobi)
 void bjac_apply(ifem_ctx *ctx, const double *x, double *y);
+const float *bjac_f32_ptr(ifem_ctx *ctx); // single-precision copy of the inverse node blocks (refreshed on demand)
 void bjac_setup(ifem_ctx *ctx);
 void dinv_setup(ifem_ctx *ctx);
 

@@ -1040,14 +1040,19 @@ __global__ void k_bjac_apply_f32(int64_t n_rows, const float *__restrict__ bj, c
     y[row * DIM + r] = t;
   }
 }
-void bjac_apply_f32(ifem_ctx *ctx, const float *x, double *y) {
-  const int64_t n = ctx->nUo;
-  if (!n) return;
-  if (!ctx->bjac_f32_valid) {
+// single-precision copy of the inverse node blocks (preconditioner-only consumers), refreshed after every bjac set-up
+const float *bjac_f32_ptr(ifem_ctx *ctx) {
+  if (!ctx->bjac_f32_valid && ctx->bjac.n) {
     if (ctx->bjac_f32.n != ctx->bjac.n) ctx->bjac_f32.alloc(ctx->bjac.n);
     hipLaunchKernelGGL(k_to_f32, dim3(vgrid((int64_t)ctx->bjac.n)), dim3(256), 0, ctx->stream, (int64_t)ctx->bjac.n, ctx->bjac.p, ctx->bjac_f32.p);
     ctx->bjac_f32_valid = true;
   }
+  return ctx->bjac_f32.p;
+}
+void bjac_apply_f32(ifem_ctx *ctx, const float *x, double *y) {
+  const int64_t n = ctx->nUo;
+  if (!n) return;
+  (void)bjac_f32_ptr(ctx);
   if (ctx->dim == 3)
     hipLaunchKernelGGL((k_bjac_apply_f32<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ctx->bjac_f32.p, x, y);
   else

@@ -393,7 +393,7 @@ void mg_inject_nodes(ifem_ctx *ctx, int64_t n_nodes, const int32_t *inj, const d
 
 // d = c0 B r per node (B = inverse diagonal block)
 template <int DIM>
-__global__ void k_cheb_init_block(int64_t n_nodes, double c0, const double *__restrict__ bj, const double *__restrict__ r,
+__global__ void k_cheb_init_block(int64_t n_nodes, double c0, const float *__restrict__ bj, const double *__restrict__ r,
                                   double *__restrict__ d) {
   const int64_t nd = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (nd >= n_nodes) return;
@@ -404,7 +404,7 @@ __global__ void k_cheb_init_block(int64_t n_nodes, double c0, const double *__re
   for (int i = 0; i < DIM; ++i) {
     double t = 0;
 #pragma unroll
-    for (int j = 0; j < DIM; ++j) t += bj[nd * DIM * DIM + i * DIM + j] * rv[j];
+    for (int j = 0; j < DIM; ++j) t += double(bj[nd * DIM * DIM + i * DIM + j]) * rv[j];
     d[nd * DIM + i] = c0 * t;
   }
 }
@@ -412,7 +412,8 @@ void cheb_init_block(ifem_ctx *ctx, double c0, const double *r, double *d) {
   const int64_t n = ctx->nUo;
   if (!n) return;
   const dim3 g(unsigned((n + 255) / 256)), b(256);
-  if (ctx->dim == 3) hipLaunchKernelGGL((k_cheb_init_block<3>), g, b, 0, ctx->stream, n, c0, ctx->bjac.p, r, d);
-  else hipLaunchKernelGGL((k_cheb_init_block<2>), g, b, 0, ctx->stream, n, c0, ctx->bjac.p, r, d);
+  const float *bjf = bjac_f32_ptr(ctx);
+  if (ctx->dim == 3) hipLaunchKernelGGL((k_cheb_init_block<3>), g, b, 0, ctx->stream, n, c0, bjf, r, d);
+  else hipLaunchKernelGGL((k_cheb_init_block<2>), g, b, 0, ctx->stream, n, c0, bjf, r, d);
 }
 } // namespace ifem

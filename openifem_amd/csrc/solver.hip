@@ -628,13 +628,14 @@ static void mg_uu_setup(MgUu &M) {
   }
 }
 
-static void mg_uu_smooth(MgUu &M, size_t l, int nsteps, double lo, double hi, double *x, double *r, bool keep_r) {
+// d_ready: the first direction d = (1/theta) B r is already in place (written by the fused residual update, MfFuse mode 3)
+static void mg_uu_smooth(MgUu &M, size_t l, int nsteps, double lo, double hi, double *x, double *r, bool keep_r, bool d_ready = false) {
   SolveState &S = M.L[l];
   ifem_ctx *c = S.ctx;
   double *d = c->mgu_vec[2].p, *t = c->mgu_vec[3].p;
   const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
   double rho_old = 1.0 / sigma;
-  cheb_init_block(c, 1.0 / theta, r, d);
+  if (!d_ready) cheb_init_block(c, 1.0 / theta, r, d);
   for (int k = 0; k < nsteps; ++k) {
     const bool last = k == nsteps - 1;
     if (last && !keep_r) { v_axpy(c, S.nuo, 1.0, d, x); break; }
@@ -668,10 +669,10 @@ static void mg_uu_vcycle(MgUu &M, size_t l) {
   halo_exchange(cc, cc->mgu_vec[1].p);
   double *e = c->mgu_vec[4].p, *t = c->mgu_vec[3].p;
   mg_csr_apply_nodes(c, c->mg_Pu, cc->mgu_vec[1].p, c->mg_Pu_mask, e);
-  MfFuse f;
-  f.mode = 1; f.xs = x; f.r = r; // x += e; r -= A e
+  MfFuse f; // x += e; r -= A e; d = (1/theta) B r: the first direction of the post-smoothing sweep
+  f.mode = 3; f.xs = x; f.r = r; f.d = c->mgu_vec[2].p; f.b = 1.0 / (0.5 * (hi + lo));
   uu_apply_level(S, e, t, &f);
-  mg_uu_smooth(M, l, M.nu_post, lo, hi, x, r, false);
+  mg_uu_smooth(M, l, M.nu_post, lo, hi, x, r, false, true);
 }
 
 static void precond_vmult(SolveState &S, const double *src, double *dst) {

@@ -4,7 +4,7 @@ same), both in the bench configuration (multigrid levels attached, IFEM_AINV_MG)
 multi-rank path: ghost cell layer, halo packing, split launches, the distributed S_m -- plus what only the validation
 transport pays (host barriers and synchronous copies where RCCL runs stream-ordered).
 
-    python tools/mr_bench.py [n] [halo_overlap 0|1]"""
+    python tools/mr_bench.py [n] [halo_overlap 0|1] [Px,Py,Pz]   (default partition 2,1,1; n^3 cells per virtual rank)"""
 import ctypes as C
 import sys
 import threading
@@ -15,6 +15,8 @@ from openifem_amd import host, capi, multigpu  # noqa
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 overlap = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+PART = tuple(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else (2, 1, 1)
+WORLD = PART[0] * PART[1] * PART[2]
 steps = 3
 EXTENT = (2.0, 0.2, 0.2)
 L = capi.load()
@@ -59,29 +61,29 @@ def timed(s, sync=None):
     return (time.time() - t0) / steps, its
 
 
-s = hierarchy((2 * n, n, n), None, 0, None)
+s = hierarchy(tuple(n * p for p in PART), None, 0, None)
 configure(s)
 t1, st = timed(s)
-print(f"one context, {2*n}x{n}x{n}: {t1*1e3:.1f} ms/step, fgmres {st.fgmres_iters} cg_mp {st.cg_mp_iters} cg_sm {st.cg_sm_iters} inner {st.inner_iters}", flush=True)
+print(f"one context, {n*PART[0]}x{n*PART[1]}x{n*PART[2]}: {t1*1e3:.1f} ms/step, fgmres {st.fgmres_iters} cg_mp {st.cg_mp_iters} cg_sm {st.cg_sm_iters} inner {st.inner_iters}", flush=True)
 depth = L.ifem_mg_depth(s.ctx)
 s.close()
 
-worlds = [C.c_void_p(L.ifem_local_world_create(2)) for _ in range(depth + 1)]
-bar = threading.Barrier(2)
-res = [None, None]
+worlds = [C.c_void_p(L.ifem_local_world_create(WORLD)) for _ in range(depth + 1)]
+bar = threading.Barrier(WORLD)
+res = [None] * WORLD
 
 
 def work(rank):
-    s = hierarchy((n, n, n), (2, 1, 1), rank, worlds)
+    s = hierarchy((n, n, n), PART, rank, worlds)
     configure(s)
     L.ifem_halo_exchange(s.ctx, capi.VEC_EVAL)
     res[rank] = timed(s, bar.wait)
     s.close()
 
 
-th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+th = [threading.Thread(target=work, args=(r,)) for r in range(WORLD)]
 for t in th: t.start()
 for t in th: t.join()
 t2, st = res[0]
-print(f"two virtual ranks of {n}^3 on one GPU (halo_overlap {overlap}): {t2*1e3:.1f} ms/step (one context: {t1*1e3:.1f}, {100*(t2/t1-1):+.1f} %), "
+print(f"{WORLD} virtual ranks of {n}^3 on one GPU (halo_overlap {overlap}): {t2*1e3:.1f} ms/step (one context: {t1*1e3:.1f}, {100*(t2/t1-1):+.1f} %), "
       f"fgmres {st.fgmres_iters} cg_mp {st.cg_mp_iters} cg_sm {st.cg_sm_iters} inner {st.inner_iters}")
