@@ -77,13 +77,19 @@ int ifemx_solver_create_box(const char *kind, const char *prm_text, int dim, con
 int ifemx_solver_create_cylinder(const char *kind, const char *prm_text, int device, int verbose, void **out) {
   return guard([&] {
     auto params = Parameters::AllParameters::from_string(prm_text);
-    if (params.dimension != 2) throw std::invalid_argument("the cylinder mesh of this build is 2D");
     auto *h = new Handle();
-    h->dim = 2;
-    h->t2.reset(new Triangulation<2>());
-    Utils::GridCreator<2>::flow_around_cylinder(*h->t2);
-    h->s2 = make_solver<2>(kind, *h->t2, params, device);
-    h->s2->pcout = verbose ? &std::cout : nullptr;
+    h->dim = params.dimension == 3 ? 3 : 2;
+    if (h->dim == 2) {
+      h->t2.reset(new Triangulation<2>());
+      Utils::GridCreator<2>::flow_around_cylinder(*h->t2);
+      h->s2 = make_solver<2>(kind, *h->t2, params, device);
+      h->s2->pcout = verbose ? &std::cout : nullptr;
+    } else { // tests/fluid_cylinder_mpi/fluid_cylinder_mpi.cpp:98-104: the extruded mesh
+      h->t3.reset(new Triangulation<3>());
+      Utils::GridCreator<3>::flow_around_cylinder(*h->t3);
+      h->s3 = make_solver<3>(kind, *h->t3, params, device);
+      h->s3->pcout = verbose ? &std::cout : nullptr;
+    }
     *out = h;
   });
 }

@@ -82,8 +82,12 @@ namespace Utils {
 //   x(xi, eta) = (1 - xi) Arc(eta) + xi Out(eta)
 // evaluated at the dyadic points (new vertices are chart-space averages pushed forward).  merge_triangulations keeps
 // the bulk's coordinates for the seam vertices; the circle is re-centred to (0.2, 0.2) (utilities.cpp:451-479).
-static void cylinder_2d(Triangulation<2> &tria, int level) {
+// for_3d: the variant flow_around_cylinder_2d(tria, false) extrudes (utilities.cpp:348-355): the channel starts at x = -0.3
+// (25 instead of 22 bulk columns), everything else -- ring, removed cells, boundary ids -- is the same.
+static void cylinder_2d(Triangulation<2> &tria, int level, bool for_3d = false) {
   const int s = 1 << level;
+  const double left = for_3d ? -0.3 : 0.0;
+  const int ncol = for_3d ? 25 : 22, hole0 = for_3d ? 4 : 1;
   const double hx = 2.2 / 22, hy = 0.41 / 4, r_in = 0.05, PI = 3.14159265358979323846;
   const double cx = 0.2, cy = 0.2, sx = 0.2, sy = 0.205;
   const double O[8][2] = {{sx + 0.1, sy}, {sx + 0.1, sy + 0.1025}, {sx, sy + 0.1025}, {sx - 0.1, sy + 0.1025},
@@ -114,9 +118,9 @@ static void cylinder_2d(Triangulation<2> &tria, int level) {
                               ids[(size_t)a * (s + 1) + b + 1], ids[(size_t)(a + 1) * (s + 1) + b + 1]});
   };
   for (int j = 0; j < 4; ++j)
-    for (int i = 0; i < 22; ++i) {
-      if ((i == 1 || i == 2) && (j == 1 || j == 2)) continue; // cells within 0.15 of (0.2, 0.2) are removed
-      emit_patch([&](double xi, double eta, double &x, double &y) { x = (i + xi) * hx; y = (j + eta) * hy; });
+    for (int i = 0; i < ncol; ++i) {
+      if ((i == hole0 || i == hole0 + 1) && (j == 1 || j == 2)) continue; // cells within 0.15 of (0.2, 0.2) are removed
+      emit_patch([&](double xi, double eta, double &x, double &y) { x = left + (i + xi) * hx; y = (j + eta) * hy; });
     }
   for (int k = 0; k < 8; ++k)
     emit_patch([&](double xi, double eta, double &x, double &y) {
@@ -139,7 +143,7 @@ static void cylinder_2d(Triangulation<2> &tria, int level) {
       const double my = 0.5 * (tria.vertices[c[fv[f][0]]][1] + tria.vertices[c[fv[f][1]]][1]);
       int id = 4;
       if (std::abs(mx - 2.2) < 1e-12) id = 1;
-      else if (std::abs(mx) < 1e-12) id = 0;
+      else if (std::abs(mx - left) < 1e-12) id = 0;
       else if (std::abs(my - 0.41) < 1e-12) id = 3;
       else if (std::abs(my) < 1e-12) id = 2;
       tria.face_bid[ci][f] = id;
@@ -158,16 +162,119 @@ void GridCreator<2>::flow_around_cylinder(Triangulation<2> &tria) {
   };
   cylinder_2d(tria, 0);
 }
+// GridCreator<3>::flow_around_cylinder (utilities.cpp:526-570): the 2D mesh of the x in [-0.3, 2.2] channel extruded to
+// z in [0, 0.41] with 9 slices (8 layers); boundary ids x: 0 / 1, y: 2 / 3, z: 4 / 5, cylinder surface 6.  A refined level
+// regenerates the 2D mesh at that level (curved ring as in 2D) and doubles the layers.
+static void cylinder_3d(Triangulation<3> &tria, int level) {
+  Triangulation<2> t2;
+  cylinder_2d(t2, level, true);
+  const int layers = 8 << level;
+  const double hz = 0.41 / layers;
+  const size_t nv2 = t2.vertices.size(), nc2 = t2.cells.size();
+  tria.is_box = false;
+  tria.vertices.clear(); tria.cells.clear(); tria.face_bid.clear();
+  tria.vertices.reserve(nv2 * (layers + 1));
+  for (int k = 0; k <= layers; ++k)
+    for (size_t v = 0; v < nv2; ++v) tria.vertices.push_back({t2.vertices[v][0], t2.vertices[v][1], k == layers ? 0.41 : k * hz});
+  for (int k = 0; k < layers; ++k)
+    for (size_t c = 0; c < nc2; ++c) {
+      std::array<int32_t, 8> cv;
+      for (int v = 0; v < 4; ++v) {
+        cv[v] = int32_t(t2.cells[c][v] + size_t(k) * nv2);
+        cv[4 + v] = int32_t(t2.cells[c][v] + size_t(k + 1) * nv2);
+      }
+      tria.cells.push_back(cv);
+      std::array<int32_t, 6> fb;
+      for (int f = 0; f < 4; ++f) fb[f] = t2.face_bid[c][f] == 4 ? 6 : t2.face_bid[c][f];
+      fb[4] = k == 0 ? 4 : -1;
+      fb[5] = k == layers - 1 ? 5 : -1;
+      tria.face_bid.push_back(fb);
+    }
+}
 template <>
-void GridCreator<3>::flow_around_cylinder(Triangulation<3> &) {
-  throw std::runtime_error("GridCreator<3>::flow_around_cylinder (extruded mesh) is not built yet");
+void GridCreator<3>::flow_around_cylinder(Triangulation<3> &tria) {
+  tria.level = 0;
+  tria.generator = [](Triangulation<3> &t, int level) {
+    auto gen = t.generator;
+    const int lv = level;
+    cylinder_3d(t, lv);
+    t.generator = gen;
+    t.level = lv;
+  };
+  cylinder_3d(tria, 0);
 }
 } // namespace Utils
+
+// 3D hexahedral meshes: a Q2 node (i, j, k) in {0, 1, 2}^3 of a cell sits at the centre of the vertices it "spans" (index 0 / 2
+// fixes the vertex bit of that direction, 1 frees it): 1 vertex, the 2 of an edge, the 4 of a face or all 8.  The sorted
+// vertex tuple identifies the entity in every cell that shares it; its coordinates are their mean (the d-linear map at
+// the midpoint), which is where MappingQ1 puts FE_Q(2)'s support points.
+static void distribute_dofs_hex(const Triangulation<3> &tria, int kv, DoFTables<3> &out, PartitionTables &part) {
+  const size_t nc = tria.cells.size(), nV = tria.vertices.size();
+  const int n1 = kv + 1, nu = n1 * n1 * n1;
+  out.kv = kv; out.nu = nu; out.np = 8;
+  out.vcoords.resize(nc * 24);
+  out.cell_face_bid.resize(nc * 6);
+  out.cell_pnodes.resize(nc * 8);
+  out.cell_unodes.resize(nc * nu);
+  for (size_t c = 0; c < nc; ++c) {
+    for (int v = 0; v < 8; ++v) {
+      for (int d = 0; d < 3; ++d) out.vcoords[(c * 8 + v) * 3 + d] = tria.vertices[tria.cells[c][v]][d];
+      out.cell_pnodes[c * 8 + v] = tria.cells[c][v];
+    }
+    for (int f = 0; f < 6; ++f) out.cell_face_bid[c * 6 + f] = tria.face_bid[c][f];
+  }
+  out.pnode_coords.assign(tria.vertices.begin(), tria.vertices.end());
+  out.n_pnodes = out.n_pnodes_owned = (int64_t)nV;
+  if (kv == 1) {
+    out.cell_unodes = out.cell_pnodes;
+    out.unode_coords = out.pnode_coords;
+  } else {
+    out.unode_coords.assign(tria.vertices.begin(), tria.vertices.end());
+    std::map<std::array<int32_t, 8>, int32_t> entity; // sorted spanned vertices, padded with -1
+    for (size_t c = 0; c < nc; ++c) {
+      const auto &cv = tria.cells[c];
+      for (int a = 0; a < 27; ++a) {
+        const int idx[3] = {a % 3, (a / 3) % 3, a / 9};
+        std::array<int32_t, 8> key;
+        key.fill(-1);
+        int n = 0;
+        for (int v = 0; v < 8; ++v) {
+          bool in = true;
+          for (int d = 0; d < 3; ++d) {
+            const int bit = (v >> d) & 1;
+            if ((idx[d] == 0 && bit != 0) || (idx[d] == 2 && bit != 1)) in = false;
+          }
+          if (in) key[n++] = cv[v];
+        }
+        if (n == 1) { out.cell_unodes[c * 27 + a] = key[0]; continue; }
+        std::sort(key.begin(), key.begin() + n);
+        auto it = entity.find(key);
+        if (it == entity.end()) {
+          it = entity.emplace(key, (int32_t)out.unode_coords.size()).first;
+          std::array<double, 3> x{0, 0, 0};
+          for (int i = 0; i < n; ++i)
+            for (int d = 0; d < 3; ++d) x[d] += tria.vertices[key[i]][d] / n;
+          out.unode_coords.push_back(x);
+        }
+        out.cell_unodes[c * 27 + a] = it->second;
+      }
+    }
+  }
+  out.n_unodes = out.n_unodes_owned = (int64_t)out.unode_coords.size();
+  part = PartitionTables();
+  part.l2g_u.resize((size_t)out.n_unodes);
+  part.l2g_p.resize((size_t)out.n_pnodes);
+  std::iota(part.l2g_u.begin(), part.l2g_u.end(), 0);
+  std::iota(part.l2g_p.begin(), part.l2g_p.end(), 0);
+  part.send_u_ptr = part.recv_u_ptr = part.send_p_ptr = part.recv_p_ptr = {0};
+  part.n_unodes_global = out.n_unodes; part.n_pnodes_global = out.n_pnodes; part.n_cells_global = (int64_t)nc;
+}
 
 template <int dim>
 void distribute_dofs_unstructured(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out, PartitionTables &part) {
   if constexpr (dim != 2) {
-    throw std::runtime_error("distribute_dofs: unstructured 3D triangulations are not supported in this build");
+    distribute_dofs_hex(tria, kv, out, part);
   } else {
     const size_t nc = tria.cells.size(), nV = tria.vertices.size();
     const int n1 = kv + 1, nu = n1 * n1;

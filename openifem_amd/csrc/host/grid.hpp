@@ -38,7 +38,8 @@ struct Triangulation {
 namespace Utils {
 // GridCreator<2>::flow_around_cylinder (reference source/utilities.cpp:345-524): the DFG cylinder benchmark mesh,
 // 22 x 4 bulk cells with the 8-cell polar/transfinite ring around the cylinder, boundary ids 0 inflow, 1 outflow,
-// 2 y=0, 3 y=0.41, 4 cylinder.
+// 2 y=0, 3 y=0.41, 4 cylinder.  GridCreator<3> (utilities.cpp:526-570): the x in [-0.3, 2.2] variant extruded to
+// z in [0, 0.41] in 8 layers, boundary ids 0 / 1 (x), 2 / 3 (y), 4 / 5 (z), 6 cylinder surface.
 template <int dim>
 struct GridCreator {
   static void flow_around_cylinder(Triangulation<dim> &tria);
@@ -97,7 +98,7 @@ void distribute_dofs_box(const std::array<int, 3> &reps, const std::array<double
 
 template <int dim>
 void distribute_dofs(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out);
-// general (unstructured, single rank) variant: vertices, edge midpoints, cell centres; 2D only in this build
+// general (unstructured, single rank) variant: vertices, edge midpoints, (face centres,) cell centres
 template <int dim>
 void distribute_dofs_unstructured(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out, PartitionTables &part);
 // Partition of an unstructured mesh given by its GLOBAL tables (every rank builds them: these meshes are small) into the

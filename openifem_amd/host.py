@@ -74,8 +74,10 @@ class FluidSolver:
     def __init__(self, prm_text, reps=None, p0=None, p1=None, device=0, verbose=False, mesh="box"):
         self.L = _lib()
         self._bc_keep = []
-        if mesh == "cylinder":  # Utils::GridCreator<2>::flow_around_cylinder
-            self.dim = 2
+        if mesh == "cylinder":  # Utils::GridCreator<dim>::flow_around_cylinder, dim from the .prm (3: the extruded mesh)
+            import re
+            mdim = re.search(r"set\s+Dimension\s*=\s*(\d)", prm_text)
+            self.dim = int(mdim.group(1)) if mdim else 2
             self.h = C.c_void_p()
             self._chk(self.L.ifemx_solver_create_cylinder(self.KIND.encode(), prm_text.encode(), device, int(verbose),
                                                           C.byref(self.h)))

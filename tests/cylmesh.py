@@ -15,9 +15,12 @@ import numpy as np
 class CylinderMesh:
     dim = 2
 
-    def __init__(self, refinements=3, kv=2):
+    def __init__(self, refinements=3, kv=2, for_3d=False):
+        # for_3d: the variant GridCreator<3> extrudes (utilities.cpp:348-355): channel from x = -0.3, 25 bulk columns
         self.kv = kv
         s = 2 ** refinements
+        left, ncol, hole = (-0.3, 25, (4, 5)) if for_3d else (0.0, 22, (1, 2))
+        self.left = left
         hx, hy = 2.2 / 22, 0.41 / 4
         c = np.array([0.2, 0.2])
         r_in = 0.05
@@ -28,10 +31,10 @@ class CylinderMesh:
         XI, ETA = np.meshgrid(t, t, indexing="ij")  # [a, b] -> xi = a/s, eta = b/s
         patches = []  # each: array [s+1, s+1, 2] of vertex coordinates in the patch's (xi, eta) frame
         for j in range(4):
-            for i in range(22):
-                if i in (1, 2) and j in (1, 2):
+            for i in range(ncol):
+                if i in hole and j in (1, 2):
                     continue
-                X = np.stack([(i + XI) * hx, (j + ETA) * hy], -1)
+                X = np.stack([left + (i + XI) * hx, (j + ETA) * hy], -1)
                 patches.append(X)
         for k in range(8):
             th = 2 * np.pi * k / 8 + ETA * (np.pi / 4)
@@ -101,7 +104,7 @@ class CylinderMesh:
                 m = 0.5 * (vcoord[cv[a]] + vcoord[cv[b]])
                 if abs(m[0] - 2.2) < 1e-12:
                     bid[ci, f] = 1
-                elif abs(m[0]) < 1e-12:
+                elif abs(m[0] - left) < 1e-12:
                     bid[ci, f] = 0
                 elif abs(m[1] - 0.41) < 1e-12:
                     bid[ci, f] = 3
@@ -142,4 +145,86 @@ def inflow_bc(p, component):
     # tests/fluid_cylinder_mpi/fluid_cylinder_mpi.cpp:32-52 (2D): parabolic profile, Umax = 0.3
     if component == 0 and abs(p[0]) < 1e-10:
         return 4 * 0.3 * p[1] * (0.41 - p[1]) / (0.41 * 0.41)
+    return 0.0
+
+
+class CylinderMesh3D:
+    """Utils::GridCreator<3>::flow_around_cylinder (utilities.cpp:526-570): the x in [-0.3, 2.2] variant of the 2D mesh
+    extruded to z in [0, 0.41] in 8 * 2^refinements layers; boundary ids 0 / 1 (x), 2 / 3 (y), 4 / 5 (z), 6 the cylinder.
+    Q2 nodes are numbered by the set of vertices they span (vertex, edge, face, cell), independently of the host mirror."""
+    dim = 3
+
+    def __init__(self, refinements=0, kv=2):
+        self.kv = kv
+        m2 = CylinderMesh(refinements, kv=1, for_3d=True)
+        layers = 8 * 2 ** refinements
+        z = np.linspace(0.0, 0.41, layers + 1)
+        nv2 = len(m2.vertex_coords)
+        self.vertex_coords = np.concatenate([np.column_stack([m2.vertex_coords, np.full(nv2, zk)]) for zk in z])
+        cells, bid = [], []
+        for k in range(layers):
+            for ci, cv in enumerate(m2.cell_vertices):
+                cells.append(list(cv + k * nv2) + list(cv + (k + 1) * nv2))
+                fb = [6 if b == 4 else b for b in m2.cell_face_bid[ci]]
+                bid.append(fb + [4 if k == 0 else -1, 5 if k == layers - 1 else -1])
+        cells = np.array(cells, np.int64)
+        self.n_cells = len(cells)
+        self.cell_vertices = cells
+        self.vcoords = np.ascontiguousarray(self.vertex_coords[cells])  # [n_cells, 8, 3]
+        self.cell_pnodes = cells.astype(np.int32)
+        self.n_pnodes = len(self.vertex_coords)
+        self.pnode_coords = self.vertex_coords
+        self.cell_face_bid = np.array(bid, np.int32)
+        if kv == 1:
+            self.cell_unodes, self.unode_coords = self.cell_pnodes, self.vertex_coords
+        else:
+            ent, coords = {}, [p for p in self.vertex_coords]
+            cu = np.zeros((self.n_cells, 27), np.int64)
+            for ci, cv in enumerate(cells):
+                for a in range(27):
+                    idx = (a % 3, (a // 3) % 3, a // 9)
+                    span = [cv[v] for v in range(8)
+                            if all(idx[d] == 1 or ((v >> d) & 1) == idx[d] // 2 for d in range(3))]
+                    if len(span) == 1:
+                        cu[ci, a] = span[0]
+                        continue
+                    key = frozenset(span)
+                    if key not in ent:
+                        ent[key] = len(coords)
+                        coords.append(self.vertex_coords[span].mean(0))
+                    cu[ci, a] = ent[key]
+            self.cell_unodes = cu.astype(np.int32)
+            self.unode_coords = np.array(coords)
+        self.n_unodes = len(self.unode_coords)
+        self.n_u = 3 * self.n_unodes
+        self.n_dofs = self.n_u + self.n_pnodes
+        self.indicator = None
+
+    def dirichlet(self, bcs, fields=None):
+        n1 = self.kv + 1
+        dofs, vals, seen = [], [], set()
+        for bid in sorted(bcs):
+            flag, value = bcs[bid]
+            comps = [c for c in range(3) if flag & (1 << c)]
+            for ci, f in zip(*np.nonzero(self.cell_face_bid == bid)):
+                nd_, side = f // 2, (f % 2) * self.kv
+                for a in range(n1 ** 3):
+                    idx = (a % n1, (a // n1) % n1, a // (n1 * n1))
+                    if idx[nd_] != side:
+                        continue
+                    node = self.cell_unodes[ci, a]
+                    for k, c in enumerate(comps):
+                        dof = 3 * node + c
+                        if dof in seen:
+                            continue
+                        seen.add(dof)
+                        dofs.append(dof)
+                        vals.append(fields[bid](self.unode_coords[node], c) if fields and bid in fields else value[k])
+        return np.array(dofs, np.int32), np.array(vals, float)
+
+
+def inflow_bc_3d(p, component):
+    # parabolic in y and z at the inlet x = -0.3 (the shape of fluid_cylinder_mpi.cpp:56-75 with Umax = 9/4 * 0.2)
+    if component == 0 and abs(p[0] + 0.3) < 1e-10:
+        return 0.45 * (4 * p[1] * (0.41 - p[1]) / 0.41 ** 2) * (4 * p[2] * (0.41 - p[2]) / 0.41 ** 2)
     return 0.0

@@ -346,6 +346,50 @@ def test_reference_driver_fluid_cylinder_mpi_through_host_mirror():
     assert abs(p.max() - 46.5226) / 46.5226 < 1e-3
 
 
+def test_extruded_cylinder_mesh_through_host_mirror_matches_oracle():
+    """Utils::GridCreator<3>::flow_around_cylinder (utilities.cpp:526-570) on the host mirror -- an unstructured hexahedral
+    Q2/Q1 mesh -- driven like tests/fluid_cylinder_mpi's dim == 3 branch (fluid_cylinder_mpi.cpp:98-104; no reference
+    constant exists for it): one time step against the oracle on an independently generated mesh (tests/cylmesh.py,
+    own entity numbering): DoF counts, maximum velocity and pressure."""
+    import os
+    import re
+    from openifem_amd import host
+    from cylmesh import CylinderMesh3D, inflow_bc_3d
+    prm = open(os.path.join(os.path.dirname(__file__), "golden", "prm", "fluid_cylinder_mpi.prm")).read()
+    prm = re.sub(r"set Dimension = 2", "set Dimension = 3", prm)
+    prm = re.sub(r"set Global refinements = 3, 0", "set Global refinements = 0, 0", prm)
+    prm = re.sub(r"set Gravity = 0.0, 0.0", "set Gravity = 0.0, 0.0, 0.0", prm)
+    prm = re.sub(r"set Initial velocity = 0.0, 0.0", "set Initial velocity = 0.0, 0.0, 0.0", prm)
+    prm = re.sub(r"set Number of Dirichlet BCs = 4", "set Number of Dirichlet BCs = 6", prm)
+    prm = re.sub(r"set Dirichlet boundary id = 0, 2, 3, 4", "set Dirichlet boundary id = 0, 2, 3, 4, 5, 6", prm)
+    prm = re.sub(r"set Dirichlet boundary components = 3, 3, 3, 3", "set Dirichlet boundary components = 7, 7, 7, 7, 7, 7", prm)
+    prm = re.sub(r"set Dirichlet boundary values = 0.2, 0, 0, 0, 0, 0, 0, 0", "set Dirichlet boundary values = " + ", ".join(["0"] * 18), prm)
+
+    flow = host.InsIM(prm, mesh="cylinder")
+    flow.add_hard_coded_boundary_condition(0, lambda p, c, t: inflow_bc_3d(p, c))
+    flow.opts.inner_rel = 1e-4
+    flow.opts.inner_maxit = 4000
+    flow.opts.fgmres_rel = 1e-8
+    flow.run()  # one time step (End time = Time step size)
+    v, p = flow.get_current_solution()
+
+    m = CylinderMesh3D(0)
+    assert flow.sizes() == (m.n_cells, 3 * m.n_unodes, m.n_pnodes)
+    zero = [0.0, 0.0, 0.0]
+    dofs, vals = m.dirichlet({k: (7, zero) for k in (0, 2, 3, 4, 5, 6)}, {0: inflow_bc_3d})
+    S = orc.System(m)
+    S.set_constraints(0, dofs, None)
+    S.set_constraints(1, dofs, vals)
+    xo = np.zeros(S.n)
+    rc, _ = S.run_one_step(orc.make_params(mu=0.001, rho=1.0, gamma=0.1, dt=1e-2, g=(0.0, 0.0, 0.0), neumann={}), True, xo,
+                           ainv=orc.SpluAinv())
+    assert rc > 0
+    vo, po = xo[:S.n_u], xo[S.n_u:]
+    assert abs(v.max() - vo.max()) <= 1e-6 * abs(vo.max()), (v.max(), vo.max())
+    assert abs(p.max() - po.max()) <= 1e-5 * abs(po.max()), (p.max(), po.max())
+    assert abs(np.abs(v).sum() - np.abs(vo).sum()) <= 1e-6 * np.abs(vo).sum()
+
+
 def test_output_results_writes_vtu_pvtu_pvd(tmp_path):
     # FluidSolver::output_results / Utils::PVDWriter through the host mirror after one step on the GPU
     import xml.etree.ElementTree as ET

@@ -156,6 +156,33 @@ def test_cylinder_grid_creator_matches_independent_builder():
     assert len(np.unique(cu)) == m.n_unodes and len(np.unique(cp)) == m.n_pnodes
 
 
+@pytest.mark.parametrize("level", [0, 1])
+def test_extruded_cylinder_grid_creator_matches_independent_builder(level):
+    # Utils::GridCreator<3>::flow_around_cylinder (utilities.cpp:526-570: the x in [-0.3, 2.2] mesh extruded in 8 layers) and
+    # the Q2/Q1 tables of an unstructured hexahedral mesh in the C++ host mirror vs tests/cylmesh.py::CylinderMesh3D
+    import re
+    from openifem_amd import host
+    from cylmesh import CylinderMesh3D
+    prm = open(os.path.join(ROOT, "tests", "golden", "prm", "fluid_cylinder_mpi.prm")).read()
+    prm = re.sub(r"set Dimension = 2", "set Dimension = 3", prm)
+    prm = re.sub(r"set Gravity = 0.0, 0.0", "set Gravity = 0.0, 0.0, 0.0", prm)
+    prm = re.sub(r"set Initial velocity = 0.0, 0.0", "set Initial velocity = 0.0, 0.0, 0.0", prm)
+    prm = re.sub(r"set Dirichlet boundary components = 3, 3, 3, 3", "set Dirichlet boundary components = 7, 7, 7, 7", prm)
+    prm = re.sub(r"set Dirichlet boundary values = 0.2, 0, 0, 0, 0, 0, 0, 0", "set Dirichlet boundary values = " + ", ".join(["0"] * 12), prm)
+    s = host.InsIM(prm, mesh="cylinder")
+    s.setup_host_only(level)
+    m = CylinderMesh3D(level)
+    assert s.sizes() == (m.n_cells, m.n_u, m.n_pnodes)
+    if level == 0:
+        assert s.sizes() == (832, 24582, 1233)
+    cu, cp, fb, vc = s.cell_tables()
+    assert np.abs(vc - m.vcoords).max() < 1e-15 and np.array_equal(fb, m.cell_face_bid)
+    uc, pc = s.node_coords()
+    assert np.abs(uc[cu] - m.unode_coords[m.cell_unodes]).max() < 1e-15
+    assert np.abs(pc[cp] - m.pnode_coords[m.cell_pnodes]).max() < 1e-15
+    assert len(np.unique(cu)) == m.n_unodes and len(np.unique(cp)) == m.n_pnodes
+
+
 def test_scnsim_host_mirror_setup_and_errors():
     # Fluid::MPI::SCnsIM through the host mirror without a device: the reference's .prm files parse (Q1/Q1, solid
     # density), equal-order is enforced (mpi_supg_solver.cpp:213-215), the cylinder tables are the Q1/Q1 ones
