@@ -462,7 +462,9 @@ __global__ __launch_bounds__(256) void k_schur_numeric(int64_t n_rows, int maxle
   int32_t *hkey = reinterpret_cast<int32_t *>(tsl + maxb);
   int32_t *tll = hkey + hsize;
   uint16_t *hpos = reinterpret_cast<uint16_t *>(tll + maxb);
-  const int64_t row = int64_t(blockIdx.x) * 4 + wave;
+  // XCD-aware row order: neighbouring pressure rows (Morton order) read the same rows of B^T -- 27 pressure rows share
+  // each -- so every XCD gets one contiguous range of rows and finds them in its own L2
+  const int64_t row = int64_t(xcd_swizzle(blockIdx.x, gridDim.x)) * 4 + wave;
   const bool active = row < n_rows;
   const int64_t rs = active ? rpS[row] : 0;
   const int len = active ? int(rpS[row + 1] - rs) : 0;
@@ -491,26 +493,57 @@ __global__ __launch_bounds__(256) void k_schur_numeric(int64_t n_rows, int maxle
   }
   wsync();
   const int half = lane >> 5, tl = lane & 31;
-  for (int kb0 = 0; kb0 < blen; kb0 += 2) {
-    const int kb = kb0 + half;
-    if (kb >= blen) continue;
-    const int64_t ts = tsl[kb];
-    const int tlen = tll[kb];
-    double bd[DIM];
+  // U rows of B^T per half-wave and trip: all their index / value loads are issued before the first lookup (one L2 round
+  // trip per trip instead of one per row: the loop is latency-bound otherwise, 30 -> 12 ms at 128^3)
+  constexpr int U = 4;
+  for (int kb0 = 0; kb0 < blen; kb0 += 2 * U) {
+    int32_t j[U];
+    double v[U];
+    bool ok[U];
+    int tlen_[U];
+    int64_t ts_[U];
 #pragma unroll
-    for (int c = 0; c < DIM; ++c) bd[c] = bdl[kb * DIM + c];
-    for (int t = tl; t < tlen; t += 32) {
-      const int32_t j = colT[ts + t];
-      double v = 0;
+    for (int u = 0; u < U; ++u) {
+      const int kb = kb0 + 2 * u + half;
+      const bool live = kb < blen;
+      const int kbs = live ? kb : 0;
+      ts_[u] = tsl[kbs];
+      tlen_[u] = tll[kbs];
+      ok[u] = live && tl < tlen_[u];
+      const int t = ok[u] ? tl : 0;
+      j[u] = colT[ts_[u] + t];
+      double s_ = 0;
 #pragma unroll
-      for (int c = 0; c < DIM; ++c) v += bd[c] * valT[ts * DIM + int64_t(c) * tlen + t];
-      unsigned h = (unsigned(j) * 2654435761u >> 8) & hmask;
-      while (true) { // every column of B^T's row k is a column of S_m's row i (pattern(S_m) = pattern(B B^T))
-        const int32_t key = hkey[h];
-        if (key == j) { unsafeAtomicAdd(&acc[hpos[h]], v); break; }
-        if (key == -1) break;
-        h = (h + 1) & hmask;
+      for (int c = 0; c < DIM; ++c) s_ += bdl[kbs * DIM + c] * valT[ts_[u] * DIM + int64_t(c) * tlen_[u] + t];
+      v[u] = s_;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ok[u]) {
+        unsigned h = (unsigned(j[u]) * 2654435761u >> 8) & hmask;
+        while (true) { // every column of B^T's row k is a column of S_m's row i (pattern(S_m) = pattern(B B^T))
+          const int32_t key = hkey[h];
+          if (key == j[u]) { unsafeAtomicAdd(&acc[hpos[h]], v[u]); break; }
+          if (key == -1) break;
+          h = (h + 1) & hmask;
+        }
       }
+      // rows of B^T longer than half a wave (more than 8 cells around a node): the remaining entries, one trip each
+      const int kb = kb0 + 2 * u + half;
+      if (kb < blen)
+        for (int t = tl + 32; t < tlen_[u]; t += 32) {
+          const int32_t jj = colT[ts_[u] + t];
+          double vv = 0;
+#pragma unroll
+          for (int c = 0; c < DIM; ++c) vv += bdl[kb * DIM + c] * valT[ts_[u] * DIM + int64_t(c) * tlen_[u] + t];
+          unsigned h = (unsigned(jj) * 2654435761u >> 8) & hmask;
+          while (true) {
+            const int32_t key = hkey[h];
+            if (key == jj) { unsafeAtomicAdd(&acc[hpos[h]], vv); break; }
+            if (key == -1) break;
+            h = (h + 1) & hmask;
+          }
+        }
     }
   }
   wsync();
