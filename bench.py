@@ -169,6 +169,8 @@ def bench_insimex(args, host):
 
 def extras(solver, capi, n_dofs, warm_ms):
     """N = 1 side measurements next to the warm `value`:
+    new_constraint_set_step -- one Newton iteration right after the set of constrained dofs changed (ifem_tuning::geo_cache = 2
+      treats every assembly that way): masked copies of the mesh-only B / B^T, S_m re-formed, nothing re-integrated.
     cold_step -- one Newton iteration with nothing kept from the previous one: B, B^T, M_p, diag(M_u) re-integrated and
       S_m = B diag(M_u)^-1 B^T re-formed, which is what the reference does in EVERY iteration (assemble() zeroes all blocks,
       mpi_insim.cpp:163-165; solve() rebuilds the preconditioner, :369 and :44-49).  Here it is the cost of the first
@@ -182,24 +184,33 @@ def extras(solver, capi, n_dofs, warm_ms):
     L, ctx = solver.L, solver.ctx
     tun = capi.Tuning()
     L.ifem_default_tuning(C.byref(tun))
-    tun.geo_cache = 0
-    assert L.ifem_set_tuning(ctx, C.byref(tun)) == 0
-    solver.assemble(False)
-    solver.solve(False)  # state: previous iteration done, nothing cached
-    solver.synchronize()
-    t0 = time.time()
-    solver.assemble(False)
-    t1 = time.time()
-    st = solver.solve(False)
-    solver.synchronize()
-    t2 = time.time()
-    out["cold_step"] = {"ms_per_step": (t2 - t0) * 1e3, "value": n_dofs / (t2 - t0), "unit": "DoF/s",
-                        "assemble_ms": (t1 - t0) * 1e3, "solve_ms": (t2 - t1) * 1e3, "fgmres_iters": st.fgmres_iters,
-                        "vs_warm": (t2 - t0) * 1e3 / warm_ms,
-                        "note": "geometry blocks re-integrated and S_m re-formed inside the step, as the reference does every "
-                                "Newton iteration; `value` above keeps them (same constrained-dof set)"}
-    tun.geo_cache = 1
-    assert L.ifem_set_tuning(ctx, C.byref(tun)) == 0
+
+    def set_geo_cache(v):  # on every multigrid level: the coarser ones re-form their S_m as well
+        tun.geo_cache = v
+        for s_ in [solver] + list(getattr(solver, "_levels", [])):
+            assert L.ifem_set_tuning(s_.ctx, C.byref(tun)) == 0
+
+    def one_step(label, note):
+        solver.assemble(False)
+        solver.solve(False)  # state: previous iteration done
+        solver.synchronize()
+        t0 = time.time()
+        solver.assemble(False)
+        t1 = time.time()
+        st = solver.solve(False)
+        solver.synchronize()
+        t2 = time.time()
+        out[label] = {"ms_per_step": (t2 - t0) * 1e3, "value": n_dofs / (t2 - t0), "unit": "DoF/s",
+                      "assemble_ms": (t1 - t0) * 1e3, "solve_ms": (t2 - t1) * 1e3, "fgmres_iters": st.fgmres_iters,
+                      "vs_warm": (t2 - t0) * 1e3 / warm_ms, "note": note}
+
+    set_geo_cache(0)
+    one_step("cold_step", "geometry blocks re-integrated and S_m re-formed inside the step, as the reference does every "
+                          "Newton iteration; `value` above keeps them (same constrained-dof set)")
+    set_geo_cache(2)
+    one_step("new_constraint_set_step", "what a change of the constrained-dof set costs here (every FSI step): B / B^T as masked "
+                                        "copies of the unconstrained blocks (integrated once per mesh), S_m re-formed on every level")
+    set_geo_cache(1)
     solver.channel_state()
     # present := perturbed state, so that the Newton loop has something to converge from
     assert L.ifem_vec_copy(ctx, capi.VEC_PRESENT, capi.VEC_EVAL) == 0

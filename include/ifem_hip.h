@@ -139,7 +139,9 @@ typedef struct {
 /* Tuning / measurement knobs of one context (defaults = the measured best; nothing here changes results beyond fp64
  * rounding).  Replaces the environment switches of the first round: the library reads no environment variable. */
 typedef struct {
-  int32_t geo_cache;     /* 1: B, B^T, M_p, diag(M_u) are kept across assemblies with an unchanged constraint set; 0:
+  int32_t geo_cache;     /* 1: B, B^T, M_p, diag(M_u) and S_m are kept across assemblies with an unchanged constrained-dof set; a
+                            new set takes B / B^T as masked copies of the unconstrained blocks (integrated once per mesh) and
+                            re-forms S_m.  2 (measurement): every assembly is treated as a new set.  0: everything is
                             re-integrated by every assembly as the reference does (mpi_insim.cpp:163-165) */
   int32_t xcd_swizzle;   /* 1: cell kernels hand every XCD one contiguous range of the (Morton-ordered) cells */
   int32_t asm_skip;      /* 0; measurement only: drop parts of the 3D Q2/Q1 assembly kernel (results invalid) */

@@ -17,8 +17,57 @@
 namespace ifem {
 
 static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero);
+static void ifem_ctx_unconstrained_geometry(ifem_ctx *ctx, const ifem_ins_params *p);
 void launch_ins_assemble2_kernel(ifem_ctx *ctx, const AsmArgs &A);
 bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A);
+
+// B / B^T of a constrained-dof set from the unconstrained blocks: distribute_local_to_global(..., true) drops the rows and
+// columns of constrained dofs, i.e. plane c of the B^T row of node a, and entry c of every B block in the
+// column of node a, when velocity dof (a, c) is constrained -- the kept entries are the unconstrained sums unchanged.
+template <int DIM>
+__global__ void k_mask_bt(int64_t n_rows, const int64_t *__restrict__ rp, const uint8_t *__restrict__ is_c,
+                          const double *__restrict__ src, double *__restrict__ dst) {
+  const int64_t row = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 5; // 32 lanes per row
+  const int lig = threadIdx.x & 31;
+  if (row >= n_rows) return;
+  const int64_t rs = rp[row];
+  const int len = int(rp[row + 1] - rs);
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) {
+    const bool drop = is_c && is_c[row * DIM + c];
+    for (int k = lig; k < len; k += 32) dst[rs * DIM + int64_t(c) * len + k] = drop ? 0.0 : src[rs * DIM + int64_t(c) * len + k];
+  }
+}
+template <int DIM>
+__global__ void k_mask_b(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                         const uint8_t *__restrict__ is_c, const double *__restrict__ src, double *__restrict__ dst) {
+  const int64_t row = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 5;
+  const int lig = threadIdx.x & 31;
+  if (row >= n_rows) return;
+  const int64_t rs = rp[row];
+  const int len = int(rp[row + 1] - rs);
+  for (int k = lig; k < len; k += 32) {
+    const int64_t nd = col[rs + k];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+      const bool drop = is_c && is_c[nd * DIM + c];
+      dst[rs * DIM + int64_t(c) * len + k] = drop ? 0.0 : src[rs * DIM + int64_t(c) * len + k];
+    }
+  }
+}
+static void masked_geometry_blocks(ifem_ctx *ctx, int use_nonzero) {
+  const int w = use_nonzero ? 1 : 0;
+  const uint8_t *flags = ctx->has_c[w] ? ctx->is_c[w].p : nullptr;
+  hipStream_t s = ctx->stream;
+  const int64_t nu = ctx->Bt.n_rows, np = ctx->B.n_rows;
+  if (ctx->dim == 3) {
+    if (nu) hipLaunchKernelGGL((k_mask_bt<3>), dim3(unsigned((nu * 32 + 255) / 256)), dim3(256), 0, s, nu, ctx->Bt.rowptr.p, flags, ctx->Bt0.p, ctx->Bt.val.p);
+    if (np) hipLaunchKernelGGL((k_mask_b<3>), dim3(unsigned((np * 32 + 255) / 256)), dim3(256), 0, s, np, ctx->B.rowptr.p, ctx->B.col.p, flags, ctx->B0.p, ctx->B.val.p);
+  } else {
+    if (nu) hipLaunchKernelGGL((k_mask_bt<2>), dim3(unsigned((nu * 32 + 255) / 256)), dim3(256), 0, s, nu, ctx->Bt.rowptr.p, flags, ctx->Bt0.p, ctx->Bt.val.p);
+    if (np) hipLaunchKernelGGL((k_mask_b<2>), dim3(unsigned((np * 32 + 255) / 256)), dim3(256), 0, s, np, ctx->B.rowptr.p, ctx->B.col.p, flags, ctx->B0.p, ctx->B.val.p);
+  }
+}
 
 void launch_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) { launch_ins_assemble_ex(ctx, p, use_nonzero, 0, 1); }
 void launch_ins_assemble_geometry(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero) { launch_ins_assemble_ex(ctx, p, use_nonzero, 0, 2); }
@@ -29,11 +78,11 @@ void launch_ins_assemble_geometry(ifem_ctx *ctx, const ifem_ins_params *p, int u
 void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero, int imex, int assemble_system) {
   hipStream_t s = ctx->stream;
   const int dim = ctx->dim;
-  const bool geo_only = assemble_system == 2;
-  if (geo_only) {
+  const bool geo_only = assemble_system >= 2; // 3: the same without constraints (pristine blocks)
+  if (assemble_system == 2) {
     const int64_t key = ctx->flag_id[use_nonzero ? 1 : 0];
-    if (ctx->geo_valid && ctx->geo_key == key) return; // still the blocks of this constrained-dof set
-  } else if (assemble_system)
+    if (ctx->geo_valid && ctx->geo_key == key && ctx->tune.geo_cache != 2) return; // still the blocks of this constrained-dof set
+  } else if (assemble_system == 1)
     ensure_auu_values(ctx);
   if (!assemble_system && !ctx->assembled) throw Error(IFEM_E_BADPARAM, "rhs-only assembly before any matrix assembly");
   if (assemble_system == 1) { // state the matrix-free A_uu needs to reproduce this matrix (apply_mf.hip)
@@ -51,7 +100,26 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   // nonzero_constraints of make_constraints list the same dofs) keeps them (bit-identical to re-integrating
   // them) and integrates A_uu and the right-hand side only.  ifem_tuning::geo_cache = 0 switches it off.
   const int64_t geo_key = ctx->flag_id[use_nonzero ? 1 : 0];
-  const bool skip_geo = ctx->tune.geo_cache && assemble_system && ctx->geo_valid && ctx->geo_key == geo_key;
+  bool skip_geo = ctx->tune.geo_cache == 1 && assemble_system && assemble_system != 3 && ctx->geo_valid && ctx->geo_key == geo_key;
+  // A NEW constrained-dof set (every FSI step): the blocks are masked copies of the unconstrained ones, which are integrated
+  // once per mesh (one geometry-only launch of the cell kernel without constraints); M_p and diag(M_u) do not depend on
+  // the set at all.  Same values as re-integrating them under the new set (the kept entries are the same sums).
+  if (assemble_system && assemble_system != 3 && !skip_geo && ctx->tune.geo_cache) {
+    if (!ctx->geo0_valid) {
+      ifem_ctx_unconstrained_geometry(ctx, p);
+      ctx->geo0_valid = true;
+    }
+    masked_geometry_blocks(ctx, use_nonzero);
+    ctx->geo_valid = true; ctx->geo_key = geo_key;
+    skip_geo = true;
+    if (geo_only) { // a multigrid level of S_m: nothing else to integrate
+      dinv_setup(ctx);
+      ctx->bbt_f32_valid = false;
+      ctx->sm_valid = false; ctx->sm_key = geo_key;
+      ctx->asm_constraint_set = use_nonzero ? 1 : 0;
+      return;
+    }
+  }
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
   if (assemble_system) {
     // (a hand-written fill kernel with 16-byte non-temporal stores measures the same 15 ms for the 78 GB at 128^3)
@@ -80,9 +148,10 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   A.diagMu = ctx->diagMu.p; A.rhs = ctx->vec[IFEM_VEC_RHS].p;
   A.v_s = ctx->want_shat ? ctx->Shat.p : nullptr;
   const int w = use_nonzero ? 1 : 0;
-  A.is_c = ctx->has_c[w] ? ctx->is_c[w].p : nullptr;
-  A.cval = ctx->has_c[w] ? ctx->cval[w].p : nullptr;
-  A.use_inhom = (use_nonzero && ctx->has_c[1]) ? 1 : 0;
+  const bool unconstrained = assemble_system == 3; // internal: the mesh-only blocks (ifem_ctx_unconstrained_geometry)
+  A.is_c = (ctx->has_c[w] && !unconstrained) ? ctx->is_c[w].p : nullptr;
+  A.cval = (ctx->has_c[w] && !unconstrained) ? ctx->cval[w].p : nullptr;
+  A.use_inhom = (use_nonzero && ctx->has_c[1] && !unconstrained) ? 1 : 0;
   A.skip_geo = skip_geo ? 1 : 0;
   A.skip_uu = geo_only ? 1 : 0;
   A.debug_skip = ctx->tune.asm_skip;
@@ -98,6 +167,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   if (!launch_ins_assemble3_kernel(ctx, A)) // assemble3.hip: 3D Q2/Q1 on the FP64 matrix cores
     launch_ins_assemble2_kernel(ctx, A);    // assemble2.hip (quadrature-point-outer, register accumulators)
   IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+  if (unconstrained) return; // the caller copies the blocks away
   if (assemble_system) { ctx->geo_valid = true; ctx->geo_key = geo_key; }
   if (geo_only) { // what the Schur complement of this level needs: 1/diag(M_u); S_m is stale if the blocks were re-integrated
     dinv_setup(ctx);
@@ -116,6 +186,17 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   hanging_condense_rhs(ctx, use_nonzero);
 }
 
+// B, B^T, M_p, diag(M_u) of the mesh alone: one geometry-only launch with no constraint set, B / B^T copied away
+static void ifem_ctx_unconstrained_geometry(ifem_ctx *ctx, const ifem_ins_params *p) {
+  launch_ins_assemble_ex(ctx, p, 0, 0, 3);
+  hipStream_t s = ctx->stream;
+  if (ctx->B0.n != ctx->B.val.n) ctx->B0.alloc(ctx->B.val.n);
+  if (ctx->Bt0.n != ctx->Bt.val.n) ctx->Bt0.alloc(ctx->Bt.val.n);
+  if (ctx->B.val.n) IFEM_HIP_CHECK(hipMemcpyAsync(ctx->B0.p, ctx->B.val.p, ctx->B.val.n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (ctx->Bt.val.n) IFEM_HIP_CHECK(hipMemcpyAsync(ctx->Bt0.p, ctx->Bt.val.p, ctx->Bt.val.n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  ctx->mp_f32_valid = false;
+}
+
 static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero) {
   dinv_setup(ctx);
   bjac_setup(ctx);
@@ -131,7 +212,7 @@ static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero) {
   // keep it across assemblies until the constraint set changes (the reference rebuilds it every solve(); same values)
   {
     const int64_t key = ctx->flag_id[use_nonzero ? 1 : 0];
-    if (key != ctx->sm_key || !ctx->tune.geo_cache) { ctx->sm_valid = false; ctx->sm_key = key; }
+    if (key != ctx->sm_key || ctx->tune.geo_cache != 1) { ctx->sm_valid = false; ctx->sm_key = key; }
   }
   ctx->shat_valid = ctx->want_shat;
   ctx->shat_aux_valid = false;

@@ -223,6 +223,11 @@ struct ifem_ctx {
   int asm_constraint_set = 0;
   bool geo_valid = false; // B, B^T, M_p, diag(M_u) hold the blocks of constraint set geo_key (assemble.hip)
   int64_t geo_key = -1;
+  // the same blocks integrated WITHOUT any constraint (functions of the mesh alone), kept once built: the blocks of a new
+  // constrained-dof set are masked copies of them instead of a re-integration (M_p and diag(M_u) do not depend on the set)
+  ifem::DBuf<double> B0, Bt0;
+  bool geo0_valid = false;
+  int64_t geo_refresh_stamp = -1; // a coarse multigrid level: the finest level's assembly its blocks were last refreshed for
   ifem::Hanging hang; // hanging-node lines (hanging.hip)
   // multigrid (ifem_mg_attach): the next coarser level (not owned) and the pressure transfers to it; per-level state of
   // the S_m V-cycle: 1/diag(S_m), largest eigenvalue of D^-1 S_m, scratch vectors [nPl]

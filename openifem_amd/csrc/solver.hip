@@ -420,7 +420,13 @@ static void mg_sm_setup(MgSm &M, int use_nonzero) {
     SolveState &S = M.L[l];
     ifem_ctx *c = S.ctx;
     if (l > 0) { // coarse levels are rediscretised: B, B^T, M_p, diag(M_u) of the level's own mesh and constraint set
-      launch_ins_assemble_geometry(c, S.P, use_nonzero);
+      // (ifem_tuning::geo_cache = 2, "every assembly is a new constrained-dof set": once per assembly of the finest level,
+      // not once per preconditioner application)
+      ifem_ctx *f0 = M.L[0].ctx;
+      if (!(c->tune.geo_cache == 2 && c->geo_refresh_stamp == f0->asm_version)) {
+        launch_ins_assemble_geometry(c, S.P, use_nonzero);
+        c->geo_refresh_stamp = f0->asm_version;
+      }
       sm_ensure(S);
     }
     for (auto &v : c->mg_vec)
