@@ -250,6 +250,7 @@ def main():
     ap.add_argument("--mg-smooth-u", type=int, default=None, help="smoothing steps of the A_uu V-cycle (--ainv 4)")
     ap.add_argument("--mg-post-u", type=int, default=None, help="smoothing steps after the coarse correction of the A_uu V-cycle (default: as before it)")
     ap.add_argument("--mg-ratio-u", type=float, default=None, help="Chebyshev interval ratio of the A_uu V-cycle (--ainv 4)")
+    ap.add_argument("--tune", action="append", default=[], help="experiment: ifem_tuning field=value (e.g. --tune spmv_pipe=0), applied to every multigrid level")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
     ap.add_argument("--outer-mf", type=int, default=0, help="experiment: apply the u-u block of the OUTER operator matrix-free too")
     ap.add_argument("--solver", default="insim", choices=["insim", "insimex"],
@@ -296,6 +297,14 @@ def main():
         solver.opts.mg_cheb_ratio_u = args.mg_ratio_u
     solver.opts.outer_matrix_free = args.outer_mf
     solver.opts.verbose = args.verbose if rank == 0 else 0
+    if args.tune:
+        tun = capi.Tuning()
+        solver.L.ifem_default_tuning(C.byref(tun))
+        for kv in args.tune:
+            k, v = kv.split("=")
+            setattr(tun, k, int(v))
+        for s_ in [solver] + list(getattr(solver, "_levels", [])):
+            assert solver.L.ifem_set_tuning(s_.ctx, C.byref(tun)) == 0
     solver.channel_state()
 
     def step():

@@ -149,6 +149,8 @@ typedef struct {
   int32_t sm_lanes;      /* 32: lanes per row of the S_m SpMV */
   int32_t mf_f32;        /* 1: single-precision cell arithmetic in the matrix-free A_uu of the INNER solve */
   int32_t tpp_operator;  /* 0; 1: SCnsIM preconditioner applies T_pp as an operator instead of the explicit matrix */
+  int32_t spmv_pipe;     /* 1: the fp64 A_uu SpMV (3 x 3 blocks) as a software-pipelined walk of row ranges (k_spmv_uu_pipe); 0: one
+                            group of lanes per row */
   int32_t halo_overlap;  /* 1: several ranks: the halo of an operator input travels on a second stream / communicator
                             while the rows (SpMV) or cells (matrix-free A_uu) that read no ghost value are processed; 0: the
                             exchange completes on the context stream before the operator starts */

@@ -133,6 +133,107 @@ __global__ __launch_bounds__(256) void k_spmv_uu(int64_t n_rows, const int64_t *
   }
 }
 
+// Software-pipelined y_u = A_uu x_u for the block-interleaved 3 x 3 layout.  The row-per-group kernel above lives for three
+// dependent round trips (row pointer -> indices / values -> x) and moves 4.6 TB/s at the pins where a plain read stream
+// reaches 6.2 (tools/readbw.hip).  Here a block keeps a contiguous range of rows (row pointers in LDS), every half-wave walks
+// its rows as a flat sequence of "items" (32 consecutive blocks of a row) and, in each iteration, requests the column
+// indices of item i + 2 and the values of item i + 1, gathers x for item i + 1 (its indices arrived an iteration ago) and
+// only then multiplies item i: three items are in flight per lane, no load is waited for next to its issue.
+struct SpmvItem { int64_t off; int row, n; bool last; }; // first block of the item, row (block-local), blocks in it, closes its row
+__global__ __launch_bounds__(256) void k_spmv_uu_pipe(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                      const double *__restrict__ val, const double *__restrict__ xu,
+                                                      double *__restrict__ yu, const int32_t *__restrict__ rows, int rows_per_block) {
+  extern __shared__ int64_t s_rp[]; // [rows_per_block][2]: begin / end of every row of the block
+  const int hw = threadIdx.x >> 5, lig = threadIdx.x & 31;
+  const int64_t r0 = int64_t(xcd_swizzle(blockIdx.x, gridDim.x)) * rows_per_block;
+  const int nr = int((r0 + rows_per_block <= n_rows ? r0 + rows_per_block : n_rows) - r0);
+  if (nr <= 0) return;
+  for (int i = threadIdx.x; i < nr; i += blockDim.x) {
+    const int64_t r = rows ? int64_t(rows[r0 + i]) : r0 + i;
+    s_rp[2 * i] = rp[r]; s_rp[2 * i + 1] = rp[r + 1];
+  }
+  __syncthreads();
+  // item iterator of this half-wave: rows hw, hw + 8, ... of the block, 32 blocks at a time
+  auto first_item = [&](int row) -> SpmvItem {
+    SpmvItem it{0, row, 0, true};
+    if (row < nr) { const int64_t b = s_rp[2 * row], e = s_rp[2 * row + 1]; it.off = b; it.n = int(e - b < 32 ? e - b : 32); it.last = e - b <= 32; }
+    return it;
+  };
+  auto next_item = [&](const SpmvItem &c) -> SpmvItem {
+    if (c.row >= nr) return c;
+    if (!c.last) {
+      const int64_t e = s_rp[2 * c.row + 1], b = c.off + 32;
+      return SpmvItem{b, c.row, int(e - b < 32 ? e - b : 32), e - b <= 32};
+    }
+    return first_item(c.row + 8);
+  };
+  SpmvItem i0 = first_item(hw), i1 = next_item(i0), i2 = next_item(i1);
+  auto load_col = [&](const SpmvItem &it) -> int32_t { return (it.row < nr && lig < it.n) ? col[it.off + lig] : 0; };
+  struct Vals { double v[9]; };
+  auto load_val = [&](const SpmvItem &it) -> Vals {
+    Vals o;
+    const bool ok = it.row < nr && lig < it.n;
+    const double *b = val + (ok ? (it.off + lig) * 9 : 0);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { const double t = b[e]; o.v[e] = ok ? t : 0.0; }
+    return o;
+  };
+  struct X3 { double x[3]; };
+  auto load_x = [&](int32_t c) -> X3 { X3 o; const double *p = xu + int64_t(c) * 3; o.x[0] = p[0]; o.x[1] = p[1]; o.x[2] = p[2]; return o; };
+  // prologue: indices of items 0 and 1, values and x of item 0
+  int32_t c1 = load_col(i1);
+  Vals v0 = load_val(i0);
+  X3 x0 = load_x(load_col(i0));
+  double acc[3] = {0, 0, 0};
+  while (i0.row < nr) {
+    const int32_t c2 = load_col(i2);  // indices two items ahead
+    const Vals v1 = load_val(i1);     // values one item ahead
+    const X3 x1 = load_x(c1);         // x one item ahead (c1 was requested an iteration ago)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[r] += v0.v[r * 3 + j] * x0.x[j];
+    if (i0.last) { // the row is complete: sum over the half-wave, one lane stores
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) acc[r] += __shfl_xor(acc[r], off, 32);
+      }
+      if (lig == 0) {
+        const int64_t row = rows ? int64_t(rows[r0 + i0.row]) : r0 + i0.row;
+        yu[row * 3 + 0] = acc[0]; yu[row * 3 + 1] = acc[1]; yu[row * 3 + 2] = acc[2];
+      }
+      acc[0] = acc[1] = acc[2] = 0;
+    }
+    i0 = i1; i1 = i2; i2 = next_item(i2);
+    c1 = c2; v0 = v1; x0 = x1;
+  }
+}
+
+// y += M x (same layout and row lists as k_spmv_planar): the B^T x_p part of the outer operator behind k_spmv_uu_pipe (taking
+// the B^T row into the pipeline as a second kind of item was measured: 19.6 ms against 14.9 + 2.1)
+template <int BR, int BC, int G, class VT = double>
+__global__ __launch_bounds__(256) void k_spmv_planar_add(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                         const VT *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+                                                         const int32_t *__restrict__ rows = nullptr) {
+  const int64_t ridx = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  const int lig = threadIdx.x & (G - 1);
+  if (ridx >= n_rows) return;
+  const int64_t row = rows ? int64_t(rows[ridx]) : ridx;
+  double acc[BR];
+#pragma unroll
+  for (int r = 0; r < BR; ++r) acc[r] = 0;
+  const int64_t rs = rp[row];
+  const int len = int(rp[row + 1] - rs);
+  row_planar_dot<BR, BC, G, true, VT>(rs, len, col, val, x, lig, acc);
+#pragma unroll
+  for (int r = 0; r < BR; ++r) acc[r] = group_sum<G>(acc[r]);
+  if (lig == 0) {
+#pragma unroll
+    for (int r = 0; r < BR; ++r) y[row * BR + r] += acc[r];
+  }
+}
+
 // y = M x with BR x BC blocks, generic (B: 1 x DIM, B^T: DIM x 1, M_p / S_m: 1 x 1)
 template <int BR, int BC, int G, class VT = double>
 __global__ __launch_bounds__(256) void k_spmv_planar(int64_t n_rows, const int64_t *__restrict__ rp,
@@ -190,7 +291,15 @@ void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool
   const bool time_it = ctx->profile && xp == nullptr; // the A_uu-only launches of the inner solver: the dominant kernel
   if (use_f32) auu_f32_refresh(ctx);
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s));
-  if (ctx->dim == 3) {
+  if (ctx->dim == 3 && !use_f32 && IFEM_UU_INTERLEAVED && ctx->tune.spmv_pipe) {
+    const int rpb = 16; // rows per block = two per half-wave (measured at 128^3: 8 / 16 / 32 / 64 rows -> 14.4 / 14.4 / 15.1 / 16.0 ms)
+    const unsigned nb = unsigned((n + rpb - 1) / rpb);
+    hipLaunchKernelGGL(k_spmv_uu_pipe, dim3(nb), dim3(256), size_t(2 * rpb) * sizeof(int64_t), s, n, ctx->Auu.rowptr.p, ctx->Auu.col.p,
+                       ctx->Auu.val.p, xu, yu, rows, rpb);
+    if (xp && ctx->Bt.n_rows) // + B^T x_p on the same rows
+      hipLaunchKernelGGL((k_spmv_planar_add<3, 1, 8>), dim3(blocks_for_rows(n, 8)), dim3(256), 0, s, n, ctx->Bt.rowptr.p, ctx->Bt.col.p,
+                         ctx->Bt.val.p, xp, yu, rows);
+  } else if (ctx->dim == 3) {
     const int Gsel = ctx->tune.spmv_lanes;
 #define IFEM_SPMV3(G)                                                                                                  \
   if (use_f32)                                                                                                         \
