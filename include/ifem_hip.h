@@ -115,7 +115,8 @@ typedef struct {
   double  mp_rel, mp_abs;     /* CG(M_p) 1e-6, 1e-10 (mpi_insim.cpp:73-74) */
   double  sm_rel, sm_abs;     /* CG(S_m) 1e-3, 1e-10 (mpi_insim.cpp:88-89) */
   int32_t ainv_kind;          /* IFEM_AINV_* */
-  int32_t inner_restart, inner_maxit; /* IFEM_AINV_MG: inner_maxit <= 0 makes A~^-1 exactly one V-cycle (no inner Krylov loop) */
+  int32_t inner_restart, inner_maxit; /* IFEM_AINV_MG: inner_maxit = 0 makes A~^-1 exactly one V-cycle, -k makes it k
+                                         stationary V-cycle sweeps x += V(b - A x) (no inner Krylov loop in either case) */
   double  inner_rel;          /* relative residual target of the inner A_uu solve */
   int32_t explicit_schur;     /* 1: form S_m = B diag(M_u)^-1 B^T explicitly like the reference (on several GPUs this
                                  needs the 2-deep pressure halo plan of ifem_partition); 0: apply it as two SpMVs */

@@ -802,9 +802,19 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
       mg_uu_vcycle(Mu, 0);
       v_copy(c, S.nuo, c->mgu_vec[1].p, y);
     };
-    if (o->inner_maxit <= 0) { // A~^-1 := one V-cycle, no inner Krylov iteration (the outer solver is flexible)
+    if (o->inner_maxit == 0) { // A~^-1 := one V-cycle, no inner Krylov iteration (the outer solver is flexible)
       Vc(S.utmp, dst0);
       S.st.inner_iters += 1;
+    } else if (o->inner_maxit < 0) { // -k: k stationary V-cycle sweeps x += V(b - A x): no Arnoldi process, k - 1 operator products
+      const int k = -o->inner_maxit;
+      Vc(S.utmp, dst0);
+      for (int it = 1; it < k; ++it) {
+        Amf(dst0, S.inner_w);
+        v_axpby(c, S.nuo, 1.0, S.utmp, -1.0, S.inner_w); // r = b - A x
+        Vc(S.inner_w, S.inner_z);
+        v_axpy(c, S.nuo, 1.0, S.inner_z, dst0);
+      }
+      S.st.inner_iters += k;
     } else { // flexible GMRES: the preconditioned directions are kept, so the update needs no extra V-cycle
       const int64_t ld = basis_ld(S.ctx, S.nuo);
       const int mi = std::max(1, o->inner_restart);
