@@ -238,6 +238,9 @@ struct ifem_ctx {
   int64_t mg_mask_key[2] = {-1, -1};          // constrained-dof sets (flag ids of this level and the coarser one) of the masks
   ifem::DBuf<double> sm_dinv, mg_vec[6], mgu_vec[5];
   double sm_lmax = 0, uu_lmax = 0;
+  // last iterate of the two power iterations: the next estimate (new constrained-dof set, same mesh) starts from it
+  ifem::DBuf<double> sm_eig, uu_eig;
+  int64_t uu_lmax_asm = -1; // ifem_tuning::geo_cache = 2: the finest level's assembly the A_uu bound was last refreshed for
   int64_t asm_version = 0, uu_mg_version = -1; // full assemblies done / the assembly the A_uu V-cycle data belong to
   double uu_lmax_key[6] = {0, 0, 0, 0, 0, -1};  // (mu, rho, gamma, dt, noconv, constrained-dof set) of the cached eigenvalue bound
   int64_t sm_version = 0, sm_mg_version = -1; // S_m values rebuilt / the version the V-cycle data belong to

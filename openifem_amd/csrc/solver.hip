@@ -435,9 +435,13 @@ static void mg_sm_setup(MgSm &M, int use_nonzero) {
     if ((int64_t)c->sm_dinv.n != c->nPo) c->sm_dinv.alloc((size_t)c->nPo);
     scalar_diag(c, c->Sm, c->Sm.val.p, c->sm_dinv.p); // owned rows; the diagonal entry has a local column id on every layout
     vec_recip(c, S.npo, c->sm_dinv.p);
-    // largest eigenvalue of D^-1 S_m: power iteration from a fixed rough vector (set-up only: host-synchronised norms)
+    // largest eigenvalue of D^-1 S_m: power iteration (set-up only: host-synchronised norms) from a fixed rough vector, or --
+    // when S_m was re-formed for another constrained-dof set of the same mesh -- from the previous run's last iterate, then
+    // stopped once the estimate moves by less than 1 %
     double *x = c->mg_vec[1].p, *y = c->mg_vec[3].p;
-    vec_rough(c, S.npo, int64_t(c->halo.rank) * 1000003, x);
+    const bool warm = c->sm_lmax > 0 && (int64_t)c->sm_eig.n == S.npo && S.npo > 0;
+    if (warm) v_copy(c, S.npo, c->sm_eig.p, x);
+    else vec_rough(c, S.npo, int64_t(c->halo.rank) * 1000003, x);
     double lam = 0;
     for (int it = 0; it < 14; ++it) {
       double nx = v_dot(c, S.npo, x, x);
@@ -448,8 +452,14 @@ static void mg_sm_setup(MgSm &M, int use_nonzero) {
       vec_mul(c, S.npo, c->sm_dinv.p, y, y);
       double ny = v_dot(c, S.npo, y, y);
       allreduce_sum(c, &ny, 1);
+      const double prev = lam;
       lam = std::sqrt(ny);
       v_copy(c, S.npo, y, x);
+      if (warm && it >= 1 && std::fabs(lam - prev) <= 0.01 * lam) break;
+    }
+    if (S.npo > 0) {
+      if ((int64_t)c->sm_eig.n != S.npo) c->sm_eig.alloc((size_t)S.npo);
+      v_copy(c, S.npo, x, c->sm_eig.p);
     }
     c->sm_lmax = lam > 0 ? lam : 1.0;
     c->sm_mg_version = c->sm_version;
@@ -613,9 +623,16 @@ static void mg_uu_setup(MgUu &M) {
                            double(f0->mf_noconv), double(c->flag_id[c->asm_constraint_set])};
     bool same = c->uu_lmax > 0;
     for (int i = 0; i < 6; ++i) same = same && key[i] == c->uu_lmax_key[i];
+    if (c->tune.geo_cache == 2 && c->uu_lmax_asm != f0->asm_version) same = false; // measurement mode: a new set per assembly
+    c->uu_lmax_asm = f0->asm_version;
     if (same) continue;
+    // power iteration on B A_uu.  A level that has an estimate from another constrained-dof set starts from that run's last
+    // iterate and stops once the estimate moves by less than 1 % (the top of this spectrum belongs to the mesh, not to the
+    // set); the first estimate starts from a fixed rough vector and runs all 12 steps.
     double *x = c->mgu_vec[1].p, *y = c->mgu_vec[3].p, *z = c->mgu_vec[2].p;
-    vec_rough(c, S.nuo, int64_t(c->halo.rank) * 7000003, x);
+    const bool warm = c->uu_lmax > 0 && (int64_t)c->uu_eig.n == S.nuo && S.nuo > 0;
+    if (warm) v_copy(c, S.nuo, c->uu_eig.p, x);
+    else vec_rough(c, S.nuo, int64_t(c->halo.rank) * 7000003, x);
     double lam = 0;
     for (int it = 0; it < 12; ++it) {
       double nx = v_dot(c, S.nuo, x, x);
@@ -626,8 +643,14 @@ static void mg_uu_setup(MgUu &M) {
       bjac_apply(c, y, z);
       double nz = v_dot(c, S.nuo, z, z);
       allreduce_sum(c, &nz, 1);
+      const double prev = lam;
       lam = std::sqrt(nz);
       v_copy(c, S.nuo, z, x);
+      if (warm && it >= 1 && std::fabs(lam - prev) <= 0.01 * lam) break;
+    }
+    if (S.nuo > 0) {
+      if ((int64_t)c->uu_eig.n != S.nuo) c->uu_eig.alloc((size_t)S.nuo);
+      v_copy(c, S.nuo, x, c->uu_eig.p);
     }
     c->uu_lmax = lam > 0 ? lam : 1.0;
     for (int i = 0; i < 6; ++i) c->uu_lmax_key[i] = key[i];
