@@ -227,6 +227,11 @@ struct ifem_ctx {
   // constrained-dof set are masked copies of them instead of a re-integration (M_p and diag(M_u) do not depend on the set)
   ifem::DBuf<double> B0, Bt0;
   bool geo0_valid = false;
+  // S_m of the unconstrained blocks (same mesh-only idea): a constrained-dof set only changes the rows whose B row touches a
+  // constrained dof, so S_m of a new set = this copy with those rows recomputed (linalg.hip::schur_numeric)
+  ifem::DBuf<double> Sm0;
+  bool sm0_valid = false;
+  ifem::DBuf<int32_t> sm_rows;
   int64_t geo_refresh_stamp = -1; // a coarse multigrid level: the finest level's assembly its blocks were last refreshed for
   ifem::Hanging hang; // hanging-node lines (hanging.hip)
   // multigrid (ifem_mg_attach): the next coarser level (not owned) and the pressure transfers to it; per-level state of

@@ -11,6 +11,7 @@ void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, in
 void ensure_auu_values(ifem_ctx *ctx);
 void build_schur_pattern(ifem_ctx *ctx);
 void build_incidence(ifem_ctx *ctx);
+int64_t compact_flagged_rows(ifem_ctx *ctx, const int64_t *flag, int64_t n, DBuf<int32_t> &rows); // ascending list of the flagged rows
 void build_mf_cell_split(ifem_ctx *ctx); // several ranks: interior-first copy of the cell tables for the matrix-free apply
 
 // assemble.hip

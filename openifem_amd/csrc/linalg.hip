@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void k_schur_numeric(int64_t n_rows, int maxle
                                                        const int64_t *__restrict__ rpB, const int32_t *__restrict__ colB,
                                                        const double *__restrict__ valB, const int64_t *__restrict__ rpT,
                                                        const int32_t *__restrict__ colT, const double *__restrict__ valT,
-                                                       const double *__restrict__ dinv) {
+                                                       const double *__restrict__ dinv, const int32_t *__restrict__ rows) {
   extern __shared__ __align__(16) unsigned char smem_s[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // per wave: acc[maxlen] | bd[maxb][DIM] | ts[maxb] (int64) | hkey[hsize] | tlen[maxb] | hpos[hsize] (uint16)
@@ -573,8 +573,9 @@ __global__ __launch_bounds__(256) void k_schur_numeric(int64_t n_rows, int maxle
   uint16_t *hpos = reinterpret_cast<uint16_t *>(tll + maxb);
   // XCD-aware row order: neighbouring pressure rows (Morton order) read the same rows of B^T -- 27 pressure rows share
   // each -- so every XCD gets one contiguous range of rows and finds them in its own L2
-  const int64_t row = int64_t(xcd_swizzle(blockIdx.x, gridDim.x)) * 4 + wave;
-  const bool active = row < n_rows;
+  const int64_t ridx = int64_t(xcd_swizzle(blockIdx.x, gridDim.x)) * 4 + wave;
+  const bool active = ridx < n_rows;
+  const int64_t row = active ? (rows ? int64_t(rows[ridx]) : ridx) : 0; // a row list: n_rows counts its entries
   const int64_t rs = active ? rpS[row] : 0;
   const int len = active ? int(rpS[row + 1] - rs) : 0;
   const unsigned hmask = unsigned(hsize - 1);
@@ -659,32 +660,76 @@ __global__ __launch_bounds__(256) void k_schur_numeric(int64_t n_rows, int maxle
   for (int i = lane; i < len; i += 64) valS[rs + i] = acc[i];
 }
 
-void schur_numeric(ifem_ctx *ctx) {
-  if (ctx->sm_valid) return;
-  const int64_t n = ctx->Sm.n_rows;
-  if (n == 0) return;
+// rows of B with a constrained velocity dof among their columns (the rows of S_m a constrained-dof set changes)
+template <int DIM>
+__global__ void k_sm_row_flag(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                              const uint8_t *__restrict__ is_c, int64_t *__restrict__ flag) {
+  const int64_t row = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 5;
+  const int lig = threadIdx.x & 31;
+  if (row >= n_rows) return;
+  int v = 0; // 32 lanes per row: every lane looks at its share of the columns, then an OR over the half-wave
+  for (int64_t k = rp[row] + lig; k < rp[row + 1] && !v; k += 32) {
+    const int64_t nd = col[k];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) v |= is_c[nd * DIM + c];
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v |= __shfl_xor(v, off, 32);
+  if (lig == 0) flag[row] = v ? 1 : 0;
+}
+
+static void launch_schur(ifem_ctx *ctx, int64_t n_list, const int32_t *rows, const double *vB, const double *vT, double *out) {
   const int maxlen = (ctx->Sm.max_row + 1) & ~1, maxb = (ctx->B.max_row + 1) & ~1;
   int hsize = 64;
   while (hsize < 2 * maxlen) hsize *= 2;
   const size_t per_wave = size_t(maxlen) * 8 + size_t(maxb) * ctx->dim * 8 + size_t(maxb) * 8 + size_t(hsize) * 4 + size_t(maxb) * 4 + size_t(hsize) * 2;
   const size_t smem = 4 * ((per_wave + 15) & ~size_t(15));
   if (smem > 160 * 1024) throw Error(IFEM_E_BADPARAM, "explicit S_m: a pressure row is too long for the LDS row buffers");
-  const unsigned blocks = unsigned((n + 3) / 4);
+  const unsigned blocks = unsigned((n_list + 3) / 4);
   static bool attr_set[2] = {false, false};
   if (smem > 48 * 1024 && !attr_set[ctx->dim == 3]) {
     if (ctx->dim == 3) IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_schur_numeric<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     else IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_schur_numeric<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[ctx->dim == 3] = true;
   }
+  if (!n_list) return;
   if (ctx->dim == 3)
-    hipLaunchKernelGGL((k_schur_numeric<3>), dim3(blocks), dim3(256), smem, ctx->stream, n, maxlen, maxb, hsize, ctx->Sm.rowptr.p,
-                       ctx->Sm.col.p, ctx->Sm.val.p, ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, ctx->Bt.rowptr.p,
-                       ctx->Bt.col.p, ctx->Bt.val.p, ctx->dinvMu.p);
+    hipLaunchKernelGGL((k_schur_numeric<3>), dim3(blocks), dim3(256), smem, ctx->stream, n_list, maxlen, maxb, hsize, ctx->Sm.rowptr.p,
+                       ctx->Sm.col.p, out, ctx->B.rowptr.p, ctx->B.col.p, vB, ctx->Bt.rowptr.p, ctx->Bt.col.p, vT, ctx->dinvMu.p, rows);
   else
-    hipLaunchKernelGGL((k_schur_numeric<2>), dim3(blocks), dim3(256), smem, ctx->stream, n, maxlen, maxb, hsize, ctx->Sm.rowptr.p,
-                       ctx->Sm.col.p, ctx->Sm.val.p, ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, ctx->Bt.rowptr.p,
-                       ctx->Bt.col.p, ctx->Bt.val.p, ctx->dinvMu.p);
+    hipLaunchKernelGGL((k_schur_numeric<2>), dim3(blocks), dim3(256), smem, ctx->stream, n_list, maxlen, maxb, hsize, ctx->Sm.rowptr.p,
+                       ctx->Sm.col.p, out, ctx->B.rowptr.p, ctx->B.col.p, vB, ctx->Bt.rowptr.p, ctx->Bt.col.p, vT, ctx->dinvMu.p, rows);
   IFEM_HIP_CHECK(hipGetLastError());
+}
+
+void schur_numeric(ifem_ctx *ctx) {
+  if (ctx->sm_valid) return;
+  const int64_t n = ctx->Sm.n_rows;
+  if (n == 0) return;
+  hipStream_t s = ctx->stream;
+  // With the unconstrained blocks at hand (assemble.hip: B / B^T are masked copies of them) only the rows whose B row touches
+  // a constrained dof differ from the S_m of the unconstrained blocks: that one is formed once per mesh, a new set copies it
+  // and recomputes the touched rows (a few per cent of them on a box with Dirichlet walls).
+  const bool partial = ctx->tune.geo_cache >= 1 && ctx->geo0_valid && ctx->geo_valid && ctx->B0.n == ctx->B.val.n;
+  if (partial) {
+    if (!ctx->sm0_valid) {
+      if (ctx->Sm0.n != ctx->Sm.val.n) ctx->Sm0.alloc(ctx->Sm.val.n);
+      launch_schur(ctx, n, nullptr, ctx->B0.p, ctx->Bt0.p, ctx->Sm0.p);
+      ctx->sm0_valid = true;
+    }
+    IFEM_HIP_CHECK(hipMemcpyAsync(ctx->Sm.val.p, ctx->Sm0.p, ctx->Sm.val.n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    const int w = ctx->asm_constraint_set;
+    if (ctx->has_c[w]) {
+      DBuf<int64_t> flag;
+      flag.alloc(n);
+      const unsigned g = unsigned((n * 32 + 255) / 256);
+      if (ctx->dim == 3) hipLaunchKernelGGL((k_sm_row_flag<3>), dim3(g), dim3(256), 0, s, n, ctx->B.rowptr.p, ctx->B.col.p, ctx->is_c[w].p, flag.p);
+      else hipLaunchKernelGGL((k_sm_row_flag<2>), dim3(g), dim3(256), 0, s, n, ctx->B.rowptr.p, ctx->B.col.p, ctx->is_c[w].p, flag.p);
+      const int64_t cnt = compact_flagged_rows(ctx, flag.p, n, ctx->sm_rows);
+      launch_schur(ctx, cnt, ctx->sm_rows.p, ctx->B.val.p, ctx->Bt.val.p, ctx->Sm.val.p);
+    }
+  } else
+    launch_schur(ctx, n, nullptr, ctx->B.val.p, ctx->Bt.val.p, ctx->Sm.val.p);
   ctx->sm_valid = true;
   ctx->sm_f32_valid = false;
   ctx->sm_version++;

@@ -202,6 +202,32 @@ void build_row_split(ifem_ctx *ctx, PlanarCsr &M, int64_t n_owned_cols, const Pl
   IFEM_HIP_CHECK(hipGetLastError());
 }
 
+// ---- list of the rows i with flag[i] != 0 (ascending); returns their number
+__global__ void k_row_pick(int64_t n_rows, const int64_t *__restrict__ flag, const int64_t *__restrict__ before, int32_t *__restrict__ rows) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x)
+    if (flag[r]) rows[before[r]] = int32_t(r);
+}
+int64_t compact_flagged_rows(ifem_ctx *ctx, const int64_t *flag, int64_t n, DBuf<int32_t> &rows) {
+  if (n == 0) return 0;
+  hipStream_t s = ctx->stream;
+  DBuf<int64_t> before;
+  before.alloc(n);
+  size_t tb = 0;
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, flag, before.p, int64_t(0), (size_t)n, rocprim::plus<int64_t>(), s));
+  DBuf<char> tmp;
+  tmp.alloc(tb + 16);
+  IFEM_HIP_CHECK(rocprim::exclusive_scan(tmp.p, tb, flag, before.p, int64_t(0), (size_t)n, rocprim::plus<int64_t>(), s));
+  int64_t lb = 0, lf = 0;
+  IFEM_HIP_CHECK(hipMemcpyAsync(&lb, before.p + (n - 1), 8, hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipMemcpyAsync(&lf, flag + (n - 1), 8, hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  const int64_t cnt = lb + lf;
+  if ((int64_t)rows.n < cnt) rows.alloc((size_t)cnt);
+  if (cnt) hipLaunchKernelGGL(k_row_pick, dim3(grid_for(n)), dim3(256), 0, s, n, flag, before.p, rows.p);
+  IFEM_HIP_CHECK(hipStreamSynchronize(s)); // `before` leaves scope
+  return cnt;
+}
+
 // ---- mass_schur(1,1) pattern (compute_mmult_pattern(B, B^T), mpi_fluid_solver.cpp:326-329).  For the Q1 pressure space
 // pattern(B B^T) = pattern(M_p^2): p-nodes i, j couple iff cells c1 with i and c2 with j share a vertex.
 __global__ void k_sq_count(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
