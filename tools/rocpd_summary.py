@@ -49,11 +49,13 @@ def main(db_path, prefix):
                 g.setdefault((name, grid), []).append(dur)
             with open(prefix + "_by_grid.csv", "w", newline="") as f:
                 w = csv.writer(f)
-                w.writerow(["kernel", "grid", "calls", "total_ms", "avg_ms"])
+                w.writerow(["kernel", "grid", "calls", "total_ms", "avg_ms", "median_ms", "min_ms", "max_ms"])
                 for (name, grid), d in sorted(g.items(), key=lambda kv: -sum(kv[1])):
                     if sum(d) / 1e6 < 0.5:
                         continue
-                    w.writerow([short(name)[:90], grid, len(d), f"{sum(d) / 1e6:.3f}", f"{sum(d) / len(d) / 1e6:.4f}"])
+                    ds = sorted(d)
+                    w.writerow([short(name)[:90], grid, len(d), f"{sum(d) / 1e6:.3f}", f"{sum(d) / len(d) / 1e6:.4f}",
+                                f"{ds[len(ds) // 2] / 1e6:.4f}", f"{ds[0] / 1e6:.4f}", f"{ds[-1] / 1e6:.4f}"])
     except sqlite3.Error as e:
         print("no per-grid view:", e)
     try:
