@@ -161,6 +161,31 @@ int32_t orc_scns_run_one_step(orc_system *s, const orc_scns_params *p, int32_t a
  * projection of 2 mu sym(grad u) from the quadrature points to the Q_kv nodes */
 void orc_update_stress(const orc_mesh *m, double mu, const double *present, double *stress /*[dim][dim][n_unodes]*/);
 
+/* ---- fluid-side inputs of MPI::FSI (source/mpi_fsi.cpp:96-127,142-223,291-663), oracle_fsi.c ----------------------------
+ * The solid is a Q1 mesh (parameters "Degree = 1" in every FSI test) at its CURRENT position (move_solid_mesh(true)), with
+ * the localized nodal fields the reference gathers on every rank (:350-362). */
+typedef struct {
+  int32_t dim, n_vertices, n_cells, n_bfaces;
+  const double  *vertices;       /* [n_vertices][dim] */
+  const int32_t *cell_vertices;  /* [n_cells][2^dim] lexicographic vertex order */
+  const int32_t *bface_vertices; /* dim 2: [n_bfaces][2] solid_boundaries (collect_solid_boundaries :78-94); dim 3: unused */
+  const double *velocity, *acceleration; /* [n_vertices][dim] */
+  const double *stress;          /* [dim(dim+1)/2][n_vertices], component order (0,0),(1,0),(1,1),(2,0).. (:459-474); or NULL */
+} orc_fsi_solid;
+void orc_fsi_solid_box(const orc_fsi_solid *s, double *box /* [2*dim] lo,hi per direction */);
+int32_t orc_fsi_point_in_solid(const orc_fsi_solid *s, const double *box, const double *point);
+int32_t orc_fsi_real_to_unit(int32_t dim, const double *X, const double *p, double *xi);
+/* the solid cell around p and the (projected) unit-cell point, or -1 */
+int32_t orc_fsi_locate(const orc_fsi_solid *s, const double *p, double *xi);
+void orc_fsi_update_indicator(const orc_mesh *m, const orc_fsi_solid *s, int32_t *indicator);
+/* FSI::find_fluid_bc on one rank.  m->indicator = result of update_indicator.  fluid_stress [dim][dim][n_unodes] (may be
+ * NULL = 0); fsi_stress [ncomp][n_unodes] is updated in place where the reference assigns it; fsi_acc [n_dofs] is
+ * overwritten; use_dirichlet_bc: line_flag / line_val [dim*n_unodes] receive the proposed lines BEFORE the merge with
+ * left_object_wins (:641-651).  Returns the number of points the cell search failed on (the reference throws). */
+int32_t orc_fsi_find_fluid_bc(const orc_mesh *m, const orc_fsi_solid *s, double dt, int32_t use_dirichlet_bc,
+                              const double *present, const double *fluid_stress, double *fsi_stress, double *fsi_acc,
+                              int32_t *line_flag, double *line_val);
+
 /* FE tables for cross-checks: phi[q][a], dphi[q][a][dim] on the reference cell, weights */
 int32_t orc_fe_tables(int32_t dim, int32_t k, int32_t nq1d, double *phi, double *dphi, double *w, double *qp);
 

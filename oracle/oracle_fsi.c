@@ -1,0 +1,390 @@
+/*
+ * oracle/oracle_fsi.c -- CPU restatement of the fluid-side inputs MPI::FSI produces before every fluid step
+ * (SURVEY 8 row f3).  TEST INFRASTRUCTURE, NOT PRODUCT CODE: see the header of oracle.h for who may load it.
+ *
+ * What it restates (reference = /root/reference):
+ *   orc_fsi_solid_box         source/mpi_fsi.cpp:96-127   FSI::update_solid_box
+ *   orc_fsi_point_in_solid    source/mpi_fsi.cpp:142-223  FSI::point_in_solid (dim 2: crossing number over the solid boundary
+ *                                                          faces, literally; dim 3: CellAccessor::point_inside of every cell)
+ *   orc_fsi_locate            source/utilities.cpp:193-244 Utils::GridInterpolator (ctor + point_value) and :295-341
+ *                                                          Utils::CellLocator::search: "the solid cell around the point" + its
+ *                                                          unit-cell coordinates
+ *   orc_fsi_update_indicator  source/mpi_fsi.cpp:291-319  FSI::update_indicator
+ *   orc_fsi_find_fluid_bc     source/mpi_fsi.cpp:323-663  FSI::find_fluid_bc: nodal fsi_stress (:415-480), fsi_acceleration
+ *                                                          (:489-556), Dirichlet lines of the artificial fluid (:569-640)
+ *
+ * Third-party arithmetic restated because deal.II is not under /root/reference: CellAccessor<3>::point_inside (vertex
+ * bounding box, then MappingQ1::transform_real_to_unit_cell and GeometryInfo::is_inside_unit_cell), GeometryInfo::
+ * distance_to_unit_cell / project_to_unit_cell, GridTools::find_active_cell_around_point (a cell whose unit-cell image of the
+ * point lies within 1e-10 of the unit cell; the smallest distance wins).  The BFS from a hint cell of CellLocator is a search
+ * strategy, not a result: any cell that contains the point gives the same interpolated value because the solid field is
+ * continuous; the restatement takes the lowest-numbered cell of smallest distance.
+ *
+ * Parity pinning: the reference holds no golden vector for these functions (its FSI tests assert end-of-run solid
+ * displacements).  They are pinned by properties in tests/test_oracle_fsi.py: the crossing-number test against the analytic
+ * inside test of convex and non-convex polygons, the interpolation against fields that Q1 reproduces exactly (d-linear),
+ * the unit-cell inversion against the forward map.  "parity unpinned" against reference artefacts, as oracle.h says for
+ * element matrices.
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static int nvert(int dim) { return 1 << dim; }
+
+void orc_fsi_solid_box(const orc_fsi_solid *s, double *box) {
+  const int dim = s->dim;
+  for (int i = 0; i < dim; ++i) box[2 * i] = box[2 * i + 1] = s->vertices[i];
+  for (int32_t v = 0; v < s->n_vertices; ++v)
+    for (int i = 0; i < dim; ++i) {
+      const double x = s->vertices[(size_t)v * dim + i];
+      if (x < box[2 * i]) box[2 * i] = x;
+      else if (x > box[2 * i + 1]) box[2 * i + 1] = x;
+    }
+}
+
+/* d-linear shape functions of the unit cell, lexicographic vertex order */
+static void q1_shape(int dim, const double *xi, double *N, double *dN /* [v][dim] or NULL */) {
+  const int nv = nvert(dim);
+  for (int v = 0; v < nv; ++v) {
+    double val = 1.0;
+    for (int d = 0; d < dim; ++d) val *= ((v >> d) & 1) ? xi[d] : 1.0 - xi[d];
+    N[v] = val;
+    if (dN)
+      for (int e = 0; e < dim; ++e) {
+        double g = 1.0;
+        for (int d = 0; d < dim; ++d) {
+          const int hi = (v >> d) & 1;
+          g *= d == e ? (hi ? 1.0 : -1.0) : (hi ? xi[d] : 1.0 - xi[d]);
+        }
+        dN[v * dim + e] = g;
+      }
+  }
+}
+
+static double det_inv(int dim, const double *J, double *Ji) {
+  if (dim == 2) {
+    const double det = J[0] * J[3] - J[1] * J[2];
+    Ji[0] = J[3] / det; Ji[1] = -J[1] / det; Ji[2] = -J[2] / det; Ji[3] = J[0] / det;
+    return det;
+  }
+  const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+  const double det = J[0] * c00 + J[1] * c01 + J[2] * c02;
+  Ji[0] = c00 / det; Ji[1] = (J[2] * J[7] - J[1] * J[8]) / det; Ji[2] = (J[1] * J[5] - J[2] * J[4]) / det;
+  Ji[3] = c01 / det; Ji[4] = (J[0] * J[8] - J[2] * J[6]) / det; Ji[5] = (J[2] * J[3] - J[0] * J[5]) / det;
+  Ji[6] = c02 / det; Ji[7] = (J[1] * J[6] - J[0] * J[7]) / det; Ji[8] = (J[0] * J[4] - J[1] * J[3]) / det;
+  return det;
+}
+
+/* MappingQ1::transform_real_to_unit_cell: Newton on x(xi) = p from the cell centre; 0 when it fails
+ * (Mapping::ExcTransformationFailed) */
+int32_t orc_fsi_real_to_unit(int32_t dim, const double *X /* [2^dim][dim] */, const double *p, double *xi) {
+  const int nv = nvert(dim);
+  double N[8], dN[24], J[9], Ji[9], F[3];
+  for (int d = 0; d < dim; ++d) xi[d] = 0.5;
+  for (int it = 0; it < 30; ++it) {
+    q1_shape(dim, xi, N, dN);
+    for (int c = 0; c < dim; ++c) {
+      double x = 0;
+      for (int v = 0; v < nv; ++v) x += N[v] * X[v * dim + c];
+      F[c] = x - p[c];
+      for (int e = 0; e < dim; ++e) {
+        double g = 0;
+        for (int v = 0; v < nv; ++v) g += dN[v * dim + e] * X[v * dim + c];
+        J[c * dim + e] = g;
+      }
+    }
+    const double det = det_inv(dim, J, Ji);
+    if (!(fabs(det) > 0)) return 0;
+    double step = 0;
+    for (int e = 0; e < dim; ++e) {
+      double dx = 0;
+      for (int c = 0; c < dim; ++c) dx += Ji[e * dim + c] * F[c];
+      xi[e] -= dx;
+      if (fabs(dx) > step) step = fabs(dx);
+      if (!(fabs(xi[e]) < 1e3)) return 0;
+    }
+    if (step < 1e-15) return 1;
+  }
+  return 1; /* stagnates at rounding level on distorted cells: the last iterate is the answer */
+}
+
+static void cell_vertices(const orc_fsi_solid *s, int32_t c, double *X) {
+  const int dim = s->dim, nv = nvert(dim);
+  for (int v = 0; v < nv; ++v)
+    for (int d = 0; d < dim; ++d) X[v * dim + d] = s->vertices[(size_t)s->cell_vertices[(size_t)c * nv + v] * dim + d];
+}
+
+/* CellAccessor<3>::point_inside: vertex bounding box, then the unit-cell image inside [0,1]^3 exactly */
+static int point_inside3(const orc_fsi_solid *s, int32_t c, const double *p) {
+  double X[24], xi[3];
+  cell_vertices(s, c, X);
+  for (int d = 0; d < 3; ++d) {
+    double lo = X[d], hi = X[d];
+    for (int v = 1; v < 8; ++v) {
+      if (X[v * 3 + d] < lo) lo = X[v * 3 + d];
+      if (X[v * 3 + d] > hi) hi = X[v * 3 + d];
+    }
+    if (p[d] < lo || p[d] > hi) return 0;
+  }
+  if (!orc_fsi_real_to_unit(3, X, p, xi)) return 0;
+  for (int d = 0; d < 3; ++d)
+    if (xi[d] < 0.0 || xi[d] > 1.0) return 0;
+  return 1;
+}
+
+int32_t orc_fsi_point_in_solid(const orc_fsi_solid *s, const double *box, const double *point) {
+  const int dim = s->dim;
+  for (int i = 0; i < dim; ++i)
+    if (point[i] < box[2 * i] || point[i] > box[2 * i + 1]) return 0; /* :147-151 */
+  if (dim == 2) { /* :154-213, statement by statement */
+    unsigned cross_number = 0, half_cross_number = 0;
+    for (int32_t f = 0; f < s->n_bfaces; ++f) {
+      const double *p1 = s->vertices + (size_t)s->bface_vertices[2 * f] * 2, *p2 = s->vertices + (size_t)s->bface_vertices[2 * f + 1] * 2;
+      const double y_diff1 = p1[1] - point[1], y_diff2 = p2[1] - point[1];
+      const double x_diff1 = p1[0] - point[0], x_diff2 = p2[0] - point[0];
+      const double r1[2] = {p1[0] - p2[0], p1[1] - p2[1]};
+      double r2[2] = {0.0, 0.0};
+      if (r1[1] != 0.0) {
+        r2[0] = r1[0] * (point[1] - p2[1]) / r1[1];
+        r2[1] = r1[1] * (point[1] - p2[1]) / r1[1];
+      }
+      if (y_diff1 * y_diff2 < 0) {
+        if (r2[0] + p2[0] > point[0]) ++cross_number;
+        else if (r2[0] + p2[0] == point[0]) return 1;
+      } else if (y_diff1 * y_diff2 == 0) {
+        if (y_diff1 == 0 && y_diff2 == 0) {
+          if (x_diff1 * x_diff2 < 0) return 1;
+          else continue;
+        } else if (r2[0] + p2[0] > point[0]) {
+          if (point[1] != box[2] && point[1] != box[3]) ++half_cross_number;
+        } else if ((point[0] == p1[0] && point[1] == p1[1]) || (point[0] == p2[0] && point[1] == p2[1]))
+          return 1;
+      }
+    }
+    cross_number += half_cross_number / 2;
+    return cross_number % 2 == 0 ? 0 : 1;
+  }
+  for (int32_t c = 0; c < s->n_cells; ++c) /* :215-222 */
+    if (point_inside3(s, c, point)) return 1;
+  return 0;
+}
+
+/* GeometryInfo::distance_to_unit_cell */
+static double dist_unit(int dim, const double *xi) {
+  double r = 0.0;
+  for (int d = 0; d < dim; ++d) {
+    if (-xi[d] > r) r = -xi[d];
+    else if (xi[d] - 1.0 > r) r = xi[d] - 1.0;
+  }
+  return r;
+}
+
+int32_t orc_fsi_locate(const orc_fsi_solid *s, const double *p, double *xi_out) {
+  const int dim = s->dim, nv = nvert(dim);
+  int32_t best = -1;
+  double best_d = 1e300, X[24], xi[3];
+  for (int32_t c = 0; c < s->n_cells; ++c) {
+    cell_vertices(s, c, X);
+    int out = 0;
+    double ext = 0;
+    double lo[3], hi[3];
+    for (int d = 0; d < dim; ++d) {
+      lo[d] = hi[d] = X[d];
+      for (int v = 1; v < nv; ++v) {
+        if (X[v * dim + d] < lo[d]) lo[d] = X[v * dim + d];
+        if (X[v * dim + d] > hi[d]) hi[d] = X[v * dim + d];
+      }
+      if (hi[d] - lo[d] > ext) ext = hi[d] - lo[d];
+    }
+    for (int d = 0; d < dim; ++d)
+      if (p[d] < lo[d] - 1e-9 * ext || p[d] > hi[d] + 1e-9 * ext) out = 1;
+    if (out || !orc_fsi_real_to_unit(dim, X, p, xi)) continue;
+    const double dd = dist_unit(dim, xi);
+    if (dd < best_d) {
+      best_d = dd;
+      best = c;
+      for (int d = 0; d < dim; ++d) xi_out[d] = xi[d];
+    }
+  }
+  if (best < 0 || !(best_d < 1e-10)) return -1;
+  for (int d = 0; d < dim; ++d) xi_out[d] = xi_out[d] < 0.0 ? 0.0 : (xi_out[d] > 1.0 ? 1.0 : xi_out[d]); /* project_to_unit_cell */
+  return best;
+}
+
+/* point_value of a vertex field with `nc` interleaved components (stride per vertex = vstride, component offset = 1) */
+static void interp(const orc_fsi_solid *s, int32_t cell, const double *xi, const double *field, int nc, int vstride, double *out) {
+  const int dim = s->dim, nv = nvert(dim);
+  double N[8];
+  q1_shape(dim, xi, N, NULL);
+  for (int c = 0; c < nc; ++c) {
+    double a = 0;
+    for (int v = 0; v < nv; ++v) a += N[v] * field[(size_t)s->cell_vertices[(size_t)cell * nv + v] * vstride + c];
+    out[c] = a;
+  }
+}
+
+void orc_fsi_update_indicator(const orc_mesh *m, const orc_fsi_solid *s, int32_t *indicator) {
+  const int dim = m->dim, nv = nvert(dim);
+  double box[6];
+  orc_fsi_solid_box(s, box);
+  for (int32_t c = 0; c < m->n_cells; ++c) {
+    int inside_count = 0;
+    for (int v = 0; v < nv; ++v) {
+      if (!orc_fsi_point_in_solid(s, box, m->vcoords + ((size_t)c * nv + v) * dim)) break;
+      ++inside_count;
+    }
+    indicator[c] = inside_count == nv ? 1 : 0;
+  }
+}
+
+/* 1D Lagrange basis on the kv+1 equidistant nodes of [0,1] and its derivative */
+static void lagrange(int kv, double x, double *L, double *dL) {
+  if (kv == 1) {
+    L[0] = 1 - x; L[1] = x;
+    dL[0] = -1; dL[1] = 1;
+  } else {
+    L[0] = 2 * (x - 0.5) * (x - 1); L[1] = -4 * x * (x - 1); L[2] = 2 * x * (x - 0.5);
+    dL[0] = 4 * x - 3; dL[1] = -8 * x + 4; dL[2] = 4 * x - 1;
+  }
+}
+
+/* support point a of fluid cell c in real space (MappingQGeneric of the d-linear cell) and the unit point */
+static void support_point(const orc_mesh *m, int32_t c, int a, double *xi, double *x) {
+  const int dim = m->dim, nv = nvert(dim), n1 = m->kv + 1;
+  double N[8];
+  int r = a;
+  for (int d = 0; d < dim; ++d) {
+    xi[d] = (double)(r % n1) / m->kv;
+    r /= n1;
+  }
+  q1_shape(dim, xi, N, NULL);
+  for (int d = 0; d < dim; ++d) {
+    double v = 0;
+    for (int k = 0; k < nv; ++k) v += N[k] * m->vcoords[((size_t)c * nv + k) * dim + d];
+    x[d] = v;
+  }
+}
+
+/* grad_v[c][e] = d v_c / d x_e of the fluid velocity at unit point xi of cell `cell` */
+static void fluid_grad(const orc_mesh *m, int32_t cell, const double *xi, const double *present, double *grad) {
+  const int dim = m->dim, nv = nvert(dim), n1 = m->kv + 1;
+  int nu = 1;
+  for (int d = 0; d < dim; ++d) nu *= n1;
+  double N[8], dN[24], J[9], Ji[9], L[3][3], dL[3][3];
+  q1_shape(dim, xi, N, dN);
+  for (int c = 0; c < dim; ++c)
+    for (int e = 0; e < dim; ++e) {
+      double g = 0;
+      for (int v = 0; v < nv; ++v) g += dN[v * dim + e] * m->vcoords[((size_t)cell * nv + v) * dim + c];
+      J[c * dim + e] = g;
+    }
+  det_inv(dim, J, Ji);
+  for (int d = 0; d < dim; ++d) lagrange(m->kv, xi[d], L[d], dL[d]);
+  double gref[9] = {0};
+  for (int b = 0; b < nu; ++b) {
+    int idx[3], r = b;
+    for (int d = 0; d < dim; ++d) { idx[d] = r % n1; r /= n1; }
+    const int32_t node = m->cell_unodes[(size_t)cell * nu + b];
+    for (int e = 0; e < dim; ++e) {
+      double g = 1;
+      for (int d = 0; d < dim; ++d) g *= d == e ? dL[d][idx[d]] : L[d][idx[d]];
+      for (int c = 0; c < dim; ++c) gref[c * dim + e] += g * present[(size_t)dim * node + c];
+    }
+  }
+  for (int c = 0; c < dim; ++c)
+    for (int e = 0; e < dim; ++e) {
+      double g = 0;
+      for (int k = 0; k < dim; ++k) g += gref[c * dim + k] * Ji[k * dim + e];
+      grad[c * dim + e] = g;
+    }
+}
+
+int32_t orc_fsi_find_fluid_bc(const orc_mesh *m, const orc_fsi_solid *s, double dt, int32_t use_dirichlet_bc,
+                              const double *present, const double *fluid_stress, double *fsi_stress, double *fsi_acc,
+                              int32_t *line_flag, double *line_val) {
+  const int dim = m->dim, n1 = m->kv + 1;
+  int nu = 1;
+  for (int d = 0; d < dim; ++d) nu *= n1;
+  const int32_t N = m->n_unodes;
+  double box[6];
+  orc_fsi_solid_box(s, box);
+  int32_t not_found = 0;
+  unsigned char *touched = (unsigned char *)calloc((size_t)N, 1);
+  /* nodal fsi_stress on the scalar Q_kv space (:415-480): owned indicator cells, first touch per node */
+  if (s->stress && fsi_stress)
+    for (int32_t c = 0; c < m->n_cells; ++c) {
+      if (!m->indicator || m->indicator[c] == 0) continue;
+      for (int a = 0; a < nu; ++a) {
+        const int32_t node = m->cell_unodes[(size_t)c * nu + a];
+        if (touched[node]) continue;
+        touched[node] = 1;
+        double xi[3], x[3], sxi[3];
+        support_point(m, c, a, xi, x);
+        if (!orc_fsi_point_in_solid(s, box, x)) continue;
+        const int32_t sc = orc_fsi_locate(s, x, sxi); /* GridInterpolator without hint; point_value = 0 if no cell */
+        int idx = 0;
+        for (int j = 0; j < dim; ++j)
+          for (int k = 0; k < j + 1; ++k) {
+            double sv = 0;
+            if (sc >= 0) interp(s, sc, sxi, s->stress + (size_t)idx * s->n_vertices, 1, 1, &sv);
+            const double fl = fluid_stress ? fluid_stress[((size_t)j * dim + k) * N + node] : 0.0;
+            fsi_stress[(size_t)idx * N + node] = fl - sv;
+            ++idx;
+          }
+      }
+    }
+  memset(touched, 0, (size_t)N);
+  memset(fsi_acc, 0, sizeof(double) * ((size_t)dim * N + m->n_pnodes)); /* tmp_fsi_acceleration is a fresh vector (:348-350) */
+  if (line_flag) memset(line_flag, 0, sizeof(int32_t) * (size_t)dim * N);
+  for (int32_t c = 0; c < m->n_cells; ++c) {
+    if (!use_dirichlet_bc) { /* :489-556 */
+      if (!m->indicator || m->indicator[c] == 0) continue;
+      for (int a = 0; a < nu; ++a) {
+        const int32_t node = m->cell_unodes[(size_t)c * nu + a];
+        if (touched[node]) continue;
+        touched[node] = 1;
+        double xi[3], x[3], sxi[3], vs[3], as[3], grad[9];
+        support_point(m, c, a, xi, x);
+        if (!orc_fsi_point_in_solid(s, box, x)) continue;
+        const int32_t sc = orc_fsi_locate(s, x, sxi);
+        if (sc < 0) { ++not_found; continue; } /* AssertThrow "Cannot find point in solid" (:526-533) */
+        interp(s, sc, sxi, s->acceleration, dim, dim, as);
+        interp(s, sc, sxi, s->velocity, dim, dim, vs);
+        fluid_grad(m, c, xi, present, grad);
+        for (int i = 0; i < dim; ++i) {
+          double conv = 0;
+          for (int e = 0; e < dim; ++e) conv += grad[i * dim + e] * present[(size_t)dim * node + e];
+          const double fluid_acc = (vs[i] - present[(size_t)dim * node + i]) / dt + conv;
+          fsi_acc[(size_t)dim * node + i] = fluid_acc - as[i];
+        }
+      }
+    } else { /* :569-640 */
+      for (int a = 0; a < nu; ++a) {
+        const int32_t node = m->cell_unodes[(size_t)c * nu + a];
+        if (touched[node]) continue;
+        int inside_dim_count = 0, r = a;
+        for (int d = 0; d < dim; ++d) {
+          const int i1 = r % n1;
+          r /= n1;
+          if (i1 > 0 && i1 < m->kv) ++inside_dim_count;
+        }
+        if (inside_dim_count == dim) continue; /* in-cell support point */
+        touched[node] = 1;
+        double xi[3], x[3], sxi[3], vs[3];
+        support_point(m, c, a, xi, x);
+        if (!orc_fsi_point_in_solid(s, box, x)) continue;
+        const int32_t sc = orc_fsi_locate(s, x, sxi);
+        if (sc < 0) { ++not_found; continue; }
+        interp(s, sc, sxi, s->velocity, dim, dim, vs);
+        for (int i = 0; i < dim; ++i) {
+          line_flag[(size_t)dim * node + i] = 1;
+          line_val[(size_t)dim * node + i] = vs[i] - present[(size_t)dim * node + i];
+        }
+      }
+    }
+  }
+  free(touched);
+  return not_found;
+}

@@ -35,6 +35,12 @@ class ScnsParams(C.Structure):
                 ("formulation", C.c_int32)]
 
 
+class _Solid(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("n_vertices", C.c_int32), ("n_cells", C.c_int32), ("n_bfaces", C.c_int32),
+                ("vertices", C.c_void_p), ("cell_vertices", C.c_void_p), ("bface_vertices", C.c_void_p),
+                ("velocity", C.c_void_p), ("acceleration", C.c_void_p), ("stress", C.c_void_p)]
+
+
 FULL_SOLVE = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double),
                          C.POINTER(C.c_double), C.POINTER(C.c_double))
 
@@ -91,6 +97,17 @@ def _bind(L):
     L.orc_scns_run_one_step.argtypes = [C.c_void_p, C.POINTER(ScnsParams), C.c_int32, C.c_double, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_update_stress.argtypes = [C.POINTER(_Mesh), C.c_double, C.c_void_p, C.c_void_p]
+    L.orc_fsi_solid_box.argtypes = [C.POINTER(_Solid), C.c_void_p]
+    L.orc_fsi_point_in_solid.restype = C.c_int32
+    L.orc_fsi_point_in_solid.argtypes = [C.POINTER(_Solid), C.c_void_p, C.c_void_p]
+    L.orc_fsi_real_to_unit.restype = C.c_int32
+    L.orc_fsi_real_to_unit.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_fsi_locate.restype = C.c_int32
+    L.orc_fsi_locate.argtypes = [C.POINTER(_Solid), C.c_void_p, C.c_void_p]
+    L.orc_fsi_update_indicator.argtypes = [C.POINTER(_Mesh), C.POINTER(_Solid), C.c_void_p]
+    L.orc_fsi_find_fluid_bc.restype = C.c_int32
+    L.orc_fsi_find_fluid_bc.argtypes = [C.POINTER(_Mesh), C.POINTER(_Solid), C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_fe_tables.restype = C.c_int32
     L.orc_fe_tables.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
@@ -283,3 +300,69 @@ class System:
         v = np.ascontiguousarray(v, float)
         self.L.orc_precond_vmult(self.h, C.byref(params), C.byref(self.opts), cb, None, _ptr(v), _ptr(z))
         return z
+
+
+class FsiSolid:
+    """the solid as MPI::FSI sees it on every rank (tests/solidmesh.py objects): oracle_fsi.c"""
+
+    def __init__(self, solid):
+        self.L = lib()
+        dim = solid.dim
+        self._keep = [np.ascontiguousarray(solid.vertices, float), np.ascontiguousarray(solid.cells, np.int32),
+                      None if dim == 3 else np.ascontiguousarray(solid.bfaces, np.int32),
+                      np.ascontiguousarray(solid.velocity, float), np.ascontiguousarray(solid.acceleration, float),
+                      None if solid.stress is None else np.ascontiguousarray(solid.stress, float)]
+        self.dim = dim
+        self.c = _Solid(dim, len(self._keep[0]), len(self._keep[1]), 0 if dim == 3 else len(self._keep[2]),
+                        *[_ptr(a) for a in self._keep])
+
+    def box(self):
+        b = np.zeros(2 * self.dim)
+        self.L.orc_fsi_solid_box(C.byref(self.c), _ptr(b))
+        return b
+
+    def point_in_solid(self, pts):
+        pts = np.ascontiguousarray(pts, float).reshape(-1, self.dim)
+        b = self.box()
+        return np.array([self.L.orc_fsi_point_in_solid(C.byref(self.c), _ptr(b), _ptr(p)) for p in pts], bool)
+
+    def locate(self, pts):
+        pts = np.ascontiguousarray(pts, float).reshape(-1, self.dim)
+        cells, xi = np.zeros(len(pts), np.int32), np.zeros((len(pts), self.dim))
+        for i, p in enumerate(pts):
+            cells[i] = self.L.orc_fsi_locate(C.byref(self.c), _ptr(p), _ptr(xi[i]))
+        return cells, xi
+
+
+def _cmesh(mesh, indicator=None):
+    keep = [np.ascontiguousarray(mesh.vcoords, float), np.ascontiguousarray(mesh.cell_unodes, np.int32),
+            np.ascontiguousarray(mesh.cell_pnodes, np.int32), np.ascontiguousarray(mesh.cell_face_bid, np.int32),
+            None if indicator is None else np.ascontiguousarray(indicator, np.int32)]
+    m = _Mesh(mesh.dim, mesh.kv, mesh.n_cells, mesh.n_unodes, mesh.n_pnodes, *[_ptr(a) for a in keep])
+    m._keep = keep
+    return m
+
+
+def fsi_update_indicator(mesh, solid):
+    """FSI::update_indicator (mpi_fsi.cpp:291-319) -> int32 [n_cells]"""
+    S = solid if isinstance(solid, FsiSolid) else FsiSolid(solid)
+    m = _cmesh(mesh)
+    out = np.zeros(mesh.n_cells, np.int32)
+    S.L.orc_fsi_update_indicator(C.byref(m), C.byref(S.c), _ptr(out))
+    return out
+
+
+def fsi_find_fluid_bc(mesh, solid, indicator, dt, use_dirichlet_bc, present, fluid_stress, fsi_stress):
+    """FSI::find_fluid_bc (mpi_fsi.cpp:323-663) on one rank: fsi_stress [ncomp][n_unodes] is updated in place; returns
+    (fsi_acc [n_dofs], line_flag, line_val [dim*n_unodes] before the left_object_wins merge, n_not_found)"""
+    S = solid if isinstance(solid, FsiSolid) else FsiSolid(solid)
+    m = _cmesh(mesh, indicator)
+    n_u = mesh.dim * mesh.n_unodes
+    acc = np.zeros(n_u + mesh.n_pnodes)
+    flag, val = np.zeros(n_u, np.int32), np.zeros(n_u)
+    present = np.ascontiguousarray(present, float)
+    fl = None if fluid_stress is None else np.ascontiguousarray(fluid_stress, float)
+    assert fsi_stress is None or (fsi_stress.flags.c_contiguous and fsi_stress.dtype == np.float64)
+    nf = S.L.orc_fsi_find_fluid_bc(C.byref(m), C.byref(S.c), dt, int(use_dirichlet_bc), _ptr(present), _ptr(fl), _ptr(fsi_stress),
+                                   _ptr(acc), _ptr(flag), _ptr(val))
+    return acc, flag, val, nf
