@@ -328,6 +328,53 @@ int ifem_scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, i
 int ifem_scns_newton_step(ifem_ctx *ctx, const ifem_scns_params *p, const ifem_solver_opts *o, int apply_nonzero,
                           double tolerance, int max_iterations, double *log);
 
+/* ---- fluid-side inputs of MPI::FSI produced on the device (source/mpi_fsi.cpp) --------------------
+ * What the FSI driver computes on the fluid mesh before every fluid step (mpi_fsi.cpp:1189-1208), from the solid as every
+ * rank sees it: the cell indicator, fsi_acceleration, the nodal fsi_stress and -- with use_dirichlet_bc -- the Dirichlet
+ * lines of the artificial fluid merged into both constraint objects.  Nothing of it leaves the device; the host hands over
+ * the (small) solid only.  The solid solver itself is outside the path.
+ * The solid is a Q1 mesh ("Degree = 1" in every FSI test of the reference) at its CURRENT position
+ * (FSI::move_solid_mesh(true), :40-76) with the localized nodal fields of :350-362. */
+typedef struct {
+  int32_t n_vertices, n_cells, n_boundary_faces;
+  const double  *vertices;      /* [n_vertices][dim] */
+  const int32_t *cell_vertices; /* [n_cells][2^dim], lexicographic (deal.II) vertex order */
+  const int32_t *boundary_face_vertices; /* dim 2: [n_boundary_faces][2] = solid_boundaries (collect_solid_boundaries,
+                                   :78-94), vertex order of face->vertex(0), ->vertex(1); dim 3: unused, may be NULL */
+  const double *velocity, *acceleration; /* [n_vertices][dim] localized_solid_velocity / _acceleration; may be NULL until
+                                   ifem_fsi_find_fluid_bc is called */
+  const double *stress;         /* [dim(dim+1)/2][n_vertices] localized_stress[i][j], j <= i in the loop order of :459-474,
+                                   or NULL: the nodal fsi_stress is then left alone */
+} ifem_fsi_solid;
+/* uploads the solid and computes solid_box (FSI::update_solid_box, :96-127) */
+int ifem_fsi_set_solid(ifem_ctx *ctx, const ifem_fsi_solid *solid);
+/* FSI::update_indicator (:291-319): indicator = 1 on the local cells (owned and ghost layer) whose vertices all lie in the
+ * solid (FSI::point_in_solid, :142-223), written to the context's cell indicator (what ifem_set_cell_fields sets);
+ * host_out [n_cells] and n_artificial may be NULL */
+int ifem_fsi_update_indicator(ifem_ctx *ctx, int32_t *host_out, int64_t *n_artificial);
+typedef struct {
+  int64_t n_candidates;  /* velocity nodes of the first-touch sets inside solid_box */
+  int64_t n_inside;      /* of them inside the solid */
+  int64_t n_lines;       /* Dirichlet lines added to each constraint object (use_dirichlet_bc) */
+  int64_t n_not_found;   /* points inside the solid no solid cell was found for: != 0 makes the call fail like the
+                            reference's AssertThrow "Cannot find point in solid" (:526-533) */
+} ifem_fsi_stats;
+/* FSI::find_fluid_bc (:323-663).  Reads IFEM_VEC_PRESENT, the projected stress of the last ifem_update_stress (zero before
+ * the first), the cell indicator; writes the nodal fsi_stress (:415-480, entries elsewhere keep their values),
+ * IFEM_VEC_FSI_ACC (:489-556; zero with use_dirichlet_bc) and, with use_dirichlet_bc, merges the lines
+ * v_solid - present (nonzero set) / 0 (zero set) of the velocity dofs inside the solid into the two constraint objects of
+ * ifem_set_constraints with left_object_wins: dofs that already carry a boundary or hanging-node line keep it (:569-651).
+ * The caller re-makes the boundary lines first, as the reference does (fluid_solver.make_constraints(), :1191).
+ * First-touch rule (:437-441, :506-508): the reference evaluates a node in the first cell of its loop that touches it;
+ * here that is the touching cell of smallest cell_order[c] (NULL: the local cell index, i.e. the loop order of a single
+ * rank).  On several ranks pass the global active-cell index: every rank then picks the same cell for the nodes it
+ * owns (the reference's VectorOperation::insert leaves that choice to message order) and ghosts take the owner's value. */
+int ifem_fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int32_t *cell_order, ifem_fsi_stats *stats);
+/* read-back hooks: nodal fsi_stress [dim(dim+1)/2][n_unodes_local]; constraint object `which`: flags and inhomogeneities
+ * over the local dofs [n_local] (either pointer may be NULL) */
+int ifem_fsi_get_stress(ifem_ctx *ctx, double *host_out);
+int ifem_get_constraints(ifem_ctx *ctx, int which, uint8_t *flags, double *inhom);
+
 /* y = [A Bt; B 0] x on context vectors (system_matrix.vmult) -- test / bench hook */
 int ifem_system_vmult(ifem_ctx *ctx, int dst, int src);
 /* y = [diag(M_u) x_u ; M_p x_p] on context vectors: the two blocks of mass_matrix the reference's preconditioner reads

@@ -110,7 +110,9 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_get_timing", "ifem_set_profiling", "ifem_synchronize", "ifem_set_hanging_constraints", "ifem_set_ainv_kind", "ifem_set_scns_fields", "ifem_update_stress",
            "ifem_scns_assemble", "ifem_scns_solve", "ifem_scns_newton_step", "ifem_imex_assemble", "ifem_imex_solve",
            "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof",
-           "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag"]
+           "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag",
+           "ifem_fsi_set_solid", "ifem_fsi_update_indicator", "ifem_fsi_find_fluid_bc", "ifem_fsi_get_stress",
+           "ifem_get_constraints"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -184,6 +186,11 @@ def load():
     L.ifem_mg_attach.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(MgTransfer)]
     L.ifem_mg_depth.argtypes = [C.c_void_p]
     L.ifem_uu_block_diag.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.ifem_fsi_set_solid.argtypes = [C.c_void_p, C.POINTER(FsiSolid)]
+    L.ifem_fsi_update_indicator.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    L.ifem_fsi_find_fluid_bc.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.POINTER(FsiStats)]
+    L.ifem_fsi_get_stress.argtypes = [C.c_void_p, C.c_void_p]
+    L.ifem_get_constraints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.ifem_abi_sizeof.argtypes = [C.c_int]
     L.ifem_abi_sizeof.restype = C.c_int64
     _lib = L
@@ -194,7 +201,17 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-ABI_STRUCTS = [MeshDesc, Partition, InsParams, SolverOpts, SolveStats, ScnsParams, Timing, Tuning, MgTransfer]
+class FsiSolid(C.Structure):  # ifem_fsi_solid
+    _fields_ = [("n_vertices", C.c_int32), ("n_cells", C.c_int32), ("n_boundary_faces", C.c_int32),
+                ("vertices", C.c_void_p), ("cell_vertices", C.c_void_p), ("boundary_face_vertices", C.c_void_p),
+                ("velocity", C.c_void_p), ("acceleration", C.c_void_p), ("stress", C.c_void_p)]
+
+
+class FsiStats(C.Structure):  # ifem_fsi_stats
+    _fields_ = [("n_candidates", C.c_int64), ("n_inside", C.c_int64), ("n_lines", C.c_int64), ("n_not_found", C.c_int64)]
+
+
+ABI_STRUCTS = [MeshDesc, Partition, InsParams, SolverOpts, SolveStats, ScnsParams, Timing, Tuning, MgTransfer, FsiSolid, FsiStats]
 
 
 def make_params(mu=1.0, rho=1.0, gamma=0.1, dt=1e-3, g=(0, 0, 0), neumann=None):
@@ -395,6 +412,38 @@ class Context:
     def set_indicator(self, ind):
         ind = None if ind is None else np.ascontiguousarray(ind, np.int32)
         self._chk(self.L.ifem_set_cell_fields(self.h, _ptr(ind)))
+
+    # ---- fluid-side inputs of MPI::FSI on the device (mpi_fsi.cpp:291-663)
+    def fsi_set_solid(self, vertices, cells, bfaces=None, velocity=None, acceleration=None, stress=None):
+        keep = [np.ascontiguousarray(vertices, float), np.ascontiguousarray(cells, np.int32),
+                None if bfaces is None else np.ascontiguousarray(bfaces, np.int32),
+                None if velocity is None else np.ascontiguousarray(velocity, float),
+                None if acceleration is None else np.ascontiguousarray(acceleration, float),
+                None if stress is None else np.ascontiguousarray(stress, float)]
+        s = FsiSolid(len(keep[0]), len(keep[1]), 0 if keep[2] is None else len(keep[2]), *[_ptr(a) for a in keep])
+        self._chk(self.L.ifem_fsi_set_solid(self.h, C.byref(s)))
+
+    def fsi_update_indicator(self, n_cells):
+        out = np.zeros(n_cells, np.int32)
+        cnt = C.c_int64()
+        self._chk(self.L.ifem_fsi_update_indicator(self.h, _ptr(out), C.byref(cnt)))
+        return out, cnt.value
+
+    def fsi_find_fluid_bc(self, dt, use_dirichlet_bc, cell_order=None):
+        order = None if cell_order is None else np.ascontiguousarray(cell_order, np.int32)
+        st = FsiStats()
+        self._chk(self.L.ifem_fsi_find_fluid_bc(self.h, dt, int(use_dirichlet_bc), _ptr(order), C.byref(st)))
+        return st
+
+    def fsi_get_stress(self):
+        out = np.zeros((self.dim * (self.dim + 1) // 2, self.n_u // self.dim))
+        self._chk(self.L.ifem_fsi_get_stress(self.h, _ptr(out)))
+        return out
+
+    def get_constraints(self, which):
+        flags, vals = np.zeros(self.n_local, np.uint8), np.zeros(self.n_local)
+        self._chk(self.L.ifem_get_constraints(self.h, which, _ptr(flags), _ptr(vals)))
+        return flags, vals
 
     def _len(self, vec):
         return self.n_local if vec in (VEC_PRESENT, VEC_EVAL, VEC_FSI_ACC, VEC_INCREMENT) else self.n_owned

@@ -20,6 +20,17 @@ static thread_local std::string g_err;
   catch (const std::exception &e) { g_err = e.what(); return IFEM_E_HIP; } \
   return IFEM_OK;
 
+namespace ifem {
+// identity of the constrained-dof set (ctx.hpp): decided over ALL ranks, since a stale cache triggers collective work
+void constraint_set_identity(ifem_ctx *ctx, int which, std::vector<uint8_t> &&f) {
+  const int other = 1 - which;
+  double differs[2] = {ctx->h_flags[which] != f ? 1.0 : 0.0, ctx->h_flags[other] != f ? 1.0 : 0.0};
+  allreduce_max(ctx, differs, 2);
+  if (differs[0] != 0.0) ctx->flag_id[which] = differs[1] == 0.0 ? ctx->flag_id[other] : ++ctx->flag_counter;
+  ctx->h_flags[which] = std::move(f);
+}
+} // namespace ifem
+
 extern "C" {
 
 const char *ifem_last_error(void) { return g_err.c_str(); }
@@ -35,6 +46,8 @@ int64_t ifem_abi_sizeof(int which) {
   case 6: return sizeof(ifem_timing);
   case 7: return sizeof(ifem_tuning);
   case 8: return sizeof(ifem_mg_transfer);
+  case 9: return sizeof(ifem_fsi_solid);
+  case 10: return sizeof(ifem_fsi_stats);
   default: return -1;
   }
 }
@@ -173,12 +186,46 @@ int ifem_set_constraints(ifem_ctx *ctx, int which, int32_t n, const int32_t *dof
   ctx->cval[which].upload(v.data(), v.size(), ctx->stream);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   ctx->has_c[which] = n > 0;
-  { // identity of the constrained-dof set (ctx.hpp): decided over ALL ranks, since a stale cache triggers collective work
-    const int other = 1 - which;
-    double differs[2] = {ctx->h_flags[which] != f ? 1.0 : 0.0, ctx->h_flags[other] != f ? 1.0 : 0.0};
-    allreduce_max(ctx, differs, 2);
-    if (differs[0] != 0.0) ctx->flag_id[which] = differs[1] == 0.0 ? ctx->flag_id[other] : ++ctx->flag_counter;
-    ctx->h_flags[which] = std::move(f);
+  constraint_set_identity(ctx, which, std::move(f));
+  IFEM_API_END
+}
+
+int ifem_fsi_set_solid(ifem_ctx *ctx, const ifem_fsi_solid *solid) {
+  IFEM_API_BEGIN
+  ifem::fsi_set_solid(ctx, solid);
+  IFEM_API_END
+}
+int ifem_fsi_update_indicator(ifem_ctx *ctx, int32_t *host_out, int64_t *n_artificial) {
+  IFEM_API_BEGIN
+  ifem::fsi_update_indicator(ctx, host_out, n_artificial);
+  IFEM_API_END
+}
+int ifem_fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int32_t *cell_order, ifem_fsi_stats *stats) {
+  IFEM_API_BEGIN
+  if (!(dt > 0)) throw Error(IFEM_E_BADPARAM, "ifem_fsi_find_fluid_bc: dt must be positive");
+  ifem::fsi_find_fluid_bc(ctx, dt, use_dirichlet_bc, cell_order, stats);
+  IFEM_API_END
+}
+int ifem_fsi_get_stress(ifem_ctx *ctx, double *host_out) {
+  IFEM_API_BEGIN
+  const size_t n = (size_t)(ctx->dim * (ctx->dim + 1) / 2) * ctx->nUl;
+  if (!host_out) throw Error(IFEM_E_BADPARAM, "null output");
+  if (ctx->fsi_stress.n != n) throw Error(IFEM_E_BADPARAM, "the context holds no nodal fsi_stress");
+  IFEM_HIP_CHECK(hipMemcpyAsync(host_out, ctx->fsi_stress.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+int ifem_get_constraints(ifem_ctx *ctx, int which, uint8_t *flags, double *inhom) {
+  IFEM_API_BEGIN
+  if (which < 0 || which > 1) throw Error(IFEM_E_BADPARAM, "which must be 0 or 1");
+  const size_t n = (size_t)ctx->n_local;
+  if (ctx->is_c[which].n != n) { // never set: no line
+    if (flags) std::fill(flags, flags + n, uint8_t(0));
+    if (inhom) std::fill(inhom, inhom + n, 0.0);
+  } else {
+    if (flags) IFEM_HIP_CHECK(hipMemcpyAsync(flags, ctx->is_c[which].p, n, hipMemcpyDeviceToHost, ctx->stream));
+    if (inhom) IFEM_HIP_CHECK(hipMemcpyAsync(inhom, ctx->cval[which].p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   }
   IFEM_API_END
 }

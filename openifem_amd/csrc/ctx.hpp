@@ -163,6 +163,24 @@ struct Hanging {
 } // namespace ifem
 
 namespace ifem {
+// the solid as MPI::FSI sees it on every rank and the scratch of the device-side FSI inputs (fsi.hip)
+struct FsiState {
+  int32_t nv = 0, nc = 0, nbf = 0;
+  DBuf<double> vert;   // [nv][dim]
+  DBuf<int32_t> cells; // [nc][2^dim]
+  DBuf<double> rec;    // per solid cell: bounding box lo[dim], hi[dim], then the vertex coordinates [2^dim][dim]
+  DBuf<double> bface;  // dim 2: per boundary face p1x p1y p2x p2y
+  DBuf<double> vel, acc, stress;
+  double box[6] = {0, 0, 0, 0, 0, 0}; // solid_box: lo, hi per direction
+  bool valid = false, has_fields = false, has_stress = false;
+  DBuf<uint32_t> order_min, first; // first-touch cell of every local velocity node: (cell << 5 | local node) or 0xFFFFFFFF
+  DBuf<int32_t> cand;              // velocity nodes whose support point lies in solid_box
+  DBuf<uint8_t> taken;             // dofs that already carry a boundary or hanging line
+  DBuf<int64_t> counters;          // [8] device counters
+};
+} // namespace ifem
+
+namespace ifem {
 // one CSR transfer table of the multigrid hierarchy (row-parallel gather on the device)
 struct MgCsr {
   int64_t n_rows = 0;
@@ -234,6 +252,7 @@ struct ifem_ctx {
   ifem::DBuf<int32_t> sm_rows;
   int64_t geo_refresh_stamp = -1; // a coarse multigrid level: the finest level's assembly its blocks were last refreshed for
   ifem::Hanging hang; // hanging-node lines (hanging.hip)
+  ifem::FsiState fsi; // solid + scratch of the device-side FSI inputs (fsi.hip)
   // multigrid (ifem_mg_attach): the next coarser level (not owned) and the pressure transfers to it; per-level state of
   // the S_m V-cycle: 1/diag(S_m), largest eigenvalue of D^-1 S_m, scratch vectors [nPl]
   ifem_ctx *mg_coarse = nullptr;

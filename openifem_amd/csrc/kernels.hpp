@@ -20,6 +20,13 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
 // B, B^T, M_p, diag(M_u) only (multigrid levels of the pressure Schur complement): no A_uu, no right-hand side state
 void launch_ins_assemble_geometry(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
 
+// fsi.hip -- fluid-side inputs of MPI::FSI (source/mpi_fsi.cpp:96-127,142-223,291-663)
+void fsi_set_solid(ifem_ctx *ctx, const ifem_fsi_solid *s);
+void fsi_update_indicator(ifem_ctx *ctx, int32_t *host_out, int64_t *n_artificial);
+void fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int32_t *cell_order, ifem_fsi_stats *stats);
+// api.hip: identity of the constrained-dof set `which` after its flags changed (f = the new flags over the local dofs)
+void constraint_set_identity(ifem_ctx *ctx, int which, std::vector<uint8_t> &&f);
+
 // assemble_scns.hip
 void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonzero);
 void launch_update_stress(ifem_ctx *ctx, double mu);
