@@ -109,8 +109,9 @@ def _boundary(m):
     return m.dirichlet({0: (3, [0, 0]), 2: (3, [0, 0]), 3: (3, [0, 0])}, {0: inflow})
 
 
-def oracle_loop(m, n_steps, use_dirichlet_bc):
+def oracle_loop(m, n_steps, use_dirichlet_bc, fsi_inputs=None):
     """the same loop on the CPU oracle; returns [(present, newton iterations)] per step"""
+    fsi_inputs = fsi_inputs or globals()["fsi_inputs"]
     n = m.n_dofs
     Cm = sp.csr_matrix(m.prolongation())
     hang = m.hang_dof
@@ -238,6 +239,100 @@ def test_fsi_caller_loop_matches_oracle(nranks, use_dirichlet_bc):
         xg, itg = got[s]
         # velocity and pressure separately, relative to their own scale; 1e-6 = what Newton to 1e-8 on an FGMRES solve to
         # 1e-6 ||rhs|| (mpi_supg_solver.cpp:311-312) leaves against the oracle's exact linear solves
+        ev = np.abs(xg[:n_u] - xr[:n_u]).max() / np.abs(xr[:n_u]).max()
+        ep = np.abs(xg[n_u:] - xr[n_u:]).max() / max(np.abs(xr[n_u:]).max(), 1e-300)
+        assert ev < 1e-6 and ep < 1e-6, (s, ev, ep, itr, itg)
+        assert abs(itg - itr) <= 1, (s, itr, itg)
+
+
+# ---- the same loop with the FSI side's work done from a MESHED solid: on the CPU by oracle/oracle_fsi.c (the restatement of
+# update_indicator / find_fluid_bc), on the GPU by ifem_fsi_update_indicator / ifem_fsi_find_fluid_bc -- nothing
+# but the solid's vertices and nodal fields crosses the boundary per step.
+
+def _meshed_solid(step):
+    """a distorted Q1 'leaflet' block in rigid motion: position, nodal velocity / acceleration / stress of time step `step`"""
+    from solidmesh import lattice_solid, wobble
+    t = step * KW["dt"]
+    base = lattice_solid((14, 8), (0.47, 0.36), (1.01, 0.68), mapping=wobble(0.004, 11.0))
+    c0 = base.vertices.mean(axis=0)
+    s = base.moved(shift=V_PATH * t, rot=0.2 + OMEGA * 4 * t, about=c0)
+    c = c0 + V_PATH * t
+    r = s.vertices - c
+    s.velocity = V_S + OMEGA * np.stack([-r[:, 1], r[:, 0]], axis=1)
+    s.acceleration = np.broadcast_to(AS, r.shape) - OMEGA ** 2 * r
+    x = s.vertices
+    s.stress = np.stack([0.4 + 0.3 * x[:, 0], 0.05 * x[:, 1] - 0.1 * x[:, 0], -0.2 + 0.1 * x[:, 1] * x[:, 0]], axis=0)
+    return s
+
+
+def fsi_inputs_meshed(m, step, present, stress, fsi_stress, boundary, use_dirichlet_bc):
+    """fsi_inputs through the oracle's restatement of mpi_fsi.cpp:291-663 (fsi_stress is updated in place)"""
+    s = _meshed_solid(step)
+    indicator = orc.fsi_update_indicator(m, s)
+    assert indicator.sum() > 0
+    fsi_acc, flag, val, nf = orc.fsi_find_fluid_bc(m, s, indicator, KW["dt"], use_dirichlet_bc, present, stress, fsi_stress)
+    assert nf == 0
+    bdofs, bvals = boundary
+    taken = np.zeros(m.n_dofs, bool)
+    taken[bdofs] = True
+    taken[m.hang_dof] = True
+    new = np.nonzero((flag == 1) & ~taken[:m.n_u])[0]  # merge with left_object_wins (:641-651)
+    dofs = np.concatenate([bdofs, new]).astype(np.int32)
+    vals = np.concatenate([bvals if step == 0 else np.zeros(len(bvals)), val[new]])
+    return indicator, fsi_acc, dofs, vals
+
+
+def hip_loop_device_inputs(m, nranks, n_steps, use_dirichlet_bc):
+    from openifem_amd import capi
+    c = m.vcoords.mean(axis=1)
+    cell_rank = np.zeros(m.n_cells, int) if nranks == 1 else (c[:, 0] > 1.02).astype(int) + 2 * (c[:, 1] > 0.5).astype(int)
+    parts = partition_mesh(m, cell_rank, nranks)
+    shared = {"present": np.zeros(m.n_dofs)}
+    barrier = threading.Barrier(nranks)
+    bdofs, bvals = _boundary(m)
+    out = [[] for _ in range(nranks)]
+
+    def work(rank, P, ctx):
+        ctx.set_hanging_constraints(P.hang_dof, P.hang_ptr, P.hang_master, P.hang_weight)
+        ctx.vec_set(capi.VEC_PRESENT, np.zeros(P.n_local))
+        prm = capi.make_scns_params(**KW)
+        nuo, nul = P.n_unodes_owned, P.n_unodes
+        moved = []
+        for step in range(n_steps):
+            s = _meshed_solid(step)
+            ctx.fsi_set_solid(s.vertices, s.cells, s.bfaces, s.velocity, s.acceleration, s.stress)  # update_solid_box (:1189)
+            ind, _ = ctx.fsi_update_indicator(len(P.cells))                                           # update_indicator (:1190)
+            moved.append(ind)
+            ld, lv = local_dirichlet(P, bdofs, bvals if step == 0 else np.zeros(len(bvals)))          # make_constraints (:1191-1197)
+            ctx.set_constraints(1, ld, lv)
+            ctx.set_constraints(0, ld, None)
+            st = ctx.fsi_find_fluid_bc(KW["dt"], use_dirichlet_bc, cell_order=P.cells)                # find_fluid_bc (:1203)
+            assert st.n_not_found == 0
+            its, log = ctx.scns_newton_step(prm, True, tol=NEWTON_TOL, maxit=NEWTON_MAXIT)            # run_one_step(true) (:1208)
+            x = ctx.vec_get(capi.VEC_PRESENT)
+            barrier.wait()
+            shared["present"][P.own_gdof] = np.concatenate([x[:2 * nuo], x[2 * nul:2 * nul + P.n_pnodes_owned]])
+            barrier.wait()
+            out[rank].append((shared["present"].copy() if rank == 0 else None, its))
+        assert any((moved[k] != moved[k + 1]).any() for k in range(n_steps - 1)) or nranks > 1
+        return None
+
+    run_virtual_ranks(capi, parts, work)
+    assert all([o[1] for o in out[r]] == [o[1] for o in out[0]] for r in range(nranks)), "ranks disagree on Newton counts"
+    return out[0]
+
+
+@pytest.mark.parametrize("use_dirichlet_bc", [True, False])
+@pytest.mark.parametrize("nranks", [1, 4])
+def test_fsi_caller_loop_with_device_produced_inputs(nranks, use_dirichlet_bc):
+    m = _mesh()
+    n_steps = 3
+    ref = oracle_loop(m, n_steps, use_dirichlet_bc, fsi_inputs=fsi_inputs_meshed)
+    got = hip_loop_device_inputs(m, nranks, n_steps, use_dirichlet_bc)
+    n_u = m.n_u
+    for s in range(n_steps):
+        xr, itr = ref[s]
+        xg, itg = got[s]
         ev = np.abs(xg[:n_u] - xr[:n_u]).max() / np.abs(xr[:n_u]).max()
         ep = np.abs(xg[n_u:] - xr[n_u:]).max() / max(np.abs(xr[n_u:]).max(), 1e-300)
         assert ev < 1e-6 and ep < 1e-6, (s, ev, ep, itr, itg)
