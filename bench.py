@@ -251,6 +251,7 @@ def main():
     ap.add_argument("--mg-post-u", type=int, default=None, help="smoothing steps after the coarse correction of the A_uu V-cycle (default: as before it)")
     ap.add_argument("--mg-ratio-u", type=float, default=None, help="Chebyshev interval ratio of the A_uu V-cycle (--ainv 4)")
     ap.add_argument("--tune", action="append", default=[], help="experiment: ifem_tuning field=value (e.g. --tune spmv_pipe=0), applied to every multigrid level")
+    ap.add_argument("--fsi", type=int, default=32, help="N = 1 only: also time the device-side FSI inputs (FSI::update_indicator + find_fluid_bc, csrc/fsi.hip) on the bench mesh with a 24x12x12-cell solid, and the oracle's restatement on the CPU at this many cells per direction (0 = skip the leg)")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
     ap.add_argument("--outer-mf", type=int, default=0, help="experiment: apply the u-u block of the OUTER operator matrix-free too")
     ap.add_argument("--solver", default="insim", choices=["insim", "insimex"],
@@ -435,6 +436,17 @@ def main():
             solver.opts.mp_rel, solver.opts.sm_rel, solver.opts.outer_matrix_free = keep  # the legs below use the reference's again
         if world == 1 and args.extras:
             out.update(extras(solver, capi, n_dofs_global, ms_per_step))
+        if world == 1 and args.fsi:
+            # side measurement, last device leg: its Dirichlet-mode call edits the constraint sets of the context
+            try:
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                import fsibench
+                solid = fsibench.make_solid3d()
+                leg = fsibench.device_leg(solver.L, solver.ctx, capi, n_cells, solid)
+                leg["cpu_baseline"] = fsibench.cpu_leg(args.fsi, solid)
+                out["fsi_inputs"] = leg
+            except Exception as e:  # a side leg must not take the headline line with it
+                out["fsi_inputs"] = {"error": repr(e)}
         cpu_sizes = [int(v) for v in str(args.cpu_n).split(",") if int(v) > 0]
         if cpu_sizes and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             out["cpu_baseline"] = cpu_baseline(cpu_sizes)

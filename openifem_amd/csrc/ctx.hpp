@@ -172,6 +172,9 @@ struct FsiState {
   DBuf<double> bface;  // dim 2: per boundary face p1x p1y p2x p2y
   DBuf<double> vel, acc, stress;
   double box[6] = {0, 0, 0, 0, 0, 0}; // solid_box: lo, hi per direction
+  DBuf<int32_t> bin_ptr, bin_cells;   // uniform grid over solid_box -> solid cells whose bounding box meets the bin
+  int G[3] = {1, 1, 1};
+  double inv_h[3] = {0, 0, 0};
   bool valid = false, has_fields = false, has_stress = false;
   DBuf<uint32_t> order_min, first; // first-touch cell of every local velocity node: (cell << 5 | local node) or 0xFFFFFFFF
   DBuf<int32_t> cand;              // velocity nodes whose support point lies in solid_box
