@@ -337,3 +337,73 @@ def test_fsi_caller_loop_with_device_produced_inputs(nranks, use_dirichlet_bc):
         ep = np.abs(xg[n_u:] - xr[n_u:]).max() / max(np.abs(xr[n_u:]).max(), 1e-300)
         assert ev < 1e-6 and ep < 1e-6, (s, ev, ep, itr, itg)
         assert abs(itg - itr) <= 1, (s, itr, itg)
+
+
+def test_fsi_loop_3d_insimex_with_device_produced_inputs():
+    """the 3D coupling of the reference runs InsIMEX<3> under MPI::FSI with the penalty form (tests/fsi_leaflet_mpi/
+    fsi_leaflet_mpi.cpp:105, use_dirichlet_bc = false): per step update_solid_box / update_indicator / make_constraints /
+    find_fluid_bc on the device, then InsIMEX::run_one_step(true) (matrix re-assembled: the indicator moved) -- against the
+    oracle doing the same with its restatements, on a Q2/Q1 box with a rotated hexahedral solid in rigid motion."""
+    from openifem_amd import capi
+    from boxmesh import BoxMesh
+    from solidmesh import lattice_solid, rotation, wobble
+    m = BoxMesh((8, 6, 5), (0, 0, 0), (1.0, 0.8, 0.6), kv=2)
+    kw = dict(mu=0.05, rho=1.0, gamma=0.1, dt=0.01, g=(0.0, 0.0, 0.0), neumann={})
+    bdofs, bvals = m.dirichlet({0: (7, [0.3, 0.0, 0.0]), 2: (7, [0, 0, 0]), 3: (7, [0, 0, 0]), 4: (7, [0, 0, 0]), 5: (7, [0, 0, 0])})
+    base = lattice_solid((4, 3, 3), (0.23, 0.21, 0.13), (0.71, 0.62, 0.49),
+                         mapping=lambda p: wobble(0.008, 6.0)(rotation(0.3, (0.47, 0.41))(p)))
+    c0 = base.vertices.mean(axis=0)
+    vs, om = np.array([0.8, 0.1, -0.05]), 0.6
+
+    def solid(step):
+        t = step * kw["dt"]
+        s = base.moved(shift=np.array([4.0, 0.5, 0.3]) * t, rot=2 * om * t, about=c0)
+        r = s.vertices - (c0 + np.array([4.0, 0.5, 0.3]) * t)
+        s.velocity = vs + om * np.stack([-r[:, 1], r[:, 0], 0 * r[:, 0]], axis=1)
+        s.acceleration = np.array([0.2, -0.1, 0.3]) - om ** 2 * r * np.array([1, 1, 0])
+        s.stress = None
+        return s
+
+    n_steps = 3
+    # oracle
+    m.indicator = np.zeros(m.n_cells, np.int32)
+    S = orc.System(m)
+    ind_buf = S._keep[4]
+    x = np.zeros(m.n_dofs)
+    ref, inds = [], []
+    ainv = orc.SpluAinv()
+    for step in range(n_steps):
+        s = solid(step)
+        ind = orc.fsi_update_indicator(m, s)
+        inds.append(ind)
+        acc, _, _, nf = orc.fsi_find_fluid_bc(m, s, ind, kw["dt"], False, x, None, None)
+        assert nf == 0 and ind.sum() > 0 and np.abs(acc).max() > 0
+        ind_buf[:] = ind
+        S.set_constraints(1, bdofs, bvals if step == 0 else np.zeros(len(bvals)))
+        S.set_constraints(0, bdofs, None)
+        rc, _, _ = S.imex_run_one_step(orc.make_params(**kw), True, True, x, ainv=ainv, fsi_acc=acc)
+        assert rc == 0
+        ref.append(x.copy())
+    m.indicator = None
+    assert any((inds[k] != inds[k + 1]).any() for k in range(n_steps - 1))
+    # device
+    ctx = capi.Context(3, 2, m.vcoords, m.cell_unodes, m.cell_pnodes, m.cell_face_bid, m.n_unodes, m.n_pnodes)
+    ctx.vec_set(capi.VEC_PRESENT, np.zeros(m.n_dofs))
+    ctx.opts.inner_rel = 1e-4
+    P = capi.make_params(**kw)
+    for step in range(n_steps):
+        s = solid(step)
+        ctx.fsi_set_solid(s.vertices, s.cells, None, s.velocity, s.acceleration, None)
+        ind, _ = ctx.fsi_update_indicator(m.n_cells)
+        assert (ind == inds[step]).all()
+        ctx.set_constraints(1, bdofs, bvals if step == 0 else np.zeros(len(bvals)))
+        ctx.set_constraints(0, bdofs, None)
+        st = ctx.fsi_find_fluid_bc(kw["dt"], False)
+        assert st.n_not_found == 0
+        ctx.imex_step(P, True, True)
+        got = ctx.vec_get(capi.VEC_PRESENT)
+        n_u = m.n_u
+        ev = np.abs(got[:n_u] - ref[step][:n_u]).max() / np.abs(ref[step][:n_u]).max()
+        ep = np.abs(got[n_u:] - ref[step][n_u:]).max() / np.abs(ref[step][n_u:]).max()
+        assert ev < 1e-6 and ep < 1e-6, (step, ev, ep)
+    ctx.close()
