@@ -9,6 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# the host driver of the MI355X boxes only supports dmabuf IPC: RCCL between processes needs this before the HSA runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 LIB_PATH = os.path.join(_HERE, "lib", "libifem_hip.so")
 
 VEC_PRESENT, VEC_EVAL, VEC_FSI_ACC, VEC_UPDATE, VEC_RHS, VEC_INCREMENT, VEC_TMP = range(7)

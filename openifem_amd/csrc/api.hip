@@ -21,13 +21,41 @@ static thread_local std::string g_err;
   return IFEM_OK;
 
 namespace ifem {
-// identity of the constrained-dof set (ctx.hpp): decided over ALL ranks, since a stale cache triggers collective work
-void constraint_set_identity(ifem_ctx *ctx, int which, std::vector<uint8_t> &&f) {
+__global__ void k_flags_diff(int64_t n, const uint8_t *a, const uint8_t *b, unsigned long long *out) {
+  unsigned long long d = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d += a[i] != b[i];
+  if (d) atomicAdd(out, d);
+}
+__global__ void k_constraint_scatter(int32_t n, const int32_t *dof, const double *val, uint8_t *flag, double *cval) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flag[dof[i]] = 1;
+  cval[dof[i]] = val ? val[i] : 0.0;
+}
+
+// out[k] = 1 when the flag arrays of pair k differ somewhere (a never-set array differs from everything), compared on the
+// device: the flags of a 128^3 mesh are 53 MB, the answer is a word
+void flags_differ(ifem_ctx *ctx, int npairs, const DBuf<uint8_t> *const *a, const DBuf<uint8_t> *const *b, double *out) {
+  const size_t N = (size_t)ctx->n_local;
+  unsigned long long *cnt = reinterpret_cast<unsigned long long *>(ctx->scal.p + kScalStageOff); // staging slots, idle here
+  IFEM_HIP_CHECK(hipMemsetAsync(cnt, 0, npairs * sizeof(unsigned long long), ctx->stream));
+  for (int k = 0; k < npairs; ++k)
+    if (a[k]->n == N && b[k]->n == N && N)
+      hipLaunchKernelGGL(k_flags_diff, dim3(1024), dim3(256), 0, ctx->stream, (int64_t)N, a[k]->p, b[k]->p, cnt + k);
+  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  IFEM_HIP_CHECK(hipMemcpyAsync(h, cnt, npairs * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < npairs; ++k) out[k] = (a[k]->n != N || b[k]->n != N || h[k] != 0) ? 1.0 : 0.0;
+}
+
+// identity of the constrained-dof set (ctx.hpp) after the flags of set `which` changed: differs_self = they are not what
+// they were, differs_other = they are not the other set's either.  Decided over ALL ranks, since a stale cache triggers
+// collective work.
+void constraint_set_identity(ifem_ctx *ctx, int which, bool differs_self, bool differs_other) {
   const int other = 1 - which;
-  double differs[2] = {ctx->h_flags[which] != f ? 1.0 : 0.0, ctx->h_flags[other] != f ? 1.0 : 0.0};
+  double differs[2] = {differs_self ? 1.0 : 0.0, differs_other ? 1.0 : 0.0};
   allreduce_max(ctx, differs, 2);
   if (differs[0] != 0.0) ctx->flag_id[which] = differs[1] == 0.0 ? ctx->flag_id[other] : ++ctx->flag_counter;
-  ctx->h_flags[which] = std::move(f);
 }
 } // namespace ifem
 
@@ -174,19 +202,55 @@ int64_t ifem_nnz(const ifem_ctx *ctx, int block) {
 int ifem_set_constraints(ifem_ctx *ctx, int which, int32_t n, const int32_t *dof, const double *inhom) {
   IFEM_API_BEGIN
   if (which < 0 || which > 1) throw Error(IFEM_E_BADPARAM, "which must be 0 or 1");
-  std::vector<uint8_t> f((size_t)ctx->n_local, 0);
-  std::vector<double> v((size_t)ctx->n_local, 0.0);
-  for (int32_t i = 0; i < n; ++i) {
-    if (dof[i] < 0 || dof[i] >= ctx->n_local) throw Error(IFEM_E_BADPARAM, "constraint dof out of range");
-    if (dof[i] >= ctx->dim * ctx->nUl) throw Error(IFEM_E_BADPARAM, "pressure Dirichlet constraints are not supported");
-    f[dof[i]] = 1;
-    v[dof[i]] = inhom ? inhom[i] : 0.0;
+  if (n < 0 || (n > 0 && !dof)) throw Error(IFEM_E_BADPARAM, "bad constraint list");
+  // Only the n lines cross the bus; flags and inhomogeneities over the local dofs are built and compared on the device
+  // (FSI re-makes the constraints every time step, mpi_fsi.cpp:1191: at 128^3 the dense host arrays were 480 MB per call).
+  // A dof listed twice keeps its LAST line, as the sequential host loop did.
+  const size_t N = (size_t)ctx->n_local;
+  std::vector<int32_t> kd;
+  std::vector<double> kv;
+  kd.reserve((size_t)n);
+  kv.reserve((size_t)n);
+  {
+    std::vector<uint8_t> &seen = ctx->seen_scratch; // all zero between calls
+    if (seen.size() != N) seen.assign(N, 0);
+    int32_t bad = 0;
+    for (int32_t i = n - 1; i >= 0; --i) {
+      const int32_t d = dof[i];
+      if (d < 0 || (size_t)d >= N) { bad = 1; break; }
+      if (d >= ctx->dim * ctx->nUl) { bad = 2; break; }
+      if (seen[d]) continue;
+      seen[d] = 1;
+      kd.push_back(d);
+      kv.push_back(inhom ? inhom[i] : 0.0);
+    }
+    for (int32_t d : kd) seen[d] = 0;
+    if (bad == 1) throw Error(IFEM_E_BADPARAM, "constraint dof out of range");
+    if (bad == 2) throw Error(IFEM_E_BADPARAM, "pressure Dirichlet constraints are not supported");
   }
-  ctx->is_c[which].upload(f.data(), f.size(), ctx->stream);
-  ctx->cval[which].upload(v.data(), v.size(), ctx->stream);
-  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  ctx->has_c[which] = n > 0;
-  constraint_set_identity(ctx, which, std::move(f));
+  hipStream_t s = ctx->stream;
+  DBuf<int32_t> d_dof;
+  DBuf<double> d_val;
+  DBuf<uint8_t> nf;
+  DBuf<double> nv;
+  nf.alloc(N);
+  nv.alloc(N);
+  if (N) {
+    IFEM_HIP_CHECK(hipMemsetAsync(nf.p, 0, N, s));
+    IFEM_HIP_CHECK(hipMemsetAsync(nv.p, 0, N * sizeof(double), s));
+  }
+  if (!kd.empty()) {
+    d_dof.upload(kd.data(), kd.size(), s);
+    d_val.upload(kv.data(), kv.size(), s);
+    hipLaunchKernelGGL(k_constraint_scatter, dim3((unsigned)((kd.size() + 255) / 256)), dim3(256), 0, s, (int32_t)kd.size(), d_dof.p, d_val.p, nf.p, nv.p);
+  }
+  const DBuf<uint8_t> *pa[2] = {&nf, &nf}, *pb[2] = {&ctx->is_c[which], &ctx->is_c[1 - which]};
+  double differs[2];
+  flags_differ(ctx, 2, pa, pb, differs); // synchronises: the host lists may go away
+  ctx->is_c[which].swap(nf);
+  ctx->cval[which].swap(nv);
+  ctx->has_c[which] = !kd.empty();
+  constraint_set_identity(ctx, which, differs[0] != 0.0, differs[1] != 0.0);
   IFEM_API_END
 }
 

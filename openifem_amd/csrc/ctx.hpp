@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
+#include <utility>
 #include <string>
 #include <vector>
 #include "../../include/ifem_hip.h"
@@ -39,6 +40,10 @@ struct DBuf { // owning device buffer
     if (p) (void)hipFree(p);
     p = nullptr;
     n = 0;
+  }
+  void swap(DBuf &o) {
+    std::swap(p, o.p);
+    std::swap(n, o.n);
   }
   void alloc(size_t count) {
     release();
@@ -179,6 +184,7 @@ struct FsiState {
   DBuf<uint32_t> order_min, first; // first-touch cell of every local velocity node: (cell << 5 | local node) or 0xFFFFFFFF
   DBuf<int32_t> cand;              // velocity nodes whose support point lies in solid_box
   DBuf<uint8_t> taken;             // dofs that already carry a boundary or hanging line
+  DBuf<uint8_t> prev[2];           // the flags of the two constraint sets before the merge (identity of the sets afterwards)
   DBuf<int64_t> counters;          // [8] device counters
 };
 } // namespace ifem
@@ -235,8 +241,9 @@ struct ifem_ctx {
   // identity of the constrained-dof SET of each AffineConstraints object (which dofs, not their values): B, B^T, M_p,
   // diag(M_u) and S_m depend on nothing else, so zero_ / nonzero_constraints with the same lines share one cache entry and
   // re-making identical constraints (time-dependent boundary values) keeps it
-  std::vector<uint8_t> h_flags[2];
+  // (decided by comparing the flag arrays on the device, api.hip::flags_differ)
   int64_t flag_id[2] = {0, 0}, flag_counter = 0;
+  std::vector<uint8_t> seen_scratch; // ifem_set_constraints: duplicate detection over the local dofs, all zero between calls
   // scalar velocity operator S^ = mu K + rho C(u) + rho/dt M on the A_uu block pattern (IFEM_AINV_SCALAR_*)
   ifem::DBuf<double> Shat, shat_dinv;
   ifem::DBuf<float> Shat_f32;

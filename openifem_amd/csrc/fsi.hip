@@ -491,17 +491,14 @@ __global__ void k_fsi_taken(int64_t n, const uint8_t *c0, const uint8_t *c1, uin
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) taken[i] = (c0 ? c0[i] : 0) | (c1 ? c1[i] : 0);
 }
-// [0] dofs on which the two flag arrays differ, [1] / [2] lines of set 0 / 1
-__global__ void k_fsi_flags_compare(int64_t n, const uint8_t *c0, const uint8_t *c1, int64_t *out) {
-  unsigned long long d = 0, a0 = 0, a1 = 0;
+__global__ void k_fsi_any(int64_t n, const uint8_t *c0, const uint8_t *c1, int64_t *out) { // [0] / [1]: lines of set 0 / 1
+  unsigned long long a0 = 0, a1 = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    d += c0[i] != c1[i];
     a0 += c0[i] != 0;
     a1 += c1[i] != 0;
   }
-  if (d) atomicAdd((unsigned long long *)&out[0], d);
-  if (a0) atomicAdd((unsigned long long *)&out[1], a0);
-  if (a1) atomicAdd((unsigned long long *)&out[2], a1);
+  if (a0) atomicAdd((unsigned long long *)&out[0], a0);
+  if (a1) atomicAdd((unsigned long long *)&out[1], a1);
 }
 __global__ void k_fsi_mark(int32_t n, const int32_t *dof, uint8_t *taken) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -713,6 +710,10 @@ void fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int
   FsiState &F = ctx->fsi;
   if (!F.has_fields) throw Error(IFEM_E_BADPARAM, "ifem_fsi_find_fluid_bc: the solid carries no velocity / acceleration");
   if (ctx->indicator.n != (size_t)ctx->n_cells) throw Error(IFEM_E_BADPARAM, "ifem_fsi_find_fluid_bc: no cell indicator (ifem_fsi_update_indicator)");
+  if (ctx->n_cells >= (int64_t(1) << 27)) throw Error(IFEM_E_BADPARAM, "ifem_fsi_find_fluid_bc: more than 2^27 local cells");
+  if (cell_order)
+    for (int64_t c = 0; c < ctx->n_cells; ++c)
+      if (cell_order[c] < 0) throw Error(IFEM_E_BADPARAM, "ifem_fsi_find_fluid_bc: negative cell_order");
   hipStream_t st = ctx->stream;
   const int dim = ctx->dim, ncomp = dim * (dim + 1) / 2;
   const int64_t nUl = ctx->nUl, nloc = ctx->n_local;
@@ -764,6 +765,10 @@ void fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int
         IFEM_HIP_CHECK(hipMemsetAsync(ctx->is_c[w].p, 0, (size_t)nloc, st));
         IFEM_HIP_CHECK(hipMemsetAsync(ctx->cval[w].p, 0, (size_t)nloc * sizeof(double), st));
       }
+    for (int w = 0; w < 2; ++w) { // what the sets were, for their identity afterwards
+      if (F.prev[w].n != (size_t)nloc) F.prev[w].alloc((size_t)nloc);
+      IFEM_HIP_CHECK(hipMemcpyAsync(F.prev[w].p, ctx->is_c[w].p, (size_t)nloc, hipMemcpyDeviceToDevice, st));
+    }
     if (F.taken.n != (size_t)nloc) F.taken.alloc((size_t)nloc);
     hipLaunchKernelGGL(k_fsi_taken, grid_for(nloc), dim3(kBlock), 0, st, nloc, ctx->is_c[0].p, ctx->is_c[1].p, F.taken.p);
     if (ctx->hang.n) hipLaunchKernelGGL(k_fsi_mark, grid_for(ctx->hang.n), dim3(kBlock), 0, st, ctx->hang.n, ctx->hang.dof.p, F.taken.p);
@@ -778,23 +783,18 @@ void fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int
     A.cval0 = ctx->cval[0].p;
     A.cval1 = ctx->cval[1].p;
     launch_node_bc(ctx, A);
-    if (ctx->halo.nranks > 1 && nUl > ctx->nUo) {
+    if (ctx->halo.nranks > 1) {
       // a ghost dof carries its owner's line: the owner saw every cell that touches the node (a ghost may be the master of a
-      // local hanging node and lie in no local cell at all)
+      // local hanging node and lie in no local cell at all).  Every rank takes part, with or without ghosts of its own.
       DBuf<double> buf;
-      buf.alloc((size_t)dim * nUl);
+      buf.alloc((size_t)dim * std::max<int64_t>(nUl, 1));
       for (int what = 0; what < 2; ++what) {
         hipLaunchKernelGGL(k_fsi_lines_pack, grid_for(dim * nUl), dim3(kBlock), 0, st, dim * nUl, what, ctx->is_c[1].p, ctx->cval[1].p, buf.p);
         halo_exchange(ctx, buf.p);
-        hipLaunchKernelGGL(k_fsi_lines_unpack, grid_for(dim * (nUl - ctx->nUo)), dim3(kBlock), 0, st, dim * nUl, dim * ctx->nUo, what, buf.p,
-                           ctx->is_c[0].p, ctx->is_c[1].p, ctx->cval[1].p);
+        if (nUl > ctx->nUo)
+          hipLaunchKernelGGL(k_fsi_lines_unpack, grid_for(dim * (nUl - ctx->nUo)), dim3(kBlock), 0, st, dim * nUl, dim * ctx->nUo, what, buf.p,
+                             ctx->is_c[0].p, ctx->is_c[1].p, ctx->cval[1].p);
       }
-      IFEM_HIP_CHECK(hipStreamSynchronize(st));
-    } else if (ctx->halo.nranks > 1) {
-      DBuf<double> buf; // ranks without ghosts still take part in the exchanges
-      buf.alloc((size_t)dim * std::max<int64_t>(nUl, 1));
-      IFEM_HIP_CHECK(hipMemsetAsync(buf.p, 0, buf.n * sizeof(double), st));
-      for (int what = 0; what < 2; ++what) halo_exchange(ctx, buf.p);
       IFEM_HIP_CHECK(hipStreamSynchronize(st));
     }
     IFEM_HIP_CHECK(hipMemcpyAsync(h_cnt, F.counters.p, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
@@ -811,17 +811,20 @@ void fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int
     stats->n_not_found = (int64_t)nf;
   }
   if (nf != 0.0) throw Error(IFEM_E_BADPARAM, "Cannot find point in solid (mpi_fsi.cpp:526-533): " + std::to_string((int64_t)nf) + " support point(s)");
-  if (use_dirichlet_bc) { // identity of the two constrained-dof sets (ctx.hpp): one read-back when they hold the same dofs
-    IFEM_HIP_CHECK(hipMemsetAsync(F.counters.p + 5, 0, 3 * sizeof(int64_t), st));
-    hipLaunchKernelGGL(k_fsi_flags_compare, dim3(1024), dim3(kBlock), 0, st, nloc, ctx->is_c[0].p, ctx->is_c[1].p, F.counters.p + 5);
-    int64_t cmp[3];
-    IFEM_HIP_CHECK(hipMemcpyAsync(cmp, F.counters.p + 5, sizeof(cmp), hipMemcpyDeviceToHost, st));
-    std::vector<uint8_t> f1 = ctx->is_c[1].download(st); // synchronises
-    std::vector<uint8_t> f0 = cmp[0] == 0 ? f1 : ctx->is_c[0].download(st);
-    ctx->has_c[0] = cmp[1] != 0;
-    ctx->has_c[1] = cmp[2] != 0;
-    constraint_set_identity(ctx, 0, std::move(f0));
-    constraint_set_identity(ctx, 1, std::move(f1));
+  if (use_dirichlet_bc) { // identity of the two constrained-dof sets (ctx.hpp), in the order two ifem_set_constraints calls
+                          // would decide it: set 0 against (old 0, old 1), then set 1 against (old 1, new 0)
+    const DBuf<uint8_t> *pa[4] = {&ctx->is_c[0], &ctx->is_c[0], &ctx->is_c[1], &ctx->is_c[1]};
+    const DBuf<uint8_t> *pb[4] = {&F.prev[0], &F.prev[1], &F.prev[1], &ctx->is_c[0]};
+    double d[4];
+    int64_t any[2] = {0, 0};
+    IFEM_HIP_CHECK(hipMemsetAsync(F.counters.p + 5, 0, 2 * sizeof(int64_t), st));
+    hipLaunchKernelGGL(k_fsi_any, dim3(1024), dim3(kBlock), 0, st, nloc, ctx->is_c[0].p, ctx->is_c[1].p, F.counters.p + 5);
+    IFEM_HIP_CHECK(hipMemcpyAsync(any, F.counters.p + 5, sizeof(any), hipMemcpyDeviceToHost, st));
+    flags_differ(ctx, 4, pa, pb, d); // synchronises
+    ctx->has_c[0] = any[0] != 0;
+    ctx->has_c[1] = any[1] != 0;
+    constraint_set_identity(ctx, 0, d[0] != 0.0, d[1] != 0.0);
+    constraint_set_identity(ctx, 1, d[2] != 0.0, d[3] != 0.0);
   }
   if (ctx->halo.nranks > 1) { // ghosts take the owner's values (fsi_acceleration and fsi_stress are ghosted vectors)
     if (!use_dirichlet_bc) halo_exchange(ctx, ctx->vec[IFEM_VEC_FSI_ACC].p);

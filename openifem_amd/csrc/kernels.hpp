@@ -24,8 +24,10 @@ void launch_ins_assemble_geometry(ifem_ctx *ctx, const ifem_ins_params *p, int u
 void fsi_set_solid(ifem_ctx *ctx, const ifem_fsi_solid *s);
 void fsi_update_indicator(ifem_ctx *ctx, int32_t *host_out, int64_t *n_artificial);
 void fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int32_t *cell_order, ifem_fsi_stats *stats);
-// api.hip: identity of the constrained-dof set `which` after its flags changed (f = the new flags over the local dofs)
-void constraint_set_identity(ifem_ctx *ctx, int which, std::vector<uint8_t> &&f);
+// api.hip: do the flag arrays of pair k differ (compared on the device); identity of the constrained-dof set `which` after
+// its flags changed
+void flags_differ(ifem_ctx *ctx, int npairs, const DBuf<uint8_t> *const *a, const DBuf<uint8_t> *const *b, double *out);
+void constraint_set_identity(ifem_ctx *ctx, int which, bool differs_self, bool differs_other);
 
 // assemble_scns.hip
 void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonzero);

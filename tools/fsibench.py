@@ -66,6 +66,18 @@ def device_leg(L, ctx, capi, n_cells, solid, dt=1e-3, reps=3):
     def chk(rc):
         if rc < 0:
             raise RuntimeError(L.ifem_last_error().decode())
+    # fluid_solver.make_constraints() of every FSI step (:1191): the boundary lines the context holds, set again
+    n_local = L.ifem_n_local_dofs(ctx)
+    flags, vals = np.zeros(n_local, np.uint8), np.zeros(n_local)
+    chk(L.ifem_get_constraints(ctx, 1, _ptr(flags), _ptr(vals)))
+    bd = np.nonzero(flags)[0].astype(np.int32)
+    bv = np.ascontiguousarray(vals[bd])
+    t_mc = []
+    for _ in range(reps):
+        t0 = time.time()
+        chk(L.ifem_set_constraints(ctx, 1, len(bd), _ptr(bd), _ptr(bv)))
+        chk(L.ifem_set_constraints(ctx, 0, len(bd), _ptr(bd), None))
+        t_mc.append(time.time() - t0)
     s = capi.FsiSolid(len(solid["vertices"]), len(solid["cells"]), 0, _ptr(solid["vertices"]), _ptr(solid["cells"]), None,
                       _ptr(solid["velocity"]), _ptr(solid["acceleration"]), _ptr(solid["stress"]))
     t0 = time.time()
@@ -87,13 +99,15 @@ def device_leg(L, ctx, capi, n_cells, solid, dt=1e-3, reps=3):
     t0 = time.time()
     chk(L.ifem_fsi_find_fluid_bc(ctx, dt, 1, None, C.byref(st)))
     t_dir.append(time.time() - t0)
-    return {"solid_cells": len(solid["cells"]), "fluid_cells": int(n_cells), "set_solid_ms": t_set * 1e3,
+    return {"solid_cells": len(solid["cells"]), "fluid_cells": int(n_cells), "boundary_lines": int(len(bd)),
+            "set_constraints_x2_ms": float(np.median(t_mc)) * 1e3, "set_solid_ms": t_set * 1e3,
             "update_indicator_ms": float(np.median(t_ind[1:])) * 1e3, "n_artificial_cells": cnt.value,
             "find_fluid_bc_ms": float(np.median(t_acc[1:])) * 1e3, **acc_stats,
             "find_fluid_bc_dirichlet_ms": t_dir[0] * 1e3, "dirichlet_candidates": st.n_candidates, "dirichlet_inside": st.n_inside,
             "dirichlet_lines": st.n_lines,
             "note": "wall clock of the synchronous C-ABI calls; fsi_stress + fsi_acceleration mode (use_dirichlet_bc = 0) and the "
-                    "Dirichlet-line mode, the latter including the read-back of the flags for the constrained-dof-set identity"}
+                    "Dirichlet-line mode (merge into both constraint sets + their identity, compared on the device); "
+                    "set_constraints_x2 = make_constraints of one FSI step (both sets re-made from their line lists)"}
 
 
 def cpu_leg(n, solid, dt=1e-3):
