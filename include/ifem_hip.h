@@ -373,6 +373,15 @@ typedef struct {
  * rank).  On several ranks pass the global active-cell index: every rank then picks the same cell for the nodes it
  * owns (the reference's VectorOperation::insert leaves that choice to message order) and ghosts take the owner's value. */
 int ifem_fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int32_t *cell_order, ifem_fsi_stats *stats);
+/* The other direction of the coupling: the fluid solution at points of the solid -- Utils::GridInterpolator(fluid
+ * dof_handler, point).point_value(present_solution) and the scalar interpolator of the nodal viscous stress in the same
+ * cell, as FSI::find_solid_bc (:727-760: sigma = -p I + viscous stress at the solid's boundary vertices) and
+ * FSI::update_solid_displacement (:268-271) use them.  Reads IFEM_VEC_PRESENT and the projected stress of the last
+ * ifem_update_stress on the device; only the n points and their results cross the bus (instead of the whole solution).
+ * values [n][dim+1] = (u, p); stress [n][dim][dim] or NULL; cell [n] = the local cell around the point (smallest
+ * distance_to_unit_cell below 1e-10, lowest index on ties) or -1 with zero values, which is what point_value returns for a
+ * point outside the locally owned cells.  On several ranks a point is found by the rank(s) whose local cells hold it. */
+int ifem_fsi_fluid_at_points(ifem_ctx *ctx, int32_t n, const double *points, double *values, double *stress, int32_t *cell);
 /* read-back hooks: nodal fsi_stress [dim(dim+1)/2][n_unodes_local]; constraint object `which`: flags and inhomogeneities
  * over the local dofs [n_local] (either pointer may be NULL) */
 int ifem_fsi_get_stress(ifem_ctx *ctx, double *host_out);

@@ -114,7 +114,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof",
            "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag",
            "ifem_fsi_set_solid", "ifem_fsi_update_indicator", "ifem_fsi_find_fluid_bc", "ifem_fsi_get_stress",
-           "ifem_get_constraints"]
+           "ifem_get_constraints", "ifem_fsi_fluid_at_points"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -192,6 +192,7 @@ def load():
     L.ifem_fsi_update_indicator.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     L.ifem_fsi_find_fluid_bc.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.POINTER(FsiStats)]
     L.ifem_fsi_get_stress.argtypes = [C.c_void_p, C.c_void_p]
+    L.ifem_fsi_fluid_at_points.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifem_get_constraints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.ifem_abi_sizeof.argtypes = [C.c_int]
     L.ifem_abi_sizeof.restype = C.c_int64
@@ -436,6 +437,15 @@ class Context:
         st = FsiStats()
         self._chk(self.L.ifem_fsi_find_fluid_bc(self.h, dt, int(use_dirichlet_bc), _ptr(order), C.byref(st)))
         return st
+
+    def fsi_fluid_at_points(self, points, with_stress=True):
+        """(u, p) [n, dim+1], viscous stress [n, dim, dim] and the local cell [n] at `points` (find_solid_bc, mpi_fsi.cpp:727-760)"""
+        pts = np.ascontiguousarray(points, float).reshape(-1, self.dim)
+        n = len(pts)
+        vals, cell = np.zeros((n, self.dim + 1)), np.zeros(n, np.int32)
+        st = np.zeros((n, self.dim, self.dim)) if with_stress else None
+        self._chk(self.L.ifem_fsi_fluid_at_points(self.h, n, _ptr(pts), _ptr(vals), _ptr(st), _ptr(cell)))
+        return vals, st, cell
 
     def fsi_get_stress(self):
         out = np.zeros((self.dim * (self.dim + 1) // 2, self.n_u // self.dim))

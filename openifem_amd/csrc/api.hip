@@ -270,6 +270,11 @@ int ifem_fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const
   ifem::fsi_find_fluid_bc(ctx, dt, use_dirichlet_bc, cell_order, stats);
   IFEM_API_END
 }
+int ifem_fsi_fluid_at_points(ifem_ctx *ctx, int32_t n, const double *points, double *values, double *stress, int32_t *cell) {
+  IFEM_API_BEGIN
+  ifem::fsi_fluid_at_points(ctx, n, points, values, stress, cell);
+  IFEM_API_END
+}
 int ifem_fsi_get_stress(ifem_ctx *ctx, double *host_out) {
   IFEM_API_BEGIN
   const size_t n = (size_t)(ctx->dim * (ctx->dim + 1) / 2) * ctx->nUl;

@@ -186,6 +186,11 @@ struct FsiState {
   DBuf<uint8_t> taken;             // dofs that already carry a boundary or hanging line
   DBuf<uint8_t> prev[2];           // the flags of the two constraint sets before the merge (identity of the sets afterwards)
   DBuf<int64_t> counters;          // [8] device counters
+  // uniform grid over the local fluid cells (point evaluation of the fluid solution, built on first use)
+  DBuf<int32_t> fbin_ptr, fbin_cells;
+  int fG[3] = {1, 1, 1};
+  double fbox_lo[3] = {0, 0, 0}, finv_h[3] = {0, 0, 0};
+  bool fbins_valid = false;
 };
 } // namespace ifem
 

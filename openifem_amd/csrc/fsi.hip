@@ -528,6 +528,148 @@ __global__ void k_fsi_lines_unpack(int64_t n, int64_t n_owned, int what, const d
   else cval1[i] = buf[i];
 }
 
+// ---- the other direction: the fluid solution at points of the solid (find_solid_bc :727-760, update_solid_displacement
+// :268-271).  A uniform grid over the bounding box of the local fluid cells, built once per context on the device
+// (count, host prefix sum, fill), lists the cells whose bounding box meets a bin; a lane per point walks its bin.
+template <int DIM> struct FluidBins {
+  const int32_t *ptr, *cells;
+  double lo[3], inv_h[3];
+  int G[3];
+};
+template <int DIM> __device__ inline void cell_bin_range(const double *X, const FluidBins<DIM> &B, int *lo, int *hi) {
+  constexpr int NV = 1 << DIM;
+  double ext = 0, blo[DIM], bhi[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    blo[d] = bhi[d] = X[d];
+    for (int v = 1; v < NV; ++v) {
+      blo[d] = fmin(blo[d], X[v * DIM + d]);
+      bhi[d] = fmax(bhi[d], X[v * DIM + d]);
+    }
+    ext = fmax(ext, bhi[d] - blo[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    const int a = (int)floor((blo[d] - 1e-8 * ext - B.lo[d]) * B.inv_h[d]), b = (int)floor((bhi[d] + 1e-8 * ext - B.lo[d]) * B.inv_h[d]);
+    lo[d] = max(0, min(B.G[d] - 1, a));
+    hi[d] = max(0, min(B.G[d] - 1, b));
+  }
+}
+__global__ void k_fluid_minmax(int64_t n, int dim, const double *v, double *partial) { // [blocks][2*dim]: min, max per direction
+  __shared__ double s[256];
+  for (int d = 0; d < dim; ++d)
+    for (int mm = 0; mm < 2; ++mm) {
+      double a = mm ? -1e300 : 1e300;
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        a = mm ? fmax(a, v[i * dim + d]) : fmin(a, v[i * dim + d]);
+      s[threadIdx.x] = a;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] = mm ? fmax(s[threadIdx.x], s[threadIdx.x + o]) : fmin(s[threadIdx.x], s[threadIdx.x + o]);
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 2 * dim + 2 * d + mm] = s[0];
+      __syncthreads();
+    }
+}
+template <int DIM> __global__ void k_fluid_bin(int pass, int64_t n_cells, const double *vcoords, FluidBins<DIM> B, int32_t *count_or_cursor, int32_t *cells) {
+  constexpr int NV = 1 << DIM;
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cells) return;
+  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  cell_bin_range<DIM>(vcoords + (size_t)c * NV * DIM, B, lo, hi);
+  for (int k = lo[2]; k <= hi[2]; ++k)
+    for (int j = lo[1]; j <= hi[1]; ++j)
+      for (int i = lo[0]; i <= hi[0]; ++i) {
+        const size_t b = (size_t)i + (size_t)B.G[0] * ((size_t)j + (size_t)B.G[1] * k);
+        const int32_t pos = atomicAdd(&count_or_cursor[b], 1);
+        if (pass == 1) cells[pos] = (int32_t)c;
+      }
+}
+template <int DIM> __global__ void k_fluid_at_points(int32_t n, const double *pts, int64_t n_cells, int kv, int nu, int64_t nUl, const double *vcoords,
+                                                     const int32_t *cell_unodes, const int32_t *cell_pnodes, const double *present,
+                                                     const double *stress, FluidBins<DIM> B, double *values, double *st_out, int32_t *cell_out) {
+  constexpr int NV = 1 << DIM;
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double p[DIM];
+  int b = 0, stride = 1;
+  bool in_box = true;
+  for (int d = 0; d < DIM; ++d) {
+    p[d] = pts[(size_t)i * DIM + d];
+    const double t = (p[d] - B.lo[d]) * B.inv_h[d];
+    if (!(t > -1.0 && t < B.G[d] + 1.0)) in_box = false; // far outside: no bin to ask (NaN lands here too)
+    int k = (int)floor(t);
+    k = k < 0 ? 0 : (k > B.G[d] - 1 ? B.G[d] - 1 : k);
+    b += k * stride;
+    stride *= B.G[d];
+  }
+  int32_t best = -1;
+  double best_d = 1e300, bxi[DIM];
+  if (in_box)
+    for (int32_t q = B.ptr[b]; q < B.ptr[b + 1]; ++q) {
+      const int32_t c = B.cells[q];
+      double X[NV * DIM], ext = 0, lo[DIM], hi[DIM], xi[DIM];
+      for (int k = 0; k < NV * DIM; ++k) X[k] = vcoords[(size_t)c * NV * DIM + k];
+      bool out = false;
+      for (int d = 0; d < DIM; ++d) {
+        lo[d] = hi[d] = X[d];
+        for (int v = 1; v < NV; ++v) {
+          lo[d] = fmin(lo[d], X[v * DIM + d]);
+          hi[d] = fmax(hi[d], X[v * DIM + d]);
+        }
+        ext = fmax(ext, hi[d] - lo[d]);
+      }
+      for (int d = 0; d < DIM; ++d)
+        if (p[d] < lo[d] - 1e-9 * ext || p[d] > hi[d] + 1e-9 * ext) out = true;
+      if (out || !real_to_unit<DIM>(X, p, xi)) continue;
+      double dd = 0.0;
+      for (int d = 0; d < DIM; ++d) {
+        if (-xi[d] > dd) dd = -xi[d];
+        else if (xi[d] - 1.0 > dd) dd = xi[d] - 1.0;
+      }
+      if (dd < best_d || (dd == best_d && c < best)) { // the bin lists are unordered: the tie rule is explicit
+        best_d = dd;
+        best = c;
+        for (int d = 0; d < DIM; ++d) bxi[d] = xi[d];
+      }
+    }
+  for (int k = 0; k < DIM + 1; ++k) values[(size_t)i * (DIM + 1) + k] = 0.0;
+  if (st_out)
+    for (int k = 0; k < DIM * DIM; ++k) st_out[(size_t)i * DIM * DIM + k] = 0.0;
+  if (best < 0 || !(best_d < 1e-10)) {
+    cell_out[i] = -1;
+    return;
+  }
+  cell_out[i] = best;
+  double L[DIM][3], dL[DIM][3], acc[DIM + 1], sacc[DIM * DIM];
+  for (int d = 0; d < DIM; ++d) {
+    bxi[d] = bxi[d] < 0.0 ? 0.0 : (bxi[d] > 1.0 ? 1.0 : bxi[d]);
+    lagrange(kv, bxi[d], L[d], dL[d]);
+  }
+  for (int k = 0; k < DIM + 1; ++k) acc[k] = 0;
+  for (int k = 0; k < DIM * DIM; ++k) sacc[k] = 0;
+  const int n1 = kv + 1;
+  for (int a = 0; a < nu; ++a) {
+    int r = a;
+    double w = 1;
+    for (int d = 0; d < DIM; ++d) {
+      w *= L[d][r % n1];
+      r /= n1;
+    }
+    const int32_t node = cell_unodes[(size_t)best * nu + a];
+    for (int c = 0; c < DIM; ++c) acc[c] += w * present[(size_t)DIM * node + c];
+    if (st_out && stress)
+      for (int k = 0; k < DIM * DIM; ++k) sacc[k] += w * stress[(size_t)k * nUl + node];
+  }
+  double Nq[NV];
+  q1_shape<DIM>(bxi, Nq, nullptr);
+  for (int v = 0; v < NV; ++v) acc[DIM] += Nq[v] * present[(size_t)DIM * nUl + cell_pnodes[(size_t)best * NV + v]];
+  for (int k = 0; k < DIM + 1; ++k) values[(size_t)i * (DIM + 1) + k] = acc[k];
+  if (st_out)
+    for (int k = 0; k < DIM * DIM; ++k) st_out[(size_t)i * DIM * DIM + k] = sacc[k];
+}
+
 inline dim3 grid_for(int64_t n, int block = kBlock) { return dim3((unsigned)std::max<int64_t>(1, (n + block - 1) / block)); }
 
 template <int DIM> SolidView<DIM> view_of(const ifem_ctx *ctx) {
@@ -841,6 +983,97 @@ void fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int
       IFEM_HIP_CHECK(hipStreamSynchronize(st));
     }
   }
+  IFEM_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+
+namespace {
+template <int DIM> FluidBins<DIM> fluid_bins_of(const ifem_ctx *ctx) {
+  const FsiState &F = ctx->fsi;
+  FluidBins<DIM> B;
+  B.ptr = F.fbin_ptr.p;
+  B.cells = F.fbin_cells.p;
+  for (int d = 0; d < 3; ++d) {
+    B.lo[d] = F.fbox_lo[d];
+    B.inv_h[d] = F.finv_h[d];
+    B.G[d] = F.fG[d];
+  }
+  return B;
+}
+void build_fluid_bins(ifem_ctx *ctx) {
+  FsiState &F = ctx->fsi;
+  if (F.fbins_valid) return;
+  hipStream_t st = ctx->stream;
+  const int dim = ctx->dim, nv = 1 << dim;
+  const int blocks = 256;
+  DBuf<double> partial;
+  partial.alloc((size_t)blocks * 2 * dim);
+  hipLaunchKernelGGL(k_fluid_minmax, dim3(blocks), dim3(256), 0, st, ctx->n_cells * nv, dim, ctx->vcoords.p, partial.p);
+  std::vector<double> hp = partial.download(st);
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  for (int d = 0; d < dim; ++d) {
+    lo[d] = 1e300;
+    hi[d] = -1e300;
+    for (int b = 0; b < blocks; ++b) {
+      lo[d] = std::min(lo[d], hp[(size_t)b * 2 * dim + 2 * d]);
+      hi[d] = std::max(hi[d], hp[(size_t)b * 2 * dim + 2 * d + 1]);
+    }
+  }
+  const int g = std::max(1, std::min(256, (int)std::lround(std::pow((double)ctx->n_cells, 1.0 / dim))));
+  int64_t nb = 1;
+  for (int d = 0; d < 3; ++d) {
+    F.fG[d] = d < dim ? g : 1;
+    F.fbox_lo[d] = lo[d];
+    F.finv_h[d] = (d < dim && hi[d] > lo[d]) ? F.fG[d] / (hi[d] - lo[d]) : 0.0;
+    nb *= F.fG[d];
+  }
+  DBuf<int32_t> count;
+  count.alloc((size_t)nb);
+  IFEM_HIP_CHECK(hipMemsetAsync(count.p, 0, (size_t)nb * sizeof(int32_t), st));
+  F.fbin_ptr.alloc((size_t)nb + 1); // so that fluid_bins_of has its pointers; filled below
+  const dim3 grid = grid_for(ctx->n_cells);
+  if (dim == 2) hipLaunchKernelGGL(k_fluid_bin<2>, grid, dim3(kBlock), 0, st, 0, ctx->n_cells, ctx->vcoords.p, fluid_bins_of<2>(ctx), count.p, (int32_t *)nullptr);
+  else hipLaunchKernelGGL(k_fluid_bin<3>, grid, dim3(kBlock), 0, st, 0, ctx->n_cells, ctx->vcoords.p, fluid_bins_of<3>(ctx), count.p, (int32_t *)nullptr);
+  std::vector<int32_t> hc = count.download(st), ptr((size_t)nb + 1, 0);
+  int64_t total = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    ptr[b] = (int32_t)total;
+    total += hc[b];
+    if (total > INT32_MAX) throw Error(IFEM_E_BADPARAM, "fluid bins: more than 2^31 (cell, bin) pairs");
+  }
+  ptr[nb] = (int32_t)total;
+  F.fbin_ptr.upload(ptr.data(), ptr.size(), st);
+  F.fbin_cells.alloc((size_t)std::max<int64_t>(total, 1));
+  IFEM_HIP_CHECK(hipMemcpyAsync(count.p, F.fbin_ptr.p, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToDevice, st)); // cursors
+  if (dim == 2) hipLaunchKernelGGL(k_fluid_bin<2>, grid, dim3(kBlock), 0, st, 1, ctx->n_cells, ctx->vcoords.p, fluid_bins_of<2>(ctx), count.p, F.fbin_cells.p);
+  else hipLaunchKernelGGL(k_fluid_bin<3>, grid, dim3(kBlock), 0, st, 1, ctx->n_cells, ctx->vcoords.p, fluid_bins_of<3>(ctx), count.p, F.fbin_cells.p);
+  IFEM_HIP_CHECK(hipStreamSynchronize(st));
+  F.fbins_valid = true;
+}
+} // namespace
+
+void fsi_fluid_at_points(ifem_ctx *ctx, int32_t n, const double *points, double *values, double *stress, int32_t *cell) {
+  if (n < 0 || (n > 0 && (!points || !values || !cell))) throw Error(IFEM_E_BADPARAM, "ifem_fsi_fluid_at_points: null argument");
+  if (n == 0) return;
+  build_fluid_bins(ctx);
+  hipStream_t st = ctx->stream;
+  const int dim = ctx->dim;
+  DBuf<double> d_pts, d_val, d_st;
+  DBuf<int32_t> d_cell;
+  d_pts.upload(points, (size_t)n * dim, st);
+  d_val.alloc((size_t)n * (dim + 1));
+  d_cell.alloc((size_t)n);
+  if (stress) d_st.alloc((size_t)n * dim * dim);
+  const double *fl = (ctx->stress_valid && ctx->stress.n == (size_t)dim * dim * ctx->nUl) ? ctx->stress.p : nullptr;
+  if (dim == 2)
+    hipLaunchKernelGGL(k_fluid_at_points<2>, grid_for(n, 128), dim3(128), 0, st, n, d_pts.p, ctx->n_cells, ctx->kv, ctx->nu, ctx->nUl, ctx->vcoords.p,
+                       ctx->cell_unodes.p, ctx->cell_pnodes.p, ctx->vec[IFEM_VEC_PRESENT].p, fl, fluid_bins_of<2>(ctx), d_val.p, d_st.p, d_cell.p);
+  else
+    hipLaunchKernelGGL(k_fluid_at_points<3>, grid_for(n, 128), dim3(128), 0, st, n, d_pts.p, ctx->n_cells, ctx->kv, ctx->nu, ctx->nUl, ctx->vcoords.p,
+                       ctx->cell_unodes.p, ctx->cell_pnodes.p, ctx->vec[IFEM_VEC_PRESENT].p, fl, fluid_bins_of<3>(ctx), d_val.p, d_st.p, d_cell.p);
+  IFEM_HIP_CHECK(hipMemcpyAsync(values, d_val.p, (size_t)n * (dim + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+  IFEM_HIP_CHECK(hipMemcpyAsync(cell, d_cell.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  if (stress) IFEM_HIP_CHECK(hipMemcpyAsync(stress, d_st.p, (size_t)n * dim * dim * sizeof(double), hipMemcpyDeviceToHost, st));
   IFEM_HIP_CHECK(hipStreamSynchronize(st));
 }
 

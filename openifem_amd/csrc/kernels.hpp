@@ -24,6 +24,7 @@ void launch_ins_assemble_geometry(ifem_ctx *ctx, const ifem_ins_params *p, int u
 void fsi_set_solid(ifem_ctx *ctx, const ifem_fsi_solid *s);
 void fsi_update_indicator(ifem_ctx *ctx, int32_t *host_out, int64_t *n_artificial);
 void fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int32_t *cell_order, ifem_fsi_stats *stats);
+void fsi_fluid_at_points(ifem_ctx *ctx, int32_t n, const double *points, double *values, double *stress, int32_t *cell);
 // api.hip: do the flag arrays of pair k differ (compared on the device); identity of the constrained-dof set `which` after
 // its flags changed
 void flags_differ(ifem_ctx *ctx, int npairs, const DBuf<uint8_t> *const *a, const DBuf<uint8_t> *const *b, double *out);

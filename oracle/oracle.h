@@ -186,6 +186,11 @@ int32_t orc_fsi_find_fluid_bc(const orc_mesh *m, const orc_fsi_solid *s, double 
                               const double *present, const double *fluid_stress, double *fsi_stress, double *fsi_acc,
                               int32_t *line_flag, double *line_val);
 
+/* the fluid solution (u, p) and the nodal viscous stress at points of the solid (find_solid_bc :727-760,
+ * update_solid_displacement :268-271): values [n][dim+1], stress [n][dim][dim] (may be NULL), cell [n] (-1: not found) */
+void orc_fsi_fluid_at_points(const orc_mesh *m, const double *present, const double *fluid_stress, int32_t n,
+                             const double *points, double *values, double *stress, int32_t *cell);
+
 /* FE tables for cross-checks: phi[q][a], dphi[q][a][dim] on the reference cell, weights */
 int32_t orc_fe_tables(int32_t dim, int32_t k, int32_t nq1d, double *phi, double *dphi, double *w, double *qp);
 

@@ -388,3 +388,70 @@ int32_t orc_fsi_find_fluid_bc(const orc_mesh *m, const orc_fsi_solid *s, double 
   free(touched);
   return not_found;
 }
+
+/* ---- the other direction of the coupling: the fluid solution at points of the solid.
+ * Utils::GridInterpolator<dim, BlockVector>(fluid dof_handler, point).point_value(present_solution) as FSI::find_solid_bc
+ * (mpi_fsi.cpp:727-733) and FSI::update_solid_displacement (:268-271, VectorTools::point_value) use it, and the scalar
+ * interpolator of the nodal viscous stress in the same cell (:737-760).  The cell: find_active_cell_around_point, restated
+ * as for the solid (smallest distance of the unit-cell image, lowest cell index on ties, accepted below 1e-10, projected).
+ * values [n][dim+1] = (u, p), stress [n][dim][dim], cell [n] = the cell or -1 (values 0, as point_value returns). */
+void orc_fsi_fluid_at_points(const orc_mesh *m, const double *present, const double *fluid_stress, int32_t n,
+                             const double *points, double *values, double *stress, int32_t *cell_out) {
+  const int dim = m->dim, nv = nvert(dim), n1 = m->kv + 1;
+  int nu = 1;
+  for (int d = 0; d < dim; ++d) nu *= n1;
+  const int32_t N = m->n_unodes;
+  for (int32_t i = 0; i < n; ++i) {
+    const double *p = points + (size_t)i * dim;
+    int32_t best = -1;
+    double best_d = 1e300, bxi[3] = {0, 0, 0}, xi[3];
+    for (int32_t c = 0; c < m->n_cells; ++c) {
+      const double *X = m->vcoords + (size_t)c * nv * dim;
+      double ext = 0, lo[3], hi[3];
+      int out = 0;
+      for (int d = 0; d < dim; ++d) {
+        lo[d] = hi[d] = X[d];
+        for (int v = 1; v < nv; ++v) {
+          if (X[v * dim + d] < lo[d]) lo[d] = X[v * dim + d];
+          if (X[v * dim + d] > hi[d]) hi[d] = X[v * dim + d];
+        }
+        if (hi[d] - lo[d] > ext) ext = hi[d] - lo[d];
+      }
+      for (int d = 0; d < dim; ++d)
+        if (p[d] < lo[d] - 1e-9 * ext || p[d] > hi[d] + 1e-9 * ext) out = 1;
+      if (out || !orc_fsi_real_to_unit(dim, X, p, xi)) continue;
+      const double dd = dist_unit(dim, xi);
+      if (dd < best_d) {
+        best_d = dd;
+        best = c;
+        for (int d = 0; d < dim; ++d) bxi[d] = xi[d];
+      }
+    }
+    for (int k = 0; k < dim + 1; ++k) values[(size_t)i * (dim + 1) + k] = 0.0;
+    if (stress)
+      for (int k = 0; k < dim * dim; ++k) stress[(size_t)i * dim * dim + k] = 0.0;
+    if (best < 0 || !(best_d < 1e-10)) {
+      cell_out[i] = -1;
+      continue;
+    }
+    cell_out[i] = best;
+    for (int d = 0; d < dim; ++d) bxi[d] = bxi[d] < 0.0 ? 0.0 : (bxi[d] > 1.0 ? 1.0 : bxi[d]);
+    double L[3][3], dL[3][3], Nq[8];
+    for (int d = 0; d < dim; ++d) lagrange(m->kv, bxi[d], L[d], dL[d]);
+    for (int b = 0; b < nu; ++b) {
+      int r = b;
+      double w = 1;
+      for (int d = 0; d < dim; ++d) {
+        w *= L[d][r % n1];
+        r /= n1;
+      }
+      const int32_t node = m->cell_unodes[(size_t)best * nu + b];
+      for (int c = 0; c < dim; ++c) values[(size_t)i * (dim + 1) + c] += w * present[(size_t)dim * node + c];
+      if (stress && fluid_stress)
+        for (int k = 0; k < dim * dim; ++k) stress[(size_t)i * dim * dim + k] += w * fluid_stress[(size_t)k * N + node];
+    }
+    q1_shape(dim, bxi, Nq, NULL);
+    for (int v = 0; v < nv; ++v)
+      values[(size_t)i * (dim + 1) + dim] += Nq[v] * present[(size_t)dim * N + m->cell_pnodes[(size_t)best * nv + v]];
+  }
+}

@@ -108,6 +108,8 @@ def _bind(L):
     L.orc_fsi_find_fluid_bc.restype = C.c_int32
     L.orc_fsi_find_fluid_bc.argtypes = [C.POINTER(_Mesh), C.POINTER(_Solid), C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_fsi_fluid_at_points.argtypes = [C.POINTER(_Mesh), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]
     L.orc_fe_tables.restype = C.c_int32
     L.orc_fe_tables.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
@@ -366,3 +368,16 @@ def fsi_find_fluid_bc(mesh, solid, indicator, dt, use_dirichlet_bc, present, flu
     nf = S.L.orc_fsi_find_fluid_bc(C.byref(m), C.byref(S.c), dt, int(use_dirichlet_bc), _ptr(present), _ptr(fl), _ptr(fsi_stress),
                                    _ptr(acc), _ptr(flag), _ptr(val))
     return acc, flag, val, nf
+
+
+def fsi_fluid_at_points(mesh, present, fluid_stress, points):
+    """(u, p) [n, dim+1], viscous stress [n, dim, dim] and the fluid cell [n] at `points` (find_solid_bc, mpi_fsi.cpp:727-760)"""
+    L = lib()
+    m = _cmesh(mesh)
+    pts = np.ascontiguousarray(points, float).reshape(-1, mesh.dim)
+    n = len(pts)
+    vals, st, cell = np.zeros((n, mesh.dim + 1)), np.zeros((n, mesh.dim, mesh.dim)), np.zeros(n, np.int32)
+    present = np.ascontiguousarray(present, float)
+    fl = None if fluid_stress is None else np.ascontiguousarray(fluid_stress, float)
+    L.orc_fsi_fluid_at_points(C.byref(m), _ptr(present), _ptr(fl), n, _ptr(pts), _ptr(vals), _ptr(st), _ptr(cell))
+    return vals, st, cell

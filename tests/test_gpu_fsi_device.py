@@ -190,3 +190,58 @@ def test_device_fsi_inputs_on_four_virtual_ranks(kind, use_dirichlet_bc):
 
     res = run_virtual_ranks(capi, parts, work)
     assert sum(res) > 0
+
+
+@pytest.mark.parametrize("kind", ["box2_q1", "box2_q2", "hang2_q1", "box3_q1", "box3_q2"])
+def test_fluid_values_at_solid_points_match_oracle(kind):
+    """ifem_fsi_fluid_at_points: (u, p) and the projected viscous stress at the solid's vertices plus points outside the
+    fluid mesh (find_solid_bc, mpi_fsi.cpp:727-760; update_solid_displacement, :268-271) -- same cell, values to 1e-12"""
+    from openifem_amd import capi
+    m, s, present, rng = _case(kind)
+    dim = m.dim
+    ctx = capi.Context(dim, m.kv, m.vcoords, m.cell_unodes, m.cell_pnodes, m.cell_face_bid, m.n_unodes, m.n_pnodes)
+    ctx.vec_set(capi.VEC_PRESENT, present)
+    hi = np.array([1.0, 0.8, 0.6][:dim])
+    pts = np.concatenate([s.vertices, rng.uniform(-0.1, 1.1, (200, dim)) * hi])
+    # before any update_stress the projected stress is zero, as fluid_solver.stress is
+    v0, st0, c0 = ctx.fsi_fluid_at_points(pts)
+    assert not st0.any()
+    stress = ctx.update_stress(0.7)
+    vo, so, co = orc.fsi_fluid_at_points(m, present, stress, pts)
+    v, st, c = ctx.fsi_fluid_at_points(pts)
+    assert (c == co).all() and (c0 == co).all() and (co >= 0).sum() > len(s.vertices) and (co < 0).sum() > 10
+    assert np.abs(v - vo).max() < 1e-12 * np.abs(vo).max() and np.abs(v0 - vo).max() < 1e-12 * np.abs(vo).max()
+    assert np.abs(st - so).max() < 1e-12 * np.abs(so).max()
+    assert not v[co < 0].any() and not st[co < 0].any()
+    ctx.close()
+
+
+def test_fluid_values_at_solid_points_on_four_virtual_ranks():
+    """every point of the mesh is found by at least one rank, with the single-context cell and values"""
+    from openifem_amd import capi
+    m, s, present, rng = _case("hang2_q1")
+    stress = orc.System(m).update_stress(0.7, present)
+    pts = np.concatenate([s.vertices, rng.uniform(-0.1, 1.1, (150, 2)) * np.array([1.0, 0.8])])
+    vo, so, co = orc.fsi_fluid_at_points(m, present, stress, pts)
+    c = m.vcoords.mean(axis=1)
+    parts = partition_mesh(m, (c[:, 0] > 0.52).astype(int) + 2 * (c[:, 1] > 0.41).astype(int), 4)
+
+    def work(rank, P, ctx):
+        if len(P.hang_dof):
+            ctx.set_hanging_constraints(P.hang_dof, P.hang_ptr, P.hang_master, P.hang_weight)
+        ctx.vec_set(capi.VEC_PRESENT, present[P.ext_gdof])
+        ctx.update_stress(0.7)
+        v, st, cl = ctx.fsi_fluid_at_points(pts)
+        found = cl >= 0
+        gc = np.where(found, P.cells[np.maximum(cl, 0)], -1)
+        # a point found here lies in that cell on the single context too; unless two local cells tie (a shared face), it is the same
+        assert np.abs(v[found] - vo[found]).max() < 1e-12 * np.abs(vo).max()
+        assert np.abs(st[found] - so[found]).max() < 1e-11 * np.abs(so).max()
+        assert (co[found] >= 0).all() and not v[~found].any()
+        return gc
+
+    res = run_virtual_ranks(capi, parts, work)
+    found_any = np.stack([r >= 0 for r in res]).any(axis=0)
+    assert (found_any == (co >= 0)).all()
+    lowest = np.min(np.where(np.stack(res) >= 0, np.stack(res), m.n_cells), axis=0)
+    assert (lowest[co >= 0] == co[co >= 0]).all()  # the lowest cell over the ranks is the single-context cell

@@ -161,3 +161,46 @@ def test_find_fluid_bc_closed_form_on_affine_fields(kind, use_dirichlet_bc):
         want = (x @ Gv.T + 0.2) - v
         assert np.abs(val.reshape(-1, dim)[lines] - want[lines]).max() < 1e-12
         assert not acc.any()
+
+
+@pytest.mark.parametrize("kind", ["box2_q2", "hang2_q1", "box3_q2"])
+def test_fluid_point_values_reproduce_the_fe_space(kind):
+    """the fluid solution at points of the solid (find_solid_bc, mpi_fsi.cpp:727-760): a field of the FE space itself
+    (componentwise quadratic for Q2 velocity / stress, affine for Q1 and the pressure) is returned exactly at any point,
+    points outside the mesh come back as not found with zero values"""
+    dim = 3 if kind.startswith("box3") else 2
+    kv = 2 if kind.endswith("q2") else 1
+    if kind == "hang2_q1":
+        m = HangingMesh((10, 8), (0, 0), (1.0, 0.8), {(i, j) for i in range(3, 7) for j in range(2, 6)}, kv=1)
+    elif dim == 2:
+        m = BoxMesh((7, 5), (0, 0), (1.0, 0.8), kv=kv)
+        m.vcoords = wobble(0.01, 5.0)(m.vcoords.reshape(-1, 2)).reshape(m.vcoords.shape)  # non-affine cells ...
+    else:
+        m = BoxMesh((4, 3, 3), (0, 0, 0), (1.0, 0.8, 0.6), kv=kv)
+    A, b = RNG.normal(size=(dim + 1, dim)), RNG.normal(size=dim + 1)
+    if kind == "box2_q2":  # ... on which only isoparametric images are exact: use the unit-cell picture of the nodes
+        x_u = np.zeros((m.n_unodes, 2))
+        loc = np.stack(np.unravel_index(np.arange(9), (3, 3)), axis=-1)[:, ::-1] / 2.0
+        for c in range(m.n_cells):
+            N = np.stack([(1 - loc[:, 0]) * (1 - loc[:, 1]), loc[:, 0] * (1 - loc[:, 1]), (1 - loc[:, 0]) * loc[:, 1], loc[:, 0] * loc[:, 1]], axis=1)
+            x_u[m.cell_unodes[c]] = N @ m.vcoords[c]
+        x_p = np.zeros((m.n_pnodes, 2))
+        x_p[m.cell_pnodes.ravel()] = m.vcoords.reshape(-1, 2)
+    else:
+        x_u, x_p = m.unode_coords, m.pnode_coords
+    f = lambda x: x @ A.T + b  # noqa: E731  affine: in every space, exact under the d-linear map
+    present = np.concatenate([f(x_u)[:, :dim].ravel(), f(x_p)[:, dim]])
+    G = RNG.normal(size=(dim * dim, dim))
+    stress = (G @ x_u.T + 0.3).reshape(dim, dim, m.n_unodes)
+    pts = RNG.uniform(-0.05, 1.05, (300, dim)) * np.array([1.0, 0.8, 0.6][:dim])
+    vals, st, cell = orc.fsi_fluid_at_points(m, present, stress, pts)
+    hi = np.array([1.0, 0.8, 0.6][:dim])
+    if kind == "box2_q2":
+        inside = cell >= 0
+        assert inside.sum() > 200
+    else:
+        inside = ((pts >= 0) & (pts <= hi)).all(axis=1)
+        assert ((cell >= 0) == inside).all() and inside.sum() > 150 and (~inside).sum() > 10
+    assert np.abs(vals[inside] - f(pts[inside])).max() < 1e-11
+    assert np.abs(st[inside].reshape(-1, dim * dim) - (pts[inside] @ G.T + 0.3)).max() < 1e-11
+    assert not vals[~inside].any() and not st[~inside].any()

@@ -78,6 +78,15 @@ def device_leg(L, ctx, capi, n_cells, solid, dt=1e-3, reps=3):
         chk(L.ifem_set_constraints(ctx, 1, len(bd), _ptr(bd), _ptr(bv)))
         chk(L.ifem_set_constraints(ctx, 0, len(bd), _ptr(bd), None))
         t_mc.append(time.time() - t0)
+    # find_solid_bc / update_solid_displacement (:727-760, :268-271): the fluid solution at the solid's vertices
+    pts = np.ascontiguousarray(solid["vertices"])
+    nv_s = len(pts)
+    vals, stv, cl = np.zeros((nv_s, 4)), np.zeros((nv_s, 3, 3)), np.zeros(nv_s, np.int32)
+    t_pt = []
+    for _ in range(reps + 1):  # the first call builds the bins over the fluid cells
+        t0 = time.time()
+        chk(L.ifem_fsi_fluid_at_points(ctx, nv_s, _ptr(pts), _ptr(vals), _ptr(stv), _ptr(cl)))
+        t_pt.append(time.time() - t0)
     s = capi.FsiSolid(len(solid["vertices"]), len(solid["cells"]), 0, _ptr(solid["vertices"]), _ptr(solid["cells"]), None,
                       _ptr(solid["velocity"]), _ptr(solid["acceleration"]), _ptr(solid["stress"]))
     t0 = time.time()
@@ -101,6 +110,8 @@ def device_leg(L, ctx, capi, n_cells, solid, dt=1e-3, reps=3):
     t_dir.append(time.time() - t0)
     return {"solid_cells": len(solid["cells"]), "fluid_cells": int(n_cells), "boundary_lines": int(len(bd)),
             "set_constraints_x2_ms": float(np.median(t_mc)) * 1e3, "set_solid_ms": t_set * 1e3,
+            "fluid_at_points": {"points": int(nv_s), "found": int((cl >= 0).sum()), "first_call_ms": t_pt[0] * 1e3,
+                                "ms": float(np.median(t_pt[1:])) * 1e3},
             "update_indicator_ms": float(np.median(t_ind[1:])) * 1e3, "n_artificial_cells": cnt.value,
             "find_fluid_bc_ms": float(np.median(t_acc[1:])) * 1e3, **acc_stats,
             "find_fluid_bc_dirichlet_ms": t_dir[0] * 1e3, "dirichlet_candidates": st.n_candidates, "dirichlet_inside": st.n_inside,
