@@ -310,10 +310,20 @@ def hip_loop_device_inputs(m, nranks, n_steps, use_dirichlet_bc):
             assert st.n_not_found == 0
             its, log = ctx.scns_newton_step(prm, True, tol=NEWTON_TOL, maxit=NEWTON_MAXIT)            # run_one_step(true) (:1208)
             x = ctx.vec_get(capi.VEC_PRESENT)
+            # find_solid_bc (:727-760): fluid stress sigma = -p I + viscous stress at the solid's vertices, from the device
+            v, tau, cl = ctx.fsi_fluid_at_points(s.vertices)
+            shared.setdefault(("sigma", step), {})[rank] = (cl >= 0, tau - v[:, 2, None, None] * np.eye(2))
             barrier.wait()
             shared["present"][P.own_gdof] = np.concatenate([x[:2 * nuo], x[2 * nul:2 * nul + P.n_pnodes_owned]])
             barrier.wait()
-            out[rank].append((shared["present"].copy() if rank == 0 else None, its))
+            sigma = None
+            if rank == 0:  # a vertex is found by the rank(s) whose local cells hold it
+                parts_ = shared[("sigma", step)]
+                sigma = np.full((len(s.vertices), 2, 2), np.nan)
+                for r in range(nranks):
+                    found, sg = parts_[r]
+                    sigma[found] = sg[found]
+            out[rank].append((shared["present"].copy() if rank == 0 else None, its, sigma))
         assert any((moved[k] != moved[k + 1]).any() for k in range(n_steps - 1)) or nranks > 1
         return None
 
@@ -332,11 +342,17 @@ def test_fsi_caller_loop_with_device_produced_inputs(nranks, use_dirichlet_bc):
     n_u = m.n_u
     for s in range(n_steps):
         xr, itr = ref[s]
-        xg, itg = got[s]
+        xg, itg, sigma = got[s]
         ev = np.abs(xg[:n_u] - xr[:n_u]).max() / np.abs(xr[:n_u]).max()
         ep = np.abs(xg[n_u:] - xr[n_u:]).max() / max(np.abs(xr[n_u:]).max(), 1e-300)
         assert ev < 1e-6 and ep < 1e-6, (s, ev, ep, itr, itg)
         assert abs(itg - itr) <= 1, (s, itr, itg)
+        # the traction data the solid side takes back (find_solid_bc): the oracle's interpolation of ITS solution and stress
+        sol = _meshed_solid(s)
+        vo, tauo, co = orc.fsi_fluid_at_points(m, xr, orc.System(m).update_stress(KW["mu"], xr), sol.vertices)
+        assert (co >= 0).all() and not np.isnan(sigma).any()
+        sigo = tauo - vo[:, 2, None, None] * np.eye(2)
+        assert np.abs(sigma - sigo).max() < 1e-5 * np.abs(sigo).max(), (s, np.abs(sigma - sigo).max(), np.abs(sigo).max())
 
 
 def test_fsi_loop_3d_insimex_with_device_produced_inputs():
