@@ -368,6 +368,8 @@ typedef struct {
  * v_solid - present (nonzero set) / 0 (zero set) of the velocity dofs inside the solid into the two constraint objects of
  * ifem_set_constraints with left_object_wins: dofs that already carry a boundary or hanging-node line keep it (:569-651).
  * The caller re-makes the boundary lines first, as the reference does (fluid_solver.make_constraints(), :1191).
+ * The nodal fsi_stress lives in the context from the first call on (zero-initialised, as fluid_solver.fsi_stress is);
+ * ifem_set_scns_fields(..., fsi_stress = NULL) releases it, a non-NULL pointer replaces it.
  * First-touch rule (:437-441, :506-508): the reference evaluates a node in the first cell of its loop that touches it;
  * here that is the touching cell of smallest cell_order[c] (NULL: the local cell index, i.e. the loop order of a single
  * rank).  On several ranks pass the global active-cell index: every rank then picks the same cell for the nodes it

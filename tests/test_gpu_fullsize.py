@@ -140,3 +140,71 @@ def test_assembled_auu_equals_matrix_free_and_solve_residual(solver):
     true_res = np.linalg.norm(r)
     assert true_res <= 1.05e-4 * np.linalg.norm(b), (true_res, np.linalg.norm(b), st.fgmres_iters, st.fgmres_res)
     assert abs(true_res - st.fgmres_res) <= 0.5 * st.fgmres_res + 1e-12 * np.linalg.norm(b)
+
+
+def test_fsi_inputs_closed_form_on_affine_fields(solver):
+    """the device-side FSI inputs (csrc/fsi.hip) at bench size against what must hold on ANY mesh: with affine solid fields
+    and an affine fluid velocity, update_indicator marks exactly the cells whose vertices lie in the (analytically known)
+    block, and find_fluid_bc writes (v_s - v)/dt + (grad v) v - a_s and -(solid stress) at exactly the nodes of those
+    cells that lie in the block -- 2.1 M cells, 17 M nodes, a 3456-cell rotated solid (mpi_fsi.cpp:291-319, :415-556)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fsibench
+    from openifem_amd import capi
+    S, n = solver, solver.n
+    L, ctx = S.L, S.ctx
+    n_cells, n_u, n_p = S.sizes()
+    rng = np.random.default_rng(5)
+    solid = fsibench.make_solid3d()
+    Gv, Ga, Gf = rng.normal(size=(3, 3)), rng.normal(size=(3, 3)), rng.normal(size=(3, 3))
+    Gs = rng.normal(size=(6, 3))
+    xs = solid["vertices"]
+    solid["velocity"] = np.ascontiguousarray(xs @ Gv.T + 0.2)
+    solid["acceleration"] = np.ascontiguousarray(xs @ Ga.T - 0.1)
+    solid["stress"] = np.ascontiguousarray(Gs @ xs.T + 0.5)
+    uc, pc = S.node_coords()
+    cu, cp, fb, vc = S.cell_tables()
+    present = np.concatenate([(uc @ Gf.T + 0.05).ravel(), rng.normal(size=n_p)])
+    _vec_set(S, capi.VEC_PRESENT, present)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    fs = capi.FsiSolid(len(xs), len(solid["cells"]), 0, p(xs), p(solid["cells"]), None, p(solid["velocity"]), p(solid["acceleration"]),
+                       p(solid["stress"]))
+    assert L.ifem_fsi_set_solid(ctx, C.byref(fs)) == 0, L.ifem_last_error()
+    ind = np.zeros(n_cells, np.int32)
+    cnt = C.c_int64()
+    assert L.ifem_fsi_update_indicator(ctx, p(ind), C.byref(cnt)) == 0, L.ifem_last_error()
+    v_in, v_gap = fsibench.inside_solid3d(vc.reshape(-1, 3))
+    # 17 M points come within ~1e-10 of the block's faces; the analytic test and the Newton inversion agree down to
+    # rounding, so only points closer than 1e-12 to a face would be ambiguous
+    assert v_gap.min() > 1e-12, "a fluid vertex sits on the solid's surface: the closed form is ambiguous there"
+    want_ind = v_in.reshape(n_cells, 8).all(axis=1)
+    assert want_ind.sum() > 1000 * (n / 128.0) ** 3 and (ind == want_ind).all() and cnt.value == want_ind.sum()
+    dt = 1e-3
+    st = capi.FsiStats()
+    try:
+        assert L.ifem_fsi_find_fluid_bc(ctx, dt, 0, None, C.byref(st)) == 0, L.ifem_last_error()
+        node_in, gap = fsibench.inside_solid3d(uc)
+        assert gap.min() > 1e-12
+        in_ind = np.zeros(len(uc), bool)
+        in_ind[np.unique(cu[want_ind])] = True
+        sel = node_in & in_ind
+        assert st.n_inside == sel.sum() > 0 and st.n_not_found == 0
+        acc = _vec_get(S, capi.VEC_FSI_ACC, n_u + n_p)
+        v = present[:n_u].reshape(-1, 3)
+        want = ((uc @ Gv.T + 0.2) - v) / dt + v @ Gf.T - (uc @ Ga.T - 0.1)
+        want[~sel] = 0.0
+        assert not acc[n_u:].any()
+        assert np.abs(acc[:n_u].reshape(-1, 3) - want).max() < 1e-9 * np.abs(want).max()
+        fsi_stress = np.zeros((6, len(uc)))
+        assert L.ifem_fsi_get_stress(ctx, p(fsi_stress)) == 0, L.ifem_last_error()
+        want_s = np.where(sel[None, :], -(Gs @ uc.T + 0.5), 0.0)  # no projected fluid stress on this context yet
+        assert np.abs(fsi_stress - want_s).max() < 1e-11 * np.abs(want_s).max()
+        # the way back (find_solid_bc): the fluid solution at the solid's vertices; the velocity is in the FE space
+        nv_s = len(xs)
+        vals, cl = np.zeros((nv_s, 4)), np.zeros(nv_s, np.int32)
+        assert L.ifem_fsi_fluid_at_points(ctx, nv_s, p(xs), p(vals), None, p(cl)) == 0, L.ifem_last_error()
+        assert (cl >= 0).all() and np.abs(vals[:, :3] - (xs @ Gf.T + 0.05)).max() < 1e-11
+    finally:  # leave the shared context as the other tests expect it
+        assert L.ifem_set_cell_fields(ctx, None) == 0
+        assert L.ifem_vec_zero(ctx, capi.VEC_FSI_ACC) == 0
+        assert L.ifem_set_scns_fields(ctx, None, None, None) == 0

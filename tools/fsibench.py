@@ -50,6 +50,20 @@ def make_solid3d(reps=(24, 12, 12), lo=(0.62, 0.052, 0.047), hi=(1.03, 0.151, 0.
             "acceleration": np.ascontiguousarray(acc), "stress": np.ascontiguousarray(stress)}
 
 
+def inside_solid3d(points, lo=(0.62, 0.052, 0.047), hi=(1.03, 0.151, 0.149), angle=0.21):
+    """analytic inside test of make_solid3d's block: (strictly inside, distance to the nearest face in the block's frame)"""
+    lo, hi = np.asarray(lo), np.asarray(hi)
+    c = 0.5 * (lo + hi)
+    r = np.asarray(points) - c
+    cb, sb = np.cos(angle / 3), np.sin(angle / 3)
+    y, z = cb * r[:, 1] + sb * r[:, 2], -sb * r[:, 1] + cb * r[:, 2]  # undo the rotation about x ...
+    ca, sa = np.cos(angle), np.sin(angle)
+    x, y = ca * r[:, 0] + sa * y, -sa * r[:, 0] + ca * y               # ... then the one about z
+    q = np.stack([x, y, z], axis=1)
+    gap = 0.5 * (hi - lo) - np.abs(q)
+    return (gap > 0).all(axis=1), np.abs(gap).min(axis=1)
+
+
 class _Solid:  # what orc.FsiSolid wants
     def __init__(self, d):
         self.dim, self.vertices, self.cells, self.bfaces = 3, d["vertices"], d["cells"], None
