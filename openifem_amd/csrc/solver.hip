@@ -31,7 +31,8 @@ struct Clock {
 static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &A, const OpFn &Pinv, bool flexible,
                  const double *b, double *x, int m, int maxit, double tol, double *V, double *Z, double *w,
                  double *res_out,
-                 const std::function<void(int, const double *, int64_t, const double *, double *)> &mdot) {
+                 const std::function<void(int, const double *, int64_t, const double *, double *)> &mdot,
+                 std::vector<double> *history = nullptr) { // residual norm after every iteration (verbose runs)
   std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), h(m + 1), h2(m + 1);
   v_zero(ctx, n, x);
   int it = 0;
@@ -83,6 +84,7 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
       g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
       res = std::fabs(g[j + 1]);
       ++it;
+      if (history) history->push_back(res);
       if (res <= tol || hn == 0) { ++j; done = true; break; }
     }
     for (int i = j - 1; i >= 0; --i) {
@@ -1047,8 +1049,9 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   OpFn Aop = [&](const double *x, double *y) { system_apply(S, x, y, true); };
   OpFn Pop = [&](const double *x, double *y) { precond_vmult(S, x, y); };
   double res = 0;
+  std::vector<double> hist;
   const int it = gmres(ctx, S.n, basis_ld(S.ctx, S.n), /*reorth=*/true, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p, ctx->krylovZ.p,
-                       S.outer_w, &res, mdot);
+                       S.outer_w, &res, mdot, o->verbose ? &hist : nullptr);
   apply_constraints(ctx, use_nonzero ? 1 : 0, upd); // constraints_used.distribute(newton_update)
   hanging_distribute(ctx, upd);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1062,6 +1065,11 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   if (o->verbose)
     fprintf(stderr, "[ifem] solve: fgmres %d its res %.3e (tol %.3e) | P applies %u CG(Mp) %u (%.1f ms) CG(Sm) %u (%.1f ms) inner %u (%.1f ms) | %.1f ms\n",
             it, res, tol, S.st.precond_applies, S.st.cg_mp_iters, S.st.t_cg_mp_ms, S.st.cg_sm_iters, S.st.t_cg_sm_ms, S.st.inner_iters, S.st.t_ainv_ms, S.st.t_total_ms);
+  if (o->verbose) {
+    fprintf(stderr, "[ifem] solve: ||rhs|| %.3e, relative residual per FGMRES iteration:", bn);
+    for (double r : hist) fprintf(stderr, " %.2e", r / bn);
+    fprintf(stderr, "\n");
+  }
   return res <= tol ? 0 : IFEM_E_KRYLOV_NOCONV;
 }
 
