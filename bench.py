@@ -247,7 +247,8 @@ def main():
     ap.add_argument("--cells", dest="n", type=int, default=128, help="cells per direction per GPU")
     ap.add_argument("--cpu-cells", dest="cpu_n", default="32,64", help="cells per direction of the CPU baseline sample(s), comma separated (0 = skip; BASELINE.md section 3 plans 32 and 64: 14 s and 63 s on the 64 threads the sweep picks)")
     ap.add_argument("--extras", type=int, default=1, help="N = 1 only: also measure cold_step (geometry blocks and S_m rebuilt, as the reference does every iteration) and time_step (a whole run_one_step Newton loop)")
-    ap.add_argument("--inner-rel", type=float, default=5e-5, help="relative residual target of the inner A_uu solve inside the preconditioner (the reference applies an exact LU there, mpi_insim.cpp:124-127).  Measured at 128^3 (profiles/r02_inner_sweep.txt): with 1e-2 ... 1e-3 the outer FGMRES needs two iterations (relative residual 9.1e-4 after the first), with 5e-5 one (7.8e-5 <= 1e-4) for the same four inner iterations in total: 275 -> 239 ms per step")
+    ap.add_argument("--inner-rel", type=float, default=1e-2, help="relative residual target of the inner A_uu solve inside the preconditioner (the reference applies an exact LU there, mpi_insim.cpp:124-127)")
+    ap.add_argument("--inner-rel-first", type=float, default=5e-5, help="the same for the FIRST preconditioner application of a solve (0: as --inner-rel).  Measured at 128^3 (profiles/r02_inner_sweep.txt): with 1e-2 the outer FGMRES needs two iterations (relative residual 9.1e-4 after the first), with 5e-5 in the first application one (7.8e-5 <= 1e-4) for the same four inner iterations in total: 275 -> 239 ms per step; later applications (later Newton iterations need 3-5 outer iterations whatever the inner accuracy) keep the cheap setting")
     ap.add_argument("--ainv", type=int, default=4, help="IFEM_AINV_* kind of the A_uu^-1 replacement (4 = matrix-free operator + geometric multigrid V-cycle, 3 = matrix-free inner operator + block Jacobi, 1 = fp32 inner matrix, 0 = fp64 matrix)")
     ap.add_argument("--sm-rel", type=float, default=None, help="experiment: relative tolerance of CG(S_m) inside the preconditioner (reference and default: 1e-3)")
     ap.add_argument("--mp-rel", type=float, default=None, help="experiment: relative tolerance of CG(M_p) inside the preconditioner (reference and default: 1e-6)")
@@ -289,6 +290,7 @@ def main():
     n_cells, n_u, n_p = solver.sizes()
     n_dofs_global = solver.global_dofs() if world > 1 else n_u + n_p
     solver.opts.inner_rel = args.inner_rel
+    solver.opts.inner_rel_first = args.inner_rel_first
     if args.inner_restart:
         solver.opts.inner_restart = args.inner_restart
     if args.sm_rel is not None:
@@ -417,7 +419,7 @@ def main():
                        "assemble_ms": t_asm / args.steps * 1e3, "solve_ms": t_solve / args.steps * 1e3,
                        "assemble_kernel_ms": asm_kernel_ms, "setup_s": t_setup,
                        "fgmres_iters": last.fgmres_iters, "cg_mp_iters": last.cg_mp_iters,
-                       "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "ainv_kind": args.ainv, "outer_matrix_free": args.outer_mf,
+                       "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "inner_rel_first": args.inner_rel_first, "ainv_kind": args.ainv, "outer_matrix_free": args.outer_mf,
                        "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms,
                        "mf_apply_ms": mf_ms / max(mf_calls, 1), "mf_applies": mf_calls,
                        "sm_multigrid_levels": int(last.sm_mg_levels),

@@ -135,6 +135,13 @@ typedef struct {
   int32_t mg_smooth_u_post;   /* 0: as many after the coarse correction as before it; > 0: that many (the cycle is then no
                                  longer symmetric, which the flexible inner GMRES does not need) */
   double  mg_cheb_ratio_u;    /* 4: its Chebyshev interval [lambda_max / ratio, lambda_max] of (block D)^-1 A_uu */
+  double  inner_rel_first;    /* 0: off.  > 0: the FIRST preconditioner application of a solve runs its inner A_uu solve to
+                                 this relative residual instead of inner_rel.  The first Krylov direction decides whether
+                                 the outer iteration ends at its first check: at 128^3, 5e-5 there (four inner iterations)
+                                 gives 7.8e-5 ||rhs|| after one outer iteration where 1e-2 gives 9.1e-4 and needs a second
+                                 one.  Only used when that first residual is velocity-dominated (pressure share below
+                                 10 fgmres_rel): a residual that is mostly continuity equation (later Newton iterations)
+                                 needs several outer iterations whatever the velocity solve does */
 } ifem_solver_opts;
 
 /* Tuning / measurement knobs of one context (defaults = the measured best; nothing here changes results beyond fp64

@@ -71,7 +71,8 @@ class SolverOpts(C.Structure):
                 ("inner_restart", C.c_int32), ("inner_maxit", C.c_int32), ("inner_rel", C.c_double),
                 ("explicit_schur", C.c_int32), ("verbose", C.c_int32), ("device_cg", C.c_int32), ("outer_matrix_free", C.c_int32),
                 ("sm_mg", C.c_int32), ("mg_smooth", C.c_int32), ("mg_cheb_ratio", C.c_double),
-                ("mg_smooth_u", C.c_int32), ("mg_smooth_u_post", C.c_int32), ("mg_cheb_ratio_u", C.c_double)]
+                ("mg_smooth_u", C.c_int32), ("mg_smooth_u_post", C.c_int32), ("mg_cheb_ratio_u", C.c_double),
+                ("inner_rel_first", C.c_double)]
 
 
 class SolveStats(C.Structure):

@@ -96,6 +96,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
   o->verbose = 0;
   o->sm_mg = 1; o->mg_smooth = 2; o->mg_cheb_ratio = 4.0;
   o->mg_smooth_u = 2; o->mg_smooth_u_post = 0; o->mg_cheb_ratio_u = 4.0;
+  o->inner_rel_first = 0.0;
 }
 
 void ifem_default_tuning(ifem_tuning *t) {

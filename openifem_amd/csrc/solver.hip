@@ -262,6 +262,7 @@ struct SolveState {
   const ifem_solver_opts *o;
   ifem_solve_stats st{};
   int64_t nuo, npo, n;
+  double p_src_norm = 0, u_src_norm = 0; // norms of the pressure / velocity parts of the vector the preconditioner is applied to
   // workspace carved out of ctx->work
   double *xu_ext, *xp_ext, *tu, *tp[6], *utmp, *inner_w, *inner_z, *outer_w;
 };
@@ -715,6 +716,13 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   double *tmp = S.tp[0], *r = S.tp[1], *p = S.tp[2], *q = S.tp[3];
   auto pdot = [&](const double *a, const double *b) { return dot_all(S, S.npo, a, b); };
   const double n1 = std::sqrt(pdot(src1, src1));
+  S.p_src_norm = n1;
+  if (S.st.precond_applies == 0 && o->inner_rel_first > 0) { // pressure share of the first Krylov vector (see the inner solve below)
+    double uu = 0;
+    v_mdot(S.ctx, S.nuo, 1, src0, S.nuo, src0, &uu);
+    allreduce_sum(S.ctx, &uu, 1);
+    S.u_src_norm = std::sqrt(uu);
+  }
   Clock ck;
   // CG for Mp (:69-84)
   // the approximate-preconditioner kinds stream M_p in single precision like S_m (the solve is to 1e-6, the rounding of the
@@ -809,6 +817,18 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   double un;
   mdot(1, S.utmp, S.nuo, S.utmp, &un);
   un = std::sqrt(un);
+  // the first application of a solve may ask for a tighter inner solve (ifem_solver_opts::inner_rel_first)
+  // ... when the residual it is applied to is velocity-dominated.  The block-triangular preconditioner leaves O(0.1) of the
+  // pressure part of a residual behind per outer iteration (the pressure Schur complement is only approximated, mpi_insim.cpp:
+  // 57-112), so a first Krylov vector whose pressure share exceeds ~10 fgmres_rel cannot be finished in one iteration by
+  // a better velocity solve -- the later Newton iterations, whose residual is almost all continuity equation (shares
+  // 0.996 / 0.66 against 7e-5 in the first one at 128^3): there the cheap setting is the better one (time_step leg of
+  // bench.py: 1.16 s against 1.27 s with the tight first application everywhere)
+  const bool pressure_dominated = S.p_src_norm > 10.0 * o->fgmres_rel * std::hypot(S.u_src_norm, S.p_src_norm);
+  const double inner_rel_now = (S.st.precond_applies == 0 && o->inner_rel_first > 0 && !pressure_dominated) ? o->inner_rel_first : o->inner_rel;
+  if (o->verbose && S.st.precond_applies == 0)
+    fprintf(stderr, "[ifem] first preconditioner application: pressure share of the residual %.3e, inner tolerance %.1e\n",
+            S.p_src_norm / std::max(std::hypot(S.u_src_norm, S.p_src_norm), 1e-300), inner_rel_now);
   double res = 0;
   if (o->ainv_kind == IFEM_AINV_MG) { // inner GMRES on the matrix-free operator, one V-cycle as its preconditioner
     MgUu Mu;
@@ -844,7 +864,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
       const int64_t ld = basis_ld(S.ctx, S.nuo);
       const int mi = std::max(1, o->inner_restart);
       if ((int64_t)c->innerZ.n < int64_t(mi) * ld) c->innerZ.alloc(size_t(mi) * size_t(ld));
-      S.st.inner_iters += gmres(c, S.nuo, ld, /*reorth=*/false, Amf, Vc, true, S.utmp, dst0, mi, o->inner_maxit, o->inner_rel * un,
+      S.st.inner_iters += gmres(c, S.nuo, ld, /*reorth=*/false, Amf, Vc, true, S.utmp, dst0, mi, o->inner_maxit, inner_rel_now * un,
                                 c->innerV.p, c->innerZ.p, S.inner_w, &res, mdot);
     }
     IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -856,11 +876,11 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   if (f32_basis) { // columns 0..m: basis, m+1: scratch for V y, up to the next multiple of 4: padding read by the fused kernels
     OpF32 Pf = [&](const float *x, double *y) { bjac_apply_f32(c, x, y); };
     S.st.inner_iters += gmres_f32basis(c, S.nuo, basis_ld(S.ctx, S.nuo), Auu, Pf, S.utmp, dst0, o->inner_restart, o->inner_maxit,
-                                       o->inner_rel * un, reinterpret_cast<float *>(c->innerV.p), S.inner_z, S.inner_w, &res,
+                                       inner_rel_now * un, reinterpret_cast<float *>(c->innerV.p), S.inner_z, S.inner_w, &res,
                                        [&](double *v, int k) { allreduce_sum(c, v, k); });
   } else
   S.st.inner_iters += gmres(c, S.nuo, basis_ld(S.ctx, S.nuo), /*reorth=*/false, Auu, Pj, false, S.utmp, dst0, o->inner_restart,
-                            o->inner_maxit, o->inner_rel * un, c->innerV.p, S.inner_z, S.inner_w, &res, mdot);
+                            o->inner_maxit, inner_rel_now * un, c->innerV.p, S.inner_z, S.inner_w, &res, mdot);
   IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
   S.st.t_ainv_ms += ck3.ms();
   S.st.precond_applies++;
