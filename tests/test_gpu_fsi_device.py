@@ -245,3 +245,29 @@ def test_fluid_values_at_solid_points_on_four_virtual_ranks():
     assert (found_any == (co >= 0)).all()
     lowest = np.min(np.where(np.stack(res) >= 0, np.stack(res), m.n_cells), axis=0)
     assert (lowest[co >= 0] == co[co >= 0]).all()  # the lowest cell over the ranks is the single-context cell
+
+
+def test_set_constraints_from_the_line_list():
+    """ifem_set_constraints builds flags / inhomogeneities on the device from the line list: a dof listed twice keeps its last
+    line (what the sequential host loop of round 1 did), an empty list clears the set, bad dofs are refused"""
+    from openifem_amd import capi
+    m, s, present, rng = _case("box2_q1")
+    ctx = capi.Context(2, 1, m.vcoords, m.cell_unodes, m.cell_pnodes, m.cell_face_bid, m.n_unodes, m.n_pnodes)
+    dofs = np.array([5, 9, 5, 40, 9, 5], np.int32)
+    vals = np.array([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])
+    ctx.set_constraints(1, dofs, vals)
+    f, v = ctx.get_constraints(1)
+    assert set(np.nonzero(f)[0]) == {5, 9, 40} and (v[[5, 9, 40]] == [6.0, 5.0, 4.0]).all() and np.count_nonzero(v) == 3
+    ctx.set_constraints(0, dofs, None)
+    f0, v0 = ctx.get_constraints(0)
+    assert (f0 == f).all() and not v0.any()
+    ctx.set_constraints(1, np.zeros(0, np.int32), None)
+    f, v = ctx.get_constraints(1)
+    assert not f.any() and not v.any()
+    with pytest.raises(capi.IfemError):
+        ctx.set_constraints(1, np.array([m.n_dofs], np.int32), None)
+    with pytest.raises(capi.IfemError):
+        ctx.set_constraints(1, np.array([m.n_u], np.int32), None)  # a pressure dof
+    f0b, _ = ctx.get_constraints(0)
+    assert (f0b == f0).all()  # a refused call leaves the other set alone
+    ctx.close()
