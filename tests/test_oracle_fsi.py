@@ -204,3 +204,22 @@ def test_fluid_point_values_reproduce_the_fe_space(kind):
     assert np.abs(vals[inside] - f(pts[inside])).max() < 1e-11
     assert np.abs(st[inside].reshape(-1, dim * dim) - (pts[inside] @ G.T + 0.3)).max() < 1e-11
     assert not vals[~inside].any() and not st[~inside].any()
+
+
+def test_bench_solid_and_its_analytic_inside_test_agree_with_the_oracle():
+    """tools/fsibench.py: the 24x12x12 rotated block of the bench leg / of the full-size GPU test, its closed-form inside test
+    (what tests/test_gpu_fullsize.py checks the device against at 128^3) and the oracle's point_in_solid say the same"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fsibench
+    s = fsibench.make_solid3d()
+    X = s["vertices"][s["cells"]]
+    det = np.einsum("ij,ij->i", np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), X[:, 4] - X[:, 0])
+    assert len(s["cells"]) == 3456 and det.min() > 0  # right-handed cells in deal.II vertex order
+    pts = RNG.uniform((0.5, 0.0, 0.0), (1.2, 0.2, 0.2), (4000, 3))
+    inside, gap = fsibench.inside_solid3d(pts)
+    got = orc.FsiSolid(fsibench._Solid(s)).point_in_solid(pts)
+    assert 300 < inside.sum() < 3700 and gap.min() > 1e-9 and (got == inside).all()
+    _, gap_v = fsibench.inside_solid3d(s["vertices"])
+    assert (gap_v < 1e-12).sum() == 25 * 13 * 13 - 23 * 11 * 11  # the boundary vertices sit on the faces, the others do not
