@@ -280,6 +280,47 @@ def test_multigrid_ainv_keeps_the_reference_stopping_rule(n):
     s.close()
 
 
+def test_tight_first_inner_solve_saves_outer_iterations_only_on_velocity_dominated_residuals():
+    """ifem_solver_opts::inner_rel_first (the bench setting): the first preconditioner application of a solve resolves A~^-1
+    further when the residual is velocity-dominated; the true residual still meets 1e-4 ||rhs||, with no more outer
+    iterations than without it.  On a residual that is mostly continuity equation the option must change nothing."""
+    from openifem_amd import capi
+    s = _hierarchy((16, 16, 16))
+    s.channel_state()
+    s.opts.ainv_kind, s.opts.inner_restart = 4, 16
+    s.assemble(False)
+    _, n_u, n_p = s.sizes()
+    nt = n_u + n_p
+    cd, _ = s.constraints()
+
+    def solve(first):
+        s.opts.inner_rel_first = first
+        st = s.solve(False)
+        x = _get(s, capi.VEC_UPDATE, nt)
+        assert s.L.ifem_vec_set(s.ctx, capi.VEC_TMP, x.ctypes.data_as(C.c_void_p)) == 0
+        assert s.L.ifem_system_vmult(s.ctx, capi.VEC_UPDATE, capi.VEC_TMP) == 0
+        r = _get(s, capi.VEC_RHS, nt) - _get(s, capi.VEC_UPDATE, nt)
+        r[cd] = 0
+        return st.fgmres_iters, st.inner_iters, np.linalg.norm(r) / np.linalg.norm(_get(s, capi.VEC_RHS, nt)), x
+
+    b = _get(s, capi.VEC_RHS, nt)
+    share = np.linalg.norm(b[n_u:]) / np.linalg.norm(b)
+    assert share < 1e-3, share  # the bench state: momentum residual of the perturbed Poiseuille flow
+    it0, in0, res0, _ = solve(0.0)
+    it1, in1, res1, _ = solve(5e-5)
+    assert res0 <= 1.05e-4 and res1 <= 1.05e-4
+    assert it1 <= it0 and in1 > 0, (it0, in0, it1, in1)
+    # a pressure-dominated right-hand side: same iterations, same update, with or without the option
+    rhs = np.zeros(nt)
+    rhs[n_u:] = np.random.default_rng(3).standard_normal(n_p)
+    rhs[n_u:] -= rhs[n_u:].mean()
+    assert s.L.ifem_vec_set(s.ctx, capi.VEC_RHS, rhs.ctypes.data_as(C.c_void_p)) == 0
+    ita, ina, resa, xa = solve(0.0)
+    itb, inb, resb, xb = solve(5e-5)
+    assert (ita, ina) == (itb, inb) and np.abs(xa - xb).max() <= 1e-12 * np.abs(xa).max()
+    s.close()
+
+
 @pytest.mark.parametrize("P", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
 def test_multigrid_ainv_on_virtual_ranks(P):
     """the bench configuration (IFEM_AINV_MG + multigrid CG(S_m), halo overlap on) on the partitions bench.py uses for 2, 4 and
