@@ -170,7 +170,7 @@ def bench_insimex(args, host):
                       "higher_is_better": True, "dtype": "f64", "data": "synthetic",
                       "config": {"workload": f"3D channel flow {n}^3 Q2/Q1, mpi_insimex steady-state time step", "n_dofs": n_u + n_p,
                                  "ainv_kind": args.ainv, "inner_rel": args.inner_rel, "inner_maxit": solver.opts.inner_maxit, "mg_smooth_u": solver.opts.mg_smooth_u,
-                                 "multigrid_levels": 1 + len(solver._levels),
+                                 "multigrid_levels": 1 + len(solver.mg_levels()),
                                  "fgmres_iters": st.fgmres_iters, "cg_mp_iters": st.cg_mp_iters, "cg_sm_iters": st.cg_sm_iters,
                                  "inner_iters": st.inner_iters}}), flush=True)
 
@@ -195,8 +195,8 @@ def extras(solver, capi, n_dofs, warm_ms):
 
     def set_geo_cache(v):  # on every multigrid level: the coarser ones re-form their S_m as well
         tun.geo_cache = v
-        for s_ in [solver] + list(getattr(solver, "_levels", [])):
-            assert L.ifem_set_tuning(s_.ctx, C.byref(tun)) == 0
+        for c_ in solver.all_ctxs():
+            assert L.ifem_set_tuning(c_, C.byref(tun)) == 0
 
     def one_step(label, note):
         solver.assemble(False)
@@ -261,6 +261,9 @@ def main():
     ap.add_argument("--mg-ratio-u", type=float, default=None, help="Chebyshev interval ratio of the A_uu V-cycle (--ainv 4)")
     ap.add_argument("--tune", action="append", default=[], help="experiment: ifem_tuning field=value (e.g. --tune spmv_pipe=0), applied to every multigrid level")
     ap.add_argument("--fsi", type=int, default=32, help="N = 1 only: also time the device-side FSI inputs (FSI::update_indicator + find_fluid_bc, csrc/fsi.hip) on the bench mesh with a 24x12x12-cell solid, and the oracle's restatement on the CPU at this many cells per direction (0 = skip the leg)")
+    ap.add_argument("--seed", type=int, default=1234, help="seed of the perturbation of the timed state")
+    ap.add_argument("--rel", type=float, default=1e-3, help="relative amplitude of the perturbation of the timed state")
+    ap.add_argument("--mg-min-cells", type=int, default=0, help="multigrid levels: a direction is halved only while it keeps this many cells per rank (0: the host mirror's default, 4)")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
     ap.add_argument("--outer-mf", type=int, default=0, help="experiment: apply the u-u block of the OUTER operator matrix-free too")
     ap.add_argument("--solver", default="insim", choices=["insim", "insimex"],
@@ -286,7 +289,7 @@ def main():
         return bench_insimex(args, host)
     n = args.n
     from openifem_amd import multigpu
-    solver, reps, t_setup = multigpu.make_channel_solver(n, rank, world, local_rank, dist, multigrid=bool(args.mg))
+    solver, reps, t_setup = multigpu.make_channel_solver(n, rank, world, local_rank, dist, multigrid=bool(args.mg), min_cells=args.mg_min_cells)
     n_cells, n_u, n_p = solver.sizes()
     n_dofs_global = solver.global_dofs() if world > 1 else n_u + n_p
     solver.opts.inner_rel = args.inner_rel
@@ -314,9 +317,9 @@ def main():
         for kv in args.tune:
             k, v = kv.split("=")
             setattr(tun, k, int(v))
-        for s_ in [solver] + list(getattr(solver, "_levels", [])):
-            assert solver.L.ifem_set_tuning(s_.ctx, C.byref(tun)) == 0
-    solver.channel_state()
+        for c_ in solver.all_ctxs():
+            assert solver.L.ifem_set_tuning(c_, C.byref(tun)) == 0
+    solver.channel_state(seed=args.seed, rel=args.rel)
 
     def step():
         solver.assemble(False)
@@ -349,6 +352,10 @@ def main():
         asm_kernel_ms += solver.timing().assemble_kernel_ms  # HIP events around the cell kernel on the context stream
     fence()
     elapsed = time.time() - t0
+    comm = solver.comm_stats(reset=True)  # exchanges / all-reduces of the K timed steps (all multigrid levels)
+    # the TRUE residual of the last timed solve, recomputed with the assembled operator (collective; outside the timed region)
+    true_res, rhs_norm = solver.true_residual()
+    solver.comm_stats(reset=True)
     if dist:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -418,12 +425,19 @@ def main():
                        "n_dofs": n_dofs_global, "cells_per_gpu": n_cells, "parallelism": f"dd{world}",
                        "assemble_ms": t_asm / args.steps * 1e3, "solve_ms": t_solve / args.steps * 1e3,
                        "assemble_kernel_ms": asm_kernel_ms, "setup_s": t_setup,
+                       "true_rel_residual": true_res / rhs_norm if rhs_norm > 0 else None, "fgmres_rel_residual": last.fgmres_res / rhs_norm if rhs_norm > 0 else None,
+                       "fgmres_rel_tol": solver.opts.fgmres_rel, "seed": args.seed, "perturbation": args.rel,
+                       "rccl_nranks": comm["rccl_nranks"], "comm_transport": {0: "none (single rank)", 1: "rccl", 2: "local world"}[comm["transport"]],
+                       "halo_neighbors": comm["n_neighbors"], "halo_stream": comm["halo_stream"],
+                       "halo_exchanges_per_step": comm["halo_exchanges"] / args.steps, "allreduce_stream_per_step": comm["allreduce_dev"] / args.steps,
+                       "allreduce_host_per_step": comm["allreduce_host"] / args.steps,
                        "fgmres_iters": last.fgmres_iters, "cg_mp_iters": last.cg_mp_iters,
                        "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "inner_rel_first": args.inner_rel_first, "ainv_kind": args.ainv, "outer_matrix_free": args.outer_mf,
                        "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms,
                        "mf_apply_ms": mf_ms / max(mf_calls, 1), "mf_applies": mf_calls,
                        "sm_multigrid_levels": int(last.sm_mg_levels),
-                       "coarse_levels": [list(s.reps) for s in getattr(solver, "_levels", [])]},
+                       "coarse_levels": [list(r) for r, _ in solver.mg_levels()],
+                       "hierarchy": "csrc/host/insim.cpp::attach_multigrid_levels (C++ host mirror)"},
             "roofline": roof,
         }
         out["config"].update({"cg_mp_rel": solver.opts.mp_rel, "cg_sm_rel": solver.opts.sm_rel})

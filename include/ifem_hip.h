@@ -191,7 +191,7 @@ enum {
 const char *ifem_last_error(void);
 /* sizeof of the structs above as this library was compiled, for a binding to check its mirror against:
  * 0 ifem_mesh_desc, 1 ifem_partition, 2 ifem_ins_params, 3 ifem_solver_opts, 4 ifem_solve_stats, 5 ifem_scns_params,
- * 6 ifem_timing, 7 ifem_tuning, 8 ifem_mg_transfer; -1 for anything else */
+ * 6 ifem_timing, 7 ifem_tuning, 8 ifem_mg_transfer, 9 ifem_fsi_solid, 10 ifem_fsi_stats, 11 ifem_comm_stats; -1 for anything else */
 int64_t ifem_abi_sizeof(int which);
 int ifem_device_count(void);
 void ifem_default_solver_opts(ifem_solver_opts *o);
@@ -199,6 +199,21 @@ void ifem_default_solver_opts(ifem_solver_opts *o);
 int ifem_comm_unique_id(uint8_t out[128]);
 /* one-rank RCCL round trip (communicator + all-reduce + grouped send/recv to self) on `device` */
 int ifem_comm_selftest(int device);
+/* What the communicator of a context looks like and how often it was used since the last reset, summed over the context
+ * and the multigrid levels attached below it: the reference's counterpart is PETSc's -log_view line of VecScatter /
+ * MPI_Allreduce counts.  rccl_nranks is ncclCommCount of the context's communicator (0: no RCCL communicator). */
+typedef struct {
+  int32_t nranks, rank, n_neighbors;
+  int32_t transport;     /* 0 single rank, 1 RCCL, 2 validation transport (local world) */
+  int32_t rccl_nranks;   /* ncclCommCount */
+  int32_t halo_stream;   /* 1: overlapped exchanges on the second communicator + priority stream */
+  int32_t levels;        /* contexts summed over (1 + attached multigrid levels) */
+  int32_t reserved_;
+  uint64_t halo_exchanges; /* packed send/recv groups (forward and reverse) */
+  uint64_t allreduce_dev;  /* all-reduces of device scalars ordered on the stream (no host wait) */
+  uint64_t allreduce_host; /* all-reduces the host waited for (Gram-Schmidt coefficients, norms) */
+} ifem_comm_stats;
+int ifem_comm_stats_get(ifem_ctx *ctx, ifem_comm_stats *out, int reset);
 /* validation transport (see ifem_partition::local_world): nranks contexts of one process on one GPU */
 void *ifem_local_world_create(int nranks);
 void ifem_local_world_destroy(void *world);
@@ -281,6 +296,10 @@ int ifem_ins_assemble(ifem_ctx *ctx, const ifem_ins_params *p, int use_nonzero);
  * Solves into IFEM_VEC_UPDATE and applies constraints.distribute(). */
 int ifem_solve(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int use_nonzero,
                ifem_solve_stats *stats);
+/* The TRUE residual of the last solve, recomputed with the assembled operator: ||system_rhs - system_matrix * newton_update||_2
+ * over the rows that carry an equation (constrained rows hold d x = 0 after constraints.distribute), all-reduced, next to
+ * ||system_rhs||_2.  What SolverControl's last_value() (mpi_insim.cpp:379-388) estimates through the Krylov recurrence. */
+int ifem_true_residual(ifem_ctx *ctx, double *residual_l2, double *rhs_l2);
 /* system_rhs.l2_norm(), mpi_insim.cpp:438 */
 int ifem_rhs_norm(ifem_ctx *ctx, double *l2);
 /* the Newton loop of InsIM::run_one_step, mpi_insim.cpp:416-473.  log (may be NULL) receives

@@ -14,6 +14,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 LIB_PATH = os.path.join(_HERE, "lib", "libifem_hip.so")
 
 VEC_PRESENT, VEC_EVAL, VEC_FSI_ACC, VEC_UPDATE, VEC_RHS, VEC_INCREMENT, VEC_TMP = range(7)
+AINV_GMRES_BJACOBI, AINV_GMRES_BJACOBI_F32, AINV_SCALAR_GMRES, AINV_GMRES_BJACOBI_MF, AINV_MG = range(5)  # IFEM_AINV_*
 
 
 class MeshDesc(C.Structure):
@@ -115,7 +116,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof",
            "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag",
            "ifem_fsi_set_solid", "ifem_fsi_update_indicator", "ifem_fsi_find_fluid_bc", "ifem_fsi_get_stress",
-           "ifem_get_constraints", "ifem_fsi_fluid_at_points"]
+           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_true_residual"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -188,6 +189,8 @@ def load():
     L.ifem_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
     L.ifem_mg_attach.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(MgTransfer)]
     L.ifem_mg_depth.argtypes = [C.c_void_p]
+    L.ifem_comm_stats_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ifem_true_residual.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ifem_uu_block_diag.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.ifem_fsi_set_solid.argtypes = [C.c_void_p, C.POINTER(FsiSolid)]
     L.ifem_fsi_update_indicator.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
@@ -215,7 +218,23 @@ class FsiStats(C.Structure):  # ifem_fsi_stats
     _fields_ = [("n_candidates", C.c_int64), ("n_inside", C.c_int64), ("n_lines", C.c_int64), ("n_not_found", C.c_int64)]
 
 
-ABI_STRUCTS = [MeshDesc, Partition, InsParams, SolverOpts, SolveStats, ScnsParams, Timing, Tuning, MgTransfer, FsiSolid, FsiStats]
+class CommStats(C.Structure):  # ifem_comm_stats
+    _fields_ = [("nranks", C.c_int32), ("rank", C.c_int32), ("n_neighbors", C.c_int32), ("transport", C.c_int32),
+                ("rccl_nranks", C.c_int32), ("halo_stream", C.c_int32), ("levels", C.c_int32), ("reserved_", C.c_int32),
+                ("halo_exchanges", C.c_uint64), ("allreduce_dev", C.c_uint64), ("allreduce_host", C.c_uint64)]
+
+
+ABI_STRUCTS = [MeshDesc, Partition, InsParams, SolverOpts, SolveStats, ScnsParams, Timing, Tuning, MgTransfer, FsiSolid, FsiStats,
+               CommStats]
+
+
+def comm_stats(L, ctx, reset=False):
+    """ifem_comm_stats_get as a dict"""
+    st = CommStats()
+    rc = L.ifem_comm_stats_get(ctx, C.byref(st), int(reset))
+    if rc < 0:
+        raise IfemError(rc, L.ifem_last_error().decode())
+    return {k: int(getattr(st, k)) for k, _ in CommStats._fields_ if k != "reserved_"}
 
 
 def make_params(mu=1.0, rho=1.0, gamma=0.1, dt=1e-3, g=(0, 0, 0), neumann=None):
@@ -370,6 +389,7 @@ class Context:
         self.n_local = self.L.ifem_n_local_dofs(self.h)
         self.n_u = dim * m.n_unodes_local
         self.n_owned = dim * m.n_unodes_owned + m.n_pnodes_owned
+        self.n_unodes_owned = m.n_unodes_owned
         self.opts = SolverOpts()
         self.L.ifem_default_solver_opts(C.byref(self.opts))
 
@@ -548,8 +568,7 @@ class Context:
 
     def uu_block_diag(self, which):
         """inverse diagonal node blocks of A_uu [n_unodes_owned, dim, dim]: 0 from the assembled matrix, 1 matrix-free"""
-        n_own = (self.n_owned - (self.n_local - self.n_u)) // self.dim if self.n_owned != self.n_local else self.n_u // self.dim
-        out = np.zeros((n_own, self.dim, self.dim))
+        out = np.zeros((self.n_unodes_owned, self.dim, self.dim))
         self._chk(self.L.ifem_uu_block_diag(self.h, which, _ptr(out)))
         return out
 

@@ -76,6 +76,7 @@ int64_t ifem_abi_sizeof(int which) {
   case 8: return sizeof(ifem_mg_transfer);
   case 9: return sizeof(ifem_fsi_solid);
   case 10: return sizeof(ifem_fsi_stats);
+  case 11: return sizeof(ifem_comm_stats);
   default: return -1;
   }
 }
@@ -178,8 +179,27 @@ int ifem_ctx_create(const ifem_mesh_desc *m, const ifem_partition *part, int dev
 void ifem_ctx_destroy(ifem_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream && ctx->owns_stream) (void)hipStreamSynchronize(ctx->stream);
-  else (void)hipDeviceSynchronize(); // a multigrid level on a borrowed stream (which may be gone already)
+  (void)hipDeviceSynchronize();
+  // unhook from a multigrid chain.  The level above forgets this one; the levels below ran on this context's stream(s) (or
+  // on those of a level further up) and stay usable by themselves: the chain below gets streams of its own.
+  if (ctx->mg_fine && ctx->mg_fine->mg_coarse == ctx) {
+    ctx->mg_fine->mg_coarse = nullptr;
+    ctx->mg_fine->sm_mg_version = -1;
+    ctx->mg_fine->uu_mg_version = -1;
+  }
+  if (ifem_ctx *below = ctx->mg_coarse) {
+    below->mg_fine = nullptr;
+    hipStream_t ns = nullptr, nh = nullptr;
+    if (!below->owns_stream && hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) == hipSuccess) {
+      for (ifem_ctx *c = below; c; c = c->mg_coarse) { c->stream = ns; c->owns_stream = c == below; }
+    }
+    if (below->halo.hstream && !below->halo.owns_hstream) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (hipStreamCreateWithPriority(&nh, hipStreamNonBlocking, hi) == hipSuccess)
+        for (ifem_ctx *c = below; c; c = c->mg_coarse) { c->halo.hstream = nh; c->halo.owns_hstream = c == below; }
+    }
+  }
   comm_destroy(ctx);
   ifem::tpp_release(ctx);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
@@ -226,8 +246,12 @@ int ifem_set_constraints(ifem_ctx *ctx, int which, int32_t n, const int32_t *dof
       kv.push_back(inhom ? inhom[i] : 0.0);
     }
     for (int32_t d : kd) seen[d] = 0;
-    if (bad == 1) throw Error(IFEM_E_BADPARAM, "constraint dof out of range");
-    if (bad == 2) throw Error(IFEM_E_BADPARAM, "pressure Dirichlet constraints are not supported");
+    // the call is collective on partitioned contexts (constraint_set_identity all-reduces): every rank must fail together,
+    // or the ranks with good lists would wait in that all-reduce for the one that threw
+    double worst = bad;
+    allreduce_max(ctx, &worst, 1);
+    if (worst == 1.0) throw Error(IFEM_E_BADPARAM, bad == 1 ? "constraint dof out of range" : "constraint dof out of range on another rank");
+    if (worst == 2.0) throw Error(IFEM_E_BADPARAM, "pressure Dirichlet constraints are not supported");
   }
   hipStream_t s = ctx->stream;
   DBuf<int32_t> d_dof;
@@ -310,13 +334,26 @@ int ifem_set_hanging_constraints(ifem_ctx *ctx, int32_t n, const int32_t *dof, c
 int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t) {
   IFEM_API_BEGIN
   if (!fine || !coarse || !t || fine == coarse) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: two contexts and a transfer table");
-  if (fine->dim != coarse->dim || fine->halo.nranks != coarse->halo.nranks || fine->device != coarse->device)
-    throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: the levels must share dimension, device and rank count");
+  if (fine->dim != coarse->dim || fine->kv != coarse->kv || fine->halo.nranks != coarse->halo.nranks ||
+      fine->halo.rank != coarse->halo.rank || fine->device != coarse->device)
+    throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: the levels must share dimension, velocity degree, device, rank and rank count");
+  if (coarse->mg_fine && coarse->mg_fine != fine)
+    throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: the coarse context already hangs below another level");
+  for (const ifem_ctx *c = coarse; c; c = c->mg_coarse)
+    if (c == fine) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: the fine context is a level below the coarse one");
+  // row pointers non-decreasing and closed: a malformed table would send the transfer kernels out of bounds
+  auto monotone = [](const int64_t *ptr, int64_t n_rows, int64_t nnz_, const char *what) {
+    if (ptr[0] != 0 || ptr[n_rows] != nnz_) throw Error(IFEM_E_BADPARAM, std::string("ifem_mg_attach: ") + what + " row pointers do not span the table");
+    for (int64_t r = 0; r < n_rows; ++r)
+      if (ptr[r + 1] < ptr[r]) throw Error(IFEM_E_BADPARAM, std::string("ifem_mg_attach: ") + what + " row pointers decrease");
+  };
   if (t->n_fine_p_owned != fine->nPo || t->n_coarse_p_local != coarse->nPl)
     throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: P_p needs one row per owned fine pressure node, R_p one per local coarse pressure node");
   if (!t->pp_ptr || !t->pp_col || !t->pp_w || !t->rp_ptr || !t->rp_col || !t->rp_w) throw Error(IFEM_E_BADPARAM, "null transfer table");
   const int64_t nnz = t->pp_ptr[fine->nPo];
-  if (t->pp_ptr[0] != 0 || t->rp_ptr[0] != 0 || t->rp_ptr[coarse->nPl] != nnz) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: R_p is not the transpose of P_p");
+  if (nnz < 0 || t->rp_ptr[coarse->nPl] != nnz) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: R_p is not the transpose of P_p");
+  monotone(t->pp_ptr, fine->nPo, nnz, "P_p");
+  monotone(t->rp_ptr, coarse->nPl, nnz, "R_p");
   for (int64_t k = 0; k < nnz; ++k) {
     if (t->pp_col[k] < 0 || t->pp_col[k] >= coarse->nPl) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: P_p column out of range");
     if (t->rp_col[k] < 0 || t->rp_col[k] >= fine->nPo) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: R_p column out of range");
@@ -336,7 +373,9 @@ int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t) 
     if (t->n_fine_u_owned != fine->nUo || t->n_coarse_u_local != coarse->nUl)
       throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: P_u needs one row per owned fine velocity node, R_u one per local coarse velocity node");
     const int64_t nu = t->pu_ptr[fine->nUo];
-    if (t->pu_ptr[0] != 0 || t->ru_ptr[0] != 0 || t->ru_ptr[coarse->nUl] != nu) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: R_u is not the transpose of P_u");
+    if (nu < 0 || t->ru_ptr[coarse->nUl] != nu) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: R_u is not the transpose of P_u");
+    monotone(t->pu_ptr, fine->nUo, nu, "P_u");
+    monotone(t->ru_ptr, coarse->nUl, nu, "R_u");
     for (int64_t k = 0; k < nu; ++k) {
       if (t->pu_col[k] < 0 || t->pu_col[k] >= coarse->nUl) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: P_u column out of range");
       if (t->ru_col[k] < 0 || t->ru_col[k] >= fine->nUo) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: R_u column out of range");
@@ -354,7 +393,9 @@ int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t) 
     fine->mg_inj_u.upload(t->inj_u, (size_t)coarse->nUo, s);
   }
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  if (fine->mg_coarse && fine->mg_coarse != coarse) fine->mg_coarse->mg_fine = nullptr; // re-attach: the old level is on its own
   fine->mg_coarse = coarse;
+  coarse->mg_fine = fine;
   fine->sm_mg_version = -1;
   fine->uu_mg_version = -1;
   // one stream for the whole chain: the V-cycle walks up and down the levels and every launch must stay in order
@@ -662,6 +703,21 @@ int ifem_system_vmult(ifem_ctx *ctx, int dst, int src) {
   IFEM_API_END
 }
 
+int ifem_true_residual(ifem_ctx *ctx, double *residual_l2, double *rhs_l2) {
+  IFEM_API_BEGIN
+  if (!ctx->assembled || !residual_l2) throw Error(IFEM_E_BADPARAM, "ifem_true_residual after an assembly and a solve");
+  const int64_t n = int64_t(ctx->dim) * ctx->nUo + ctx->nPo;
+  DBuf<double> r;
+  r.alloc((size_t)n + 8);
+  ins_system_vmult(ctx, ctx->vec[IFEM_VEC_UPDATE].p, r.p);
+  v_axpby(ctx, n, 1.0, ctx->vec[IFEM_VEC_RHS].p, -1.0, r.p); // r = b - A x
+  apply_constraints(ctx, 0, r.p); // zero_constraints: the constrained rows are set to 0 and drop out of the norm
+  *residual_l2 = std::sqrt(bv_dot(ctx, r.p, r.p));
+  if (rhs_l2) *rhs_l2 = std::sqrt(bv_dot(ctx, ctx->vec[IFEM_VEC_RHS].p, ctx->vec[IFEM_VEC_RHS].p));
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+
 int ifem_mass_vmult(ifem_ctx *ctx, int dst, int src) {
   IFEM_API_BEGIN
   if (!vec_ok(dst) || !vec_ok(src) || is_ext(dst) || is_ext(src) || dst == src) throw Error(IFEM_E_BADPARAM, "use two non-ghosted vectors");
@@ -782,6 +838,13 @@ int ifem_export_csr(ifem_ctx *ctx, int which, int64_t *rowptr, int32_t *col, dou
 int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t) {
   IFEM_API_BEGIN
   *t = ctx->timing; // spmv_uu_bytes is set by the profiled launches themselves (linalg.hip::spmv_uu)
+  IFEM_API_END
+}
+
+int ifem_comm_stats_get(ifem_ctx *ctx, ifem_comm_stats *out, int reset) {
+  IFEM_API_BEGIN
+  if (!out) throw Error(IFEM_E_BADPARAM, "ifem_comm_stats_get: null output");
+  ifem::comm_stats(ctx, out, reset != 0);
   IFEM_API_END
 }
 

@@ -174,6 +174,7 @@ static void exchange(ifem_ctx *ctx, double *x, int which, bool async = false) {
   double *sendbuf = sendbuf_of(ctx);
   const int nn = (int)h.nbr.size();
   const int64_t ns = sptr[nn];
+  ++h.n_exchanges;
   if (ns) {
     int64_t g = (ns * bs + 255) / 256;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, ctx->stream, ns, bs, sidx.p, x, sendbuf);
@@ -257,6 +258,7 @@ static void reverse_add(ifem_ctx *ctx, double *x, int which) {
   double *buf = h.sendbuf.p + (which == 0 ? 0 : (size_t)ctx->dim * h.send_u_ptr.back()); // the forward send region, now receiving
   const int nn = (int)h.nbr.size();
   const int64_t ns = sptr[nn];
+  ++h.n_exchanges;
   if (h.local) {
     auto *w = static_cast<LocalWorld *>(h.local);
     h.rev_src = x;
@@ -328,6 +330,7 @@ int comm_unique_id(uint8_t out[128]) {
 static void allreduce(ifem_ctx *ctx, double *host_vals, int n, bool is_max) {
   Halo &h = ctx->halo;
   if (h.nranks == 1) return;
+  ++h.n_allreduce_host;
   if (h.local) {
     auto *w = static_cast<LocalWorld *>(h.local);
     w->red[h.rank].assign(host_vals, host_vals + n);
@@ -362,7 +365,9 @@ void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, hos
 void allreduce_sum_dev(ifem_ctx *ctx, double *dev_vals, int n) {
   Halo &h = ctx->halo;
   if (h.nranks == 1 || n <= 0) return;
+  ++h.n_allreduce_dev;
   if (h.local) {
+    --h.n_allreduce_host; // the validation transport goes through the host path below: count it once, as a device one
     std::vector<double> tmp(n);
     IFEM_HIP_CHECK(hipMemcpyAsync(tmp.data(), dev_vals, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -432,6 +437,30 @@ int comm_selftest(int device) {
   for (int i = 0; i < 64; ++i) if (out2[i] != h[i]) throw Error(IFEM_E_COMM, "RCCL self-test: wrong data on the halo stream");
   for (int i = 0; i < 64; ++i) if (out[i] != h[i]) throw Error(IFEM_E_COMM, "RCCL self-test: wrong data");
   return IFEM_OK;
+}
+
+// what the context's communicator looks like and how much it was used (the whole multigrid chain below ctx included)
+void comm_stats(ifem_ctx *ctx, ifem_comm_stats *out, bool reset) {
+  std::memset(out, 0, sizeof(*out));
+  const Halo &h0 = ctx->halo;
+  out->nranks = h0.nranks;
+  out->rank = h0.rank;
+  out->n_neighbors = (int32_t)h0.nbr.size();
+  out->transport = h0.nranks == 1 ? 0 : (h0.local ? 2 : 1);
+  if (h0.comm) {
+    int cn = 0;
+    IFEM_NCCL_CHECK(ncclCommCount((ncclComm_t)h0.comm, &cn));
+    out->rccl_nranks = cn;
+    out->halo_stream = h0.comm2 && h0.hstream ? 1 : 0;
+  }
+  for (ifem_ctx *c = ctx; c; c = c->mg_coarse) {
+    Halo &h = c->halo;
+    out->halo_exchanges += h.n_exchanges;
+    out->allreduce_dev += h.n_allreduce_dev;
+    out->allreduce_host += h.n_allreduce_host;
+    ++out->levels;
+    if (reset) h.n_exchanges = h.n_allreduce_dev = h.n_allreduce_host = 0;
+  }
 }
 
 void *local_world_create(int nranks) { return new LocalWorld(nranks); }

@@ -151,6 +151,9 @@ struct Halo {
   hipEvent_t ev_pack = nullptr, ev_done = nullptr;
   void *local = nullptr; // LocalWorld* (in-process virtual ranks, validation transport)
   const double *rev_src = nullptr; // local world only: the extended vector whose ghosts the peers fetch in a reverse exchange
+  // counters since the last ifem_comm_stats(reset): halo exchanges (forward + reverse), all-reduces ordered on the stream,
+  // all-reduces that made the host wait for the device
+  uint64_t n_exchanges = 0, n_allreduce_dev = 0, n_allreduce_host = 0;
 };
 
 } // namespace ifem
@@ -271,12 +274,15 @@ struct ifem_ctx {
   // multigrid (ifem_mg_attach): the next coarser level (not owned) and the pressure transfers to it; per-level state of
   // the S_m V-cycle: 1/diag(S_m), largest eigenvalue of D^-1 S_m, scratch vectors [nPl]
   ifem_ctx *mg_coarse = nullptr;
+  ifem_ctx *mg_fine = nullptr; // back link (not owned): the level this context hangs below, whose stream(s) it borrows
   ifem::MgCsr mg_Pp, mg_Rp, mg_Pu, mg_Ru;
   ifem::DBuf<int32_t> mg_inj_u; // [nUo of the coarse level] coincident owned velocity node of this level
   ifem::DBuf<uint8_t> mg_Pu_mask, mg_Ru_mask; // per weight: components dropped by the Dirichlet flags of the two levels
   int64_t mg_mask_key[2] = {-1, -1};          // constrained-dof sets (flag ids of this level and the coarser one) of the masks
   ifem::DBuf<double> sm_dinv, mg_vec[6], mgu_vec[5];
   double sm_lmax = 0, uu_lmax = 0;
+  double uu_evn = 0, uu_lmax_evn = -1; // ||evaluation point|| of the current assembly (finest level) / of the cached A_uu bound
+  int64_t uu_evn_asm = -1;
   // last iterate of the two power iterations: the next estimate (new constrained-dof set, same mesh) starts from it
   ifem::DBuf<double> sm_eig, uu_eig;
   int64_t uu_lmax_asm = -1; // ifem_tuning::geo_cache = 2: the finest level's assembly the A_uu bound was last refreshed for

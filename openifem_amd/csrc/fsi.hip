@@ -952,7 +952,9 @@ void fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int
     stats->n_lines = h_cnt[3];
     stats->n_not_found = (int64_t)nf;
   }
-  if (nf != 0.0) throw Error(IFEM_E_BADPARAM, "Cannot find point in solid (mpi_fsi.cpp:526-533): " + std::to_string((int64_t)nf) + " support point(s)");
+  // (the reference's "Cannot find point in solid", mpi_fsi.cpp:526-533, is raised at the END of this function: by then the
+  // Dirichlet-merge kernels have written the flags of both sets, and a caller that catches the error must find the set
+  // identities -- which decide whether B, B^T and S_m are reused -- in step with those flags)
   if (use_dirichlet_bc) { // identity of the two constrained-dof sets (ctx.hpp), in the order two ifem_set_constraints calls
                           // would decide it: set 0 against (old 0, old 1), then set 1 against (old 1, new 0)
     const DBuf<uint8_t> *pa[4] = {&ctx->is_c[0], &ctx->is_c[0], &ctx->is_c[1], &ctx->is_c[1]};
@@ -984,6 +986,7 @@ void fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int
     }
   }
   IFEM_HIP_CHECK(hipStreamSynchronize(st));
+  if (nf != 0.0) throw Error(IFEM_E_BADPARAM, "Cannot find point in solid (mpi_fsi.cpp:526-533): " + std::to_string((int64_t)nf) + " support point(s)");
 }
 
 

@@ -271,6 +271,71 @@ int ifemx_sm_plan_tables(void *hv, int32_t *box_id, int32_t *send_s_ptr, int32_t
   });
 }
 
+// Multigrid levels of the host mirror (insim.hpp, FluidSolver::multigrid): on / off, the smallest number of cells per rank a
+// halved direction keeps, and -- validation transport only -- the local worlds of the coarser levels.  Before ifemx_setup.
+int ifemx_set_multigrid(void *hv, int on, int min_cells, void *const *level_worlds, int n_worlds) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto set = [&](auto &s) {
+      s.multigrid = on != 0;
+      if (min_cells > 0) s.mg_min_cells = min_cells;
+      s.mg_local_worlds.assign(level_worlds, level_worlds + (level_worlds ? n_worlds : 0));
+    };
+    if (h->dim == 2) set(*h->s2); else set(*h->s3);
+  });
+}
+// the levels attached below the solver's context: *n_levels, their global repetitions reps[level][3] and contexts (each
+// array may be NULL; room for 16 levels)
+int ifemx_mg_levels(void *hv, int *n_levels, int32_t *reps, void **ctxs) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto fill = [&](auto &s) {
+      auto lv = s.multigrid_levels();
+      if (lv.size() > 16) throw std::runtime_error("ifemx_mg_levels: more than 16 levels");
+      if (n_levels) *n_levels = (int)lv.size();
+      for (size_t k = 0; k < lv.size(); ++k) {
+        if (reps) for (int d = 0; d < 3; ++d) reps[3 * k + d] = lv[k]->get_triangulation().reps[d];
+        if (ctxs) ctxs[k] = lv[k]->context();
+      }
+    };
+    if (h->dim == 2) fill(*h->s2); else fill(*h->s3);
+  });
+}
+// multigrid.hpp::coarse_level_chain: out[level][3] cells per rank (room for 16 levels), *n_levels
+int ifemx_coarse_level_chain(int dim, const int *cells_per_rank, const int *P, const double *extent, int min_cells,
+                             int32_t *out, int *n_levels) {
+  return guard([&] {
+    std::array<int, 3> n{1, 1, 1}, p{1, 1, 1};
+    std::array<double, 3> e{1, 1, 1};
+    for (int d = 0; d < dim; ++d) { n[d] = cells_per_rank[d]; p[d] = P[d]; e[d] = extent[d]; }
+    auto chain = coarse_level_chain(dim, n, p, e, min_cells, 16);
+    *n_levels = (int)chain.size();
+    for (size_t k = 0; k < chain.size(); ++k) for (int d = 0; d < 3; ++d) out[3 * k + d] = chain[k][d];
+  });
+}
+// multigrid.hpp::box_prolongation for the tests' checker.  Two calls: with col = NULL it fills ptr [n_fine + 1] only
+// (the number of entries is ptr[n_fine]), with col / w it fills them too.
+int ifemx_box_prolongation(int dim, const int *reps_fine, const int *reps_coarse, int degree, const int64_t *l2g_fine,
+                           int64_t n_fine, const int64_t *l2g_coarse, int64_t n_coarse, int64_t *ptr, int32_t *col, double *w) {
+  return guard([&] {
+    std::array<int, 3> rf{1, 1, 1}, rc{1, 1, 1};
+    for (int d = 0; d < dim; ++d) { rf[d] = reps_fine[d]; rc[d] = reps_coarse[d]; }
+    CsrTransfer P;
+    box_prolongation(dim, rf, rc, degree, l2g_fine, n_fine, l2g_coarse, n_coarse, P);
+    std::memcpy(ptr, P.ptr.data(), P.ptr.size() * sizeof(int64_t));
+    if (col) { std::memcpy(col, P.col.data(), P.col.size() * sizeof(int32_t)); std::memcpy(w, P.w.data(), P.w.size() * sizeof(double)); }
+  });
+}
+int ifemx_box_injection(int dim, const int *reps_fine, const int *reps_coarse, int degree, const int64_t *l2g_coarse,
+                        int64_t n_coarse, const int64_t *l2g_fine, int64_t n_fine, int32_t *out) {
+  return guard([&] {
+    std::array<int, 3> rf{1, 1, 1}, rc{1, 1, 1};
+    for (int d = 0; d < dim; ++d) { rf[d] = reps_fine[d]; rc[d] = reps_coarse[d]; }
+    auto inj = box_injection(dim, rf, rc, degree, l2g_coarse, n_coarse, l2g_fine, n_fine);
+    std::memcpy(out, inj.data(), inj.size() * sizeof(int32_t));
+  });
+}
+
 #define DISPATCH(h, expr2, expr3) (static_cast<Handle *>(h)->dim == 2 ? (expr2) : (expr3))
 
 int ifemx_run(void *hv) {
@@ -397,38 +462,8 @@ int ifemx_cell_tables(void *hv, int32_t *cell_unodes, int32_t *cell_pnodes, int3
 int ifemx_channel_state(void *hv, double L, double H, double dP, double mu, uint64_t seed, double rel) {
   auto *h = static_cast<Handle *>(hv);
   return guard([&] {
-    auto fill = [&](auto &solver, auto dimtag) {
-      constexpr int D = decltype(dimtag)::value;
-      auto &d = solver.dof_tables();
-      const int64_t n_u = d.n_u(), n = d.n_dofs();
-      std::vector<double> present((size_t)n, 0.0), ev;
-      const double umax = dP * H * H / (8 * mu * L);
-      for (int64_t nd = 0; nd < d.n_unodes; ++nd) {
-        const double y = d.unode_coords[nd][1];
-        present[nd * D] = dP / (2 * mu * L) * y * (H - y);
-      }
-      for (int64_t nd = 0; nd < d.n_pnodes; ++nd) present[n_u + nd] = dP * (1.0 - d.pnode_coords[nd][0] / L);
-      ev = present;
-      // perturbation keyed by the GLOBAL dof so that every partition of the mesh sees the same field:
-      // one mt19937_64(seed) draw sequence would depend on the local numbering
-      auto &pt = solver.partition();
-      auto unit = [&](uint64_t key) {
-        std::mt19937_64 gen(seed ^ (key * 0x9E3779B97F4A7C15ull));
-        gen.discard(1);
-        return std::uniform_real_distribution<double>(-1.0, 1.0)(gen);
-      };
-      for (int64_t nd = 0; nd < d.n_unodes; ++nd)
-        for (int c = 0; c < D; ++c) ev[nd * D + c] += rel * umax * unit((uint64_t)pt.l2g_u[nd] * D + c);
-      for (int64_t nd = 0; nd < d.n_pnodes; ++nd) ev[n_u + nd] += rel * dP * unit((uint64_t)(D * pt.n_unodes_global + pt.l2g_p[nd]));
-      // constrained dofs keep the boundary values
-      std::vector<int32_t> cd; std::vector<double> cv;
-      solver.constraint_lines(cd, cv);
-      for (size_t k = 0; k < cd.size(); ++k) ev[cd[k]] = present[cd[k]];
-      if (ifem_vec_set(solver.context(), IFEM_VEC_PRESENT, present.data()) < 0 ||
-          ifem_vec_set(solver.context(), IFEM_VEC_EVAL, ev.data()) < 0)
-        throw std::runtime_error(ifem_last_error());
-    };
-    if (h->dim == 2) fill(*h->s2, std::integral_constant<int, 2>()); else fill(*h->s3, std::integral_constant<int, 3>());
+    if (h->dim == 2) Utils::channel_bench_state<2>(*h->s2, L, H, dP, mu, seed, rel);
+    else Utils::channel_bench_state<3>(*h->s3, L, H, dP, mu, seed, rel);
   });
 }
 

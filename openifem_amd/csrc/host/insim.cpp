@@ -32,7 +32,78 @@ FluidSolver<dim>::FluidSolver(Triangulation<dim> &tria, const Parameters::AllPar
 
 template <int dim>
 FluidSolver<dim>::~FluidSolver() {
+  mg_coarse.reset(); // coarser levels first: their contexts run on this context's stream
   if (ctx) ifem_ctx_destroy(ctx);
+}
+
+template <int dim>
+std::vector<const FluidSolver<dim> *> FluidSolver<dim>::multigrid_levels() const {
+  std::vector<const FluidSolver<dim> *> out;
+  for (const FluidSolver<dim> *s = mg_coarse.get(); s; s = s->mg_coarse.get()) out.push_back(s);
+  return out;
+}
+
+// The chain of coarser levels below this solver: the next coarser box mesh of multigrid.hpp, the same
+// formulation / parameters / boundary conditions / partition on it (a full solver: it makes its own constraints and
+// builds ITS coarser level in its initialize_system), the nodal transfers between the two lattices, ifem_mg_attach.
+template <int dim>
+bool FluidSolver<dim>::attach_multigrid_levels() {
+  mg_coarse.reset();
+  mg_tria.reset();
+  if (!multigrid || !triangulation.is_box || !ctx) return false;
+  std::array<int, 3> n{1, 1, 1}, next;
+  std::array<double, 3> extent{1, 1, 1};
+  for (int d = 0; d < dim; ++d) {
+    n[d] = triangulation.reps[d] / proc_grid[d];
+    extent[d] = triangulation.p1[d] - triangulation.p0[d];
+  }
+  if (!next_coarser_level(dim, n, proc_grid, extent, mg_min_cells, next)) return false;
+  // validation transport: every level rendezvous in a world of its own, handed in by the caller; none left = chain ends
+  void *level_world = nullptr;
+  if (local_world) {
+    if (mg_local_worlds.empty()) return false;
+    level_world = mg_local_worlds.front();
+  }
+  mg_tria.reset(new Triangulation<dim>());
+  std::vector<unsigned> reps(dim);
+  std::array<double, dim> a, b;
+  for (int d = 0; d < dim; ++d) { reps[d] = (unsigned)(next[d] * proc_grid[d]); a[d] = triangulation.p0[d]; b[d] = triangulation.p1[d]; }
+  GridGenerator::subdivided_hyper_rectangle<dim>(*mg_tria, reps, a, b, triangulation.colorized, /*lazy=*/true);
+  std::unique_ptr<FluidSolver<dim>> c = make_level_solver(*mg_tria);
+  if (!c) { mg_tria.reset(); return false; }
+  c->pcout = nullptr;
+  c->multigrid = true;
+  c->mg_min_cells = mg_min_cells;
+  c->dofs.morton = dofs.morton;
+  c->hard_coded_boundary_values = hard_coded_boundary_values;
+  c->field_time = field_time;
+  c->set_partition(proc_grid, part_rank, nccl_id.empty() ? nullptr : nccl_id.data(), level_world);
+  c->mg_local_worlds.assign(mg_local_worlds.begin() + (mg_local_worlds.empty() ? 0 : 1), mg_local_worlds.end());
+  c->setup_dofs();
+  c->make_constraints();
+  c->initialize_system(); // recursion: attaches the levels below c
+  // transfers between the two node lattices (owned fine rows, local coarse columns)
+  const int kv = dofs.kv;
+  std::array<int, 3> rf{1, 1, 1}, rc{1, 1, 1};
+  for (int d = 0; d < dim; ++d) { rf[d] = triangulation.reps[d]; rc[d] = mg_tria->reps[d]; }
+  CsrTransfer Pp, Rp, Pu, Ru;
+  box_prolongation(dim, rf, rc, 1, part.l2g_p.data(), dofs.n_pnodes_owned, c->part.l2g_p.data(), c->dofs.n_pnodes, Pp);
+  transpose_transfer(Pp, Rp);
+  box_prolongation(dim, rf, rc, kv, part.l2g_u.data(), dofs.n_unodes_owned, c->part.l2g_u.data(), c->dofs.n_unodes, Pu);
+  transpose_transfer(Pu, Ru);
+  const std::vector<int32_t> inj = box_injection(dim, rf, rc, kv, c->part.l2g_u.data(), c->dofs.n_unodes_owned,
+                                                 part.l2g_u.data(), dofs.n_unodes_owned);
+  ifem_mg_transfer t{};
+  t.n_fine_p_owned = Pp.n_rows; t.n_coarse_p_local = Pp.n_cols;
+  t.pp_ptr = Pp.ptr.data(); t.pp_col = Pp.col.data(); t.pp_w = Pp.w.data();
+  t.rp_ptr = Rp.ptr.data(); t.rp_col = Rp.col.data(); t.rp_w = Rp.w.data();
+  t.n_fine_u_owned = Pu.n_rows; t.n_coarse_u_local = Pu.n_cols;
+  t.pu_ptr = Pu.ptr.data(); t.pu_col = Pu.col.data(); t.pu_w = Pu.w.data();
+  t.ru_ptr = Ru.ptr.data(); t.ru_col = Ru.col.data(); t.ru_w = Ru.w.data();
+  t.inj_u = inj.data();
+  check(ifem_mg_attach(ctx, c->ctx, &t), "attach_multigrid_levels");
+  mg_coarse = std::move(c);
+  return true;
 }
 
 template <int dim>
@@ -121,6 +192,10 @@ void FluidSolver<dim>::make_constraints() {
     check(ifem_set_constraints(ctx, 1, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nonzero_values.data()), "make_constraints");
     check(ifem_set_constraints(ctx, 0, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nullptr), "make_constraints");
   }
+  if (mg_coarse) { // the levels keep their constraint sets in step with this one (ifem_hip.h, ifem_mg_attach)
+    mg_coarse->field_time = field_time;
+    mg_coarse->make_constraints();
+  }
 }
 
 template <int dim>
@@ -177,6 +252,12 @@ InsIM<dim>::InsIM(Triangulation<dim> &tria, const Parameters::AllParameters &par
 template <int dim>
 void InsIM<dim>::initialize_system() {
   FluidSolver<dim>::initialize_system();
+  // box meshes: multigrid levels for A~^-1 and CG(S_m); the measured best inner solver on them becomes the default
+  // (matrix-free operator + V-cycle, restart 16 = one multi-dot pass of the single-precision basis)
+  if (this->attach_multigrid_levels() && solver_opts.ainv_kind == IFEM_AINV_GMRES_BJACOBI) {
+    solver_opts.ainv_kind = IFEM_AINV_MG;
+    solver_opts.inner_restart = 16;
+  }
 }
 
 template <int dim>
@@ -266,6 +347,12 @@ InsIMEX<dim>::InsIMEX(Triangulation<dim> &tria, const Parameters::AllParameters 
     throw std::invalid_argument("Velocity finite element should be one order higher than pressure!");
   ifem_default_solver_opts(&solver_opts);
   solver_opts.inner_rel = 1e-4; // CG for A: max(1e-12, 1e-4 ||.||)  (mpi_insimex.cpp:117-118)
+}
+
+template <int dim>
+void InsIMEX<dim>::initialize_system() {
+  FluidSolver<dim>::initialize_system();
+  this->attach_multigrid_levels(); // CG(S_m) is multigrid-preconditioned on box meshes; A~^-1 stays the caller's choice
 }
 
 template <int dim>

@@ -15,6 +15,7 @@
 #include <vector>
 #include "../../../include/ifem_hip.h"
 #include "grid.hpp"
+#include "multigrid.hpp"
 #include "parameters.hpp"
 
 namespace ifem_host {
@@ -103,8 +104,20 @@ public:
   unsigned int current_timestep() const { return time.get_timestep(); }
   double current_time() const { return time.current(); }
   const DoFTables<dim> &dof_tables() const { return dofs; }
+  const Triangulation<dim> &get_triangulation() const { return triangulation; }
   void constraint_lines(std::vector<int32_t> &d, std::vector<double> &v) const { d = constraint_dofs; v = nonzero_values; }
   std::ostream *pcout = &std::cout; // ConditionalOStream on rank 0; nullptr silences
+  // Geometric multigrid levels for the preconditioner's inner solves.  When the triangulation is a box
+  // and the formulation uses them (InsIM, InsIMEX), initialize_system() builds the chain of coarser box meshes
+  // (multigrid.hpp::next_coarser_level), sets each up as a solver of the same problem on the same partition and hangs it
+  // below this context with ifem_mg_attach.  The reference needs none: MUMPS (mpi_insim.cpp:124-127).
+  bool multigrid = true;
+  int mg_min_cells = 4; // a direction is halved only while it keeps this many cells per rank
+  // validation transport only (set_partition with local_world): the worlds of the coarser levels, finest coarse level
+  // first -- every level's virtual ranks meet in a world of their own; the chain ends where the list does
+  std::vector<void *> mg_local_worlds;
+  // the coarser levels hanging below this solver, finest first (borrowed pointers; each level owns the next)
+  std::vector<const FluidSolver<dim> *> multigrid_levels() const;
 
   virtual void run_one_step(bool apply_nonzero_constraints, bool assemble_system = true) = 0;
   void setup_dofs();
@@ -113,6 +126,12 @@ public:
 
 protected:
   void check(int rc, const char *what) const;
+  // the same formulation on another triangulation (a coarser multigrid level); nullptr: this family keeps no levels
+  virtual std::unique_ptr<FluidSolver<dim>> make_level_solver(Triangulation<dim> &) const { return nullptr; }
+  // builds the next coarser level (recursively the whole chain) and attaches it; false when there is none
+  bool attach_multigrid_levels();
+  std::unique_ptr<Triangulation<dim>> mg_tria;        // declared before mg_coarse: destroyed after it
+  std::unique_ptr<FluidSolver<dim>> mg_coarse;        // the next coarser level (its context borrows this one's stream)
   // refine_mesh (mpi_fluid_solver.cpp:418-488, called from run_one_step when time_to_refine() fires in a pure-fluid run,
   // mpi_insim.cpp:485-489) is not part of the host mirror: stop with a message instead of computing on another mesh
   void refine_mesh_not_supported() const;
@@ -153,6 +172,11 @@ public:
   ifem_solve_stats last_stats{};
   ifem_ins_params ins_params() const;
 
+protected:
+  std::unique_ptr<FluidSolver<dim>> make_level_solver(Triangulation<dim> &t) const override {
+    return std::unique_ptr<FluidSolver<dim>>(new InsIM<dim>(t, parameters, this->device));
+  }
+
 private:
   using FluidSolver<dim>::parameters;
   using FluidSolver<dim>::time;
@@ -168,6 +192,7 @@ public:
   InsIMEX(Triangulation<dim> &, const Parameters::AllParameters &, int device = 0);
   void run() override;
   void run_one_step(bool apply_nonzero_constraints, bool assemble_system = true) override;
+  void initialize_system() override;
   void assemble(bool use_nonzero_constraints, bool assemble_system);
   std::pair<unsigned int, double> solve(bool use_nonzero_constraints, bool assemble_system);
   void assemble(bool use_nonzero_constraints) { assemble(use_nonzero_constraints, true); }
@@ -175,6 +200,11 @@ public:
   ifem_solver_opts solver_opts;
   ifem_solve_stats last_stats{};
   ifem_ins_params ins_params() const;
+
+protected:
+  std::unique_ptr<FluidSolver<dim>> make_level_solver(Triangulation<dim> &t) const override {
+    return std::unique_ptr<FluidSolver<dim>>(new InsIMEX<dim>(t, parameters, this->device));
+  }
 
 private:
   using FluidSolver<dim>::parameters;
@@ -238,4 +268,13 @@ private:
 
 } // namespace MPI
 } // namespace Fluid
+
+namespace Utils {
+// The timed state of the benchmark channel [0,L]x[0,H](x[0,W]): present = analytic plane Poiseuille of the
+// pressure-driven channel, evaluation point = present + a seeded perturbation keyed by the GLOBAL dof id (uniform in
+// +-rel*Umax on unconstrained velocity dofs, +-rel*dP on pressure), both uploaded; Dirichlet dofs keep the present values.
+template <int dim>
+void channel_bench_state(Fluid::MPI::FluidSolver<dim> &solver, double L = 2.0, double H = 0.2, double dP = 10.0, double mu = 1.0,
+                         uint64_t seed = 1234, double rel = 1e-3);
+} // namespace Utils
 } // namespace ifem_host

@@ -146,6 +146,7 @@ void allreduce_max(ifem_ctx *ctx, double *host_vals, int n);
 void allreduce_sum_dev(ifem_ctx *ctx, double *dev_vals, int n); // device scalars, in place, stream-ordered
 int comm_unique_id(uint8_t out[128]);
 int comm_selftest(int device);
+void comm_stats(ifem_ctx *ctx, ifem_comm_stats *out, bool reset);
 void *local_world_create(int nranks);
 void local_world_destroy(void *w);
 // ghost refresh of a ghost-extended velocity buffer [dim*nUl] / pressure buffer [nPl] (RCCL send/recv over xGMI)

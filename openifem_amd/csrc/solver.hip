@@ -588,8 +588,17 @@ static void uu_apply_level(SolveState &S, const double *x, double *y, const MfFu
   apply_uu_mf(c, xe, y, true, fuse);
 }
 
-static void mg_uu_setup(MgUu &M) {
+static void mg_uu_setup(MgUu &M, bool force_bounds = false) {
   ifem_ctx *f0 = M.L[0].ctx;
+  // size of the evaluation point the bounds below were estimated at: A_uu carries rho C(u), so a bound taken at a small
+  // velocity must not outlive a grown convective part.  One norm per assembly on the finest level (all levels see the same
+  // field by injection); a change of more than 10 % refreshes the estimates (warm: 2-3 power steps per level)
+  if (f0->uu_evn_asm != f0->asm_version) {
+    double e2 = v_dot(f0, int64_t(f0->dim) * f0->nUo, f0->mf_eval.p, f0->mf_eval.p);
+    allreduce_sum(f0, &e2, 1);
+    f0->uu_evn = std::sqrt(e2);
+    f0->uu_evn_asm = f0->asm_version;
+  }
   for (size_t l = 0; l < M.L.size(); ++l) {
     SolveState &S = M.L[l];
     ifem_ctx *c = S.ctx;
@@ -624,11 +633,13 @@ static void mg_uu_setup(MgUu &M) {
     // point (the viscous and mass terms carry the top of the spectrum): estimated once per such state
     const double key[6] = {f0->mf_params.viscosity, f0->mf_params.rho, f0->mf_params.grad_div, f0->mf_params.dt,
                            double(f0->mf_noconv), double(c->flag_id[c->asm_constraint_set])};
-    bool same = c->uu_lmax > 0;
+    bool same = c->uu_lmax > 0 && !force_bounds;
     for (int i = 0; i < 6; ++i) same = same && key[i] == c->uu_lmax_key[i];
+    same = same && std::fabs(f0->uu_evn - c->uu_lmax_evn) <= 0.1 * std::max(c->uu_lmax_evn, 1e-300);
     if (c->tune.geo_cache == 2 && c->uu_lmax_asm != f0->asm_version) same = false; // measurement mode: a new set per assembly
     c->uu_lmax_asm = f0->asm_version;
     if (same) continue;
+    if (force_bounds) c->uu_lmax = 0; // cold estimate: all 12 steps from a rough vector
     // power iteration on B A_uu.  A level that has an estimate from another constrained-dof set starts from that run's last
     // iterate and stops once the estimate moves by less than 1 % (the top of this spectrum belongs to the mesh, not to the
     // set); the first estimate starts from a fixed rough vector and runs all 12 steps.
@@ -655,7 +666,8 @@ static void mg_uu_setup(MgUu &M) {
       if ((int64_t)c->uu_eig.n != S.nuo) c->uu_eig.alloc((size_t)S.nuo);
       v_copy(c, S.nuo, x, c->uu_eig.p);
     }
-    c->uu_lmax = lam > 0 ? lam : 1.0;
+    c->uu_lmax = lam > 0 && std::isfinite(lam) ? lam : 1.0;
+    c->uu_lmax_evn = f0->uu_evn;
     for (int i = 0; i < 6; ++i) c->uu_lmax_key[i] = key[i];
   }
 }
@@ -847,25 +859,47 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
       mg_uu_vcycle(Mu, 0);
       v_copy(c, S.nuo, c->mgu_vec[1].p, y);
     };
-    if (o->inner_maxit == 0) { // A~^-1 := one V-cycle, no inner Krylov iteration (the outer solver is flexible)
-      Vc(S.utmp, dst0);
-      S.st.inner_iters += 1;
-    } else if (o->inner_maxit < 0) { // -k: k stationary V-cycle sweeps x += V(b - A x): no Arnoldi process, k - 1 operator products
-      const int k = -o->inner_maxit;
-      Vc(S.utmp, dst0);
-      for (int it = 1; it < k; ++it) {
-        Amf(dst0, S.inner_w);
-        v_axpby(c, S.nuo, 1.0, S.utmp, -1.0, S.inner_w); // r = b - A x
-        Vc(S.inner_w, S.inner_z);
-        v_axpy(c, S.nuo, 1.0, S.inner_z, dst0);
+    // one attempt of A~^-1 with the V-cycle; returns false when the result is not finite (a Chebyshev bound below the
+    // spectral radius turns the smoothers into amplifiers)
+    auto attempt = [&]() -> bool {
+      if (o->inner_maxit == 0) { // A~^-1 := one V-cycle, no inner Krylov iteration (the outer solver is flexible)
+        Vc(S.utmp, dst0);
+        S.st.inner_iters += 1;
+      } else if (o->inner_maxit < 0) { // -k: k stationary V-cycle sweeps x += V(b - A x): no Arnoldi process, k - 1 operator products
+        const int k = -o->inner_maxit;
+        Vc(S.utmp, dst0);
+        for (int it = 1; it < k; ++it) {
+          Amf(dst0, S.inner_w);
+          v_axpby(c, S.nuo, 1.0, S.utmp, -1.0, S.inner_w); // r = b - A x
+          Vc(S.inner_w, S.inner_z);
+          v_axpy(c, S.nuo, 1.0, S.inner_z, dst0);
+        }
+        S.st.inner_iters += k;
+      } else { // flexible GMRES: the preconditioned directions are kept, so the update needs no extra V-cycle
+        const int64_t ld = basis_ld(S.ctx, S.nuo);
+        const int mi = std::max(1, o->inner_restart);
+        if ((int64_t)c->innerZ.n < int64_t(mi) * ld) c->innerZ.alloc(size_t(mi) * size_t(ld));
+        S.st.inner_iters += gmres(c, S.nuo, ld, /*reorth=*/false, Amf, Vc, true, S.utmp, dst0, mi, o->inner_maxit, inner_rel_now * un,
+                                  c->innerV.p, c->innerZ.p, S.inner_w, &res, mdot);
       }
-      S.st.inner_iters += k;
-    } else { // flexible GMRES: the preconditioned directions are kept, so the update needs no extra V-cycle
-      const int64_t ld = basis_ld(S.ctx, S.nuo);
-      const int mi = std::max(1, o->inner_restart);
-      if ((int64_t)c->innerZ.n < int64_t(mi) * ld) c->innerZ.alloc(size_t(mi) * size_t(ld));
-      S.st.inner_iters += gmres(c, S.nuo, ld, /*reorth=*/false, Amf, Vc, true, S.utmp, dst0, mi, o->inner_maxit, inner_rel_now * un,
-                                c->innerV.p, c->innerZ.p, S.inner_w, &res, mdot);
+      if (o->inner_maxit > 0) return std::isfinite(res); // the Arnoldi recurrence carries any NaN / Inf of the V-cycle
+      double dn;
+      mdot(1, dst0, S.nuo, dst0, &dn);
+      return std::isfinite(dn);
+    };
+    if (!attempt()) {
+      // re-estimate every level's bound from scratch and try once more; if that fails too, this application falls back to
+      // the node-block Jacobi preconditioned inner solve (the preconditioner degrades, the outer solver stays correct)
+      if (o->verbose) fprintf(stderr, "[ifem] A_uu V-cycle returned non-finite values: re-estimating the Chebyshev bounds\n");
+      mg_uu_setup(Mu, /*force_bounds=*/true);
+      res = 0;
+      if (!attempt()) {
+        if (o->verbose) fprintf(stderr, "[ifem] A_uu V-cycle still non-finite: node-block Jacobi for this application\n");
+        OpFn Pbj = [&](const double *x, double *y) { bjac_apply(c, x, y); };
+        res = 0;
+        S.st.inner_iters += gmres(c, S.nuo, basis_ld(S.ctx, S.nuo), /*reorth=*/false, Amf, Pbj, false, S.utmp, dst0, std::max(1, o->inner_restart),
+                                  std::max(o->inner_maxit, 50), inner_rel_now * un, c->innerV.p, S.inner_z, S.inner_w, &res, mdot);
+      }
     }
     IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
     S.st.t_ainv_ms += ck3.ms();

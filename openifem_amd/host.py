@@ -61,6 +61,12 @@ def _lib():
     L.ifemx_partition_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     L.ifemx_sm_plan_sizes.argtypes = [C.c_void_p, C.c_void_p]
     L.ifemx_sm_plan_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+    L.ifemx_set_multigrid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.ifemx_mg_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+    L.ifemx_coarse_level_chain.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    L.ifemx_box_prolongation.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifemx_box_injection.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.ifemx_channel_state.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_double]
     L._ifemx_bound = True
     return L
@@ -178,19 +184,25 @@ class FluidSolver:
         self._chk(self.L.ifemx_set_partition(self.h, Pa.ctypes.data_as(C.c_void_p), rank,
                                              None if idbuf is None else idbuf.ctypes.data_as(C.c_void_p), local_world))
 
-    def attach_coarse(self, coarse, velocity=True):
-        """ifem_mg_attach: `coarse` is the same problem on a coarser box mesh (nested, ratio 1 or 2 per direction, same
-        partition).  Builds the pressure-node prolongation from the two lattices and keeps `coarse` alive."""
-        tf, tc = self.partition_tables(), coarse.partition_tables()
-        Pp = capi.box_prolongation(self.reps, coarse.reps, 1, tf["l2g_p"][:tf["n_pnodes_owned"]], tc["l2g_p"])
-        Pu, inj = None, None
-        if velocity:
-            kv = 2 if tf["n_unodes_global"] != tf["n_pnodes_global"] else 1
-            fo = tf["l2g_u"][:tf["n_unodes_owned"]]
-            Pu = capi.box_prolongation(self.reps, coarse.reps, kv, fo, tc["l2g_u"])
-            inj = capi.box_injection(self.reps, coarse.reps, kv, tc["l2g_u"][:tc["n_unodes_owned"]], fo)
-        capi.mg_attach(self.L, self.ctx, coarse.ctx, Pp, Pu, inj)
-        self._coarse = coarse
+    def set_multigrid(self, on=True, min_cells=0, level_worlds=None):
+        """FluidSolver::multigrid / mg_min_cells / mg_local_worlds of the C++ host mirror (insim.hpp); call before
+        setup().  The hierarchy itself -- level chain, transfers, ifem_mg_attach -- is built by
+        FluidSolver::attach_multigrid_levels inside initialize_system()."""
+        worlds = list(level_worlds or [])
+        arr = (C.c_void_p * max(len(worlds), 1))(*worlds)
+        self._chk(self.L.ifemx_set_multigrid(self.h, int(on), int(min_cells), arr if worlds else None, len(worlds)))
+
+    def mg_levels(self):
+        """[(global repetitions, context handle)] of the levels attached below this solver's context, finest first"""
+        n = C.c_int(0)
+        reps = np.zeros((16, 3), np.int32)
+        ctxs = (C.c_void_p * 16)()
+        self._chk(self.L.ifemx_mg_levels(self.h, C.byref(n), reps.ctypes.data_as(C.c_void_p), ctxs))
+        return [(tuple(int(v) for v in reps[k][:self.dim]), C.c_void_p(ctxs[k])) for k in range(n.value)]
+
+    def all_ctxs(self):
+        """this solver's context and those of its multigrid levels"""
+        return [self.ctx] + [c for _, c in self.mg_levels()]
 
     def set_node_order(self, morton=True):
         self._chk(self.L.ifemx_set_node_order(self.h, int(morton)))
@@ -303,6 +315,17 @@ class FluidSolver:
     def channel_state(self, L=2.0, H=0.2, dP=10.0, mu=1.0, seed=1234, rel=1e-3):
         self._chk(self.L.ifemx_channel_state(self.h, L, H, dP, mu, seed, rel))
 
+    def true_residual(self):
+        """(||b - A x||, ||b||) of the last solve, recomputed with the assembled operator (ifem_true_residual)"""
+        r, b = C.c_double(0), C.c_double(0)
+        rc = self.L.ifem_true_residual(self.ctx, C.byref(r), C.byref(b))
+        if rc < 0:
+            raise HostError(rc, self.L.ifem_last_error().decode())
+        return r.value, b.value
+
+    def comm_stats(self, reset=False):
+        return capi.comm_stats(self.L, self.ctx, reset)
+
     def set_profiling(self, on=True):
         self.L.ifem_set_profiling(self.ctx, int(on))
 
@@ -317,6 +340,54 @@ class FluidSolver:
         if rc < 0:
             raise HostError(rc, self.L.ifem_last_error().decode())
         return t
+
+
+def coarse_level_chain(cells_per_rank, P, extent, min_cells=4):
+    """multigrid.hpp::coarse_level_chain of the C++ host mirror: per-rank cell counts of the coarser levels"""
+    L = _lib()
+    dim = len(cells_per_rank)
+    n, p, e = (np.ascontiguousarray(v, t) for v, t in ((cells_per_rank, np.int32), (P, np.int32), (extent, float)))
+    out, cnt = np.zeros((16, 3), np.int32), C.c_int(0)
+    rc = L.ifemx_coarse_level_chain(dim, n.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
+                                    min_cells, out.ctypes.data_as(C.c_void_p), C.byref(cnt))
+    if rc < 0:
+        raise HostError(rc, L.ifemx_last_error().decode())
+    return [tuple(int(v) for v in out[k][:dim]) for k in range(cnt.value)]
+
+
+def box_prolongation(reps_fine, reps_coarse, degree, l2g_fine, l2g_coarse):
+    """multigrid.hpp::box_prolongation of the C++ host mirror as a scipy CSR matrix (tests compare it with the numpy
+    restatement capi.box_prolongation)"""
+    import scipy.sparse as sp
+    L = _lib()
+    dim = len(reps_fine)
+    rf, rc_ = np.ascontiguousarray(reps_fine, np.int32), np.ascontiguousarray(reps_coarse, np.int32)
+    lf, lc = np.ascontiguousarray(l2g_fine, np.int64), np.ascontiguousarray(l2g_coarse, np.int64)
+    ptr = np.zeros(len(lf) + 1, np.int64)
+    args = [dim, rf.ctypes.data_as(C.c_void_p), rc_.ctypes.data_as(C.c_void_p), degree, lf.ctypes.data_as(C.c_void_p), len(lf),
+            lc.ctypes.data_as(C.c_void_p), len(lc), ptr.ctypes.data_as(C.c_void_p)]
+    rc = L.ifemx_box_prolongation(*args, None, None)
+    if rc < 0:
+        raise HostError(rc, L.ifemx_last_error().decode())
+    col, w = np.zeros(ptr[-1], np.int32), np.zeros(ptr[-1])
+    rc = L.ifemx_box_prolongation(*args, col.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p))
+    if rc < 0:
+        raise HostError(rc, L.ifemx_last_error().decode())
+    return sp.csr_matrix((w, col, ptr), shape=(len(lf), len(lc)))
+
+
+def box_injection(reps_fine, reps_coarse, degree, l2g_coarse, l2g_fine):
+    L = _lib()
+    dim = len(reps_fine)
+    rf, rc_ = np.ascontiguousarray(reps_fine, np.int32), np.ascontiguousarray(reps_coarse, np.int32)
+    lf, lc = np.ascontiguousarray(l2g_fine, np.int64), np.ascontiguousarray(l2g_coarse, np.int64)
+    out = np.zeros(len(lc), np.int32)
+    rc = L.ifemx_box_injection(dim, rf.ctypes.data_as(C.c_void_p), rc_.ctypes.data_as(C.c_void_p), degree,
+                               lc.ctypes.data_as(C.c_void_p), len(lc), lf.ctypes.data_as(C.c_void_p), len(lf),
+                               out.ctypes.data_as(C.c_void_p))
+    if rc < 0:
+        raise HostError(rc, L.ifemx_last_error().decode())
+    return out
 
 
 class InsIM(FluidSolver):

@@ -21,23 +21,18 @@ pytestmark = pytest.mark.gpu
 EXTENT = (2.0, 0.2, 0.2)
 
 
-def _make(reps, P=None, rank=0, worlds=None, level=0, kind="InsIM"):
+def _hierarchy(n, P=(1, 1, 1), rank=0, worlds=None, kind="InsIM"):
+    """the channel through the C++ host mirror: FluidSolver::attach_multigrid_levels (csrc/host/insim.cpp) builds the level
+    chain, the transfers and the ifem_mg_attach calls inside initialize_system; on virtual ranks every level gets the
+    world handed in for it"""
     from openifem_amd import host
-    cls = getattr(host, kind)
-    s = cls(host.channel_prm(3), reps, (0, 0, 0), EXTENT)
-    if P is not None:
-        s.set_partition(P, rank, local_world=worlds[level])
+    reps = tuple(n[d] * P[d] for d in range(3))
+    s = getattr(host, kind)(host.channel_prm(3), reps, (0, 0, 0), EXTENT)
+    if worlds is not None:
+        s.set_partition(P, rank, local_world=worlds[0])
+        s.set_multigrid(True, 0, worlds[1:])
     s.setup(0)
     return s
-
-
-def _hierarchy(n, P=(1, 1, 1), rank=0, worlds=None, kind="InsIM"):
-    from openifem_amd import multigpu
-    reps = tuple(n[d] * P[d] for d in range(3))
-    part = P if worlds is not None else None
-    fine = _make(reps, part, rank, worlds, 0, kind)
-    fine._levels = multigpu.attach_levels(lambda r, lev: _make(r, part, rank, worlds, lev, kind), fine, n, P, EXTENT)
-    return fine
 
 
 def _get(s, vec, n):
@@ -46,11 +41,21 @@ def _get(s, vec, n):
     return x
 
 
-def test_level_chain_follows_the_cell_aspect_ratio():
-    from openifem_amd import multigpu
-    assert multigpu.coarse_level_chain((128, 128, 128), (1, 1, 1), EXTENT) == [(128, 64, 64), (128, 32, 32), (128, 16, 16), (64, 8, 8), (32, 4, 4)]
-    assert multigpu.coarse_level_chain((16, 16, 16), (2, 2, 2), (1, 1, 1)) == [(8, 8, 8), (4, 4, 4)]
-    assert multigpu.coarse_level_chain((6, 6, 6), (1, 1, 1), (1, 1, 1)) == []
+def test_host_mirror_attaches_the_level_chain_and_selects_the_multigrid_inner_solver():
+    # InsIM<3>::initialize_system on a box: the chain of multigrid.hpp hangs below the context and the inner solver of
+    # A~^-1 defaults to the V-cycle-preconditioned one (what a C++ caller of InsIM<3>::run() gets)
+    from openifem_amd import capi, host
+    s = _hierarchy((16, 16, 16))
+    want = host.coarse_level_chain((16, 16, 16), (1, 1, 1), EXTENT)
+    assert [r for r, _ in s.mg_levels()] == want and len(want) >= 2
+    assert s.L.ifem_mg_depth(s.ctx) == len(want)
+    assert s.opts.ainv_kind == capi.AINV_MG and s.opts.inner_restart == 16
+    s.close()
+    s = getattr(host, "InsIM")(host.channel_prm(3), (16, 16, 16), (0, 0, 0), EXTENT)
+    s.set_multigrid(False)
+    s.setup(0)
+    assert s.mg_levels() == [] and s.opts.ainv_kind == 0
+    s.close()
 
 
 @pytest.mark.parametrize("n", [(16, 16, 16), (24, 16, 16)])

@@ -6,30 +6,25 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
-from openifem_amd import capi, host, multigpu
+from openifem_amd import capi, host
 
 EXTENT = (2.0, 0.2, 0.2)
-
-
-def make(reps, P, rank, worlds, level):
-    s = host.InsIM(host.channel_prm(3), reps, (0, 0, 0), EXTENT)
-    if worlds is not None:
-        s.set_partition(P, rank, local_world=worlds[level])
-    s.setup(0)
-    return s
 
 
 def run(n, P, mg, nu=2, ratio=4.0, ainv=3, nu_u=3, ratio_u=8.0, restart=16):
     L = capi.load()
     world = int(np.prod(P))
-    depth = len(multigpu.coarse_level_chain(n, P, EXTENT))
+    depth = len(host.coarse_level_chain(n, P, EXTENT))
     worlds = [C.c_void_p(L.ifem_local_world_create(world)) for _ in range(depth + 1)] if world > 1 else None
     out = [None] * world
 
     def work(rank):
         reps = tuple(n[d] * P[d] for d in range(3))
-        s = make(reps, P, rank, worlds, 0)
-        s._levels = multigpu.attach_levels(lambda r, lev: make(r, P, rank, worlds, lev), s, n, P, EXTENT)
+        s = host.InsIM(host.channel_prm(3), reps, (0, 0, 0), EXTENT)
+        if worlds is not None:
+            s.set_partition(P, rank, local_world=worlds[0])
+            s.set_multigrid(True, 0, worlds[1:])
+        s.setup(0)  # the C++ host mirror attaches the multigrid levels
         s.channel_state()
         if world > 1:
             L.ifem_halo_exchange(s.ctx, capi.VEC_EVAL)

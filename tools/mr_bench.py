@@ -4,7 +4,7 @@ same), both in the bench configuration (multigrid levels attached, IFEM_AINV_MG)
 multi-rank path: ghost cell layer, halo packing, split launches, the distributed S_m -- plus what only the validation
 transport pays (host barriers and synchronous copies where RCCL runs stream-ordered).
 
-    python tools/mr_bench.py [n] [halo_overlap 0|1] [Px,Py,Pz]   (default partition 2,1,1; n^3 cells per virtual rank)"""
+    python tools/mr_bench.py [n] [halo_overlap 0|1] [Px,Py,Pz] [mg_min_cells]   (default partition 2,1,1; n^3 cells per virtual rank)"""
 import ctypes as C
 import sys
 import threading
@@ -22,19 +22,18 @@ EXTENT = (2.0, 0.2, 0.2)
 L = capi.load()
 
 
-def make(reps, P, rank, worlds, level):
-    s = host.InsIM(host.channel_prm(3), reps, (0, 0, 0), EXTENT, verbose=False)
-    if P is not None:
-        s.set_partition(P, rank, local_world=worlds[level])
-    s.setup(0)
-    return s
+MIN_CELLS = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # coarse-level policy: smallest number of cells per rank a halved direction keeps
 
 
 def hierarchy(cells, P, rank, worlds):
+    """the channel through the C++ host mirror; its initialize_system attaches the multigrid levels"""
     reps = tuple(cells[d] * (P[d] if P else 1) for d in range(3))
-    fine = make(reps, P, rank, worlds, 0)
-    fine._levels = multigpu.attach_levels(lambda r, lev: make(r, P, rank, worlds, lev), fine, cells, P or (1, 1, 1), EXTENT)
-    return fine
+    s = host.InsIM(host.channel_prm(3), reps, (0, 0, 0), EXTENT, verbose=False)
+    if P is not None:
+        s.set_partition(P, rank, local_world=worlds[0])
+    s.set_multigrid(True, MIN_CELLS, worlds[1:] if worlds else None)
+    s.setup(0)
+    return s
 
 
 def configure(s):
@@ -44,8 +43,8 @@ def configure(s):
     tun = capi.Tuning()
     L.ifem_default_tuning(C.byref(tun))
     tun.halo_overlap = overlap
-    for c in [s] + list(s._levels):
-        assert L.ifem_set_tuning(c.ctx, C.byref(tun)) == 0
+    for c in s.all_ctxs():
+        assert L.ifem_set_tuning(c, C.byref(tun)) == 0
     s.channel_state()
 
 
@@ -54,16 +53,17 @@ def timed(s, sync=None):
     if sync: sync()
     t0 = time.time()
     its = None
+    s.comm_stats(reset=True)
     for _ in range(steps):
         s.assemble(False)
         its = s.solve(False)
     s.synchronize()
-    return (time.time() - t0) / steps, its
+    return (time.time() - t0) / steps, its, s.comm_stats()
 
 
 s = hierarchy(tuple(n * p for p in PART), None, 0, None)
 configure(s)
-t1, st = timed(s)
+t1, st, _ = timed(s)
 print(f"one context, {n*PART[0]}x{n*PART[1]}x{n*PART[2]}: {t1*1e3:.1f} ms/step, fgmres {st.fgmres_iters} cg_mp {st.cg_mp_iters} cg_sm {st.cg_sm_iters} inner {st.inner_iters}", flush=True)
 depth = L.ifem_mg_depth(s.ctx)
 s.close()
@@ -84,6 +84,7 @@ def work(rank):
 th = [threading.Thread(target=work, args=(r,)) for r in range(WORLD)]
 for t in th: t.start()
 for t in th: t.join()
-t2, st = res[0]
+t2, st, cs = res[0]
 print(f"{WORLD} virtual ranks of {n}^3 on one GPU (halo_overlap {overlap}): {t2*1e3:.1f} ms/step (one context: {t1*1e3:.1f}, {100*(t2/t1-1):+.1f} %), "
-      f"fgmres {st.fgmres_iters} cg_mp {st.cg_mp_iters} cg_sm {st.cg_sm_iters} inner {st.inner_iters}")
+      f"fgmres {st.fgmres_iters} cg_mp {st.cg_mp_iters} cg_sm {st.cg_sm_iters} inner {st.inner_iters}; per step: "
+      f"{cs['halo_exchanges'] / steps:.0f} halo exchanges, {cs['allreduce_dev'] / steps:.0f} stream-ordered + {cs['allreduce_host'] / steps:.0f} host-waited all-reduces over {cs['levels']} levels")
