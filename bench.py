@@ -71,10 +71,27 @@ def _cpu_model():
     return "unknown CPU"
 
 
+def physical_cores():
+    """physical cores of the host (unique (socket, core) pairs of /proc/cpuinfo), not hardware threads"""
+    pairs, phys = set(), None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    pairs.add((phys, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return len(pairs) or (os.cpu_count() or 1)
+
+
 def _cpu_step(n_cpu, threads):
-    """One assemble + solve of the n_cpu^3 channel on the CPU oracle; returns (n_dofs, assemble s, solve s, FGMRES its)."""
+    """One assemble + solve of the n_cpu^3 channel on the CPU oracle with one subdomain per thread (owner computes row, no
+    atomics: oracle.c::orc_ins_assemble_subdomains, the shared-memory restatement of the reference's one-rank-per-core
+    assembly, mpi_insim.cpp:206-209); returns (n_dofs, assemble s, solve s, FGMRES its)."""
     import orc
-    from boxmesh import BoxMesh
+    from boxmesh import BoxMesh, block_partition
     from cases import channel3d_state
     m = BoxMesh([n_cpu] * 3, (0, 0, 0), (2.0, 0.2, 0.2), kv=2)
     dofs, vals, present, ev, kw = channel3d_state(m)
@@ -89,8 +106,14 @@ def _cpu_step(n_cpu, threads):
     S.opts.inner_maxit = 400
     S.opts.n_threads = threads
     P = orc.make_params(**kw)
+    parts = threads
+    while True:  # the largest block count <= threads the lattice can be cut into
+        part, used = block_partition(m.reps, parts)
+        if used == parts or parts == 1:
+            break
+        parts -= 1
     t0 = time.time()
-    S.assemble(P, False, ev, present)
+    S.assemble_subdomains(P, False, ev, present, part, used, threads)
     t1 = time.time()
     rc, upd, it, res = S.solve(P, False)
     t2 = time.time()
@@ -102,38 +125,46 @@ def np_log2(x):
     return math.log2(x)
 
 
-def cpu_baseline(sizes, sweep_n=12, budget_s=75.0):
+def cpu_baseline(sizes, sweep_n=24, budget_s=90.0):
     """The CPU oracle (a port of the reference algorithm, oracle/oracle.c: dense per-cell Ke, CSR scatter, FGMRES with the
     block Schur preconditioner, same inner-solver settings as the GPU run) on a bounded sample of the same workload:
-    one Newton step of the n^3 channel for every n in `sizes` (BASELINE.md section 3 plans n = 32 and 64; the default run
-    does n = 32 to stay within a few minutes, `--cpu-cells 32,64` does both), on the host cores.  The thread count is
-    picked by a short sweep on a sweep_n^3 mesh (the oracle's OpenMP loops stop scaling long before 256 threads)."""
-    ncpu = os.cpu_count() or 1
-    cand = sorted({max(1, ncpu // d) for d in (1, 2, 4, 8, 16)})
-    sweep = {}
+    one Newton step of the n^3 channel for every n in `sizes` (BASELINE.md section 3 plans n = 32 and 64) on ALL physical
+    cores of the host, one subdomain per core as the reference runs one MPI rank per core.  A strong-scaling table
+    16 -> all cores on a sweep_n^3 mesh goes into the line (threads, seconds, parallel efficiency against the smallest
+    count)."""
+    ncores = physical_cores()
+    cand = sorted({t for t in (16, 32, 64, 128, 192, 256, ncores) if t <= ncores} | {ncores})
+    sweep = []
     for t in cand:
         nd, ta, ts, _ = _cpu_step(sweep_n, t)
-        sweep[t] = ta + ts
-    best = min(sweep, key=sweep.get)
+        sweep.append({"threads": t, "assemble_s": ta, "solve_s": ts})
+    base = sweep[0]
+    for r in sweep:
+        r["assemble_efficiency"] = base["assemble_s"] * base["threads"] / (r["assemble_s"] * r["threads"])
+        r["step_efficiency"] = (base["assemble_s"] + base["solve_s"]) * base["threads"] / ((r["assemble_s"] + r["solve_s"]) * r["threads"])
     runs, skipped = [], []
     for n in sorted(sizes):
         # keep the default run bounded: a sample is skipped when the previous (smaller) one predicts more than `budget_s`
-        # for it (cost grows ~ 4.6x per doubling of n on this oracle: 13.6 s -> 63 s measured)
+        # for it (cost grows ~ 8x per doubling of n at a fixed thread count)
         if runs and budget_s > 0:
             prev = runs[-1]
-            predicted = (prev["assemble_s"] + prev["solve_s"]) * 4.6 ** (np_log2(n / prev["n"]))
+            predicted = (prev["assemble_s"] + prev["solve_s"]) * 8.0 ** (np_log2(n / prev["n"]))
             if predicted > budget_s:
                 skipped.append({"n": n, "predicted_s": predicted, "budget_s": budget_s})
                 continue
-        nd, ta, ts, it = _cpu_step(n, best)
+        nd, ta, ts, it = _cpu_step(n, ncores)
         runs.append({"n": n, "n_dofs": nd, "assemble_s": ta, "solve_s": ts, "fgmres_iters": it, "dofs_per_s": nd / (ta + ts),
                      "assemble_dofs_per_s": nd / ta, "solve_dofs_per_s": nd / ts})
     big = runs[-1]
-    return {"value": big["dofs_per_s"], "unit": "DoF/s", "cores": best, "kind": "port", "cpu_model": _cpu_model(),
-            "host_threads_available": ncpu, "thread_sweep_s": {str(k): v for k, v in sweep.items()}, "runs": runs, "skipped": skipped,
+    return {"value": big["dofs_per_s"], "unit": "DoF/s", "cores": ncores, "kind": "port", "cpu_model": _cpu_model(),
+            "host_threads_available": os.cpu_count(), "physical_cores": ncores,
+            "parallelisation": "one subdomain per core, owner computes row, no atomics (orc_ins_assemble_subdomains); OpenMP loops in the solve",
+            "scaling_table": {"mesh": f"{sweep_n}^3", "rows": sweep}, "runs": runs, "skipped": skipped,
+            "not_sampled": "128^3: the oracle's CSR with all couplings (as the reference's BlockSparsityPattern, mpi_fluid_solver.cpp:311-322) "
+                           "needs ~0.25 TB there and ~10 min per step; the 64^3 step is the bounded sample",
             "sample": f"1 Newton step (assemble {big['assemble_s']:.2f}s + solve {big['solve_s']:.2f}s, FGMRES its "
                       f"{big['fgmres_iters']}) of the {big['n']}^3 Q2/Q1 channel ({big['n_dofs']} DoF), oracle/oracle.c with "
-                      f"OpenMP on {best} threads of {_cpu_model()}"}
+                      f"OpenMP on {ncores} threads = physical cores of {_cpu_model()}"}
 
 
 def bench_insimex(args, host):
@@ -264,6 +295,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1234, help="seed of the perturbation of the timed state")
     ap.add_argument("--rel", type=float, default=1e-3, help="relative amplitude of the perturbation of the timed state")
     ap.add_argument("--mg-min-cells", type=int, default=0, help="multigrid levels: a direction is halved only while it keeps this many cells per rank (0: the host mirror's default, 4)")
+    ap.add_argument("--fgmres-rel", type=float, default=None, help="test aid: relative tolerance of the outer FGMRES (reference and default: 1e-4)")
+    ap.add_argument("--dump-update", default=None, help="test aid: every rank writes its owned entries of the last Newton update and their global lattice ids to <path>.rank<r>.npz")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
     ap.add_argument("--outer-mf", type=int, default=0, help="experiment: apply the u-u block of the OUTER operator matrix-free too")
     ap.add_argument("--solver", default="insim", choices=["insim", "insimex"],
@@ -271,6 +304,9 @@ def main():
                          "time step of MPI::InsIMEX (rhs-only assembly + solve), reported as a side measurement")
     args = ap.parse_args()
 
+    # the CPU baseline leg pins one OpenMP thread per physical core (read by libgomp when the oracle library loads)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "IFEM_BENCH_DEVICE" in os.environ:  # debugging aid: several ranks on one GPU (RCCL normally refuses this)
@@ -301,6 +337,8 @@ def main():
     if args.mp_rel is not None:
         solver.opts.mp_rel = args.mp_rel
     solver.opts.ainv_kind = args.ainv
+    if args.fgmres_rel is not None:
+        solver.opts.fgmres_rel = args.fgmres_rel
     if args.inner_maxit is not None:
         solver.opts.inner_maxit = args.inner_maxit
     if args.mg_smooth_u is not None:
@@ -356,6 +394,14 @@ def main():
     # the TRUE residual of the last timed solve, recomputed with the assembled operator (collective; outside the timed region)
     true_res, rhs_norm = solver.true_residual()
     solver.comm_stats(reset=True)
+    if args.dump_update:
+        import numpy as np
+        t = solver.partition_tables()
+        nuo, npo = t["n_unodes_owned"], t["n_pnodes_owned"]
+        upd = np.zeros(3 * nuo + npo)
+        assert solver.L.ifem_vec_get(solver.ctx, capi.VEC_UPDATE, upd.ctypes.data_as(C.c_void_p)) == 0
+        np.savez(f"{args.dump_update}.rank{rank}.npz", update=upd, l2g_u=t["l2g_u"][:nuo], l2g_p=t["l2g_p"][:npo],
+                 n_unodes_global=t["n_unodes_global"], n_pnodes_global=t["n_pnodes_global"])
     if dist:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)

@@ -162,6 +162,11 @@ typedef struct {
   int32_t halo_overlap;  /* 1: several ranks: the halo of an operator input travels on a second stream / communicator
                             while the rows (SpMV) or cells (matrix-free A_uu) that read no ghost value are processed; 0: the
                             exchange completes on the context stream before the operator starts */
+  int32_t asm3_variant;  /* 3D Q2/Q1 cell kernel: 0 (default) = no per-cell shape tables in LDS (rebuilt on the fly from tensor
+                            factors: 19 KB of LDS per cell, four workgroups per CU); 1 = the 23 KB per-cell tables of rounds 1-2
+                            (two workgroups per CU); 2 = tables for assemblies that integrate B / B^T / M_p, none otherwise */
+  int32_t asm3_waves;    /* 3: waves per SIMD the no-tables variant of that kernel is compiled for (2: 256 registers per lane, 3: 168,
+                            4: 128 with spills around the scatter) */
   int64_t tpp_dense_max; /* 12288: largest pressure space whose T_pp may be factorised densely (0 = never) */
   int64_t basis_pad;     /* 32*33 doubles of padding between Krylov basis columns (HBM channel spread) */
 } ifem_tuning;

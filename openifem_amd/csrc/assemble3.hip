@@ -12,6 +12,9 @@
 // read the same tables.  Accumulator layout of the instruction (tools/microbench.hip): lane l supplies
 // A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15], register r of the result is D[(l>>4) + 4r][l&15].
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <set>
+#include <type_traits>
 #include "kernels.hpp"
 #include "assemble_common.hpp"
 
@@ -19,15 +22,27 @@ namespace ifem {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-struct Cell3 {
+// Per-cell LDS.  TABLES layout (OTF = false): the physical gradient / value tables of the cell, 23 KB, read by the MFMA
+// loop, the rhs and the B / B^T integrals: two cells fill half a CU's LDS, two waves per SIMD.  OTF layout: no per-cell
+// tables -- every consumer rebuilds N_a(q) and grad N_a(q) on the fly from the workgroup's 1D / 2D tensor factors
+// (Shared3) and the cell's inverse Jacobians Ji[q] (1.9 KB): 18.7 KB per cell, four workgroups per CU, so that the
+// atomic-unit time of one cell's scatter overlaps the integration of three others instead of one.
+struct Cell3Tabs {
+  double tabG[3][27][27]; // physical shape gradients
+  double tabN[27][27];    // shape values
+};
+struct Cell3Otf {
+  double Ji[27 * 9];      // [q][reference direction e][physical direction d]
+  double part1[27 * 18];  // partial nodal sums of the cell's second wave (phase 1)
+};
+template <bool OTF>
+struct Cell3 : std::conditional<OTF, Cell3Otf, Cell3Tabs>::type {
   static constexpr int DIM = 3, NU = 27, NP = 8, NQ = 27, ND = 89, BS = 9;
   static constexpr int NODAL = 3 * NU * DIM + NP, STAGE = 64 * BS + 64;
-  double tabG[DIM][NQ][NU]; // physical shape gradients
-  double tabN[NQ][NU];      // shape values
   double X[NP * DIM], C[8 * DIM];
   double JxW[NQ], uq[NQ * DIM];
   double gqs[NQ * 9]; // rho JxW grad u
-  // Ji[243] | Vc[243] | Sc[81] | divw[27] until the rhs is integrated, then the scatter staging of the cell's second wave
+  // Ji[243] (TABLES layout) | Vc[243] | Sc[81] | divw[27] until the rhs is integrated, then the scatter staging of the cell's second wave
   double dead[STAGE];
   double scratch[STAGE > NODAL ? STAGE : NODAL]; // nodal values (phase 1) | scatter staging of the cell's first wave
   double fe[ND], cv[ND];
@@ -41,20 +56,44 @@ struct Cell3 {
 struct Shared3 {
   Tab1D t;
   double psi[27 * 8];
+  // OTF layout: 2D tensor factors over (q0 q1) x (a0 a1): N2 = Nx Ny, DX2 = Nx' Ny, DY2 = Nx Ny'
+  double N2[81], DX2[81], DY2[81];
 };
+
+// N_a(q) and the physical gradient of N_a at q from the tensor factors and the inverse Jacobian of the point: the same
+// products and sums, in the same order, as the table build of the TABLES layout
+__device__ __forceinline__ void shape_ref(const Shared3 &T, int q, int a, double &N, double r[3]) {
+  const int i2 = (q % 9) * 9 + (a % 9), i1 = (q / 9) * 3 + a / 9;
+  const double n2 = T.N2[i2], dx2 = T.DX2[i2], dy2 = T.DY2[i2], nz = T.t.N[i1], dz = T.t.dN[i1];
+  N = n2 * nz;
+  r[0] = dx2 * nz; r[1] = dy2 * nz; r[2] = n2 * dz;
+}
+__device__ __forceinline__ void shape_otf(const Shared3 &T, const double *__restrict__ Jq, int q, int a, double &N, double g[3]) {
+  double r[3];
+  shape_ref(T, q, a, N, r);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) g[d] = r[0] * Jq[d] + r[1] * Jq[3 + d] + r[2] * Jq[6 + d];
+}
 
 // CPB cells per workgroup, TWO wavefronts per cell (h = 0, 1) sharing the cell's LDS tables: the tables cap the
 // workgroup at ~150 KB of LDS, and one wave per SIMD leaves every LDS / global round trip exposed; with two waves per
 // cell the SIMDs hold two waves each.  Phases are separated by workgroup barriers (uniform control flow).
-template <int CPB>
-__global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1) {
+// WAVES: waves per SIMD the register allocation is held to (2: 256 registers, 3: 168, 4: 128).  The TABLES layout runs at 2
+// (its LDS allows no more); the OTF layout is built for 3 (ks loop not unrolled: the whole kernel spills 80 bytes per lane,
+// none of it inside the contraction) and 4 (240 bytes, most of it around the staged scatter).
+template <int CPB, bool OTF, int WAVES>
+__global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_ins_assemble3(AsmArgs A, Tab1D t1) {
   constexpr int DIM = 3, N1 = 3, NU = 27, NP = 8, NQ = 27, ND = 89, BS = 9;
   constexpr int NBP = NU * NP, BROUNDS = (NBP + 63) / 64, FR = (ND + 63) / 64;
   extern __shared__ __align__(16) unsigned char smem[];
   Shared3 &T = *reinterpret_cast<Shared3 *>(smem);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = wave >> 1, h = wave & 1;
-  Cell3 &S = *reinterpret_cast<Cell3 *>(smem + ((sizeof(Shared3) + 15) & ~size_t(15)) + size_t(slot) * ((sizeof(Cell3) + 15) & ~size_t(15)));
-  double *const Ji_ = S.dead, *const Vc_ = S.dead + 243, *const Sc_ = S.dead + 486, *const divw_ = S.dead + 567;
+  using Cell = Cell3<OTF>;
+  Cell &S = *reinterpret_cast<Cell *>(smem + ((sizeof(Shared3) + 15) & ~size_t(15)) + size_t(slot) * ((sizeof(Cell) + 15) & ~size_t(15)));
+  double *Ji_, *part1;
+  if constexpr (OTF) { Ji_ = S.Ji; part1 = S.part1; }
+  else { Ji_ = S.dead; part1 = &S.tabG[0][0][0]; } // the tables are not built yet when the partial sums are parked there
+  double *const Vc_ = S.dead + 243, *const Sc_ = S.dead + 486, *const divw_ = S.dead + 567;
   if (threadIdx.x < 9) { T.t.N[threadIdx.x] = t1.N[threadIdx.x]; T.t.dN[threadIdx.x] = t1.dN[threadIdx.x]; }
   if (threadIdx.x < 3) { T.t.xi[threadIdx.x] = t1.xi[threadIdx.x]; T.t.w[threadIdx.x] = t1.w[threadIdx.x]; }
   for (int i = threadIdx.x; i < NQ * NP; i += blockDim.x) {
@@ -67,6 +106,12 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
     }
     T.psi[i] = v;
   }
+  if constexpr (OTF)
+    for (int i = threadIdx.x; i < 81; i += blockDim.x) {
+      const int q01 = i / 9, a01 = i - q01 * 9;
+      const int ix = (q01 % 3) * N1 + (a01 % 3), iy = (q01 / 3) * N1 + (a01 / 3);
+      T.N2[i] = t1.N[ix] * t1.N[iy]; T.DX2[i] = t1.dN[ix] * t1.N[iy]; T.DY2[i] = t1.N[ix] * t1.dN[iy];
+    }
   __syncthreads();
 
   const int64_t idx = int64_t(A.xcd_swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * CPB + slot;
@@ -152,7 +197,7 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
   // ---- phase 1: per quadrature point (lane = q): Jacobian, fields of the evaluation point, rhs coefficients
   // the nodal sums are split over the two waves of the cell: the second wave handles nodes 14..26 and parks its partial
   // sums in the (not yet built) gradient table
-  double *const part1 = &S.tabG[0][0][0]; // [27 lanes][18]
+  // (part1: [27 lanes][18])
   if (h == 1 && lane < NQ) {
     const int q = lane;
     const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
@@ -240,11 +285,16 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       S.uq[q * 3 + c] = A.imex ? 0.0 : u[c]; // only the matrix reads uq (u . grad N_b): no convection in the IMEX matrix
-      double adv = 0;
+      double adv = 0, vc[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         adv += g[c * 3 + d] * u[d];
-        Vc_[(q * 3 + c) * 3 + d] = w * (-A.mu * g[c * 3 + d] + (c == d ? p - A.gamma * A.rho * dv : 0.0));
+        vc[d] = w * (-A.mu * g[c * 3 + d] + (c == d ? p - A.gamma * A.rho * dv : 0.0));
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if constexpr (OTF) Vc_[(q * 3 + c) * 3 + d] = Ji[d * 3] * vc[0] + Ji[d * 3 + 1] * vc[1] + Ji[d * 3 + 2] * vc[2]; // reference-gradient basis
+        else Vc_[(q * 3 + c) * 3 + d] = vc[d];
       }
       double sc = -A.rho * adv - A.rho * A.inv_dt * (u[c] - u0[c]) + A.rho * A.g[c];
       if (ind == 1) sc += A.rho * ac[c];
@@ -253,6 +303,7 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
   }
   __syncthreads();
   // ---- node tables, once per cell: tabN[q][a], tabG[d][q][a] (both waves, interleaved rounds)
+  if constexpr (!OTF)
   for (int t = lane + 64 * h; t < (A.debug_skip == 7 ? 128 : NQ * NU); t += 128) {
     const int q = t / NU, a = t - q * NU;
     const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)}, ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
@@ -304,9 +355,15 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
     if (i < NU * DIM) {
       const int a = i / DIM, c = i - a * DIM;
 #pragma unroll 3
-      for (int q = 0; q < NQ; ++q)
+      for (int q = 0; q < NQ; ++q) {
+        if constexpr (OTF) {
+          double N, r[3];
+          shape_ref(T, q, a, N, r);
+          f += Sc_[q * 3 + c] * N + Vc_[(q * 3 + c) * 3 + 0] * r[0] + Vc_[(q * 3 + c) * 3 + 1] * r[1] + Vc_[(q * 3 + c) * 3 + 2] * r[2];
+        } else
         f += Sc_[q * 3 + c] * S.tabN[q][a] + Vc_[(q * 3 + c) * 3 + 0] * S.tabG[0][q][a] + Vc_[(q * 3 + c) * 3 + 1] * S.tabG[1][q][a] +
              Vc_[(q * 3 + c) * 3 + 2] * S.tabG[2][q][a];
+      }
     } else if (i < ND) {
 #pragma unroll 3
       for (int q = 0; q < NQ; ++q) f += divw_[q] * T.psi[q * NP + (i - NU * DIM)];
@@ -330,7 +387,13 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
 #pragma unroll 3
       for (int q = 0; q < NQ; ++q) {
         const double wpsi = S.JxW[q] * T.psi[q * NP + pb];
+        if constexpr (OTF) {
+          double N, g[3];
+          shape_otf(T, Ji_ + q * 9, q, a, N, g);
+          v[0] -= wpsi * g[0]; v[1] -= wpsi * g[1]; v[2] -= wpsi * g[2];
+        } else {
         v[0] -= wpsi * S.tabG[0][q][a]; v[1] -= wpsi * S.tabG[1][q][a]; v[2] -= wpsi * S.tabG[2][q][a];
+        }
       }
       const bool pc = S.cf[NU * DIM + pb];
       if (S.len_bt[a] >= 0) {
@@ -371,7 +434,12 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
     if (h == 0 && lane < NU) {
       double m = 0;
 #pragma unroll 3
-      for (int q = 0; q < NQ; ++q) m += S.JxW[q] * S.tabN[q][lane] * S.tabN[q][lane];
+      for (int q = 0; q < NQ; ++q) {
+        double N;
+        if constexpr (OTF) { double r[3]; shape_ref(T, q, lane, N, r); }
+        else N = S.tabN[q][lane];
+        m += S.JxW[q] * N * N;
+      }
       if (active && S.len_uu[lane] >= 0)
         for (int c = 0; c < DIM; ++c) unsafeAtomicAdd(&A.diagMu[int64_t(DIM) * S.un[lane] + c], m);
     }
@@ -406,17 +474,25 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
         posr[r] = A.posUU[(cc * NU + (a < NU ? a : 0)) * NU + bc_]; // unconditional (clamped): no branch, no wait here
       }
       if (A.debug_skip != 2) {
-#pragma unroll
+#pragma unroll(OTF ? 1 : 7)
         for (int ks = 0; ks < 7; ++ks) {
           const int q = 4 * ks + (lane >> 4);
           const bool qv = q < NQ;
           const int qq = qv ? q : 0;
           const double ma = (av && qv) ? 1.0 : 0.0, mb = (bv && qv) ? 1.0 : 0.0; // padding rows / columns / points contribute 0
           const double w = S.JxW[qq];
-          const double Na = ma * S.tabN[qq][ac_], Nb = mb * S.tabN[qq][bc_];
-          double ga[3], gb[3];
+          double Na, Nb, ga[3], gb[3];
+          if constexpr (OTF) {
+            shape_otf(T, Ji_ + qq * 9, qq, ac_, Na, ga);
+            shape_otf(T, Ji_ + qq * 9, qq, bc_, Nb, gb);
+            Na *= ma; Nb *= mb;
 #pragma unroll
-          for (int d = 0; d < 3; ++d) { ga[d] = ma * S.tabG[d][qq][ac_]; gb[d] = mb * S.tabG[d][qq][bc_]; }
+            for (int d = 0; d < 3; ++d) { ga[d] *= ma; gb[d] *= mb; }
+          } else {
+            Na = ma * S.tabN[qq][ac_]; Nb = mb * S.tabN[qq][bc_];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { ga[d] = ma * S.tabG[d][qq][ac_]; gb[d] = mb * S.tabG[d][qq][bc_]; }
+          }
           const double ugb = S.uq[qq * 3] * gb[0] + S.uq[qq * 3 + 1] * gb[1] + S.uq[qq * 3 + 2] * gb[2];
           const double wmu = w * A.mu, wNa = w * Na;
           // scalar part
@@ -506,25 +582,40 @@ __global__ __launch_bounds__(128 * CPB) void k_ins_assemble3(AsmArgs A, Tab1D t1
 }
 
 // 3D Q2/Q1 only; the block-interleaved A_uu layout is assumed by the staged scatter
-bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A) {
-#if !IFEM_UU_INTERLEAVED
-  return false;
-#else
-  if (ctx->dim != 3 || ctx->kv != 2) return false;
+template <bool OTF, int WAVES>
+static void launch3(ifem_ctx *ctx, const AsmArgs &A) {
   constexpr int CPB = 2; // cells per workgroup (two waves each)
-  const size_t smem = ((sizeof(Shared3) + 15) & ~size_t(15)) + CPB * ((sizeof(Cell3) + 15) & ~size_t(15));
-  static bool attr_set = false;
-  if (!attr_set) {
-    IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ins_assemble3<CPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
+  const size_t smem = ((sizeof(Shared3) + 15) & ~size_t(15)) + CPB * ((sizeof(Cell3<OTF>) + 15) & ~size_t(15));
+  // the dynamic-LDS limit is an attribute of the function ON A DEVICE: remembered per device, not per process
+  static std::mutex mu;
+  static std::set<int> done;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done.count(ctx->device)) {
+      IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ins_assemble3<CPB, OTF, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      done.insert(ctx->device);
+    }
   }
   Tab1D t;
   tab1d(t, 2);
   AsmArgs B = A;
   B.order = nullptr; B.first = 0; B.count = A.n_cells;
   const int64_t nblk = (B.count + CPB - 1) / CPB;
-  hipLaunchKernelGGL((k_ins_assemble3<CPB>), dim3((unsigned)nblk), dim3(128 * CPB), smem, ctx->stream, B, t);
+  hipLaunchKernelGGL((k_ins_assemble3<CPB, OTF, WAVES>), dim3((unsigned)nblk), dim3(128 * CPB), smem, ctx->stream, B, t);
   IFEM_HIP_CHECK(hipGetLastError());
+}
+
+bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A) {
+#if !IFEM_UU_INTERLEAVED
+  return false;
+#else
+  if (ctx->dim != 3 || ctx->kv != 2) return false;
+  const int v = ctx->tune.asm3_variant;
+  const bool tables = v == 1 || (v == 2 && !A.skip_geo && !A.rhs_only);
+  if (tables) launch3<false, 2>(ctx, A);
+  else if (ctx->tune.asm3_waves == 4) launch3<true, 4>(ctx, A);
+  else if (ctx->tune.asm3_waves == 2) launch3<true, 2>(ctx, A);
+  else launch3<true, 3>(ctx, A);
   return true;
 #endif
 }

@@ -450,6 +450,107 @@ void orc_ins_assemble(orc_system *s, const orc_params *P, int32_t use_nonzero, c
   }
 }
 
+/* The same assembly the way the reference runs it on P MPI ranks (mpi_insim.cpp:206-209: every rank integrates the cells
+ * of its subdomain, PETSc owns matrix rows per rank), restated for shared memory WITHOUT atomics: cell_part[cell] names the
+ * subdomain of a cell, a row belongs to the lowest subdomain among the cells around its dof, and subdomain t integrates
+ * every cell that touches one of its rows (its own cells + the layer behind its upper faces) and writes only its own
+ * rows -- where PETSc would stash and send the off-process contributions, the neighbour recomputes the cell.  One thread
+ * per subdomain (static schedule).  Bitwise equal to orc_ins_assemble up to the summation order of the cell contributions.
+ * The CPU baseline leg of bench.py times this variant: it is the one that scales with the cores. */
+void orc_ins_assemble_subdomains(orc_system *s, const orc_params *P, int32_t use_nonzero, const double *eval,
+                                 const double *present, const double *fsi_acc, const int32_t *cell_part, int32_t n_parts,
+                                 int32_t n_threads) {
+  const int nd = s->ndof_cell, n = s->n, nc = s->m.n_cells;
+  int nt = n_threads > 0 ? n_threads : omp_get_max_threads();
+  if (nt > n_parts) nt = n_parts;
+  size_t nnz = (size_t)s->rowptr[n];
+  const unsigned char *isc = s->is_c[use_nonzero ? 1 : 0];
+  const double *cv = s->cval[use_nonzero ? 1 : 0];
+  int32_t *owner = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  for (int g = 0; g < n; ++g) owner[g] = n_parts;
+  for (int cell = 0; cell < nc; ++cell) {
+    int32_t idx[MAXDOF];
+    cell_dofs(s, cell, idx);
+    for (int i = 0; i < nd; ++i) if (cell_part[cell] < owner[idx[i]]) owner[idx[i]] = cell_part[cell];
+  }
+  /* cells of every subdomain: all cells with at least one row it owns (CSR over subdomains) */
+  int64_t *cptr = (int64_t *)calloc((size_t)n_parts + 1, sizeof(int64_t));
+  unsigned char *mark = (unsigned char *)malloc((size_t)n_parts);
+  for (int pass = 0; pass < 2; ++pass) {
+    int32_t *clist = NULL;
+    int64_t *fill = NULL;
+    if (pass == 1) {
+      for (int t = 0; t < n_parts; ++t) cptr[t + 1] += cptr[t];
+      clist = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cptr[n_parts] > 0 ? cptr[n_parts] : 1));
+      fill = (int64_t *)malloc(sizeof(int64_t) * (size_t)n_parts);
+      for (int t = 0; t < n_parts; ++t) fill[t] = cptr[t];
+    }
+    for (int cell = 0; cell < nc; ++cell) {
+      int32_t idx[MAXDOF];
+      cell_dofs(s, cell, idx);
+      int32_t seen[MAXDOF]; int ns = 0;
+      for (int i = 0; i < nd; ++i) {
+        const int32_t o = owner[idx[i]];
+        int dup = 0;
+        for (int k = 0; k < ns; ++k) if (seen[k] == o) { dup = 1; break; }
+        if (!dup) seen[ns++] = o;
+      }
+      for (int k = 0; k < ns; ++k) {
+        if (pass == 0) cptr[seen[k] + 1]++;
+        else clist[fill[seen[k]]++] = cell;
+      }
+    }
+    if (pass == 1) {
+#pragma omp parallel num_threads(nt)
+      {
+        double *Ke = (double *)malloc(sizeof(double) * (size_t)nd * nd);
+        double *Me = (double *)malloc(sizeof(double) * (size_t)nd * nd);
+        double fe[MAXDOF]; int32_t idx[MAXDOF];
+        /* first touch: every subdomain zeroes its own rows (system_matrix = 0; mass_matrix = 0; system_rhs = 0) */
+#pragma omp for schedule(static)
+        for (int g = 0; g < n; ++g) {
+          for (int64_t k = s->rowptr[g]; k < s->rowptr[g + 1]; ++k) { s->A[k] = 0; s->M[k] = 0; }
+          s->rhs[g] = 0;
+        }
+#pragma omp for schedule(static, 1)
+        for (int t = 0; t < n_parts; ++t)
+          for (int64_t ci = cptr[t]; ci < cptr[t + 1]; ++ci) {
+            const int cell = clist[ci];
+            cell_integrals(s, P, cell, eval, present, fsi_acc, Ke, Me, fe);
+            cell_dofs(s, cell, idx);
+            double avgK = 0, avgM = 0; int any_c = 0;
+            for (int i = 0; i < nd; ++i) { avgK += fabs(Ke[i * nd + i]); avgM += fabs(Me[i * nd + i]); if (isc[idx[i]]) any_c = 1; }
+            avgK /= nd; avgM /= nd;
+            for (int i = 0; i < nd; ++i) {
+              const int gi = idx[i];
+              if (owner[gi] != t) continue; /* another subdomain's row */
+              if (isc[gi]) {
+                const double kd = fabs(Ke[i * nd + i]) != 0 ? fabs(Ke[i * nd + i]) : avgK;
+                const double md = fabs(Me[i * nd + i]) != 0 ? fabs(Me[i * nd + i]) : avgM;
+                const int64_t p = find_pos(s, gi, gi);
+                s->A[p] += kd; s->M[p] += md; s->rhs[gi] += cv[gi] * kd;
+                continue;
+              }
+              double b = fe[i];
+              if (any_c)
+                for (int r = 0; r < nd; ++r) if (isc[idx[r]]) b -= Ke[i * nd + r] * cv[idx[r]];
+              s->rhs[gi] += b;
+              for (int j = 0; j < nd; ++j) {
+                if (isc[idx[j]]) continue;
+                const int64_t p = find_pos(s, gi, idx[j]);
+                s->A[p] += Ke[i * nd + j]; s->M[p] += Me[i * nd + j];
+              }
+            }
+          }
+        free(Ke); free(Me);
+      }
+      free(clist); free(fill);
+    }
+  }
+  (void)nnz;
+  free(mark); free(cptr); free(owner);
+}
+
 /* InsIM assembly through AffineConstraints that also hold hanging-node lines
  * (DoFTools::make_hanging_node_constraints, mpi_fluid_solver.cpp:182-184, then interpolate_boundary_values which skips
  * dofs that are already constrained, :185-271, then close()).  distribute_local_to_global(Ke, fe, idx, A, rhs, true)

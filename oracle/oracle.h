@@ -89,6 +89,11 @@ double *orc_rhs(orc_system *s);
 
 void orc_ins_assemble(orc_system *s, const orc_params *p, int32_t use_nonzero, const double *eval,
                       const double *present, const double *fsi_acc);
+/* the same matrix and right-hand side assembled by subdomains without atomics (owner computes row; cell_part[cell] in
+ * [0, n_parts) names the subdomain of a cell): the CPU baseline leg */
+void orc_ins_assemble_subdomains(orc_system *s, const orc_params *p, int32_t use_nonzero, const double *eval,
+                                 const double *present, const double *fsi_acc, const int32_t *cell_part, int32_t n_parts,
+                                 int32_t n_threads /* 0: OpenMP default */);
 /* the same assembly through constraints that also hold hanging-node lines x[dof[l]] = sum_k weight[k] x[master[k]],
  * k in [ptr[l], ptr[l+1]); dense n x n output (row-major) for small meshes; Dirichlet lines from orc_set_constraints */
 void orc_ins_assemble_affine_dense(orc_system *s, const orc_params *p, int32_t use_nonzero, const double *eval,

@@ -79,3 +79,37 @@ class BoxMesh:
                     else:
                         vals.append(value[k])
         return np.array(dofs, np.int32), np.array(vals, float)
+
+
+def block_partition(reps, n_parts):
+    """cell -> subdomain for a box mesh (cells numbered x fastest): n_parts lattice blocks, the factorisation of n_parts
+    chosen so that the blocks are as cubic as possible (what p4est's Morton partition of the reference amounts to on a
+    box).  Returns (cell_part [n_cells] int32, number of subdomains actually used)."""
+    reps = list(reps)
+    dim = len(reps)
+    best, best_cost = None, None
+    def factorisations(n, k):
+        if k == 1:
+            yield (n,)
+            return
+        for f in range(1, n + 1):
+            if n % f == 0:
+                for rest in factorisations(n // f, k - 1):
+                    yield (f,) + rest
+    for P in factorisations(n_parts, dim):
+        if any(P[d] > reps[d] for d in range(dim)):
+            continue
+        side = [reps[d] / P[d] for d in range(dim)]
+        cost = sum(np.prod(side) / side[d] for d in range(dim))  # surface of a block
+        if best_cost is None or cost < best_cost:
+            best, best_cost = P, cost
+    if best is None:
+        best = tuple(min(reps[d], 1) for d in range(dim))
+    ci = np.stack(np.unravel_index(np.arange(int(np.prod(reps))), reps[::-1]), axis=-1)[:, ::-1]  # (ix, iy, iz)
+    part = np.zeros(len(ci), np.int64)
+    stride = 1
+    for d in range(dim):
+        b = (ci[:, d] * best[d]) // reps[d]
+        part += b * stride
+        stride *= best[d]
+    return part.astype(np.int32), int(np.prod(best))

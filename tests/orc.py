@@ -54,10 +54,11 @@ def lib(native=False):
     global _lib
     name = "liboracle_native.so" if native else "liboracle.so"
     path = os.path.join(_ODIR, name)
-    if not os.path.exists(path):
-        subprocess.check_call(["make", "-C", _ODIR] + (["native"] if native else []), stdout=subprocess.DEVNULL)
-    if native:
+    if native:  # host-tuned build for the CPU baseline leg: always rebuilt on the box that runs it (-march=native)
+        subprocess.check_call(["make", "-C", _ODIR, "native"], stdout=subprocess.DEVNULL)
         return _bind(C.CDLL(path))
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", _ODIR], stdout=subprocess.DEVNULL)
     if _lib is None:
         _lib = _bind(C.CDLL(path))
     return _lib
@@ -76,6 +77,8 @@ def _bind(L):
         getattr(L, f).restype = C.POINTER(t)
         getattr(L, f).argtypes = [C.c_void_p]
     L.orc_ins_assemble.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_ins_assemble_subdomains.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int32, C.c_int32]
     L.orc_ins_assemble_affine_dense.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_ins_cell.argtypes = [C.POINTER(_Mesh), C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -221,6 +224,12 @@ class System:
 
     def assemble(self, params, use_nonzero, evalp, present, fsi_acc=None):
         self.L.orc_ins_assemble(self.h, C.byref(params), int(use_nonzero), _ptr(evalp), _ptr(present), _ptr(fsi_acc))
+
+    def assemble_subdomains(self, params, use_nonzero, evalp, present, cell_part, n_parts, n_threads=0, fsi_acc=None):
+        """orc_ins_assemble_subdomains: owner-computes rows over the subdomains cell_part names, no atomics"""
+        cp = np.ascontiguousarray(cell_part, np.int32)
+        self.L.orc_ins_assemble_subdomains(self.h, C.byref(params), int(use_nonzero), _ptr(evalp), _ptr(present), _ptr(fsi_acc),
+                                           _ptr(cp), int(n_parts), int(n_threads))
 
     def assemble_affine_dense(self, params, use_nonzero, evalp, present, mesh, fsi_acc=None):
         """assembly through constraints that also hold the hanging lines of `mesh` (tests/hangmesh.py): dense (A, rhs)"""

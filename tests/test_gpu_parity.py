@@ -5,6 +5,8 @@ difference is floating-point summation order: component-block form + atomics vs 
 linear solves meet the reference's own stopping rule ||b - A x|| <= 1e-4 ||b|| (mpi_insim.cpp:379-380), checked
 with the ORACLE's matrix; converged Newton steps agree to 1e-6 relative (Newton tolerance of the .prm files).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -517,8 +519,11 @@ def test_cached_geometry_blocks_stay_identical_across_assemblies(dim, kv, reps):
     ctx.close()
 
 
-def test_mfma_assembly_entrywise_on_odd_mesh_with_many_workgroups():
-    """k_ins_assemble3 (3D Q2/Q1, matrix cores) entry by entry against the oracle on a 9x7x5 mesh: 315 cells = 158
+@pytest.mark.parametrize("variant,waves", [(0, 3), (0, 4), (0, 2), (1, 2), (2, 3)])
+def test_mfma_assembly_entrywise_on_odd_mesh_with_many_workgroups(variant, waves):
+    """every build of the cell kernel (ifem_tuning::asm3_variant: shape tables rebuilt on the fly / per-cell tables in LDS /
+    mixed; asm3_waves: register budget for 2, 3 or 4 waves per SIMD):
+    k_ins_assemble3 (3D Q2/Q1, matrix cores) entry by entry against the oracle on a 9x7x5 mesh: 315 cells = 158
     workgroups of two cells (every XCD gets several, the XCD remap is exercised with a grid that is not a multiple of 8),
     an odd cell count (the last workgroup has an idle slot), distorted cells, Neumann inlet, inhomogeneous Dirichlet
     values, both constraint sets, and the cached-block path (second assembly with the same constraint set and another
@@ -533,6 +538,11 @@ def test_mfma_assembly_entrywise_on_odd_mesh_with_many_workgroups():
     dofs, vals = m.dirichlet(bcs)
     kw = dict(mu=0.7, rho=1.3, gamma=0.2, dt=0.01, g=(0.3, -9.8, 0.5), neumann={1: 2.5})
     ctx = _ctx(m)
+    tun = capi.Tuning()
+    ctx.L.ifem_default_tuning(C.byref(tun))
+    assert (tun.asm3_variant, tun.asm3_waves) == (0, 3)
+    tun.asm3_variant, tun.asm3_waves = variant, waves
+    assert ctx.L.ifem_set_tuning(ctx.h, C.byref(tun)) == 0
     ctx.set_constraints(0, dofs, None)
     ctx.set_constraints(1, dofs, vals)
     S = orc.System(m)

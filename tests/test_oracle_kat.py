@@ -330,3 +330,30 @@ def test_acoustic_pml_mpi_known_answer():
                          sigma_of_x=lambda xq: np.where(xq > 0.2, 340000.0 * ((xq - 0.2) / 1.2) ** 4, 0.0))
     assert abs(x[:S.n_u].max()) < 5e-2
     assert np.abs(x[:S.n_u]).max() > 0  # the run did move the fluid
+
+
+def test_subdomain_assembly_without_atomics_equals_the_cell_loop():
+    """orc_ins_assemble_subdomains (owner computes row, one subdomain per thread: the CPU baseline leg of bench.py) against
+    orc_ins_assemble on a distorted 3D Q2/Q1 mesh with inhomogeneous constraints and a Neumann face"""
+    from boxmesh import BoxMesh, block_partition
+    rng = np.random.default_rng(5)
+    m = BoxMesh((5, 4, 3), (0, 0, 0), (1.0, 0.8, 0.6), kv=2)
+    m.vcoords = m.vcoords + 0.01 * rng.standard_normal(m.vcoords.shape)
+    dofs, vals = m.dirichlet({0: (7, [0.3, -0.2, 0.1]), 2: (7, [0, 0, 0]), 3: (1, [0.05])})
+    kw = dict(mu=0.7, rho=1.3, gamma=0.2, dt=0.01, g=(0.3, -9.8, 0.5), neumann={1: 2.5})
+    ev, pr = rng.standard_normal(m.n_dofs), rng.standard_normal(m.n_dofs)
+    S = orc.System(m)
+    S.set_constraints(0, dofs, None)
+    S.set_constraints(1, dofs, vals)
+    P = orc.make_params(**kw)
+    for use_nonzero in (True, False):
+        S.assemble(P, use_nonzero, ev, pr)
+        A0, M0, b0 = S.csr("A"), S.csr("M"), S.rhs()
+        for n_parts in (1, 6, 12):
+            part, used = block_partition(m.reps, n_parts)
+            assert used == n_parts and part.max() == n_parts - 1
+            S.assemble_subdomains(P, use_nonzero, ev, pr, part, used, n_threads=4)
+            A1, M1, b1 = S.csr("A"), S.csr("M"), S.rhs()
+            assert abs(A1 - A0).max() <= 1e-13 * abs(A0).max()
+            assert abs(M1 - M0).max() <= 1e-13 * abs(M0).max()
+            assert np.abs(b1 - b0).max() <= 1e-13 * np.abs(b0).max()

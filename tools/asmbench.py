@@ -1,15 +1,43 @@
-"""Time ifem_ins_assemble at n^3 (kernel time from HIP events): python tools/asmbench.py [n] [asm_skip]"""
-import os, sys
+"""Time ifem_ins_assemble at n^3 (kernel time from HIP events) for the builds of the 3D Q2/Q1 cell kernel:
+    python tools/asmbench.py [n] [variant:waves[:asm_skip] ...]      e.g.  128 0:3 0:4 0:2 1:2 0:3:1
+variant = ifem_tuning::asm3_variant (0 tables rebuilt on the fly, 1 per-cell tables in LDS), waves = asm3_waves, asm_skip =
+the measurement switch (1: no A_uu scatter, 2: no contraction either).  Prints warm (cached geometry blocks) and cold
+(geo_cache = 0: B, B^T, M_p, diag(M_u) re-integrated) kernel times, median of 5."""
+import ctypes as C
+import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from openifem_amd import host
+from openifem_amd import capi, host
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+combos = sys.argv[2:] or ["0:3", "0:4", "0:2", "1:2"]
 s = host.InsIM(host.channel_prm(3), (n, n, n), (0, 0, 0), (2.0, 0.2, 0.2))
-s.setup(0); s.channel_state()
-if len(sys.argv) > 2:
-    import ctypes as C
-    from openifem_amd import capi
-    t = capi.Tuning(); s.L.ifem_default_tuning(C.byref(t)); t.asm_skip = int(sys.argv[2])
+s.set_multigrid(False)
+s.setup(0)
+s.channel_state()
+
+
+def tune(**kw):
+    t = capi.Tuning()
+    s.L.ifem_default_tuning(C.byref(t))
+    for k, v in kw.items():
+        setattr(t, k, v)
     assert s.L.ifem_set_tuning(s.ctx, C.byref(t)) == 0
-for _ in range(3):
+
+
+def med(k=5):
+    v = []
+    for _ in range(k):
+        s.assemble(False)
+        v.append(s.timing().assemble_kernel_ms)
+    return sorted(v)[len(v) // 2]
+
+
+for c in combos:
+    f = [int(x) for x in c.split(":")]
+    variant, waves, skip = f[0], f[1], (f[2] if len(f) > 2 else 0)
+    tune(asm3_variant=variant, asm3_waves=waves, asm_skip=skip)
     s.assemble(False)
-    print("asm_skip", sys.argv[2] if len(sys.argv) > 2 else 0, "assemble kernel ms", round(s.timing().assemble_kernel_ms, 2), flush=True)
+    warm = med()
+    tune(asm3_variant=variant, asm3_waves=waves, asm_skip=skip, geo_cache=0)
+    cold = med(3)
+    print(f"n {n} variant {variant} waves {waves} asm_skip {skip}: warm kernel {warm:.2f} ms, cold kernel {cold:.2f} ms", flush=True)
