@@ -167,6 +167,8 @@ typedef struct {
                             (two workgroups per CU); 2 = tables for assemblies that integrate B / B^T / M_p, none otherwise */
   int32_t asm3_waves;    /* 3: waves per SIMD the no-tables variant of that kernel is compiled for (2: 256 registers per lane, 3: 168,
                             4: 128 with spills around the scatter) */
+  int32_t asm3_cpb;      /* 2: cells per workgroup of the no-tables variant at 3 waves per SIMD (1, 2 or 4; two waves per cell) */
+  int32_t reserved_;
   int64_t tpp_dense_max; /* 12288: largest pressure space whose T_pp may be factorised densely (0 = never) */
   int64_t basis_pad;     /* 32*33 doubles of padding between Krylov basis columns (HBM channel spread) */
 } ifem_tuning;

@@ -82,7 +82,7 @@ __device__ __forceinline__ void shape_otf(const Shared3 &T, const double *__rest
 // (its LDS allows no more); the OTF layout is built for 3 (ks loop not unrolled: the whole kernel spills 80 bytes per lane,
 // none of it inside the contraction) and 4 (240 bytes, most of it around the staged scatter).
 template <int CPB, bool OTF, int WAVES>
-__global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_ins_assemble3(AsmArgs A, Tab1D t1) {
+__global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES ? WAVES : 1, WAVES ? WAVES : 4))) void k_ins_assemble3(AsmArgs A, Tab1D t1) {
   constexpr int DIM = 3, N1 = 3, NU = 27, NP = 8, NQ = 27, ND = 89, BS = 9;
   constexpr int NBP = NU * NP, BROUNDS = (NBP + 63) / 64, FR = (ND + 63) / 64;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
         posr[r] = A.posUU[(cc * NU + (a < NU ? a : 0)) * NU + bc_]; // unconditional (clamped): no branch, no wait here
       }
       if (A.debug_skip != 2) {
-#pragma unroll(OTF ? 1 : 7)
+#pragma unroll OTF ? 1 : 7
         for (int ks = 0; ks < 7; ++ks) {
           const int q = 4 * ks + (lane >> 4);
           const bool qv = q < NQ;
@@ -582,9 +582,8 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
 }
 
 // 3D Q2/Q1 only; the block-interleaved A_uu layout is assumed by the staged scatter
-template <bool OTF, int WAVES>
+template <bool OTF, int WAVES, int CPB> // CPB cells per workgroup (two waves each)
 static void launch3(ifem_ctx *ctx, const AsmArgs &A) {
-  constexpr int CPB = 2; // cells per workgroup (two waves each)
   const size_t smem = ((sizeof(Shared3) + 15) & ~size_t(15)) + CPB * ((sizeof(Cell3<OTF>) + 15) & ~size_t(15));
   // the dynamic-LDS limit is an attribute of the function ON A DEVICE: remembered per device, not per process
   static std::mutex mu;
@@ -612,10 +611,13 @@ bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A) {
   if (ctx->dim != 3 || ctx->kv != 2) return false;
   const int v = ctx->tune.asm3_variant;
   const bool tables = v == 1 || (v == 2 && !A.skip_geo && !A.rhs_only);
-  if (tables) launch3<false, 2>(ctx, A);
-  else if (ctx->tune.asm3_waves == 4) launch3<true, 4>(ctx, A);
-  else if (ctx->tune.asm3_waves == 2) launch3<true, 2>(ctx, A);
-  else launch3<true, 3>(ctx, A);
+  const int cpb = ctx->tune.asm3_cpb;
+  if (tables) launch3<false, 0, 2>(ctx, A); // register allocation left to the compiler, as in rounds 1-2 (170 + 80 accumulation registers)
+  else if (ctx->tune.asm3_waves == 4) launch3<true, 4, 2>(ctx, A);
+  else if (ctx->tune.asm3_waves == 2) launch3<true, 2, 2>(ctx, A);
+  else if (cpb == 1) launch3<true, 3, 1>(ctx, A);
+  else if (cpb == 4) launch3<true, 3, 4>(ctx, A);
+  else launch3<true, 3, 2>(ctx, A);
   return true;
 #endif
 }

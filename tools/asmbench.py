@@ -1,5 +1,5 @@
 """Time ifem_ins_assemble at n^3 (kernel time from HIP events) for the builds of the 3D Q2/Q1 cell kernel:
-    python tools/asmbench.py [n] [variant:waves[:asm_skip] ...]      e.g.  128 0:3 0:4 0:2 1:2 0:3:1
+    python tools/asmbench.py [n] [variant:waves[:asm_skip[:cells per workgroup]] ...]      e.g.  128 0:3 0:4 0:2 1:2 0:3:1 0:3:0:1
 variant = ifem_tuning::asm3_variant (0 tables rebuilt on the fly, 1 per-cell tables in LDS), waves = asm3_waves, asm_skip =
 the measurement switch (1: no A_uu scatter, 2: no contraction either).  Prints warm (cached geometry blocks) and cold
 (geo_cache = 0: B, B^T, M_p, diag(M_u) re-integrated) kernel times, median of 5."""
@@ -34,10 +34,10 @@ def med(k=5):
 
 for c in combos:
     f = [int(x) for x in c.split(":")]
-    variant, waves, skip = f[0], f[1], (f[2] if len(f) > 2 else 0)
-    tune(asm3_variant=variant, asm3_waves=waves, asm_skip=skip)
+    variant, waves, skip, cpb = f[0], f[1], (f[2] if len(f) > 2 else 0), (f[3] if len(f) > 3 else 2)
+    tune(asm3_variant=variant, asm3_waves=waves, asm_skip=skip, asm3_cpb=cpb)
     s.assemble(False)
     warm = med()
-    tune(asm3_variant=variant, asm3_waves=waves, asm_skip=skip, geo_cache=0)
+    tune(asm3_variant=variant, asm3_waves=waves, asm_skip=skip, asm3_cpb=cpb, geo_cache=0)
     cold = med(3)
-    print(f"n {n} variant {variant} waves {waves} asm_skip {skip}: warm kernel {warm:.2f} ms, cold kernel {cold:.2f} ms", flush=True)
+    print(f"n {n} variant {variant} waves {waves} cells/workgroup {cpb} asm_skip {skip}: warm kernel {warm:.2f} ms, cold kernel {cold:.2f} ms", flush=True)
