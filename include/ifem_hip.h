@@ -169,7 +169,8 @@ typedef struct {
                             4: 128 with spills around the scatter) */
   int32_t asm3_cpb;      /* 2: cells per workgroup of the no-tables variant at 3 waves per SIMD (1, 2 or 4; two waves per cell) */
   int32_t reserved_;
-  int64_t tpp_dense_max; /* 12288: largest pressure space whose T_pp may be factorised densely (0 = never) */
+  int64_t tpp_ilu_order; /* SCnsIM, explicit T_pp: preconditioner of its inner GMRES -- 0 (default) ILU(0) in the natural row order,
+                            level-scheduled; 1 multicolour ILU(0) (a few dozen levels whatever the mesh); -1 Jacobi(T_pp) */
   int64_t basis_pad;     /* 32*33 doubles of padding between Krylov basis columns (HBM channel spread) */
 } ifem_tuning;
 void ifem_default_tuning(ifem_tuning *t);
@@ -436,6 +437,12 @@ int ifem_uu_block_diag(ifem_ctx *ctx, int which, double *host_out);
 int ifem_uu_vmult(ifem_ctx *ctx, int dst, int src, int variant);
 /* z = P^-1 v, BlockSchurPreconditioner::vmult (mpi_insim.cpp:57-128) on context vectors -- test hook */
 int ifem_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int dst, int src);
+
+/* Test hook of the SCnsIM preconditioner (single-rank contexts, after ifem_scns_assemble): forms the explicit
+ * T_pp = A_pp - A_pv P_vv^-1 A_vp and its ILU(0) (ifem_tuning::tpp_ilu_order) as ifem_scns_solve would.  Call with rowptr only
+ * to size the arrays (n_p + 1 entries, nnz = rowptr[n_p]); with col / val it also returns the CSR of T_pp, and with x / y
+ * (host, n_p entries) y = (LU)^-1 x.  *levels (may be NULL) receives the number of forward levels of the schedule. */
+int ifem_tpp_ilu_probe(ifem_ctx *ctx, int64_t *rowptr, int32_t *col, double *val, const double *x, double *y, int32_t *levels);
 
 /* Export the assembled block system as one CSR over the local dofs [u|p] (host arrays; call twice: first
  * with col = val = NULL to get nnz through rowptr[n]).  which: 0 system_matrix, 1 mass (diag(M_u), M_p). */

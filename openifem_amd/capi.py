@@ -96,7 +96,7 @@ class MgTransfer(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("geo_cache", C.c_int32), ("xcd_swizzle", C.c_int32), ("asm_skip", C.c_int32), ("spmv_lanes", C.c_int32),
                 ("sm_lanes", C.c_int32), ("mf_f32", C.c_int32), ("tpp_operator", C.c_int32), ("spmv_pipe", C.c_int32), ("halo_overlap", C.c_int32),
-                ("asm3_variant", C.c_int32), ("asm3_waves", C.c_int32), ("asm3_cpb", C.c_int32), ("reserved_", C.c_int32), ("tpp_dense_max", C.c_int64), ("basis_pad", C.c_int64)]
+                ("asm3_variant", C.c_int32), ("asm3_waves", C.c_int32), ("asm3_cpb", C.c_int32), ("reserved_", C.c_int32), ("tpp_ilu_order", C.c_int64), ("basis_pad", C.c_int64)]
 
 
 class Timing(C.Structure):
@@ -116,7 +116,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof",
            "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag",
            "ifem_fsi_set_solid", "ifem_fsi_update_indicator", "ifem_fsi_find_fluid_bc", "ifem_fsi_get_stress",
-           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_true_residual"]
+           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_true_residual", "ifem_tpp_ilu_probe"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -190,6 +190,7 @@ def load():
     L.ifem_mg_attach.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(MgTransfer)]
     L.ifem_mg_depth.argtypes = [C.c_void_p]
     L.ifem_comm_stats_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ifem_tpp_ilu_probe.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.ifem_true_residual.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ifem_uu_block_diag.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.ifem_fsi_set_solid.argtypes = [C.c_void_p, C.POINTER(FsiSolid)]
@@ -393,15 +394,33 @@ class Context:
         self.opts = SolverOpts()
         self.L.ifem_default_solver_opts(C.byref(self.opts))
 
+    @classmethod
+    def borrow(cls, handle, dim, kv, n_unodes, n_pnodes):
+        """the methods of this class on a context somebody else owns (the C++ host mirror's, host.FluidSolver.ctx):
+        single-rank contexts; close() leaves the context alone"""
+        self = cls.__new__(cls)
+        self.L = load()
+        self._keep = []
+        self.dim, self.kv = dim, kv
+        self.h = C.c_void_p(handle.value if isinstance(handle, C.c_void_p) else handle)
+        self._borrowed = True
+        self.n_local = self.L.ifem_n_local_dofs(self.h)
+        self.n_u = dim * n_unodes
+        self.n_owned = dim * n_unodes + n_pnodes
+        self.n_unodes_owned = n_unodes
+        self.opts = SolverOpts()
+        self.L.ifem_default_solver_opts(C.byref(self.opts))
+        return self
+
     def _chk(self, rc):
         if rc < 0:
             raise IfemError(rc, self.L.ifem_last_error().decode())
         return rc
 
     def close(self):
-        if self.h:
+        if self.h and not getattr(self, "_borrowed", False):
             self.L.ifem_ctx_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
     def __del__(self):
         try:

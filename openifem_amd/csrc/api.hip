@@ -102,7 +102,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
 
 void ifem_default_tuning(ifem_tuning *t) {
   t->geo_cache = 1; t->xcd_swizzle = 1; t->asm_skip = 0; t->spmv_lanes = 32; t->sm_lanes = 32; t->mf_f32 = 1;
-  t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->asm3_waves = 3; t->asm3_cpb = 2; t->reserved_ = 0; t->tpp_dense_max = 12288; t->basis_pad = 32 * 33;
+  t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->asm3_waves = 3; t->asm3_cpb = 2; t->reserved_ = 0; t->tpp_ilu_order = 0; t->basis_pad = 32 * 33;
 }
 
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
@@ -111,7 +111,8 @@ int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
   const int g[2] = {t->spmv_lanes, t->sm_lanes};
   for (int v : g)
     if (v != 8 && v != 16 && v != 32 && v != 64) throw Error(IFEM_E_BADPARAM, "lanes per row must be 8, 16, 32 or 64");
-  if (t->basis_pad < 0 || t->tpp_dense_max < 0) throw Error(IFEM_E_BADPARAM, "negative size in ifem_tuning");
+  if (t->basis_pad < 0) throw Error(IFEM_E_BADPARAM, "negative size in ifem_tuning");
+  if (t->tpp_ilu_order < -1 || t->tpp_ilu_order > 1) throw Error(IFEM_E_BADPARAM, "tpp_ilu_order must be -1, 0 or 1");
   ctx->tune = *t;
   IFEM_API_END
 }
@@ -201,7 +202,6 @@ void ifem_ctx_destroy(ifem_ctx *ctx) {
     }
   }
   comm_destroy(ctx);
-  ifem::tpp_release(ctx);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -405,7 +405,6 @@ int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t) 
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     c->stream = s;
     c->owns_stream = false;
-    if (c->rocblas) ifem::tpp_release(c);
     // likewise one halo stream (the levels share the communicators, comm.hip)
     if (fine->halo.hstream && c->halo.hstream && c->halo.hstream != fine->halo.hstream) {
       IFEM_HIP_CHECK(hipStreamSynchronize(c->halo.hstream));
@@ -777,6 +776,36 @@ int ifem_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solve
   if (!o) { ifem_default_solver_opts(&def); o = &def; }
   ins_precond_vmult(ctx, p, o, ctx->vec[src].p, ctx->vec[dst].p);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  IFEM_API_END
+}
+
+int ifem_tpp_ilu_probe(ifem_ctx *ctx, int64_t *rowptr, int32_t *col, double *val, const double *x, double *y, int32_t *levels) {
+  IFEM_API_BEGIN
+  if (!ctx->assembled || !ctx->has_app) throw Error(IFEM_E_BADPARAM, "ifem_tpp_ilu_probe after ifem_scns_assemble");
+  if (ctx->halo.nranks > 1) throw Error(IFEM_E_BADPARAM, "ifem_tpp_ilu_probe: single-rank contexts only");
+  if (!rowptr) throw Error(IFEM_E_BADPARAM, "ifem_tpp_ilu_probe: rowptr is required");
+  hipStream_t s = ctx->stream;
+  bjac_setup(ctx);
+  ifem::tpp_numeric(ctx);
+  const int64_t n = ctx->Sm.n_rows;
+  IFEM_HIP_CHECK(hipMemcpyAsync(rowptr, ctx->Sm.rowptr.p, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  if (col && val) {
+    IFEM_HIP_CHECK(hipMemcpyAsync(col, ctx->Sm.col.p, (size_t)rowptr[n] * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    IFEM_HIP_CHECK(hipMemcpyAsync(val, ctx->Tpp.p, (size_t)rowptr[n] * sizeof(double), hipMemcpyDeviceToHost, s));
+    IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  if (x && y) {
+    if (ctx->tune.tpp_ilu_order < 0) throw Error(IFEM_E_BADPARAM, "ifem_tpp_ilu_probe: tpp_ilu_order = -1 keeps no ILU");
+    ifem::tpp_ilu_factor(ctx);
+    DBuf<double> dx, dy;
+    dx.upload(x, (size_t)n, s);
+    dy.alloc((size_t)n);
+    ifem::tpp_ilu_apply(ctx, dx.p, dy.p);
+    IFEM_HIP_CHECK(hipMemcpyAsync(y, dy.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    IFEM_HIP_CHECK(hipStreamSynchronize(s));
+    if (levels) *levels = ifem::tpp_ilu_levels(ctx);
+  }
   IFEM_API_END
 }
 

@@ -159,6 +159,14 @@ struct Halo {
 } // namespace ifem
 
 namespace ifem {
+// ILU(0) of the explicit T_pp on its own pattern (tpp.hip): analysis once per pattern, numeric factors per Newton iteration
+struct TppIlu {
+  DBuf<int32_t> ent, n_low, diag, rows_f, rows_b;
+  std::vector<int64_t> lvl_f, lvl_b; // level pointers into rows_f / rows_b (host: one launch per level)
+  DBuf<double> LU;
+  bool analysed = false, factored = false;
+  int order_kind = 0;
+};
 // hanging-node constraint lines x[dof_i] = sum_k w_k x[master_k] (closed), see hanging.hip
 struct Hanging {
   int32_t n = 0;
@@ -290,10 +298,9 @@ struct ifem_ctx {
   double uu_lmax_key[6] = {0, 0, 0, 0, 0, -1};  // (mu, rho, gamma, dt, noconv, constrained-dof set) of the cached eigenvalue bound
   int64_t sm_version = 0, sm_mg_version = -1; // S_m values rebuilt / the version the V-cycle data belong to
   // explicit T_pp = A_pp - A_pv Binv A_vp on the pattern of Sm and its dense LU (tpp.hip)
-  ifem::DBuf<double> Tpp, tpp_diag, tpp_dense;
-  ifem::DBuf<int> tpp_ipiv;
-  bool tpp_valid = false, tpp_dense_valid = false, tpp_prefer_dense = false;
-  void *rocblas = nullptr;
+  ifem::DBuf<double> Tpp, tpp_diag;
+  bool tpp_valid = false;
+  ifem::TppIlu tpp_ilu; // level-scheduled ILU(0) of T_pp (tpp.hip)
   // matrix-free A_uu (IFEM_AINV_GMRES_BJACOBI_MF): state of the last ifem_ins_assemble
   ifem::DBuf<double> mf_ycell; // per-cell results of the matrix-free apply [n_cells][nu][dim] (two-stage scatter)
   ifem::DBuf<double> mf_eval;  // velocity part of the evaluation point, ghost-extended

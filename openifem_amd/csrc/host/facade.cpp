@@ -271,6 +271,57 @@ int ifemx_sm_plan_tables(void *hv, int32_t *box_id, int32_t *send_s_ptr, int32_t
   });
 }
 
+// The refinement loop of the reference's FSI drivers (tests/fsi_leaflet_mpi/fsi_leaflet_mpi.cpp:65-75): set_refine_flag on every
+// coarse cell whose centre lies in [lo, hi] along direction `dir`, then execute_coarsening_and_refinement.  Before ifemx_setup.
+int ifemx_refine_band(void *hv, int dir, double lo, double hi, int64_t *n_flagged) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto run = [&](auto &tria) {
+      int64_t cnt = 0;
+      for (size_t c = 0; c < tria.n_active_cells(); ++c) {
+        const auto center = tria.cell_center(c);
+        if (center[dir] >= lo && center[dir] <= hi) { tria.set_refine_flag(c); ++cnt; }
+      }
+      tria.execute_coarsening_and_refinement();
+      if (n_flagged) *n_flagged = cnt;
+    };
+    if (dir < 0 || dir >= h->dim) throw std::invalid_argument("ifemx_refine_band: bad direction");
+    if (h->dim == 2) run(*h->t2); else run(*h->t3);
+  });
+}
+// hanging-node lines of the solver's DoF tables: sizes = [n_lines, n_entries]; then the arrays (dof [n], ptr [n + 1],
+// master / weight [n_entries]); any output may be NULL
+int ifemx_hanging_lines(void *hv, int64_t *sizes, int32_t *dof, int32_t *ptr, int32_t *master, double *weight) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto fill = [&](auto &s) {
+      const HangingLines &L = s.hanging_lines();
+      if (sizes) { sizes[0] = (int64_t)L.dof.size(); sizes[1] = (int64_t)L.master.size(); }
+      if (dof && !L.dof.empty()) std::memcpy(dof, L.dof.data(), L.dof.size() * 4);
+      if (ptr) std::memcpy(ptr, L.ptr.data(), L.ptr.size() * 4);
+      if (master && !L.master.empty()) std::memcpy(master, L.master.data(), L.master.size() * 4);
+      if (weight && !L.weight.empty()) std::memcpy(weight, L.weight.data(), L.weight.size() * 8);
+    };
+    if (h->dim == 2) fill(*h->s2); else fill(*h->s3);
+  });
+}
+// FluidSolver::make_constraints(): the boundary lines re-made (MPI::FSI::run does this every time step, mpi_fsi.cpp:1191-1198);
+// zero_inhomogeneities != 0: nonzero_constraints := copy of zero_constraints, as the FSI driver does after the first step
+int ifemx_make_constraints(void *hv, int zero_inhomogeneities) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto run = [&](auto &s) {
+      s.make_constraints();
+      if (zero_inhomogeneities) {
+        std::vector<int32_t> d; std::vector<double> v;
+        s.constraint_lines(d, v);
+        if (ifem_set_constraints(s.context(), 1, (int32_t)d.size(), d.data(), nullptr) < 0) throw std::runtime_error(ifem_last_error());
+      }
+    };
+    if (h->dim == 2) run(*h->s2); else run(*h->s3);
+  });
+}
+
 // Multigrid levels of the host mirror (insim.hpp, FluidSolver::multigrid): on / off, the smallest number of cells per rank a
 // halved direction keeps, and -- validation transport only -- the local worlds of the coarser levels.  Before ifemx_setup.
 int ifemx_set_multigrid(void *hv, int on, int min_cells, void *const *level_worlds, int n_worlds) {

@@ -1,6 +1,10 @@
 // grid.cpp -- see grid.hpp.
 #include "grid.hpp"
 #include <cmath>
+#include <map>
+#include <numeric>
+#include <unordered_map>
+#include <cmath>
 #include <functional>
 #include <map>
 #include <numeric>
@@ -72,6 +76,33 @@ void Triangulation<dim>::refine_global(int times) {
   for (int d = 0; d < dim; ++d) { a[d] = p0[d]; b[d] = p1[d]; }
   // colorised ids survive refinement (children inherit the face's boundary id)
   GridGenerator::subdivided_hyper_rectangle<dim>(*this, r, a, b, colorized, cells.empty());
+}
+template <int dim>
+void Triangulation<dim>::set_refine_flag(size_t coarse_cell) {
+  if (!is_box || locally_refined) throw std::runtime_error("set_refine_flag: one level of local refinement on a box triangulation");
+  const size_t nc = n_active_cells();
+  if (coarse_cell >= nc) throw std::out_of_range("set_refine_flag: no such cell");
+  if (refine_flags.size() != nc) refine_flags.assign(nc, 0);
+  refine_flags[coarse_cell] = 1;
+}
+template <int dim>
+std::array<double, dim> Triangulation<dim>::cell_center(size_t c) const {
+  std::array<double, dim> x{};
+  size_t rem = c;
+  for (int d = 0; d < dim; ++d) {
+    const size_t i = rem % (size_t)reps[d];
+    rem /= (size_t)reps[d];
+    x[d] = p0[d] + (double(i) + 0.5) * ((p1[d] - p0[d]) / reps[d]);
+  }
+  return x;
+}
+template <int dim>
+void Triangulation<dim>::execute_coarsening_and_refinement() {
+  if (!is_box) throw std::runtime_error("execute_coarsening_and_refinement: box triangulations only");
+  bool any = false;
+  for (uint8_t f : refine_flags) any = any || f;
+  locally_refined = any;
+  if (!any) refine_flags.clear();
 }
 template struct Triangulation<2>;
 template struct Triangulation<3>;
@@ -732,14 +763,154 @@ template void distribute_dofs<2>(const Triangulation<2> &, int, DoFTables<2> &);
 template void distribute_dofs<3>(const Triangulation<3> &, int, DoFTables<3> &);
 
 template <int dim>
+void distribute_dofs_refined_box(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out, PartitionTables &part,
+                                 HangingLines &lines) {
+  if (!tria.is_box) throw std::runtime_error("distribute_dofs_refined_box: box triangulations only");
+  constexpr int NV = 1 << dim;
+  const int n1 = kv + 1;
+  int nu = 1;
+  for (int d = 0; d < dim; ++d) nu *= n1;
+  int reps[3] = {1, 1, 1};
+  double h[3] = {0, 0, 0};
+  for (int d = 0; d < dim; ++d) { reps[d] = tria.reps[d]; h[d] = (tria.p1[d] - tria.p0[d]) / reps[d]; }
+  const size_t n_coarse = (size_t)reps[0] * reps[1] * reps[2];
+  const bool flagged = tria.locally_refined && tria.refine_flags.size() == n_coarse;
+  // cells on the half-cell lattice: origin and size (1: child of a refined cell, 2: unrefined coarse cell)
+  struct Cell { int org[3]; int size; };
+  std::vector<Cell> cells;
+  for (size_t c = 0; c < n_coarse; ++c) {
+    int ci[3] = {int(c % reps[0]), int((c / reps[0]) % reps[1]), int(c / ((size_t)reps[0] * reps[1]))};
+    if (flagged && tria.refine_flags[c]) {
+      for (int ch = 0; ch < NV; ++ch) {
+        Cell k{{0, 0, 0}, 1};
+        for (int d = 0; d < dim; ++d) k.org[d] = 2 * ci[d] + ((ch >> d) & 1);
+        cells.push_back(k);
+      }
+    } else {
+      Cell k{{0, 0, 0}, 2};
+      for (int d = 0; d < dim; ++d) k.org[d] = 2 * ci[d];
+      cells.push_back(k);
+    }
+  }
+  const size_t nc = cells.size();
+  auto pack = [](const int64_t *k) { return (uint64_t(k[2]) << 42) | (uint64_t(k[1]) << 21) | uint64_t(k[0]); };
+  std::unordered_map<uint64_t, int32_t> uid, pid;
+  std::vector<std::array<int64_t, 3>> ukeys, pkeys;
+  out = DoFTables<dim>();
+  out.kv = kv; out.nu = nu; out.np = NV;
+  out.cell_unodes.resize(nc * nu); out.cell_pnodes.resize(nc * NV);
+  out.vcoords.resize(nc * NV * dim); out.cell_face_bid.assign(nc * 2 * dim, -1);
+  for (size_t c = 0; c < nc; ++c) {
+    const Cell &k = cells[c];
+    for (int a = 0; a < nu; ++a) { // velocity lattice: kv units per half cell
+      const int l[3] = {a % n1, (a / n1) % n1, a / (n1 * n1)};
+      int64_t key[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) key[d] = int64_t(k.org[d]) * kv + int64_t(l[d]) * k.size;
+      auto it = uid.emplace(pack(key), (int32_t)uid.size());
+      if (it.second) ukeys.push_back({key[0], key[1], key[2]});
+      out.cell_unodes[c * nu + a] = it.first->second;
+    }
+    for (int a = 0; a < NV; ++a) {
+      int64_t key[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) key[d] = k.org[d] + ((a >> d) & 1) * k.size;
+      auto it = pid.emplace(pack(key), (int32_t)pid.size());
+      if (it.second) pkeys.push_back({key[0], key[1], key[2]});
+      out.cell_pnodes[c * NV + a] = it.first->second;
+      for (int d = 0; d < dim; ++d) out.vcoords[(c * NV + a) * dim + d] = tria.p0[d] + double(key[d]) * h[d] / 2;
+    }
+    for (int d = 0; d < dim; ++d) { // colorised boundary ids 2d / 2d + 1 (children inherit them)
+      if (k.org[d] == 0) out.cell_face_bid[c * 2 * dim + 2 * d] = tria.colorized ? 2 * d : 0;
+      if (k.org[d] + k.size == 2 * reps[d]) out.cell_face_bid[c * 2 * dim + 2 * d + 1] = tria.colorized ? 2 * d + 1 : 0;
+    }
+  }
+  out.n_unodes = out.n_unodes_owned = (int64_t)uid.size();
+  out.n_pnodes = out.n_pnodes_owned = (int64_t)pid.size();
+  out.unode_coords.resize(ukeys.size());
+  out.pnode_coords.resize(pkeys.size());
+  for (size_t i = 0; i < ukeys.size(); ++i)
+    for (int d = 0; d < dim; ++d) out.unode_coords[i][d] = tria.p0[d] + double(ukeys[i][d]) * h[d] / (2 * kv);
+  for (size_t i = 0; i < pkeys.size(); ++i)
+    for (int d = 0; d < dim; ++d) out.pnode_coords[i][d] = tria.p0[d] + double(pkeys[i][d]) * h[d] / 2;
+  part = PartitionTables();
+  part.l2g_u.resize(ukeys.size()); part.l2g_p.resize(pkeys.size());
+  std::iota(part.l2g_u.begin(), part.l2g_u.end(), 0);
+  std::iota(part.l2g_p.begin(), part.l2g_p.end(), 0);
+  part.n_unodes_global = out.n_unodes; part.n_pnodes_global = out.n_pnodes; part.n_cells_global = (int64_t)nc;
+  part.send_u_ptr = {0}; part.recv_u_ptr = {0}; part.send_p_ptr = {0}; part.recv_p_ptr = {0};
+  // hanging lines: the first unrefined coarse cell (in cell order) whose closure holds a foreign node interpolates it
+  lines.clear();
+  const int64_t n_u = dim * out.n_unodes;
+  std::map<int32_t, std::pair<std::vector<int32_t>, std::vector<double>>> found;
+  auto lagrange = [](int k, double t, double *w) {
+    for (int i = 0; i <= k; ++i) {
+      w[i] = 1.0;
+      for (int j = 0; j <= k; ++j)
+        if (j != i) w[i] *= (t - double(j) / k) / (double(i) / k - double(j) / k);
+    }
+  };
+  for (size_t c = 0; c < nc; ++c) {
+    const Cell &k = cells[c];
+    if (k.size != 2) continue;
+    for (int space = 0; space < 2; ++space) { // velocity nodes (degree kv, dim components), pressure nodes (degree 1)
+      const int deg = space == 0 ? kv : 1, unit = deg, m1 = deg + 1;
+      const auto &table = space == 0 ? uid : pid;
+      const int32_t *cell_nodes = space == 0 ? &out.cell_unodes[c * nu] : &out.cell_pnodes[c * NV];
+      const int n_cell_nodes = space == 0 ? nu : NV;
+      const int span = 2 * unit; // lattice units across the coarse cell
+      int64_t cnt = 1;
+      for (int d = 0; d < dim; ++d) cnt *= span + 1;
+      for (int64_t q = 0; q < cnt; ++q) {
+        int64_t key[3] = {0, 0, 0}, rem = q;
+        int off[3] = {0, 0, 0};
+        for (int d = 0; d < dim; ++d) { off[d] = int(rem % (span + 1)); rem /= span + 1; key[d] = int64_t(k.org[d]) * unit + off[d]; }
+        auto it = table.find(pack(key));
+        if (it == table.end()) continue;
+        const int32_t nd = it->second;
+        bool mine = false;
+        for (int a = 0; a < n_cell_nodes; ++a) mine = mine || cell_nodes[a] == nd;
+        if (mine) continue;
+        double w1[3][4];
+        for (int d = 0; d < dim; ++d) lagrange(deg, double(off[d]) / span, w1[d]);
+        std::vector<int32_t> ms;
+        std::vector<double> ws;
+        for (int a = 0; a < n_cell_nodes; ++a) {
+          const int l[3] = {a % m1, (a / m1) % m1, a / (m1 * m1)};
+          double w = 1.0;
+          for (int d = 0; d < dim; ++d) w *= w1[d][l[d]];
+          if (std::fabs(w) > 1e-13) { ms.push_back(cell_nodes[a]); ws.push_back(w); }
+        }
+        const int ncomp = space == 0 ? dim : 1;
+        for (int cpt = 0; cpt < ncomp; ++cpt) {
+          const int32_t dof = space == 0 ? int32_t(dim * nd + cpt) : int32_t(n_u + nd);
+          if (found.count(dof)) continue;
+          std::vector<int32_t> md(ms.size());
+          for (size_t i = 0; i < ms.size(); ++i) md[i] = space == 0 ? int32_t(dim * ms[i] + cpt) : int32_t(n_u + ms[i]);
+          found.emplace(dof, std::make_pair(md, ws));
+        }
+      }
+    }
+  }
+  for (auto &kv_ : found) { // ascending dof
+    lines.dof.push_back(kv_.first);
+    lines.master.insert(lines.master.end(), kv_.second.first.begin(), kv_.second.first.end());
+    lines.weight.insert(lines.weight.end(), kv_.second.second.begin(), kv_.second.second.end());
+    lines.ptr.push_back((int32_t)lines.master.size());
+  }
+}
+template void distribute_dofs_refined_box<2>(const Triangulation<2> &, int, DoFTables<2> &, PartitionTables &, HangingLines &);
+template void distribute_dofs_refined_box<3>(const Triangulation<3> &, int, DoFTables<3> &, PartitionTables &, HangingLines &);
+
+template <int dim>
 void make_dirichlet(const DoFTables<dim> &dofs,
                     const std::map<unsigned, std::pair<unsigned, std::vector<double>>> &bcs,
                     const std::map<int, std::function<double(const std::array<double, dim> &, unsigned)>> &hard_coded,
-                    std::vector<int32_t> &dof, std::vector<double> &value) {
+                    std::vector<int32_t> &dof, std::vector<double> &value, const std::vector<int32_t> *skip) {
   dof.clear();
   value.clear();
   const int kv = dofs.kv, n1 = kv + 1, nu = dofs.nu;
   std::vector<uint8_t> seen((size_t)dofs.n_u(), 0);
+  if (skip)
+    for (int32_t d : *skip) if (d >= 0 && d < dofs.n_u()) seen[(size_t)d] = 1;
   // per boundary id, in ascending id order; an already constrained dof keeps its first line
   // (interpolate_boundary_values + AffineConstraints::add_line semantics, mpi_fluid_solver.cpp:185-272)
   for (const auto &bc : bcs) {
@@ -774,10 +945,10 @@ void make_dirichlet(const DoFTables<dim> &dofs,
 template void make_dirichlet<2>(const DoFTables<2> &,
                                 const std::map<unsigned, std::pair<unsigned, std::vector<double>>> &,
                                 const std::map<int, std::function<double(const std::array<double, 2> &, unsigned)>> &,
-                                std::vector<int32_t> &, std::vector<double> &);
+                                std::vector<int32_t> &, std::vector<double> &, const std::vector<int32_t> *);
 template void make_dirichlet<3>(const DoFTables<3> &,
                                 const std::map<unsigned, std::pair<unsigned, std::vector<double>>> &,
                                 const std::map<int, std::function<double(const std::array<double, 3> &, unsigned)>> &,
-                                std::vector<int32_t> &, std::vector<double> &);
+                                std::vector<int32_t> &, std::vector<double> &, const std::vector<int32_t> *);
 
 } // namespace ifem_host

@@ -33,6 +33,23 @@ struct Triangulation {
   std::function<void(Triangulation<dim> &, int level)> generator;
   int level = 0;
   void refine_global(int times);
+  // One level of LOCAL refinement of a box triangulation: cell->set_refine_flag() on coarse cells (numbered x fastest) and
+  // execute_coarsening_and_refinement(), as the reference's FSI drivers refine a band of the fluid mesh
+  // (tests/fsi_leaflet_mpi/fsi_leaflet_mpi.cpp:65-75).  Flagged cells are replaced by their 2^dim children; the mesh is
+  // one-irregular by construction (one level) and the hanging-node lines come from distribute_dofs_refined_box.
+  std::vector<uint8_t> refine_flags; // per coarse cell, empty: none
+  bool locally_refined = false;
+  void set_refine_flag(size_t coarse_cell);
+  std::array<double, dim> cell_center(size_t coarse_cell) const;
+  void execute_coarsening_and_refinement();
+};
+
+// hanging-node lines x[dof] = sum_k weight[k] x[master[k]], k in [ptr[i], ptr[i+1]), in the block numbering
+// [dim * unode + c | n_u + pnode] (DoFTools::make_hanging_node_constraints, mpi_fluid_solver.cpp:182-184)
+struct HangingLines {
+  std::vector<int32_t> dof, ptr{0}, master;
+  std::vector<double> weight;
+  void clear() { dof.clear(); ptr.assign(1, 0); master.clear(); weight.clear(); }
 };
 
 namespace Utils {
@@ -98,6 +115,13 @@ void distribute_dofs_box(const std::array<int, 3> &reps, const std::array<double
 
 template <int dim>
 void distribute_dofs(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out);
+// a box triangulation after execute_coarsening_and_refinement (single rank): coarse cells x fastest with the children of
+// a refined cell in its place, nodes numbered in order of first appearance, and the hanging-node lines of the
+// refinement interfaces (a node in the closure of an unrefined coarse cell that is not one of its nodes is interpolated
+// from that cell's shape functions)
+template <int dim>
+void distribute_dofs_refined_box(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out, PartitionTables &part,
+                                 HangingLines &lines);
 // general (unstructured, single rank) variant: vertices, edge midpoints, (face centres,) cell centres
 template <int dim>
 void distribute_dofs_unstructured(const Triangulation<dim> &tria, int kv, DoFTables<dim> &out, PartitionTables &part);
@@ -110,10 +134,11 @@ void partition_unstructured(const DoFTables<dim> &global, int nranks, int rank, 
 
 // Dirichlet lines (dof, value) in block numbering [u|p]; `bcs`: id -> (component flag 1..7, values);
 // `hard_coded`: id -> f(point, component) overriding the constant values (add_hard_coded_boundary_condition).
+// `skip` (may be NULL): dofs that already carry a line (hanging nodes): interpolate_boundary_values leaves them alone
 template <int dim>
 void make_dirichlet(const DoFTables<dim> &dofs,
                     const std::map<unsigned, std::pair<unsigned, std::vector<double>>> &bcs,
                     const std::map<int, std::function<double(const std::array<double, dim> &, unsigned)>> &hard_coded,
-                    std::vector<int32_t> &dof, std::vector<double> &value);
+                    std::vector<int32_t> &dof, std::vector<double> &value, const std::vector<int32_t> *skip = nullptr);
 
 } // namespace ifem_host

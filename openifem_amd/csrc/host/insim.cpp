@@ -50,7 +50,7 @@ template <int dim>
 bool FluidSolver<dim>::attach_multigrid_levels() {
   mg_coarse.reset();
   mg_tria.reset();
-  if (!multigrid || !triangulation.is_box || !ctx) return false;
+  if (!multigrid || !triangulation.is_box || triangulation.locally_refined || !ctx) return false;
   std::array<int, 3> n{1, 1, 1}, next;
   std::array<double, 3> extent{1, 1, 1};
   for (int d = 0; d < dim; ++d) {
@@ -169,9 +169,18 @@ void FluidSolver<dim>::setup_dofs() {
       const DoFTables<dim> global = dofs;
       partition_unstructured<dim>(global, nranks, part_rank, dofs, part);
     }
-  } else
-  distribute_dofs_box<dim>(triangulation.reps, triangulation.p0, triangulation.p1, triangulation.colorized,
-                           (int)parameters.fluid_velocity_degree, proc_grid, part_rank, dofs, part);
+  } else if (triangulation.locally_refined) { // one level of local refinement (execute_coarsening_and_refinement)
+    if (proc_grid[0] * proc_grid[1] * proc_grid[2] > 1)
+      throw std::runtime_error("setup_dofs: locally refined box triangulations are single-rank in the host mirror (partitioned "
+                               "contexts take hanging lines through ifem_set_hanging_constraints)");
+    const bool morton = dofs.morton;
+    distribute_dofs_refined_box<dim>(triangulation, (int)parameters.fluid_velocity_degree, dofs, part, hanging);
+    dofs.morton = morton;
+  } else {
+    hanging.clear();
+    distribute_dofs_box<dim>(triangulation.reps, triangulation.p0, triangulation.p1, triangulation.colorized,
+                             (int)parameters.fluid_velocity_degree, proc_grid, part_rank, dofs, part);
+  }
   dofs_per_block = {(size_t)(dim * part.n_unodes_global), (size_t)part.n_pnodes_global};
   if (this->pcout)
     *this->pcout << "   Number of active fluid cells: " << triangulation.n_active_cells() << std::endl
@@ -187,7 +196,8 @@ void FluidSolver<dim>::make_constraints() {
     auto f = kv.second;
     hc[kv.first] = [f, t](const Point &p, unsigned c) { return f(p, c, t); };
   }
-  make_dirichlet<dim>(dofs, parameters.fluid_dirichlet_bcs, hc, constraint_dofs, nonzero_values);
+  // hanging-node lines first (mpi_fluid_solver.cpp:182-184), then the boundary values, which skip dofs that carry a line
+  make_dirichlet<dim>(dofs, parameters.fluid_dirichlet_bcs, hc, constraint_dofs, nonzero_values, hanging.dof.empty() ? nullptr : &hanging.dof);
   if (ctx) {
     check(ifem_set_constraints(ctx, 1, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nonzero_values.data()), "make_constraints");
     check(ifem_set_constraints(ctx, 0, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nullptr), "make_constraints");
@@ -223,6 +233,9 @@ void FluidSolver<dim>::initialize_system() {
     }
   }
   check(ifem_ctx_create(&m, part.nranks > 1 ? &ip : nullptr, device, &ctx), "initialize_system");
+  if (!hanging.dof.empty())
+    check(ifem_set_hanging_constraints(ctx, (int32_t)hanging.dof.size(), hanging.dof.data(), hanging.ptr.data(), hanging.master.data(),
+                                       hanging.weight.data()), "initialize_system");
   check(ifem_set_constraints(ctx, 1, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nonzero_values.data()), "initialize_system");
   check(ifem_set_constraints(ctx, 0, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nullptr), "initialize_system");
   if (initial_condition_field) { // apply_initial_condition (mpi_fluid_solver.cpp:367-415): nodal interpolation

@@ -104,6 +104,8 @@ public:
   unsigned int current_timestep() const { return time.get_timestep(); }
   double current_time() const { return time.current(); }
   const DoFTables<dim> &dof_tables() const { return dofs; }
+  // the hanging-node lines of a locally refined triangulation (empty otherwise), block numbering [u | p]
+  const HangingLines &hanging_lines() const { return hanging; }
   const Triangulation<dim> &get_triangulation() const { return triangulation; }
   void constraint_lines(std::vector<int32_t> &d, std::vector<double> &v) const { d = constraint_dofs; v = nonzero_values; }
   std::ostream *pcout = &std::cout; // ConditionalOStream on rank 0; nullptr silences
@@ -138,6 +140,7 @@ protected:
   Triangulation<dim> &triangulation;
   Parameters::AllParameters parameters;
   DoFTables<dim> dofs;
+  HangingLines hanging;
   std::vector<size_t> dofs_per_block;
   std::map<int, std::function<double(const Point &, const unsigned int, const double)>> hard_coded_boundary_values;
   std::shared_ptr<std::function<double(const Point &, const unsigned int)>> initial_condition_field;

@@ -116,9 +116,9 @@ void spmv_planar_scalar(ifem_ctx *ctx, const PlanarCsr &M, const double *val, co
 // explicit pressure Schur complement of the SUPG block preconditioner (tpp.hip)
 void tpp_numeric(ifem_ctx *ctx);
 void spmv_tpp(ifem_ctx *ctx, const double *xp, double *yp);
-bool tpp_dense_setup(ifem_ctx *ctx);
-void tpp_dense_solve(ifem_ctx *ctx, const double *x, double *y);
-void tpp_release(ifem_ctx *ctx);
+void tpp_ilu_factor(ifem_ctx *ctx);
+void tpp_ilu_apply(ifem_ctx *ctx, const double *x, double *y);
+int tpp_ilu_levels(const ifem_ctx *ctx);
 // hanging-node lines (hanging.hip): C x on a copy of x, C^T and the hanging rows on y, distribute, set-up
 void hanging_set(ifem_ctx *ctx, int32_t n, const int32_t *dof, const int32_t *ptr, const int32_t *master, const double *weight);
 const double *hanging_input(ifem_ctx *ctx, const double *x); // ghost-extended [u_l | p_l] copy of x with C applied

@@ -985,7 +985,7 @@ void ins_system_vmult(ifem_ctx *ctx, const double *src, double *dst) {
 
 // SUPGFluidSolver::solve + BlockIncompSchurPreconditioner::vmult (mpi_supg_solver.cpp:35-192, 297-328).
 //   P_vv^-1  : node-block Jacobi of A_vv            (reference: Hypre-Euclid ILU(0))
-//   T_pp     : A_pp - A_pv P_vv^-1 A_vp, solved by GMRES(200) to 1e-3 ||.|| with Jacobi(diag A_pp)
+//   T_pp     : A_pp - A_pv P_vv^-1 A_vp, solved by GMRES(200) to 1e-3 ||.|| with the ILU(0) of the explicit T_pp
 //                                                   (reference: ILU(0) of B2pp = A_pp - A_pv rowsum|A_vv|^-1 A_vp)
 int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats) {
   if (!ctx->assembled || !ctx->has_app) throw Error(IFEM_E_BADPARAM, "ifem_scns_solve called before ifem_scns_assemble");
@@ -1023,18 +1023,19 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
     v_axpy(ctx, S.npo, -1.0, S.tp[4], y);
   };
   OpFn Jpp = [&](const double *x, double *y) { vec_div(ctx, S.npo, ctx->app_diag.p, x, y); };
-  // one rank: T_pp as an explicit matrix (tpp.hip) -- exact dense solve on small pressure spaces, else one SpMV per inner
-  // iteration and the Jacobi preconditioner of T_pp itself.  ifem_tuning::tpp_operator keeps the operator form.
+  // one rank: T_pp as an explicit matrix (tpp.hip): one SpMV per inner iteration, and the inner GMRES preconditioned by the
+  // ILU(0) of that matrix (the reference: Euclid ILU(0) of B2pp, mpi_supg_solver.cpp:141-192, preconditioner_pilut.cpp:124-138),
+  // factorised once per Newton iteration and applied by level-scheduled triangular solves.  ifem_tuning::tpp_operator keeps
+  // the operator form with Jacobi (what several ranks use), tpp_ilu_order = -1 the explicit matrix with Jacobi.
   const bool tpp_explicit = ctx->halo.nranks == 1 && !ctx->tune.tpp_operator;
-  // The dense LU costs one factorisation per Newton iteration: it is switched on (for the life of the context) the first
-  // time an inner solve does not converge within `tpp_switch_its` iterations -- acoustics with dt ~ 1e-7 never get there.
-  const int tpp_switch_its = 100;
-  bool tpp_dense = false;
   if (tpp_explicit) {
     tpp_numeric(ctx);
-    if (ctx->tpp_prefer_dense) tpp_dense = tpp_dense_setup(ctx);
     Tpp = [&](const double *x, double *y) { spmv_tpp(ctx, x, y); };
-    Jpp = [&](const double *x, double *y) { vec_div(ctx, S.npo, ctx->tpp_diag.p, x, y); };
+    if (ctx->tune.tpp_ilu_order >= 0) {
+      tpp_ilu_factor(ctx);
+      Jpp = [&](const double *x, double *y) { tpp_ilu_apply(ctx, x, y); };
+    } else
+      Jpp = [&](const double *x, double *y) { vec_div(ctx, S.npo, ctx->tpp_diag.p, x, y); };
   }
   OpFn Pop = [&](const double *src, double *dst) {
     const double *src0 = src, *src1 = src + S.nuo;
@@ -1046,19 +1047,8 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
     mdot_p(1, S.tp[0], S.npo, S.tp[0], &pn);
     double res = 0;
     const double inner_tol = 1e-3 * std::sqrt(pn);
-    if (!tpp_dense) {
-      const bool may_switch = tpp_explicit && !ctx->tpp_prefer_dense && S.npo <= ctx->tune.tpp_dense_max;
-      S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.ctx, S.npo), /*reorth=*/true, Tpp, Jpp, false, S.tp[0], dst1, mt,
-                                may_switch ? tpp_switch_its : 100000, inner_tol, ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p);
-      if (may_switch && res > inner_tol) { // too slow for this system: factorise instead
-        ctx->tpp_prefer_dense = true;
-        tpp_dense = tpp_dense_setup(ctx);
-        if (!tpp_dense) // no rocSOLVER: carry on iteratively
-          S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.ctx, S.npo), true, Tpp, Jpp, false, S.tp[0], dst1, mt, 100000, inner_tol,
-                                    ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p);
-      }
-    }
-    if (tpp_dense) tpp_dense_solve(ctx, S.tp[0], dst1);
+    S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.ctx, S.npo), /*reorth=*/true, Tpp, Jpp, false, S.tp[0], dst1, mt, 100000, inner_tol,
+                              ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p);
     bt_apply(dst1, S.tu);                          // A_vp dst1
     bjac_apply(ctx, S.tu, S.utmp);
     v_copy(ctx, S.nuo, S.inner_w, dst0);

@@ -3,26 +3,26 @@
 //   of A_vv), solved by GMRES(200) that is preconditioned with the ILU(0) of the assembled B2pp = A_pp - A_pv D^-1 A_vp.
 // Here P_vv^-1 is the node-block Jacobi of A_vv, so T_pp itself has the sparsity of A_pv A_vp (= the pattern of
 // mass_schur) and is assembled once per Newton iteration:  T~[i,j] = A_pp[i,j] - sum_k A_pv[i,k] Binv_k A_vp[k,j].
-// Its inverse is then applied exactly where the pressure space is small (dense LU through rocSOLVER, up to
-// ifem_tuning::tpp_dense_max rows: the 2D benchmark meshes of the reference), and by Jacobi-preconditioned GMRES on one SpMV per
-// iteration beyond.  Only the preconditioner is affected.  Single-rank contexts (the pattern needs a 2-deep halo).
+// The inner GMRES(200) on it is preconditioned by an ILU(0) of T~ -- the reference's choice for B2pp (Euclid ILU(0),
+// preconditioner_pilut.cpp:124-138) -- factorised and applied on the device by level scheduling: rows are grouped into
+// levels of the elimination DAG (natural order, as Euclid's serial sweep) or into the colours of a greedy colouring of the
+// matrix graph (multicolour ILU(0): a few dozen levels whatever the mesh size); one launch per level, one wave per row in
+// the factorisation, 16 lanes per row in the triangular solves.  Only the preconditioner is affected.  Single-rank
+// contexts (the pattern needs a 2-deep halo).
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
+#include <algorithm>
 #include <cstdlib>
+#include <numeric>
 #include "ctx.hpp"
 #include "kernels.hpp"
 
 namespace ifem {
 
-// rocSOLVER is linked at build time: bound at load, its code objects stay deferred until the first factorisation (a
-// dlopen after the HIP runtime is up loads them eagerly, which takes minutes).
-#define IFEM_ROCBLAS_CHECK(expr)                                                                              \
-  do {                                                                                                        \
-    rocblas_status st_ = (expr);                                                                              \
-    if (st_ != rocblas_status_success)                                                                        \
-      throw ::ifem::Error(IFEM_E_HIP, std::string(#expr) + ": rocblas status " + std::to_string(int(st_)));   \
-  } while (0)
+__device__ inline void wsync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // one wave per pressure row i, as k_schur_numeric; the row of A_pp is merged in at the end
 template <int DIM>
@@ -92,13 +92,6 @@ __global__ __launch_bounds__(256) void k_tpp_numeric(int64_t n_rows, int maxlen,
   for (int i = lane; i < len; i += 64) valS[rs + i] = acc[i];
 }
 
-__global__ void k_csr_to_dense(int64_t n, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
-                               const double *__restrict__ val, double *__restrict__ D) {
-  const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (row >= n) return;
-  for (int64_t k = rp[row] + (threadIdx.x & 63); k < rp[row + 1]; k += 64) D[row + int64_t(col[k]) * n] = val[k]; // column-major
-}
-
 void tpp_numeric(ifem_ctx *ctx) {
   if (ctx->tpp_valid) return;
   if (ctx->halo.nranks > 1) throw Error(IFEM_E_BADPARAM, "explicit T_pp: single-rank contexts only");
@@ -119,7 +112,7 @@ void tpp_numeric(ifem_ctx *ctx) {
   if (ctx->tpp_diag.n != (size_t)n) ctx->tpp_diag.alloc((size_t)n);
   scalar_diag(ctx, ctx->Sm, ctx->Tpp.p, ctx->tpp_diag.p);
   ctx->tpp_valid = true;
-  ctx->tpp_dense_valid = false;
+  ctx->tpp_ilu.factored = false;
 }
 
 void spmv_tpp(ifem_ctx *ctx, const double *xp, double *yp) {
@@ -129,46 +122,201 @@ void spmv_tpp(ifem_ctx *ctx, const double *xp, double *yp) {
 }
 
 
-static rocblas_handle handle_of(ifem_ctx *ctx) {
-  if (!ctx->rocblas) {
-    rocblas_handle h;
-    IFEM_ROCBLAS_CHECK(rocblas_create_handle(&h));
-    IFEM_ROCBLAS_CHECK(rocblas_set_stream(h, ctx->stream));
-    ctx->rocblas = h;
+// ---- ILU(0) of T~ on its own pattern ---------------------------------------------------------------------------------
+// Elimination order `ord` (a permutation position per row); "lower" entries of row i are the columns k with ord[k] <
+// ord[i].  Per row the entry positions are listed sorted by the order of their column (ent), n_low of them lower, then
+// the diagonal, then the upper ones: the factorisation walks the lower ones in elimination order, the triangular solves
+// take either side.  Levels: rows of one level have no lower (forward) / upper (backward) entry in the same level.
+struct IluHost {
+  std::vector<int32_t> ent, n_low, diag, rows_f, rows_b;
+  std::vector<int64_t> lvl_f, lvl_b; // level pointers into rows_f / rows_b
+};
+
+static void ilu_analyse(const std::vector<int64_t> &rp, const std::vector<int32_t> &col, int order_kind, IluHost &H) {
+  const int64_t n = (int64_t)rp.size() - 1;
+  std::vector<int32_t> ord((size_t)n);
+  if (order_kind == 1) { // greedy colouring of the (structurally symmetric) matrix graph, rows ordered by (colour, index)
+    std::vector<int32_t> colour((size_t)n, -1), mark;
+    int32_t ncol = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      mark.assign((size_t)ncol + 1, 0);
+      for (int64_t k = rp[i]; k < rp[i + 1]; ++k) { const int32_t c = colour[col[k]]; if (c >= 0 && col[k] != i) mark[c] = 1; }
+      int32_t c = 0;
+      while (c < ncol && mark[c]) ++c;
+      colour[i] = c;
+      if (c == ncol) ++ncol;
+    }
+    std::vector<int32_t> idx((size_t)n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return colour[a] < colour[b]; });
+    for (int64_t p = 0; p < n; ++p) ord[idx[p]] = (int32_t)p;
+  } else
+    std::iota(ord.begin(), ord.end(), 0);
+  H.ent.resize(col.size()); H.n_low.assign((size_t)n, 0); H.diag.assign((size_t)n, -1);
+  std::vector<int32_t> lf((size_t)n, 0), lb((size_t)n, 0), by_ord((size_t)n);
+  for (int64_t i = 0; i < n; ++i) by_ord[ord[i]] = (int32_t)i;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t rs = rp[i];
+    const int len = int(rp[i + 1] - rs);
+    int32_t *e = &H.ent[(size_t)rs];
+    std::iota(e, e + len, 0);
+    std::sort(e, e + len, [&](int32_t a, int32_t b) { return ord[col[rs + a]] < ord[col[rs + b]]; });
+    int nl = 0;
+    for (int t = 0; t < len; ++t) {
+      const int32_t c = col[rs + e[t]];
+      if (c == i) H.diag[i] = e[t];
+      else if (ord[c] < ord[i]) ++nl;
+    }
+    if (H.diag[i] < 0) throw Error(IFEM_E_BADPARAM, "ILU(0) of T_pp: a row has no diagonal entry");
+    H.n_low[i] = nl;
   }
-  return static_cast<rocblas_handle>(ctx->rocblas);
-}
-void tpp_release(ifem_ctx *ctx) {
-  if (ctx->rocblas) rocblas_destroy_handle(static_cast<rocblas_handle>(ctx->rocblas));
-  ctx->rocblas = nullptr;
+  // forward levels in elimination order, backward levels in reverse
+  int32_t nlf = 0, nlb = 0;
+  for (int64_t p = 0; p < n; ++p) {
+    const int32_t i = by_ord[p];
+    int32_t l = 0;
+    for (int t = 0; t < H.n_low[i]; ++t) l = std::max(l, lf[col[rp[i] + H.ent[(size_t)rp[i] + t]]] + 1);
+    lf[i] = l; nlf = std::max(nlf, l + 1);
+  }
+  for (int64_t p = n - 1; p >= 0; --p) {
+    const int32_t i = by_ord[p];
+    const int len = int(rp[i + 1] - rp[i]);
+    int32_t l = 0;
+    for (int t = H.n_low[i] + 1; t < len; ++t) l = std::max(l, lb[col[rp[i] + H.ent[(size_t)rp[i] + t]]] + 1);
+    lb[i] = l; nlb = std::max(nlb, l + 1);
+  }
+  auto bucket = [&](const std::vector<int32_t> &lv, int32_t nl, std::vector<int64_t> &ptr, std::vector<int32_t> &rows) {
+    ptr.assign((size_t)nl + 1, 0);
+    for (int64_t i = 0; i < n; ++i) ++ptr[(size_t)lv[i] + 1];
+    for (int32_t l = 0; l < nl; ++l) ptr[(size_t)l + 1] += ptr[l];
+    rows.resize((size_t)n);
+    std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) rows[(size_t)fill[lv[i]]++] = (int32_t)i;
+  };
+  bucket(lf, nlf, H.lvl_f, H.rows_f);
+  bucket(lb, nlb, H.lvl_b, H.rows_b);
 }
 
-// LU factors of the dense copy of T~ (partial pivoting); false when the pressure space is too large for this path
-bool tpp_dense_setup(ifem_ctx *ctx) {
-  const int64_t n = ctx->Sm.n_rows;
-  if (n == 0 || n > ctx->tune.tpp_dense_max) return false;
-  if (ctx->tpp_dense_valid) return true;
-  rocblas_handle h = handle_of(ctx);
-  if (ctx->tpp_dense.n != size_t(n) * size_t(n)) ctx->tpp_dense.alloc(size_t(n) * size_t(n));
-  if (ctx->tpp_ipiv.n != size_t(n) + 1) ctx->tpp_ipiv.alloc(size_t(n) + 1);
-  IFEM_HIP_CHECK(hipMemsetAsync(ctx->tpp_dense.p, 0, ctx->tpp_dense.n * sizeof(double), ctx->stream));
-  hipLaunchKernelGGL(k_csr_to_dense, dim3(unsigned((n + 3) / 4)), dim3(256), 0, ctx->stream, n, ctx->Sm.rowptr.p, ctx->Sm.col.p,
-                     ctx->Tpp.p, ctx->tpp_dense.p);
-  int *info = ctx->tpp_ipiv.p + n;
-  IFEM_ROCBLAS_CHECK(rocsolver_dgetrf(h, (rocblas_int)n, (rocblas_int)n, ctx->tpp_dense.p, (rocblas_int)n, ctx->tpp_ipiv.p, info));
-  int hinfo = 0;
-  IFEM_HIP_CHECK(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  if (hinfo != 0) throw Error(IFEM_E_KRYLOV_NOCONV, "T_pp is singular (dense LU pivot " + std::to_string(hinfo) + ")");
-  ctx->tpp_dense_valid = true;
-  return true;
+// factorisation of the rows of one level: one wave per row, the row's values in LDS.  For every lower entry (i, k) in
+// elimination order: l_ik = a_ik / u_kk, then a_ij -= l_ik u_kj over the upper entries of row k that exist in row i.
+__global__ __launch_bounds__(256) void k_ilu_factor(int64_t n_rows, const int32_t *__restrict__ rows, int maxlen,
+                                                    const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                    const int32_t *__restrict__ ent, const int32_t *__restrict__ n_low,
+                                                    const int32_t *__restrict__ diag, double *__restrict__ LU) {
+  extern __shared__ __align__(16) unsigned char smem_i[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *w = reinterpret_cast<double *>(smem_i) + size_t(wave) * maxlen;
+  const int64_t r = int64_t(blockIdx.x) * 4 + wave;
+  if (r >= n_rows) return; // whole waves leave: no workgroup barrier below
+  const int32_t i = rows[r];
+  const int64_t rs = rp[i];
+  const int len = int(rp[i + 1] - rs);
+  for (int t = lane; t < len; t += 64) w[t] = LU[rs + t];
+  wsync_lds();
+  const int nl = n_low[i];
+  for (int t = 0; t < nl; ++t) {
+    const int32_t e = ent[rs + t];
+    const int32_t k = col[rs + e];
+    const int64_t ks = rp[k];
+    const int klen = int(rp[k + 1] - ks);
+    const double lik = w[e] / LU[ks + diag[k]];
+    for (int u = n_low[k] + 1 + lane; u < klen; u += 64) { // upper entries of row k (its final values: an earlier level)
+      const int32_t e2 = ent[ks + u];
+      const int32_t j = col[ks + e2];
+      int lo = 0, hi = len - 1, p = -1; // columns of a row are sorted
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int32_t cv = col[rs + mid];
+        if (cv == j) { p = mid; break; }
+        if (cv < j) lo = mid + 1; else hi = mid - 1;
+      }
+      if (p >= 0) w[p] -= lik * LU[ks + e2]; // distinct j, distinct p
+    }
+    wsync_lds();
+    if (lane == 0) w[e] = lik;
+    wsync_lds();
+  }
+  for (int t = lane; t < len; t += 64) LU[rs + t] = w[t];
 }
 
-// y = T~^-1 x
-void tpp_dense_solve(ifem_ctx *ctx, const double *x, double *y) {
-  const int64_t n = ctx->Sm.n_rows;
-  v_copy(ctx, n, x, y);
-  IFEM_ROCBLAS_CHECK(rocsolver_dgetrs(handle_of(ctx), rocblas_operation_none, (rocblas_int)n, 1, ctx->tpp_dense.p, (rocblas_int)n, ctx->tpp_ipiv.p, y, (rocblas_int)n));
+// one level of a triangular solve, 16 lanes per row.  forward: y_i = x_i - sum_lower l_ik y_k (unit diagonal);
+// backward: y_i = (y_i - sum_upper u_ij y_j) / u_ii, in place
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void k_ilu_solve(int64_t n_rows, const int32_t *__restrict__ rows, const int64_t *__restrict__ rp,
+                                                   const int32_t *__restrict__ col, const int32_t *__restrict__ ent,
+                                                   const int32_t *__restrict__ n_low, const int32_t *__restrict__ diag,
+                                                   const double *__restrict__ LU, const double *__restrict__ x, double *__restrict__ y) {
+  const int64_t r = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 4;
+  const int lig = threadIdx.x & 15;
+  const bool active = r < n_rows;
+  const int32_t i = active ? rows[r] : 0;
+  const int64_t rs = rp[i];
+  const int len = int(rp[i + 1] - rs), nl = n_low[i];
+  const int t0 = FORWARD ? 0 : nl + 1, t1 = FORWARD ? nl : len;
+  double s = 0;
+  if (active)
+    for (int t = t0 + lig; t < t1; t += 16) {
+      const int32_t e = ent[rs + t];
+      s += LU[rs + e] * y[col[rs + e]];
+    }
+  for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+  if (active && lig == 0) y[i] = FORWARD ? x[i] - s : (y[i] - s) / LU[rs + diag[i]];
 }
+
+void tpp_ilu_factor(ifem_ctx *ctx) {
+  TppIlu &I = ctx->tpp_ilu;
+  const int64_t n = ctx->Sm.n_rows;
+  if (n == 0 || I.factored) return;
+  hipStream_t s = ctx->stream;
+  const int order_kind = ctx->tune.tpp_ilu_order == 1 ? 1 : 0;
+  if (!I.analysed || I.order_kind != order_kind) { // once per pattern: the elimination DAG on the host
+    std::vector<int64_t> rp((size_t)n + 1);
+    std::vector<int32_t> col((size_t)ctx->Sm.nnzb);
+    IFEM_HIP_CHECK(hipMemcpyAsync(rp.data(), ctx->Sm.rowptr.p, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    IFEM_HIP_CHECK(hipMemcpyAsync(col.data(), ctx->Sm.col.p, col.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    IFEM_HIP_CHECK(hipStreamSynchronize(s));
+    IluHost H;
+    ilu_analyse(rp, col, order_kind, H);
+    I.ent.upload(H.ent.data(), H.ent.size(), s);
+    I.n_low.upload(H.n_low.data(), H.n_low.size(), s);
+    I.diag.upload(H.diag.data(), H.diag.size(), s);
+    I.rows_f.upload(H.rows_f.data(), H.rows_f.size(), s);
+    I.rows_b.upload(H.rows_b.data(), H.rows_b.size(), s);
+    IFEM_HIP_CHECK(hipStreamSynchronize(s));
+    I.lvl_f = H.lvl_f; I.lvl_b = H.lvl_b;
+    I.analysed = true; I.order_kind = order_kind;
+  }
+  if (I.LU.n != ctx->Tpp.n) I.LU.alloc(ctx->Tpp.n);
+  IFEM_HIP_CHECK(hipMemcpyAsync(I.LU.p, ctx->Tpp.p, ctx->Tpp.n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  const int maxlen = (ctx->Sm.max_row + 1) & ~1;
+  const size_t smem = size_t(4) * maxlen * sizeof(double);
+  for (size_t l = 0; l + 1 < I.lvl_f.size(); ++l) {
+    const int64_t first = I.lvl_f[l], cnt = I.lvl_f[l + 1] - first;
+    if (cnt <= 0) continue;
+    hipLaunchKernelGGL(k_ilu_factor, dim3(unsigned((cnt + 3) / 4)), dim3(256), smem, s, cnt, I.rows_f.p + first, maxlen, ctx->Sm.rowptr.p,
+                       ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p);
+  }
+  IFEM_HIP_CHECK(hipGetLastError());
+  I.factored = true;
+}
+
+// y = (LU)^-1 x
+void tpp_ilu_apply(ifem_ctx *ctx, const double *x, double *y) {
+  TppIlu &I = ctx->tpp_ilu;
+  hipStream_t s = ctx->stream;
+  for (size_t l = 0; l + 1 < I.lvl_f.size(); ++l) {
+    const int64_t first = I.lvl_f[l], cnt = I.lvl_f[l + 1] - first;
+    if (cnt > 0)
+      hipLaunchKernelGGL((k_ilu_solve<true>), dim3(unsigned((cnt * 16 + 255) / 256)), dim3(256), 0, s, cnt, I.rows_f.p + first, ctx->Sm.rowptr.p,
+                         ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
+  }
+  for (size_t l = 0; l + 1 < I.lvl_b.size(); ++l) {
+    const int64_t first = I.lvl_b[l], cnt = I.lvl_b[l + 1] - first;
+    if (cnt > 0)
+      hipLaunchKernelGGL((k_ilu_solve<false>), dim3(unsigned((cnt * 16 + 255) / 256)), dim3(256), 0, s, cnt, I.rows_b.p + first, ctx->Sm.rowptr.p,
+                         ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
+  }
+}
+int tpp_ilu_levels(const ifem_ctx *ctx) { return (int)ctx->tpp_ilu.lvl_f.size() - 1; }
 
 } // namespace ifem

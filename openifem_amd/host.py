@@ -61,6 +61,9 @@ def _lib():
     L.ifemx_partition_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     L.ifemx_sm_plan_sizes.argtypes = [C.c_void_p, C.c_void_p]
     L.ifemx_sm_plan_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+    L.ifemx_refine_band.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int64)]
+    L.ifemx_hanging_lines.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    L.ifemx_make_constraints.argtypes = [C.c_void_p, C.c_int]
     L.ifemx_set_multigrid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.ifemx_mg_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
     L.ifemx_coarse_level_chain.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
@@ -183,6 +186,28 @@ class FluidSolver:
         idbuf = None if nccl_unique_id is None else np.ascontiguousarray(nccl_unique_id, np.uint8)
         self._chk(self.L.ifemx_set_partition(self.h, Pa.ctypes.data_as(C.c_void_p), rank,
                                              None if idbuf is None else idbuf.ctypes.data_as(C.c_void_p), local_world))
+
+    def refine_band(self, direction, lo, hi):
+        """cell->set_refine_flag() on the coarse cells whose centre lies in [lo, hi] along `direction`, then
+        execute_coarsening_and_refinement (tests/fsi_leaflet_mpi/fsi_leaflet_mpi.cpp:65-75); before setup().  Returns the
+        number of flagged cells."""
+        n = C.c_int64(0)
+        self._chk(self.L.ifemx_refine_band(self.h, int(direction), float(lo), float(hi), C.byref(n)))
+        return n.value
+
+    def hanging_lines(self):
+        """(dof, ptr, master, weight) of the hanging-node lines the host mirror made for a locally refined mesh"""
+        z = np.zeros(2, np.int64)
+        self._chk(self.L.ifemx_hanging_lines(self.h, z.ctypes.data_as(C.c_void_p), None, None, None, None))
+        dof, ptr = np.zeros(z[0], np.int32), np.zeros(z[0] + 1, np.int32)
+        master, weight = np.zeros(z[1], np.int32), np.zeros(z[1])
+        self._chk(self.L.ifemx_hanging_lines(self.h, None, *[a.ctypes.data_as(C.c_void_p) for a in (dof, ptr, master, weight)]))
+        return dof, ptr, master, weight
+
+    def make_constraints(self, zero_inhomogeneities=False):
+        """FluidSolver::make_constraints again (every step of MPI::FSI::run); zero_inhomogeneities: nonzero_constraints :=
+        zero_constraints, as the FSI driver does after the first step (mpi_fsi.cpp:1193-1198)"""
+        self._chk(self.L.ifemx_make_constraints(self.h, int(zero_inhomogeneities)))
 
     def set_multigrid(self, on=True, min_cells=0, level_worlds=None):
         """FluidSolver::multigrid / mg_min_cells / mg_local_worlds of the C++ host mirror (insim.hpp); call before

@@ -355,6 +355,90 @@ def test_fsi_caller_loop_with_device_produced_inputs(nranks, use_dirichlet_bc):
         assert np.abs(sigma - sigo).max() < 1e-5 * np.abs(sigo).max(), (s, np.abs(sigma - sigo).max(), np.abs(sigo).max())
 
 
+def mirror_loop_device_inputs(n_steps, use_dirichlet_bc):
+    """BASELINE config 5's 2D fluid set-up on the C++ host mirror, line for line with tests/fsi_leaflet_mpi/fsi_leaflet_mpi.cpp:
+    56-78 -- subdivided_hyper_rectangle, the refinement loop over the band [L/4 - 2a, L/4 + 3a], SCnsIM<2>,
+    add_hard_coded_boundary_condition -- and the per-step calls of MPI::FSI::run (mpi_fsi.cpp:1186-1212) on the device.  The
+    mesh, its hanging-node lines and the boundary lines are the mirror's own (csrc/host/grid.cpp), no Python mesh helper."""
+    from openifem_amd import capi, host
+    prm = f"""
+subsection Simulation
+  set Simulation type = FSI
+  set Dimension = 2
+  set Global refinements = 0, 0
+  set End time = 1
+  set Time step size = {KW["dt"]}
+  set Output interval = 1
+  set Refinement interval = 1000
+  set Save interval = 1000
+  set Gravity = 0.0, 0.0
+end
+subsection Fluid finite element system
+  set Pressure degree = 1
+  set Velocity degree = 1
+end
+subsection Fluid material properties
+  set Dynamic viscosity = {KW["mu"]}
+  set Fluid density = {KW["rho"]}
+end
+subsection Fluid solver control
+  set Grad-Div stabilization = 0.1
+  set Max Newton iterations = {NEWTON_MAXIT}
+  set Nonlinear system tolerance = {NEWTON_TOL}
+end
+subsection Fluid Dirichlet BCs
+  set Use hard-coded boundary values = 1
+  set Number of Dirichlet BCs = 3
+  set Dirichlet boundary id = 0, 2, 3
+  set Dirichlet boundary components = 3, 3, 3
+  set Dirichlet boundary values = 0, 0, 0, 0, 0, 0
+end
+subsection Fluid Neumann BCs
+  set Number of Neumann BCs = 0
+end
+subsection Solid material properties
+  set Solid density = {KW["solid_rho"]}
+end
+"""
+    reps = (int(L_ / HC), int(H_ / HC))
+    flow = host.SCnsIM(prm, reps, (0, 0), (L_, H_))
+    assert flow.refine_band(0, L_ / 4 - 2 * A_, L_ / 4 + 3 * A_) > 0           # (fsi_leaflet_mpi.cpp:65-75)
+    flow.add_hard_coded_boundary_condition(0, lambda p, c, t: 6.0 * p[1] * (H_ - p[1]) / H_ ** 2 if c == 0 else 0.0)
+    flow.setup(0)
+    n_cells, n_u, n_p = flow.sizes()
+    assert len(flow.hanging_lines()[0]) > 0
+    ctx = capi.Context.borrow(flow.ctx, 2, 1, n_u // 2, n_p)
+    out = []
+    for step in range(n_steps):
+        s = _meshed_solid(step)
+        ctx.fsi_set_solid(s.vertices, s.cells, s.bfaces, s.velocity, s.acceleration, s.stress)  # update_solid_box (:1189)
+        ind, _ = ctx.fsi_update_indicator(n_cells)                                               # update_indicator (:1190)
+        flow.make_constraints(zero_inhomogeneities=step > 0)                                      # make_constraints (:1191-1198)
+        st = ctx.fsi_find_fluid_bc(KW["dt"], use_dirichlet_bc)                                    # find_fluid_bc (:1203)
+        assert st.n_not_found == 0
+        flow.run_one_step(True)                                                                   # run_one_step(true) (:1208)
+        v, p = flow.get_current_solution()
+        out.append((np.concatenate([v, p]), ind))
+    flow.close()
+    return out
+
+
+@pytest.mark.parametrize("use_dirichlet_bc", [True, False])
+def test_fsi_caller_loop_on_the_host_mirror_with_its_own_locally_refined_mesh(use_dirichlet_bc):
+    m = _mesh()  # the oracle's side keeps the independent builder; tests/test_host_layer.py shows the two meshes are equal
+    n_steps = 3
+    ref = oracle_loop(m, n_steps, use_dirichlet_bc, fsi_inputs=fsi_inputs_meshed)
+    got = mirror_loop_device_inputs(n_steps, use_dirichlet_bc)
+    n_u = m.n_u
+    assert any((got[k][1] != got[k + 1][1]).any() for k in range(n_steps - 1)), "the indicator never moved"
+    for s in range(n_steps):
+        xr, _ = ref[s]
+        xg, _ = got[s]
+        ev = np.abs(xg[:n_u] - xr[:n_u]).max() / np.abs(xr[:n_u]).max()
+        ep = np.abs(xg[n_u:] - xr[n_u:]).max() / max(np.abs(xr[n_u:]).max(), 1e-300)
+        assert ev < 1e-6 and ep < 1e-6, (s, ev, ep)
+
+
 def test_fsi_loop_3d_insimex_with_device_produced_inputs():
     """the 3D coupling of the reference runs InsIMEX<3> under MPI::FSI with the penalty form (tests/fsi_leaflet_mpi/
     fsi_leaflet_mpi.cpp:105, use_dirichlet_bc = false): per step update_solid_box / update_indicator / make_constraints /

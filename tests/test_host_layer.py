@@ -308,3 +308,43 @@ def test_cpp_transfer_tables_equal_the_numpy_restatement(dim, reps_f, reps_c, P,
     co = tc["l2g_u"][:tc["n_unodes_owned"]]
     fo = tf["l2g_u"][:tf["n_unodes_owned"]]
     assert (host.box_injection(reps_f, reps_c, 2, co, fo) == capi.box_injection(reps_f, reps_c, 2, co, fo)).all()
+
+
+# ---- one level of local refinement in the C++ host mirror against the tests' independent builder (tests/hangmesh.py)
+@pytest.mark.parametrize("dim,kv,reps,band", [(2, 1, (32, 8), (0.5, 1.75)), (2, 2, (8, 4), (1.0, 2.0)), (3, 2, (4, 3, 2), (0.9, 2.1)),
+                                              (3, 1, (5, 3, 3), (0.0, 0.9))])
+def test_local_refinement_tables_and_hanging_lines_equal_the_independent_builder(dim, kv, reps, band):
+    """set_refine_flag on a band of coarse cells + execute_coarsening_and_refinement (tests/fsi_leaflet_mpi/
+    fsi_leaflet_mpi.cpp:65-75), then setup_dofs / make_constraints: cell tables, node coordinates, the hanging-node lines
+    (DoFTools::make_hanging_node_constraints) and the boundary lines, which skip hanging dofs"""
+    from hangmesh import HangingMesh
+    from openifem_amd import host
+    p0, p1 = (0.0,) * dim, (4.0, 1.0, 0.75)[:dim]
+    prm = host.channel_prm(dim).replace("set Velocity degree = 2", f"set Velocity degree = {kv}")
+    if kv == 1:
+        prm = prm.replace("set Pressure degree = 1", "set Pressure degree = 1")
+    cls = host.InsIM if kv == 2 else host.SCnsIM
+    s = cls(prm, reps, p0, p1)
+    hx = (p1[0] - p0[0]) / reps[0]
+    n_flag = s.refine_band(0, *band)
+    cols = [i for i in range(reps[0]) if band[0] <= p0[0] + (i + 0.5) * hx <= band[1]]
+    assert n_flag == len(cols) * int(np.prod(reps[1:])) and 0 < len(cols) < reps[0]
+    s.setup_host_only(0)
+    import itertools
+    refine = {(i,) + rest for i in cols for rest in itertools.product(*[range(r) for r in reps[1:]])}
+    m = HangingMesh(reps, p0, p1, refine, kv=kv)
+    cu, cp, fb, vc = s.cell_tables(kv=kv)
+    assert cu.shape == m.cell_unodes.shape and (cu == m.cell_unodes).all() and (cp == m.cell_pnodes).all()
+    assert (fb == m.cell_face_bid).all() and np.abs(vc - m.vcoords).max() < 1e-14
+    uc, pc = s.node_coords()
+    assert np.abs(uc - m.unode_coords).max() < 1e-14 and np.abs(pc - m.pnode_coords).max() < 1e-14
+    dof, ptr, master, weight = s.hanging_lines()
+    assert len(dof) > 0
+    assert (dof == m.hang_dof).all() and (ptr == m.hang_ptr).all() and (master == m.hang_master).all()
+    assert np.abs(weight - m.hang_weight).max() < 1e-14
+    # boundary lines: the reference's Dirichlet ids / flags of the .prm, hanging dofs keep their hanging line
+    flags = {2: (3, [0, 0]), 3: (3, [0, 0])} if dim == 2 else {2: (7, [0, 0, 0]), 3: (7, [0, 0, 0]), 4: (4, [0]), 5: (4, [0])}
+    wd, wv = m.dirichlet(flags)
+    gd, gv = s.constraints()
+    assert sorted(gd.tolist()) == sorted(wd.tolist()) and not set(gd.tolist()) & set(dof.tolist())
+    s.close()
