@@ -56,19 +56,22 @@ struct Cell3 : std::conditional<OTF, Cell3Otf, Cell3Tabs>::type {
 struct Shared3 {
   Tab1D t;
   double psi[27 * 8];
-  // OTF layout: 2D tensor factors over (q0 q1) x (a0 a1): N2 = Nx Ny, DX2 = Nx' Ny, DY2 = Nx Ny'
+};
+// OTF layout: + the 2D tensor factors over (q0 q1) x (a0 a1): N2 = Nx Ny, DX2 = Nx' Ny, DY2 = Nx Ny'.  (A separate type: the
+// TABLES layout fills 80 of a CU's 160 KB with two workgroups, 2 KB more would leave room for one.)
+struct Shared3Otf : Shared3 {
   double N2[81], DX2[81], DY2[81];
 };
 
 // N_a(q) and the physical gradient of N_a at q from the tensor factors and the inverse Jacobian of the point: the same
 // products and sums, in the same order, as the table build of the TABLES layout
-__device__ __forceinline__ void shape_ref(const Shared3 &T, int q, int a, double &N, double r[3]) {
+__device__ __forceinline__ void shape_ref(const Shared3Otf &T, int q, int a, double &N, double r[3]) {
   const int i2 = (q % 9) * 9 + (a % 9), i1 = (q / 9) * 3 + a / 9;
   const double n2 = T.N2[i2], dx2 = T.DX2[i2], dy2 = T.DY2[i2], nz = T.t.N[i1], dz = T.t.dN[i1];
   N = n2 * nz;
   r[0] = dx2 * nz; r[1] = dy2 * nz; r[2] = n2 * dz;
 }
-__device__ __forceinline__ void shape_otf(const Shared3 &T, const double *__restrict__ Jq, int q, int a, double &N, double g[3]) {
+__device__ __forceinline__ void shape_otf(const Shared3Otf &T, const double *__restrict__ Jq, int q, int a, double &N, double g[3]) {
   double r[3];
   shape_ref(T, q, a, N, r);
 #pragma unroll
@@ -86,10 +89,11 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
   constexpr int DIM = 3, N1 = 3, NU = 27, NP = 8, NQ = 27, ND = 89, BS = 9;
   constexpr int NBP = NU * NP, BROUNDS = (NBP + 63) / 64, FR = (ND + 63) / 64;
   extern __shared__ __align__(16) unsigned char smem[];
-  Shared3 &T = *reinterpret_cast<Shared3 *>(smem);
+  using Shared = typename std::conditional<OTF, Shared3Otf, Shared3>::type;
+  Shared &T = *reinterpret_cast<Shared *>(smem);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = wave >> 1, h = wave & 1;
   using Cell = Cell3<OTF>;
-  Cell &S = *reinterpret_cast<Cell *>(smem + ((sizeof(Shared3) + 15) & ~size_t(15)) + size_t(slot) * ((sizeof(Cell) + 15) & ~size_t(15)));
+  Cell &S = *reinterpret_cast<Cell *>(smem + ((sizeof(Shared) + 15) & ~size_t(15)) + size_t(slot) * ((sizeof(Cell) + 15) & ~size_t(15)));
   double *Ji_, *part1;
   if constexpr (OTF) { Ji_ = S.Ji; part1 = S.part1; }
   else { Ji_ = S.dead; part1 = &S.tabG[0][0][0]; } // the tables are not built yet when the partial sums are parked there
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
 // 3D Q2/Q1 only; the block-interleaved A_uu layout is assumed by the staged scatter
 template <bool OTF, int WAVES, int CPB> // CPB cells per workgroup (two waves each)
 static void launch3(ifem_ctx *ctx, const AsmArgs &A) {
-  const size_t smem = ((sizeof(Shared3) + 15) & ~size_t(15)) + CPB * ((sizeof(Cell3<OTF>) + 15) & ~size_t(15));
+  const size_t smem = ((sizeof(typename std::conditional<OTF, Shared3Otf, Shared3>::type) + 15) & ~size_t(15)) + CPB * ((sizeof(Cell3<OTF>) + 15) & ~size_t(15));
   // the dynamic-LDS limit is an attribute of the function ON A DEVICE: remembered per device, not per process
   static std::mutex mu;
   static std::set<int> done;

@@ -96,7 +96,7 @@ void v_copy(ifem_ctx *ctx, int64_t n, const double *x, double *y);
 void v_zero(ifem_ctx *ctx, int64_t n, double *x);
 double v_dot(ifem_ctx *ctx, int64_t n, const double *x, const double *y); // local (no all-reduce), syncs
 // multi-dot: out[i] = <V_i, w> for i < k (V column-major with leading dimension ld), one pass, syncs
-void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *w, double *out_host);
+void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *w, double *out_host, bool all_ranks = false);
 // w -= sum_i h[i] V_i
 void v_maxpy(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *h_host, double *w);
 // single-precision Krylov basis (inner solver): V float, w / coefficients / accumulation double

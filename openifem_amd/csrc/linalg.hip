@@ -886,15 +886,26 @@ __global__ __launch_bounds__(256) void k_maxpy(int64_t n, int k0, const double *
   }
 }
 
-// out_host[i] = <V_i, w>, i < k.  Device scalars live in ctx->scal[0..63]; result is NOT all-reduced.
-void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *w, double *out_host) {
+// out_host[i] = <V_i, w>, i < k.  Device scalars live in ctx->scal[0..63].  all_ranks = false: the local sums; true: summed
+// over the ranks ON THE STREAM (comm.hip::allreduce_sum_dev on the device scalars) before the one copy to the host -- the
+// Gram-Schmidt coefficients of FGMRES / the inner GMRES cross PCIe once per pass and wait for the device once.
+void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *w, double *out_host, bool all_ranks) {
   if (k > 64) { // the staging buffers hold 64 dot products: long bases (GMRES(200)) go in chunks
-    for (int k0 = 0; k0 < k; k0 += 64) v_mdot(ctx, n, std::min(64, k - k0), V + int64_t(k0) * ld, ld, w, out_host + k0);
+    for (int k0 = 0; k0 < k; k0 += 64) v_mdot(ctx, n, std::min(64, k - k0), V + int64_t(k0) * ld, ld, w, out_host + k0, all_ranks);
     return;
   }
   hipStream_t s = ctx->stream;
+  all_ranks = all_ranks && ctx->halo.nranks > 1;
   if (ctx->partials.n == 0) ctx->partials.alloc(size_t(64) * MDOT_MAXB);
-  if (n == 0) { for (int i = 0; i < k; ++i) out_host[i] = 0; return; }
+  if (n == 0 && !all_ranks) { for (int i = 0; i < k; ++i) out_host[i] = 0; return; }
+  if (n == 0) { // a rank without entries still takes part in the sum
+    IFEM_HIP_CHECK(hipMemsetAsync(ctx->scal.p, 0, k * sizeof(double), s));
+    allreduce_sum_dev(ctx, ctx->scal.p, k);
+    IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->scal.p, k * sizeof(double), hipMemcpyDeviceToHost, s));
+    IFEM_HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < k; ++i) out_host[i] = ctx->h_scal[i];
+    return;
+  }
   const unsigned nblk = vgrid(n);
   int k0 = 0;
   while (k0 < k && n > 0) {
@@ -905,6 +916,7 @@ void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const 
     else { hipLaunchKernelGGL((k_mdot<1>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, w, ctx->partials.p); k0 += 1; }
   }
   hipLaunchKernelGGL(k_reduce_final, dim3(k), dim3(256), 0, s, (int)nblk, ctx->partials.p, ctx->scal.p);
+  if (all_ranks) allreduce_sum_dev(ctx, ctx->scal.p, k);
   IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->scal.p, k * sizeof(double), hipMemcpyDeviceToHost, s));
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
   for (int i = 0; i < k; ++i) out_host[i] = ctx->h_scal[i];

@@ -758,8 +758,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   // stopping rule on the true residual, fewer iterations (the reference uses PreconditionNone; counts are no parity target)
   const bool pjac = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF || o->ainv_kind == IFEM_AINV_MG;
   auto pmdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
-    v_mdot(c, S.npo, k, V, ld, w, out);
-    allreduce_sum(c, out, k);
+    v_mdot(c, S.npo, k, V, ld, w, out, /*all_ranks=*/true);
   };
   const int pmax = (int)std::min<int64_t>(std::max<int64_t>(c->n_global_p, 1), 1 << 30);
   // device-resident recurrences on any number of ranks: the dot products are all-reduced on the stream (comm.hip::allreduce_sum_dev)
@@ -823,8 +822,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   if (scalar_op) Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_shat(c, xe, y, true); };
   OpFn Pj = [&](const double *x, double *y) { if (scalar_op) shat_jacobi(c, x, y); else bjac_apply(c, x, y); };
   auto mdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
-    v_mdot(c, S.nuo, k, V, ld, w, out);
-    allreduce_sum(c, out, k);
+    v_mdot(c, S.nuo, k, V, ld, w, out, /*all_ranks=*/true);
   };
   double un;
   mdot(1, S.utmp, S.nuo, S.utmp, &un);
@@ -997,12 +995,10 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
   grow_inner_basis(ctx, (int64_t)(mt + 1) * basis_ld(S.ctx, S.npo));
   double *rhs = ctx->vec[IFEM_VEC_RHS].p, *upd = ctx->vec[IFEM_VEC_UPDATE].p;
   auto mdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
-    v_mdot(ctx, S.n, k, V, ld, w, out);
-    allreduce_sum(ctx, out, k);
+    v_mdot(ctx, S.n, k, V, ld, w, out, /*all_ranks=*/true);
   };
   auto mdot_p = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
-    v_mdot(ctx, S.npo, k, V, ld, w, out);
-    allreduce_sum(ctx, out, k);
+    v_mdot(ctx, S.npo, k, V, ld, w, out, /*all_ranks=*/true);
   };
   double bn;
   mdot(1, rhs, S.n, rhs, &bn);
@@ -1081,8 +1077,7 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   ctx->timing.mf_calls = 0;
   double *rhs = ctx->vec[IFEM_VEC_RHS].p, *upd = ctx->vec[IFEM_VEC_UPDATE].p;
   auto mdot = [&](int k, const double *V, int64_t ld, const double *w, double *out) {
-    v_mdot(ctx, S.n, k, V, ld, w, out);
-    allreduce_sum(ctx, out, k);
+    v_mdot(ctx, S.n, k, V, ld, w, out, /*all_ranks=*/true);
   };
   double bn;
   mdot(1, rhs, S.n, rhs, &bn);
