@@ -168,7 +168,8 @@ typedef struct {
   int32_t asm3_waves;    /* 3: waves per SIMD the no-tables variant of that kernel is compiled for (2: 256 registers per lane, 3: 168,
                             4: 128 with spills around the scatter) */
   int32_t asm3_cpb;      /* 2: cells per workgroup of the no-tables variant at 3 waves per SIMD (1, 2 or 4; two waves per cell) */
-  int32_t reserved_;
+  int32_t tpp_milu_permille; /* SCnsIM, ILU(0) of T_pp: 950 (default); 0 plain ILU(0); w in (0, 1000]: relaxed modified ILU, w/1000 of every dropped
+                                fill-in entry is added to the diagonal of its row */
   int64_t tpp_ilu_order; /* SCnsIM, explicit T_pp: preconditioner of its inner GMRES -- 0 (default) ILU(0) in the natural row order,
                             level-scheduled; 1 multicolour ILU(0) (a few dozen levels whatever the mesh); -1 Jacobi(T_pp) */
   int64_t basis_pad;     /* 32*33 doubles of padding between Krylov basis columns (HBM channel spread) */
@@ -216,7 +217,8 @@ typedef struct {
   int32_t rccl_nranks;   /* ncclCommCount */
   int32_t halo_stream;   /* 1: overlapped exchanges on the second communicator + priority stream */
   int32_t levels;        /* contexts summed over (1 + attached multigrid levels) */
-  int32_t reserved_;
+  int32_t tpp_milu_permille; /* SCnsIM, ILU(0) of T_pp: 950 (default); 0 plain ILU(0); w in (0, 1000]: relaxed modified ILU, w/1000 of every dropped
+                                fill-in entry is added to the diagonal of its row */
   uint64_t halo_exchanges; /* packed send/recv groups (forward and reverse) */
   uint64_t allreduce_dev;  /* all-reduces of device scalars ordered on the stream (no host wait) */
   uint64_t allreduce_host; /* all-reduces the host waited for (Gram-Schmidt coefficients, norms) */

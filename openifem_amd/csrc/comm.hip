@@ -16,6 +16,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <atomic>
+#include <thread>
 #include "ctx.hpp"
 #include "kernels.hpp"
 
@@ -36,12 +38,34 @@ struct LocalWorld {
   long generation = 0;
   std::vector<ifem_ctx *> ctx;           // published contexts
   std::vector<std::vector<double>> red;  // all-reduce staging
-  explicit LocalWorld(int n) : nranks(n), ctx(n, nullptr), red(n) {}
+  // stream-ordered exchanges: rank r records ev_packed[r] behind its packing kernel and ev_copied[r] behind its copies out of
+  // the peers' send buffers; the peers' streams wait on those events, no host thread waits for the device
+  std::vector<hipEvent_t> ev_packed, ev_copied;
+  std::vector<const double *> red_ptr; // device scalars of every rank during a stream-ordered all-reduce
+  explicit LocalWorld(int n) : nranks(n), ctx(n, nullptr), red(n), ev_packed(n, nullptr), ev_copied(n, nullptr), red_ptr(n, nullptr) {}
+  ~LocalWorld() {
+    for (auto e : ev_packed) if (e) (void)hipEventDestroy(e);
+    for (auto e : ev_copied) if (e) (void)hipEventDestroy(e);
+  }
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
     const long gen = generation;
     if (++waiting == nranks) { waiting = 0; ++generation; cv.notify_all(); }
     else cv.wait(lk, [&] { return generation != gen; });
+  }
+  // host-only rendezvous of the exchanges (no device synchronisation around it): spin briefly, then yield
+  std::atomic<long> spin_count{0};
+  std::atomic<long> spin_gen{0};
+  void rendezvous() {
+    const long gen = spin_gen.load(std::memory_order_acquire);
+    if (spin_count.fetch_add(1, std::memory_order_acq_rel) + 1 == nranks) {
+      spin_count.store(0, std::memory_order_relaxed);
+      spin_gen.store(gen + 1, std::memory_order_release);
+    } else {
+      int spins = 0;
+      while (spin_gen.load(std::memory_order_acquire) == gen)
+        if (++spins > 2000) std::this_thread::yield();
+    }
   }
 };
 
@@ -85,6 +109,10 @@ void comm_init(ifem_ctx *ctx, const ifem_partition *part) {
     if (w->nranks != h.nranks) throw Error(IFEM_E_BADPARAM, "local world size mismatch");
     h.local = w;
     w->ctx[h.rank] = ctx;
+    if (!w->ev_packed[h.rank]) {
+      IFEM_HIP_CHECK(hipEventCreateWithFlags(&w->ev_packed[h.rank], hipEventDisableTiming));
+      IFEM_HIP_CHECK(hipEventCreateWithFlags(&w->ev_copied[h.rank], hipEventDisableTiming));
+    }
     w->barrier();
   } else {
     if (!part->nccl_unique_id) throw Error(IFEM_E_BADPARAM, "ifem_partition needs nccl_unique_id or local_world");
@@ -180,9 +208,11 @@ static void exchange(ifem_ctx *ctx, double *x, int which, bool async = false) {
     hipLaunchKernelGGL(k_pack, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, ctx->stream, ns, bs, sidx.p, x, sendbuf);
   }
   if (h.local) {
+    // stream-ordered like the RCCL path: my copies wait (on the device) for the peers' packing kernels, the peers' next
+    // packing kernels wait for my copies; the host threads only meet to know that the events have been recorded
     auto *w = static_cast<LocalWorld *>(h.local);
-    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // my send buffer is complete
-    w->barrier();
+    IFEM_HIP_CHECK(hipEventRecord(w->ev_packed[h.rank], ctx->stream)); // my send buffer is complete at this point of my stream
+    w->rendezvous();
     for (int k = 0; k < nn; ++k) {
       const int64_t rc = int64_t(rptr[k + 1] - rptr[k]) * bs;
       if (!rc) continue;
@@ -193,11 +223,14 @@ static void exchange(ifem_ctx *ctx, double *x, int which, bool async = false) {
       if (me < 0) throw Error(IFEM_E_COMM, "local world: neighbour lists are not symmetric");
       const std::vector<int32_t> &psptr = which == 0 ? ph.send_u_ptr : (which == 1 ? ph.send_p_ptr : ph.send_s_ptr);
       if (int64_t(psptr[me + 1] - psptr[me]) * bs != rc) throw Error(IFEM_E_COMM, "local world: send/recv count mismatch");
+      IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_packed[h.nbr[k]], 0));
       IFEM_HIP_CHECK(hipMemcpyAsync(x + (n_owned + rptr[k]) * bs, sendbuf_of(peer) + int64_t(psptr[me]) * bs,
                                     rc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     }
-    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    w->barrier(); // peers may now overwrite their send buffers
+    IFEM_HIP_CHECK(hipEventRecord(w->ev_copied[h.rank], ctx->stream));
+    w->rendezvous();
+    // whatever I launch next (the next packing kernel first of all) must not overwrite what a peer is still reading
+    for (int k = 0; k < nn; ++k) IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_copied[h.nbr[k]], 0));
     return;
   }
   async = async && h.comm2 && h.hstream;
@@ -359,6 +392,16 @@ static void allreduce(ifem_ctx *ctx, double *host_vals, int n, bool is_max) {
 
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, host_vals, n, false); }
 
+constexpr int kMaxLocalPeers = 8;
+struct PeerPtrs { const double *p[kMaxLocalPeers]; };
+__global__ void k_sum_peers(int n, int nranks, PeerPtrs pp, double *__restrict__ out) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  double s = 0;
+  for (int r = 0; r < nranks; ++r) s += pp.p[r][i];
+  out[i] = s;
+}
+
 // Sum of n DEVICE-resident scalars over the ranks, in place, ordered on the context stream and without a host round trip
 // (RCCL): what the device-resident CG recurrences use between their partial reductions and the scalar update.  The
 // validation transport has no device-side collective: it synchronises and goes through the host path.
@@ -367,13 +410,34 @@ void allreduce_sum_dev(ifem_ctx *ctx, double *dev_vals, int n) {
   if (h.nranks == 1 || n <= 0) return;
   ++h.n_allreduce_dev;
   if (h.local) {
-    --h.n_allreduce_host; // the validation transport goes through the host path below: count it once, as a device one
-    std::vector<double> tmp(n);
-    IFEM_HIP_CHECK(hipMemcpyAsync(tmp.data(), dev_vals, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    allreduce(ctx, tmp.data(), n, false);
-    IFEM_HIP_CHECK(hipMemcpyAsync(dev_vals, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // tmp leaves scope
+    auto *w = static_cast<LocalWorld *>(h.local);
+    if (h.nranks > kMaxLocalPeers || n > 64) { // beyond the fixed-size argument block: through the host
+      std::vector<double> tmp(n);
+      IFEM_HIP_CHECK(hipMemcpyAsync(tmp.data(), dev_vals, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      allreduce(ctx, tmp.data(), n, false);
+      --h.n_allreduce_host; // counted as a device one above
+      IFEM_HIP_CHECK(hipMemcpyAsync(dev_vals, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // tmp leaves scope
+      return;
+    }
+    // stream-ordered, like ncclAllReduce on the device scalars: every rank sums the peers' values (in rank order: the same
+    // result everywhere) into a staging slot once their producers have run, and takes it over once everybody has read
+    w->red_ptr[h.rank] = dev_vals;
+    IFEM_HIP_CHECK(hipEventRecord(w->ev_packed[h.rank], ctx->stream));
+    w->rendezvous();
+    PeerPtrs pp{};
+    for (int r = 0; r < h.nranks; ++r) {
+      pp.p[r] = w->red_ptr[r];
+      if (r != h.rank) IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_packed[r], 0));
+    }
+    double *stage = ctx->scal.p + kScalStageOff + kScalStage - 64; // the tail of the staging slots (n <= 64)
+    hipLaunchKernelGGL(k_sum_peers, dim3(1), dim3(64), 0, ctx->stream, n, h.nranks, pp, stage);
+    IFEM_HIP_CHECK(hipEventRecord(w->ev_copied[h.rank], ctx->stream));
+    w->rendezvous();
+    for (int r = 0; r < h.nranks; ++r)
+      if (r != h.rank) IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_copied[r], 0));
+    IFEM_HIP_CHECK(hipMemcpyAsync(dev_vals, stage, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return;
   }
   IFEM_NCCL_CHECK(ncclAllReduce(dev_vals, dev_vals, n, ncclDouble, ncclSum, (ncclComm_t)h.comm, ctx->stream));

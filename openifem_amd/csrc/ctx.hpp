@@ -1,5 +1,6 @@
 // ctx.hpp -- device-side state of one ifem_ctx (one per GPU / process).
 #pragma once
+#include <array>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -162,7 +163,9 @@ namespace ifem {
 // ILU(0) of the explicit T_pp on its own pattern (tpp.hip): analysis once per pattern, numeric factors per Newton iteration
 struct TppIlu {
   DBuf<int32_t> ent, n_low, diag, rows_f, rows_b;
-  std::vector<int64_t> lvl_f, lvl_b; // level pointers into rows_f / rows_b (host: one launch per level)
+  std::vector<int64_t> lvl_f, lvl_b; // level pointers into rows_f / rows_b (host: the launch plan)
+  DBuf<int64_t> d_lvl_f, d_lvl_b;    // the same on the device (batched runs of small levels)
+  std::vector<std::array<int32_t, 2>> plan_f, plan_b; // {level, -1}: one wide level; {l0, l1}: a run of small levels in one launch
   DBuf<double> LU;
   bool analysed = false, factored = false;
   int order_kind = 0;

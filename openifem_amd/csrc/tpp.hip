@@ -11,6 +11,7 @@
 // contexts (the pattern needs a 2-deep halo).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <numeric>
 #include "ctx.hpp"
@@ -202,7 +203,7 @@ static void ilu_analyse(const std::vector<int64_t> &rp, const std::vector<int32_
 __global__ __launch_bounds__(256) void k_ilu_factor(int64_t n_rows, const int32_t *__restrict__ rows, int maxlen,
                                                     const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
                                                     const int32_t *__restrict__ ent, const int32_t *__restrict__ n_low,
-                                                    const int32_t *__restrict__ diag, double *__restrict__ LU) {
+                                                    const int32_t *__restrict__ diag, double *__restrict__ LU, double omega) {
   extern __shared__ __align__(16) unsigned char smem_i[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *w = reinterpret_cast<double *>(smem_i) + size_t(wave) * maxlen;
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void k_ilu_factor(int64_t n_rows, const int32_
   for (int t = lane; t < len; t += 64) w[t] = LU[rs + t];
   wsync_lds();
   const int nl = n_low[i];
+  const int di = diag[i];
   for (int t = 0; t < nl; ++t) {
     const int32_t e = ent[rs + t];
     const int32_t k = col[rs + e];
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(256) void k_ilu_factor(int64_t n_rows, const int32_
         if (cv < j) lo = mid + 1; else hi = mid - 1;
       }
       if (p >= 0) w[p] -= lik * LU[ks + e2]; // distinct j, distinct p
+      else if (omega != 0.0) unsafeAtomicAdd(&w[di], -omega * lik * LU[ks + e2]); // relaxed MILU: dropped fill goes to the diagonal
     }
     wsync_lds();
     if (lane == 0) w[e] = lik;
@@ -263,6 +266,57 @@ __global__ __launch_bounds__(256) void k_ilu_solve(int64_t n_rows, const int32_t
   if (active && lig == 0) y[i] = FORWARD ? x[i] - s : (y[i] - s) / LU[rs + diag[i]];
 }
 
+// a run of consecutive SMALL levels in one launch: one workgroup of 64 row groups walks the levels with a workgroup barrier in
+// between (natural-order ILU(0) of a 2D stencil has hundreds of levels of a few dozen rows: one launch per level is
+// launch-bound).  y is read and written with agent-scope accesses: the rows of the previous level were written by other
+// waves of this workgroup.
+template <bool FORWARD>
+__global__ __launch_bounds__(1024) void k_ilu_solve_batch(int l0, int l1, const int64_t *__restrict__ lvl, const int32_t *__restrict__ rows,
+                                                          const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                          const int32_t *__restrict__ ent, const int32_t *__restrict__ n_low,
+                                                          const int32_t *__restrict__ diag, const double *__restrict__ LU,
+                                                          const double *__restrict__ x, double *y) {
+  const int lig = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  for (int l = l0; l < l1; ++l) {
+    const int64_t first = lvl[l], cnt = lvl[l + 1] - first;
+    for (int64_t r = grp; r < cnt; r += 64) {
+      const int32_t i = rows[first + r];
+      const int64_t rs = rp[i];
+      const int len = int(rp[i + 1] - rs), nl = n_low[i];
+      const int t0 = FORWARD ? 0 : nl + 1, t1 = FORWARD ? nl : len;
+      double s = 0;
+      for (int t = t0 + lig; t < t1; t += 16) {
+        const int32_t e = ent[rs + t];
+        s += LU[rs + e] * __hip_atomic_load(&y[col[rs + e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+      if (lig == 0) {
+        const double v = FORWARD ? x[i] - s : (__hip_atomic_load(&y[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - s) / LU[rs + diag[i]];
+        __hip_atomic_store(&y[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // the stores above are agent-scope (write-through to L2), the loads of the next level agent-scope too (past the L1):
+    // the workgroup barrier with its release / acquire orders them
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+  }
+}
+
+// launch plan of one triangular sweep: runs of consecutive levels with at most kBatchRows rows each go to the batch kernel
+static constexpr int64_t kBatchRows = 256;
+static void plan_sweep(const std::vector<int64_t> &lvl, std::vector<std::array<int32_t, 2>> &plan) {
+  plan.clear();
+  const int nl = (int)lvl.size() - 1;
+  int l = 0;
+  while (l < nl) {
+    if (lvl[l + 1] - lvl[l] > kBatchRows) { plan.push_back({l, -1}); ++l; continue; } // a wide level: its own multi-workgroup launch
+    int e = l;
+    while (e < nl && lvl[e + 1] - lvl[e] <= kBatchRows) ++e;
+    plan.push_back({l, e});
+    l = e;
+  }
+}
+
 void tpp_ilu_factor(ifem_ctx *ctx) {
   TppIlu &I = ctx->tpp_ilu;
   const int64_t n = ctx->Sm.n_rows;
@@ -282,19 +336,24 @@ void tpp_ilu_factor(ifem_ctx *ctx) {
     I.diag.upload(H.diag.data(), H.diag.size(), s);
     I.rows_f.upload(H.rows_f.data(), H.rows_f.size(), s);
     I.rows_b.upload(H.rows_b.data(), H.rows_b.size(), s);
+    I.d_lvl_f.upload(H.lvl_f.data(), H.lvl_f.size(), s);
+    I.d_lvl_b.upload(H.lvl_b.data(), H.lvl_b.size(), s);
     IFEM_HIP_CHECK(hipStreamSynchronize(s));
     I.lvl_f = H.lvl_f; I.lvl_b = H.lvl_b;
+    plan_sweep(I.lvl_f, I.plan_f);
+    plan_sweep(I.lvl_b, I.plan_b);
     I.analysed = true; I.order_kind = order_kind;
   }
   if (I.LU.n != ctx->Tpp.n) I.LU.alloc(ctx->Tpp.n);
   IFEM_HIP_CHECK(hipMemcpyAsync(I.LU.p, ctx->Tpp.p, ctx->Tpp.n * sizeof(double), hipMemcpyDeviceToDevice, s));
   const int maxlen = (ctx->Sm.max_row + 1) & ~1;
   const size_t smem = size_t(4) * maxlen * sizeof(double);
+  const double omega = 1e-3 * std::min(std::max(ctx->tune.tpp_milu_permille, 0), 1000);
   for (size_t l = 0; l + 1 < I.lvl_f.size(); ++l) {
     const int64_t first = I.lvl_f[l], cnt = I.lvl_f[l + 1] - first;
     if (cnt <= 0) continue;
     hipLaunchKernelGGL(k_ilu_factor, dim3(unsigned((cnt + 3) / 4)), dim3(256), smem, s, cnt, I.rows_f.p + first, maxlen, ctx->Sm.rowptr.p,
-                       ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p);
+                       ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, omega);
   }
   IFEM_HIP_CHECK(hipGetLastError());
   I.factored = true;
@@ -304,18 +363,30 @@ void tpp_ilu_factor(ifem_ctx *ctx) {
 void tpp_ilu_apply(ifem_ctx *ctx, const double *x, double *y) {
   TppIlu &I = ctx->tpp_ilu;
   hipStream_t s = ctx->stream;
-  for (size_t l = 0; l + 1 < I.lvl_f.size(); ++l) {
-    const int64_t first = I.lvl_f[l], cnt = I.lvl_f[l + 1] - first;
-    if (cnt > 0)
-      hipLaunchKernelGGL((k_ilu_solve<true>), dim3(unsigned((cnt * 16 + 255) / 256)), dim3(256), 0, s, cnt, I.rows_f.p + first, ctx->Sm.rowptr.p,
-                         ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
-  }
-  for (size_t l = 0; l + 1 < I.lvl_b.size(); ++l) {
-    const int64_t first = I.lvl_b[l], cnt = I.lvl_b[l + 1] - first;
-    if (cnt > 0)
-      hipLaunchKernelGGL((k_ilu_solve<false>), dim3(unsigned((cnt * 16 + 255) / 256)), dim3(256), 0, s, cnt, I.rows_b.p + first, ctx->Sm.rowptr.p,
-                         ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
-  }
+  auto sweep = [&](bool forward) {
+    const auto &plan = forward ? I.plan_f : I.plan_b;
+    const auto &lvl = forward ? I.lvl_f : I.lvl_b;
+    const int64_t *d_lvl = forward ? I.d_lvl_f.p : I.d_lvl_b.p;
+    const int32_t *rows = forward ? I.rows_f.p : I.rows_b.p;
+    for (const auto &st : plan) {
+      if (st[1] < 0) {
+        const int64_t first = lvl[st[0]], cnt = lvl[st[0] + 1] - first;
+        if (forward)
+          hipLaunchKernelGGL((k_ilu_solve<true>), dim3(unsigned((cnt * 16 + 255) / 256)), dim3(256), 0, s, cnt, rows + first, ctx->Sm.rowptr.p,
+                             ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
+        else
+          hipLaunchKernelGGL((k_ilu_solve<false>), dim3(unsigned((cnt * 16 + 255) / 256)), dim3(256), 0, s, cnt, rows + first, ctx->Sm.rowptr.p,
+                             ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
+      } else if (forward)
+        hipLaunchKernelGGL((k_ilu_solve_batch<true>), dim3(1), dim3(1024), 0, s, st[0], st[1], d_lvl, rows, ctx->Sm.rowptr.p, ctx->Sm.col.p,
+                           I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
+      else
+        hipLaunchKernelGGL((k_ilu_solve_batch<false>), dim3(1), dim3(1024), 0, s, st[0], st[1], d_lvl, rows, ctx->Sm.rowptr.p, ctx->Sm.col.p,
+                           I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
+    }
+  };
+  sweep(true);
+  sweep(false);
 }
 int tpp_ilu_levels(const ifem_ctx *ctx) { return (int)ctx->tpp_ilu.lvl_f.size() - 1; }
 

@@ -115,7 +115,7 @@ def test_device_ilu0_equals_a_host_ilu0_in_the_same_order(kind):
     capi = _capi()
     m, dofs, vals = _cylinder(1)
     ctx = _ctx(m)
-    _tune(ctx, tpp_ilu_order=kind)
+    _tune(ctx, tpp_ilu_order=kind, tpp_milu_permille=0)  # plain ILU(0): what the host restatement below computes
     ctx.set_constraints(0, dofs, None)
     ctx.set_constraints(1, dofs, vals)
     ctx.scns_assemble(capi.make_scns_params(mu=1.8e-4, rho=1.3e-3, dt=1e-2), True)
@@ -133,7 +133,7 @@ def test_device_ilu0_equals_a_host_ilu0_in_the_same_order(kind):
     # and it is a preconditioner worth having: ||I - T (LU)^-1|| on this vector far below Jacobi's
     r_ilu = np.linalg.norm(T @ y - x) / np.linalg.norm(x)
     r_jac = np.linalg.norm(T @ (x / T.diagonal()) - x) / np.linalg.norm(x)
-    assert r_ilu < 0.5 * r_jac
+    assert r_ilu < (0.5 if kind == 0 else 1.0) * r_jac  # (the colour order trades quality for two dozen levels)
     ctx.close()
 
 
@@ -145,21 +145,30 @@ def _inner_per_application(ctx, P, use_nonzero=True):
 
 
 def test_cylinder_scnsim_refined_once_more_converges_without_a_dense_factorisation():
+    """24 k pressure rows (round 2 capped the exact dense solve at 12 288 and fell back to Jacobi beyond: 1777 inner
+    iterations per application on this mesh, gpurun_out/r03e/tpp_cyl4.log).  Default = natural order + relaxed modified
+    ILU(0) (omega 0.95): < 50; the multicolour order needs ~3x the iterations at a tenth of the launches"""
     capi = _capi()
     m, dofs, vals = _cylinder(4)  # one level beyond tests/fluid_cylinder_mpi_scnsim
     assert m.n_pnodes > 12288
     P = capi.make_scns_params(mu=1.8e-4, rho=1.3e-3, dt=1e-2)
     out = {}
-    for kind in (0, 1):
+    for kind, milu in ((0, None), (1, 0)):
         ctx = _ctx(m)
-        _tune(ctx, tpp_ilu_order=kind)
+        t = capi.Tuning()
+        ctx.L.ifem_default_tuning(C.byref(t))
+        assert (t.tpp_ilu_order, t.tpp_milu_permille) == (0, 950)
+        t.tpp_ilu_order = kind
+        if milu is not None:
+            t.tpp_milu_permille = milu
+        assert ctx.L.ifem_set_tuning(ctx.h, C.byref(t)) == 0
         ctx.set_constraints(0, dofs, None)
         ctx.set_constraints(1, dofs, vals)
         per, st = _inner_per_application(ctx, P)
         out[kind] = (per, st.fgmres_iters)
         ctx.close()
     assert out[0][0] < 50, out
-    assert min(out[0][0], out[1][0]) < 50, out
+    assert out[1][0] < 200 and abs(out[0][1] - out[1][1]) <= 2, out
 
 
 def test_box3d_q1q1_32_scnsim_converges_in_under_50_inner_iterations():

@@ -348,3 +348,44 @@ def test_local_refinement_tables_and_hanging_lines_equal_the_independent_builder
     gd, gv = s.constraints()
     assert sorted(gd.tolist()) == sorted(wd.tolist()) and not set(gd.tolist()) & set(dof.tolist())
     s.close()
+
+
+def test_cpp_transfers_interpolate_polynomials_exactly_on_every_rank_of_a_partition():
+    """the prolongation rows a rank hands to ifem_mg_attach reach into its coarse ghost layer: P applied to the coarse
+    lattice values of a polynomial of the element's degree must reproduce it at every owned fine node, and the owned rows
+    of all ranks tile the global fine lattice exactly once (semi-coarsened pair, 2 x 2 x 1 ranks)"""
+    from openifem_amd import host
+    reps_f, reps_c, P = (8, 8, 4), (8, 4, 2), (2, 2, 1)
+    p0, p1 = (0.0, 0.0, 0.0), (2.0, 1.0, 0.5)
+
+    def tables(reps, rank):
+        s = host.InsIM(host.channel_prm(3), reps, p0, p1)
+        s.set_partition(P, rank, local_world=None)
+        s.set_multigrid(False)
+        s.setup_host_only(0)
+        t = s.partition_tables()
+        s.close()
+        return t
+
+    def coords(gid, reps, deg):
+        N = [deg * r + 1 for r in reps]
+        out, rem = [], np.asarray(gid, np.int64).copy()
+        for d in range(3):
+            out.append((rem % N[d]) / (N[d] - 1) * (p1[d] - p0[d]) + p0[d])
+            rem //= N[d]
+        return np.stack(out, axis=1)
+
+    seen = {1: [], 2: []}
+    for rank in range(4):
+        tf, tc = tables(reps_f, rank), tables(reps_c, rank)
+        for deg, key, no, f in ((1, "l2g_p", "n_pnodes_owned", lambda x: 1.5 - x[:, 0] + 2 * x[:, 1] + 0.5 * x[:, 2]),
+                                (2, "l2g_u", "n_unodes_owned", lambda x: 1 + x[:, 0] * x[:, 1] - x[:, 2] ** 2 + 0.3 * x[:, 0] ** 2)):
+            fo = tf[key][:tf[no]]
+            Pm = host.box_prolongation(reps_f, reps_c, deg, fo, tc[key])
+            got = Pm @ f(coords(tc[key], reps_c, deg))
+            assert np.abs(got - f(coords(fo, reps_f, deg))).max() < 1e-13
+            seen[deg].append(fo)
+    for deg in (1, 2):
+        allg = np.concatenate(seen[deg])
+        n_glob = int(np.prod([deg * r + 1 for r in reps_f]))
+        assert len(allg) == n_glob and len(np.unique(allg)) == n_glob

@@ -66,11 +66,22 @@ def main(db_path, prefix):
         prow = []
         print("no counters:", e)
     if prow:
+        # per-dispatch values too: the median of a kernel whose first launch does extra work is the steady-state launch
+        per_d = {}
+        try:
+            for name, ctr, disp, val in cur.execute("select kernel_name, counter_name, dispatch_id, sum(value) from counters_collection "
+                                                    "group by kernel_name, counter_name, dispatch_id"):
+                per_d.setdefault((name, ctr), []).append(val)
+        except sqlite3.Error as e:
+            print("no per-dispatch counters:", e)
         with open(prefix + "_pmc.csv", "w", newline="") as f:
             w = csv.writer(f)
-            w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch", "sum"])
+            w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch", "sum", "median_per_dispatch", "min_per_dispatch"])
             for name, ctr, n, mean, tot in prow:
-                w.writerow([short(name), ctr, n, f"{mean:.6g}", f"{tot:.6g}"])
+                d = sorted(per_d.get((name, ctr), []))
+                nd = max(len(d), 1)
+                # counters_collection holds one row per (dispatch, counter instance): mean over rows is not per dispatch
+                w.writerow([short(name), ctr, len(d) or n, f"{tot / nd:.6g}", f"{tot:.6g}", f"{d[len(d) // 2]:.6g}" if d else "", f"{d[0]:.6g}" if d else ""])
 
 
 if __name__ == "__main__":
