@@ -140,8 +140,11 @@ typedef struct {
                                  the outer iteration ends at its first check: at 128^3, 5e-5 there (four inner iterations)
                                  gives 7.8e-5 ||rhs|| after one outer iteration where 1e-2 gives 9.1e-4 and needs a second
                                  one.  Only used when that first residual is velocity-dominated (pressure share below
-                                 10 fgmres_rel): a residual that is mostly continuity equation (later Newton iterations)
+                                 inner_first_pshare): a residual that is mostly continuity equation (later Newton iterations)
                                  needs several outer iterations whatever the velocity solve does */
+  double  inner_first_pshare; /* 0 (default): 10 fgmres_rel.  The largest pressure share ||r_p|| / ||r|| of the first Krylov vector
+                                 for which inner_rel_first is used -- a heuristic: the block-triangular preconditioner leaves
+                                 O(0.1) of the pressure part of a residual behind per outer iteration */
 } ifem_solver_opts;
 
 /* Tuning / measurement knobs of one context (defaults = the measured best; nothing here changes results beyond fp64
@@ -173,6 +176,9 @@ typedef struct {
   int64_t tpp_ilu_order; /* SCnsIM, explicit T_pp: preconditioner of its inner GMRES -- 0 (default) ILU(0) in the natural row order,
                             level-scheduled; 1 multicolour ILU(0) (a few dozen levels whatever the mesh); -1 Jacobi(T_pp) */
   int64_t basis_pad;     /* 32*33 doubles of padding between Krylov basis columns (HBM channel spread) */
+  int32_t tpp_tri_sweeps; /* SCnsIM, ILU(0) of T_pp: 0 (default) exact level-scheduled triangular solves; k > 0: k Jacobi sweeps per
+                             triangular system instead (2 k row-parallel launches whatever the number of levels) */
+  int32_t reserved_;
 } ifem_tuning;
 void ifem_default_tuning(ifem_tuning *t);
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t);

@@ -29,7 +29,7 @@ using MfTables = MfTablesT<double>;
 
 // R = arithmetic type of the cell kernel: double for the operator of an outer solve, float for the preconditioner-only
 // inner Krylov solve (tolerance 1e-2; its basis is single precision already).  Vectors in HBM stay double either way.
-template <typename R>
+template <typename R, typename XT = double>
 struct MfArgsT {
   int64_t n_cells, nUo; // n_cells: one past the last cell of this launch
   int64_t first_cell;   // first cell of this launch
@@ -37,7 +37,7 @@ struct MfArgsT {
   const int32_t *cell_unodes;
   const uint8_t *is_c; // constraint flags of the set the matrix was assembled with (local dofs) or nullptr
   const double *eval;  // evaluation point of the assembled matrix, velocity part, ghost-extended
-  const double *x;     // ghost-extended input
+  const XT *x;         // ghost-extended input (float: a level vector of the V-cycle)
   double *y;           // owned rows
   R mu, rho, gamma, inv_dt;
   int xcd;
@@ -76,8 +76,8 @@ struct MfCell { // per-cell LDS scratch
 
 // CONV = false: the evaluation point is zero (InsIMEX matrix: no convective / Newton terms) -- the second field group is
 // neither gathered nor interpolated
-template <int DIM, int KV, int WPB, bool CONV, typename R>
-__global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
+template <int DIM, int KV, int WPB, bool CONV, typename R, typename XT>
+__global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R, XT> A) {
   constexpr int N1 = KV + 1, NN = MfGeo<DIM, N1>::NN, NV = 1 << DIM;
   constexpr int NP = NN / N1;        // pencils per field and direction
   constexpr int NPL = DIM * NP;      // pencil lanes per round (one field group of DIM components)
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
   const int64_t p_first = vb * per_block + wave;
   // 32-bit index arithmetic in the prefetch (cells * nodes-per-cell and dim * nodes are below 2^31 by the int32 node ids)
   auto cell_of = [&](int64_t pr) { const int64_t c = A.first_cell + 2 * pr + half; return (pr < p_end && c < A.n_cells) ? uint32_t(c) : 0u; };
-  struct Pre { int32_t nd; double x[DIM], u[DIM], vc; uint8_t f[DIM]; } pre;
+  struct Pre { int32_t nd; XT x[DIM]; double u[DIM], vc; uint8_t f[DIM]; } pre;
   auto load_id = [&](int64_t pr) -> int32_t { return q_lane ? A.cell_unodes[cell_of(pr) * uint32_t(NN) + uint32_t(hl)] : 0; };
   auto load_vals = [&](int64_t pr, int32_t nd, Pre &o) {
     o.nd = nd;
@@ -364,10 +364,10 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R> A) {
 // spot -- fuse.mode 1: xs += x, r -= t (residual update after the coarse correction); mode 2: the Chebyshev step
 // xs += x, r -= t, x <- a x + b B r with the inverse node block B (x is the smoother's direction vector and is updated in
 // place: the cell kernel that read it has completed, and a thread only touches the entries of its own node).
-template <int DIM, typename R, bool FUSE>
+template <int DIM, typename R, bool FUSE, typename V>
 __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc,
                             const R *__restrict__ ycell, const uint8_t *__restrict__ is_c,
-                            const double *__restrict__ bjac, const float *__restrict__ bjf, const double *x, double *y, MfFuse fuse) {
+                            const double *__restrict__ bjac, const float *__restrict__ bjf, const V *x, double *y, MfFuseT<V> fuse) {
   // one thread per node: the incidence list is walked once for the DIM components (24 contiguous bytes per entry)
   const int64_t nd = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (nd * DIM >= n) return;
@@ -411,11 +411,11 @@ __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_p
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
       const int64_t i = nd * DIM + c;
-      xv[c] = x[i];
+      xv[c] = double(x[i]);
       const double t = fl[c] ? xv[c] / bj[c * DIM + c] : s[c];
-      rv[c] = fuse.r[i] - t;
-      fuse.xs[i] += xv[c];
-      fuse.r[i] = rv[c];
+      rv[c] = double(fuse.r[i]) - t;
+      fuse.xs[i] = V(double(fuse.xs[i]) + xv[c]);
+      fuse.r[i] = V(rv[c]);
     }
     if (fuse.mode >= 2) {
       const double a = fuse.mode == 2 ? fuse.a : 0.0;
@@ -424,7 +424,7 @@ __global__ void k_mf_gather(int64_t n, int nn, const int64_t *__restrict__ inc_p
         double z = 0;
 #pragma unroll
         for (int j = 0; j < DIM; ++j) z += bj[c * DIM + j] * rv[j];
-        fuse.d[nd * DIM + c] = a * xv[c] + fuse.b * z;
+        fuse.d[nd * DIM + c] = V(a * xv[c] + fuse.b * z);
       }
     }
   }
@@ -465,12 +465,12 @@ static void mf_tables(MfTables &t, int kv) {
     }
 }
 
-template <typename R>
-static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu, const MfFuse *fuse, int part) {
+template <typename R, typename XT>
+static void apply_uu_mf_t(ifem_ctx *ctx, const XT *xu, double *yu, const MfFuseT<XT> *fuse, int part) {
   if (!ctx->mf_valid) throw Error(IFEM_E_BADPARAM, "matrix-free A_uu: no assembled state (call ifem_ins_assemble first)");
   const int64_t n = int64_t(ctx->dim) * ctx->nUo;
   hipStream_t s = ctx->stream;
-  MfArgsT<R> a{};
+  MfArgsT<R, XT> a{};
   // cell range of this launch; with the interior-first tables (several ranks) every part uses them, part 0 included
   if (part != 0 && ctx->mf_n_interior < 0) throw Error(IFEM_E_BADPARAM, "matrix-free A_uu: cell split not built");
   const bool perm = ctx->mf_n_interior >= 0;
@@ -505,10 +505,10 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu, const MfF
   };
   const unsigned g_all = unsigned(std::min<int64_t>((n_pairs + WPB - 1) / WPB, int64_t(1) << 30));
 #define IFEM_MF2(D, K)                                                                                                 \
-  { if (conv) { static const unsigned cap = grid_for_kernel(reinterpret_cast<const void *>(&k_apply_uu_mf2<D, K, WPB, true, R>));  \
-                hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, true, R>), dim3(std::min(cap, g_all)), block, 0, s, a); }       \
-    else { static const unsigned cap = grid_for_kernel(reinterpret_cast<const void *>(&k_apply_uu_mf2<D, K, WPB, false, R>));     \
-           hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, false, R>), dim3(std::min(cap, g_all)), block, 0, s, a); } }
+  { if (conv) { static const unsigned cap = grid_for_kernel(reinterpret_cast<const void *>(&k_apply_uu_mf2<D, K, WPB, true, R, XT>));  \
+                hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, true, R, XT>), dim3(std::min(cap, g_all)), block, 0, s, a); }       \
+    else { static const unsigned cap = grid_for_kernel(reinterpret_cast<const void *>(&k_apply_uu_mf2<D, K, WPB, false, R, XT>));     \
+           hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, false, R, XT>), dim3(std::min(cap, g_all)), block, 0, s, a); } }
   if (n_pairs > 0) {
     if (ctx->dim == 3 && ctx->kv == 2) IFEM_MF2(3, 2)
     else if (ctx->dim == 3) IFEM_MF2(3, 1)
@@ -518,9 +518,9 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu, const MfF
 #undef IFEM_MF2
   if (part == 1) return; // the node gather follows the boundary cells
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
-  const MfFuse f0 = fuse ? *fuse : MfFuse{};
+  const MfFuseT<XT> f0 = fuse ? *fuse : MfFuseT<XT>{};
 #define IFEM_MFG(D, F)                                                                                                 \
-  hipLaunchKernelGGL((k_mf_gather<D, R, F>), dim3(unsigned((n / D + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p, \
+  hipLaunchKernelGGL((k_mf_gather<D, R, F, XT>), dim3(unsigned((n / D + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p, \
                      ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, fuse ? bjac_f32_ptr(ctx) : nullptr, xu, yu, f0)
   if (ctx->dim == 3) { if (fuse) IFEM_MFG(3, true); else IFEM_MFG(3, false); }
   else { if (fuse) IFEM_MFG(2, true); else IFEM_MFG(2, false); }
@@ -536,8 +536,12 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const double *xu, double *yu, const MfF
 
 // single = true: single-precision cell arithmetic (the inner, preconditioner-only solve); ifem_tuning::mf_f32 = 0 forces double
 void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single, const MfFuse *fuse, int part) {
-  if (single && ctx->tune.mf_f32) apply_uu_mf_t<float>(ctx, xu, yu, fuse, part);
-  else apply_uu_mf_t<double>(ctx, xu, yu, fuse, part);
+  if (single && ctx->tune.mf_f32) apply_uu_mf_t<float, double>(ctx, xu, yu, fuse, part);
+  else apply_uu_mf_t<double, double>(ctx, xu, yu, fuse, part);
+}
+void apply_uu_mf_f32v(ifem_ctx *ctx, const float *xu, const MfFuseT<float> *fuse, int part) {
+  if (!fuse) throw Error(IFEM_E_BADPARAM, "apply_uu_mf_f32v: the fused form only");
+  apply_uu_mf_t<float, float>(ctx, xu, nullptr, fuse, part);
 }
 
 } // namespace ifem

@@ -173,8 +173,8 @@ void comm_destroy(ifem_ctx *ctx) {
   ctx->halo.comm = nullptr;
 }
 
-__global__ void k_pack(int64_t n, int bs, const int32_t *__restrict__ idx, const double *__restrict__ x,
-                       double *__restrict__ buf) {
+template <typename T>
+__global__ void k_pack(int64_t n, int bs, const int32_t *__restrict__ idx, const T *__restrict__ x, T *__restrict__ buf) {
   for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < n * bs; t += int64_t(gridDim.x) * blockDim.x) {
     const int64_t i = t / bs;
     const int c = int(t - i * bs);
@@ -186,7 +186,14 @@ __global__ void k_pack(int64_t n, int bs, const int32_t *__restrict__ idx, const
 // which: 0 velocity halo, 1 pressure halo, 2 the 2-deep pressure halo of the distributed S_m
 // async: the send/recv group goes to the halo stream (second communicator) behind an event recorded after the packing
 // kernel, and leaves an event for halo_wait; otherwise everything is ordered on the context stream
-static void exchange(ifem_ctx *ctx, double *x, int which, bool async = false) {
+template <typename T> struct NcclType;
+template <> struct NcclType<double> { static constexpr ncclDataType_t v = ncclDouble; };
+template <> struct NcclType<float> { static constexpr ncclDataType_t v = ncclFloat; };
+
+// T = double for the vectors of the Krylov solvers, float for the level vectors of the A_uu V-cycle (the send buffer is
+// sized in doubles and reinterpreted)
+template <typename T>
+static void exchange(ifem_ctx *ctx, T *x, int which, bool async = false) {
   Halo &h = ctx->halo;
   const int bs = which == 0 ? ctx->dim : 1;
   const int64_t n_owned = which == 0 ? ctx->nUo : ctx->nPo;
@@ -197,15 +204,15 @@ static void exchange(ifem_ctx *ctx, double *x, int which, bool async = false) {
     size_t off = 0;
     if (which >= 1) off += (size_t)c->dim * c->halo.send_u_ptr.back();
     if (which >= 2) off += (size_t)c->halo.send_p_ptr.back();
-    return c->halo.sendbuf.p + off;
+    return reinterpret_cast<T *>(c->halo.sendbuf.p) + off;
   };
-  double *sendbuf = sendbuf_of(ctx);
+  T *sendbuf = sendbuf_of(ctx);
   const int nn = (int)h.nbr.size();
   const int64_t ns = sptr[nn];
   ++h.n_exchanges;
   if (ns) {
     int64_t g = (ns * bs + 255) / 256;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, ctx->stream, ns, bs, sidx.p, x, sendbuf);
+    hipLaunchKernelGGL((k_pack<T>), dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, ctx->stream, ns, bs, sidx.p, (const T *)x, sendbuf);
   }
   if (h.local) {
     // stream-ordered like the RCCL path: my copies wait (on the device) for the peers' packing kernels, the peers' next
@@ -225,7 +232,7 @@ static void exchange(ifem_ctx *ctx, double *x, int which, bool async = false) {
       if (int64_t(psptr[me + 1] - psptr[me]) * bs != rc) throw Error(IFEM_E_COMM, "local world: send/recv count mismatch");
       IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_packed[h.nbr[k]], 0));
       IFEM_HIP_CHECK(hipMemcpyAsync(x + (n_owned + rptr[k]) * bs, sendbuf_of(peer) + int64_t(psptr[me]) * bs,
-                                    rc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                                    rc * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
     }
     IFEM_HIP_CHECK(hipEventRecord(w->ev_copied[h.rank], ctx->stream));
     w->rendezvous();
@@ -243,8 +250,8 @@ static void exchange(ifem_ctx *ctx, double *x, int which, bool async = false) {
   IFEM_NCCL_CHECK(ncclGroupStart());
   for (int k = 0; k < nn; ++k) {
     const int64_t sc = int64_t(sptr[k + 1] - sptr[k]) * bs, rc = int64_t(rptr[k + 1] - rptr[k]) * bs;
-    if (sc) IFEM_NCCL_CHECK(ncclSend(sendbuf + int64_t(sptr[k]) * bs, sc, ncclDouble, h.nbr[k], cm, st));
-    if (rc) IFEM_NCCL_CHECK(ncclRecv(x + (n_owned + rptr[k]) * bs, rc, ncclDouble, h.nbr[k], cm, st));
+    if (sc) IFEM_NCCL_CHECK(ncclSend(sendbuf + int64_t(sptr[k]) * bs, sc, NcclType<T>::v, h.nbr[k], cm, st));
+    if (rc) IFEM_NCCL_CHECK(ncclRecv(x + (n_owned + rptr[k]) * bs, rc, NcclType<T>::v, h.nbr[k], cm, st));
   }
   IFEM_NCCL_CHECK(ncclGroupEnd());
   if (async) IFEM_HIP_CHECK(hipEventRecord(h.ev_done, st));
@@ -263,14 +270,18 @@ void halo_start(ifem_ctx *ctx, double *x_ext, int which) {
   if (which == 2 && !ctx->halo.has_s) throw Error(IFEM_E_BADPARAM, "no 2-deep pressure halo plan in this context");
   exchange(ctx, x_ext, which, true);
 }
+void halo_start_f32(ifem_ctx *ctx, float *xu_ext) {
+  if (ctx->halo.nranks == 1) return;
+  exchange(ctx, xu_ext, 0, true);
+}
 void halo_wait(ifem_ctx *ctx) {
   Halo &h = ctx->halo;
   if (h.nranks == 1 || h.local || !h.comm2 || !h.hstream) return;
   IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, h.ev_done, 0));
 }
 
-__global__ void k_unpack_add(int64_t n, int bs, const int32_t *__restrict__ idx, const double *__restrict__ buf,
-                             double *__restrict__ x) {
+template <typename T>
+__global__ void k_unpack_add(int64_t n, int bs, const int32_t *__restrict__ idx, const T *__restrict__ buf, T *__restrict__ x) {
   for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < n * bs; t += int64_t(gridDim.x) * blockDim.x) {
     const int64_t i = t / bs;
     const int c = int(t - i * bs);
@@ -281,14 +292,15 @@ __global__ void k_unpack_add(int64_t n, int bs, const int32_t *__restrict__ idx,
 // Transpose of the halo exchange: the ghost entries of x_ext travel back to their owners and are ADDED to the owned
 // entries (PETSc VecScatter in reverse / ADD_VALUES mode; deal.II compress(VectorOperation::add)).  Used by C^T of the
 // hanging-node lines whose masters live on another rank.  which: 0 velocity nodes (bs = dim), 1 pressure nodes.
-static void reverse_add(ifem_ctx *ctx, double *x, int which) {
+template <typename T>
+static void reverse_add(ifem_ctx *ctx, T *x, int which) {
   Halo &h = ctx->halo;
   const int bs = which == 0 ? ctx->dim : 1;
   const int64_t n_owned = which == 0 ? ctx->nUo : ctx->nPo;
   const std::vector<int32_t> &sptr = which == 0 ? h.send_u_ptr : h.send_p_ptr;
   const std::vector<int32_t> &rptr = which == 0 ? h.recv_u_ptr : h.recv_p_ptr;
   const DBuf<int32_t> &sidx = which == 0 ? h.send_u_idx : h.send_p_idx;
-  double *buf = h.sendbuf.p + (which == 0 ? 0 : (size_t)ctx->dim * h.send_u_ptr.back()); // the forward send region, now receiving
+  T *buf = reinterpret_cast<T *>(h.sendbuf.p) + (which == 0 ? 0 : (size_t)ctx->dim * h.send_u_ptr.back()); // the forward send region, now receiving
   const int nn = (int)h.nbr.size();
   const int64_t ns = sptr[nn];
   ++h.n_exchanges;
@@ -308,7 +320,7 @@ static void reverse_add(ifem_ctx *ctx, double *x, int which) {
       const std::vector<int32_t> &prptr = which == 0 ? ph.recv_u_ptr : ph.recv_p_ptr;
       const int64_t pn_owned = which == 0 ? peer->nUo : peer->nPo;
       if (int64_t(prptr[me + 1] - prptr[me]) * bs != sc) throw Error(IFEM_E_COMM, "local world: send/recv count mismatch");
-      IFEM_HIP_CHECK(hipMemcpyAsync(buf + int64_t(sptr[k]) * bs, ph.rev_src + (pn_owned + prptr[me]) * bs, sc * sizeof(double),
+      IFEM_HIP_CHECK(hipMemcpyAsync(buf + int64_t(sptr[k]) * bs, static_cast<const T *>(ph.rev_src) + (pn_owned + prptr[me]) * bs, sc * sizeof(T),
                                     hipMemcpyDeviceToDevice, ctx->stream));
     }
     IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -317,20 +329,28 @@ static void reverse_add(ifem_ctx *ctx, double *x, int which) {
     IFEM_NCCL_CHECK(ncclGroupStart());
     for (int k = 0; k < nn; ++k) {
       const int64_t sc = int64_t(sptr[k + 1] - sptr[k]) * bs, rc = int64_t(rptr[k + 1] - rptr[k]) * bs;
-      if (rc) IFEM_NCCL_CHECK(ncclSend(x + (n_owned + rptr[k]) * bs, rc, ncclDouble, h.nbr[k], (ncclComm_t)h.comm, ctx->stream));
-      if (sc) IFEM_NCCL_CHECK(ncclRecv(buf + int64_t(sptr[k]) * bs, sc, ncclDouble, h.nbr[k], (ncclComm_t)h.comm, ctx->stream));
+      if (rc) IFEM_NCCL_CHECK(ncclSend(x + (n_owned + rptr[k]) * bs, rc, NcclType<T>::v, h.nbr[k], (ncclComm_t)h.comm, ctx->stream));
+      if (sc) IFEM_NCCL_CHECK(ncclRecv(buf + int64_t(sptr[k]) * bs, sc, NcclType<T>::v, h.nbr[k], (ncclComm_t)h.comm, ctx->stream));
     }
     IFEM_NCCL_CHECK(ncclGroupEnd());
   }
   if (ns) {
     int64_t g = (ns * bs + 255) / 256;
-    hipLaunchKernelGGL(k_unpack_add, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, ctx->stream, ns, bs, sidx.p, buf, x);
+    hipLaunchKernelGGL((k_unpack_add<T>), dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, ctx->stream, ns, bs, sidx.p, (const T *)buf, x);
   }
 }
 
 void halo_reverse_add(ifem_ctx *ctx, double *xu_ext) {
   if (ctx->halo.nranks == 1) return;
   reverse_add(ctx, xu_ext, 0);
+}
+void halo_reverse_add_f32(ifem_ctx *ctx, float *xu_ext) {
+  if (ctx->halo.nranks == 1) return;
+  reverse_add(ctx, xu_ext, 0);
+}
+void halo_exchange_f32(ifem_ctx *ctx, float *xu_ext) {
+  if (ctx->halo.nranks == 1) return;
+  exchange(ctx, xu_ext, 0);
 }
 void halo_reverse_add_p(ifem_ctx *ctx, double *xp_ext) {
   if (ctx->halo.nranks == 1) return;

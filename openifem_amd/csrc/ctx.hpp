@@ -151,7 +151,7 @@ struct Halo {
   bool owns_hstream = false;
   hipEvent_t ev_pack = nullptr, ev_done = nullptr;
   void *local = nullptr; // LocalWorld* (in-process virtual ranks, validation transport)
-  const double *rev_src = nullptr; // local world only: the extended vector whose ghosts the peers fetch in a reverse exchange
+  const void *rev_src = nullptr; // local world only: the extended vector whose ghosts the peers fetch in a reverse exchange
   // counters since the last ifem_comm_stats(reset): halo exchanges (forward + reverse), all-reduces ordered on the stream,
   // all-reduces that made the host wait for the device
   uint64_t n_exchanges = 0, n_allreduce_dev = 0, n_allreduce_host = 0;
@@ -166,7 +166,7 @@ struct TppIlu {
   std::vector<int64_t> lvl_f, lvl_b; // level pointers into rows_f / rows_b (host: the launch plan)
   DBuf<int64_t> d_lvl_f, d_lvl_b;    // the same on the device (batched runs of small levels)
   std::vector<std::array<int32_t, 2>> plan_f, plan_b; // {level, -1}: one wide level; {l0, l1}: a run of small levels in one launch
-  DBuf<double> LU;
+  DBuf<double> LU, t0, t1; // factors; scratch of the Jacobi-sweep triangular solves
   bool analysed = false, factored = false;
   int order_kind = 0;
 };
@@ -291,6 +291,7 @@ struct ifem_ctx {
   ifem::DBuf<uint8_t> mg_Pu_mask, mg_Ru_mask; // per weight: components dropped by the Dirichlet flags of the two levels
   int64_t mg_mask_key[2] = {-1, -1};          // constrained-dof sets (flag ids of this level and the coarser one) of the masks
   ifem::DBuf<double> sm_dinv, mg_vec[6], mgu_vec[5];
+  ifem::DBuf<float> mguf_vec[5]; // single-precision level vectors of the A_uu V-cycle (solver.hip)
   double sm_lmax = 0, uu_lmax = 0;
   double uu_evn = 0, uu_lmax_evn = -1; // ||evaluation point|| of the current assembly (finest level) / of the cached A_uu bound
   int64_t uu_evn_asm = -1;

@@ -49,14 +49,19 @@ void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool
 // stored.  mode 1: xs += x, r -= t; mode 2 additionally d = a x + b B r (B = inverse node block, single-precision copy) -- the
 // Chebyshev step of the multigrid smoother, d being the owned part of x itself; mode 3: mode 1, then d = b B r into another
 // vector d -- the first direction of the smoothing sweep that follows the coarse correction
-struct MfFuse {
+template <typename V>
+struct MfFuseT {
   int mode = 0;
   double a = 0, b = 0;
-  double *xs = nullptr, *r = nullptr, *d = nullptr;
+  V *xs = nullptr, *r = nullptr, *d = nullptr;
 };
+using MfFuse = MfFuseT<double>;
 // part (several ranks, build_mf_cell_split): 0 every cell, then the node gather; 1 only the cells whose nodes are all owned
 // (no ghost entry of xu is read: the halo may still be in flight); 2 the remaining cells, then the gather
 void apply_uu_mf(ifem_ctx *ctx, const double *xu, double *yu, bool single = false, const MfFuse *fuse = nullptr, int part = 0);
+// the same on SINGLE-PRECISION vectors, fused form only (the level vectors of the A_uu V-cycle, solver.hip): single-precision
+// cell arithmetic, x and the vectors of `fuse` are float
+void apply_uu_mf_f32v(ifem_ctx *ctx, const float *xu, const MfFuseT<float> *fuse, int part = 0);
 // scalar velocity operator S^ (IFEM_AINV_SCALAR_GMRES): auxiliary data, SpMV on all components, Jacobi
 void shat_refresh(ifem_ctx *ctx, bool f32);
 void spmv_shat(ifem_ctx *ctx, const double *xu, double *yu, bool f32);
@@ -139,6 +144,11 @@ void mg_csr_mask(ifem_ctx *ctx, const MgCsr &M, const uint8_t *flag_in, const ui
 void mg_csr_apply_nodes(ifem_ctx *ctx, const MgCsr &M, const double *x, const DBuf<uint8_t> &mask, double *y);
 void mg_inject_nodes(ifem_ctx *ctx, int64_t n_nodes, const int32_t *inj, const double *fine, double *coarse);
 void cheb_init_block(ifem_ctx *ctx, double c0, const double *r, double *d);
+void cheb_init_block_f32(ifem_ctx *ctx, double c0, const float *r, float *d);
+void mg_csr_apply_nodes_f32(ifem_ctx *ctx, const MgCsr &M, const float *x, const DBuf<uint8_t> &mask, float *y);
+void v_cvt_d2f(ifem_ctx *ctx, int64_t n, const double *x, float *y);
+void v_cvt_f2d(ifem_ctx *ctx, int64_t n, const float *x, double *y);
+void v_axpy_f32v(ifem_ctx *ctx, int64_t n, float a, const float *x, float *y);
 
 // all-reduce helpers (identity for a single rank)
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n);
@@ -154,6 +164,10 @@ void halo_exchange(ifem_ctx *ctx, double *xu_ext);
 void halo_exchange_p(ifem_ctx *ctx, double *xp_ext);
 // transpose: ghost entries are sent back to their owners and added there (C^T of hanging lines across ranks)
 void halo_reverse_add(ifem_ctx *ctx, double *xu_ext);
+// single-precision velocity vectors (level vectors of the A_uu V-cycle): same plans, half the bytes
+void halo_exchange_f32(ifem_ctx *ctx, float *xu_ext);
+void halo_reverse_add_f32(ifem_ctx *ctx, float *xu_ext);
+void halo_start_f32(ifem_ctx *ctx, float *xu_ext);
 void halo_reverse_add_p(ifem_ctx *ctx, double *xp_ext);
 // overlapped form: halo_start (pack + transfers on the halo stream), work that reads no ghost entry, halo_wait
 bool halo_overlap_ok(const ifem_ctx *ctx);

@@ -327,10 +327,10 @@ void mg_csr_mask(ifem_ctx *ctx, const MgCsr &M, const uint8_t *flag_in, const ui
   else hipLaunchKernelGGL((k_mg_mask<2>), dim3(mgrid(M.n_rows)), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, flag_in, flag_out, mask.p);
 }
 
-template <int DIM, int G>
+template <int DIM, int G, typename V>
 __global__ __launch_bounds__(256) void k_mg_csr_nodes(int64_t n_rows, const int64_t *__restrict__ ptr, const int32_t *__restrict__ col,
-                                                      const double *__restrict__ w, const double *__restrict__ x,
-                                                      const uint8_t *__restrict__ mask, double *__restrict__ y) {
+                                                      const double *__restrict__ w, const V *__restrict__ x,
+                                                      const uint8_t *__restrict__ mask, V *__restrict__ y) {
   const int lig = threadIdx.x % G;
   const int64_t r = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) / G;
   const bool live = r < n_rows;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void k_mg_csr_nodes(int64_t n_rows, const int6
       const unsigned m = mask[k];
       double xv[DIM];
 #pragma unroll
-      for (int c = 0; c < DIM; ++c) xv[c] = x[j + c];
+      for (int c = 0; c < DIM; ++c) xv[c] = double(x[j + c]);
 #pragma unroll
       for (int c = 0; c < DIM; ++c) s[c] += ((m >> c) & 1u) ? 0.0 : wk * xv[c];
     }
@@ -358,16 +358,16 @@ __global__ __launch_bounds__(256) void k_mg_csr_nodes(int64_t n_rows, const int6
     double v = s[0];
 #pragma unroll
     for (int c = 1; c < DIM; ++c) v = lig == c ? s[c] : v;
-    y[r * DIM + lig] = v;
+    y[r * DIM + lig] = V(v);
   }
 }
 
-template <int DIM>
-static void launch_csr_nodes(ifem_ctx *ctx, const MgCsr &M, const double *x, const uint8_t *mask, double *y) {
+template <int DIM, typename V>
+static void launch_csr_nodes(ifem_ctx *ctx, const MgCsr &M, const V *x, const uint8_t *mask, V *y) {
   const double mean = double(M.col.n) / double(M.n_rows);
   const int g = mean <= 6 ? 4 : (mean <= 12 ? 8 : (mean <= 24 ? 16 : 32));
   const unsigned blocks = unsigned((M.n_rows * g + 255) / 256);
-#define IFEM_CSRN(G) hipLaunchKernelGGL((k_mg_csr_nodes<DIM, G>), dim3(blocks), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, M.w.p, x, mask, y)
+#define IFEM_CSRN(G) hipLaunchKernelGGL((k_mg_csr_nodes<DIM, G, V>), dim3(blocks), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, M.w.p, x, mask, y)
   if (g == 4) IFEM_CSRN(4); else if (g == 8) IFEM_CSRN(8); else if (g == 16) IFEM_CSRN(16); else IFEM_CSRN(32);
 #undef IFEM_CSRN
 }
@@ -375,8 +375,14 @@ static void launch_csr_nodes(ifem_ctx *ctx, const MgCsr &M, const double *x, con
 void mg_csr_apply_nodes(ifem_ctx *ctx, const MgCsr &M, const double *x, const DBuf<uint8_t> &mask, double *y) {
   if (!M.n_rows) return;
   if (mask.n != M.col.n) throw Error(IFEM_E_BADPARAM, "multigrid transfer without its constraint mask");
-  if (ctx->dim == 3) launch_csr_nodes<3>(ctx, M, x, mask.p, y);
-  else launch_csr_nodes<2>(ctx, M, x, mask.p, y);
+  if (ctx->dim == 3) launch_csr_nodes<3, double>(ctx, M, x, mask.p, y);
+  else launch_csr_nodes<2, double>(ctx, M, x, mask.p, y);
+}
+void mg_csr_apply_nodes_f32(ifem_ctx *ctx, const MgCsr &M, const float *x, const DBuf<uint8_t> &mask, float *y) {
+  if (!M.n_rows) return;
+  if (mask.n != M.col.n) throw Error(IFEM_E_BADPARAM, "multigrid transfer without its constraint mask");
+  if (ctx->dim == 3) launch_csr_nodes<3, float>(ctx, M, x, mask.p, y);
+  else launch_csr_nodes<2, float>(ctx, M, x, mask.p, y);
 }
 
 __global__ void k_mg_inject(int64_t n_nodes, int dim, const int32_t *__restrict__ inj, const double *__restrict__ fine,
@@ -392,28 +398,51 @@ void mg_inject_nodes(ifem_ctx *ctx, int64_t n_nodes, const int32_t *inj, const d
 }
 
 // d = c0 B r per node (B = inverse diagonal block)
-template <int DIM>
-__global__ void k_cheb_init_block(int64_t n_nodes, double c0, const float *__restrict__ bj, const double *__restrict__ r,
-                                  double *__restrict__ d) {
+template <int DIM, typename V>
+__global__ void k_cheb_init_block(int64_t n_nodes, double c0, const float *__restrict__ bj, const V *__restrict__ r,
+                                  V *__restrict__ d) {
   const int64_t nd = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (nd >= n_nodes) return;
   double rv[DIM];
 #pragma unroll
-  for (int j = 0; j < DIM; ++j) rv[j] = r[nd * DIM + j];
+  for (int j = 0; j < DIM; ++j) rv[j] = double(r[nd * DIM + j]);
 #pragma unroll
   for (int i = 0; i < DIM; ++i) {
     double t = 0;
 #pragma unroll
     for (int j = 0; j < DIM; ++j) t += double(bj[nd * DIM * DIM + i * DIM + j]) * rv[j];
-    d[nd * DIM + i] = c0 * t;
+    d[nd * DIM + i] = V(c0 * t);
   }
 }
-void cheb_init_block(ifem_ctx *ctx, double c0, const double *r, double *d) {
+template <typename V>
+static void cheb_init_block_t(ifem_ctx *ctx, double c0, const V *r, V *d) {
   const int64_t n = ctx->nUo;
   if (!n) return;
   const dim3 g(unsigned((n + 255) / 256)), b(256);
   const float *bjf = bjac_f32_ptr(ctx);
-  if (ctx->dim == 3) hipLaunchKernelGGL((k_cheb_init_block<3>), g, b, 0, ctx->stream, n, c0, bjf, r, d);
-  else hipLaunchKernelGGL((k_cheb_init_block<2>), g, b, 0, ctx->stream, n, c0, bjf, r, d);
+  if (ctx->dim == 3) hipLaunchKernelGGL((k_cheb_init_block<3, V>), g, b, 0, ctx->stream, n, c0, bjf, r, d);
+  else hipLaunchKernelGGL((k_cheb_init_block<2, V>), g, b, 0, ctx->stream, n, c0, bjf, r, d);
+}
+void cheb_init_block(ifem_ctx *ctx, double c0, const double *r, double *d) { cheb_init_block_t<double>(ctx, c0, r, d); }
+void cheb_init_block_f32(ifem_ctx *ctx, double c0, const float *r, float *d) { cheb_init_block_t<float>(ctx, c0, r, d); }
+
+// conversions between the double vectors of the Krylov solvers and the single-precision level vectors, y (+)= a x
+__global__ void k_cvt_d2f(int64_t n, const double *__restrict__ x, float *__restrict__ y) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] = float(x[i]);
+}
+__global__ void k_cvt_f2d(int64_t n, const float *__restrict__ x, double *__restrict__ y) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] = double(x[i]);
+}
+__global__ void k_axpy_f32v(int64_t n, float a, const float *__restrict__ x, float *__restrict__ y) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] += a * x[i];
+}
+void v_cvt_d2f(ifem_ctx *ctx, int64_t n, const double *x, float *y) {
+  if (n) hipLaunchKernelGGL(k_cvt_d2f, dim3(mgrid(n)), dim3(256), 0, ctx->stream, n, x, y);
+}
+void v_cvt_f2d(ifem_ctx *ctx, int64_t n, const float *x, double *y) {
+  if (n) hipLaunchKernelGGL(k_cvt_f2d, dim3(mgrid(n)), dim3(256), 0, ctx->stream, n, x, y);
+}
+void v_axpy_f32v(ifem_ctx *ctx, int64_t n, float a, const float *x, float *y) {
+  if (n) hipLaunchKernelGGL(k_axpy_f32v, dim3(mgrid(n)), dim3(256), 0, ctx->stream, n, a, x, y);
 }
 } // namespace ifem

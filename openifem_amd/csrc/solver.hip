@@ -563,8 +563,11 @@ static void carve_workspace(SolveState &S, bool krylov = true);
 // applies its own matrix-free A_uu (apply_mf.hip, single-precision cell arithmetic) at the evaluation point injected from
 // the level above; smoother = Chebyshev iteration on (node-block diagonal)^-1 A_uu.  The coarse block diagonals are
 // integrated matrix-free (mg.hip::k_uu_diag), the finest level uses the blocks of the assembled matrix.  Level vectors
-// (ctx->mgu_vec, dim * nUl + 8 each): 0 right-hand side / residual, 1 solution, 2 direction, 3 operator product,
-// 4 prolongated correction; compact owned entries first, so the buffers double as ghost-extended velocity vectors.
+// (ctx->mguf_vec, SINGLE precision since round 3 -- the cell arithmetic of the level operators, the node blocks of the smoother
+// and the basis of the Krylov solver around the cycle are single precision already -- dim * nUl + 8 each): 0 right-hand side /
+// residual, 1 solution, 2 direction, 3 (unused: the operator product is consumed inside the fused gather), 4 prolongated
+// correction; compact owned entries first, so the buffers double as ghost-extended velocity vectors.  The double vectors
+// ctx->mgu_vec[1..3] remain as scratch of the eigenvalue estimates.
 struct MgUu {
   std::vector<SolveState> L;
   int nu = 3, nu_post = 3;
@@ -588,6 +591,21 @@ static void uu_apply_level(SolveState &S, const double *x, double *y, const MfFu
   apply_uu_mf(c, xe, y, true, fuse);
 }
 
+// the same on a level vector of the V-cycle (single precision, ghost-extended in place: owned entries first), fused form
+static void uu_apply_level_f32(SolveState &S, float *x_ext, const MfFuseT<float> *fuse) {
+  ifem_ctx *c = S.ctx;
+  if (halo_overlap_ok(c)) {
+    build_mf_cell_split(c);
+    halo_start_f32(c, x_ext);
+    apply_uu_mf_f32v(c, x_ext, fuse, 1);
+    halo_wait(c);
+    apply_uu_mf_f32v(c, x_ext, fuse, 2);
+    return;
+  }
+  halo_exchange_f32(c, x_ext);
+  apply_uu_mf_f32v(c, x_ext, fuse);
+}
+
 static void mg_uu_setup(MgUu &M, bool force_bounds = false) {
   ifem_ctx *f0 = M.L[0].ctx;
   // size of the evaluation point the bounds below were estimated at: A_uu carries rho C(u), so a bound taken at a small
@@ -603,8 +621,12 @@ static void mg_uu_setup(MgUu &M, bool force_bounds = false) {
     SolveState &S = M.L[l];
     ifem_ctx *c = S.ctx;
     const int64_t nv = int64_t(c->dim) * c->nUl + 8;
-    for (auto &v : c->mgu_vec)
+    for (int k = 1; k <= 3; ++k) {
+      auto &v = c->mgu_vec[k];
       if ((int64_t)v.n < nv) { v.alloc((size_t)nv); IFEM_HIP_CHECK(hipMemsetAsync(v.p, 0, v.n * sizeof(double), c->stream)); }
+    }
+    for (auto &v : c->mguf_vec)
+      if ((int64_t)v.n < nv) { v.alloc((size_t)nv); IFEM_HIP_CHECK(hipMemsetAsync(v.p, 0, v.n * sizeof(float), c->stream)); }
     if (l > 0 && c->uu_mg_version != f0->asm_version) { // operator state of a coarse level: rediscretisation at the injected point
       ifem_ctx *p = M.L[l - 1].ctx;
       c->mf_params = f0->mf_params;
@@ -673,32 +695,32 @@ static void mg_uu_setup(MgUu &M, bool force_bounds = false) {
 }
 
 // d_ready: the first direction d = (1/theta) B r is already in place (written by the fused residual update, MfFuse mode 3)
-static void mg_uu_smooth(MgUu &M, size_t l, int nsteps, double lo, double hi, double *x, double *r, bool keep_r, bool d_ready = false) {
+static void mg_uu_smooth(MgUu &M, size_t l, int nsteps, double lo, double hi, float *x, float *r, bool keep_r, bool d_ready = false) {
   SolveState &S = M.L[l];
   ifem_ctx *c = S.ctx;
-  double *d = c->mgu_vec[2].p, *t = c->mgu_vec[3].p;
+  float *d = c->mguf_vec[2].p;
   const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
   double rho_old = 1.0 / sigma;
-  if (!d_ready) cheb_init_block(c, 1.0 / theta, r, d);
+  if (!d_ready) cheb_init_block_f32(c, 1.0 / theta, r, d);
   for (int k = 0; k < nsteps; ++k) {
     const bool last = k == nsteps - 1;
-    if (last && !keep_r) { v_axpy(c, S.nuo, 1.0, d, x); break; }
+    if (last && !keep_r) { v_axpy_f32v(c, S.nuo, 1.0f, d, x); break; }
     const double rho_new = 1.0 / (2.0 * sigma - rho_old);
     // x += d; r -= A d; d = rho_new rho_old d + (2 rho_new / delta) B r, fused into the node gather of the product
-    MfFuse f;
+    MfFuseT<float> f;
     f.mode = 2; f.a = rho_new * rho_old; f.b = 2.0 * rho_new / delta; f.xs = x; f.r = r; f.d = d;
-    uu_apply_level(S, d, t, &f);
+    uu_apply_level_f32(S, d, &f);
     rho_old = rho_new;
   }
 }
 
-// level l: mgu_vec[1] = V(mgu_vec[0]); mgu_vec[0] is overwritten by the residual
+// level l: mguf_vec[1] = V(mguf_vec[0]); mguf_vec[0] is overwritten by the residual
 static void mg_uu_vcycle(MgUu &M, size_t l) {
   SolveState &S = M.L[l];
   ifem_ctx *c = S.ctx;
-  double *r = c->mgu_vec[0].p, *x = c->mgu_vec[1].p;
+  float *r = c->mguf_vec[0].p, *x = c->mguf_vec[1].p;
   const double hi = 1.1 * c->uu_lmax;
-  v_zero(c, S.nuo, x);
+  IFEM_HIP_CHECK(hipMemsetAsync(x, 0, size_t(S.nuo) * sizeof(float), c->stream));
   if (l + 1 == M.L.size()) {
     mg_uu_smooth(M, l, 24, hi / 400.0, hi, x, r, false);
     return;
@@ -707,15 +729,15 @@ static void mg_uu_vcycle(MgUu &M, size_t l) {
   mg_uu_smooth(M, l, M.nu, lo, hi, x, r, true);
   SolveState &Sc = M.L[l + 1];
   ifem_ctx *cc = Sc.ctx;
-  mg_csr_apply_nodes(c, c->mg_Ru, r, c->mg_Ru_mask, cc->mgu_vec[0].p);
-  halo_reverse_add(cc, cc->mgu_vec[0].p);
+  mg_csr_apply_nodes_f32(c, c->mg_Ru, r, c->mg_Ru_mask, cc->mguf_vec[0].p);
+  halo_reverse_add_f32(cc, cc->mguf_vec[0].p);
   mg_uu_vcycle(M, l + 1);
-  halo_exchange(cc, cc->mgu_vec[1].p);
-  double *e = c->mgu_vec[4].p, *t = c->mgu_vec[3].p;
-  mg_csr_apply_nodes(c, c->mg_Pu, cc->mgu_vec[1].p, c->mg_Pu_mask, e);
-  MfFuse f; // x += e; r -= A e; d = (1/theta) B r: the first direction of the post-smoothing sweep
-  f.mode = 3; f.xs = x; f.r = r; f.d = c->mgu_vec[2].p; f.b = 1.0 / (0.5 * (hi + lo));
-  uu_apply_level(S, e, t, &f);
+  halo_exchange_f32(cc, cc->mguf_vec[1].p);
+  float *e = c->mguf_vec[4].p;
+  mg_csr_apply_nodes_f32(c, c->mg_Pu, cc->mguf_vec[1].p, c->mg_Pu_mask, e);
+  MfFuseT<float> f; // x += e; r -= A e; d = (1/theta) B r: the first direction of the post-smoothing sweep
+  f.mode = 3; f.xs = x; f.r = r; f.d = c->mguf_vec[2].p; f.b = 1.0 / (0.5 * (hi + lo));
+  uu_apply_level_f32(S, e, &f);
   mg_uu_smooth(M, l, M.nu_post, lo, hi, x, r, false, true);
 }
 
@@ -834,7 +856,8 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   // a better velocity solve -- the later Newton iterations, whose residual is almost all continuity equation (shares
   // 0.996 / 0.66 against 7e-5 in the first one at 128^3): there the cheap setting is the better one (time_step leg of
   // bench.py: 1.16 s against 1.27 s with the tight first application everywhere)
-  const bool pressure_dominated = S.p_src_norm > 10.0 * o->fgmres_rel * std::hypot(S.u_src_norm, S.p_src_norm);
+  const double pshare_max = o->inner_first_pshare > 0 ? o->inner_first_pshare : 10.0 * o->fgmres_rel;
+  const bool pressure_dominated = S.p_src_norm > pshare_max * std::hypot(S.u_src_norm, S.p_src_norm);
   const double inner_rel_now = (S.st.precond_applies == 0 && o->inner_rel_first > 0 && !pressure_dominated) ? o->inner_rel_first : o->inner_rel;
   if (o->verbose && S.st.precond_applies == 0)
     fprintf(stderr, "[ifem] first preconditioner application: pressure share of the residual %.3e, inner tolerance %.1e\n",
@@ -853,9 +876,9 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     mg_uu_setup(Mu);
     OpFn Amf = [&](const double *x, double *y) { uu_apply_level(S, x, y); };
     OpFn Vc = [&](const double *x, double *y) {
-      v_copy(c, S.nuo, x, c->mgu_vec[0].p);
+      v_cvt_d2f(c, S.nuo, x, c->mguf_vec[0].p);
       mg_uu_vcycle(Mu, 0);
-      v_copy(c, S.nuo, c->mgu_vec[1].p, y);
+      v_cvt_f2d(c, S.nuo, c->mguf_vec[1].p, y);
     };
     // one attempt of A~^-1 with the V-cycle; returns false when the result is not finite (a Chebyshev bound below the
     // spectral radius turns the smoothers into amplifiers)

@@ -266,6 +266,36 @@ __global__ __launch_bounds__(256) void k_ilu_solve(int64_t n_rows, const int32_t
   if (active && lig == 0) y[i] = FORWARD ? x[i] - s : (y[i] - s) / LU[rs + diag[i]];
 }
 
+// Jacobi sweeps on a triangular system instead of its exact solution (iterative triangular solves, Anzt / Chow / Dongarra):
+// forward  y <- x - (L - I) y_old,  backward  y <- (z - (U - D) y_old) / D, every row at once.  k sweeps reproduce the first k
+// terms of the Neumann series of the triangular inverse: an approximate application of the same ILU(0) factors in 2 k
+// launches whatever the number of levels.  A fixed k is a fixed linear operator: plain (non-flexible) GMRES may use it.
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void k_ilu_jacobi_sweep(int64_t n, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                          const int32_t *__restrict__ ent, const int32_t *__restrict__ n_low,
+                                                          const int32_t *__restrict__ diag, const double *__restrict__ LU,
+                                                          const double *__restrict__ rhs, const double *__restrict__ y_old,
+                                                          double *__restrict__ y_new) {
+  const int64_t i = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 4;
+  const int lig = threadIdx.x & 15;
+  const bool active = i < n;
+  const int64_t rs = active ? rp[i] : 0;
+  const int len = active ? int(rp[i + 1] - rs) : 0, nl = active ? n_low[i] : 0;
+  const int t0 = FORWARD ? 0 : nl + 1, t1 = FORWARD ? nl : len;
+  double s = 0;
+  for (int t = t0 + lig; t < t1; t += 16) {
+    const int32_t e = ent[rs + t];
+    s += LU[rs + e] * y_old[col[rs + e]];
+  }
+  for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+  if (active && lig == 0) y_new[i] = FORWARD ? rhs[i] - s : (rhs[i] - s) / LU[rs + diag[i]];
+}
+__global__ void k_ilu_diag_scale(int64_t n, const int64_t *__restrict__ rp, const int32_t *__restrict__ diag,
+                                 const double *__restrict__ LU, const double *__restrict__ x, double *__restrict__ y) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = x[i] / LU[rp[i] + diag[i]];
+}
+
 // a run of consecutive SMALL levels in one launch: one workgroup of 64 row groups walks the levels with a workgroup barrier in
 // between (natural-order ILU(0) of a 2D stencil has hundreds of levels of a few dozen rows: one launch per level is
 // launch-bound).  y is read and written with agent-scope accesses: the rows of the previous level were written by other
@@ -363,6 +393,32 @@ void tpp_ilu_factor(ifem_ctx *ctx) {
 void tpp_ilu_apply(ifem_ctx *ctx, const double *x, double *y) {
   TppIlu &I = ctx->tpp_ilu;
   hipStream_t s = ctx->stream;
+  const int sweeps = ctx->tune.tpp_tri_sweeps;
+  if (sweeps > 0) { // approximate triangular solves: 2 * sweeps row-parallel launches
+    const int64_t n = ctx->Sm.n_rows;
+    if ((int64_t)I.t0.n < n) { I.t0.alloc((size_t)n); I.t1.alloc((size_t)n); }
+    const dim3 g(unsigned((n * 16 + 255) / 256)), b(256);
+    // forward: start from y0 = x (the zeroth Neumann term), ping-pong between t0 and t1
+    const double *cur = x;
+    double *bufs[2] = {I.t0.p, I.t1.p};
+    for (int k = 0; k < sweeps; ++k) {
+      double *nxt = bufs[k & 1];
+      hipLaunchKernelGGL((k_ilu_jacobi_sweep<true>), g, b, 0, s, n, ctx->Sm.rowptr.p, ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, cur, nxt);
+      cur = nxt;
+    }
+    const double *z = cur; // L^-1 x (approximately): the right-hand side of the backward system, lives in one of the buffers
+    // backward: y0 = D^-1 z into y, then sweeps ping-pong between y and the buffer that does not hold z
+    hipLaunchKernelGGL(k_ilu_diag_scale, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, ctx->Sm.rowptr.p, I.diag.p, I.LU.p, z, y);
+    double *other = (z == I.t0.p) ? I.t1.p : I.t0.p;
+    const double *curb = y;
+    for (int k = 0; k < sweeps; ++k) {
+      double *nxt = (curb == y) ? other : y;
+      hipLaunchKernelGGL((k_ilu_jacobi_sweep<false>), g, b, 0, s, n, ctx->Sm.rowptr.p, ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, z, curb, nxt);
+      curb = nxt;
+    }
+    if (curb != y) IFEM_HIP_CHECK(hipMemcpyAsync(y, curb, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return;
+  }
   auto sweep = [&](bool forward) {
     const auto &plan = forward ? I.plan_f : I.plan_b;
     const auto &lvl = forward ? I.lvl_f : I.lvl_b;

@@ -22,11 +22,12 @@ else:
     dofs, vals = m.dirichlet({0: (7, [0.5, 0, 0]), 2: (7, [0, 0, 0]), 3: (7, [0, 0, 0]), 4: (7, [0, 0, 0]), 5: (7, [0, 0, 0])})
 P = capi.make_scns_params(mu=1.8e-4, rho=1.3e-3, dt=1e-2)
 print(kind, arg, "pressure rows", m.n_pnodes, flush=True)
-for order, milu in ((-1, 0), (0, 0), (0, 800), (0, 950), (0, 1000), (1, 0), (1, 950)):
+combos = ((-1, 0, 0), (0, 950, 0), (1, 0, 0), (0, 950, 2), (0, 950, 4), (0, 950, 8), (0, 950, 16), (0, 0, 4), (0, 0, 8), (0, 1000, 8), (1, 0, 4), (1, 0, 8))
+for order, milu, sweeps in combos:
     ctx = capi.Context(m.dim, m.kv, m.vcoords, m.cell_unodes, m.cell_pnodes, m.cell_face_bid, m.n_unodes, m.n_pnodes)
     t = capi.Tuning()
     ctx.L.ifem_default_tuning(C.byref(t))
-    t.tpp_ilu_order, t.tpp_milu_permille = order, milu
+    t.tpp_ilu_order, t.tpp_milu_permille, t.tpp_tri_sweeps = order, milu, sweeps
     assert ctx.L.ifem_set_tuning(ctx.h, C.byref(t)) == 0
     ctx.set_constraints(0, dofs, None)
     ctx.set_constraints(1, dofs, vals)
@@ -34,8 +35,8 @@ for order, milu in ((-1, 0), (0, 0), (0, 800), (0, 950), (0, 1000), (1, 0), (1, 
     t0 = time.time()
     try:
         st = ctx.scns_solve(True)
-        print(f"order {order} milu {milu}: outer {st.fgmres_iters}, inner per application {st.inner_iters / max(st.precond_applies, 1):.1f}, "
+        print(f"order {order} milu {milu} tri_sweeps {sweeps}: outer {st.fgmres_iters}, inner per application {st.inner_iters / max(st.precond_applies, 1):.1f}, "
               f"solve {time.time() - t0:.2f} s", flush=True)
     except Exception as e:
-        print(f"order {order} milu {milu}: FAILED {e}", flush=True)
+        print(f"order {order} milu {milu} tri_sweeps {sweeps}: FAILED {e}", flush=True)
     ctx.close()
