@@ -2,10 +2,12 @@
     python tools/asmbench.py [n] [variant:waves[:asm_skip[:cells per workgroup]] ...]      e.g.  128 0:3 0:4 0:2 1:2 0:3:1 0:3:0:1
 variant = ifem_tuning::asm3_variant (0 tables rebuilt on the fly, 1 per-cell tables in LDS), waves = asm3_waves, asm_skip =
 the measurement switch (1: no A_uu scatter, 2: no contraction either).  Prints warm (cached geometry blocks) and cold
-(geo_cache = 0: B, B^T, M_p, diag(M_u) re-integrated) kernel times, median of 5."""
+(geo_cache = 0: B, B^T, M_p, diag(M_u) re-integrated) kernel times and the wall time of the whole ifem_ins_assemble call (zero
+fills included), median of 5."""
 import ctypes as C
 import os
 import sys
+import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openifem_amd import capi, host
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
@@ -26,11 +28,15 @@ def tune(**kw):
 
 
 def med(k=5):
-    v = []
+    v, w = [], []
     for _ in range(k):
+        s.synchronize()
+        t0 = time.time()
         s.assemble(False)
+        s.synchronize()
+        w.append((time.time() - t0) * 1e3)
         v.append(s.timing().assemble_kernel_ms)
-    return sorted(v)[len(v) // 2]
+    return sorted(v)[len(v) // 2], sorted(w)[len(w) // 2]
 
 
 for c in combos:
@@ -38,9 +44,9 @@ for c in combos:
     variant, waves, skip, cpb = f[0], f[1], (f[2] if len(f) > 2 else 0), (f[3] if len(f) > 3 else 2)
     tune(asm3_variant=variant, asm3_waves=waves, asm_skip=skip, asm3_cpb=cpb)
     s.assemble(False)
-    warm = med()
-    cold = float("nan")
+    warm, warm_wall = med()
+    cold = cold_wall = float("nan")
     if not WARM_ONLY:
         tune(asm3_variant=variant, asm3_waves=waves, asm_skip=skip, asm3_cpb=cpb, geo_cache=0)
-        cold = med(3)
-    print(f"n {n} variant {variant} waves {waves} cells/workgroup {cpb} asm_skip {skip}: warm kernel {warm:.2f} ms, cold kernel {cold:.2f} ms", flush=True)
+        cold, cold_wall = med(3)
+    print(f"n {n} variant {variant} waves {waves} cells/workgroup {cpb} asm_skip {skip}: warm kernel {warm:.2f} ms (call {warm_wall:.2f}), cold kernel {cold:.2f} ms (call {cold_wall:.2f})", flush=True)
