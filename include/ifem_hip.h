@@ -141,7 +141,10 @@ typedef struct {
                                  gives 7.8e-5 ||rhs|| after one outer iteration where 1e-2 gives 9.1e-4 and needs a second
                                  one.  Only used when that first residual is velocity-dominated (pressure share below
                                  inner_first_pshare): a residual that is mostly continuity equation (later Newton iterations)
-                                 needs several outer iterations whatever the velocity solve does */
+                                 needs several outer iterations whatever the velocity solve does.  Self-correcting: when a solve
+                                 that used it still needed a second outer iteration (the extra inner iterations bought nothing:
+                                 64^3 channel), the context skips it for its next 8 (16, 32, 64 after repeated misses) qualifying
+                                 solves before trying again */
   double  inner_first_pshare; /* 0 (default): 10 fgmres_rel.  The largest pressure share ||r_p|| / ||r|| of the first Krylov vector
                                  for which inner_rel_first is used -- a heuristic: the block-triangular preconditioner leaves
                                  O(0.1) of the pressure part of a residual behind per outer iteration */
@@ -189,6 +192,7 @@ typedef struct {
   uint32_t precond_applies, cg_mp_iters, cg_sm_iters, inner_iters;
   double t_schur_setup_ms, t_cg_mp_ms, t_cg_sm_ms, t_ainv_ms, t_spmv_ms, t_total_ms;
   uint32_t sm_mg_levels; /* levels used by the multigrid-preconditioned CG(S_m) of the last solve (0: plain CG) */
+  uint32_t inner_first_tight; /* 1: the first preconditioner application of this solve ran with inner_rel_first */
 } ifem_solve_stats;
 
 /* context-resident block vectors (reference members of FluidSolver / InsIM) */

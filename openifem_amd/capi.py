@@ -81,7 +81,7 @@ class SolveStats(C.Structure):
                 ("cg_mp_iters", C.c_uint32), ("cg_sm_iters", C.c_uint32), ("inner_iters", C.c_uint32),
                 ("t_schur_setup_ms", C.c_double), ("t_cg_mp_ms", C.c_double), ("t_cg_sm_ms", C.c_double),
                 ("t_ainv_ms", C.c_double), ("t_spmv_ms", C.c_double), ("t_total_ms", C.c_double),
-                ("sm_mg_levels", C.c_uint32)]
+                ("sm_mg_levels", C.c_uint32), ("inner_first_tight", C.c_uint32)]
 
 
 class MgTransfer(C.Structure):

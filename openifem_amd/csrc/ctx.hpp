@@ -338,5 +338,6 @@ struct ifem_ctx {
   // timing
   ifem_timing timing{};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int tight_first_misses = 0, tight_first_backoff = 0; // ifem_solver_opts::inner_rel_first: consecutive misses, qualifying solves left to skip
   double spmv_uu_ms_total = 0;
 };

@@ -263,6 +263,7 @@ struct SolveState {
   ifem_solve_stats st{};
   int64_t nuo, npo, n;
   double p_src_norm = 0, u_src_norm = 0; // norms of the pressure / velocity parts of the vector the preconditioner is applied to
+  bool tight_candidate = false, tight_used = false; // inner_rel_first: the solve qualified for it / its first application ran with it
   // workspace carved out of ctx->work
   double *xu_ext, *xp_ext, *tu, *tp[6], *utmp, *inner_w, *inner_z, *outer_w;
 };
@@ -858,7 +859,15 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   // bench.py: 1.16 s against 1.27 s with the tight first application everywhere)
   const double pshare_max = o->inner_first_pshare > 0 ? o->inner_first_pshare : 10.0 * o->fgmres_rel;
   const bool pressure_dominated = S.p_src_norm > pshare_max * std::hypot(S.u_src_norm, S.p_src_norm);
-  const double inner_rel_now = (S.st.precond_applies == 0 && o->inner_rel_first > 0 && !pressure_dominated) ? o->inner_rel_first : o->inner_rel;
+  // ... and while it pays: a solve whose tight first application did NOT end the outer iteration at its first check has spent
+  // the extra inner iterations for nothing (64^3 channel: 2 outer iterations either way, 29.8 instead of 24.5 ms).  After such a
+  // miss the context leaves the option off for its next 8 / 16 / 32 / 64 qualifying solves (ins_solve keeps the count), then tries again.
+  bool tight = false;
+  if (S.st.precond_applies == 0 && o->inner_rel_first > 0 && !pressure_dominated) {
+    S.tight_candidate = true;
+    tight = S.tight_used = c->tight_first_backoff == 0;
+  }
+  const double inner_rel_now = tight ? o->inner_rel_first : o->inner_rel;
   if (o->verbose && S.st.precond_applies == 0)
     fprintf(stderr, "[ifem] first preconditioner application: pressure share of the residual %.3e, inner tolerance %.1e\n",
             S.p_src_norm / std::max(std::hypot(S.u_src_norm, S.p_src_norm), 1e-300), inner_rel_now);
@@ -1117,6 +1126,13 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   apply_constraints(ctx, use_nonzero ? 1 : 0, upd); // constraints_used.distribute(newton_update)
   hanging_distribute(ctx, upd);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  // inner_rel_first pays only when it ends the outer iteration at its first check (precond_vmult); `it` is the same on all ranks
+  if (S.tight_used) {
+    if (it <= 1) ctx->tight_first_misses = 0;
+    else { ctx->tight_first_misses = std::min(ctx->tight_first_misses + 1, 4); ctx->tight_first_backoff = 4 << ctx->tight_first_misses; }
+  } else if (S.tight_candidate && ctx->tight_first_backoff > 0)
+    ctx->tight_first_backoff--;
+  S.st.inner_first_tight = S.tight_used ? 1u : 0u;
   S.st.fgmres_iters = it;
   S.st.fgmres_res = res;
   S.st.t_total_ms = total.ms();

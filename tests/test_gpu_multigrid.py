@@ -326,6 +326,35 @@ def test_tight_first_inner_solve_saves_outer_iterations_only_on_velocity_dominat
     s.close()
 
 
+def test_tight_first_inner_solve_backs_off_after_a_miss():
+    """inner_rel_first is self-correcting: a solve that used it and still needed a second outer iteration has bought nothing
+    with the extra inner iterations, so the context leaves it off for its next 8 qualifying solves (16, 32, 64 after repeated
+    misses) and then tries again; a solve that ends at its first check keeps it on.  The miss is forced here with an outer
+    tolerance no single iteration reaches."""
+    s = _hierarchy((16, 16, 16))
+    s.channel_state()
+    s.opts.ainv_kind, s.opts.inner_restart = 4, 16
+    s.opts.inner_rel_first = 5e-5
+    s.opts.inner_first_pshare = 1e-2  # (the default, 10 fgmres_rel, moves with the outer tolerance this test plays with)
+    s.assemble(False)
+    s.opts.fgmres_rel = 1e-9
+    used = []
+    for _ in range(11):
+        st = s.solve(False)
+        assert st.fgmres_iters > 1
+        used.append(st.inner_first_tight)
+    assert used == [1] + [0] * 8 + [1, 0], used  # miss -> 8 solves without it -> retry -> second miss: 16 solves off
+    # a solve that does end at its first check (outer tolerance 0.5) switches it back on for good
+    s.opts.fgmres_rel = 0.5
+    seen = []
+    for _ in range(20):
+        st = s.solve(False)
+        assert st.fgmres_iters == 1
+        seen.append(st.inner_first_tight)
+    assert seen[:15] == [0] * 15 and seen[15:] == [1] * 5, seen
+    s.close()
+
+
 @pytest.mark.parametrize("P", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
 def test_multigrid_ainv_on_virtual_ranks(P):
     """the bench configuration (IFEM_AINV_MG + multigrid CG(S_m), halo overlap on) on the partitions bench.py uses for 2, 4 and
