@@ -51,6 +51,8 @@ struct Cell3 : std::conditional<OTF, Cell3Otf, Cell3Tabs>::type {
   int32_t un[NU], pn[NP];
   int32_t bid[6], ind; // boundary ids of the faces (only read with Neumann conditions), FSI indicator of the cell
   uint8_t cf[ND + 7];
+  uint8_t perm[32];    // tile column -> local node, the cell's nodes in the order of their (local) node ids: the order of the columns
+                       // in every row of the sorted pattern, so that neighbouring lanes of the staged scatter hit neighbouring blocks
 };
 
 struct Shared3 {
@@ -183,6 +185,16 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
     }
   }
   __syncthreads();
+  if (h == 1 && lane < 32) { // rank of every node id among the cell's 27 (ids are distinct); columns 27..31 of the tiles stay padding
+    int rank = lane;
+    if (lane < NU) {
+      const int32_t mine = S.un[lane];
+      rank = 0;
+#pragma unroll 9
+      for (int j = 0; j < NU; ++j) rank += S.un[j] < mine ? 1 : 0;
+    }
+    S.perm[rank] = uint8_t(lane);
+  }
   if (h == 0 && lane < NP * DIM) { // monomial coefficients of the trilinear map
     const int k = lane / DIM, e = lane % DIM;
     double acc = 0;
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
 #pragma unroll 1
     for (int tp = 2 * h; tp < 2 * h + 2; ++tp) {
       const int ti = tp >> 1, tj = tp & 1;
-      const int al = 16 * ti + (lane & 15), bl = 16 * tj + (lane & 15); // my A-row node, my B-column node
+      const int al = 16 * ti + (lane & 15), bl = S.perm[16 * tj + (lane & 15)]; // my A-row node, my B-column node (columns in node-id order)
       const bool av = al < NU, bv = bl < NU;
       const int ac_ = av ? al : 0, bc_ = bv ? bl : 0;
       d4 acc[BS], sac = {0, 0, 0, 0};
