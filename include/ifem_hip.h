@@ -181,7 +181,9 @@ typedef struct {
   int64_t basis_pad;     /* 32*33 doubles of padding between Krylov basis columns (HBM channel spread) */
   int32_t tpp_tri_sweeps; /* SCnsIM, ILU(0) of T_pp: 0 (default) exact level-scheduled triangular solves; k > 0: k Jacobi sweeps per
                              triangular system instead (2 k row-parallel launches whatever the number of levels) */
-  int32_t reserved_;
+  int32_t uu_row_order;  /* 1 (default): 3D Q2/Q1 contexts store the blocks of an A_uu row in the order (last cell, first cell, column) of the
+                            cells that touch them instead of column order, so that a cell's part of a row is a few contiguous runs for the
+                            cell kernel's atomics (takes effect before the first assembly of the context); 0: column order */
 } ifem_tuning;
 void ifem_default_tuning(ifem_tuning *t);
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t);

@@ -80,6 +80,18 @@ __device__ __forceinline__ void shape_otf(const Shared3Otf &T, const double *__r
   for (int d = 0; d < 3; ++d) g[d] = r[0] * Jq[d] + r[1] * Jq[3 + d] + r[2] * Jq[6 + d];
 }
 
+// rank of `key` among the 16 lanes of my row of lanes (keys distinct): 15 row rotations by DPP, no LDS.  The staged scatter
+// orders the 16 node pairs of a matrix row by their position in that row, so that neighbouring lanes of its atomics hit
+// neighbouring blocks whatever order the row stores its blocks in (setup.hip: scatter order of the A_uu rows).
+__device__ __forceinline__ int rank_in_row16(unsigned key) {
+  int rank = 0;
+#define IFEM_ROR16(n) rank += unsigned(__builtin_amdgcn_update_dpp(0, int(key), 0x120 + n, 0xf, 0xf, false)) < key ? 1 : 0;
+  IFEM_ROR16(1) IFEM_ROR16(2) IFEM_ROR16(3) IFEM_ROR16(4) IFEM_ROR16(5) IFEM_ROR16(6) IFEM_ROR16(7) IFEM_ROR16(8)
+  IFEM_ROR16(9) IFEM_ROR16(10) IFEM_ROR16(11) IFEM_ROR16(12) IFEM_ROR16(13) IFEM_ROR16(14) IFEM_ROR16(15)
+#undef IFEM_ROR16
+  return rank;
+}
+
 // CPB cells per workgroup, TWO wavefronts per cell (h = 0, 1) sharing the cell's LDS tables: the tables cap the
 // workgroup at ~150 KB of LDS, and one wave per SIMD leaves every LDS / global round trip exposed; with two waves per
 // cell the SIMDs hold two waves each.  Phases are separated by workgroup barriers (uniform control flow).
@@ -90,6 +102,7 @@ template <int CPB, bool OTF, int WAVES>
 __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES ? WAVES : 1, WAVES ? WAVES : 4))) void k_ins_assemble3(AsmArgs A, Tab1D t1) {
   constexpr int DIM = 3, N1 = 3, NU = 27, NP = 8, NQ = 27, ND = 89, BS = 9;
   constexpr int NBP = NU * NP, BROUNDS = (NBP + 63) / 64, FR = (ND + 63) / 64;
+  constexpr int SPAN = 16 * BS + 8; // lanes per staged matrix row in the scatter: 16 blocks + up to 7 lanes of alignment shift
   extern __shared__ __align__(16) unsigned char smem[];
   using Shared = typename std::conditional<OTF, Shared3Otf, Shared3>::type;
   Shared &T = *reinterpret_cast<Shared *>(smem);
@@ -535,6 +548,8 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
       for (int r = 0; r < 4; ++r) {
         const int a = 16 * ti + (lane >> 4) + 4 * r, b = bl;
         const bool have = active && a < NU && b < NU && S.len_uu[a < NU ? a : 0] >= 0 && !A.debug_skip;
+        // stage slot: my 16-lane group holds one matrix row; its pairs in the order of their positions in that row
+        const int slot = (lane & 48) | rank_in_row16(bv ? (unsigned(posr[r]) << 4 | unsigned(lane & 15)) : (0x100000u | unsigned(lane & 15)));
         int64_t off = -1;
         if (have) {
           const uint16_t pos = posr[r];
@@ -544,7 +559,7 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
           if (A.v_s) unsafeAtomicAdd(A.v_s + S.rs_uu[a] + pos, s);
           if (!any_c) {
 #pragma unroll
-            for (int e = 0; e < BS; ++e) stage[lane * BS + e] = acc[e][r] + ((e == 0 || e == 4 || e == 8) ? s : 0.0);
+            for (int e = 0; e < BS; ++e) stage[slot * BS + e] = acc[e][r] + ((e == 0 || e == 4 || e == 8) ? s : 0.0);
           } else
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
@@ -564,17 +579,24 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
                 const double g = S.cv[b * 3 + d];
                 if (g != 0.0) unsafeAtomicAdd(&S.fe[a * 3 + c], -v * g);
               }
-              stage[lane * BS + c * 3 + d] = w;
+              stage[slot * BS + c * 3 + d] = w;
             }
           }
         }
-        soff[lane] = off;
+        soff[slot] = off;
         wsync2();
+        // lane = (pair, entry) of the four matrix rows staged above, each row's 144 values shifted by the position of its first
+        // block inside a 64-byte segment: an instruction boundary (every 64 lanes) then falls on a segment boundary wherever the
+        // row's blocks are contiguous, instead of making two instructions touch the same segment (tools/scatter_sim.py)
 #pragma unroll
-        for (int rr = 0; rr < BS; ++rr) {
-          const int t = lane + 64 * rr, pl = t / BS, e = t - pl * BS;
-          const int64_t o = soff[pl];
-          const double w = stage[t];
+        for (int rr = 0; rr < BS + 1; ++rr) {
+          const int t = lane + 64 * rr, g = t / SPAN;
+          const int64_t o0 = soff[16 * (g < 4 ? g : 0)];
+          const int u = t - g * SPAN - (o0 >= 0 ? int(o0 & 7) : 0);
+          const bool in = g < 4 && u >= 0 && u < 16 * BS;
+          const int uc = in ? u : 0, pl = uc / BS, e = uc - pl * BS;
+          const int64_t o = in ? soff[16 * g + pl] : -1;
+          const double w = stage[(16 * (g < 4 ? g : 0) + pl) * BS + e];
           if (o >= 0 && w != 0.0) unsafeAtomicAdd(A.v_uu + o + e, w);
         }
         wsync2();

@@ -321,6 +321,7 @@ struct ifem_ctx {
   bool bjac_f32_valid = false;
   // scatter maps: position of the column inside the row, 0xFFFF = row not owned here
   ifem::DBuf<uint16_t> posUU, posUP, posPU, posPP;
+  ifem::DBuf<int32_t> uu_diag_pos; // position of the diagonal block in every owned A_uu row (setup.hip::ensure_auu_values)
   // constraints (local dof numbering), sets 0 = zero, 1 = nonzero
   ifem::DBuf<uint8_t> is_c[2];
   ifem::DBuf<double> cval[2];

@@ -1183,19 +1183,13 @@ void v_minmax(ifem_ctx *ctx, int64_t n, const double *x, double *mn, double *mx)
 // ---------------------------------------------------------------------------------------------------
 // node-block Jacobi: inverse of the dim x dim diagonal blocks of A_uu
 template <int DIM>
-__global__ void k_bjac_setup(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+__global__ void k_bjac_setup(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ diag_pos,
                              const double *__restrict__ val, double *__restrict__ out) {
   const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (row >= n_rows) return;
   const int64_t rs = rp[row];
   const int len = int(rp[row + 1] - rs);
-  int lo = 0, hi = len - 1, pos = -1;
-  while (lo <= hi) {
-    const int mid = (lo + hi) >> 1;
-    const int32_t v = col[rs + mid];
-    if (v == row) { pos = mid; break; }
-    if (v < row) lo = mid + 1; else hi = mid - 1;
-  }
+  const int pos = diag_pos[row]; // (the blocks of a row are not necessarily in column order: setup.hip)
   double D[DIM * DIM], Di[DIM * DIM];
   for (int e = 0; e < DIM * DIM; ++e) D[e] = (pos >= 0) ? val[uu_base(rs, len, pos, DIM * DIM) + int64_t(e) * uu_estride(len)] : ((e / DIM == e % DIM) ? 1.0 : 0.0);
   if constexpr (DIM == 2) {
@@ -1264,10 +1258,10 @@ void bjac_setup(ifem_ctx *ctx) {
   if (!n) return;
   if (ctx->dim == 3)
     hipLaunchKernelGGL((k_bjac_setup<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
-                       ctx->Auu.rowptr.p, ctx->Auu.col.p, ctx->Auu.val.p, ctx->bjac.p);
+                       ctx->Auu.rowptr.p, ctx->uu_diag_pos.p, ctx->Auu.val.p, ctx->bjac.p);
   else
     hipLaunchKernelGGL((k_bjac_setup<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
-                       ctx->Auu.rowptr.p, ctx->Auu.col.p, ctx->Auu.val.p, ctx->bjac.p);
+                       ctx->Auu.rowptr.p, ctx->uu_diag_pos.p, ctx->Auu.val.p, ctx->bjac.p);
 }
 
 void bjac_apply(ifem_ctx *ctx, const double *x, double *y) {

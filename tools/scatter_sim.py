@@ -1,17 +1,25 @@
 """How many 64-byte segments does the staged A_uu scatter of k_ins_assemble3 touch per cell?  (CPU only: the C++ host mirror's
 DoF tables, the block-interleaved layout of ctx.hpp and the lane -> (pair, entry) mapping of assemble3.hip, replayed in numpy.)
 The memory-side atomic path retires ~24 G such segments per second whatever the data type, scope, footprint or number of CUs
-(profiles/r03_atomics_types.txt), so this count is the kernel's floor.  Compares column orders of the MFMA tiles.
+(profiles/r03_atomics_types.txt), so this count is the kernel's floor.
 
-    python tools/scatter_sim.py [n] [order ...]     order: lex (shipped), morton, sorted (by global node id per cell)"""
-import sys
+    python tools/scatter_sim.py [n] [--lex-nodes]
+
+replays, on the n^3 channel mesh of the host mirror,
+  rows "col"   : blocks of a row in column order;           rows "cells": in the order (last cell, first cell, column) (setup.hip)
+  tiles "lex"  : tile columns in the element's node order;  tiles "id"  : in the order of the cell's node ids (Cell3::perm)
+  slots "lane" : stage slot = lane;                         slots "rank": the 16 pairs of a matrix row by their position in it;
+  slots "aligned": as "rank", every staged row shifted by the position of its first block inside a 64-byte segment (152 lanes per row)
+and prints segments per cell next to the floor of the row order (one ideal instruction per cell row) and of the layout (820)."""
 import os
+import sys
+from collections import defaultdict
+
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openifem_amd import host
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-orders = [a for a in sys.argv[2:] if not a.startswith("--")] or ["lex", "morton", "sorted"]
+n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else 12
 s = host.InsIM(host.channel_prm(3), (n, n, n), (0, 0, 0), (2.0, 0.2, 0.2))
 s.set_multigrid(False)
 if "--lex-nodes" in sys.argv:
@@ -19,73 +27,73 @@ if "--lex-nodes" in sys.argv:
 s.setup_host_only(0)
 cu, _, _, _ = s.cell_tables()
 nc, NU = cu.shape
-nn = cu.max() + 1
-# row patterns: sorted unique neighbours
-pairs = np.unique((cu[:, :, None].astype(np.int64) * nn + cu[:, None, :]).ravel())
-rows, cols = pairs // nn, pairs % nn
-rowptr = np.zeros(nn + 1, np.int64)
-np.add.at(rowptr, rows + 1, 1)
-rowptr = np.cumsum(rowptr)
-key = pairs  # sorted: position of (r, c) = searchsorted(key, r * nn + c)
+nn = int(cu.max()) + 1
+rowcells = [defaultdict(list) for _ in range(nn)]  # row -> column -> cells that hold both
+for c in range(nc):
+    nd = cu[c]
+    for a in nd:
+        rc = rowcells[a]
+        for b in nd:
+            rc[b].append(c)
 
 
-def block_addr(a_nodes, b_nodes):
-    """byte offset of block (a, b) in the block-interleaved value array"""
-    return np.searchsorted(key, a_nodes.astype(np.int64) * nn + b_nodes) * 72
+def build_rows(kind):
+    pos, rowptr = [None] * nn, np.zeros(nn + 1, np.int64)
+    for r in range(nn):
+        rc = rowcells[r]
+        key = (lambda b: b) if kind == "col" else (lambda b: (max(rc[b]), min(rc[b]), b))
+        cols = sorted(rc.keys(), key=key)
+        pos[r] = {b: k for k, b in enumerate(cols)}
+        rowptr[r + 1] = rowptr[r] + len(cols)
+    return pos, rowptr
 
 
-lexmorton = sorted(range(27), key=lambda b: (sum(((b // 3 ** d) % 3 >> 1) << d for d in range(3)) << 3 | sum(((b // 3 ** d) % 3 & 1) << d for d in range(3))))
-
-
-def simulate(order, cells):
-    total_seg = total_inst = total_atom = 0
+def replay(pos, rowptr, cells, tiles, slots):
+    floor = tot = inst = 0
+    lanes = np.arange(64)
     for c in cells:
         nd = cu[c]
-        if order == "lex":
-            perm = list(range(27))
-        elif order == "morton":
-            perm = lexmorton
-        else:
-            perm = list(np.argsort(nd, kind="stable"))
-        perm = perm + [-1] * 5  # 32 tile columns
+        for a in nd:
+            addr = (np.array([rowptr[a] + pos[a][b] for b in nd]) * 72)[:, None] + 8 * np.arange(9)[None, :]
+            floor += len(np.unique(addr // 64))
+        perm = (list(range(27)) if tiles == "lex" else list(np.argsort(nd, kind="stable"))) + [-1] * 5
         for ti in range(2):
             for tj in range(2):
                 for r in range(4):
-                    a = 16 * ti + (np.arange(64) >> 4) + 4 * r
-                    bcol = 16 * tj + (np.arange(64) & 15)
-                    b = np.array([perm[x] for x in bcol])
-                    ok = (a < 27) & (b >= 0)
-                    off = np.full(64, -1, np.int64)
-                    off[ok] = block_addr(nd[a[ok]], nd[b[ok]])
-                    for rr in range(9):
-                        t = np.arange(64) + 64 * rr
-                        pl, e = t // 9, t % 9
-                        o = off[pl]
+                    off = np.full(64, -1, np.int64)  # per stage slot
+                    for g in range(4):
+                        a = 16 * ti + g + 4 * r
+                        cols = [perm[16 * tj + j] for j in range(16)]
+                        p = [pos[nd[a]][nd[b]] if (a < 27 and b >= 0) else None for b in cols]
+                        key = [(q << 4 | j) if q is not None else (0x100000 | j) for j, q in enumerate(p)]
+                        rank = np.arange(16) if slots == "lane" else np.argsort(np.argsort(key))
+                        for j in range(16):
+                            if p[j] is not None:
+                                off[16 * g + rank[j]] = (rowptr[nd[a]] + p[j]) * 72
+                    span = 152 if slots == "aligned" else 144
+                    for rr in range(10 if slots == "aligned" else 9):
+                        t = lanes + 64 * rr
+                        g = t // span
+                        gc = np.minimum(g, 3)
+                        o0 = off[16 * gc]
+                        u = t - g * span - (np.where(o0 >= 0, (o0 // 8) & 7, 0) if slots == "aligned" else 0)
+                        ok = (g < 4) & (u >= 0) & (u < 144)
+                        uc = np.where(ok, u, 0)
+                        o = np.where(ok, off[16 * gc + uc // 9], -1)
                         v = o >= 0
-                        if not v.any():
-                            continue
-                        addr = o[v] + 8 * e[v]
-                        total_seg += len(np.unique(addr // 64))
-                        total_inst += 1
-                        total_atom += int(v.sum())
-    return total_seg / len(cells), total_inst / len(cells), total_atom / len(cells)
-
-
-def row_floor(cells):
-    """segments per cell if every (cell, row) were scattered by one ideal instruction: what the numbering alone allows"""
-    tot = 0
-    for c in cells:
-        nd = cu[c]
-        for a in range(27):
-            addr = block_addr(np.full(27, nd[a]), nd)[:, None] + 8 * np.arange(9)[None, :]
-            tot += len(np.unique(addr // 64))
-    return tot / len(cells)
+                        if v.any():
+                            tot += len(np.unique((o[v] + 8 * (uc % 9)[v]) // 64))
+                            inst += 1
+    k = len(cells)
+    return floor / k, tot / k, inst / k
 
 
 rng = np.random.default_rng(1)
-cells = rng.choice(nc, size=min(nc, 400), replace=False)
-print(f"{n}^3 cells, {len(cells)} sampled; layout floor 729 * 72 / 64 = {729 * 72 / 64:.0f} segments per cell")
-print(f"floor of this node numbering (one ideal instruction per cell row): {row_floor(cells):.1f} segments per cell")
-for o in orders:
-    seg, inst, atom = simulate(o, cells)
-    print(f"column order {o:7s}: {seg:7.1f} segments per cell ({seg / 729:.3f} per block), {inst:.1f} atomic instructions, {atom:.0f} atomics")
+cells = rng.choice(nc, size=min(nc, 200), replace=False)
+print(f"{n}^3 cells, {len(cells)} sampled; layout floor 729 * 72 / 64 = 820 segments per cell")
+for rows in ("col", "cells"):
+    pos, rowptr = build_rows(rows)
+    for tiles, slots in (("lex", "lane"), ("id", "lane"), ("id", "rank"), ("id", "aligned")):
+        fl, seg, inst = replay(pos, rowptr, cells, tiles, slots)
+        tag = {("col", "lex", "lane"): "  <- rounds 1-2", ("col", "id", "lane"): "  <- 1fdd41d", ("cells", "id", "rank"): "  <- 96.6 ms", ("cells", "id", "aligned"): "  <- shipped"}.get((rows, tiles, slots), "")
+        print(f"rows {rows:5s} tiles {tiles:3s} slots {slots:4s}: {seg:7.1f} segments per cell ({seg / 729:.3f} per block; floor of this row order {fl:6.1f}), {inst:.0f} atomic instructions{tag}", flush=True)
