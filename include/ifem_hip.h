@@ -459,7 +459,9 @@ int ifem_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solve
 int ifem_tpp_ilu_probe(ifem_ctx *ctx, int64_t *rowptr, int32_t *col, double *val, const double *x, double *y, int32_t *levels);
 
 /* Export the assembled block system as one CSR over the local dofs [u|p] (host arrays; call twice: first
- * with col = val = NULL to get nnz through rowptr[n]).  which: 0 system_matrix, 1 mass (diag(M_u), M_p). */
+ * with col = val = NULL to get nnz through rowptr[n]).  which: 0 system_matrix, 1 mass (diag(M_u), M_p).
+ * The columns of a row are NOT sorted in general: 3D Q2/Q1 contexts store the velocity-velocity blocks of a row in scatter
+ * order (ifem_tuning::uu_row_order); every (row, column) appears once. */
 int ifem_export_csr(ifem_ctx *ctx, int which, int64_t *rowptr, int32_t *col, double *val);
 
 /* per-kernel timing of the last assemble/solve, HIP events on the context stream */
