@@ -44,13 +44,15 @@ struct Cell3 : std::conditional<OTF, Cell3Otf, Cell3Tabs>::type {
   double gqs[NQ * 9]; // rho JxW grad u
   // Ji[243] (TABLES layout) | Vc[243] | Sc[81] | divw[27] until the rhs is integrated, then the scatter staging of the cell's second wave
   double dead[STAGE];
-  double scratch[STAGE > NODAL ? STAGE : NODAL]; // nodal values (phase 1) | scatter staging of the cell's first wave
+  // nodal values (phase 1) | B entries in row order (second wave, uncached assemblies) | scatter staging of the cell's first wave
+  double scratch[(STAGE > NODAL ? STAGE : NODAL) > NU * NP * DIM ? (STAGE > NODAL ? STAGE : NODAL) : NU * NP * DIM];
   double fe[ND], cv[ND];
   int64_t rs_uu[NU], rs_bt[NU], rs_b[NP], rs_mp[NP];
   int32_t len_uu[NU], len_bt[NU], len_b[NP], len_mp[NP];
   int32_t un[NU], pn[NP];
   int32_t bid[6], ind; // boundary ids of the faces (only read with Neumann conditions), FSI indicator of the cell
   uint8_t cf[ND + 7];
+  uint8_t iperm[32], permp[8]; // rank of a velocity node among the cell's 27 (inverse of perm); pressure nodes in the order of their ids
   uint8_t perm[32];    // tile column -> local node, the cell's nodes in the order of their (local) node ids: the order of the columns
                        // in every row of the sorted pattern, so that neighbouring lanes of the staged scatter hit neighbouring blocks
 };
@@ -207,6 +209,14 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
       for (int j = 0; j < NU; ++j) rank += S.un[j] < mine ? 1 : 0;
     }
     S.perm[rank] = uint8_t(lane);
+    S.iperm[lane] = uint8_t(rank);
+  }
+  if (h == 1 && lane >= 32 && lane < 32 + NP) { // the same for the 8 pressure nodes (B^T and M_p rows are in column order)
+    const int32_t mine = S.pn[lane - 32];
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) rank += S.pn[j] < mine ? 1 : 0;
+    S.permp[rank] = uint8_t(lane - 32);
   }
   if (h == 0 && lane < NP * DIM) { // monomial coefficients of the trilinear map
     const int k = lane / DIM, e = lane % DIM;
@@ -406,12 +416,16 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
     const bool mine = (lane < ND && S.cf[lane] && S.cv[lane] != 0.0) || (lane + 64 < ND && S.cf[lane + 64] && S.cv[lane + 64] != 0.0);
     need_b = A.use_inhom && __any(mine);
   }
+  // Lanes = (velocity node a, pressure node in id order): the eight entries of a B^T row land next to each other.  The B entries go
+  // through LDS (bst, the idle scratch zone) into the order (pressure node, velocity nodes by id) = the order of B's rows, so that
+  // neighbouring lanes of its atomics hit neighbouring entries too: 984 -> ~530 64-byte segments per cell for B, B^T and M_p
+  double *const bst = S.scratch;
   if (need_b) {
 #pragma unroll 1
     for (int k = 0; k < BROUNDS; ++k) {
       const int t = lane + 64 * k;
       if (t >= NBP) continue;
-      const int a = t / NP, pb = t - a * NP;
+      const int a = t / NP, pb = S.permp[t - a * NP];
       double v[3] = {0, 0, 0};
 #pragma unroll 3
       for (int q = 0; q < NQ; ++q) {
@@ -435,13 +449,31 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
           else if (A.use_inhom && S.cv[NU * DIM + pb] != 0.0) unsafeAtomicAdd(&S.fe[a * DIM + c], -v[c] * S.cv[NU * DIM + pb]);
         }
       }
-      if (S.len_b[pb] >= 0 && !pc) {
+      const bool brow = S.len_b[pb] >= 0 && !pc;
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) {
+        double w = 0.0;
+        if (brow) {
+          if (!S.cf[a * DIM + c]) w = v[c];
+          else if (A.use_inhom && S.cv[a * DIM + c] != 0.0) unsafeAtomicAdd(&S.fe[NU * DIM + pb], -v[c] * S.cv[a * DIM + c]);
+        }
+        if (!A.skip_geo) bst[(pb * NU + S.iperm[a]) * DIM + c] = w;
+      }
+    }
+    if (!A.skip_geo) { // B in row order: lane = (pressure node, velocity node by id), one plane per instruction
+      wsync2();
+#pragma unroll 1
+      for (int k = 0; k < BROUNDS; ++k) {
+        const int t = lane + 64 * k;
+        if (t >= NBP) continue;
+        const int pb = t / NU, a = S.perm[t - pb * NU];
+        if (S.len_b[pb] < 0) continue;
         const int len = S.len_b[pb];
         double *base = A.v_b + S.rs_b[pb] * DIM + A.posPU[(cc * NP + pb) * NU + a];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
-          if (!S.cf[a * DIM + c]) { if (!A.skip_geo) unsafeAtomicAdd(base + int64_t(c) * len, v[c]); }
-          else if (A.use_inhom && S.cv[a * DIM + c] != 0.0) unsafeAtomicAdd(&S.fe[NU * DIM + pb], -v[c] * S.cv[a * DIM + c]);
+          const double w = bst[t * DIM + c];
+          if (w != 0.0) unsafeAtomicAdd(base + int64_t(c) * len, w);
         }
       }
     }
@@ -449,7 +481,7 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
   // ---- pressure mass matrix M_p and diag(M_u)
   if (!A.rhs_only && !A.skip_geo && A.debug_skip < 4) {
     if (h == 1 && lane < NP * NP) {
-      const int pa = lane / NP, pb = lane - pa * NP;
+      const int pa = lane / NP, pb = S.permp[lane - pa * NP];
       double m = 0;
 #pragma unroll 3
       for (int q = 0; q < NQ; ++q) m += S.JxW[q] * T.psi[q * NP + pa] * T.psi[q * NP + pb];
