@@ -128,8 +128,8 @@ static void pattern_from_keys(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_row
 // ---- scatter order of the A_uu rows (3D Q2/Q1 cell kernel).  The blocks of a row need not be stored in column order: nothing
 // but the scatter map and the column array know where a block lives.  The cell kernel's atomics cost one memory-side request
 // per 64-byte segment they touch, and a cell's 27 blocks of a row are contiguous only as far as no block of
-// another cell lies between them.  Ordering the blocks of a row by (last cell, first cell, column) of the cells that touch
-// them puts the blocks exclusive to a cell next to those it shares with its neighbours: a cell's part of a row becomes one to
+// another cell lies between them.  Ordering the blocks of a row by (last cell, [tile, below], first cell, column) of the cells
+// that touch them puts the blocks exclusive to a cell next to those it shares with its neighbours: a cell's part of a row becomes one to
 // four runs instead of fourteen (Morton numbering) -- 865 instead of 962 segments per cell before packing losses
 // (tools/scatter_sim.py).  Applied once, before the values exist; posUU is mapped through the permutation.
 __global__ void k_block_cells(int64_t n_cells, int NU, const int32_t *__restrict__ cu, int64_t n_rows_owned, const int64_t *__restrict__ rowptr,
@@ -145,10 +145,29 @@ __global__ void k_block_cells(int64_t n_cells, int NU, const int32_t *__restrict
     atomicMax(&cmax[e], int32_t(cell));
   }
 }
+// second key: in the LAST cell that touches a block, does the block's column belong to the second MFMA tile (columns 16..26 of
+// that cell's nodes in id order, Cell3::perm)?  The cell kernel scatters the two tiles of a matrix row at different times;
+// with the last cell's first-tile blocks in front of its second-tile blocks each piece stays one run (936 instead of 974 segments)
+__global__ void k_block_tile(int64_t n_cells, int NU, const int32_t *__restrict__ cu, int64_t n_rows_owned, const int64_t *__restrict__ rowptr,
+                             const uint16_t *__restrict__ pos, const int32_t *__restrict__ cmax, uint8_t *__restrict__ tile) {
+  const int64_t total = n_cells * NU * NU;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cell = t / (NU * NU);
+    const int rc = int(t - cell * NU * NU), a = rc / NU, b = rc - a * NU;
+    const int32_t row = cu[cell * NU + a];
+    if (row >= n_rows_owned) continue;
+    const int64_t e = rowptr[row] + pos[t];
+    if (cmax[e] != int32_t(cell)) continue;
+    const int32_t mine = cu[cell * NU + b];
+    int rank = 0;
+    for (int j = 0; j < NU; ++j) rank += cu[cell * NU + j] < mine ? 1 : 0;
+    tile[e] = rank >= 16 ? 1 : 0;
+  }
+}
 constexpr int kReorderMaxRow = 512;
-// one wavefront per row: rank of every block by (cmax, cmin, col); newpos[old entry] = rank, col_out in the new order
+// one wavefront per row: rank of every block by (cmax, tile, cmin, col); newpos[old entry] = rank, col_out in the new order
 __global__ __launch_bounds__(256) void k_row_reorder(int64_t n_rows, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                     const int32_t *__restrict__ cmin, const int32_t *__restrict__ cmax,
+                                                     const int32_t *__restrict__ cmin, const int32_t *__restrict__ cmax, const uint8_t *__restrict__ tile,
                                                      int32_t *__restrict__ col_out, uint16_t *__restrict__ newpos) {
   __shared__ uint64_t k1[4][kReorderMaxRow];
   __shared__ int32_t k2[4][kReorderMaxRow];
@@ -162,7 +181,7 @@ __global__ __launch_bounds__(256) void k_row_reorder(int64_t n_rows, const int64
     for (int i = lane; i < len; i += 64) { col_out[rs + i] = col[rs + i]; newpos[rs + i] = uint16_t(i); }
   if (sortable)
     for (int i = lane; i < len; i += 64) {
-      k1[wave][i] = (uint64_t(uint32_t(cmax[rs + i])) << 32) | uint32_t(cmin[rs + i]);
+      k1[wave][i] = (uint64_t(uint32_t(cmax[rs + i])) << 33) | (uint64_t(tile[rs + i]) << 32) | uint32_t(cmin[rs + i]);
       k2[wave][i] = col[rs + i];
     }
   __syncthreads();
@@ -201,7 +220,11 @@ static void reorder_uu_rows(ifem_ctx *ctx) {
   IFEM_HIP_CHECK(hipMemsetAsync(cmax.p, 0, (size_t)nnzb * sizeof(int32_t), s));
   const int64_t N = nc * ctx->nu * ctx->nu;
   hipLaunchKernelGGL(k_block_cells, dim3(grid_for(N)), dim3(256), 0, s, nc, ctx->nu, ctx->cell_unodes.p, M.n_rows, M.rowptr.p, ctx->posUU.p, cmin.p, cmax.p);
-  hipLaunchKernelGGL(k_row_reorder, dim3(unsigned((M.n_rows + 3) / 4)), dim3(256), 0, s, M.n_rows, M.rowptr.p, M.col.p, cmin.p, cmax.p, col2.p, newpos.p);
+  DBuf<uint8_t> tile;
+  tile.alloc((size_t)nnzb);
+  IFEM_HIP_CHECK(hipMemsetAsync(tile.p, 0, (size_t)nnzb, s));
+  hipLaunchKernelGGL(k_block_tile, dim3(grid_for(N)), dim3(256), 0, s, nc, ctx->nu, ctx->cell_unodes.p, M.n_rows, M.rowptr.p, ctx->posUU.p, cmax.p, tile.p);
+  hipLaunchKernelGGL(k_row_reorder, dim3(unsigned((M.n_rows + 3) / 4)), dim3(256), 0, s, M.n_rows, M.rowptr.p, M.col.p, cmin.p, cmax.p, tile.p, col2.p, newpos.p);
   hipLaunchKernelGGL(k_pos_remap, dim3(grid_for(N)), dim3(256), 0, s, nc, ctx->nu, ctx->cell_unodes.p, M.n_rows, M.rowptr.p, newpos.p, ctx->posUU.p);
   IFEM_HIP_CHECK(hipMemcpyAsync(M.col.p, col2.p, (size_t)nnzb * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
   IFEM_HIP_CHECK(hipStreamSynchronize(s));

@@ -6,7 +6,7 @@ The memory-side atomic path retires ~24 G such segments per second whatever the 
     python tools/scatter_sim.py [n] [--lex-nodes]
 
 replays, on the n^3 channel mesh of the host mirror,
-  rows "col"   : blocks of a row in column order;           rows "cells": in the order (last cell, first cell, column) (setup.hip)
+  rows "col"   : blocks of a row in column order;           rows "cells": in the order (last cell, its tile, first cell, column) (setup.hip)
   tiles "lex"  : tile columns in the element's node order;  tiles "id"  : in the order of the cell's node ids (Cell3::perm)
   slots "lane" : stage slot = lane;                         slots "rank": the 16 pairs of a matrix row by their position in it;
   slots "aligned": as "rank", every staged row shifted by the position of its first block inside a 64-byte segment (152 lanes per row)
@@ -28,6 +28,10 @@ s.setup_host_only(0)
 cu, _, _, _ = s.cell_tables()
 nc, NU = cu.shape
 nn = int(cu.max()) + 1
+rank_in_cell = {}  # (cell, node) -> rank of the node's id among the cell's 27: ranks 16..26 are the second MFMA tile's columns
+for c in range(nc):
+    for k, j in enumerate(np.argsort(cu[c], kind="stable")):
+        rank_in_cell[(c, cu[c][j])] = k
 rowcells = [defaultdict(list) for _ in range(nn)]  # row -> column -> cells that hold both
 for c in range(nc):
     nd = cu[c]
@@ -41,7 +45,7 @@ def build_rows(kind):
     pos, rowptr = [None] * nn, np.zeros(nn + 1, np.int64)
     for r in range(nn):
         rc = rowcells[r]
-        key = (lambda b: b) if kind == "col" else (lambda b: (max(rc[b]), min(rc[b]), b))
+        key = (lambda b: b) if kind == "col" else (lambda b: (max(rc[b]), rank_in_cell[(max(rc[b]), b)] >= 16, min(rc[b]), b))
         cols = sorted(rc.keys(), key=key)
         pos[r] = {b: k for k, b in enumerate(cols)}
         rowptr[r + 1] = rowptr[r] + len(cols)
