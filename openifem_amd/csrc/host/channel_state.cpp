@@ -21,10 +21,13 @@ void channel_bench_state(Fluid::MPI::FluidSolver<dim> &solver, double L, double 
   // perturbation keyed by the GLOBAL dof so that every partition of the mesh sees the same field:
   // one mt19937_64(seed) draw sequence would depend on the local numbering
   auto &pt = solver.partition();
+  // (a stateless hash of (seed, key) -- splitmix64 -- not a generator per dof: seeding 53 M Mersenne twisters took 20 s at 128^3)
   auto unit = [&](uint64_t key) {
-    std::mt19937_64 gen(seed ^ (key * 0x9E3779B97F4A7C15ull));
-    gen.discard(1);
-    return std::uniform_real_distribution<double>(-1.0, 1.0)(gen);
+    uint64_t z = seed + (key + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return double(z >> 11) * (2.0 / 9007199254740992.0) - 1.0; // 53 bits -> [-1, 1)
   };
   for (int64_t nd = 0; nd < d.n_unodes; ++nd)
     for (int c = 0; c < dim; ++c) ev[nd * dim + c] += rel * umax * unit((uint64_t)pt.l2g_u[nd] * dim + c);
