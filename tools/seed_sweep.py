@@ -44,7 +44,8 @@ def main():
                 r, b = solver.true_residual()
                 row = {"cells": args.cells, "amp": amp, "seed": seed, "inner_rel_first": first, "fgmres_iters": st.fgmres_iters,
                        "inner_iters": st.inner_iters, "cg_sm_iters": st.cg_sm_iters, "cg_mp_iters": st.cg_mp_iters,
-                       "fgmres_rel_residual": st.fgmres_res / b, "true_rel_residual": r / b, "solve_ms": ms}
+                       "fgmres_rel_residual": st.fgmres_res / b, "true_rel_residual": r / b, "solve_ms": ms,
+                       "inner_first_tight": int(st.inner_first_tight)}  # 0 with inner_rel_first > 0: the option has backed off after a miss
                 rows.append(row)
                 print(json.dumps(row), flush=True)
     if args.out:
@@ -57,7 +58,7 @@ def main():
         for first in sorted({r["inner_rel_first"] for r in rows}):
             sel = [r for r in rows if r["amp"] == amp and r["inner_rel_first"] == first]
             ms = sorted(r["solve_ms"] for r in sel)
-            print(f"# {amp:g}  {first:g}  {[r['fgmres_iters'] for r in sel]}  {max(r['true_rel_residual'] for r in sel):.3e}  {ms[len(ms) // 2]:.1f}")
+            print(f"# {amp:g}  {first:g}  {[r['fgmres_iters'] for r in sel]}  {max(r['true_rel_residual'] for r in sel):.3e}  {ms[len(ms) // 2]:.1f}  tight used {[r['inner_first_tight'] for r in sel]}")
 
 
 if __name__ == "__main__":
