@@ -4,13 +4,19 @@
 // The velocity-velocity block of the element matrix is a sum over the 27 quadrature points of outer products,
 //   Ke[(a,c),(b,d)] = sum_q  (wg ga_c)(q,a) gb_d(q,b)  +  (N_a rho w d_d u_c)(q) N_b(q)           (grad-div, Newton term)
 //                 + d_cd sum_q [ sum_e (w mu ga_e) gb_e + (w rho N_a)(u.gb) + (w rho/dt N_a) N_b ]  (scalar part),
-// i.e. for every (c,d) a 27x27 GEMM with K = 54 (+ a shared 27x27 GEMM with K = 135).  One wavefront per cell runs them
+// i.e. for every (c,d) a 27x27 GEMM with K = 54 (+ a shared 27x27 GEMM with K = 135).  Two wavefronts per cell run them
 // as v_mfma_f64_16x16x4 on 2x2 tiles of 16x16 (27 padded to 32, K padded to 28): 644 MFMAs per cell.  FP64 MFMA has the
 // same peak as the vector FMA on MI355X -- the point is the instruction stream: an MFMA retires 2048 flops for two
 // 8-byte operands per lane, where the vector path of assemble2.hip issues ~47 instructions per 58 flops.
 // The operands come from per-cell LDS tables tabN[q][a], tabG[d][q][a] (23 KB), built once per cell; rhs, B/B^T, M_p
-// read the same tables.  Accumulator layout of the instruction (tools/microbench.hip): lane l supplies
-// A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15], register r of the result is D[(l>>4) + 4r][l&15].
+// read the same tables (default build: no tables, shapes rebuilt where consumed from tensor factors, Cell3Otf).  Accumulator
+// layout of the instruction (tools/microbench.hip): lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15], register r
+// of the result is D[(l>>4) + 4r][l&15].
+// The scatter is what bounds the kernel: the memory-side atomic path retires ~24 G requests of up to 64 bytes per second
+// whatever the type, scope or footprint (tools/atomics_types.hip), so everything after the contraction is organised around the
+// number of 64-byte segments a cell's 729 blocks touch (tools/scatter_sim.py replays it on the CPU): tile columns in the order
+// of the cell's node ids (perm), the 16 node pairs of a matrix row ranked by their position in the row (rank_in_row16; the rows
+// themselves are stored in scatter order, setup.hip::reorder_uu_rows), every staged row shifted to a segment boundary.
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <set>
