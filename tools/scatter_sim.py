@@ -19,85 +19,96 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openifem_amd import host
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else 12
-s = host.InsIM(host.channel_prm(3), (n, n, n), (0, 0, 0), (2.0, 0.2, 0.2))
-s.set_multigrid(False)
-if "--lex-nodes" in sys.argv:
-    s.set_node_order(False)  # nodes numbered lexicographically (x fastest) instead of along the Morton curve
-s.setup_host_only(0)
-cu, _, _, _ = s.cell_tables()
-nc, NU = cu.shape
-nn = int(cu.max()) + 1
-rank_in_cell = {}  # (cell, node) -> rank of the node's id among the cell's 27: ranks 16..26 are the second MFMA tile's columns
-for c in range(nc):
-    for k, j in enumerate(np.argsort(cu[c], kind="stable")):
-        rank_in_cell[(c, cu[c][j])] = k
-rowcells = [defaultdict(list) for _ in range(nn)]  # row -> column -> cells that hold both
-for c in range(nc):
-    nd = cu[c]
-    for a in nd:
-        rc = rowcells[a]
-        for b in nd:
-            rc[b].append(c)
+
+class Replay:
+    """the DoF tables of the n^3 channel mesh of the host mirror and the replay of the scatter on them"""
+
+    def __init__(self, n, lex_nodes=False):
+        s = host.InsIM(host.channel_prm(3), (n, n, n), (0, 0, 0), (2.0, 0.2, 0.2))
+        s.set_multigrid(False)
+        if lex_nodes:
+            s.set_node_order(False)  # nodes numbered lexicographically (x fastest) instead of along the Morton curve
+        s.setup_host_only(0)
+        self.cu, _, _, _ = s.cell_tables()
+        self.nc, self.NU = self.cu.shape
+        self.nn = int(self.cu.max()) + 1
+        cu = self.cu
+        self.rank_in_cell = {}  # (cell, node) -> rank of the node's id among the cell's 27: ranks 16..26 are the second MFMA tile's columns
+        for c in range(self.nc):
+            for k, j in enumerate(np.argsort(cu[c], kind="stable")):
+                self.rank_in_cell[(c, cu[c][j])] = k
+        self.rowcells = [defaultdict(list) for _ in range(self.nn)]  # row -> column -> cells that hold both
+        for c in range(self.nc):
+            nd = cu[c]
+            for a in nd:
+                rc = self.rowcells[a]
+                for b in nd:
+                    rc[b].append(c)
+
+    def build_rows(self, kind):
+        pos, rowptr = [None] * self.nn, np.zeros(self.nn + 1, np.int64)
+        for r in range(self.nn):
+            rc = self.rowcells[r]
+            key = (lambda b: b) if kind == "col" else (lambda b: (max(rc[b]), self.rank_in_cell[(max(rc[b]), b)] >= 16, min(rc[b]), b))
+            cols = sorted(rc.keys(), key=key)
+            pos[r] = {b: k for k, b in enumerate(cols)}
+            rowptr[r + 1] = rowptr[r] + len(cols)
+        return pos, rowptr
+
+    def replay(self, pos, rowptr, cells, tiles, slots):
+        cu = self.cu
+        floor = tot = inst = 0
+        lanes = np.arange(64)
+        for c in cells:
+            nd = cu[c]
+            for a in nd:
+                addr = (np.array([rowptr[a] + pos[a][b] for b in nd]) * 72)[:, None] + 8 * np.arange(9)[None, :]
+                floor += len(np.unique(addr // 64))
+            perm = (list(range(27)) if tiles == "lex" else list(np.argsort(nd, kind="stable"))) + [-1] * 5
+            for ti in range(2):
+                for tj in range(2):
+                    for r in range(4):
+                        off = np.full(64, -1, np.int64)  # per stage slot
+                        for g in range(4):
+                            a = 16 * ti + g + 4 * r
+                            cols = [perm[16 * tj + j] for j in range(16)]
+                            p = [pos[nd[a]][nd[b]] if (a < 27 and b >= 0) else None for b in cols]
+                            key = [(q << 4 | j) if q is not None else (0x100000 | j) for j, q in enumerate(p)]
+                            rank = np.arange(16) if slots == "lane" else np.argsort(np.argsort(key))
+                            for j in range(16):
+                                if p[j] is not None:
+                                    off[16 * g + rank[j]] = (rowptr[nd[a]] + p[j]) * 72
+                        span = 152 if slots == "aligned" else 144
+                        for rr in range(10 if slots == "aligned" else 9):
+                            t = lanes + 64 * rr
+                            g = t // span
+                            gc = np.minimum(g, 3)
+                            o0 = off[16 * gc]
+                            u = t - g * span - (np.where(o0 >= 0, (o0 // 8) & 7, 0) if slots == "aligned" else 0)
+                            ok = (g < 4) & (u >= 0) & (u < 144)
+                            uc = np.where(ok, u, 0)
+                            o = np.where(ok, off[16 * gc + uc // 9], -1)
+                            v = o >= 0
+                            if v.any():
+                                tot += len(np.unique((o[v] + 8 * (uc % 9)[v]) // 64))
+                                inst += 1
+        k = len(cells)
+        return floor / k, tot / k, inst / k
 
 
-def build_rows(kind):
-    pos, rowptr = [None] * nn, np.zeros(nn + 1, np.int64)
-    for r in range(nn):
-        rc = rowcells[r]
-        key = (lambda b: b) if kind == "col" else (lambda b: (max(rc[b]), rank_in_cell[(max(rc[b]), b)] >= 16, min(rc[b]), b))
-        cols = sorted(rc.keys(), key=key)
-        pos[r] = {b: k for k, b in enumerate(cols)}
-        rowptr[r + 1] = rowptr[r] + len(cols)
-    return pos, rowptr
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else 12
+    R = Replay(n, "--lex-nodes" in sys.argv)
+    rng = np.random.default_rng(1)
+    cells = rng.choice(R.nc, size=min(R.nc, 200), replace=False)
+    print(f"{n}^3 cells, {len(cells)} sampled; layout floor 729 * 72 / 64 = 820 segments per cell")
+    for rows in ("col", "cells"):
+        pos, rowptr = R.build_rows(rows)
+        for tiles, slots in (("lex", "lane"), ("id", "lane"), ("id", "rank"), ("id", "aligned")):
+            fl, seg, inst = R.replay(pos, rowptr, cells, tiles, slots)
+            tag = {("col", "lex", "lane"): "  <- rounds 1-2", ("col", "id", "lane"): "  <- 1fdd41d", ("cells", "id", "aligned"): "  <- shipped"}.get((rows, tiles, slots), "")
+            print(f"rows {rows:5s} tiles {tiles:3s} slots {slots:7s}: {seg:7.1f} segments per cell ({seg / 729:.3f} per block; floor of this row order {fl:6.1f}), {inst:.0f} atomic instructions{tag}", flush=True)
 
 
-def replay(pos, rowptr, cells, tiles, slots):
-    floor = tot = inst = 0
-    lanes = np.arange(64)
-    for c in cells:
-        nd = cu[c]
-        for a in nd:
-            addr = (np.array([rowptr[a] + pos[a][b] for b in nd]) * 72)[:, None] + 8 * np.arange(9)[None, :]
-            floor += len(np.unique(addr // 64))
-        perm = (list(range(27)) if tiles == "lex" else list(np.argsort(nd, kind="stable"))) + [-1] * 5
-        for ti in range(2):
-            for tj in range(2):
-                for r in range(4):
-                    off = np.full(64, -1, np.int64)  # per stage slot
-                    for g in range(4):
-                        a = 16 * ti + g + 4 * r
-                        cols = [perm[16 * tj + j] for j in range(16)]
-                        p = [pos[nd[a]][nd[b]] if (a < 27 and b >= 0) else None for b in cols]
-                        key = [(q << 4 | j) if q is not None else (0x100000 | j) for j, q in enumerate(p)]
-                        rank = np.arange(16) if slots == "lane" else np.argsort(np.argsort(key))
-                        for j in range(16):
-                            if p[j] is not None:
-                                off[16 * g + rank[j]] = (rowptr[nd[a]] + p[j]) * 72
-                    span = 152 if slots == "aligned" else 144
-                    for rr in range(10 if slots == "aligned" else 9):
-                        t = lanes + 64 * rr
-                        g = t // span
-                        gc = np.minimum(g, 3)
-                        o0 = off[16 * gc]
-                        u = t - g * span - (np.where(o0 >= 0, (o0 // 8) & 7, 0) if slots == "aligned" else 0)
-                        ok = (g < 4) & (u >= 0) & (u < 144)
-                        uc = np.where(ok, u, 0)
-                        o = np.where(ok, off[16 * gc + uc // 9], -1)
-                        v = o >= 0
-                        if v.any():
-                            tot += len(np.unique((o[v] + 8 * (uc % 9)[v]) // 64))
-                            inst += 1
-    k = len(cells)
-    return floor / k, tot / k, inst / k
-
-
-rng = np.random.default_rng(1)
-cells = rng.choice(nc, size=min(nc, 200), replace=False)
-print(f"{n}^3 cells, {len(cells)} sampled; layout floor 729 * 72 / 64 = 820 segments per cell")
-for rows in ("col", "cells"):
-    pos, rowptr = build_rows(rows)
-    for tiles, slots in (("lex", "lane"), ("id", "lane"), ("id", "rank"), ("id", "aligned")):
-        fl, seg, inst = replay(pos, rowptr, cells, tiles, slots)
-        tag = {("col", "lex", "lane"): "  <- rounds 1-2", ("col", "id", "lane"): "  <- 1fdd41d", ("cells", "id", "rank"): "  <- 96.6 ms", ("cells", "id", "aligned"): "  <- shipped"}.get((rows, tiles, slots), "")
-        print(f"rows {rows:5s} tiles {tiles:3s} slots {slots:4s}: {seg:7.1f} segments per cell ({seg / 729:.3f} per block; floor of this row order {fl:6.1f}), {inst:.0f} atomic instructions{tag}", flush=True)
+if __name__ == "__main__":
+    main()
