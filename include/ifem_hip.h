@@ -158,7 +158,8 @@ typedef struct {
                             re-forms S_m.  2 (measurement): every assembly is treated as a new set.  0: everything is
                             re-integrated by every assembly as the reference does (mpi_insim.cpp:163-165) */
   int32_t xcd_swizzle;   /* 1: cell kernels hand every XCD one contiguous range of the (Morton-ordered) cells */
-  int32_t asm_skip;      /* 0; measurement only: drop parts of the 3D Q2/Q1 assembly kernel (results invalid) */
+  int32_t asm_skip;      /* 0; read by measurement builds only (-DIFEM_ASM_PROBES): drop parts of the 3D Q2/Q1 assembly kernel (results
+                            invalid); the default build ignores it */
   int32_t spmv_lanes;    /* 32: lanes per block row of the A_uu SpMV (8/16/32/64) */
   int32_t sm_lanes;      /* 32: lanes per row of the S_m SpMV */
   int32_t mf_f32;        /* 1: single-precision cell arithmetic in the matrix-free A_uu of the INNER solve */
@@ -168,12 +169,10 @@ typedef struct {
   int32_t halo_overlap;  /* 1: several ranks: the halo of an operator input travels on a second stream / communicator
                             while the rows (SpMV) or cells (matrix-free A_uu) that read no ghost value are processed; 0: the
                             exchange completes on the context stream before the operator starts */
-  int32_t asm3_variant;  /* 3D Q2/Q1 cell kernel: 0 (default) = no per-cell shape tables in LDS (rebuilt on the fly from tensor
-                            factors: 19 KB of LDS per cell, four workgroups per CU); 1 = the 23 KB per-cell tables of rounds 1-2
-                            (two workgroups per CU); 2 = tables for assemblies that integrate B / B^T / M_p, none otherwise */
-  int32_t asm3_waves;    /* 3: waves per SIMD the no-tables variant of that kernel is compiled for (2: 256 registers per lane, 3: 168,
-                            4: 128 with spills around the scatter) */
-  int32_t asm3_cpb;      /* 2: cells per workgroup of the no-tables variant at 3 waves per SIMD (1, 2 or 4; two waves per cell) */
+  int32_t asm3_variant;  /* 3D Q2/Q1 cell kernel: 0 (default) = the matrix-core kernel of assemble3.hip (one wavefront per cell); 1 = the
+                            general vector kernel of assemble2.hip (also taken when an A_uu row holds 512 blocks or more) */
+  int32_t asm3_reserved; /* unused */
+  int32_t asm3_cpb;      /* 2: cells (= wavefronts) per workgroup of that kernel (1, 2, 4 or 8) */
   int32_t tpp_milu_permille; /* SCnsIM, ILU(0) of T_pp: 950 (default); 0 plain ILU(0); w in (0, 1000]: relaxed modified ILU, w/1000 of every dropped
                                 fill-in entry is added to the diagonal of its row */
   int64_t tpp_ilu_order; /* SCnsIM, explicit T_pp: preconditioner of its inner GMRES -- 0 (default) ILU(0) in the natural row order,

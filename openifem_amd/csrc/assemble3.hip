@@ -2,229 +2,347 @@
 // source/mpi_insim.cpp:153-362; same mathematics, scatter and constraint handling as assemble2.hip).
 //
 // The velocity-velocity block of the element matrix is a sum over the 27 quadrature points of outer products,
-//   Ke[(a,c),(b,d)] = sum_q  (wg ga_c)(q,a) gb_d(q,b)  +  (N_a rho w d_d u_c)(q) N_b(q)           (grad-div, Newton term)
-//                 + d_cd sum_q [ sum_e (w mu ga_e) gb_e + (w rho N_a)(u.gb) + (w rho/dt N_a) N_b ]  (scalar part),
-// i.e. for every (c,d) a 27x27 GEMM with K = 54 (+ a shared 27x27 GEMM with K = 135).  Two wavefronts per cell run them
-// as v_mfma_f64_16x16x4 on 2x2 tiles of 16x16 (27 padded to 32, K padded to 28): 644 MFMAs per cell.  FP64 MFMA has the
-// same peak as the vector FMA on MI355X -- the point is the instruction stream: an MFMA retires 2048 flops for two
-// 8-byte operands per lane, where the vector path of assemble2.hip issues ~47 instructions per 58 flops.
-// The operands come from per-cell LDS tables tabN[q][a], tabG[d][q][a] (23 KB), built once per cell; rhs, B/B^T, M_p
-// read the same tables (default build: no tables, shapes rebuilt where consumed from tensor factors, Cell3Otf).  Accumulator
-// layout of the instruction (tools/microbench.hip): lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15], register r
-// of the result is D[(l>>4) + 4r][l&15].
-// The scatter is what bounds the kernel: the memory-side atomic path retires ~24 G requests of up to 64 bytes per second
-// whatever the type, scope or footprint (tools/atomics_types.hip), so everything after the contraction is organised around the
-// number of 64-byte segments a cell's 729 blocks touch (tools/scatter_sim.py replays it on the CPU): tile columns in the order
-// of the cell's node ids (perm), the 16 node pairs of a matrix row ranked by their position in the row (rank_in_row16; the rows
-// themselves are stored in scatter order, setup.hip::reorder_uu_rows), every staged row shifted to a segment boundary.
+//   Ke[(a,c),(b,d)] = sum_q  (w gam ga_c)(q,a) gb_d(q,b)  +  (N_a (rho w d_d u_c + d_cd rho/dt w))(q) N_b(q)     (grad-div, Newton + mass)
+//                 + d_cd sum_q sum_e (w mu ga_e + rho w u_e N_a)(q,a) gb_e(q,b)                                  (viscous + convective),
+// i.e. for every (c,d) a 27x27 GEMM with K = 54 plus a shared 27x27 GEMM with K = 81, run as v_mfma_f64_16x16x4 on 2x2 tiles of
+// 16x16 (27 padded to 32, K to 28): 588 MFMAs per cell.
+//
+// Round 4: ONE wavefront per cell.  On gfx950 the FP64 MFMA runs on the vector pipe: a wave's MFMAs and its other VALU
+// instructions add up (tools/overlap_mfma.hip: 4 MFMAs 274 cycles, + 64 v_fma / v_add 600; an MFMA wave and a VALU wave on one
+// SIMD take the sum of their times), so the kernel is bound by the INSTRUCTIONS it issues -- 68 cycles per MFMA, 4.5 per VALU
+// instruction -- and by the memory-side rate of its atomics, not by latency or occupancy.  Everything here is
+// arranged to issue few instructions:
+//  * fields at the quadrature points and the local right-hand side by sum factorisation (pencil passes over 27-value arrays
+//    in LDS, 1D tables in SGPRs) instead of 27-lane loops over the nodes;
+//  * both column tiles of a row tile are integrated together (80 accumulator registers per lane, two waves per SIMD): the
+//    row-side operands are built once per point, and a matrix row's 27 blocks leave in one piece;
+//  * the scatter stages a matrix row as the IMAGE of its memory: block k of the row (in the order of the blocks' positions,
+//    setup.hip::build_scat3) at double s + 9 k, s = alignment of the row's first block inside a 64-byte segment, each double
+//    with the byte address "block address - 8 * image index" beside it.  The reading lanes are linear in the image: lane l of
+//    round rr adds image[64 rr + l] to base + 8 (64 rr + l) -- two VALU instructions per atomic instruction, instruction
+//    boundaries on segment boundaries wherever the row is contiguous (tools/scatter_sim.py: 871 segments per cell);
+//  * ranks, positions and alignments come from per-cell records built once per pattern; reference tables from the host.
+// Accumulator layout of the instruction (tools/microbench.hip): lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15],
+// register r of the result is D[(l>>4) + 4r][l&15].
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <set>
-#include <type_traits>
 #include "kernels.hpp"
 #include "assemble_common.hpp"
 
 namespace ifem {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) double gdouble; // global address space: global_atomic_add_f64, not the flat form
 
-// Per-cell LDS.  TABLES layout (OTF = false): the physical gradient / value tables of the cell, 23 KB, read by the MFMA
-// loop, the rhs and the B / B^T integrals: two cells fill half a CU's LDS, two waves per SIMD.  OTF layout: no per-cell
-// tables -- every consumer rebuilds N_a(q) and grad N_a(q) on the fly from the workgroup's 1D / 2D tensor factors
-// (Shared3) and the cell's inverse Jacobians Ji[q] (1.9 KB): 18.7 KB per cell, four workgroups per CU, so that the
-// atomic-unit time of one cell's scatter overlaps the integration of three others instead of one.
-struct Cell3Tabs {
-  double tabG[3][27][27]; // physical shape gradients
-  double tabN[27][27];    // shape values
-};
-struct Cell3Otf {
-  double Ji[27 * 9];      // [q][reference direction e][physical direction d]
-  double part1[27 * 18];  // partial nodal sums of the cell's second wave (phase 1)
-};
-template <bool OTF>
-struct Cell3 : std::conditional<OTF, Cell3Otf, Cell3Tabs>::type {
-  static constexpr int DIM = 3, NU = 27, NP = 8, NQ = 27, ND = 89, BS = 9;
-  static constexpr int NODAL = 3 * NU * DIM + NP, STAGE = 64 * BS + 64;
-  double X[NP * DIM], C[8 * DIM];
-  double JxW[NQ], uq[NQ * DIM];
-  double gqs[NQ * 9]; // rho JxW grad u
-  // Ji[243] (TABLES layout) | Vc[243] | Sc[81] | divw[27] until the rhs is integrated, then the scatter staging of the cell's second wave
-  double dead[STAGE];
-  // nodal values (phase 1) | B entries in row order (second wave, uncached assemblies) | scatter staging of the cell's first wave
-  double scratch[(STAGE > NODAL ? STAGE : NODAL) > NU * NP * DIM ? (STAGE > NODAL ? STAGE : NODAL) : NU * NP * DIM];
-  double fe[ND], cv[ND];
-  int64_t rs_uu[NU], rs_bt[NU], rs_b[NP], rs_mp[NP];
-  int32_t len_uu[NU], len_bt[NU], len_b[NP], len_mp[NP];
-  int32_t un[NU], pn[NP];
-  int32_t bid[6], ind; // boundary ids of the faces (only read with Neumann conditions), FSI indicator of the cell
-  uint8_t cf[ND + 7];
-  uint8_t iperm[32], permp[8]; // rank of a velocity node among the cell's 27 (inverse of perm); pressure nodes in the order of their ids
-  uint8_t perm[32];    // tile column -> local node, the cell's nodes in the order of their (local) node ids: the order of the columns
-                       // in every row of the sorted pattern, so that neighbouring lanes of the staged scatter hit neighbouring blocks
+#ifdef IFEM_ASM_PROBES // measurement build (tools/asmbench.py): ifem_tuning::asm_skip drops parts of the kernel, results invalid
+#define IFEM_PROBE(x) (x)
+#else
+#define IFEM_PROBE(x) false
+#endif
+
+// per-cell LDS of one wavefront; the scatter stages two matrix rows per sub-step (image of 2 x 256 doubles + their bases)
+struct Cell4 {
+  static constexpr int NU = 27, NP = 8, ND = 89;
+  static constexpr int IMG = 2 * 256;
+  static constexpr int ZONE = 2 * IMG;
+  double Ji[28 * 9];  // [q][reference direction e][physical direction d]; point 27 = padding of the K dimension, all zero
+  double gqs[28 * 9]; // rho JxW grad u + d_cd rho/dt JxW
+  double rwu[28 * 3]; // rho JxW u
+  double JxW[28];
+  double X[24], C[24];
+  double fe[96]; // velocity part by component: [c][a], pressure part at 81 + b
+  double cv[96]; // inhomogeneities in dof order (a * 3 + c, 81 + b)
+  // phase 1: nodal values [9][27] | pencil intermediates; then rhs coefficient fields; B staging (uncached assemblies); scatter image
+  double zone[ZONE];
+  int64_t rs_uu[27], rs_bt[27], rs_b[8], rs_mp[8];
+  int32_t len_uu[27], len_bt[27], len_b[8], len_mp[8];
+  int32_t un[27], pn[8];
+  int32_t bid[6], ind;
+  uint8_t cf[96];
+  uint8_t hdr[kAsm3Hdr]; // perm[32] | iperm[32] | permp[8] | srow[32] (setup.hip::build_scat3)
 };
 
-struct Shared3 {
-  Tab1D t;
-  double psi[27 * 8];
-};
-// OTF layout: + the 2D tensor factors over (q0 q1) x (a0 a1): N2 = Nx Ny, DX2 = Nx' Ny, DY2 = Nx Ny'.  (A separate type: the
-// TABLES layout fills 80 of a CU's 160 KB with two workgroups, 2 KB more would leave room for one.)
-struct Shared3Otf : Shared3 {
-  double N2[81], DX2[81], DY2[81];
-};
-
-// N_a(q) and the physical gradient of N_a at q from the tensor factors and the inverse Jacobian of the point: the same
-// products and sums, in the same order, as the table build of the TABLES layout
-__device__ __forceinline__ void shape_ref(const Shared3Otf &T, int q, int a, double &N, double r[3]) {
-  const int i2 = (q % 9) * 9 + (a % 9), i1 = (q / 9) * 3 + a / 9;
-  const double n2 = T.N2[i2], dx2 = T.DX2[i2], dy2 = T.DY2[i2], nz = T.t.N[i1], dz = T.t.dN[i1];
+// N_a(q) and the reference gradient of N_a at q from the tensor factors; q9 = (q % 9) * 9, q4 = (q / 9) * 4, a9 = a % 9, a3 = a / 9.
+// The z factor is zero for q = 27 and a >= 27 (padding of the MFMA tiles): no masks in the contraction.
+__device__ __forceinline__ void shape_ref4(const Tabs3 &T, int q9, int q4, int a9, int a3, double &N, double r[3]) {
+  const int i2 = q9 + a9, i1 = q4 + a3;
+  const double n2 = T.N2[i2], dx2 = T.DX2[i2], dy2 = T.DY2[i2], nz = T.Nz[i1], dz = T.dNz[i1];
   N = n2 * nz;
   r[0] = dx2 * nz; r[1] = dy2 * nz; r[2] = n2 * dz;
 }
-__device__ __forceinline__ void shape_otf(const Shared3Otf &T, const double *__restrict__ Jq, int q, int a, double &N, double g[3]) {
+__device__ __forceinline__ void shape_phys4(const Tabs3 &T, const double *Jq, int q9, int q4, int a9, int a3, double &N, double g[3]) {
   double r[3];
-  shape_ref(T, q, a, N, r);
+  shape_ref4(T, q9, q4, a9, a3, N, r);
 #pragma unroll
   for (int d = 0; d < 3; ++d) g[d] = r[0] * Jq[d] + r[1] * Jq[3 + d] + r[2] * Jq[6 + d];
 }
 
-// rank of `key` among the 16 lanes of my row of lanes (keys distinct): 15 row rotations by DPP, no LDS.  The staged scatter
-// orders the 16 node pairs of a matrix row by their position in that row, so that neighbouring lanes of its atomics hit
-// neighbouring blocks whatever order the row stores its blocks in (setup.hip: scatter order of the A_uu rows).
-__device__ __forceinline__ int rank_in_row16(unsigned key) {
-  int rank = 0;
-#define IFEM_ROR16(n) rank += unsigned(__builtin_amdgcn_update_dpp(0, int(key), 0x120 + n, 0xf, 0xf, false)) < key ? 1 : 0;
-  IFEM_ROR16(1) IFEM_ROR16(2) IFEM_ROR16(3) IFEM_ROR16(4) IFEM_ROR16(5) IFEM_ROR16(6) IFEM_ROR16(7) IFEM_ROR16(8)
-  IFEM_ROR16(9) IFEM_ROR16(10) IFEM_ROR16(11) IFEM_ROR16(12) IFEM_ROR16(13) IFEM_ROR16(14) IFEM_ROR16(15)
-#undef IFEM_ROR16
-  return rank;
+// One tensor direction of narr arrays of 27 values: out[arr][.. o ..] (+)= sum_j M[o][j] in[arr][.. j ..], M = N or N' of the 1D
+// element (TRANS: its transpose -- the test-function side).  Item = (array, pencil of three values); the table sits in SGPRs.
+template <int DIR, bool TRANS, bool DERIV, bool ACC>
+__device__ __forceinline__ void pencil_pass(const Tab1D &t, const double *__restrict__ in, double *__restrict__ out, int narr, int lane) {
+  constexpr int st = DIR == 0 ? 1 : (DIR == 1 ? 3 : 9);
+  for (int it = lane; it < narr * 9; it += 64) {
+    const int arr = it / 9, p = it - arr * 9;
+    const int b = DIR == 0 ? 3 * p : (DIR == 1 ? p + 6 * (p / 3) : p);
+    const double *src = in + arr * 27 + b;
+    double *dst = out + arr * 27 + b;
+    const double v0 = src[0], v1 = src[st], v2 = src[2 * st];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      const double c0 = DERIV ? (TRANS ? t.dN[o] : t.dN[o * 3]) : (TRANS ? t.N[o] : t.N[o * 3]);
+      const double c1 = DERIV ? (TRANS ? t.dN[3 + o] : t.dN[o * 3 + 1]) : (TRANS ? t.N[3 + o] : t.N[o * 3 + 1]);
+      const double c2 = DERIV ? (TRANS ? t.dN[6 + o] : t.dN[o * 3 + 2]) : (TRANS ? t.N[6 + o] : t.N[o * 3 + 2]);
+      double r = c0 * v0 + c1 * v1 + c2 * v2;
+      if (ACC) r += dst[o * st];
+      dst[o * st] = r;
+    }
+  }
 }
 
-// CPB cells per workgroup, TWO wavefronts per cell (h = 0, 1) sharing the cell's LDS tables: the tables cap the
-// workgroup at ~150 KB of LDS, and one wave per SIMD leaves every LDS / global round trip exposed; with two waves per
-// cell the SIMDs hold two waves each.  Phases are separated by workgroup barriers (uniform control flow).
-// WAVES: waves per SIMD the register allocation is held to (2: 256 registers, 3: 168, 4: 128).  The TABLES layout runs at 2
-// (its LDS allows no more); the OTF layout is built for 3 (ks loop not unrolled: the whole kernel spills 80 bytes per lane,
-// none of it inside the contraction) and 4 (240 bytes, most of it around the staged scatter).
-template <int CPB, bool OTF, int WAVES>
-__global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES ? WAVES : 1, WAVES ? WAVES : 4))) void k_ins_assemble3(AsmArgs A, Tab1D t1) {
-  constexpr int DIM = 3, N1 = 3, NU = 27, NP = 8, NQ = 27, ND = 89, BS = 9;
-  constexpr int NBP = NU * NP, BROUNDS = (NBP + 63) / 64, FR = (ND + 63) / 64;
-  constexpr int SPAN = 16 * BS + 8; // lanes per staged matrix row in the scatter: 16 blocks + up to 7 lanes of alignment shift
-  extern __shared__ __align__(16) unsigned char smem[];
-  using Shared = typename std::conditional<OTF, Shared3Otf, Shared3>::type;
-  Shared &T = *reinterpret_cast<Shared *>(smem);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = wave >> 1, h = wave & 1;
-  using Cell = Cell3<OTF>;
-  Cell &S = *reinterpret_cast<Cell *>(smem + ((sizeof(Shared) + 15) & ~size_t(15)) + size_t(slot) * ((sizeof(Cell) + 15) & ~size_t(15)));
-  double *Ji_, *part1;
-  if constexpr (OTF) { Ji_ = S.Ji; part1 = S.part1; }
-  else { Ji_ = S.dead; part1 = &S.tabG[0][0][0]; } // the tables are not built yet when the partial sums are parked there
-  double *const Vc_ = S.dead + 243, *const Sc_ = S.dead + 486, *const divw_ = S.dead + 567;
-  if (threadIdx.x < 9) { T.t.N[threadIdx.x] = t1.N[threadIdx.x]; T.t.dN[threadIdx.x] = t1.dN[threadIdx.x]; }
-  if (threadIdx.x < 3) { T.t.xi[threadIdx.x] = t1.xi[threadIdx.x]; T.t.w[threadIdx.x] = t1.w[threadIdx.x]; }
-  for (int i = threadIdx.x; i < NQ * NP; i += blockDim.x) {
-    const int q = i / NP, b = i - q * NP;
-    double v = 1;
-    for (int d = 0; d < DIM; ++d) {
-      const int qd = d == 0 ? q % N1 : (d == 1 ? (q / N1) % N1 : q / (N1 * N1));
-      const double x = t1.xi[0] * (qd == 0) + t1.xi[1] * (qd == 1) + t1.xi[2] * (qd == 2);
-      v *= ((b >> d) & 1) ? x : 1.0 - x;
+// One row tile (matrix rows 16 TI .. 16 TI + 15) of the velocity-velocity block: the contraction over the 27 points for both column
+// tiles, then the scatter of its rows, two per sub-step (see the head of the file).
+template <int TI>
+__device__ __forceinline__ void row_tile(const AsmArgs &A, const Tabs3 &T, Cell4 &S, const uint4 rc, const int lane, const bool any_c, const bool mass_s) {
+  constexpr int NU = 27, BS = 9, DIM = 3;
+  const uint8_t *const perm = S.hdr, *const srow = S.hdr + 72;
+  const double wgam = A.gamma * A.rho, rdt = A.rho * A.inv_dt;
+  double *const imv = S.zone;                                               // image of two matrix rows: values ...
+  uint64_t *const imb = reinterpret_cast<uint64_t *>(S.zone + Cell4::IMG);  // ... and "address - 8 * image index" of every double
+  const int l15 = lane & 15, g = lane >> 4;
+  const int bn0 = perm[l15], bn1 = perm[16 + l15]; // my column nodes (columns in node-id order; 27..31: padding)
+  const int b9_0 = bn0 % 9, b3_0 = bn0 / 9, b9_1 = bn1 % 9, b3_1 = bn1 / 9;
+  const int al = 16 * TI + l15; // my A-row node (27..31: padding, zero through the z factor)
+  const int a9 = al % 9, a3 = al / 9;
+  d4 acc0[BS], acc1[BS], sac0 = {0, 0, 0, 0}, sac1 = {0, 0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < BS; ++e) { acc0[e] = d4{0, 0, 0, 0}; acc1[e] = d4{0, 0, 0, 0}; }
+  if (!IFEM_PROBE(A.debug_skip == 2)) {
+#pragma unroll 1
+    for (int ks = 0; ks < 7; ++ks) {
+      const int q = 4 * ks + g; // 27: the zero point
+      const int q3 = q / 9, q9 = (q - q3 * 9) * 9, q4 = q3 * 4;
+      const double *Jq = S.Ji + q * 9;
+      const double w = S.JxW[q];
+      double Na, Nb0, Nb1, ga[3], gb0[3], gb1[3];
+      shape_phys4(T, Jq, q9, q4, a9, a3, Na, ga);
+      shape_phys4(T, Jq, q9, q4, b9_0, b3_0, Nb0, gb0);
+      shape_phys4(T, Jq, q9, q4, b9_1, b3_1, Nb1, gb1);
+      const double wmu = w * A.mu, wg = w * wgam;
+      // viscous + convective: sum_e (w mu ga_e + rho w u_e N_a) gb_e
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const double av = S.rwu[q * 3 + e] * Na + wmu * ga[e];
+        sac0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, gb0[e], sac0, 0, 0, 0);
+        sac1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, gb1[e], sac1, 0, 0, 0);
+      }
+      // grad-div part of the nine blocks
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double wga = wg * ga[c];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          acc0[c * 3 + d] = __builtin_amdgcn_mfma_f64_16x16x4f64(wga, gb0[d], acc0[c * 3 + d], 0, 0, 0);
+          acc1[c * 3 + d] = __builtin_amdgcn_mfma_f64_16x16x4f64(wga, gb1[d], acc1[c * 3 + d], 0, 0, 0);
+        }
+      }
+      // Newton term rho N_a N_b d_d u_c with the mass term on its diagonal blocks
+      if (!A.imex) {
+#pragma unroll
+        for (int e = 0; e < BS; ++e) {
+          const double an = Na * S.gqs[q * 9 + e];
+          acc0[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(an, Nb0, acc0[e], 0, 0, 0);
+          acc1[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(an, Nb1, acc1[e], 0, 0, 0);
+        }
+      }
+      if (mass_s) {
+        const double am = rdt * w * Na;
+        sac0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, Nb0, sac0, 0, 0, 0);
+        sac1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, Nb1, sac1, 0, 0, 0);
+      }
     }
-    T.psi[i] = v;
   }
-  if constexpr (OTF)
-    for (int i = threadIdx.x; i < 81; i += blockDim.x) {
-      const int q01 = i / 9, a01 = i - q01 * 9;
-      const int ix = (q01 % 3) * N1 + (a01 % 3), iy = (q01 / 3) * N1 + (a01 / 3);
-      T.N2[i] = t1.N[ix] * t1.N[iy]; T.DX2[i] = t1.dN[ix] * t1.N[iy]; T.DY2[i] = t1.N[ix] * t1.dN[iy];
+  // ---- scatter: register r of a tile holds the pair (a = 16 TI + (lane>>4) + 4 r, b = column node of the lane)
+  // the doubles of a row image no block covers (alignment head, tail) carry null bases: written before the blocks of every sub-step
+  const int nrow = lane >= 24 ? 1 : 0, nj = lane - 24 * nrow;
+  const int nulli = 256 * nrow + (nj < 8 ? nj : 232 + nj); // lanes 0..47: doubles 0..7 and 240..255 of the two rows
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row0 = 16 * TI + 4 * r;
+    if (row0 >= NU) continue; // rows 28..31 do not exist
+    const int arow = row0 + g;
+    const int ar = arow < NU ? arow : NU - 1;
+    const bool rowok = arow < NU && S.len_uu[ar] >= 0 && !IFEM_PROBE(A.debug_skip == 1);
+    const uint64_t okm = __ballot(rowok); // bit 16 g: row g of this step exists and is owned
+    const int sp = srow[ar];              // position of the row's first block inside its 64-byte segment, in doubles
+    const int64_t rs = S.rs_uu[ar];
+    const uint64_t rowbase = uint64_t(A.v_uu) + 72ull * uint64_t(rs) - 8ull * unsigned(sp); // address of double 0 of the row's image
+    const int64_t row_dof0 = int64_t(DIM) * S.un[ar];
+    int i0[2];
+    uint64_t base[2];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const unsigned w32 = tj == 0 ? ((r & 2) ? rc.y : rc.x) : ((r & 2) ? rc.w : rc.z);
+      const unsigned sc = (r & 1) ? (w32 >> 16) : (w32 & 0xffffu);
+      const unsigned pr = sc & 511u, rank = (sc >> 9) & 31u; // position of my block in the row minus its rank among the cell's 27, rank
+      i0[tj] = sp + BS * int(rank);
+      base[tj] = rowbase + 72ull * pr;
+      if (A.v_s && rowok && 16 * tj + l15 < NU) unsafeAtomicAdd(A.v_s + rs + pr + rank, tj == 0 ? sac0[r] : sac1[r]);
     }
-  __syncthreads();
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      if (row0 + 2 * ss >= NU) continue;
+      if (lane < 48) imb[nulli] = 0ull;
+      const bool writer = rowok && (g >> 1) == ss;
+      const int rowoff = (g & 1) * 256;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        if (!writer || 16 * tj + l15 >= NU) continue;
+        const double s = tj == 0 ? sac0[r] : sac1[r];
+        const int at = rowoff + i0[tj];
+#pragma unroll
+        for (int e = 0; e < BS; ++e) {
+          imv[at + e] = (tj == 0 ? acc0[e][r] : acc1[e][r]) + ((e == 0 || e == 4 || e == 8) ? s : 0.0);
+          imb[at + e] = base[tj];
+        }
+        if (any_c) { // rows / columns of constrained dofs: patch my block in the image
+          const int b = tj == 0 ? bn0 : bn1;
+          const unsigned rm = unsigned(S.cf[ar * 3]) | unsigned(S.cf[ar * 3 + 1]) << 1 | unsigned(S.cf[ar * 3 + 2]) << 2;
+          const unsigned cm = unsigned(S.cf[b * 3]) | unsigned(S.cf[b * 3 + 1]) << 1 | unsigned(S.cf[b * 3 + 2]) << 2;
+          if (rm | cm) {
+#pragma unroll 1
+            for (int e = 0; e < BS; ++e) {
+              const int c = e / 3, d = e - 3 * c;
+              const bool rcn = (rm >> c) & 1u, ccn = (cm >> d) & 1u;
+              if (!rcn && !ccn) continue;
+              const double v = imv[at + e];
+              double w = 0.0;
+              if (rcn) {
+                if (ar == b && c == d) { // |Ke(r,r)| on the diagonal, rhs so that the update equals the inhomogeneity
+                  w = fabs(v);
+                  if (A.use_inhom) unsafeAtomicAdd(&A.rhs[row_dof0 + c], S.cv[ar * 3 + c] * fabs(v));
+                }
+              } else if (A.use_inhom) {
+                const double gi = S.cv[b * 3 + d];
+                if (gi != 0.0) unsafeAtomicAdd(&S.fe[c * NU + ar], -v * gi);
+              }
+              imv[at + e] = w;
+              imb[at + e] = w != 0.0 ? base[tj] : 0ull;
+            }
+          }
+        }
+      }
+      wsync2();
+      // lane l of round rr owns double 64 rr + l of the image: of row rr / 4, at 8 (64 (rr % 4) + l) bytes behind its base
+      {
+        uint64_t bs[8];
+        double wv[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const bool on = row0 + 2 * ss + rr / 4 < NU && ((okm >> (16 * (2 * ss + rr / 4))) & 1ull); // compile-time && wave-uniform: a row of this rank
+          bs[rr] = on ? imb[64 * rr + lane] : 0ull;
+          wv[rr] = on ? imv[64 * rr + lane] : 0.0;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          if (row0 + 2 * ss + rr / 4 >= NU) continue;
+          if (bs[rr] != 0ull) {
+            gdouble *dst = reinterpret_cast<gdouble *>(bs[rr] + 8ull * unsigned(lane)) + 64 * (rr & 3);
+            if (IFEM_PROBE(A.debug_skip == 6)) *dst = wv[rr]; // rate of plain stores in place of the atomics (results invalid)
+            else __builtin_amdgcn_global_atomic_fadd_f64(dst, wv[rr]);
+          }
+        }
+      }
+      wsync2();
+    }
+  }
+}
 
-  const int64_t idx = int64_t(A.xcd_swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * CPB + slot;
-  const bool active = idx < A.count;
-  const int64_t cc = active ? (A.order ? int64_t(A.order[A.first + idx]) : idx) : 0;
+// CPB cells per workgroup, one wavefront each; the workgroup shares the reference tables only.
+template <int CPB>
+__global__ __launch_bounds__(64 * CPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ins_assemble3(AsmArgs A, Tab1D t1) {
+  constexpr int DIM = 3, NU = 27, NP = 8, NQ = 27, ND = 89;
+  constexpr int NBP = NU * NP, BROUNDS = (NBP + 63) / 64;
+  using Cell = Cell4;
+  extern __shared__ __align__(16) unsigned char smem[];
+  Tabs3 &T = *reinterpret_cast<Tabs3 *>(smem);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  Cell &S = *reinterpret_cast<Cell *>(smem + ((sizeof(Tabs3) + 15) & ~size_t(15)) + size_t(wave) * ((sizeof(Cell) + 15) & ~size_t(15)));
+  {
+    const double *src = reinterpret_cast<const double *>(A.tabs3);
+    double *dst = reinterpret_cast<double *>(&T);
+    for (int i = threadIdx.x; i < int(sizeof(Tabs3) / 8); i += 64 * CPB) dst[i] = src[i];
+  }
+  __syncthreads(); // the only workgroup barrier: from here on every wave works on its own cell
+  const int64_t idx = int64_t(A.xcd_swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * CPB + wave;
+  if (idx >= A.count) return;
+  const int64_t cc = A.order ? int64_t(A.order[A.first + idx]) : idx;
   const int64_t p_off = int64_t(DIM) * A.nUl;
-  double *ue = S.scratch, *u0e = S.scratch + NU * DIM, *ae = S.scratch + 2 * NU * DIM, *pe = S.scratch + 3 * NU * DIM;
+  double *const zone = S.zone;
+  const uint8_t *const perm = S.hdr, *const iperm = S.hdr + 32, *const permp = S.hdr + 64;
 
-  // ---- phase 0: ids, coordinates, nodal values, row descriptors, constraint flags.  One workgroup fills a CU's LDS, so
-  // nothing hides a global round trip: every wave issues ALL its loads (two dependent rounds: ids, then everything keyed
-  // by the id) before the first LDS store that needs one.  Optional arrays fall back to a valid address + select.
-  if (h == 0) {
-    const int a = lane < NU ? lane : 0;
-    const int32_t nd = A.cell_unodes[cc * NU + a];
-    int32_t bid = -1;
-    if (A.n_neumann != 0 && lane < 2 * DIM) bid = A.cell_face_bid[cc * 2 * DIM + lane];
-    const bool own = nd < A.nUo;
+  // ---- phase 0: ids, coordinates, nodal values, row descriptors, constraint flags, scatter records.  Lanes 0..26: velocity
+  // nodes, 32..39: pressure nodes, 40..63: vertex coordinates.  Two dependent rounds of loads (ids, then everything keyed by an
+  // id), all issued before the first LDS store; optional arrays fall back to a valid address + select.
+  const bool isU = lane < NU, isP = lane >= 32 && lane < 32 + NP, isX = lane >= 40;
+  const int nf = (A.fsi_acc && A.indicator) ? 9 : 6; // nodal fields carried through phase 1: u, u0 (+ a_fsi)
+  const uint4 *recp = reinterpret_cast<const uint4 *>(A.scat3 + cc * kAsm3Rec);
+  {
+    const int32_t nd = isP ? A.cell_pnodes[cc * NP + (lane - 32)] : A.cell_unodes[cc * NU + (isU ? lane : 0)];
+    const double xv = A.vcoords[cc * NP * DIM + (isX ? lane - 40 : 0)];
+    int32_t bidv = -1;
+    if (A.n_neumann != 0) bidv = A.cell_face_bid[cc * 2 * DIM + (lane < 2 * DIM ? lane : 0)];
+    const int32_t indv = A.indicator ? A.indicator[cc] : 0;
+    const uint32_t hdrw = reinterpret_cast<const uint32_t *>(A.hdr3 + cc * kAsm3Hdr)[lane & 31];
+    const bool own = nd < (isP ? A.nPo : A.nUo);
     const int64_t ndr = own ? nd : 0;
-    const int64_t r0 = A.rp_uu[ndr], r1 = A.rp_uu[ndr + 1], t0 = A.rp_bt[ndr], t1_ = A.rp_bt[ndr + 1];
-    const int64_t dof = int64_t(DIM) * nd;
+    const int64_t *rpa = isP ? A.rp_b : A.rp_uu, *rpb = isP ? A.rp_mp : A.rp_bt;
+    const int64_t r0 = rpa[ndr], r1 = rpa[ndr + 1], t0 = rpb[ndr], t1_ = rpb[ndr + 1];
+    const int64_t dof = isP ? p_off + nd : int64_t(DIM) * nd;
     const double *fa = A.fsi_acc ? A.fsi_acc : A.eval, *cvp = A.cval ? A.cval : A.eval;
     const uint8_t *icp = A.is_c ? A.is_c : reinterpret_cast<const uint8_t *>(A.eval);
     double ev[DIM], pv[DIM], av[DIM], cvv[DIM];
     uint8_t cfv[DIM];
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
-      ev[c] = A.eval[dof + c]; pv[c] = A.present[dof + c]; av[c] = fa[dof + c]; cvv[c] = cvp[dof + c]; cfv[c] = icp[dof + c];
+      const int64_t k = dof + (isP ? 0 : c);
+      ev[c] = A.eval[k]; pv[c] = A.present[k]; av[c] = fa[k]; cvv[c] = cvp[k]; cfv[c] = icp[k];
     }
-    if (lane < NU) {
+    if (isU) {
+      const int a = lane;
       S.un[a] = nd;
       S.rs_uu[a] = own ? r0 : 0; S.len_uu[a] = own ? int32_t(r1 - r0) : -1;
       S.rs_bt[a] = own ? t0 : 0; S.len_bt[a] = own ? int32_t(t1_ - t0) : -1;
 #pragma unroll
       for (int c = 0; c < DIM; ++c) {
-        ue[a * DIM + c] = ev[c];
-        u0e[a * DIM + c] = pv[c];
-        ae[a * DIM + c] = A.fsi_acc ? av[c] : 0.0;
+        zone[c * 27 + a] = ev[c];
+        zone[(3 + c) * 27 + a] = pv[c];
+        if (nf == 9) zone[(6 + c) * 27 + a] = av[c];
         S.cf[a * DIM + c] = A.is_c ? cfv[c] : uint8_t(0);
         S.cv[a * DIM + c] = A.cval ? cvv[c] : 0.0;
       }
     }
-    if (lane < 2 * DIM) S.bid[lane] = bid;
-    for (int i = lane; i < ND; i += 64) S.fe[i] = 0.0;
-  } else {
-    const int b = lane < NP ? lane : 0;
-    const int32_t nd = A.cell_pnodes[cc * NP + b];
-    const double xv = A.vcoords[cc * NP * DIM + (lane < NP * DIM ? lane : 0)];
-    const int32_t indv = (A.indicator && lane == 0) ? A.indicator[cc] : 0;
-    const bool own = nd < A.nPo;
-    const int64_t ndr = own ? nd : 0;
-    const int64_t r0 = A.rp_b[ndr], r1 = A.rp_b[ndr + 1], m0 = A.rp_mp[ndr], m1 = A.rp_mp[ndr + 1];
-    const double *cvp = A.cval ? A.cval : A.eval;
-    const uint8_t *icp = A.is_c ? A.is_c : reinterpret_cast<const uint8_t *>(A.eval);
-    const double pev = A.eval[p_off + nd], cvv = cvp[p_off + nd];
-    const uint8_t cfv = icp[p_off + nd];
-    if (lane < NP * DIM) S.X[lane] = xv;
-    if (lane == 0) S.ind = indv;
-    if (lane < NP) {
+    if (isP) {
+      const int b = lane - 32;
       S.pn[b] = nd;
       S.rs_b[b] = own ? r0 : 0; S.len_b[b] = own ? int32_t(r1 - r0) : -1;
-      S.rs_mp[b] = own ? m0 : 0; S.len_mp[b] = own ? int32_t(m1 - m0) : -1;
-      pe[b] = pev;
-      S.cf[NU * DIM + b] = A.is_c ? cfv : uint8_t(0);
-      S.cv[NU * DIM + b] = A.cval ? cvv : 0.0;
+      S.rs_mp[b] = own ? t0 : 0; S.len_mp[b] = own ? int32_t(t1_ - t0) : -1;
+      zone[972 + b] = ev[0];
+      S.cf[NU * DIM + b] = A.is_c ? cfv[0] : uint8_t(0);
+      S.cv[NU * DIM + b] = A.cval ? cvv[0] : 0.0;
     }
+    if (isX) S.X[lane - 40] = xv;
+    if (lane < 2 * DIM) S.bid[lane] = bidv;
+    if (lane == 0) S.ind = indv;
+    if (lane < 32) reinterpret_cast<uint32_t *>(S.hdr)[lane] = hdrw;
+    for (int i = lane; i < 96; i += 64) S.fe[i] = 0.0;
   }
-  __syncthreads();
-  if (h == 1 && lane < 32) { // rank of every node id among the cell's 27 (ids are distinct); columns 27..31 of the tiles stay padding
-    int rank = lane;
-    if (lane < NU) {
-      const int32_t mine = S.un[lane];
-      rank = 0;
-#pragma unroll 9
-      for (int j = 0; j < NU; ++j) rank += S.un[j] < mine ? 1 : 0;
-    }
-    S.perm[rank] = uint8_t(lane);
-    S.iperm[lane] = uint8_t(rank);
-  }
-  if (h == 1 && lane >= 32 && lane < 32 + NP) { // the same for the 8 pressure nodes (B^T and M_p rows are in column order)
-    const int32_t mine = S.pn[lane - 32];
-    int rank = 0;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) rank += S.pn[j] < mine ? 1 : 0;
-    S.permp[rank] = uint8_t(lane - 32);
-  }
-  if (h == 0 && lane < NP * DIM) { // monomial coefficients of the trilinear map
+  uint4 rec0 = {0, 0, 0, 0}, rec1 = {0, 0, 0, 0}; // [row tile][lane]: (position | rank << 9) of my pairs [column tile][r]
+  if (!A.rhs_only && !A.skip_uu) { rec0 = recp[lane]; rec1 = recp[64 + lane]; }
+  wsync2();
+  const int ind = S.ind;
+  if (lane < NP * DIM) { // monomial coefficients of the trilinear map
     const int k = lane / DIM, e = lane % DIM;
     double acc = 0;
 #pragma unroll
@@ -236,64 +354,32 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
     }
     S.C[k * DIM + e] = acc;
   }
-  __syncthreads();
-  const int ind = active ? S.ind : 0;
-
-  // ---- phase 1: per quadrature point (lane = q): Jacobian, fields of the evaluation point, rhs coefficients
-  // the nodal sums are split over the two waves of the cell: the second wave handles nodes 14..26 and parks its partial
-  // sums in the (not yet built) gradient table
-  // (part1: [27 lanes][18])
-  if (h == 1 && lane < NQ) {
-    const int q = lane;
-    const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
-    double u[3] = {0, 0, 0}, u0[3] = {0, 0, 0}, ac[3] = {0, 0, 0}, gr[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) gr[i] = 0;
-#pragma unroll 1
-    for (int a = 14; a < (A.debug_skip == 6 ? 15 : NU); ++a) {
-      const int ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
-      const double nx = T.t.N[qi[0] * N1 + ai[0]], ny = T.t.N[qi[1] * N1 + ai[1]], nz = T.t.N[qi[2] * N1 + ai[2]];
-      const double dx = T.t.dN[qi[0] * N1 + ai[0]], dy = T.t.dN[qi[1] * N1 + ai[1]], dz = T.t.dN[qi[2] * N1 + ai[2]];
-      const double N = nx * ny * nz, dr[3] = {dx * ny * nz, nx * dy * nz, nx * ny * dz};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double uv = ue[a * 3 + c];
-        u[c] += N * uv; u0[c] += N * u0e[a * 3 + c]; ac[c] += N * ae[a * 3 + c];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) gr[c * 3 + e] += uv * dr[e];
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { part1[q * 18 + c] = u[c]; part1[q * 18 + 3 + c] = u0[c]; part1[q * 18 + 6 + c] = ac[c]; }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) part1[q * 18 + 9 + i] = gr[i];
+  // ---- phase 1: the nodal fields at the 27 points by sum factorisation: values of u, u0 (a_fsi) and the reference gradient of u.
+  // zone: nodal [nf][27] | X pass [nf + 3][27] | Y pass [nf + 6][27] at 567; the Z pass overwrites the first two
+  {
+    double *const nodal = zone, *const PX = zone + 243, *const PY = zone + 567, *const PZ = zone;
+    pencil_pass<0, false, false, false>(t1, nodal, PX, nf, lane);         // N_x of every field
+    pencil_pass<0, false, true, false>(t1, nodal, PX + nf * 27, 3, lane); // N'_x of u
+    wsync2();
+    pencil_pass<1, false, false, false>(t1, PX, PY, nf + 3, lane);          // N_y of all of them
+    pencil_pass<1, false, true, false>(t1, PX, PY + (nf + 3) * 27, 3, lane); // N'_y of (N_x u)
+    wsync2();
+    pencil_pass<2, false, false, false>(t1, PY, PZ, nf + 6, lane);          // values [0, nf), d/dxi_0 u at nf, d/dxi_1 u at nf + 3
+    pencil_pass<2, false, true, false>(t1, PY, PZ + (nf + 6) * 27, 3, lane); // d/dxi_2 u at nf + 6
+    wsync2();
   }
-  double u_[3] = {0, 0, 0}, u0_[3] = {0, 0, 0}, ac_[3] = {0, 0, 0}, gr_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (h == 0 && lane < NQ) { // first half of the nodes, in registers across the barrier
+  // ---- per quadrature point (lane = q): Jacobian, physical gradient, coefficients of the matrix and of the right-hand side
+  // rhs coefficient fields for the transposed passes at zone + 567: [S | V0 | V1 | V2][c][27], div term at zone + 891
+  double *const fld = zone + 567, *const divw_ = zone + 891;
+  // the mass term rho/dt N_a N_b rides on the Newton term's diagonal blocks; without a Newton term (IMEX), or when the scalar
+  // part is wanted by itself (v_s), it is one more product of the scalar part
+  const bool mass_s = A.imex || A.v_s != nullptr;
+  if (lane < NQ) {
     const int q = lane;
-    const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
-#pragma unroll 1
-    for (int a = 0; a < (A.debug_skip == 6 ? 1 : 14); ++a) {
-      const int ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
-      const double nx = T.t.N[qi[0] * N1 + ai[0]], ny = T.t.N[qi[1] * N1 + ai[1]], nz = T.t.N[qi[2] * N1 + ai[2]];
-      const double dx = T.t.dN[qi[0] * N1 + ai[0]], dy = T.t.dN[qi[1] * N1 + ai[1]], dz = T.t.dN[qi[2] * N1 + ai[2]];
-      const double N = nx * ny * nz, dr[3] = {dx * ny * nz, nx * dy * nz, nx * ny * dz};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double uv = ue[a * 3 + c];
-        u_[c] += N * uv; u0_[c] += N * u0e[a * 3 + c]; ac_[c] += N * ae[a * 3 + c];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) gr_[c * 3 + e] += uv * dr[e];
-      }
-    }
-  }
-  __syncthreads();
-  if (h == 0 && lane < NQ) {
-    const int q = lane;
-    const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
+    const int qi[3] = {q % 3, (q / 3) % 3, q / 9};
     double xi[3], wq = 1.0;
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) { xi[d] = T.t.xi[qi[d]]; wq *= T.t.w[qi[d]]; }
+    for (int d = 0; d < DIM; ++d) { xi[d] = t1.xi[0] * (qi[d] == 0) + t1.xi[1] * (qi[d] == 1) + t1.xi[2] * (qi[d] == 2); wq *= t1.w[0] * (qi[d] == 0) + t1.w[1] * (qi[d] == 1) + t1.w[2] * (qi[d] == 2); }
     double J[9], Ji[9];
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
@@ -307,29 +393,29 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
     const double w = fabs(det) * wq;
     double u[3], u0[3], ac[3], gr[9], p = 0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { u[c] = u_[c] + part1[q * 18 + c]; u0[c] = u0_[c] + part1[q * 18 + 3 + c]; ac[c] = ac_[c] + part1[q * 18 + 6 + c]; }
+    for (int c = 0; c < 3; ++c) {
+      u[c] = zone[c * 27 + q]; u0[c] = zone[(3 + c) * 27 + q]; ac[c] = nf == 9 ? zone[(6 + c) * 27 + q] : 0.0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) gr[i] = gr_[i] + part1[q * 18 + 9 + i];
+      for (int e = 0; e < 3; ++e) gr[c * 3 + e] = zone[(nf + 3 * e + c) * 27 + q];
+    }
 #pragma unroll
-    for (int b = 0; b < NP; ++b) p += T.psi[q * NP + b] * pe[b];
-    double g[9], dv = 0;
+    for (int b = 0; b < NP; ++b) p += T.psi[q * NP + b] * zone[972 + b];
+    double g[9];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        double t = 0;
-#pragma unroll
-        for (int e = 0; e < 3; ++e) t += gr[c * 3 + e] * Ji[e * 3 + d];
-        g[c * 3 + d] = t;
-      }
-    dv = g[0] + g[4] + g[8];
+      for (int d = 0; d < 3; ++d) g[c * 3 + d] = gr[c * 3] * Ji[d] + gr[c * 3 + 1] * Ji[3 + d] + gr[c * 3 + 2] * Ji[6 + d];
+    const double dv = g[0] + g[4] + g[8];
+    const double rdtw = A.rho * A.inv_dt * w;
     S.JxW[q] = w;
-    divw_[q] = w * dv;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { Ji_[q * 9 + i] = Ji[i]; S.gqs[q * 9 + i] = A.imex ? 0.0 : A.rho * w * g[i]; }
+    for (int i = 0; i < 9; ++i) {
+      S.Ji[q * 9 + i] = Ji[i];
+      S.gqs[q * 9 + i] = (A.imex ? 0.0 : A.rho * w * g[i]) + (((i == 0 || i == 4 || i == 8) && !mass_s) ? rdtw : 0.0);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      S.uq[q * 3 + c] = A.imex ? 0.0 : u[c]; // only the matrix reads uq (u . grad N_b): no convection in the IMEX matrix
+      S.rwu[q * 3 + c] = A.imex ? 0.0 : A.rho * w * u[c]; // only the matrix reads it (u . grad N_b): no convection in the IMEX matrix
       double adv = 0, vc[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
@@ -337,31 +423,22 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
         vc[d] = w * (-A.mu * g[c * 3 + d] + (c == d ? p - A.gamma * A.rho * dv : 0.0));
       }
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        if constexpr (OTF) Vc_[(q * 3 + c) * 3 + d] = Ji[d * 3] * vc[0] + Ji[d * 3 + 1] * vc[1] + Ji[d * 3 + 2] * vc[2]; // reference-gradient basis
-        else Vc_[(q * 3 + c) * 3 + d] = vc[d];
-      }
+      for (int e = 0; e < 3; ++e) fld[((1 + e) * 3 + c) * 27 + q] = Ji[e * 3] * vc[0] + Ji[e * 3 + 1] * vc[1] + Ji[e * 3 + 2] * vc[2]; // reference-gradient basis
       double sc = -A.rho * adv - A.rho * A.inv_dt * (u[c] - u0[c]) + A.rho * A.g[c];
       if (ind == 1) sc += A.rho * ac[c];
-      Sc_[q * 3 + c] = w * sc;
+      fld[c * 27 + q] = w * sc;
     }
-  }
-  __syncthreads();
-  // ---- node tables, once per cell: tabN[q][a], tabG[d][q][a] (both waves, interleaved rounds)
-  if constexpr (!OTF)
-  for (int t = lane + 64 * h; t < (A.debug_skip == 7 ? 128 : NQ * NU); t += 128) {
-    const int q = t / NU, a = t - q * NU;
-    const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)}, ai[3] = {a % N1, (a / N1) % N1, a / (N1 * N1)};
-    const double nx = T.t.N[qi[0] * N1 + ai[0]], ny = T.t.N[qi[1] * N1 + ai[1]], nz = T.t.N[qi[2] * N1 + ai[2]];
-    const double dx = T.t.dN[qi[0] * N1 + ai[0]], dy = T.t.dN[qi[1] * N1 + ai[1]], dz = T.t.dN[qi[2] * N1 + ai[2]];
-    const double dr[3] = {dx * ny * nz, nx * dy * nz, nx * ny * dz};
-    S.tabN[q][a] = nx * ny * nz;
+    divw_[q] = w * dv;
+  } else if (lane == NQ) { // the padding point of the K dimension
+    S.JxW[NQ] = 0.0;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) S.tabG[d][q][a] = dr[0] * Ji_[q * 9 + d] + dr[1] * Ji_[q * 9 + 3 + d] + dr[2] * Ji_[q * 9 + 6 + d];
+    for (int i = 0; i < 9; ++i) { S.Ji[NQ * 9 + i] = 0.0; S.gqs[NQ * 9 + i] = 0.0; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) S.rwu[NQ * 3 + c] = 0.0;
   }
-  __syncthreads();
+  wsync2();
   // ---- Neumann (pressure) boundary faces  (:313-341)
-  if (A.n_neumann != 0 && active && h == 0) {
+  if (A.n_neumann != 0) {
     for (int f = 0; f < 2 * DIM; ++f) {
       const int bid = S.bid[f];
       if (bid < 0) continue;
@@ -370,7 +447,7 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
       if (!hit) continue;
       const int nd = f >> 1; const double sgn = (f & 1) ? 1.0 : -1.0;
       for (int i = lane; i < NU * DIM; i += 64) {
-        const int a = i / DIM, c = i - a * DIM;
+        const int c = i / NU, a = i - c * NU;
         double acc = 0;
 #pragma unroll 1
         for (int qf = 0; qf < A.fe->nqf; ++qf) {
@@ -386,63 +463,63 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
           nn = sqrt(nn);
           acc += A.fe->fphi[(f * A.fe->nqf + qf) * NU + a] * (nv[c] / nn) * pbc * fabs(det) * nn * A.fe->fw[qf];
         }
-        unsafeAtomicAdd(&S.fe[i], -acc); // the cell's second wave adds to S.fe concurrently
+        S.fe[i] -= acc;
       }
     }
+    wsync2();
   }
-  wsync2();
-  // ---- local rhs (:281-304) from the tables: first wave; the second wave integrates B / B^T and M_p meanwhile
-  if (h == 0)
+  // ---- local rhs (:281-304): the transposed passes, fe[c][a] += sum_q N_a S_c + d_e N_a V_ce
+  {
+    double *const ZA = zone, *const YB = zone + 243;
+    pencil_pass<2, true, false, false>(t1, fld, ZA, 9, lane);         // N_z^T of S, V0, V1
+    wsync2();
+    pencil_pass<2, true, true, true>(t1, fld + 9 * 27, ZA, 3, lane);  // + N'_z^T V2 onto the S part
+    wsync2();
+    pencil_pass<1, true, false, false>(t1, ZA, YB, 6, lane);          // N_y^T of (S + V2) and V0
+    wsync2();
+    pencil_pass<1, true, true, true>(t1, ZA + 6 * 27, YB, 3, lane);   // + N'_y^T V1
+    wsync2();
+    pencil_pass<0, true, false, true>(t1, YB, S.fe, 3, lane);         // N_x^T
+    wsync2();
+    pencil_pass<0, true, true, true>(t1, YB + 3 * 27, S.fe, 3, lane); // + N'_x^T V0
+    { // pressure rows: sum_q (w div u) psi_b
+      const int b = lane & 7, k = lane >> 3;
+      double f = 0;
 #pragma unroll
-  for (int k = 0; k < FR; ++k) {
-    const int i = lane + 64 * k;
-    double f = 0;
-    if (i < NU * DIM) {
-      const int a = i / DIM, c = i - a * DIM;
-#pragma unroll 3
-      for (int q = 0; q < NQ; ++q) {
-        if constexpr (OTF) {
-          double N, r[3];
-          shape_ref(T, q, a, N, r);
-          f += Sc_[q * 3 + c] * N + Vc_[(q * 3 + c) * 3 + 0] * r[0] + Vc_[(q * 3 + c) * 3 + 1] * r[1] + Vc_[(q * 3 + c) * 3 + 2] * r[2];
-        } else
-        f += Sc_[q * 3 + c] * S.tabN[q][a] + Vc_[(q * 3 + c) * 3 + 0] * S.tabG[0][q][a] + Vc_[(q * 3 + c) * 3 + 1] * S.tabG[1][q][a] +
-             Vc_[(q * 3 + c) * 3 + 2] * S.tabG[2][q][a];
+      for (int j = 0; j < 4; ++j) {
+        const int q = k + 8 * j;
+        if (q < NQ) f += divw_[q] * T.psi[q * NP + b];
       }
-    } else if (i < ND) {
-#pragma unroll 3
-      for (int q = 0; q < NQ; ++q) f += divw_[q] * T.psi[q * NP + (i - NU * DIM)];
+      f += __shfl_xor(f, 8); f += __shfl_xor(f, 16); f += __shfl_xor(f, 32);
+      if (lane < NP) S.fe[NU * DIM + lane] += f;
     }
-    if (i < ND) unsafeAtomicAdd(&S.fe[i], f);
+    wsync2();
   }
 
   // ---- velocity-pressure blocks: -JxW psi_b grad N_a
-  bool need_b = !A.rhs_only && A.debug_skip < 3 && active && h == 1;
+  bool need_b = !A.rhs_only && !IFEM_PROBE(A.debug_skip >= 3);
   if (need_b && A.skip_geo) { // cached blocks: only a cell with an inhomogeneous constrained dof still needs the entries
     const bool mine = (lane < ND && S.cf[lane] && S.cv[lane] != 0.0) || (lane + 64 < ND && S.cf[lane + 64] && S.cv[lane + 64] != 0.0);
     need_b = A.use_inhom && __any(mine);
   }
   // Lanes = (velocity node a, pressure node in id order): the eight entries of a B^T row land next to each other.  The B entries go
-  // through LDS (bst, the idle scratch zone) into the order (pressure node, velocity nodes by id) = the order of B's rows, so that
-  // neighbouring lanes of its atomics hit neighbouring entries too: 984 -> ~530 64-byte segments per cell for B, B^T and M_p
-  double *const bst = S.scratch;
+  // through LDS (the idle zone) into the order (pressure node, velocity nodes by id) = the order of B's rows, so that
+  // neighbouring lanes of its atomics hit neighbouring entries too
   if (need_b) {
+    double *const bst = zone;
 #pragma unroll 1
     for (int k = 0; k < BROUNDS; ++k) {
       const int t = lane + 64 * k;
       if (t >= NBP) continue;
-      const int a = t / NP, pb = S.permp[t - a * NP];
+      const int a = t / NP, pb = permp[t - a * NP];
+      const int a9 = a % 9, a3 = a / 9;
       double v[3] = {0, 0, 0};
 #pragma unroll 3
       for (int q = 0; q < NQ; ++q) {
         const double wpsi = S.JxW[q] * T.psi[q * NP + pb];
-        if constexpr (OTF) {
-          double N, g[3];
-          shape_otf(T, Ji_ + q * 9, q, a, N, g);
-          v[0] -= wpsi * g[0]; v[1] -= wpsi * g[1]; v[2] -= wpsi * g[2];
-        } else {
-        v[0] -= wpsi * S.tabG[0][q][a]; v[1] -= wpsi * S.tabG[1][q][a]; v[2] -= wpsi * S.tabG[2][q][a];
-        }
+        double N, g[3];
+        shape_phys4(T, S.Ji + q * 9, (q % 9) * 9, (q / 9) * 4, a9, a3, N, g);
+        v[0] -= wpsi * g[0]; v[1] -= wpsi * g[1]; v[2] -= wpsi * g[2];
       }
       const bool pc = S.cf[NU * DIM + pb];
       if (S.len_bt[a] >= 0) {
@@ -452,7 +529,7 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
         for (int c = 0; c < DIM; ++c) {
           if (S.cf[a * DIM + c]) continue;
           if (!pc) { if (!A.skip_geo) unsafeAtomicAdd(base + int64_t(c) * len, v[c]); }
-          else if (A.use_inhom && S.cv[NU * DIM + pb] != 0.0) unsafeAtomicAdd(&S.fe[a * DIM + c], -v[c] * S.cv[NU * DIM + pb]);
+          else if (A.use_inhom && S.cv[NU * DIM + pb] != 0.0) unsafeAtomicAdd(&S.fe[c * NU + a], -v[c] * S.cv[NU * DIM + pb]);
         }
       }
       const bool brow = S.len_b[pb] >= 0 && !pc;
@@ -463,7 +540,7 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
           if (!S.cf[a * DIM + c]) w = v[c];
           else if (A.use_inhom && S.cv[a * DIM + c] != 0.0) unsafeAtomicAdd(&S.fe[NU * DIM + pb], -v[c] * S.cv[a * DIM + c]);
         }
-        if (!A.skip_geo) bst[(pb * NU + S.iperm[a]) * DIM + c] = w;
+        if (!A.skip_geo) bst[(pb * NU + iperm[a]) * DIM + c] = w;
       }
     }
     if (!A.skip_geo) { // B in row order: lane = (pressure node, velocity node by id), one plane per instruction
@@ -472,7 +549,7 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
       for (int k = 0; k < BROUNDS; ++k) {
         const int t = lane + 64 * k;
         if (t >= NBP) continue;
-        const int pb = t / NU, a = S.perm[t - pb * NU];
+        const int pb = t / NU, a = perm[t - pb * NU];
         if (S.len_b[pb] < 0) continue;
         const int len = S.len_b[pb];
         double *base = A.v_b + S.rs_b[pb] * DIM + A.posPU[(cc * NP + pb) * NU + a];
@@ -485,33 +562,33 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
     }
   }
   // ---- pressure mass matrix M_p and diag(M_u)
-  if (!A.rhs_only && !A.skip_geo && A.debug_skip < 4) {
-    if (h == 1 && lane < NP * NP) {
-      const int pa = lane / NP, pb = S.permp[lane - pa * NP];
+  if (!A.rhs_only && !A.skip_geo && !IFEM_PROBE(A.debug_skip >= 4)) {
+    {
+      const int pa = lane / NP, pb = permp[lane - pa * NP];
       double m = 0;
 #pragma unroll 3
       for (int q = 0; q < NQ; ++q) m += S.JxW[q] * T.psi[q * NP + pa] * T.psi[q * NP + pb];
-      if (active && S.len_mp[pa] >= 0) {
+      if (S.len_mp[pa] >= 0) {
         const bool ra = S.cf[NU * DIM + pa], cb = S.cf[NU * DIM + pb];
         double *dst = A.v_mp + S.rs_mp[pa] + A.posPP[(cc * NP + pa) * NP + pb];
         if (!ra && !cb) unsafeAtomicAdd(dst, m);
         else if (ra && pa == pb) unsafeAtomicAdd(dst, fabs(m));
       }
     }
-    if (h == 0 && lane < NU) {
+    if (lane < NU) {
+      const int a9 = lane % 9, a3 = lane / 9;
       double m = 0;
 #pragma unroll 3
       for (int q = 0; q < NQ; ++q) {
-        double N;
-        if constexpr (OTF) { double r[3]; shape_ref(T, q, lane, N, r); }
-        else N = S.tabN[q][lane];
+        double N, r[3];
+        shape_ref4(T, (q % 9) * 9, (q / 9) * 4, a9, a3, N, r);
         m += S.JxW[q] * N * N;
       }
-      if (active && S.len_uu[lane] >= 0)
+      if (S.len_uu[lane] >= 0)
         for (int c = 0; c < DIM; ++c) unsafeAtomicAdd(&A.diagMu[int64_t(DIM) * S.un[lane] + c], m);
     }
   }
-  __syncthreads(); // rhs, B / B^T and M_p are integrated: the dead zone may be reused, S.fe is complete up to the scatter corrections
+  wsync2(); // rhs, B / B^T and M_p are integrated: the zone may be reused, S.fe is complete up to the scatter corrections
   // most cells carry no constrained dof: a wave-uniform flag lets their scatter skip the per-entry constraint logic
   bool any_c;
   {
@@ -519,181 +596,88 @@ __global__ __launch_bounds__(128 * CPB) __attribute__((amdgpu_waves_per_eu(WAVES
     for (int i = lane; i < ND; i += 64) mine = mine || S.cf[i];
     any_c = __any(mine);
   }
-  const double wgam = A.gamma * A.rho, rdt = A.rho * A.inv_dt;
-  double *stage = h == 0 ? S.scratch : S.dead; // the second wave stages in the dead zone (Ji, Vc, Sc, divw are consumed)
-  int64_t *soff = reinterpret_cast<int64_t *>(stage + 64 * BS);
-  // ---- velocity-velocity block on the matrix cores, one 16x16 tile pair (ti, tj) at a time
-  if (!A.rhs_only && !A.skip_uu && A.debug_skip < 5) {
-#pragma unroll 1
-    for (int tp = 2 * h; tp < 2 * h + 2; ++tp) {
-      const int ti = tp >> 1, tj = tp & 1;
-      const int al = 16 * ti + (lane & 15), bl = S.perm[16 * tj + (lane & 15)]; // my A-row node, my B-column node (columns in node-id order)
-      const bool av = al < NU, bv = bl < NU;
-      const int ac_ = av ? al : 0, bc_ = bv ? bl : 0;
-      d4 acc[BS], sac = {0, 0, 0, 0};
-#pragma unroll
-      for (int e = 0; e < BS; ++e) acc[e] = d4{0, 0, 0, 0};
-      // scatter positions of my four pairs: loaded now, needed after the contraction
-      uint16_t posr[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int a = 16 * ti + (lane >> 4) + 4 * r;
-        posr[r] = A.posUU[(cc * NU + (a < NU ? a : 0)) * NU + bc_]; // unconditional (clamped): no branch, no wait here
-      }
-      if (A.debug_skip != 2) {
-#pragma unroll OTF ? 1 : 7
-        for (int ks = 0; ks < 7; ++ks) {
-          const int q = 4 * ks + (lane >> 4);
-          const bool qv = q < NQ;
-          const int qq = qv ? q : 0;
-          const double ma = (av && qv) ? 1.0 : 0.0, mb = (bv && qv) ? 1.0 : 0.0; // padding rows / columns / points contribute 0
-          const double w = S.JxW[qq];
-          double Na, Nb, ga[3], gb[3];
-          if constexpr (OTF) {
-            shape_otf(T, Ji_ + qq * 9, qq, ac_, Na, ga);
-            shape_otf(T, Ji_ + qq * 9, qq, bc_, Nb, gb);
-            Na *= ma; Nb *= mb;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { ga[d] *= ma; gb[d] *= mb; }
-          } else {
-            Na = ma * S.tabN[qq][ac_]; Nb = mb * S.tabN[qq][bc_];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { ga[d] = ma * S.tabG[d][qq][ac_]; gb[d] = mb * S.tabG[d][qq][bc_]; }
-          }
-          const double ugb = S.uq[qq * 3] * gb[0] + S.uq[qq * 3 + 1] * gb[1] + S.uq[qq * 3 + 2] * gb[2];
-          const double wmu = w * A.mu, wNa = w * Na;
-          // scalar part
-          sac = __builtin_amdgcn_mfma_f64_16x16x4f64(wmu * ga[0], gb[0], sac, 0, 0, 0);
-          // grad-div part of the nine blocks (independent accumulators between dependent MFMAs)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const double wga = w * wgam * ga[c];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) acc[c * 3 + d] = __builtin_amdgcn_mfma_f64_16x16x4f64(wga, gb[d], acc[c * 3 + d], 0, 0, 0);
-          }
-          sac = __builtin_amdgcn_mfma_f64_16x16x4f64(wmu * ga[1], gb[1], sac, 0, 0, 0);
-          if (!A.imex) { // Newton term rho N_a N_b d_d u_c
-#pragma unroll
-            for (int e = 0; e < BS; ++e) acc[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(Na * S.gqs[qq * 9 + e], Nb, acc[e], 0, 0, 0);
-          }
-          sac = __builtin_amdgcn_mfma_f64_16x16x4f64(wmu * ga[2], gb[2], sac, 0, 0, 0);
-          if (!A.imex) sac = __builtin_amdgcn_mfma_f64_16x16x4f64(A.rho * wNa, ugb, sac, 0, 0, 0);
-          sac = __builtin_amdgcn_mfma_f64_16x16x4f64(rdt * wNa, Nb, sac, 0, 0, 0);
-        }
-      }
-      // ---- scatter: register r of a tile holds the pair (a = 16 ti + (lane>>4) + 4 r, b = 16 tj + (lane&15))
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int a = 16 * ti + (lane >> 4) + 4 * r, b = bl;
-        const bool have = active && a < NU && b < NU && S.len_uu[a < NU ? a : 0] >= 0 && !A.debug_skip;
-        // stage slot: my 16-lane group holds one matrix row; its pairs in the order of their positions in that row
-        const int slot = (lane & 48) | rank_in_row16(bv ? (unsigned(posr[r]) << 4 | unsigned(lane & 15)) : (0x100000u | unsigned(lane & 15)));
-        int64_t off = -1;
-        if (have) {
-          const uint16_t pos = posr[r];
-          off = uu_base(S.rs_uu[a], S.len_uu[a], pos, BS);
-          const double s = sac[r];
-          const int64_t row_dof0 = int64_t(DIM) * S.un[a];
-          if (A.v_s) unsafeAtomicAdd(A.v_s + S.rs_uu[a] + pos, s);
-          if (!any_c) {
-#pragma unroll
-            for (int e = 0; e < BS; ++e) stage[slot * BS + e] = acc[e][r] + ((e == 0 || e == 4 || e == 8) ? s : 0.0);
-          } else
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const bool rc = S.cf[a * 3 + c];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-              const bool ccn = S.cf[b * 3 + d];
-              const double v = acc[c * 3 + d][r] + (c == d ? s : 0.0);
-              double w = 0.0;
-              if (!rc && !ccn) w = v;
-              else if (rc) {
-                if (a == b && c == d) { // |Ke(r,r)| on the diagonal, rhs so that the update equals the inhomogeneity
-                  w = fabs(v);
-                  if (A.use_inhom) unsafeAtomicAdd(&A.rhs[row_dof0 + c], S.cv[a * 3 + c] * fabs(v));
-                }
-              } else if (A.use_inhom) {
-                const double g = S.cv[b * 3 + d];
-                if (g != 0.0) unsafeAtomicAdd(&S.fe[a * 3 + c], -v * g);
-              }
-              stage[slot * BS + c * 3 + d] = w;
-            }
-          }
-        }
-        soff[slot] = off;
-        wsync2();
-        // lane = (pair, entry) of the four matrix rows staged above, each row's 144 values shifted by the position of its first
-        // block inside a 64-byte segment: an instruction boundary (every 64 lanes) then falls on a segment boundary wherever the
-        // row's blocks are contiguous, instead of making two instructions touch the same segment (tools/scatter_sim.py)
-#pragma unroll
-        for (int rr = 0; rr < BS + 1; ++rr) {
-          const int t = lane + 64 * rr, g = t / SPAN;
-          const int64_t o0 = soff[16 * (g < 4 ? g : 0)];
-          const int u = t - g * SPAN - (o0 >= 0 ? int(o0 & 7) : 0);
-          const bool in = g < 4 && u >= 0 && u < 16 * BS;
-          const int uc = in ? u : 0, pl = uc / BS, e = uc - pl * BS;
-          const int64_t o = in ? soff[16 * g + pl] : -1;
-          const double w = stage[(16 * (g < 4 ? g : 0) + pl) * BS + e];
-          if (o >= 0 && w != 0.0) unsafeAtomicAdd(A.v_uu + o + e, w);
-        }
-        wsync2();
-      }
-    }
+  // ---- velocity-velocity block on the matrix cores, one row tile (16 matrix rows) after the other
+  if (!A.rhs_only && !A.skip_uu && !IFEM_PROBE(A.debug_skip == 5)) {
+    row_tile<0>(A, T, S, rec0, lane, any_c, mass_s);
+    row_tile<1>(A, T, S, rec1, lane, any_c, mass_s);
   }
-  __syncthreads();
+  wsync2();
   // ---- rhs scatter (unconstrained owned rows; constrained rows were handled with the diagonal)
-  if (active && h == 0) {
-    for (int i = lane; i < ND; i += 64) {
-      if (S.cf[i]) continue;
-      if (i < NU * DIM) {
-        const int a = i / DIM, c = i - a * DIM;
-        if (S.len_uu[a] >= 0) unsafeAtomicAdd(&A.rhs[int64_t(DIM) * S.un[a] + c], S.fe[i]);
-      } else {
-        const int b = i - NU * DIM;
-        if (S.len_b[b] >= 0) unsafeAtomicAdd(&A.rhs[int64_t(DIM) * A.nUo + S.pn[b]], S.fe[i]);
-      }
+  for (int i = lane; i < ND; i += 64) {
+    if (i < NU * DIM) {
+      const int c = i / NU, a = i - c * NU;
+      if (!S.cf[a * DIM + c] && S.len_uu[a] >= 0) unsafeAtomicAdd(&A.rhs[int64_t(DIM) * S.un[a] + c], S.fe[i]);
+    } else {
+      const int b = i - NU * DIM;
+      if (!S.cf[i] && S.len_b[b] >= 0) unsafeAtomicAdd(&A.rhs[int64_t(DIM) * A.nUo + S.pn[b]], S.fe[i]);
     }
   }
 }
 
-// 3D Q2/Q1 only; the block-interleaved A_uu layout is assumed by the staged scatter
-template <bool OTF, int WAVES, int CPB> // CPB cells per workgroup (two waves each)
+// reference tables of the Q2/Q1 hexahedron at the 27 Gauss points (built once per process, uploaded once per device)
+static void build_tabs3(Tabs3 &T, const Tab1D &t) {
+  std::memset(&T, 0, sizeof(T));
+  for (int q = 0; q < 3; ++q)
+    for (int a = 0; a < 3; ++a) { T.Nz[q * 4 + a] = t.N[q * 3 + a]; T.dNz[q * 4 + a] = t.dN[q * 3 + a]; }
+  for (int i = 0; i < 81; ++i) {
+    const int q01 = i / 9, a01 = i - q01 * 9;
+    const int ix = (q01 % 3) * 3 + (a01 % 3), iy = (q01 / 3) * 3 + (a01 / 3);
+    T.N2[i] = t.N[ix] * t.N[iy]; T.DX2[i] = t.dN[ix] * t.N[iy]; T.DY2[i] = t.N[ix] * t.dN[iy];
+  }
+  for (int i = 0; i < 27 * 8; ++i) {
+    const int q = i / 8, b = i - q * 8;
+    double v = 1;
+    for (int d = 0; d < 3; ++d) {
+      const int qd = d == 0 ? q % 3 : (d == 1 ? (q / 3) % 3 : q / 9);
+      const double x = t.xi[qd];
+      v *= ((b >> d) & 1) ? x : 1.0 - x;
+    }
+    T.psi[i] = v;
+  }
+}
+
+template <int CPB>
 static void launch3(ifem_ctx *ctx, const AsmArgs &A) {
-  const size_t smem = ((sizeof(typename std::conditional<OTF, Shared3Otf, Shared3>::type) + 15) & ~size_t(15)) + CPB * ((sizeof(Cell3<OTF>) + 15) & ~size_t(15));
+  const size_t smem = ((sizeof(Tabs3) + 15) & ~size_t(15)) + CPB * ((sizeof(Cell4) + 15) & ~size_t(15));
   // the dynamic-LDS limit is an attribute of the function ON A DEVICE: remembered per device, not per process
   static std::mutex mu;
   static std::set<int> done;
   {
     std::lock_guard<std::mutex> lk(mu);
     if (!done.count(ctx->device)) {
-      IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ins_assemble3<CPB, OTF, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      IFEM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ins_assemble3<CPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       done.insert(ctx->device);
     }
   }
   Tab1D t;
   tab1d(t, 2);
+  if (ctx->tabs3.n == 0) {
+    Tabs3 T;
+    build_tabs3(T, t);
+    ctx->tabs3.upload(&T, 1, ctx->stream);
+    IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // T is a stack object
+  }
   AsmArgs B = A;
   B.order = nullptr; B.first = 0; B.count = A.n_cells;
+  B.tabs3 = ctx->tabs3.p; B.scat3 = ctx->scat3.p; B.hdr3 = ctx->hdr3.p;
   const int64_t nblk = (B.count + CPB - 1) / CPB;
-  hipLaunchKernelGGL((k_ins_assemble3<CPB, OTF, WAVES>), dim3((unsigned)nblk), dim3(128 * CPB), smem, ctx->stream, B, t);
+  hipLaunchKernelGGL((k_ins_assemble3<CPB>), dim3((unsigned)nblk), dim3(64 * CPB), smem, ctx->stream, B, t);
   IFEM_HIP_CHECK(hipGetLastError());
 }
 
+// 3D Q2/Q1 only; the block-interleaved A_uu layout is assumed by the staged scatter, rows of at most 511 blocks by its records
 bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A) {
 #if !IFEM_UU_INTERLEAVED
   return false;
 #else
-  if (ctx->dim != 3 || ctx->kv != 2) return false;
-  const int v = ctx->tune.asm3_variant;
-  const bool tables = v == 1 || (v == 2 && !A.skip_geo && !A.rhs_only);
-  const int cpb = ctx->tune.asm3_cpb;
-  if (tables) launch3<false, 0, 2>(ctx, A); // register allocation left to the compiler, as in rounds 1-2 (170 + 80 accumulation registers)
-  else if (ctx->tune.asm3_waves == 4) launch3<true, 4, 2>(ctx, A);
-  else if (ctx->tune.asm3_waves == 2) launch3<true, 2, 2>(ctx, A);
-  else if (cpb == 1) launch3<true, 3, 1>(ctx, A);
-  else if (cpb == 4) launch3<true, 3, 4>(ctx, A);
-  else launch3<true, 3, 2>(ctx, A);
+  if (ctx->dim != 3 || ctx->kv != 2 || ctx->tune.asm3_variant == 1) return false;
+  if (!ensure_scat3(ctx, !A.skip_uu && !A.rhs_only)) return false;
+  switch (ctx->tune.asm3_cpb) {
+  case 1: launch3<1>(ctx, A); break;
+  case 4: launch3<4>(ctx, A); break;
+  case 8: launch3<8>(ctx, A); break;
+  default: launch3<2>(ctx, A);
+  }
   return true;
 #endif
 }

@@ -27,6 +27,7 @@ struct AsmArgs {
   const double *vcoords;
   const int32_t *cell_unodes, *cell_pnodes, *cell_face_bid, *indicator;
   const uint16_t *posUU, *posUP, *posPU, *posPP;
+  const uint16_t *scat3; const uint8_t *hdr3; const Tabs3 *tabs3; // 3D Q2/Q1 cell kernel only (assemble3.hip)
   const int64_t *rp_uu, *rp_bt, *rp_b, *rp_mp;
   double *v_uu, *v_bt, *v_b, *v_mp, *diagMu, *rhs;
   double *v_s; // scalar velocity operator (one value per A_uu block) or nullptr
@@ -45,7 +46,7 @@ struct AsmArgs {
   int skip_geo;   // B, B^T, M_p and diag(M_u) of the previous assembly are still valid (same mesh, same constraint set):
                   // integrate them only where a constrained dof needs their entries for the right-hand side
   int skip_uu;    // geometry-only assembly (multigrid levels): the velocity-velocity block is neither integrated nor scattered
-  int debug_skip; // measurement aid (IFEM_ASM_SKIP): 1 = skip the A_uu scatter, 2 = skip the pair contraction too
+  int debug_skip; // measurement builds only (-DIFEM_ASM_PROBES, ifem_tuning::asm_skip): 1 = no A_uu scatter, 2 = no contraction either
 };
 
 template <int DIM>

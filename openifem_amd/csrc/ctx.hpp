@@ -218,6 +218,21 @@ struct MgCsr {
 };
 } // namespace ifem
 
+namespace ifem {
+// reference tables of the 3D Q2/Q1 cell kernel (assemble3.hip), built on the host, copied into LDS by every workgroup
+struct Tabs3 {
+  double Nz[16], dNz[16];           // [q2 (4)][a2 (4)] 1D shape values / derivatives, zero for q2 = 3 or a2 = 3 (MFMA padding)
+  double N2[81], DX2[81], DY2[81];  // [(q0 q1)][(a0 a1)]: N_x N_y, N'_x N_y, N_x N'_y
+  double psi[27 * 8];               // [q][b] trilinear (pressure, geometry)
+};
+// per-cell records of that kernel (setup.hip::ensure_scat3): kAsm3Rec uint16 = [row tile 2][lane 64][column tile 2][r 4] holding
+// (position of the block in its A_uu row - rank | rank << 9), rank = rank of that position among the row's 27 blocks of this cell,
+// 0xFFFF = no block; kAsm3Hdr bytes = perm[32] (tile column -> local node, the cell's nodes in the order of their ids) | iperm[32] |
+// permp[8] (the same for the pressure nodes) | srow[32] (position of the row's first block inside a 64-byte segment, in doubles) | padding
+constexpr int kAsm3Rec = 1024, kAsm3Hdr = 128;
+
+} // namespace ifem
+
 struct ifem_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -322,6 +337,11 @@ struct ifem_ctx {
   // scatter maps: position of the column inside the row, 0xFFFF = row not owned here
   ifem::DBuf<uint16_t> posUU, posUP, posPU, posPP;
   ifem::DBuf<int32_t> uu_diag_pos; // position of the diagonal block in every owned A_uu row (setup.hip::ensure_auu_values)
+  // 3D Q2/Q1 cell kernel (assemble3.hip): per-cell scatter records and headers (setup.hip::ensure_scat3), reference tables
+  ifem::DBuf<uint16_t> scat3;
+  ifem::DBuf<uint8_t> hdr3;
+  ifem::DBuf<ifem::Tabs3> tabs3;
+  bool hdr3_rows = false; // the headers carry the row alignments of the present A_uu row order
   // constraints (local dof numbering), sets 0 = zero, 1 = nonzero
   ifem::DBuf<uint8_t> is_c[2];
   ifem::DBuf<double> cval[2];

@@ -9,6 +9,7 @@ void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, in
                    const int32_t *d_cols, DBuf<uint16_t> &pos);
 
 void ensure_auu_values(ifem_ctx *ctx);
+bool ensure_scat3(ifem_ctx *ctx, bool with_rows); // records of the 3D Q2/Q1 cell kernel (assemble3.hip); false: not applicable
 void build_schur_pattern(ifem_ctx *ctx);
 void build_incidence(ifem_ctx *ctx);
 int64_t compact_flagged_rows(ifem_ctx *ctx, const int64_t *flag, int64_t n, DBuf<int32_t> &rows); // ascending list of the flagged rows

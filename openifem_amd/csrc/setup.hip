@@ -128,10 +128,11 @@ static void pattern_from_keys(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_row
 // ---- scatter order of the A_uu rows (3D Q2/Q1 cell kernel).  The blocks of a row need not be stored in column order: nothing
 // but the scatter map and the column array know where a block lives.  The cell kernel's atomics cost one memory-side request
 // per 64-byte segment they touch, and a cell's 27 blocks of a row are contiguous only as far as no block of
-// another cell lies between them.  Ordering the blocks of a row by (last cell, [tile, below], first cell, column) of the cells
+// another cell lies between them.  Ordering the blocks of a row by (last cell, first cell, column) of the cells
 // that touch them puts the blocks exclusive to a cell next to those it shares with its neighbours: a cell's part of a row becomes one to
-// four runs instead of fourteen (Morton numbering) -- 865 instead of 962 segments per cell before packing losses
-// (tools/scatter_sim.py).  Applied once, before the values exist; posUU is mapped through the permutation.
+// four runs instead of fourteen (Morton numbering) -- 862 instead of 957 segments per cell before packing losses
+// (tools/scatter_sim.py).  Applied once, before the values exist; posUU is mapped through the permutation.  (Round 3 keyed on the
+// MFMA column tile too: the two-waves-per-cell kernel scattered the two tiles of a row at different times; round 4's sends a row whole.)
 __global__ void k_block_cells(int64_t n_cells, int NU, const int32_t *__restrict__ cu, int64_t n_rows_owned, const int64_t *__restrict__ rowptr,
                               const uint16_t *__restrict__ pos, int32_t *__restrict__ cmin, int32_t *__restrict__ cmax) {
   const int64_t total = n_cells * NU * NU;
@@ -145,29 +146,10 @@ __global__ void k_block_cells(int64_t n_cells, int NU, const int32_t *__restrict
     atomicMax(&cmax[e], int32_t(cell));
   }
 }
-// second key: in the LAST cell that touches a block, does the block's column belong to the second MFMA tile (columns 16..26 of
-// that cell's nodes in id order, Cell3::perm)?  The cell kernel scatters the two tiles of a matrix row at different times;
-// with the last cell's first-tile blocks in front of its second-tile blocks each piece stays one run (936 instead of 974 segments)
-__global__ void k_block_tile(int64_t n_cells, int NU, const int32_t *__restrict__ cu, int64_t n_rows_owned, const int64_t *__restrict__ rowptr,
-                             const uint16_t *__restrict__ pos, const int32_t *__restrict__ cmax, uint8_t *__restrict__ tile) {
-  const int64_t total = n_cells * NU * NU;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t cell = t / (NU * NU);
-    const int rc = int(t - cell * NU * NU), a = rc / NU, b = rc - a * NU;
-    const int32_t row = cu[cell * NU + a];
-    if (row >= n_rows_owned) continue;
-    const int64_t e = rowptr[row] + pos[t];
-    if (cmax[e] != int32_t(cell)) continue;
-    const int32_t mine = cu[cell * NU + b];
-    int rank = 0;
-    for (int j = 0; j < NU; ++j) rank += cu[cell * NU + j] < mine ? 1 : 0;
-    tile[e] = rank >= 16 ? 1 : 0;
-  }
-}
 constexpr int kReorderMaxRow = 512;
-// one wavefront per row: rank of every block by (cmax, tile, cmin, col); newpos[old entry] = rank, col_out in the new order
+// one wavefront per row: rank of every block by (cmax, cmin, col); newpos[old entry] = rank, col_out in the new order
 __global__ __launch_bounds__(256) void k_row_reorder(int64_t n_rows, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                     const int32_t *__restrict__ cmin, const int32_t *__restrict__ cmax, const uint8_t *__restrict__ tile,
+                                                     const int32_t *__restrict__ cmin, const int32_t *__restrict__ cmax,
                                                      int32_t *__restrict__ col_out, uint16_t *__restrict__ newpos) {
   __shared__ uint64_t k1[4][kReorderMaxRow];
   __shared__ int32_t k2[4][kReorderMaxRow];
@@ -181,7 +163,7 @@ __global__ __launch_bounds__(256) void k_row_reorder(int64_t n_rows, const int64
     for (int i = lane; i < len; i += 64) { col_out[rs + i] = col[rs + i]; newpos[rs + i] = uint16_t(i); }
   if (sortable)
     for (int i = lane; i < len; i += 64) {
-      k1[wave][i] = (uint64_t(uint32_t(cmax[rs + i])) << 33) | (uint64_t(tile[rs + i]) << 32) | uint32_t(cmin[rs + i]);
+      k1[wave][i] = (uint64_t(uint32_t(cmax[rs + i])) << 32) | uint32_t(cmin[rs + i]);
       k2[wave][i] = col[rs + i];
     }
   __syncthreads();
@@ -220,16 +202,92 @@ static void reorder_uu_rows(ifem_ctx *ctx) {
   IFEM_HIP_CHECK(hipMemsetAsync(cmax.p, 0, (size_t)nnzb * sizeof(int32_t), s));
   const int64_t N = nc * ctx->nu * ctx->nu;
   hipLaunchKernelGGL(k_block_cells, dim3(grid_for(N)), dim3(256), 0, s, nc, ctx->nu, ctx->cell_unodes.p, M.n_rows, M.rowptr.p, ctx->posUU.p, cmin.p, cmax.p);
-  DBuf<uint8_t> tile;
-  tile.alloc((size_t)nnzb);
-  IFEM_HIP_CHECK(hipMemsetAsync(tile.p, 0, (size_t)nnzb, s));
-  hipLaunchKernelGGL(k_block_tile, dim3(grid_for(N)), dim3(256), 0, s, nc, ctx->nu, ctx->cell_unodes.p, M.n_rows, M.rowptr.p, ctx->posUU.p, cmax.p, tile.p);
-  hipLaunchKernelGGL(k_row_reorder, dim3(unsigned((M.n_rows + 3) / 4)), dim3(256), 0, s, M.n_rows, M.rowptr.p, M.col.p, cmin.p, cmax.p, tile.p, col2.p, newpos.p);
+  hipLaunchKernelGGL(k_row_reorder, dim3(unsigned((M.n_rows + 3) / 4)), dim3(256), 0, s, M.n_rows, M.rowptr.p, M.col.p, cmin.p, cmax.p, col2.p, newpos.p);
   hipLaunchKernelGGL(k_pos_remap, dim3(grid_for(N)), dim3(256), 0, s, nc, ctx->nu, ctx->cell_unodes.p, M.n_rows, M.rowptr.p, newpos.p, ctx->posUU.p);
   IFEM_HIP_CHECK(hipMemcpyAsync(M.col.p, col2.p, (size_t)nnzb * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
   IFEM_HIP_CHECK(hipGetLastError());
   M.n_interior = -1; // a row list built from the old order stays valid (it lists rows), but keep the invariant simple
+  ctx->scat3.release(); // records of the old order
+  ctx->hdr3_rows = false;
+}
+
+// ---- per-cell records of the 3D Q2/Q1 cell kernel (assemble3.hip; layouts: ctx.hpp kAsm3Rec / kAsm3Hdr).  Everything the
+// kernel's scatter would otherwise work out per cell and per assembly from the node ids and the scatter map: the order of the
+// cell's nodes by id, the rank of every block among the 27 the cell adds to a row (by position in the row) and the alignment of
+// the row's first block -- functions of the mesh and of the pattern alone.
+__global__ void k_scat3_hdr(int64_t n_cells, const int32_t *__restrict__ cu, const int32_t *__restrict__ cp, int64_t n_rows_owned,
+                            const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ pos, int with_rows, uint8_t *__restrict__ hdr) {
+  const int64_t cell = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (cell >= n_cells) return;
+  uint8_t *h = hdr + cell * kAsm3Hdr;
+  const int32_t *nd = cu + cell * 27, *pd = cp + cell * 8;
+  for (int k = 27; k < 32; ++k) { h[k] = uint8_t(k); h[32 + k] = uint8_t(k); }
+  for (int a = 0; a < 27; ++a) {
+    int rank = 0;
+    for (int j = 0; j < 27; ++j) rank += nd[j] < nd[a] ? 1 : 0;
+    h[rank] = uint8_t(a);      // perm
+    h[32 + a] = uint8_t(rank); // iperm
+  }
+  for (int b = 0; b < 8; ++b) {
+    int rank = 0;
+    for (int j = 0; j < 8; ++j) rank += pd[j] < pd[b] ? 1 : 0;
+    h[64 + rank] = uint8_t(b); // permp
+  }
+  for (int a = 0; a < 32; ++a) {
+    uint8_t s = 0;
+    if (with_rows && a < 27 && nd[a] < n_rows_owned) {
+      int p0 = 0xFFFF;
+      for (int b = 0; b < 27; ++b) { const int p = pos[(cell * 27 + a) * 27 + b]; p0 = p < p0 ? p : p0; }
+      s = uint8_t((rowptr[nd[a]] + p0) & 7); // blocks are 9 doubles: (9 k) mod 8 = k mod 8
+    }
+    h[72 + a] = s;
+  }
+  for (int k = 104; k < kAsm3Hdr; ++k) h[k] = 0;
+}
+__global__ void k_scat3_rec(int64_t n_cells, const int32_t *__restrict__ cu, int64_t n_rows_owned, const uint16_t *__restrict__ pos,
+                            const uint8_t *__restrict__ hdr, uint16_t *__restrict__ rec) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_cells * 128) return;
+  const int64_t cell = t >> 7;
+  const int ti = int(t >> 6) & 1, lane = int(t) & 63, l15 = lane & 15, g = lane >> 4;
+  const uint8_t *perm = hdr + cell * kAsm3Hdr;
+  uint16_t *out = rec + cell * kAsm3Rec + (ti * 64 + lane) * 8;
+  for (int tj = 0; tj < 2; ++tj)
+    for (int r = 0; r < 4; ++r) {
+      const int a = 16 * ti + g + 4 * r, col = 16 * tj + l15;
+      uint16_t v = 0xFFFF;
+      if (a < 27 && col < 27 && cu[cell * 27 + a] < n_rows_owned) {
+        const uint16_t *row = pos + (cell * 27 + a) * 27;
+        const int p = row[perm[col]];
+        int rank = 0;
+        for (int j = 0; j < 27; ++j) rank += row[j] < p ? 1 : 0;
+        v = uint16_t((p - rank) | (rank << 9)); // rank <= position: the blocks before it in the row include its predecessors of this cell
+      }
+      out[tj * 4 + r] = v;
+    }
+}
+// headers always; records (2 KB per cell) and row alignments only for a context that assembles A_uu.  false: the rows are too
+// long for the records (position < 512) -- the caller falls back to the general kernel of assemble2.hip
+bool ensure_scat3(ifem_ctx *ctx, bool with_rows) {
+  if (ctx->dim != 3 || ctx->kv != 2 || ctx->n_cells == 0) return false;
+  if (with_rows && ctx->Auu.max_row >= 512) return false;
+  hipStream_t s = ctx->stream;
+  const int64_t nc = ctx->n_cells;
+  const bool need_hdr = ctx->hdr3.n == 0 || (with_rows && !ctx->hdr3_rows);
+  if (need_hdr) {
+    if (ctx->hdr3.n == 0) ctx->hdr3.alloc(size_t(nc) * kAsm3Hdr);
+    hipLaunchKernelGGL(k_scat3_hdr, dim3(unsigned((nc + 127) / 128)), dim3(128), 0, s, nc, ctx->cell_unodes.p, ctx->cell_pnodes.p, ctx->Auu.n_rows,
+                       ctx->Auu.rowptr.p, ctx->posUU.p, with_rows ? 1 : 0, ctx->hdr3.p);
+    ctx->hdr3_rows = with_rows;
+  }
+  if (with_rows && ctx->scat3.n == 0) {
+    ctx->scat3.alloc(size_t(nc) * kAsm3Rec);
+    hipLaunchKernelGGL(k_scat3_rec, dim3(unsigned((nc * 128 + 255) / 256)), dim3(256), 0, s, nc, ctx->cell_unodes.p, ctx->Auu.n_rows, ctx->posUU.p,
+                       ctx->hdr3.p, ctx->scat3.p);
+  }
+  IFEM_HIP_CHECK(hipGetLastError());
+  return true;
 }
 // position of the diagonal block in every owned row (the rows are not necessarily in column order)
 __global__ void k_diag_pos(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col, int32_t *__restrict__ dp) {

@@ -519,16 +519,16 @@ def test_cached_geometry_blocks_stay_identical_across_assemblies(dim, kv, reps):
     ctx.close()
 
 
-@pytest.mark.parametrize("variant,waves,row_order", [(0, 3, 1), (0, 4, 1), (0, 2, 1), (1, 2, 1), (2, 3, 1), (0, 3, 0), (1, 2, 0)])
-def test_mfma_assembly_entrywise_on_odd_mesh_with_many_workgroups(variant, waves, row_order):
-    """every build of the cell kernel (ifem_tuning::asm3_variant: shape tables rebuilt on the fly / per-cell tables in LDS /
-    mixed; asm3_waves: register budget for 2, 3 or 4 waves per SIMD):
-    k_ins_assemble3 (3D Q2/Q1, matrix cores) entry by entry against the oracle on a 9x7x5 mesh: 315 cells = 158
-    workgroups of two cells (every XCD gets several, the XCD remap is exercised with a grid that is not a multiple of 8),
-    an odd cell count (the last workgroup has an idle slot), distorted cells, Neumann inlet, inhomogeneous Dirichlet
+@pytest.mark.parametrize("variant,cpb,row_order", [(0, 2, 1), (0, 4, 1), (0, 2, 0), (0, 4, 0), (1, 2, 1), (1, 2, 0)])
+def test_mfma_assembly_entrywise_on_odd_mesh_with_many_workgroups(variant, cpb, row_order):
+    """every build of the cell kernel (ifem_tuning::asm3_cpb: cells = wavefronts per workgroup; asm3_variant 1: the general vector
+    kernel of assemble2.hip on the same context):
+    k_ins_assemble3 (3D Q2/Q1, matrix cores, one wavefront per cell) entry by entry against the oracle on a 9x7x5 mesh: 315 cells =
+    158 workgroups of two cells / 79 of four (every XCD gets several, the XCD remap is exercised with a grid that is not a multiple
+    of 8), an odd cell count (the last workgroup has an idle wave), distorted cells, Neumann inlet, inhomogeneous Dirichlet
     values, both constraint sets, and the cached-block path (second assembly with the same constraint set and another
     evaluation point keeps B, B^T, M_p, diag(M_u)).  row_order = ifem_tuning::uu_row_order: the blocks of an A_uu row stored
-    in the order (first cell, last cell, column) of the cells that touch them (default) or in column order -- the exported
+    in the order (last cell, first cell, column) of the cells that touch them (default) or in column order -- the exported
     matrix, the block-Jacobi blocks (diagonal position table) and the stored-matrix product must not care."""
     capi = _capi()
     rng = np.random.default_rng(97531)
@@ -542,9 +542,9 @@ def test_mfma_assembly_entrywise_on_odd_mesh_with_many_workgroups(variant, waves
     ctx = _ctx(m)
     tun = capi.Tuning()
     ctx.L.ifem_default_tuning(C.byref(tun))
-    assert (tun.asm3_variant, tun.asm3_waves) == (0, 3)
+    assert (tun.asm3_variant, tun.asm3_cpb) == (0, 2)
     assert tun.uu_row_order == 1
-    tun.asm3_variant, tun.asm3_waves, tun.uu_row_order = variant, waves, row_order
+    tun.asm3_variant, tun.asm3_cpb, tun.uu_row_order = variant, cpb, row_order
     assert ctx.L.ifem_set_tuning(ctx.h, C.byref(tun)) == 0
     ctx.set_constraints(0, dofs, None)
     ctx.set_constraints(1, dofs, vals)

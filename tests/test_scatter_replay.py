@@ -29,3 +29,10 @@ def test_each_step_of_the_scatter_reorganisation_lowers_the_segment_count():
     assert shipped < ranked < by_id < lex
     assert lex > 1150 and by_id < 0.9 * lex and shipped < 0.81 * lex, (lex, by_id, ranked, shipped)
     assert inst_a <= 130  # the alignment shift costs at most one more round per step
+    # round 4: a row's 27 blocks leave together, staged as the image of their memory
+    cel2 = R.build_rows("cells2")
+    fl2, full, inst_f = R.replay(*cel2, cells, "id", "full")
+    _, full_u, _ = R.replay(*cel2, cells, "id", "full_unaligned")
+    assert inst_f == 108  # 27 rows x 4 instructions
+    assert 820 <= fl2 <= fl_cel and fl2 <= full < full_u
+    assert full < 0.95 * shipped and full < 1.03 * fl2, (full, shipped, fl2)

@@ -1,9 +1,9 @@
 """Time ifem_ins_assemble at n^3 (kernel time from HIP events) for the builds of the 3D Q2/Q1 cell kernel:
-    python tools/asmbench.py [n] [variant:waves[:asm_skip[:cells per workgroup]] ...]      e.g.  128 0:3 0:4 0:2 1:2 0:3:1 0:3:0:1
-variant = ifem_tuning::asm3_variant (0 tables rebuilt on the fly, 1 per-cell tables in LDS), waves = asm3_waves, asm_skip =
-the measurement switch (1: no A_uu scatter, 2: no contraction either).  Prints warm (cached geometry blocks) and cold
-(geo_cache = 0: B, B^T, M_p, diag(M_u) re-integrated) kernel times and the wall time of the whole ifem_ins_assemble call (zero
-fills included), median of 5."""
+    python tools/asmbench.py [n] [cpb[:asm_skip[:variant]] ...]      e.g.  128 2 4 2:1 2:2 2:5 2:0:1
+cpb = ifem_tuning::asm3_cpb (cells = wavefronts per workgroup), asm_skip =
+the measurement switch of -DIFEM_ASM_PROBES builds (1: no A_uu scatter, 2: no contraction either), variant 1 = the general vector
+kernel of assemble2.hip.  Prints warm (cached geometry blocks) and cold (geo_cache = 0: B, B^T, M_p, diag(M_u) re-integrated)
+kernel times and the wall time of the whole ifem_ins_assemble call (zero fills included), median of 5."""
 import ctypes as C
 import os
 import sys
@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openifem_amd import capi, host
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 WARM_ONLY = "--warm-only" in sys.argv  # PMC passes: the steady-state launch only (after one assembly that integrates every block)
-combos = [a for a in sys.argv[2:] if not a.startswith("--")] or ["0:3", "0:4", "0:2", "1:2"]
+combos = [a for a in sys.argv[2:] if not a.startswith("--")] or ["2", "4"]
 s = host.InsIM(host.channel_prm(3), (n, n, n), (0, 0, 0), (2.0, 0.2, 0.2))
 s.set_multigrid(False)
 s.setup(0)
@@ -41,12 +41,12 @@ def med(k=5):
 
 for c in combos:
     f = [int(x) for x in c.split(":")]
-    variant, waves, skip, cpb = f[0], f[1], (f[2] if len(f) > 2 else 0), (f[3] if len(f) > 3 else 2)
-    tune(asm3_variant=variant, asm3_waves=waves, asm_skip=skip, asm3_cpb=cpb)
+    cpb, skip, variant = f[0], (f[1] if len(f) > 1 else 0), (f[2] if len(f) > 2 else 0)
+    tune(asm3_variant=variant, asm_skip=skip, asm3_cpb=cpb)
     s.assemble(False)
     warm, warm_wall = med()
     cold = cold_wall = float("nan")
     if not WARM_ONLY:
-        tune(asm3_variant=variant, asm3_waves=waves, asm_skip=skip, asm3_cpb=cpb, geo_cache=0)
+        tune(asm3_variant=variant, asm_skip=skip, asm3_cpb=cpb, geo_cache=0)
         cold, cold_wall = med(3)
-    print(f"n {n} variant {variant} waves {waves} cells/workgroup {cpb} asm_skip {skip}: warm kernel {warm:.2f} ms (call {warm_wall:.2f}), cold kernel {cold:.2f} ms (call {cold_wall:.2f})", flush=True)
+    print(f"n {n} variant {variant} cells/workgroup {cpb} asm_skip {skip}: warm kernel {warm:.2f} ms (call {warm_wall:.2f}), cold kernel {cold:.2f} ms (call {cold_wall:.2f})", flush=True)

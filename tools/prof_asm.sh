@@ -2,7 +2,7 @@
 # usage: tools/prof_asm.sh <tag> [variant:waves]     (on the GPU box; writes gpurun_out/<tag>/asm_*)
 set -x
 TAG=${1:-r03}
-V=${2:-0:3}
+V=${2:-2}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O

@@ -6,10 +6,14 @@ The memory-side atomic path retires ~24 G such segments per second whatever the 
     python tools/scatter_sim.py [n] [--lex-nodes]
 
 replays, on the n^3 channel mesh of the host mirror,
-  rows "col"   : blocks of a row in column order;           rows "cells": in the order (last cell, its tile, first cell, column) (setup.hip)
-  tiles "lex"  : tile columns in the element's node order;  tiles "id"  : in the order of the cell's node ids (Cell3::perm)
+  rows "col"   : blocks of a row in column order;           rows "cells": in the order (last cell, its tile, first cell, column)
+  rows "cells2": (last cell, first cell, column) (setup.hip, round 4)
+  tiles "lex"  : tile columns in the element's node order;  tiles "id"  : in the order of the cell's node ids (perm)
   slots "lane" : stage slot = lane;                         slots "rank": the 16 pairs of a matrix row by their position in it;
-  slots "aligned": as "rank", every staged row shifted by the position of its first block inside a 64-byte segment (152 lanes per row)
+  slots "aligned": as "rank", every staged row shifted by the position of its first block inside a 64-byte segment (152 lanes per
+                   row; the kernel of round 3: two wavefronts per cell, a row's two column tiles scattered at different times)
+  slots "full" : the kernel of round 4 -- a matrix row's 27 blocks staged as the image of their memory (blocks by position, image
+                 shifted to the row's alignment), 64 lanes per instruction along the image; "full_unaligned": without the shift
 and prints segments per cell next to the floor of the row order (one ideal instruction per cell row) and of the layout (820)."""
 import os
 import sys
@@ -49,7 +53,8 @@ class Replay:
         pos, rowptr = [None] * self.nn, np.zeros(self.nn + 1, np.int64)
         for r in range(self.nn):
             rc = self.rowcells[r]
-            key = (lambda b: b) if kind == "col" else (lambda b: (max(rc[b]), self.rank_in_cell[(max(rc[b]), b)] >= 16, min(rc[b]), b))
+            key = {"col": lambda b: b, "cells": lambda b: (max(rc[b]), self.rank_in_cell[(max(rc[b]), b)] >= 16, min(rc[b]), b),
+                   "cells2": lambda b: (max(rc[b]), min(rc[b]), b)}[kind]  # "cells2" (round 4): a row's 27 blocks are scattered together
             cols = sorted(rc.keys(), key=key)
             pos[r] = {b: k for k, b in enumerate(cols)}
             rowptr[r + 1] = rowptr[r] + len(cols)
@@ -65,6 +70,23 @@ class Replay:
                 addr = (np.array([rowptr[a] + pos[a][b] for b in nd]) * 72)[:, None] + 8 * np.arange(9)[None, :]
                 floor += len(np.unique(addr // 64))
             perm = (list(range(27)) if tiles == "lex" else list(np.argsort(nd, kind="stable"))) + [-1] * 5
+            if slots in ("full", "full_unaligned"):
+                # round 4: both column tiles of a row tile are integrated together, a matrix row's 27 blocks leave in one piece: blocks in
+                # the order of their positions in the row, the row's image shifted to its alignment inside a 64-byte segment, 64 lanes
+                # per instruction along the image (4 instructions per row)
+                for a in range(27):
+                    o = np.sort(np.array([rowptr[nd[a]] + pos[nd[a]][b] for b in nd]) * 72)
+                    s0 = ((o[0] // 8) & 7) if slots == "full" else 0
+                    img = np.full(256 + 8, -1, np.int64)
+                    for k in range(27):
+                        img[s0 + 9 * k:s0 + 9 * k + 9] = o[k] + 8 * np.arange(9)
+                    for rr in range(4):
+                        seg = img[64 * rr:64 * rr + 64]
+                        v = seg >= 0
+                        if v.any():
+                            tot += len(np.unique(seg[v] // 64))
+                            inst += 1
+                continue
             for ti in range(2):
                 for tj in range(2):
                     for r in range(4):
@@ -78,6 +100,24 @@ class Replay:
                             for j in range(16):
                                 if p[j] is not None:
                                     off[16 * g + rank[j]] = (rowptr[nd[a]] + p[j]) * 72
+                        if slots in ("static7", "static7row"):
+                            # round 4: stage slots compacted per tile (16 or 11 columns per row), instruction = 7 consecutive slots x 9
+                            # entries on 63 lanes ("static7row": every matrix row starts a new instruction)
+                            ncol = 16 if tj == 0 else 11
+                            seq = []
+                            for g in range(4):
+                                row = [off[16 * g + k] for k in range(ncol)]
+                                if slots == "static7row":
+                                    row += [-1] * ((-len(row)) % 7)
+                                seq += row
+                            seq += [-1] * ((-len(seq)) % 7)
+                            for k in range(0, len(seq), 7):
+                                o = np.repeat(np.array(seq[k:k + 7], np.int64), 9)
+                                v = o >= 0
+                                if v.any():
+                                    tot += len(np.unique((o[v] + 8 * np.tile(np.arange(9), 7)[v]) // 64))
+                                    inst += 1
+                            continue
                         span = 152 if slots == "aligned" else 144
                         for rr in range(10 if slots == "aligned" else 9):
                             t = lanes + 64 * rr
@@ -102,13 +142,13 @@ def main():
     rng = np.random.default_rng(1)
     cells = rng.choice(R.nc, size=min(R.nc, 200), replace=False)
     print(f"{n}^3 cells, {len(cells)} sampled; layout floor 729 * 72 / 64 = 820 segments per cell")
-    for rows in ("col", "cells"):
+    for rows, combos in (("col", (("lex", "lane"), ("id", "lane"))), ("cells", (("id", "rank"), ("id", "aligned"))),
+                         ("cells2", (("id", "full_unaligned"), ("id", "full")))):
         pos, rowptr = R.build_rows(rows)
-        for tiles, slots in (("lex", "lane"), ("id", "lane"), ("id", "rank"), ("id", "aligned")):
+        for tiles, slots in combos:
             fl, seg, inst = R.replay(pos, rowptr, cells, tiles, slots)
-            tag = {("col", "lex", "lane"): "  <- rounds 1-2", ("col", "id", "lane"): "  <- 1fdd41d", ("cells", "id", "aligned"): "  <- shipped"}.get((rows, tiles, slots), "")
-            print(f"rows {rows:5s} tiles {tiles:3s} slots {slots:7s}: {seg:7.1f} segments per cell ({seg / 729:.3f} per block; floor of this row order {fl:6.1f}), {inst:.0f} atomic instructions{tag}", flush=True)
-
+            tag = {("col", "lex", "lane"): "  <- rounds 1-2", ("cells", "id", "aligned"): "  <- round 3", ("cells2", "id", "full"): "  <- shipped"}.get((rows, tiles, slots), "")
+            print(f"rows {rows:6s} tiles {tiles:3s} slots {slots:14s}: {seg:7.1f} segments per cell ({seg / 729:.3f} per block; floor of this row order {fl:6.1f}), {inst:.0f} atomic instructions{tag}", flush=True)
 
 if __name__ == "__main__":
     main()
