@@ -134,12 +134,17 @@ def _cpu_step(n_cpu, threads):
         if used == parts or parts == 1:
             break
         parts -= 1
+    import resource
+    r0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.time()
     S.assemble_subdomains(P, False, ev, present, part, used, threads)
     t1 = time.time()
     rc, upd, it, res = S.solve(P, False)
     t2 = time.time()
-    return m.n_dofs, t1 - t0, t2 - t1, it
+    r1 = resource.getrusage(resource.RUSAGE_SELF)
+    # CPU seconds (user + system, all threads of the process) over wall seconds = the number of cores the step kept busy
+    busy = ((r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)) / max(t2 - t0, 1e-9)
+    return m.n_dofs, t1 - t0, t2 - t1, it, busy
 
 
 def np_log2(x):
@@ -156,11 +161,13 @@ def cpu_baseline(sizes, sweep_n=24, budget_s=100.0):
     count)."""
     ncores = physical_cores()
     quota, affinity = cpu_allowance()
-    cand = sorted({t for t in (16, 32, 64, 128, 192, 256, ncores) if t <= ncores} | {ncores})
+    # what the job may use: the affinity mask and the cgroup quota both cap it (the pool's boxes: quota 16 of 2 x 64 cores)
+    allowed = min(x for x in (ncores, affinity, quota) if x)
+    cand = sorted({t for t in (2, 4, 8, 16, 32, 64, 128, ncores) if t <= ncores and t <= 4 * allowed} | {max(1, int(allowed))})
     sweep = []
     for t in cand:
-        nd, ta, ts, _ = _cpu_step(sweep_n, t)
-        sweep.append({"threads": t, "assemble_s": ta, "solve_s": ts})
+        nd, ta, ts, _, busy = _cpu_step(sweep_n, t)
+        sweep.append({"threads": t, "assemble_s": ta, "solve_s": ts, "cores_busy": busy})
     base = sweep[0]
     for r in sweep:
         r["assemble_efficiency"] = base["assemble_s"] * base["threads"] / (r["assemble_s"] * r["threads"])
@@ -179,19 +186,25 @@ def cpu_baseline(sizes, sweep_n=24, budget_s=100.0):
             if predicted > budget_s:
                 skipped.append({"n": n, "predicted_s": predicted, "budget_s": budget_s})
                 continue
-        nd, ta, ts, it = _cpu_step(n, fastest)
+        nd, ta, ts, it, busy = _cpu_step(n, fastest)
         runs.append({"n": n, "n_dofs": nd, "assemble_s": ta, "solve_s": ts, "fgmres_iters": it, "dofs_per_s": nd / (ta + ts),
-                     "assemble_dofs_per_s": nd / ta, "solve_dofs_per_s": nd / ts})
+                     "assemble_dofs_per_s": nd / ta, "solve_dofs_per_s": nd / ts, "cores_busy": busy})
     big = runs[-1]
-    return {"value": big["dofs_per_s"], "unit": "DoF/s", "cores": fastest, "kind": "port", "cpu_model": _cpu_model(),
+    # `cores` = the cores the timed sample actually kept busy (CPU seconds / wall seconds, rounded up), never more than the threads
+    # it ran or than the job is allowed; `threads` = the OpenMP threads it ran
+    cores_used = int(min(fastest, max(1.0, -(-big["cores_busy"] // 1))))
+    return {"value": big["dofs_per_s"], "unit": "DoF/s", "cores": cores_used, "threads": fastest, "cores_busy_measured": big["cores_busy"],
+            "kind": "port", "cpu_model": _cpu_model(), "nproc": os.cpu_count(),
             "host_threads_available": os.cpu_count(), "physical_cores": ncores, "cgroup_cpu_quota": quota, "affinity_cpus": affinity,
+            "omp_binding": os.environ.get("OMP_PLACES", "none"),
             "parallelisation": "one subdomain per core, owner computes row, no atomics (orc_ins_assemble_subdomains); OpenMP loops in the solve",
             "scaling_table": {"mesh": f"{sweep_n}^3", "rows": sweep}, "runs": runs, "skipped": skipped,
             "not_sampled": "128^3: the oracle's CSR with all couplings (as the reference's BlockSparsityPattern, mpi_fluid_solver.cpp:311-322) "
                            "needs ~0.25 TB there and ~10 min per step; the 64^3 step is the bounded sample",
             "sample": f"1 Newton step (assemble {big['assemble_s']:.2f}s + solve {big['solve_s']:.2f}s, FGMRES its "
                       f"{big['fgmres_iters']}) of the {big['n']}^3 Q2/Q1 channel ({big['n_dofs']} DoF), oracle/oracle.c with "
-                      f"OpenMP on {fastest} threads (fastest of the scaling table; {ncores} physical cores, cgroup quota {quota}) of {_cpu_model()}"}
+                      f"OpenMP on {fastest} threads keeping {big['cores_busy']:.1f} cores busy (CPU s / wall s; fastest of the scaling table; "
+                      f"{ncores} physical cores, affinity mask {affinity}, cgroup quota {quota}) of {_cpu_model()}"}
 
 
 def bench_insimex(args, host):
@@ -331,9 +344,13 @@ def main():
                          "time step of MPI::InsIMEX (rhs-only assembly + solve), reported as a side measurement")
     args = ap.parse_args()
 
-    # the CPU baseline leg pins one OpenMP thread per physical core (read by libgomp when the oracle library loads)
-    os.environ.setdefault("OMP_PROC_BIND", "spread")
-    os.environ.setdefault("OMP_PLACES", "cores")
+    # the CPU baseline leg pins one OpenMP thread per physical core (read by libgomp when the oracle library loads) -- only when
+    # the job owns the machine: with an affinity mask or a cgroup quota smaller than the core count, places outside the allowance
+    # would stack the threads on a few CPUs
+    _quota, _aff = cpu_allowance()
+    if min(x for x in (physical_cores(), _aff, _quota) if x) >= physical_cores():
+        os.environ.setdefault("OMP_PROC_BIND", "spread")
+        os.environ.setdefault("OMP_PLACES", "cores")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "IFEM_BENCH_DEVICE" in os.environ:  # debugging aid: several ranks on one GPU (RCCL normally refuses this)

@@ -456,6 +456,10 @@ int ifem_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solve
  * to size the arrays (n_p + 1 entries, nnz = rowptr[n_p]); with col / val it also returns the CSR of T_pp, and with x / y
  * (host, n_p entries) y = (LU)^-1 x.  *levels (may be NULL) receives the number of forward levels of the schedule. */
 int ifem_tpp_ilu_probe(ifem_ctx *ctx, int64_t *rowptr, int32_t *col, double *val, const double *x, double *y, int32_t *levels);
+/* Test aid: replace the values of the explicit T_pp (pattern and order as returned by ifem_tpp_ilu_probe) so that the next
+ * factorisation sees them -- the breakdown path of the ILU(0) (zero / non-finite pivot -> IFEM_E_KRYLOV_NOCONV from the probe, Jacobi
+ * in ifem_scns_solve) cannot be reached from an assembled fluid matrix at will. */
+int ifem_tpp_override(ifem_ctx *ctx, const double *val);
 
 /* Export the assembled block system as one CSR over the local dofs [u|p] (host arrays; call twice: first
  * with col = val = NULL to get nnz through rowptr[n]).  which: 0 system_matrix, 1 mass (diag(M_u), M_p).

@@ -116,7 +116,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof",
            "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag",
            "ifem_fsi_set_solid", "ifem_fsi_update_indicator", "ifem_fsi_find_fluid_bc", "ifem_fsi_get_stress",
-           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_true_residual", "ifem_tpp_ilu_probe"]
+           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_true_residual", "ifem_tpp_ilu_probe", "ifem_tpp_override"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -191,6 +191,7 @@ def load():
     L.ifem_mg_depth.argtypes = [C.c_void_p]
     L.ifem_comm_stats_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.ifem_tpp_ilu_probe.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.ifem_tpp_override.argtypes = [C.c_void_p, C.c_void_p]
     L.ifem_true_residual.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ifem_uu_block_diag.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.ifem_fsi_set_solid.argtypes = [C.c_void_p, C.POINTER(FsiSolid)]

@@ -798,7 +798,9 @@ int ifem_tpp_ilu_probe(ifem_ctx *ctx, int64_t *rowptr, int32_t *col, double *val
   }
   if (x && y) {
     if (ctx->tune.tpp_ilu_order < 0) throw Error(IFEM_E_BADPARAM, "ifem_tpp_ilu_probe: tpp_ilu_order = -1 keeps no ILU");
-    ifem::tpp_ilu_factor(ctx);
+    if (!ifem::tpp_ilu_factor(ctx))
+      throw Error(IFEM_E_KRYLOV_NOCONV, "ILU(0) of T_pp broke down: zero, tiny or non-finite pivot (|pivot| in [" + std::to_string(ctx->tpp_ilu.pivot_min) +
+                                            ", " + std::to_string(ctx->tpp_ilu.pivot_max) + "])");
     DBuf<double> dx, dy;
     dx.upload(x, (size_t)n, s);
     dy.alloc((size_t)n);
@@ -807,6 +809,15 @@ int ifem_tpp_ilu_probe(ifem_ctx *ctx, int64_t *rowptr, int32_t *col, double *val
     IFEM_HIP_CHECK(hipStreamSynchronize(s));
     if (levels) *levels = ifem::tpp_ilu_levels(ctx);
   }
+  IFEM_API_END
+}
+
+int ifem_tpp_override(ifem_ctx *ctx, const double *val) {
+  IFEM_API_BEGIN
+  if (!ctx->tpp_valid || !val) throw Error(IFEM_E_BADPARAM, "ifem_tpp_override after ifem_tpp_ilu_probe, with values");
+  IFEM_HIP_CHECK(hipMemcpyAsync(ctx->Tpp.p, val, ctx->Tpp.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->tpp_ilu.factored = false;
   IFEM_API_END
 }
 

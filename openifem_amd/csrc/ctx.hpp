@@ -168,6 +168,9 @@ struct TppIlu {
   std::vector<std::array<int32_t, 2>> plan_f, plan_b; // {level, -1}: one wide level; {l0, l1}: a run of small levels in one launch
   DBuf<double> LU, t0, t1; // factors; scratch of the Jacobi-sweep triangular solves
   bool analysed = false, factored = false;
+  double pivot_min = 0, pivot_max = 0;
+  bool broken = false; // the last factorisation met a zero / non-finite pivot: the caller falls back to Jacobi
+  DBuf<unsigned long long> chk; // [3] device: min |pivot|, max |pivot| (bit patterns), non-finite entries
   int order_kind = 0;
 };
 // hanging-node constraint lines x[dof_i] = sum_k w_k x[master_k] (closed), see hanging.hip
@@ -320,6 +323,7 @@ struct ifem_ctx {
   ifem::DBuf<double> Tpp, tpp_diag;
   bool tpp_valid = false;
   ifem::TppIlu tpp_ilu; // level-scheduled ILU(0) of T_pp (tpp.hip)
+  ifem::PlanarCsr TppPat; // several ranks: pattern of the owned x owned block of T_pp (the per-rank ILU(0), tpp.hip)
   // matrix-free A_uu (IFEM_AINV_GMRES_BJACOBI_MF): state of the last ifem_ins_assemble
   ifem::DBuf<double> mf_ycell; // per-cell results of the matrix-free apply [n_cells][nu][dim] (two-stage scatter)
   ifem::DBuf<double> mf_eval;  // velocity part of the evaluation point, ghost-extended

@@ -11,6 +11,7 @@ void build_pattern(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, in
 void ensure_auu_values(ifem_ctx *ctx);
 bool ensure_scat3(ifem_ctx *ctx, bool with_rows); // records of the 3D Q2/Q1 cell kernel (assemble3.hip); false: not applicable
 void build_schur_pattern(ifem_ctx *ctx);
+void build_schur_pattern_owned(ifem_ctx *ctx); // several ranks: owned x owned block, into ctx->TppPat
 void build_incidence(ifem_ctx *ctx);
 int64_t compact_flagged_rows(ifem_ctx *ctx, const int64_t *flag, int64_t n, DBuf<int32_t> &rows); // ascending list of the flagged rows
 void build_mf_cell_split(ifem_ctx *ctx); // several ranks: interior-first copy of the cell tables for the matrix-free apply
@@ -122,7 +123,7 @@ void spmv_planar_scalar(ifem_ctx *ctx, const PlanarCsr &M, const double *val, co
 // explicit pressure Schur complement of the SUPG block preconditioner (tpp.hip)
 void tpp_numeric(ifem_ctx *ctx);
 void spmv_tpp(ifem_ctx *ctx, const double *xp, double *yp);
-void tpp_ilu_factor(ifem_ctx *ctx);
+bool tpp_ilu_factor(ifem_ctx *ctx); // false: zero / tiny / non-finite pivot (ctx->tpp_ilu.broken): do not apply the factors
 void tpp_ilu_apply(ifem_ctx *ctx, const double *x, double *y);
 int tpp_ilu_levels(const ifem_ctx *ctx);
 // hanging-node lines (hanging.hip): C x on a copy of x, C^T and the hanging rows on y, distribute, set-up

@@ -407,21 +407,31 @@ int64_t compact_flagged_rows(ifem_ctx *ctx, const int64_t *flag, int64_t n, DBuf
 
 // ---- mass_schur(1,1) pattern (compute_mmult_pattern(B, B^T), mpi_fluid_solver.cpp:326-329).  For the Q1 pressure space
 // pattern(B B^T) = pattern(M_p^2): p-nodes i, j couple iff cells c1 with i and c2 with j share a vertex.
+// OWNED: only the owned x owned block through owned intermediate nodes (several ranks: rows of ghost nodes are not held here)
+template <bool OWNED>
 __global__ void k_sq_count(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
                            int64_t *__restrict__ cnt) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t c = 0;
-    for (int64_t k = rp[i]; k < rp[i + 1]; ++k) { const int32_t m = col[k]; c += rp[m + 1] - rp[m]; }
+    for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
+      const int32_t m = col[k];
+      if (!OWNED) c += rp[m + 1] - rp[m];
+      else if (m < n_rows)
+        for (int64_t l = rp[m]; l < rp[m + 1]; ++l) c += col[l] < n_rows ? 1 : 0;
+    }
     cnt[i] = c;
   }
 }
+template <bool OWNED>
 __global__ void k_sq_fill(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
                           const int64_t *__restrict__ off, uint64_t *__restrict__ keys) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t o = off[i];
     for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
       const int32_t m = col[k];
-      for (int64_t l = rp[m]; l < rp[m + 1]; ++l) keys[o++] = (uint64_t(uint32_t(i)) << 32) | uint32_t(col[l]);
+      if (OWNED && m >= n_rows) continue;
+      for (int64_t l = rp[m]; l < rp[m + 1]; ++l)
+        if (!OWNED || col[l] < n_rows) keys[o++] = (uint64_t(uint32_t(i)) << 32) | uint32_t(col[l]);
     }
   }
 }
@@ -611,15 +621,15 @@ void schur_probe_fill(ifem_ctx *ctx, int color, const double *y) {
                             color % 5, (color / 5) % 5, color / 25, ctx->Sm.rowptr.p, y, ctx->Sm.val.p);
 }
 
-void build_schur_pattern(ifem_ctx *ctx) {
-  if (ctx->halo.nranks != 1) throw Error(IFEM_E_BADPARAM, "explicit S_m needs a 2-deep pressure halo: single rank only");
+template <bool OWNED>
+static void schur_pattern_into(ifem_ctx *ctx, PlanarCsr &M) {
   hipStream_t s = ctx->stream;
   const int64_t n = ctx->nPo;
   DBuf<int64_t> cnt, off;
   cnt.alloc(n + 1);
   off.alloc(n + 1);
   IFEM_HIP_CHECK(hipMemsetAsync(cnt.p, 0, (n + 1) * 8, s));
-  hipLaunchKernelGGL(k_sq_count, dim3(grid_for(n)), dim3(256), 0, s, n, ctx->Mp.rowptr.p, ctx->Mp.col.p, cnt.p);
+  hipLaunchKernelGGL((k_sq_count<OWNED>), dim3(grid_for(n)), dim3(256), 0, s, n, ctx->Mp.rowptr.p, ctx->Mp.col.p, cnt.p);
   size_t tb = 0;
   IFEM_HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, cnt.p, off.p, int64_t(0), (size_t)(n + 1), rocprim::plus<int64_t>(), s));
   DBuf<char> tmp;
@@ -630,9 +640,15 @@ void build_schur_pattern(ifem_ctx *ctx) {
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
   DBuf<uint64_t> keys;
   keys.alloc(N);
-  hipLaunchKernelGGL(k_sq_fill, dim3(grid_for(n)), dim3(256), 0, s, n, ctx->Mp.rowptr.p, ctx->Mp.col.p, off.p, keys.p);
-  pattern_from_keys(ctx, ctx->Sm, 1, n, keys, N);
+  hipLaunchKernelGGL((k_sq_fill<OWNED>), dim3(grid_for(n)), dim3(256), 0, s, n, ctx->Mp.rowptr.p, ctx->Mp.col.p, off.p, keys.p);
+  pattern_from_keys(ctx, M, 1, n, keys, N);
   IFEM_HIP_CHECK(hipGetLastError());
 }
+void build_schur_pattern(ifem_ctx *ctx) {
+  if (ctx->halo.nranks != 1) throw Error(IFEM_E_BADPARAM, "explicit S_m needs a 2-deep pressure halo: single rank only");
+  schur_pattern_into<false>(ctx, ctx->Sm);
+}
+// several ranks: the owned x owned block of pattern(M_p^2), local pressure numbering (the per-rank ILU(0) of T_pp, tpp.hip)
+void build_schur_pattern_owned(ifem_ctx *ctx) { schur_pattern_into<true>(ctx, ctx->TppPat); }
 
 } // namespace ifem

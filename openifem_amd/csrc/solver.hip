@@ -1053,17 +1053,29 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
   OpFn Jpp = [&](const double *x, double *y) { vec_div(ctx, S.npo, ctx->app_diag.p, x, y); };
   // one rank: T_pp as an explicit matrix (tpp.hip): one SpMV per inner iteration, and the inner GMRES preconditioned by the
   // ILU(0) of that matrix (the reference: Euclid ILU(0) of B2pp, mpi_supg_solver.cpp:141-192, preconditioner_pilut.cpp:124-138),
-  // factorised once per Newton iteration and applied by level-scheduled triangular solves.  ifem_tuning::tpp_operator keeps
-  // the operator form with Jacobi (what several ranks use), tpp_ilu_order = -1 the explicit matrix with Jacobi.
+  // factorised once per Newton iteration and applied by level-scheduled triangular solves.  Several ranks: the operator stays
+  // distributed, the preconditioner is the ILU(0) of the owned x owned block of T_pp on every rank (block-Jacobi ILU: what
+  // Euclid does across ranks, mpi_supg_solver.cpp:49-53,120-133).  ifem_tuning::tpp_operator keeps the operator form with
+  // Jacobi, tpp_ilu_order = -1 the explicit matrix with Jacobi.  A factorisation that breaks down (zero / tiny / non-finite
+  // pivot) is not applied: Jacobi instead.
   const bool tpp_explicit = ctx->halo.nranks == 1 && !ctx->tune.tpp_operator;
+  auto ilu_or_warn = [&]() {
+    const bool ok = tpp_ilu_factor(ctx);
+    if (!ok && o->verbose)
+      fprintf(stderr, "[ifem] scns solve: ILU(0) of T_pp broke down (|pivot| in [%.3e, %.3e]): Jacobi instead\n", ctx->tpp_ilu.pivot_min,
+              ctx->tpp_ilu.pivot_max);
+    return ok;
+  };
   if (tpp_explicit) {
     tpp_numeric(ctx);
     Tpp = [&](const double *x, double *y) { spmv_tpp(ctx, x, y); };
-    if (ctx->tune.tpp_ilu_order >= 0) {
-      tpp_ilu_factor(ctx);
+    if (ctx->tune.tpp_ilu_order >= 0 && ilu_or_warn())
       Jpp = [&](const double *x, double *y) { tpp_ilu_apply(ctx, x, y); };
-    } else
+    else
       Jpp = [&](const double *x, double *y) { vec_div(ctx, S.npo, ctx->tpp_diag.p, x, y); };
+  } else if (ctx->halo.nranks > 1 && !ctx->tune.tpp_operator && ctx->tune.tpp_ilu_order >= 0) {
+    tpp_numeric(ctx); // the owned x owned block
+    if (ilu_or_warn()) Jpp = [&](const double *x, double *y) { tpp_ilu_apply(ctx, x, y); };
   }
   OpFn Pop = [&](const double *src, double *dst) {
     const double *src0 = src, *src1 = src + S.nuo;

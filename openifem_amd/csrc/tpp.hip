@@ -7,12 +7,17 @@
 // preconditioner_pilut.cpp:124-138) -- factorised and applied on the device by level scheduling: rows are grouped into
 // levels of the elimination DAG (natural order, as Euclid's serial sweep) or into the colours of a greedy colouring of the
 // matrix graph (multicolour ILU(0): a few dozen levels whatever the mesh size); one launch per level, one wave per row in
-// the factorisation, 16 lanes per row in the triangular solves.  Only the preconditioner is affected.  Single-rank
-// contexts (the pattern needs a 2-deep halo).
+// the factorisation, 16 lanes per row in the triangular solves.  Only the preconditioner is affected.
+// Several ranks (round 4): the operator T_pp stays distributed (solver.hip), its preconditioner is the ILU(0) of the OWNED x OWNED
+// block of T~ on every rank -- block-Jacobi ILU, what Euclid does by default across ranks (mpi_supg_solver.cpp:49-53,120-133):
+// pattern = owned block of pattern(M_p^2) (setup.hip::build_schur_pattern_owned), products through owned velocity nodes only.
+// A zero, tiny or non-finite pivot (T~ is not an M-matrix, the relaxed MILU moves dropped fill onto the diagonal) is detected
+// after the factorisation; the caller falls back to Jacobi.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <array>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include "ctx.hpp"
 #include "kernels.hpp"
@@ -25,6 +30,10 @@ __device__ inline void wsync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// the pattern T~ lives on: mass_schur's on one rank, the owned x owned block on several
+static PlanarCsr &tpp_pat(ifem_ctx *ctx) { return ctx->halo.nranks > 1 ? ctx->TppPat : ctx->Sm; }
+static const PlanarCsr &tpp_pat(const ifem_ctx *ctx) { return ctx->halo.nranks > 1 ? ctx->TppPat : ctx->Sm; }
+
 // one wave per pressure row i, as k_schur_numeric; the row of A_pp is merged in at the end
 template <int DIM>
 __global__ __launch_bounds__(256) void k_tpp_numeric(int64_t n_rows, int maxlen, const int64_t *__restrict__ rpS,
@@ -33,7 +42,7 @@ __global__ __launch_bounds__(256) void k_tpp_numeric(int64_t n_rows, int maxlen,
                                                      const double *__restrict__ valB, const int64_t *__restrict__ rpT,
                                                      const int32_t *__restrict__ colT, const double *__restrict__ valT,
                                                      const double *__restrict__ binv, const int64_t *__restrict__ rpM,
-                                                     const int32_t *__restrict__ colM, const double *__restrict__ app) {
+                                                     const int32_t *__restrict__ colM, const double *__restrict__ app, int64_t n_u_owned) {
   extern __shared__ __align__(16) unsigned char smem_t[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *acc = reinterpret_cast<double *>(smem_t) + size_t(wave) * maxlen;
@@ -59,6 +68,7 @@ __global__ __launch_bounds__(256) void k_tpp_numeric(int64_t n_rows, int maxlen,
     const int blen = int(rpB[row + 1] - bs);
     for (int kb = lane; kb < blen; kb += 64) {
       const int32_t k = colB[bs + kb];
+      if (k >= n_u_owned) continue; // a ghost velocity node: its row of A_vp and its diagonal block live on another rank
       double a[DIM], bd[DIM];
 #pragma unroll
       for (int e = 0; e < DIM; ++e) a[e] = valB[bs * DIM + int64_t(e) * blen + kb];
@@ -95,31 +105,31 @@ __global__ __launch_bounds__(256) void k_tpp_numeric(int64_t n_rows, int maxlen,
 
 void tpp_numeric(ifem_ctx *ctx) {
   if (ctx->tpp_valid) return;
-  if (ctx->halo.nranks > 1) throw Error(IFEM_E_BADPARAM, "explicit T_pp: single-rank contexts only");
-  if (ctx->Sm.n_rows == 0) build_schur_pattern(ctx);
-  const int64_t n = ctx->Sm.n_rows;
+  PlanarCsr &Pt = tpp_pat(ctx);
+  if (Pt.n_rows == 0) { if (ctx->halo.nranks > 1) build_schur_pattern_owned(ctx); else build_schur_pattern(ctx); }
+  const int64_t n = Pt.n_rows;
   if (n == 0) return;
-  if (ctx->Tpp.n != ctx->Sm.val.n) ctx->Tpp.alloc(ctx->Sm.val.n);
-  const int maxlen = (ctx->Sm.max_row + 1) & ~1;
+  if (ctx->Tpp.n != (size_t)Pt.nnzb) ctx->Tpp.alloc((size_t)Pt.nnzb);
+  const int maxlen = (Pt.max_row + 1) & ~1;
   const size_t smem = size_t(4) * maxlen * (sizeof(double) + sizeof(int32_t));
   const unsigned blocks = unsigned((n + 3) / 4);
 #define IFEM_TPP(D)                                                                                                     \
-  hipLaunchKernelGGL((k_tpp_numeric<D>), dim3(blocks), dim3(256), smem, ctx->stream, n, maxlen, ctx->Sm.rowptr.p,       \
-                     ctx->Sm.col.p, ctx->Tpp.p, ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, ctx->Bt.rowptr.p,          \
-                     ctx->Bt.col.p, ctx->Bt.val.p, ctx->bjac.p, ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->App.p)
+  hipLaunchKernelGGL((k_tpp_numeric<D>), dim3(blocks), dim3(256), smem, ctx->stream, n, maxlen, Pt.rowptr.p,            \
+                     Pt.col.p, ctx->Tpp.p, ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, ctx->Bt.rowptr.p,               \
+                     ctx->Bt.col.p, ctx->Bt.val.p, ctx->bjac.p, ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->App.p, ctx->nUo)
   if (ctx->dim == 3) IFEM_TPP(3); else IFEM_TPP(2);
 #undef IFEM_TPP
   IFEM_HIP_CHECK(hipGetLastError());
   if (ctx->tpp_diag.n != (size_t)n) ctx->tpp_diag.alloc((size_t)n);
-  scalar_diag(ctx, ctx->Sm, ctx->Tpp.p, ctx->tpp_diag.p);
+  scalar_diag(ctx, Pt, ctx->Tpp.p, ctx->tpp_diag.p);
   ctx->tpp_valid = true;
   ctx->tpp_ilu.factored = false;
 }
 
 void spmv_tpp(ifem_ctx *ctx, const double *xp, double *yp) {
-  const int64_t n = ctx->Sm.n_rows;
-  if (n == 0) return;
-  spmv_planar_scalar(ctx, ctx->Sm, ctx->Tpp.p, xp, yp);
+  const PlanarCsr &Pt = tpp_pat(ctx);
+  if (Pt.n_rows == 0) return;
+  spmv_planar_scalar(ctx, Pt, ctx->Tpp.p, xp, yp);
 }
 
 
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(256) void k_ilu_factor(int64_t n_rows, const int32_
     const int64_t ks = rp[k];
     const int klen = int(rp[k + 1] - ks);
     const double lik = w[e] / LU[ks + diag[k]];
+    double dropped = 0.0; // fill-in this lane drops in this step (relaxed MILU: it goes to the diagonal, below)
     for (int u = n_low[k] + 1 + lane; u < klen; u += 64) { // upper entries of row k (its final values: an earlier level)
       const int32_t e2 = ent[ks + u];
       const int32_t j = col[ks + e2];
@@ -233,10 +244,16 @@ __global__ __launch_bounds__(256) void k_ilu_factor(int64_t n_rows, const int32_
         if (cv < j) lo = mid + 1; else hi = mid - 1;
       }
       if (p >= 0) w[p] -= lik * LU[ks + e2]; // distinct j, distinct p
-      else if (omega != 0.0) unsafeAtomicAdd(&w[di], -omega * lik * LU[ks + e2]); // relaxed MILU: dropped fill goes to the diagonal
+      else dropped += lik * LU[ks + e2];
+    }
+    // one lane updates the diagonal after the wave has finished the step: no lane races the w[di] update of the j == i entry
+    // above, and the sum has a fixed order (deterministic factors)
+    if (omega != 0.0) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) dropped += __shfl_xor(dropped, off);
     }
     wsync_lds();
-    if (lane == 0) w[e] = lik;
+    if (lane == 0) { w[e] = lik; if (omega != 0.0) w[di] -= omega * dropped; }
     wsync_lds();
   }
   for (int t = lane; t < len; t += 64) LU[rs + t] = w[t];
@@ -332,6 +349,20 @@ __global__ __launch_bounds__(1024) void k_ilu_solve_batch(int l0, int l1, const 
   }
 }
 
+// after the factorisation: smallest and largest |pivot| and the number of non-finite entries of the factors
+__global__ void k_ilu_check(int64_t n, const int64_t *__restrict__ rp, const int32_t *__restrict__ diag, const double *__restrict__ LU,
+                            unsigned long long *__restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long bad = 0;
+  for (int64_t k = rp[i]; k < rp[i + 1]; ++k) bad += isfinite(LU[k]) ? 0 : 1;
+  const double d = fabs(LU[rp[i] + diag[i]]);
+  if (bad || !isfinite(d)) { atomicAdd(&out[2], bad ? bad : 1ull); return; }
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(d); // order-preserving for non-negative doubles
+  atomicMin(&out[0], bits);
+  atomicMax(&out[1], bits);
+}
+
 // launch plan of one triangular sweep: runs of consecutive levels with at most kBatchRows rows each go to the batch kernel
 static constexpr int64_t kBatchRows = 256;
 static void plan_sweep(const std::vector<int64_t> &lvl, std::vector<std::array<int32_t, 2>> &plan) {
@@ -347,17 +378,19 @@ static void plan_sweep(const std::vector<int64_t> &lvl, std::vector<std::array<i
   }
 }
 
-void tpp_ilu_factor(ifem_ctx *ctx) {
+bool tpp_ilu_factor(ifem_ctx *ctx) {
   TppIlu &I = ctx->tpp_ilu;
-  const int64_t n = ctx->Sm.n_rows;
-  if (n == 0 || I.factored) return;
+  const PlanarCsr &Pt = tpp_pat(ctx);
+  const int64_t n = Pt.n_rows;
+  if (n == 0) return true;
+  if (I.factored) return !I.broken;
   hipStream_t s = ctx->stream;
   const int order_kind = ctx->tune.tpp_ilu_order == 1 ? 1 : 0;
   if (!I.analysed || I.order_kind != order_kind) { // once per pattern: the elimination DAG on the host
     std::vector<int64_t> rp((size_t)n + 1);
-    std::vector<int32_t> col((size_t)ctx->Sm.nnzb);
-    IFEM_HIP_CHECK(hipMemcpyAsync(rp.data(), ctx->Sm.rowptr.p, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    IFEM_HIP_CHECK(hipMemcpyAsync(col.data(), ctx->Sm.col.p, col.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> col((size_t)Pt.nnzb);
+    IFEM_HIP_CHECK(hipMemcpyAsync(rp.data(), Pt.rowptr.p, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    IFEM_HIP_CHECK(hipMemcpyAsync(col.data(), Pt.col.p, col.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     IFEM_HIP_CHECK(hipStreamSynchronize(s));
     IluHost H;
     ilu_analyse(rp, col, order_kind, H);
@@ -376,26 +409,41 @@ void tpp_ilu_factor(ifem_ctx *ctx) {
   }
   if (I.LU.n != ctx->Tpp.n) I.LU.alloc(ctx->Tpp.n);
   IFEM_HIP_CHECK(hipMemcpyAsync(I.LU.p, ctx->Tpp.p, ctx->Tpp.n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  const int maxlen = (ctx->Sm.max_row + 1) & ~1;
+  const int maxlen = (Pt.max_row + 1) & ~1;
   const size_t smem = size_t(4) * maxlen * sizeof(double);
   const double omega = 1e-3 * std::min(std::max(ctx->tune.tpp_milu_permille, 0), 1000);
   for (size_t l = 0; l + 1 < I.lvl_f.size(); ++l) {
     const int64_t first = I.lvl_f[l], cnt = I.lvl_f[l + 1] - first;
     if (cnt <= 0) continue;
-    hipLaunchKernelGGL(k_ilu_factor, dim3(unsigned((cnt + 3) / 4)), dim3(256), smem, s, cnt, I.rows_f.p + first, maxlen, ctx->Sm.rowptr.p,
-                       ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, omega);
+    hipLaunchKernelGGL(k_ilu_factor, dim3(unsigned((cnt + 3) / 4)), dim3(256), smem, s, cnt, I.rows_f.p + first, maxlen, Pt.rowptr.p,
+                       Pt.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, omega);
   }
+  // breakdown check: the pivots divide in every later elimination step and in every triangular solve
+  if (I.chk.n != 3) I.chk.alloc(3);
+  const unsigned long long init[3] = {~0ull, 0ull, 0ull};
+  IFEM_HIP_CHECK(hipMemcpyAsync(I.chk.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_ilu_check, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, Pt.rowptr.p, I.diag.p, I.LU.p, I.chk.p);
+  unsigned long long res[3];
+  IFEM_HIP_CHECK(hipMemcpyAsync(res, I.chk.p, sizeof(res), hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
   IFEM_HIP_CHECK(hipGetLastError());
+  double pmin, pmax;
+  static_assert(sizeof(double) == sizeof(unsigned long long), "bit copy");
+  std::memcpy(&pmin, &res[0], 8); std::memcpy(&pmax, &res[1], 8);
+  I.pivot_min = res[2] ? 0.0 : pmin; I.pivot_max = res[2] ? 0.0 : pmax;
+  I.broken = res[2] != 0 || !(pmin > 1e-14 * pmax);
   I.factored = true;
+  return !I.broken;
 }
 
 // y = (LU)^-1 x
 void tpp_ilu_apply(ifem_ctx *ctx, const double *x, double *y) {
   TppIlu &I = ctx->tpp_ilu;
+  const PlanarCsr &Pt = tpp_pat(ctx);
   hipStream_t s = ctx->stream;
   const int sweeps = ctx->tune.tpp_tri_sweeps;
   if (sweeps > 0) { // approximate triangular solves: 2 * sweeps row-parallel launches
-    const int64_t n = ctx->Sm.n_rows;
+    const int64_t n = Pt.n_rows;
     if ((int64_t)I.t0.n < n) { I.t0.alloc((size_t)n); I.t1.alloc((size_t)n); }
     const dim3 g(unsigned((n * 16 + 255) / 256)), b(256);
     // forward: start from y0 = x (the zeroth Neumann term), ping-pong between t0 and t1
@@ -403,17 +451,17 @@ void tpp_ilu_apply(ifem_ctx *ctx, const double *x, double *y) {
     double *bufs[2] = {I.t0.p, I.t1.p};
     for (int k = 0; k < sweeps; ++k) {
       double *nxt = bufs[k & 1];
-      hipLaunchKernelGGL((k_ilu_jacobi_sweep<true>), g, b, 0, s, n, ctx->Sm.rowptr.p, ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, cur, nxt);
+      hipLaunchKernelGGL((k_ilu_jacobi_sweep<true>), g, b, 0, s, n, Pt.rowptr.p, Pt.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, cur, nxt);
       cur = nxt;
     }
     const double *z = cur; // L^-1 x (approximately): the right-hand side of the backward system, lives in one of the buffers
     // backward: y0 = D^-1 z into y, then sweeps ping-pong between y and the buffer that does not hold z
-    hipLaunchKernelGGL(k_ilu_diag_scale, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, ctx->Sm.rowptr.p, I.diag.p, I.LU.p, z, y);
+    hipLaunchKernelGGL(k_ilu_diag_scale, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, Pt.rowptr.p, I.diag.p, I.LU.p, z, y);
     double *other = (z == I.t0.p) ? I.t1.p : I.t0.p;
     const double *curb = y;
     for (int k = 0; k < sweeps; ++k) {
       double *nxt = (curb == y) ? other : y;
-      hipLaunchKernelGGL((k_ilu_jacobi_sweep<false>), g, b, 0, s, n, ctx->Sm.rowptr.p, ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, z, curb, nxt);
+      hipLaunchKernelGGL((k_ilu_jacobi_sweep<false>), g, b, 0, s, n, Pt.rowptr.p, Pt.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, z, curb, nxt);
       curb = nxt;
     }
     if (curb != y) IFEM_HIP_CHECK(hipMemcpyAsync(y, curb, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -428,16 +476,16 @@ void tpp_ilu_apply(ifem_ctx *ctx, const double *x, double *y) {
       if (st[1] < 0) {
         const int64_t first = lvl[st[0]], cnt = lvl[st[0] + 1] - first;
         if (forward)
-          hipLaunchKernelGGL((k_ilu_solve<true>), dim3(unsigned((cnt * 16 + 255) / 256)), dim3(256), 0, s, cnt, rows + first, ctx->Sm.rowptr.p,
-                             ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
+          hipLaunchKernelGGL((k_ilu_solve<true>), dim3(unsigned((cnt * 16 + 255) / 256)), dim3(256), 0, s, cnt, rows + first, Pt.rowptr.p,
+                             Pt.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
         else
-          hipLaunchKernelGGL((k_ilu_solve<false>), dim3(unsigned((cnt * 16 + 255) / 256)), dim3(256), 0, s, cnt, rows + first, ctx->Sm.rowptr.p,
-                             ctx->Sm.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
+          hipLaunchKernelGGL((k_ilu_solve<false>), dim3(unsigned((cnt * 16 + 255) / 256)), dim3(256), 0, s, cnt, rows + first, Pt.rowptr.p,
+                             Pt.col.p, I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
       } else if (forward)
-        hipLaunchKernelGGL((k_ilu_solve_batch<true>), dim3(1), dim3(1024), 0, s, st[0], st[1], d_lvl, rows, ctx->Sm.rowptr.p, ctx->Sm.col.p,
+        hipLaunchKernelGGL((k_ilu_solve_batch<true>), dim3(1), dim3(1024), 0, s, st[0], st[1], d_lvl, rows, Pt.rowptr.p, Pt.col.p,
                            I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
       else
-        hipLaunchKernelGGL((k_ilu_solve_batch<false>), dim3(1), dim3(1024), 0, s, st[0], st[1], d_lvl, rows, ctx->Sm.rowptr.p, ctx->Sm.col.p,
+        hipLaunchKernelGGL((k_ilu_solve_batch<false>), dim3(1), dim3(1024), 0, s, st[0], st[1], d_lvl, rows, Pt.rowptr.p, Pt.col.p,
                            I.ent.p, I.n_low.p, I.diag.p, I.LU.p, x, y);
     }
   };

@@ -184,6 +184,44 @@ def test_box3d_q1q1_32_scnsim_converges_in_under_50_inner_iterations():
     ctx.close()
 
 
+def test_ilu0_breakdown_is_detected_and_the_factors_are_deterministic():
+    """(i) a zero / non-finite pivot of the ILU(0) must not flow into the Krylov solve: the probe reports it (the solver
+    falls back to Jacobi); (ii) the relaxed MILU update of the diagonal is one ordered sum per elimination step: two
+    factorisations of the same matrix give bit-identical applications."""
+    capi = _capi()
+    m, dofs, vals = _cylinder(1)
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.scns_assemble(capi.make_scns_params(mu=1.8e-4, rho=1.3e-3, dt=1e-2), True)
+    x = np.random.default_rng(5).standard_normal(m.n_pnodes)
+    T, y1, _ = _probe(ctx, m.n_pnodes, x)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    val = np.ascontiguousarray(T.data)
+    assert ctx.L.ifem_tpp_override(ctx.h, P(val)) == 0  # the same values: factorised again from scratch
+    _, y2, _ = _probe(ctx, m.n_pnodes, x)
+    assert np.array_equal(y1, y2)
+    # a matrix whose first pivot is zero
+    bad = val.copy()
+    rp, col = T.indptr, T.indices
+    bad[rp[0] + int(np.nonzero(col[rp[0]:rp[1]] == 0)[0][0])] = 0.0
+    assert ctx.L.ifem_tpp_override(ctx.h, P(bad)) == 0
+    rpb = np.zeros(m.n_pnodes + 1, np.int64)
+    yb = np.zeros(m.n_pnodes)
+    rc = ctx.L.ifem_tpp_ilu_probe(ctx.h, P(rpb), None, None, P(x), P(yb), None)
+    assert rc != 0 and b"broke down" in ctx.L.ifem_last_error()
+    # and one with a NaN
+    bad = val.copy()
+    bad[rp[5]] = np.nan
+    assert ctx.L.ifem_tpp_override(ctx.h, P(bad)) == 0
+    assert ctx.L.ifem_tpp_ilu_probe(ctx.h, P(rpb), None, None, P(x), P(yb), None) != 0
+    # the solver itself survives a broken factorisation of a REAL matrix: Jacobi instead (same answer, more inner iterations)
+    ctx.scns_assemble(capi.make_scns_params(mu=1.8e-4, rho=1.3e-3, dt=1e-2), True)
+    st = ctx.scns_solve(True)
+    assert st.fgmres_iters > 0
+    ctx.close()
+
+
 def test_library_links_no_vendor_solver():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run(["readelf", "-d", os.path.join(root, "openifem_amd", "lib", "libifem_hip.so")], capture_output=True, text=True).stdout
