@@ -477,7 +477,7 @@ def main():
                     "traffic": pmc_traffic("k_spmv_uu", n, "f32" if args.ainv == 1 else "f64") if world == 1 else None,
                     "launch_ms": spmv_avg_ms, "launches_timed": spmv_calls, "algorithmic_bytes": tm.spmv_uu_bytes}
         else:
-            name = {"asm": "k_ins_assemble3 (cell integration on the FP64 matrix cores + scatter)", "mf": "k_apply_uu_mf2<3,2,float> (matrix-free A_uu of the inner solver, fp32 cell arithmetic)"}[dom]
+            name = {"asm": "k_ins_assemble3 (one wavefront per cell: sum-factorised front, FP64 MFMA contraction, row-image atomic scatter)", "mf": "k_apply_uu_mf2<3,2,float> (matrix-free A_uu of the inner solver, fp32 cell arithmetic)"}[dom]
             ms = asm_kernel_ms if dom == "asm" else mf_avg_ms
             nb, nf = models[dom]
             gbs, tfs = nb / (ms * 1e-3) / 1e9, nf / (ms * 1e-3) / 1e12
@@ -496,12 +496,16 @@ def main():
                          "compute_peak": "FP64 MFMA" if dom == "asm" else "FP32 vector FMA",
                          "kernel_ms_per_step": totals})
             if dom == "asm":
-                # what actually bounds this kernel: the rate of the f64 atomic unit.  One atomic per (cell, dof pair) of the
-                # velocity-velocity block; peak = the contiguous-footprint rate measured by tools/microbench.hip
-                # (profiles/r01_microbench.txt: 188 Gatom/s; 72-byte strided footprints reach 24 Gatom/s)
+                # what actually bounds this kernel: the memory-side rate of its f64 atomic requests.  One atomic per
+                # (cell, dof pair) of the velocity-velocity block; the unit retires ~24 G requests of up to 64 bytes per second
+                # whatever the lane count (tools/atomics_types.hip: 23.9 G/s f64, 188 G atomics/s only when 8 lanes share a
+                # segment); the kernel's staged scatter touches 871 segments per cell (tools/scatter_sim.py, CPU replay)
                 n_atom = float(n_cells) * (27 * 3) ** 2
+                n_seg = float(n_cells) * 871.0
                 roof.update({"atomic_adds": n_atom, "atomic_rate_gatom_s": n_atom / (ms * 1e-3) / 1e9, "atomic_peak_gatom_s": 188.0,
-                             "atomic_frac": n_atom / (ms * 1e-3) / 1e9 / 188.0})
+                             "atomic_frac": n_atom / (ms * 1e-3) / 1e9 / 188.0,
+                             "atomic_segments": n_seg, "atomic_segment_rate_g_s": n_seg / (ms * 1e-3) / 1e9, "atomic_segment_peak_g_s": 24.0,
+                             "atomic_segment_frac": n_seg / (ms * 1e-3) / 1e9 / 24.0})
         out = {
             "metric": "DoF/s per Newton step (assemble+solve), 3D INS Q2/Q1",
             "value": n_dofs_global / (elapsed / args.steps),

@@ -228,8 +228,7 @@ typedef struct {
   int32_t rccl_nranks;   /* ncclCommCount */
   int32_t halo_stream;   /* 1: overlapped exchanges on the second communicator + priority stream */
   int32_t levels;        /* contexts summed over (1 + attached multigrid levels) */
-  int32_t tpp_milu_permille; /* SCnsIM, ILU(0) of T_pp: 950 (default); 0 plain ILU(0); w in (0, 1000]: relaxed modified ILU, w/1000 of every dropped
-                                fill-in entry is added to the diagonal of its row */
+  int32_t reserved_;     /* padding, always 0 */
   uint64_t halo_exchanges; /* packed send/recv groups (forward and reverse) */
   uint64_t allreduce_dev;  /* all-reduces of device scalars ordered on the stream (no host wait) */
   uint64_t allreduce_host; /* all-reduces the host waited for (Gram-Schmidt coefficients, norms) */
@@ -290,7 +289,13 @@ int ifem_halo_exchange(ifem_ctx *ctx, int vec);           /* ghosted-vector assi
  * P_p: pressure-node prolongation, rows = the OWNED pressure nodes of `fine`, columns = LOCAL (owned + ghost) pressure
  * nodes of `coarse` on the same rank; R_p = P_p^T, rows = LOCAL pressure nodes of `coarse`, columns = owned pressure
  * nodes of `fine` (ghost rows are sent to their owners and added, like a PETSc reverse scatter).  The caller keeps
- * `coarse` alive and keeps its constraint sets in step with those of `fine`; the tables are copied. */
+ * `coarse` alive and keeps its BOUNDARY constraint sets in step with those of `fine`; the tables are copied.  Lines that only
+ * the fine context carries (the artificial-fluid Dirichlet lines ifem_fsi_find_fluid_bc merges into its sets every coupled step)
+ * need not be mirrored: the coarse levels then treat those dofs as free, the transfers still drop them on the fine side
+ * (per-weight masks rebuilt whenever a constrained-dof set changes) -- a weaker coarse correction inside the preconditioner,
+ * the outer operator and its stopping rule are untouched (tests/test_gpu_fsi_caller.py runs InsIM with attached levels under
+ * such lines).  The V-cycle of the A_uu block always runs on single-precision level vectors, whatever ifem_tuning::mf_f32 says
+ * (that switch selects the cell arithmetic of the inner GMRES's operator only). */
 typedef struct {
   int64_t n_fine_p_owned, n_coarse_p_local;
   const int64_t *pp_ptr; const int32_t *pp_col; const double *pp_w; /* CSR of P_p */

@@ -56,6 +56,7 @@ struct LocalWorld {
   // host-only rendezvous of the exchanges (no device synchronisation around it): spin briefly, then yield
   std::atomic<long> spin_count{0};
   std::atomic<long> spin_gen{0};
+  std::atomic<bool> aborted{false}; // a rank left an exchange by an exception: its peers must not wait for it for ever
   void rendezvous() {
     const long gen = spin_gen.load(std::memory_order_acquire);
     if (spin_count.fetch_add(1, std::memory_order_acq_rel) + 1 == nranks) {
@@ -63,8 +64,31 @@ struct LocalWorld {
       spin_gen.store(gen + 1, std::memory_order_release);
     } else {
       int spins = 0;
-      while (spin_gen.load(std::memory_order_acquire) == gen)
+      while (spin_gen.load(std::memory_order_acquire) == gen) {
+        if (aborted.load(std::memory_order_acquire)) throw Error(IFEM_E_COMM, "local world: a peer rank aborted an exchange");
         if (++spins > 2000) std::this_thread::yield();
+      }
+    }
+  }
+  // the halo plans of all ranks against each other, once (comm_init, every context registered): what the exchanges would
+  // otherwise find out between two rendezvous, leaving the peers of the throwing rank spinning
+  void validate(int rank) const {
+    const ifem_ctx *c = ctx[rank];
+    const Halo &h = c->halo;
+    for (size_t k = 0; k < h.nbr.size(); ++k) {
+      const int pr = h.nbr[k];
+      if (pr < 0 || pr >= nranks || !ctx[pr]) throw Error(IFEM_E_COMM, "local world: neighbour rank out of range");
+      const ifem_ctx *peer = ctx[pr];
+      if (peer->device != c->device) throw Error(IFEM_E_COMM, "local world: all contexts must live on one device (the all-reduce reads the peers' scalars directly)");
+      const Halo &ph = peer->halo;
+      int me = -1;
+      for (size_t j = 0; j < ph.nbr.size(); ++j) if (ph.nbr[j] == rank) me = (int)j;
+      if (me < 0) throw Error(IFEM_E_COMM, "local world: neighbour lists are not symmetric");
+      if (ph.send_u_ptr[me + 1] - ph.send_u_ptr[me] != h.recv_u_ptr[k + 1] - h.recv_u_ptr[k] ||
+          ph.send_p_ptr[me + 1] - ph.send_p_ptr[me] != h.recv_p_ptr[k + 1] - h.recv_p_ptr[k])
+        throw Error(IFEM_E_COMM, "local world: send/recv count mismatch between rank " + std::to_string(rank) + " and " + std::to_string(pr));
+      if (h.has_s != ph.has_s || (h.has_s && ph.send_s_ptr[me + 1] - ph.send_s_ptr[me] != h.recv_s_ptr[k + 1] - h.recv_s_ptr[k]))
+        throw Error(IFEM_E_COMM, "local world: 2-deep pressure halo plans do not match");
     }
   }
 };
@@ -114,6 +138,11 @@ void comm_init(ifem_ctx *ctx, const ifem_partition *part) {
       IFEM_HIP_CHECK(hipEventCreateWithFlags(&w->ev_copied[h.rank], hipEventDisableTiming));
     }
     w->barrier();
+    // every rank validates (and every rank passes the second barrier even if it throws afterwards: no peer is left waiting)
+    std::string bad;
+    try { w->validate(h.rank); } catch (const Error &e) { bad = e.what(); }
+    w->barrier();
+    if (!bad.empty()) throw Error(IFEM_E_COMM, bad);
   } else {
     if (!part->nccl_unique_id) throw Error(IFEM_E_BADPARAM, "ifem_partition needs nccl_unique_id or local_world");
     ncclUniqueId id;
@@ -218,6 +247,7 @@ static void exchange(ifem_ctx *ctx, T *x, int which, bool async = false) {
     // stream-ordered like the RCCL path: my copies wait (on the device) for the peers' packing kernels, the peers' next
     // packing kernels wait for my copies; the host threads only meet to know that the events have been recorded
     auto *w = static_cast<LocalWorld *>(h.local);
+    try {
     IFEM_HIP_CHECK(hipEventRecord(w->ev_packed[h.rank], ctx->stream)); // my send buffer is complete at this point of my stream
     w->rendezvous();
     for (int k = 0; k < nn; ++k) {
@@ -238,6 +268,7 @@ static void exchange(ifem_ctx *ctx, T *x, int which, bool async = false) {
     w->rendezvous();
     // whatever I launch next (the next packing kernel first of all) must not overwrite what a peer is still reading
     for (int k = 0; k < nn; ++k) IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_copied[h.nbr[k]], 0));
+    } catch (...) { w->aborted.store(true, std::memory_order_release); throw; } // the peers leave their rendezvous with an error
     return;
   }
   async = async && h.comm2 && h.hstream;

@@ -507,3 +507,54 @@ def test_fsi_loop_3d_insimex_with_device_produced_inputs():
         ep = np.abs(got[n_u:] - ref[step][n_u:]).max() / np.abs(ref[step][n_u:]).max()
         assert ev < 1e-6 and ep < 1e-6, (step, ev, ep)
     ctx.close()
+
+
+def test_insim_with_attached_multigrid_levels_under_fsi_dirichlet_lines():
+    """ADVICE r3: InsIM::initialize_system attaches the multigrid chain on box meshes and makes IFEM_AINV_MG the default inner solver --
+    also when the solver is the fluid side of MPI::FSI, whose find_fluid_bc (use_dirichlet_bc = true) merges Dirichlet lines of the
+    artificial fluid into the FINE context's constraint sets every step while the coarse levels keep the boundary lines only
+    (include/ifem_hip.h, ifem_mg_attach).  The levels then are a weaker preconditioner, nothing else: the per-step loop converges
+    and gives the solution of the same loop without levels (Jacobi-preconditioned inner GMRES)."""
+    from openifem_amd import capi, host
+    from solidmesh import lattice_solid, rotation
+    reps, ext = (16, 8, 8), (2.0, 0.4, 0.4)
+    base = lattice_solid((4, 3, 3), (0.55, 0.12, 0.11), (0.95, 0.29, 0.30), mapping=rotation(0.2, (0.7, 0.2)))
+    dt = 1e-3
+
+    def solid(step):
+        s = base.moved(shift=np.array([0.5, 0.02, 0.01]) * step * dt * 40, rot=0.0, about=base.vertices.mean(axis=0))
+        s.velocity = np.tile(np.array([0.02, 0.001, 0.0005]), (len(s.vertices), 1))
+        s.acceleration = np.zeros_like(s.velocity)
+        s.stress = None
+        return s
+
+    sols, its = {}, {}
+    for mg in (True, False):
+        flow = host.InsIM(host.channel_prm(3, dt=dt), reps, (0, 0, 0), ext)
+        flow.set_multigrid(mg)
+        flow.setup(0)
+        assert (len(flow.mg_levels()) > 0) == mg
+        n_cells, n_u, n_p = flow.sizes()
+        if not mg:
+            flow.opts.inner_rel = 1e-3
+            flow.opts.inner_maxit = 4000
+        ctx = capi.Context.borrow(flow.ctx, 3, 2, n_u // 3, n_p)
+        n_lines = []
+        for step in range(2):
+            s = solid(step)
+            ctx.fsi_set_solid(s.vertices, s.cells, None, s.velocity, s.acceleration, None)
+            ind, n_art = ctx.fsi_update_indicator(n_cells)
+            flow.make_constraints(zero_inhomogeneities=step > 0)
+            st = ctx.fsi_find_fluid_bc(dt, True)
+            assert st.n_not_found == 0 and st.n_lines > 0
+            n_lines.append(st.n_lines)
+            flow.run_one_step(True)
+        v, p = flow.get_current_solution()
+        sols[mg] = np.concatenate([v, p])
+        its[mg] = flow.last_stats().fgmres_iters
+        flow.close()
+    a, b = sols[True], sols[False]
+    n_u3 = len(a) - n_p
+    assert np.abs(a[:n_u3] - b[:n_u3]).max() <= 1e-5 * np.abs(b[:n_u3]).max()
+    assert np.abs(a[n_u3:] - b[n_u3:]).max() <= 1e-4 * np.abs(b[n_u3:]).max()
+    assert its[True] <= 30, its
