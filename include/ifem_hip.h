@@ -451,7 +451,8 @@ int ifem_mass_vmult(ifem_ctx *ctx, int dst, int src);
  * (what a coarse multigrid level uses, mg.hip::k_uu_diag) */
 int ifem_uu_block_diag(ifem_ctx *ctx, int which, double *host_out);
 /* y_u = A_uu x_u on the velocity part of two context vectors -- test / bench hook.  variant: IFEM_AINV_GMRES_BJACOBI
- * (stored fp64 matrix), _F32 (its single-precision copy) or _MF (matrix-free) */
+ * (stored fp64 matrix), _F32 (its single-precision copy), _MF (matrix-free, fp64 cell arithmetic) or IFEM_AINV_MG (matrix-free
+ * with the single-precision cell arithmetic of the inner solve: ifem_tuning::mf_f32) */
 int ifem_uu_vmult(ifem_ctx *ctx, int dst, int src, int variant);
 /* z = P^-1 v, BlockSchurPreconditioner::vmult (mpi_insim.cpp:57-128) on context vectors -- test hook */
 int ifem_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int dst, int src);

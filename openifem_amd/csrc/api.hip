@@ -763,9 +763,10 @@ int ifem_uu_vmult(ifem_ctx *ctx, int dst, int src, int variant) {
   v_copy(ctx, nuo, ctx->vec[src].p, xe);
   if (ctx->halo.nranks > 1) halo_exchange(ctx, xe);
   if (variant == IFEM_AINV_GMRES_BJACOBI_MF) apply_uu_mf(ctx, xe, ctx->vec[dst].p);
+  else if (variant == IFEM_AINV_MG) apply_uu_mf(ctx, xe, ctx->vec[dst].p, /*single=*/true); // the inner solve's single-precision operator
   else if (variant == IFEM_AINV_GMRES_BJACOBI || variant == IFEM_AINV_GMRES_BJACOBI_F32)
     spmv_uu(ctx, xe, nullptr, ctx->vec[dst].p, variant == IFEM_AINV_GMRES_BJACOBI_F32);
-  else throw Error(IFEM_E_BADPARAM, "variant: IFEM_AINV_GMRES_BJACOBI, _F32 or _MF");
+  else throw Error(IFEM_E_BADPARAM, "variant: IFEM_AINV_GMRES_BJACOBI, _F32, _MF or IFEM_AINV_MG (single-precision matrix-free)");
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   IFEM_API_END
 }

@@ -57,6 +57,10 @@ struct MfGeo {
 // SGPRs, N1 LDS writes, in place), the quadrature-point stage runs on 27 of 32 lanes, the trilinear geometry comes
 // from 8 monomial coefficients, and the only synchronisation is wave-local (LDS operations of one wave execute in
 // order).  ~330 wave instructions per 3D Q2 cell (the first, item-per-lane version of round 1 needed ~1200).
+// Round 4 measured a variant with TWO cells per lane in packed arithmetic (v_pk_fma_f32 by construction, four cells per wave trip;
+// profiles/r04_valu_rate.txt, r04_mf_packed.txt): 1.97 against 1.75 ms per application at 128^3 -- v_pk_fma_f32 issues in 4.7
+// cycles against 4.1 for v_fma_f32 (1.7 x per FMA), but packed multiplies / adds gain nothing (the two-operand forms issue in 2.5
+// cycles), the pair needs 195 registers (two waves per SIMD, where every instruction issues ~15 % slower) and 8-byte LDS items.
 __device__ inline void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

@@ -413,3 +413,28 @@ def test_multigrid_ainv_on_virtual_ranks(P):
     assert abs(out[0][2] - st1.inner_iters) <= max(3, st1.inner_iters // 4), (out[0][2], st1.inner_iters)
     for w in worlds:
         L.ifem_local_world_destroy(w)
+
+
+@pytest.mark.parametrize("reps", [(9, 7, 5), (4, 4, 4), (3, 1, 2)])
+def test_single_precision_operator_matches_the_fp64_operator(reps):
+    """the inner solve's single-precision matrix-free A_uu (ifem_uu_vmult variant IFEM_AINV_MG) against the fp64 matrix-free operator
+    (itself 1e-12 against the assembled matrix, test_gpu_parity.py) on distorted meshes whose cell counts leave every kind of tail
+    (315 cells, 64, 6), with constraints and a convective state"""
+    from openifem_amd import capi
+    from boxmesh import BoxMesh
+    rng = np.random.default_rng(11)
+    m = BoxMesh(reps, (0, 0, 0), (1.8, 0.7, 0.5), kv=2)
+    m.vcoords = m.vcoords.copy()
+    m.vcoords += 0.01 * rng.standard_normal(m.vcoords.shape)
+    dofs, vals = m.dirichlet({0: (7, [0.3, -0.2, 0.1]), 2: (7, [0.0, 0.0, 0.0])})
+    ctx = capi.Context(3, 2, m.vcoords, m.cell_unodes, m.cell_pnodes, m.cell_face_bid, m.n_unodes, m.n_pnodes)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.vec_set(capi.VEC_PRESENT, rng.standard_normal(m.n_dofs))
+    ctx.vec_set(capi.VEC_EVAL, rng.standard_normal(m.n_dofs))
+    ctx.assemble(capi.make_params(mu=0.7, rho=1.3, gamma=0.2, dt=0.01), False)
+    n_u = 3 * m.n_unodes
+    x = rng.standard_normal(m.n_dofs)
+    y64, y32 = ctx.uu_vmult(x, 3)[:n_u], ctx.uu_vmult(x, 4)[:n_u]
+    assert np.abs(y32 - y64).max() <= 3e-5 * np.abs(y64).max()
+    ctx.close()
