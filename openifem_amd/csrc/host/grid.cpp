@@ -369,7 +369,8 @@ template void distribute_dofs_unstructured<2>(const Triangulation<2> &, int, DoF
 template void distribute_dofs_unstructured<3>(const Triangulation<3> &, int, DoFTables<3> &, PartitionTables &);
 
 template <int dim>
-void partition_unstructured(const DoFTables<dim> &g, int nranks, int rank, DoFTables<dim> &out, PartitionTables &part) {
+void partition_unstructured(const DoFTables<dim> &g, int nranks, int rank, DoFTables<dim> &out, PartitionTables &part,
+                            const HangingLines *lines, HangingLines *local_lines) {
   constexpr int NV = 1 << dim;
   const int nu = g.nu;
   const size_t nc = g.cell_unodes.size() / nu;
@@ -404,6 +405,20 @@ void partition_unstructured(const DoFTables<dim> &g, int nranks, int rank, DoFTa
       L.cells.push_back(c);
       for (int a = 0; a < nu; ++a) useu[g.cell_unodes[c * nu + a]] = 1;
       for (int v = 0; v < NV; ++v) usep[g.cell_pnodes[c * NV + v]] = 1;
+    }
+    // hanging-node lines: the masters of every local hanging node join the ghost layer (the interpolation x_h = sum w x_m and
+    // its transpose run on local data; masters are regular nodes of an unrefined cell, so one pass closes the set)
+    if (lines) {
+      const int64_t n_u_glob = int64_t(dim) * g.n_unodes;
+      for (size_t i = 0; i < lines->dof.size(); ++i) {
+        const int64_t d = lines->dof[i];
+        const bool vel = d < n_u_glob;
+        if (!(vel ? useu[d / dim] : usep[d - n_u_glob])) continue;
+        for (int32_t k = lines->ptr[i]; k < lines->ptr[i + 1]; ++k) {
+          const int64_t md = lines->master[k];
+          if (vel) useu[md / dim] = 1; else usep[md - n_u_glob] = 1;
+        }
+      }
     }
     auto number = [&](const std::vector<char> &use, const std::vector<int> &own, std::vector<int64_t> &l2g, int64_t &n_owned) {
       for (int64_t i = 0; i < (int64_t)use.size(); ++i) if (use[i] && own[i] == t) l2g.push_back(i);
@@ -465,9 +480,32 @@ void partition_unstructured(const DoFTables<dim> &g, int nranks, int rank, DoFTa
   }
   if (part.recv_u_ptr.back() != out.n_unodes - out.n_unodes_owned || part.recv_p_ptr.back() != out.n_pnodes - out.n_pnodes_owned)
     throw std::logic_error("partition_unstructured: ghost bookkeeping is inconsistent");
+  // 6. the lines of the local (owned AND ghost) hanging dofs in local block numbering [dim * unode + c | dim * n_unodes + pnode]
+  if (lines && local_lines) {
+    local_lines->clear();
+    const int64_t n_u_glob = int64_t(dim) * g.n_unodes, n_u_loc = int64_t(dim) * out.n_unodes;
+    auto loc = [&](int64_t d) -> int64_t {
+      if (d < n_u_glob) { const int32_t l = gu2l[d / dim]; return l < 0 ? -1 : int64_t(dim) * l + d % dim; }
+      const int32_t l = gp2l[d - n_u_glob];
+      return l < 0 ? -1 : n_u_loc + l;
+    };
+    std::map<int64_t, size_t> mine; // ascending local dof
+    for (size_t i = 0; i < lines->dof.size(); ++i) { const int64_t l = loc(lines->dof[i]); if (l >= 0) mine[l] = i; }
+    for (auto &kv_ : mine) {
+      const size_t i = kv_.second;
+      local_lines->dof.push_back((int32_t)kv_.first);
+      for (int32_t k = lines->ptr[i]; k < lines->ptr[i + 1]; ++k) {
+        const int64_t lm = loc(lines->master[k]);
+        if (lm < 0) throw std::logic_error("partition_unstructured: a master of a local hanging node is not local");
+        local_lines->master.push_back((int32_t)lm);
+        local_lines->weight.push_back(lines->weight[k]);
+      }
+      local_lines->ptr.push_back((int32_t)local_lines->master.size());
+    }
+  }
 }
-template void partition_unstructured<2>(const DoFTables<2> &, int, int, DoFTables<2> &, PartitionTables &);
-template void partition_unstructured<3>(const DoFTables<3> &, int, int, DoFTables<3> &, PartitionTables &);
+template void partition_unstructured<2>(const DoFTables<2> &, int, int, DoFTables<2> &, PartitionTables &, const HangingLines *, HangingLines *);
+template void partition_unstructured<3>(const DoFTables<3> &, int, int, DoFTables<3> &, PartitionTables &, const HangingLines *, HangingLines *);
 
 template <int dim>
 static void map_point(const double *X /*[NV][dim]*/, const double *xi, double *out) {

@@ -129,8 +129,13 @@ void distribute_dofs_unstructured(const Triangulation<dim> &tria, int kv, DoFTab
 // tables of rank `rank` of `nranks`: cells are cut into strips of equal count along x (p4est / METIS stand-in: results
 // do not depend on the partition), a node belongs to the lowest rank among the cells around it, the local cells are all
 // cells touching an owned node ("owner computes row"), ghosts are grouped by owner in global order.
+// `lines` (global hanging-node lines, e.g. of distribute_dofs_refined_box): the masters of every local hanging node join the
+// ghost layer, `local_lines` receives the lines of the local (owned and ghost) hanging dofs in local numbering -- what
+// ifem_set_hanging_constraints takes on a partitioned context (the reference runs its locally refined FSI meshes on >= 2 ranks:
+// tests/fsi_leaflet_mpi/fsi_leaflet_mpi.cpp:65-76, mpi_fluid_solver.cpp:182-184)
 template <int dim>
-void partition_unstructured(const DoFTables<dim> &global, int nranks, int rank, DoFTables<dim> &out, PartitionTables &part);
+void partition_unstructured(const DoFTables<dim> &global, int nranks, int rank, DoFTables<dim> &out, PartitionTables &part,
+                            const HangingLines *lines = nullptr, HangingLines *local_lines = nullptr);
 
 // Dirichlet lines (dof, value) in block numbering [u|p]; `bcs`: id -> (component flag 1..7, values);
 // `hard_coded`: id -> f(point, component) overriding the constant values (add_hard_coded_boundary_condition).

@@ -170,12 +170,17 @@ void FluidSolver<dim>::setup_dofs() {
       partition_unstructured<dim>(global, nranks, part_rank, dofs, part);
     }
   } else if (triangulation.locally_refined) { // one level of local refinement (execute_coarsening_and_refinement)
-    if (proc_grid[0] * proc_grid[1] * proc_grid[2] > 1)
-      throw std::runtime_error("setup_dofs: locally refined box triangulations are single-rank in the host mirror (partitioned "
-                               "contexts take hanging lines through ifem_set_hanging_constraints)");
+    const int nranks = proc_grid[0] * proc_grid[1] * proc_grid[2];
     const bool morton = dofs.morton;
     distribute_dofs_refined_box<dim>(triangulation, (int)parameters.fluid_velocity_degree, dofs, part, hanging);
     dofs.morton = morton;
+    if (nranks > 1) { // round 4: every rank builds the global tables and lines (these meshes are small) and keeps its strip, the
+                      // masters of its hanging nodes included (the reference runs these meshes on >= 2 ranks, fsi_leaflet_mpi.cpp:65-76)
+      const DoFTables<dim> global = dofs;
+      const HangingLines global_lines = hanging;
+      partition_unstructured<dim>(global, nranks, part_rank, dofs, part, &global_lines, &hanging);
+      dofs.morton = morton;
+    }
   } else {
     hanging.clear();
     distribute_dofs_box<dim>(triangulation.reps, triangulation.p0, triangulation.p1, triangulation.colorized,
@@ -233,7 +238,8 @@ void FluidSolver<dim>::initialize_system() {
     }
   }
   check(ifem_ctx_create(&m, part.nranks > 1 ? &ip : nullptr, device, &ctx), "initialize_system");
-  if (!hanging.dof.empty())
+  // collective: a rank whose strip holds no hanging node still takes part in the exchanges of the lines of the others
+  if (!hanging.dof.empty() || (triangulation.locally_refined && part.nranks > 1))
     check(ifem_set_hanging_constraints(ctx, (int32_t)hanging.dof.size(), hanging.dof.data(), hanging.ptr.data(), hanging.master.data(),
                                        hanging.weight.data()), "initialize_system");
   check(ifem_set_constraints(ctx, 1, (int32_t)constraint_dofs.size(), constraint_dofs.data(), nonzero_values.data()), "initialize_system");

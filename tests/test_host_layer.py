@@ -389,3 +389,66 @@ def test_cpp_transfers_interpolate_polynomials_exactly_on_every_rank_of_a_partit
         allg = np.concatenate(seen[deg])
         n_glob = int(np.prod([deg * r + 1 for r in reps_f]))
         assert len(allg) == n_glob and len(np.unique(allg)) == n_glob
+
+
+@pytest.mark.parametrize("dim,kv,reps,band,world", [(2, 1, (16, 4), (0.5, 1.8), 4), (2, 2, (8, 3), (1.0, 2.6), 2), (3, 2, (6, 2, 2), (1.2, 2.8), 3)])
+def test_locally_refined_box_on_a_strip_partition(dim, kv, reps, band, world):
+    """round 4 (missing #4): the host mirror cuts its own locally refined mesh into strips and hands every rank the
+    hanging-node lines of its local (owned and ghost) hanging dofs with their masters in the ghost layer -- the reference runs
+    these meshes on >= 2 ranks (tests/fsi_leaflet_mpi/fsi_leaflet_mpi.cpp:65-76).  Against the single-rank tables of the same
+    mirror: every global node is owned once, every local line is the global line under the local numbering, the halo plans of
+    the ranks match pairwise, every cell that touches an owned node is local."""
+    from openifem_amd import host
+    p0, p1 = (0.0,) * dim, (4.0, 1.0, 0.75)[:dim]
+    prm = host.channel_prm(dim).replace("set Velocity degree = 2", f"set Velocity degree = {kv}")
+    cls = host.InsIM if kv == 2 else host.SCnsIM
+
+    def build(rank):
+        s = cls(prm, reps, p0, p1)
+        assert s.refine_band(0, *band) > 0
+        if rank is not None:
+            s.set_partition((world, 1, 1), rank, local_world=None)
+        s.setup_host_only(0)
+        out = dict(tables=s.partition_tables(), cells=s.cell_tables(kv=kv), lines=s.hanging_lines(), cons=s.constraints(), sizes=s.partition_sizes())
+        s.close()
+        return out
+
+    g = build(None)
+    gdof, gptr, gmaster, gweight = g["lines"]
+    n_ug = g["tables"]["n_unodes_global"]
+    n_pg = g["tables"]["n_pnodes_global"]
+    gline = {int(d): (gmaster[gptr[i]:gptr[i + 1]], gweight[gptr[i]:gptr[i + 1]]) for i, d in enumerate(gdof)}
+    owned_u, owned_p, seen_lines = np.zeros(n_ug, int), np.zeros(n_pg, int), set()
+    parts = [build(r) for r in range(world)]
+    for r, q in enumerate(parts):
+        t = q["tables"]
+        nuo, npo = t["n_unodes_owned"], t["n_pnodes_owned"]
+        l2g_u, l2g_p = t["l2g_u"], t["l2g_p"]
+        owned_u[l2g_u[:nuo]] += 1
+        owned_p[l2g_p[:npo]] += 1
+        n_ul = len(l2g_u)
+
+        def to_global(d):
+            return dim * l2g_u[d // dim] + d % dim if d < dim * n_ul else dim * n_ug + l2g_p[d - dim * n_ul]
+
+        dof, ptr, master, weight = q["lines"]  # (a strip far from the band holds no hanging node)
+        for i, d in enumerate(dof):
+            gd = int(to_global(int(d)))
+            gm, gw = gline[gd]
+            lm = np.array([to_global(int(x)) for x in master[ptr[i]:ptr[i + 1]]])
+            assert (lm == gm).all() and np.abs(weight[ptr[i]:ptr[i + 1]] - gw).max() < 1e-14
+            seen_lines.add(gd)
+        # the local hanging dofs are exactly the global hanging dofs whose node is local here
+        local_globals = set(int(to_global(d)) for d in range(dim * n_ul + len(l2g_p)))
+        assert set(int(to_global(int(d))) for d in dof) == set(gline) & local_globals
+        # boundary lines skip hanging dofs
+        assert not set(q["cons"][0].tolist()) & set(dof.tolist())
+    assert (owned_u == 1).all() and (owned_p == 1).all()
+    assert seen_lines == set(gline) and len(gline) > 0
+    # every rank assembles every cell that touches one of its owned velocity nodes ("owner computes row")
+    cu_g = g["cells"][0]
+    for r, q in enumerate(parts):
+        t = q["tables"]
+        mine = set(t["l2g_u"][:t["n_unodes_owned"]].tolist())
+        want = sum(1 for c in range(len(cu_g)) if mine & set(cu_g[c].tolist()))
+        assert len(q["cells"][0]) == want

@@ -1,4 +1,5 @@
-"""Time the matrix-free A_uu (variant 3: fp64 cell arithmetic; 4: the inner solve's single-precision kernel, single-precision kernel) on the meshes of the multigrid chain: python tools/mfbench.py [variant]"""
+"""Time the matrix-free A_uu (variant 3: fp64 cell arithmetic; 4: the inner solve's single-precision kernel) on the meshes of
+the multigrid chain: python tools/mfbench.py [variant]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openifem_amd import host, capi
