@@ -4,6 +4,7 @@
 #include <random>
 #include <sstream>
 #include "insim.hpp"
+#include "multigrid.hpp"
 
 using namespace ifem_host;
 
@@ -43,6 +44,61 @@ int guard(F f) {
   catch (const std::exception &e) { g_err = e.what(); return IFEM_E_BADPARAM; }
 }
 } // namespace
+
+// the nested transfers of the cylinder meshes (multigrid.hpp::nested_prolongation / nested_injection) between refinement levels
+// `level` and level - 1, checked on the host -- out[0]: max |row sum - 1| of P_u and P_p (partition of unity), out[1]: number of
+// coarse velocity nodes c whose fine twin's row of P_u is not the unit vector e_c, out[2]: max error of a linear function at the
+// fine velocity nodes that sit where the parent's d-linear map puts them (every patch but the curved ring), out[3]: their share
+template <int dim>
+static void nested_check(int level, int kv, double *out) {
+  Triangulation<dim> tf, tc;
+  Utils::GridCreator<dim>::flow_around_cylinder(tf);
+  tf.refine_global(level);
+  Utils::GridCreator<dim>::flow_around_cylinder(tc);
+  tc.refine_global(level - 1);
+  DoFTables<dim> df, dc;
+  PartitionTables pf, pc;
+  distribute_dofs_unstructured<dim>(tf, kv, df, pf);
+  distribute_dofs_unstructured<dim>(tc, kv, dc, pc);
+  const size_t ncf = df.cell_unodes.size() / df.nu, ncc = dc.cell_unodes.size() / dc.nu;
+  std::vector<size_t> parent(ncf);
+  std::vector<int> offset(ncf);
+  for (size_t k = 0; k < ncf; ++k) tf.parent_of(level, k, parent[k], offset[k]);
+  CsrTransfer Pu, Pp;
+  nested_prolongation(dim, kv, df.cell_unodes.data(), ncf, df.n_unodes, dc.cell_unodes.data(), dc.n_unodes, parent, offset, Pu);
+  nested_prolongation(dim, 1, df.cell_pnodes.data(), ncf, df.n_pnodes, dc.cell_pnodes.data(), dc.n_pnodes, parent, offset, Pp);
+  const std::vector<int32_t> inj = nested_injection(dim, kv, df.cell_unodes.data(), ncf, dc.cell_unodes.data(), ncc, dc.n_unodes, parent, offset);
+  double rs = 0;
+  for (const CsrTransfer *P : {&Pu, &Pp})
+    for (int64_t i = 0; i < P->n_rows; ++i) {
+      double s = 0;
+      for (int64_t k = P->ptr[(size_t)i]; k < P->ptr[(size_t)i + 1]; ++k) s += P->w[(size_t)k];
+      rs = std::max(rs, std::fabs(s - 1.0));
+    }
+  int64_t bad = 0;
+  for (int64_t c = 0; c < dc.n_unodes; ++c) {
+    const int64_t i = inj[(size_t)c];
+    bool ok = Pu.ptr[(size_t)i + 1] - Pu.ptr[(size_t)i] == 1 && Pu.col[(size_t)Pu.ptr[(size_t)i]] == c && std::fabs(Pu.w[(size_t)Pu.ptr[(size_t)i]] - 1.0) < 1e-13;
+    bad += ok ? 0 : 1;
+  }
+  auto f = [](const std::array<double, dim> &x) { double v = 1.0; const double g[3] = {2.0, -3.0, 0.5}; for (int d = 0; d < dim; ++d) v += g[d] * x[d]; return v; };
+  double err = 0;
+  int64_t n_straight = 0;
+  for (int64_t i = 0; i < df.n_unodes; ++i) {
+    double v = 0;
+    std::array<double, dim> xi{};
+    for (int64_t k = Pu.ptr[(size_t)i]; k < Pu.ptr[(size_t)i + 1]; ++k) {
+      v += Pu.w[(size_t)k] * f(dc.unode_coords[(size_t)Pu.col[(size_t)k]]);
+      for (int d = 0; d < dim; ++d) xi[d] += Pu.w[(size_t)k] * dc.unode_coords[(size_t)Pu.col[(size_t)k]][d];
+    }
+    double dist = 0;
+    for (int d = 0; d < dim; ++d) dist = std::max(dist, std::fabs(xi[d] - df.unode_coords[(size_t)i][d]));
+    if (dist > 1e-12) continue; // a node the curved ring moved
+    ++n_straight;
+    err = std::max(err, std::fabs(v - f(df.unode_coords[(size_t)i])));
+  }
+  out[0] = rs; out[1] = double(bad); out[2] = err; out[3] = double(n_straight) / double(df.n_unodes);
+}
 
 extern "C" {
 
@@ -385,6 +441,10 @@ int ifemx_box_injection(int dim, const int *reps_fine, const int *reps_coarse, i
     auto inj = box_injection(dim, rf, rc, degree, l2g_coarse, n_coarse, l2g_fine, n_fine);
     std::memcpy(out, inj.data(), inj.size() * sizeof(int32_t));
   });
+}
+
+int ifemx_nested_transfer_check(int dim, int level, int kv, double *out) {
+  return guard([&] { if (dim == 2) nested_check<2>(level, kv, out); else nested_check<3>(level, kv, out); });
 }
 
 #define DISPATCH(h, expr2, expr3) (static_cast<Handle *>(h)->dim == 2 ? (expr2) : (expr3))

@@ -186,10 +186,19 @@ void GridCreator<2>::flow_around_cylinder(Triangulation<2> &tria) {
   tria.level = 0;
   tria.generator = [](Triangulation<2> &t, int level) {
     auto gen = t.generator;
+    auto par = t.parent_of;
     const int lv = level;
     cylinder_2d(t, lv);
     t.generator = gen;
+    t.parent_of = par;
     t.level = lv;
+  };
+  // every coarse patch emits its (2^level)^2 cells row by row (emit_patch): the parent of cell (a, b) of a patch is (a/2, b/2)
+  tria.parent_of = [](int level, size_t c, size_t &parent, int &offset) {
+    const size_t sf = size_t(1) << level, sc = sf / 2;
+    const size_t patch = c / (sf * sf), r = c % (sf * sf), b = r / sf, a = r % sf;
+    parent = patch * sc * sc + (b / 2) * sc + a / 2;
+    offset = int(a & 1) | int(b & 1) << 1;
   };
   cylinder_2d(tria, 0);
 }
@@ -227,10 +236,21 @@ void GridCreator<3>::flow_around_cylinder(Triangulation<3> &tria) {
   tria.level = 0;
   tria.generator = [](Triangulation<3> &t, int level) {
     auto gen = t.generator;
+    auto par = t.parent_of;
     const int lv = level;
     cylinder_3d(t, lv);
     t.generator = gen;
+    t.parent_of = par;
     t.level = lv;
+  };
+  // layer k of the extrusion holds the 2D mesh of the level (116 patches of (2^level)^2 cells): 2D rule + the layer pair
+  tria.parent_of = [](int level, size_t c, size_t &parent, int &offset) {
+    const size_t n_patches = 25 * 4 - 4 + 8;
+    const size_t sf = size_t(1) << level, sc = sf / 2, nc2f = n_patches * sf * sf, nc2c = n_patches * sc * sc;
+    const size_t k = c / nc2f, c2 = c % nc2f;
+    const size_t patch = c2 / (sf * sf), r = c2 % (sf * sf), b = r / sf, a = r % sf;
+    parent = (k / 2) * nc2c + patch * sc * sc + (b / 2) * sc + a / 2;
+    offset = int(a & 1) | int(b & 1) << 1 | int(k & 1) << 2;
   };
   cylinder_3d(tria, 0);
 }

@@ -32,6 +32,10 @@ struct Triangulation {
   // refine_global: the generator places the new vertices on the manifolds the reference attaches
   std::function<void(Triangulation<dim> &, int level)> generator;
   int level = 0;
+  // ... and know their refinement history: cell `fine_cell` of level `level` (>= 1) is child `offset` (bit d: upper half in
+  // direction d of the parent's reference cell) of cell `parent` of level - 1 -- what deal.II's cell->parent() / child(i) give
+  // the multigrid transfers (host/multigrid.cpp::nested_prolongation)
+  std::function<void(int level, size_t fine_cell, size_t &parent, int &offset)> parent_of;
   void refine_global(int times);
   // One level of LOCAL refinement of a box triangulation: cell->set_refine_flag() on coarse cells (numbered x fastest) and
   // execute_coarsening_and_refinement(), as the reference's FSI drivers refine a band of the fluid mesh

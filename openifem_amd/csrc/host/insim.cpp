@@ -50,6 +50,7 @@ template <int dim>
 bool FluidSolver<dim>::attach_multigrid_levels() {
   mg_coarse.reset();
   mg_tria.reset();
+  if (multigrid && ctx && !triangulation.is_box) return attach_nested_levels();
   if (!multigrid || !triangulation.is_box || triangulation.locally_refined || !ctx) return false;
   std::array<int, 3> n{1, 1, 1}, next;
   std::array<double, 3> extent{1, 1, 1};
@@ -102,6 +103,56 @@ bool FluidSolver<dim>::attach_multigrid_levels() {
   t.ru_ptr = Ru.ptr.data(); t.ru_col = Ru.col.data(); t.ru_w = Ru.w.data();
   t.inj_u = inj.data();
   check(ifem_mg_attach(ctx, c->ctx, &t), "attach_multigrid_levels");
+  mg_coarse = std::move(c);
+  return true;
+}
+
+// Unstructured meshes that know their refinement history (Utils::GridCreator::flow_around_cylinder under refine_global,
+// source/utilities.cpp:345-570, mpi_insim.cpp:493-519): the level chain IS the history -- the same generator one level down, the same
+// formulation / boundary conditions on it, transfers from the parent-child tables (host/multigrid.cpp::nested_prolongation).
+// Single rank (the strips of partition_unstructured are cut per level; their ghost layers do not cover each other's transfers).
+template <int dim>
+bool FluidSolver<dim>::attach_nested_levels() {
+  if (!triangulation.generator || !triangulation.parent_of || triangulation.level < 1) return false;
+  if (proc_grid[0] * proc_grid[1] * proc_grid[2] > 1 || triangulation.locally_refined) return false;
+  mg_tria.reset(new Triangulation<dim>());
+  mg_tria->generator = triangulation.generator;
+  mg_tria->parent_of = triangulation.parent_of;
+  mg_tria->generator(*mg_tria, triangulation.level - 1);
+  std::unique_ptr<FluidSolver<dim>> c = make_level_solver(*mg_tria);
+  if (!c) { mg_tria.reset(); return false; }
+  c->pcout = nullptr;
+  c->multigrid = true;
+  c->mg_min_cells = mg_min_cells;
+  c->dofs.morton = dofs.morton;
+  c->hard_coded_boundary_values = hard_coded_boundary_values;
+  c->field_time = field_time;
+  c->setup_dofs();
+  c->make_constraints();
+  c->initialize_system(); // recursion: attaches the levels below c
+  const size_t ncf = dofs.cell_unodes.size() / dofs.nu, ncc = c->dofs.cell_unodes.size() / c->dofs.nu;
+  std::vector<size_t> parent(ncf);
+  std::vector<int> offset(ncf);
+  for (size_t k = 0; k < ncf; ++k) {
+    triangulation.parent_of(triangulation.level, k, parent[k], offset[k]);
+    if (parent[k] >= ncc) throw std::logic_error("attach_nested_levels: parent cell out of range");
+  }
+  CsrTransfer Pp, Rp, Pu, Ru;
+  nested_prolongation(dim, 1, dofs.cell_pnodes.data(), ncf, dofs.n_pnodes, c->dofs.cell_pnodes.data(), c->dofs.n_pnodes, parent, offset, Pp);
+  transpose_transfer(Pp, Rp);
+  nested_prolongation(dim, dofs.kv, dofs.cell_unodes.data(), ncf, dofs.n_unodes, c->dofs.cell_unodes.data(), c->dofs.n_unodes, parent, offset, Pu);
+  transpose_transfer(Pu, Ru);
+  const std::vector<int32_t> inj = nested_injection(dim, dofs.kv, dofs.cell_unodes.data(), ncf, c->dofs.cell_unodes.data(), ncc,
+                                                    c->dofs.n_unodes, parent, offset);
+  ifem_mg_transfer t{};
+  t.n_fine_p_owned = Pp.n_rows; t.n_coarse_p_local = Pp.n_cols;
+  t.pp_ptr = Pp.ptr.data(); t.pp_col = Pp.col.data(); t.pp_w = Pp.w.data();
+  t.rp_ptr = Rp.ptr.data(); t.rp_col = Rp.col.data(); t.rp_w = Rp.w.data();
+  t.n_fine_u_owned = Pu.n_rows; t.n_coarse_u_local = Pu.n_cols;
+  t.pu_ptr = Pu.ptr.data(); t.pu_col = Pu.col.data(); t.pu_w = Pu.w.data();
+  t.ru_ptr = Ru.ptr.data(); t.ru_col = Ru.col.data(); t.ru_w = Ru.w.data();
+  t.inj_u = inj.data();
+  check(ifem_mg_attach(ctx, c->ctx, &t), "attach_nested_levels");
   mg_coarse = std::move(c);
   return true;
 }

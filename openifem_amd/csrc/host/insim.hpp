@@ -132,6 +132,7 @@ protected:
   virtual std::unique_ptr<FluidSolver<dim>> make_level_solver(Triangulation<dim> &) const { return nullptr; }
   // builds the next coarser level (recursively the whole chain) and attaches it; false when there is none
   bool attach_multigrid_levels();
+  bool attach_nested_levels(); // unstructured meshes with a refinement history (cylinder under refine_global), single rank
   std::unique_ptr<Triangulation<dim>> mg_tria;        // declared before mg_coarse: destroyed after it
   std::unique_ptr<FluidSolver<dim>> mg_coarse;        // the next coarser level (its context borrows this one's stream)
   // refine_mesh (mpi_fluid_solver.cpp:418-488, called from run_one_step when time_to_refine() fires in a pure-fluid run,

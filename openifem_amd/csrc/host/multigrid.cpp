@@ -179,4 +179,82 @@ std::vector<int32_t> box_injection(int dim, const std::array<int, 3> &reps_f, co
   return out;
 }
 
+void nested_prolongation(int dim, int degree, const int32_t *cnf, size_t ncf, int64_t n_fine, const int32_t *cnc, int64_t n_coarse,
+                         const std::vector<size_t> &parent, const std::vector<int> &offset, CsrTransfer &P) {
+  const int n1 = degree + 1;
+  int nn = 1;
+  for (int d = 0; d < dim; ++d) nn *= n1;
+  // one (cell, local index) per fine node: the first cell that holds it
+  std::vector<int64_t> where((size_t)n_fine, -1);
+  for (size_t c = 0; c < ncf; ++c)
+    for (int a = 0; a < nn; ++a) {
+      int64_t &w = where[(size_t)cnf[c * nn + a]];
+      if (w < 0) w = int64_t(c) * nn + a;
+    }
+  P.n_rows = n_fine; P.n_cols = n_coarse;
+  P.ptr.assign((size_t)n_fine + 1, 0);
+  P.col.clear(); P.w.clear();
+  std::vector<std::pair<int32_t, double>> row;
+  for (int64_t i = 0; i < n_fine; ++i) {
+    if (where[(size_t)i] < 0) throw std::runtime_error("nested_prolongation: a fine node belongs to no cell");
+    const size_t c = size_t(where[(size_t)i] / nn);
+    const int a = int(where[(size_t)i] % nn);
+    double w1[3][4];
+    for (int d = 0; d < dim; ++d) {
+      const int l = d == 0 ? a % n1 : (d == 1 ? (a / n1) % n1 : a / (n1 * n1));
+      const double t = (double((offset[c] >> d) & 1) + double(l) / degree) / 2.0; // position in the parent's reference cell
+      for (int q = 0; q <= degree; ++q) {
+        double la = 1.0;
+        for (int b = 0; b <= degree; ++b)
+          if (b != q) la *= (t - double(b) / degree) / (double(q) / degree - double(b) / degree);
+        w1[d][q] = la;
+      }
+    }
+    row.clear();
+    for (int q = 0; q < nn; ++q) {
+      double w = 1.0;
+      for (int d = 0; d < dim; ++d) w *= w1[d][d == 0 ? q % n1 : (d == 1 ? (q / n1) % n1 : q / (n1 * n1))];
+      if (std::fabs(w) < 1e-14) continue;
+      row.emplace_back(cnc[parent[c] * nn + q], w);
+    }
+    std::sort(row.begin(), row.end());
+    for (auto &e : row) { P.col.push_back(e.first); P.w.push_back(e.second); }
+    P.ptr[(size_t)i + 1] = (int64_t)P.col.size();
+  }
+}
+
+std::vector<int32_t> nested_injection(int dim, int degree, const int32_t *cnf, size_t ncf, const int32_t *cnc, size_t ncc,
+                                      int64_t n_coarse, const std::vector<size_t> &parent, const std::vector<int> &offset) {
+  if (degree != 1 && degree != 2) throw std::invalid_argument("nested_injection: degree 1 or 2");
+  const int n1 = degree + 1;
+  int nn = 1;
+  for (int d = 0; d < dim; ++d) nn *= n1;
+  const int nch = 1 << dim;
+  std::vector<size_t> child(ncc * nch, size_t(-1));
+  for (size_t c = 0; c < ncf; ++c) child[parent[c] * nch + offset[c]] = c;
+  std::vector<int32_t> out((size_t)n_coarse, -1);
+  for (size_t K = 0; K < ncc; ++K)
+    for (int q = 0; q < nn; ++q) {
+      const int32_t nd = cnc[K * nn + q];
+      if (out[(size_t)nd] >= 0) continue;
+      int off = 0, af = 0, stride = 1;
+      for (int d = 0; d < dim; ++d) {
+        const int l = d == 0 ? q % n1 : (d == 1 ? (q / n1) % n1 : q / (n1 * n1));
+        // coarse reference position l / degree in {0, 1/2, 1} (degree 2) or {0, 1} (degree 1): child and position in the child
+        const int twice = 2 * l;                       // position in units of 1 / (2 degree)
+        const int o = twice >= 2 * degree ? 1 : (twice > degree ? 1 : 0);
+        const int lf = twice - o * degree;             // in units of 1 / degree of the child
+        off |= o << d;
+        af += lf * stride;
+        stride *= n1;
+      }
+      const size_t cf = child[K * nch + off];
+      if (cf == size_t(-1)) throw std::runtime_error("nested_injection: a coarse cell misses a child");
+      out[(size_t)nd] = cnf[cf * nn + af];
+    }
+  for (int64_t i = 0; i < n_coarse; ++i)
+    if (out[(size_t)i] < 0) throw std::runtime_error("nested_injection: a coarse node belongs to no cell");
+  return out;
+}
+
 } // namespace ifem_host

@@ -39,4 +39,17 @@ std::vector<int32_t> box_injection(int dim, const std::array<int, 3> &reps_fine,
                                    int degree, const int64_t *l2g_coarse, int64_t n_coarse, const int64_t *l2g_fine,
                                    int64_t n_fine);
 
+// Nodal transfers between two levels of a globally refined unstructured mesh (the cylinder benchmark under refine_global,
+// source/utilities.cpp:345-570): row i = fine node i, interpolated from the Q_degree shape functions of the PARENT of a fine cell
+// that holds it, at the node's position in the parent's reference cell ((child offset + reference position in the child) / 2 --
+// the transfer deal.II's MGTransfer builds from cell->child(i); curved patches move the nodes, not the reference positions).
+// cell_nodes_* : [cells][n1^dim] tensor-lexicographic local order; parent[c] / offset[c] of every fine cell.
+void nested_prolongation(int dim, int degree, const int32_t *cell_nodes_fine, size_t n_cells_fine, int64_t n_nodes_fine,
+                         const int32_t *cell_nodes_coarse, int64_t n_nodes_coarse, const std::vector<size_t> &parent,
+                         const std::vector<int> &offset, CsrTransfer &P);
+// for every coarse node the fine node at the same reference point of the refinement tree
+std::vector<int32_t> nested_injection(int dim, int degree, const int32_t *cell_nodes_fine, size_t n_cells_fine,
+                                      const int32_t *cell_nodes_coarse, size_t n_cells_coarse, int64_t n_nodes_coarse,
+                                      const std::vector<size_t> &parent, const std::vector<int> &offset);
+
 } // namespace ifem_host

@@ -70,6 +70,7 @@ def _lib():
     L.ifemx_box_prolongation.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifemx_box_injection.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    L.ifemx_nested_transfer_check.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.ifemx_channel_state.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_double]
     L._ifemx_bound = True
     return L
@@ -399,6 +400,18 @@ def box_prolongation(reps_fine, reps_coarse, degree, l2g_fine, l2g_coarse):
     if rc < 0:
         raise HostError(rc, L.ifemx_last_error().decode())
     return sp.csr_matrix((w, col, ptr), shape=(len(lf), len(lc)))
+
+
+def nested_transfer_check(dim, level, kv):
+    """host/multigrid.cpp::nested_prolongation / nested_injection between the cylinder meshes of refinement `level` and level - 1:
+    (max |row sum - 1|, coarse nodes whose fine twin does not interpolate from them alone, error of a linear function on the
+    straight patches, share of the fine nodes on straight patches)"""
+    L = _lib()
+    out = np.zeros(4)
+    rc = L.ifemx_nested_transfer_check(dim, level, kv, out.ctypes.data_as(C.c_void_p))
+    if rc < 0:
+        raise HostError(rc, L.ifemx_last_error().decode())
+    return tuple(out)
 
 
 def box_injection(reps_fine, reps_coarse, degree, l2g_coarse, l2g_fine):

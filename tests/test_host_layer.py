@@ -452,3 +452,16 @@ def test_locally_refined_box_on_a_strip_partition(dim, kv, reps, band, world):
         mine = set(t["l2g_u"][:t["n_unodes_owned"]].tolist())
         want = sum(1 for c in range(len(cu_g)) if mine & set(cu_g[c].tolist()))
         assert len(q["cells"][0]) == want
+
+
+@pytest.mark.parametrize("dim,level,kv", [(2, 1, 2), (2, 2, 2), (2, 3, 1), (3, 1, 2)])
+def test_nested_transfers_of_the_cylinder_levels(dim, level, kv):
+    """round 4 (missing #3): the multigrid level chain of an unstructured mesh is its refinement history -- the cylinder
+    benchmark mesh under refine_global (source/utilities.cpp:345-570).  The transfers the host mirror builds from the parent-child
+    tables: rows sum to one, the fine twin of a coarse node interpolates from that node alone (injection and prolongation agree),
+    and a linear function is reproduced exactly wherever the refinement keeps the parent's d-linear geometry (every patch but the
+    curved ring around the cylinder)."""
+    from openifem_amd import host
+    rowsum, bad_twins, lin_err, straight = host.nested_transfer_check(dim, level, kv)
+    assert rowsum < 1e-13 and bad_twins == 0 and lin_err < 1e-12
+    assert 0.9 < straight < 1.0
