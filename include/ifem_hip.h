@@ -175,8 +175,10 @@ typedef struct {
   int32_t asm3_cpb;      /* 2: cells (= wavefronts) per workgroup of that kernel (1, 2, 4 or 8) */
   int32_t tpp_milu_permille; /* SCnsIM, ILU(0) of T_pp: 950 (default); 0 plain ILU(0); w in (0, 1000]: relaxed modified ILU, w/1000 of every dropped
                                 fill-in entry is added to the diagonal of its row */
-  int64_t tpp_ilu_order; /* SCnsIM, explicit T_pp: preconditioner of its inner GMRES -- 0 (default) ILU(0) in the natural row order,
-                            level-scheduled; 1 multicolour ILU(0) (a few dozen levels whatever the mesh); -1 Jacobi(T_pp) */
+  int64_t tpp_ilu_order; /* SCnsIM, explicit T_pp: preconditioner of its inner GMRES -- 2 (default): ILU(0), natural row order when its
+                            elimination levels hold >= 1024 rows on average, multicolour otherwise; 0: natural order always (fewest
+                            iterations, O(n^(1/dim)) level-scheduled launches); 1: multicolour always (a few dozen levels whatever
+                            the mesh, ~3 x the iterations); -1 Jacobi(T_pp) */
   int64_t basis_pad;     /* 32*33 doubles of padding between Krylov basis columns (HBM channel spread) */
   int32_t tpp_tri_sweeps; /* SCnsIM, ILU(0) of T_pp: 0 (default) exact level-scheduled triangular solves; k > 0: k Jacobi sweeps per
                              triangular system instead (2 k row-parallel launches whatever the number of levels) */

@@ -103,7 +103,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
 
 void ifem_default_tuning(ifem_tuning *t) {
   t->geo_cache = 1; t->xcd_swizzle = 1; t->asm_skip = 0; t->spmv_lanes = 32; t->sm_lanes = 32; t->mf_f32 = 1;
-  t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->asm3_reserved = 0; t->asm3_cpb = 2; t->tpp_milu_permille = 950; t->tpp_ilu_order = 0; t->basis_pad = 32 * 33; t->tpp_tri_sweeps = 0; t->uu_row_order = 1;
+  t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->asm3_reserved = 0; t->asm3_cpb = 2; t->tpp_milu_permille = 950; t->tpp_ilu_order = 2; t->basis_pad = 32 * 33; t->tpp_tri_sweeps = 0; t->uu_row_order = 1;
 }
 
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
@@ -113,7 +113,7 @@ int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
   for (int v : g)
     if (v != 8 && v != 16 && v != 32 && v != 64) throw Error(IFEM_E_BADPARAM, "lanes per row must be 8, 16, 32 or 64");
   if (t->basis_pad < 0) throw Error(IFEM_E_BADPARAM, "negative size in ifem_tuning");
-  if (t->tpp_ilu_order < -1 || t->tpp_ilu_order > 1) throw Error(IFEM_E_BADPARAM, "tpp_ilu_order must be -1, 0 or 1");
+  if (t->tpp_ilu_order < -1 || t->tpp_ilu_order > 2) throw Error(IFEM_E_BADPARAM, "tpp_ilu_order must be -1, 0, 1 or 2");
   ctx->tune = *t;
   IFEM_API_END
 }

@@ -81,7 +81,14 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   const bool geo_only = assemble_system >= 2; // 3: the same without constraints (pristine blocks)
   if (assemble_system == 2) {
     const int64_t key = ctx->flag_id[use_nonzero ? 1 : 0];
-    if (ctx->geo_valid && ctx->geo_key == key && ctx->tune.geo_cache != 2) return; // still the blocks of this constrained-dof set
+    if (ctx->geo_valid && ctx->geo_key == key && ctx->tune.geo_cache != 2) { // still the blocks of this constrained-dof set
+      if (++ctx->geo_unchanged == 4 && ctx->geo0_valid) { // a multigrid level: its unconstrained copies go the way of the finest level's (below)
+        ctx->B0.release(); ctx->Bt0.release(); ctx->Sm0.release();
+        ctx->geo0_valid = false; ctx->sm0_valid = false;
+      }
+      return;
+    }
+    ctx->geo_unchanged = 0;
   } else if (assemble_system == 1)
     ensure_auu_values(ctx);
   if (!assemble_system && !ctx->assembled) throw Error(IFEM_E_BADPARAM, "rhs-only assembly before any matrix assembly");
@@ -101,6 +108,16 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   // them) and integrates A_uu and the right-hand side only.  ifem_tuning::geo_cache = 0 switches it off.
   const int64_t geo_key = ctx->flag_id[use_nonzero ? 1 : 0];
   bool skip_geo = ctx->tune.geo_cache == 1 && assemble_system && assemble_system != 3 && ctx->geo_valid && ctx->geo_key == geo_key;
+  // the unconstrained copies of B / B^T / S_m (19 + 4 GB at 128^3) only serve a CHANGE of the constrained-dof set (FSI steps): a run
+  // whose set has stood still for a few assemblies (pure-fluid runs: for ever) gives them back; a later change re-integrates them
+  // once (one geometry-only launch)
+  if (assemble_system == 1) {
+    ctx->geo_unchanged = skip_geo ? ctx->geo_unchanged + 1 : 0;
+    if (ctx->geo_unchanged == 4 && ctx->geo0_valid) {
+      ctx->B0.release(); ctx->Bt0.release(); ctx->Sm0.release();
+      ctx->geo0_valid = false; ctx->sm0_valid = false;
+    }
+  }
   // A NEW constrained-dof set (every FSI step): the blocks are masked copies of the unconstrained ones, which are integrated
   // once per mesh (one geometry-only launch of the cell kernel without constraints); M_p and diag(M_u) do not depend on
   // the set at all.  Same values as re-integrating them under the new set (the kept entries are the same sums).

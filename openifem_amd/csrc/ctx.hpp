@@ -171,7 +171,7 @@ struct TppIlu {
   double pivot_min = 0, pivot_max = 0;
   bool broken = false; // the last factorisation met a zero / non-finite pivot: the caller falls back to Jacobi
   DBuf<unsigned long long> chk; // [3] device: min |pivot|, max |pivot| (bit patterns), non-finite entries
-  int order_kind = 0;
+  int order_kind = 0, order_used = 0; // ifem_tuning::tpp_ilu_order the analysis was made for; the order it chose (0 natural, 1 multicolour)
 };
 // hanging-node constraint lines x[dof_i] = sum_k w_k x[master_k] (closed), see hanging.hip
 struct Hanging {
@@ -292,6 +292,7 @@ struct ifem_ctx {
   // constrained-dof set are masked copies of them instead of a re-integration (M_p and diag(M_u) do not depend on the set)
   ifem::DBuf<double> B0, Bt0;
   bool geo0_valid = false;
+  int geo_unchanged = 0; // consecutive full assemblies that kept the cached blocks (assemble.hip: the copies are released at 4)
   // S_m of the unconstrained blocks (same mesh-only idea): a constrained-dof set only changes the rows whose B row touches a
   // constrained dof, so S_m of a new set = this copy with those rows recomputed (linalg.hip::schur_numeric)
   ifem::DBuf<double> Sm0;

@@ -385,7 +385,8 @@ bool tpp_ilu_factor(ifem_ctx *ctx) {
   if (n == 0) return true;
   if (I.factored) return !I.broken;
   hipStream_t s = ctx->stream;
-  const int order_kind = ctx->tune.tpp_ilu_order == 1 ? 1 : 0;
+  // 2 (default): natural order where its levels are wide enough to fill the device, multicolour otherwise (below)
+  const int order_kind = ctx->tune.tpp_ilu_order >= 2 ? 2 : (ctx->tune.tpp_ilu_order == 1 ? 1 : 0);
   if (!I.analysed || I.order_kind != order_kind) { // once per pattern: the elimination DAG on the host
     std::vector<int64_t> rp((size_t)n + 1);
     std::vector<int32_t> col((size_t)Pt.nnzb);
@@ -393,7 +394,17 @@ bool tpp_ilu_factor(ifem_ctx *ctx) {
     IFEM_HIP_CHECK(hipMemcpyAsync(col.data(), Pt.col.p, col.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     IFEM_HIP_CHECK(hipStreamSynchronize(s));
     IluHost H;
-    ilu_analyse(rp, col, order_kind, H);
+    ilu_analyse(rp, col, order_kind == 1 ? 1 : 0, H);
+    if (order_kind == 2) {
+      // The natural order preconditions better (cylinder refined once more: 49 against 154 inner iterations per application) but
+      // its elimination DAG has O(n^(1/dim)) levels: below ~1000 rows per level the triangular sweeps are launch- and
+      // barrier-bound and the multicolour order wins on the clock by 4-7 x (profiles/r03_tpp_ilu_sweep.txt: 0.17 / 0.64 / 4.5 s
+      // against 0.69 / 4.1 / 17 s per solve at 36 k / 6 k / 24 k rows; profiles/r04_ilu_order.txt: 22 against 159 ms per time step
+      // of tests/fluid_body_force_mpi)
+      const int64_t levels = (int64_t)H.lvl_f.size() - 1;
+      if (levels > 0 && n / levels < 1024) { H = IluHost(); ilu_analyse(rp, col, 1, H); I.order_used = 1; }
+      else I.order_used = 0;
+    } else I.order_used = order_kind;
     I.ent.upload(H.ent.data(), H.ent.size(), s);
     I.n_low.upload(H.n_low.data(), H.n_low.size(), s);
     I.diag.upload(H.diag.data(), H.diag.size(), s);

@@ -146,18 +146,20 @@ def _inner_per_application(ctx, P, use_nonzero=True):
 
 def test_cylinder_scnsim_refined_once_more_converges_without_a_dense_factorisation():
     """24 k pressure rows (round 2 capped the exact dense solve at 12 288 and fell back to Jacobi beyond: 1777 inner
-    iterations per application on this mesh, gpurun_out/r03e/tpp_cyl4.log).  Default = natural order + relaxed modified
-    ILU(0) (omega 0.95): < 50; the multicolour order needs ~3x the iterations at a tenth of the launches"""
+    iterations per application on this mesh, gpurun_out/r03e/tpp_cyl4.log).  Natural order + relaxed modified ILU(0) (omega 0.95):
+    < 50; the multicolour order needs ~3x the iterations at a tenth of the launches -- and a quarter of the time
+    (profiles/r03_tpp_ilu_sweep.txt), which is why the default (tpp_ilu_order 2) picks it while the natural order's levels are
+    narrow (here: a few dozen rows per level)"""
     capi = _capi()
     m, dofs, vals = _cylinder(4)  # one level beyond tests/fluid_cylinder_mpi_scnsim
     assert m.n_pnodes > 12288
     P = capi.make_scns_params(mu=1.8e-4, rho=1.3e-3, dt=1e-2)
     out = {}
-    for kind, milu in ((0, None), (1, 0)):
+    for kind, milu in ((0, None), (1, 0), (2, None)):
         ctx = _ctx(m)
         t = capi.Tuning()
         ctx.L.ifem_default_tuning(C.byref(t))
-        assert (t.tpp_ilu_order, t.tpp_milu_permille) == (0, 950)
+        assert (t.tpp_ilu_order, t.tpp_milu_permille) == (2, 950)
         t.tpp_ilu_order = kind
         if milu is not None:
             t.tpp_milu_permille = milu
@@ -165,10 +167,11 @@ def test_cylinder_scnsim_refined_once_more_converges_without_a_dense_factorisati
         ctx.set_constraints(0, dofs, None)
         ctx.set_constraints(1, dofs, vals)
         per, st = _inner_per_application(ctx, P)
-        out[kind] = (per, st.fgmres_iters)
+        out[kind] = (per, st.fgmres_iters, st.t_total_ms)
         ctx.close()
     assert out[0][0] < 50, out
     assert out[1][0] < 200 and abs(out[0][1] - out[1][1]) <= 2, out
+    assert out[2][0] < 200 and out[2][2] < 0.6 * out[0][2], out  # the default took the multicolour order and is faster for it
 
 
 def test_box3d_q1q1_32_scnsim_converges_in_under_50_inner_iterations():
@@ -180,7 +183,7 @@ def test_box3d_q1q1_32_scnsim_converges_in_under_50_inner_iterations():
     ctx.set_constraints(0, dofs, None)
     ctx.set_constraints(1, dofs, vals)
     per, st = _inner_per_application(ctx, capi.make_scns_params(mu=1.8e-4, rho=1.3e-3, dt=1e-2))
-    assert per < 50, (per, st.fgmres_iters, st.inner_iters)
+    assert per < 50, (per, st.fgmres_iters, st.inner_iters)  # (370 rows per natural-order level: the default takes the multicolour order, 19-25)
     ctx.close()
 
 
