@@ -67,43 +67,74 @@ __device__ inline void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int DIM, int N1, typename R>
-struct MfCell { // per-cell LDS scratch
+// LDS layout of the nodal / quadrature-point fields of a cell.  The pencil passes touch, per instruction, one entry of every
+// (pencil, component) pair with one index fixed; the quadrature-point stage one entry per point with the component fixed.  On 3D
+// Q2 the compact layout (component * 27 + i + 3 j + 9 k) puts two lanes of a 32-lane group on one bank in two of the three pass
+// directions (29 % of the LDS cycles of rounds 1-3 were conflict cycles, and the LDS array is this kernel's busiest unit).  Entries
+// that share a bank must differ in all four indices (i, j, k, component): the cosets of (1,1,1,1) in Z_3^4 are such sets, so entry
+// (c; i,j,k) goes to row c (32 entries) at column (i-c) + 3 (j-c) + 9 (k-c), differences mod 3 -- every access pattern of the kernel
+// is conflict-free.  Other element types keep the compact layout.
+template <int DIM, int N1>
+struct MfLay {
   static constexpr int NN = MfGeo<DIM, N1>::NN;
-  R V[2 * DIM * NN];  // nodal values -> values at the Gauss points -> integrand -> nodal result, in place
-  R G[2 * DIM * NN];  // one reference-gradient direction at a time
-  R C[8 * DIM];       // monomial coefficients of the d-linear map
-  R X[(1 << DIM) * DIM];
-  int32_t node[NN];
-  uint8_t flag[NN * DIM + 3];
+  static constexpr bool SWZ = DIM == 3 && N1 == 3;
+  static constexpr int CS = SWZ ? 32 : NN; // entries per component
+  static constexpr int SZ = DIM * CS;
+  __device__ static int rot(int x) { return x < 0 ? x + N1 : x; }
+  __device__ static int off(int c, int i0, int i1, int i2) {
+    if constexpr (SWZ) return CS * c + rot(i0 - c) + 3 * rot(i1 - c) + 9 * rot(i2 - c);
+    else return CS * c + i0 + N1 * i1 + N1 * N1 * i2;
+  }
 };
 
-// CONV = false: the evaluation point is zero (InsIMEX matrix: no convective / Newton terms) -- the second field group is
-// neither gathered nor interpolated
+// NF fields per entry: the increment x and (CONV) the evaluation point u side by side, so that one ds_read_b64 (same LDS cycles as
+// a ds_read_b32) fetches both
+template <typename R, int NF>
+struct alignas(sizeof(R) * NF) MfVal { R f[NF]; };
+
+template <int DIM, int N1, typename R, int NF>
+struct alignas(16) MfCell { // per-cell LDS scratch
+  static constexpr int SZ = MfLay<DIM, N1>::SZ;
+  MfVal<R, NF> V[SZ]; // nodal values -> values at the Gauss points; then, as R[SZ] over its head, integrand -> nodal result
+  MfVal<R, NF> G[SZ]; // one reference-gradient direction at a time; R[SZ] over its head in the transposed passes
+  R C[8 * DIM];       // [e][k]: monomial coefficients of the d-linear map
+  R X[(1 << DIM) * DIM];
+};
+
+// CONV = false: the evaluation point is zero (InsIMEX matrix: no convective / Newton terms) -- the second field is neither gathered
+// nor interpolated
 template <int DIM, int KV, int WPB, bool CONV, typename R, typename XT>
 __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R, XT> A) {
-  constexpr int N1 = KV + 1, NN = MfGeo<DIM, N1>::NN, NV = 1 << DIM;
+  constexpr int N1 = KV + 1, NN = MfGeo<DIM, N1>::NN, NV = 1 << DIM, NF = CONV ? 2 : 1;
   constexpr int NP = NN / N1;        // pencils per field and direction
-  constexpr int NPL = DIM * NP;      // pencil lanes per round (one field group of DIM components)
-  __shared__ MfCell<DIM, N1, R> SS[2 * WPB];
+  constexpr int NPL = DIM * NP;      // pencil lanes (one per pencil and component)
+  using Lay = MfLay<DIM, N1>;
+  using Val = MfVal<R, NF>;
+  __shared__ MfCell<DIM, N1, R, NF> SS[2 * WPB];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
-  MfCell<DIM, N1, R> &S = SS[2 * wave + half];
+  MfCell<DIM, N1, R, NF> &S = SS[2 * wave + half];
+  R *const Vs = reinterpret_cast<R *>(S.V), *const Gs = reinterpret_cast<R *>(S.G); // single-field views (transposed passes)
   // ---- per-lane roles (fixed for the life of the wave)
   const bool pen_lane = hl < NPL;
   const int comp = pen_lane ? hl / NP : 0, pen = pen_lane ? hl % NP : 0;
-  int pbase[DIM], pstride[DIM];
-  if constexpr (DIM == 3) {
+  int padr[DIM][N1]; // entry of point i of this lane's pencil in direction d
+  {
     const int a = pen % N1, b = pen / N1;
-    pbase[0] = N1 * a + N1 * N1 * b; pstride[0] = 1;
-    pbase[1] = a + N1 * N1 * b;      pstride[1] = N1;
-    pbase[2] = a + N1 * b;           pstride[2] = N1 * N1;
-  } else {
-    pbase[0] = N1 * pen; pstride[0] = 1;
-    pbase[1] = pen;      pstride[1] = N1;
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      if constexpr (DIM == 3) {
+        padr[0][i] = Lay::off(comp, i, a, b); padr[1][i] = Lay::off(comp, a, i, b); padr[2][i] = Lay::off(comp, a, b, i);
+      } else {
+        padr[0][i] = Lay::off(comp, i, pen, 0); padr[1][i] = Lay::off(comp, pen, i, 0);
+      }
+    }
   }
   const bool q_lane = hl < NN;
   const int q = q_lane ? hl : 0;
   const int qi[3] = {q % N1, (q / N1) % N1, q / (N1 * N1)};
+  int qoff[DIM]; // entry of node / quadrature point q, component c
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) qoff[c] = Lay::off(c, qi[0], qi[1], DIM == 3 ? qi[2] : 0);
   R xi[3] = {0, 0, 0}, wq = 1;
 #pragma unroll
   for (int d = 0; d < DIM; ++d) {
@@ -126,10 +157,9 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R, XT> A) {
   const int64_t p_first = vb * per_block + wave;
   // 32-bit index arithmetic in the prefetch (cells * nodes-per-cell and dim * nodes are below 2^31 by the int32 node ids)
   auto cell_of = [&](int64_t pr) { const int64_t c = A.first_cell + 2 * pr + half; return (pr < p_end && c < A.n_cells) ? uint32_t(c) : 0u; };
-  struct Pre { int32_t nd; XT x[DIM]; double u[DIM], vc; uint8_t f[DIM]; } pre;
+  struct Pre { XT x[DIM]; double u[DIM], vc; uint8_t f[DIM]; } pre;
   auto load_id = [&](int64_t pr) -> int32_t { return q_lane ? A.cell_unodes[cell_of(pr) * uint32_t(NN) + uint32_t(hl)] : 0; };
   auto load_vals = [&](int64_t pr, int32_t nd, Pre &o) {
-    o.nd = nd;
     if (q_lane) {
 #pragma unroll
       for (int c = 0; c < DIM; ++c) {
@@ -151,13 +181,12 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R, XT> A) {
     const int32_t nd_next = nd_ahead;
     nd_ahead = load_id(pair + 2 * WPB);
     if (q_lane) {
-      S.node[hl] = cur.nd;
 #pragma unroll
       for (int c = 0; c < DIM; ++c) {
-        const bool con = cur.f[c] != 0;
-        S.flag[hl * DIM + c] = con;
-        S.V[c * NN + hl] = con ? R(0) : R(cur.x[c]);
-        if constexpr (CONV) S.V[(DIM + c) * NN + hl] = R(cur.u[c]);
+        Val v;
+        v.f[0] = cur.f[c] != 0 ? R(0) : R(cur.x[c]);
+        if constexpr (CONV) v.f[1] = R(cur.u[c]);
+        S.V[qoff[c]] = v;
       }
     }
     if (hl < NV * DIM) S.X[hl] = R(cur.vc);
@@ -173,25 +202,26 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R, XT> A) {
         const R xv = S.X[v * DIM + e];
         acc += sub ? (par ? -xv : xv) : R(0);
       }
-      S.C[k * DIM + e] = acc;
+      S.C[e * 8 + k] = acc;
     }
-    // ---- nodal values -> Gauss points (x fields in round 0, evaluation-point fields in round 1), in place
+    // ---- nodal values -> Gauss points (both fields of an entry at once), in place
     if (pen_lane) {
 #pragma unroll
       for (int d = 0; d < DIM; ++d) {
+        Val in[N1];
 #pragma unroll
-        for (int r = 0; r < (CONV ? 2 : 1); ++r) {
-          R *b = S.V + (r * DIM + comp) * NN + pbase[d];
-          R in[N1];
+        for (int i = 0; i < N1; ++i) in[i] = S.V[padr[d][i]];
 #pragma unroll
-          for (int i = 0; i < N1; ++i) in[i] = b[i * pstride[d]];
+        for (int o = 0; o < N1; ++o) {
+          Val acc;
 #pragma unroll
-          for (int o = 0; o < N1; ++o) {
-            R acc = 0;
+          for (int r = 0; r < NF; ++r) {
+            R s = 0;
 #pragma unroll
-            for (int i = 0; i < N1; ++i) acc += A.t.N[o * N1 + i] * in[i];
-            b[o * pstride[d]] = acc;
+            for (int i = 0; i < N1; ++i) s += A.t.N[o * N1 + i] * in[i].f[r];
+            acc.f[r] = s;
           }
+          S.V[padr[d][o]] = acc;
         }
         wsync();
       }
@@ -207,16 +237,16 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R, XT> A) {
         const R e_ = xi[1], z_ = xi[2], x_ = xi[0];
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-          const R c1 = S.C[1 * 3 + e], c2 = S.C[2 * 3 + e], c3 = S.C[3 * 3 + e], c4 = S.C[4 * 3 + e],
-                       c5 = S.C[5 * 3 + e], c6 = S.C[6 * 3 + e], c7 = S.C[7 * 3 + e];
-          J[e * 3 + 0] = c1 + c3 * e_ + c5 * z_ + c7 * (e_ * z_);
-          J[e * 3 + 1] = c2 + c3 * x_ + c6 * z_ + c7 * (x_ * z_);
-          J[e * 3 + 2] = c4 + c5 * x_ + c6 * e_ + c7 * (x_ * e_);
+          typedef R R4 __attribute__((ext_vector_type(4)));
+          const R4 lo = *reinterpret_cast<const R4 *>(&S.C[e * 8]), hi = *reinterpret_cast<const R4 *>(&S.C[e * 8 + 4]); // wave-uniform addresses: wide broadcast reads
+          J[e * 3 + 0] = lo[1] + lo[3] * e_ + hi[1] * z_ + hi[3] * (e_ * z_);
+          J[e * 3 + 1] = lo[2] + lo[3] * x_ + hi[2] * z_ + hi[3] * (x_ * z_);
+          J[e * 3 + 2] = hi[0] + hi[1] * x_ + hi[2] * e_ + hi[3] * (x_ * e_);
         }
       } else {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const R c1 = S.C[1 * 2 + e], c2 = S.C[2 * 2 + e], c3 = S.C[3 * 2 + e];
+          const R c1 = S.C[e * 8 + 1], c2 = S.C[e * 8 + 2], c3 = S.C[e * 8 + 3];
           J[e * 2 + 0] = c1 + c3 * xi[1];
           J[e * 2 + 1] = c2 + c3 * xi[0];
         }
@@ -245,32 +275,32 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R, XT> A) {
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
       if (pen_lane) {
+        Val in[N1];
 #pragma unroll
-        for (int r = 0; r < (CONV ? 2 : 1); ++r) {
-          const int off = (r * DIM + comp) * NN + pbase[d];
-          R in[N1];
+        for (int i = 0; i < N1; ++i) in[i] = S.V[padr[d][i]];
 #pragma unroll
-          for (int i = 0; i < N1; ++i) in[i] = S.V[off + i * pstride[d]];
+        for (int o = 0; o < N1; ++o) {
+          Val acc;
 #pragma unroll
-          for (int o = 0; o < N1; ++o) {
-            R acc = 0;
+          for (int r = 0; r < NF; ++r) {
+            R s = 0;
 #pragma unroll
-            for (int i = 0; i < N1; ++i) acc += A.t.D[o * N1 + i] * in[i];
-            S.G[off + o * pstride[d]] = acc;
+            for (int i = 0; i < N1; ++i) s += A.t.D[o * N1 + i] * in[i].f[r];
+            acc.f[r] = s;
           }
+          S.G[padr[d][o]] = acc;
         }
       }
       wsync();
       if (q_lane) {
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
-          const R rx = S.G[c * NN + q];
+          const Val g = S.G[qoff[c]];
 #pragma unroll
-          for (int e = 0; e < DIM; ++e) gx[c][e] += Ji[d * DIM + e] * rx;
+          for (int e = 0; e < DIM; ++e) gx[c][e] += Ji[d * DIM + e] * g.f[0];
           if constexpr (CONV) {
-            const R ru = S.G[(DIM + c) * NN + q];
 #pragma unroll
-            for (int e = 0; e < DIM; ++e) gu[c][e] += Ji[d * DIM + e] * ru;
+            for (int e = 0; e < DIM; ++e) gu[c][e] += Ji[d * DIM + e] * g.f[1];
           }
         }
       }
@@ -281,16 +311,17 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R, XT> A) {
     if (q_lane) {
       R xq[DIM], uq[DIM];
 #pragma unroll
-      for (int c = 0; c < DIM; ++c) { xq[c] = S.V[c * NN + q]; uq[c] = CONV ? S.V[(DIM + c) * NN + q] : R(0); }
+      for (int c = 0; c < DIM; ++c) { const Val v = S.V[qoff[c]]; xq[c] = v.f[0]; uq[c] = CONV ? v.f[NF - 1] : R(0); }
       R divx = 0;
 #pragma unroll
       for (int c = 0; c < DIM; ++c) divx += gx[c][c];
+      R mass[DIM];
 #pragma unroll
       for (int c = 0; c < DIM; ++c) {
         R conv = 0, newt = 0;
 #pragma unroll
         for (int e = 0; e < DIM; ++e) { conv += uq[e] * gx[c][e]; newt += xq[e] * gu[c][e]; }
-        S.V[c * NN + q] = JxW * A.rho * (conv + A.inv_dt * xq[c] + newt);
+        mass[c] = JxW * A.rho * (conv + A.inv_dt * xq[c] + newt);
         R tp[DIM];
 #pragma unroll
         for (int e = 0; e < DIM; ++e) tp[e] = JxW * (A.mu * gx[c][e] + (e == c ? A.gamma * A.rho * divx : R(0)));
@@ -302,6 +333,10 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R, XT> A) {
           That[c][d] = t;
         }
       }
+      // the integrand goes to the single-field view over the head of V: every paired value of the wave has been read above
+      // (the LDS executes one wave's operations in order)
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) Vs[qoff[c]] = mass[c];
     }
     // ---- the next cell's values: their latency hides behind the transposed passes below
     load_vals(pair + WPB, nd_next, pre);
@@ -310,20 +345,19 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R, XT> A) {
     for (int d = 0; d < DIM; ++d) {
       if (q_lane) {
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) S.G[c * NN + q] = That[c][d];
+        for (int c = 0; c < DIM; ++c) Gs[qoff[c]] = That[c][d];
       }
       wsync();
       if (pen_lane) {
-        const int off = comp * NN + pbase[d];
         R t[N1];
 #pragma unroll
-        for (int i = 0; i < N1; ++i) t[i] = S.G[off + i * pstride[d]];
+        for (int i = 0; i < N1; ++i) t[i] = Gs[padr[d][i]];
 #pragma unroll
         for (int o = 0; o < N1; ++o) {
-          R acc = S.V[off + o * pstride[d]];
+          R acc = Vs[padr[d][o]];
 #pragma unroll
           for (int i = 0; i < N1; ++i) acc += A.t.D[i * N1 + o] * t[i];
-          S.V[off + o * pstride[d]] = acc;
+          Vs[padr[d][o]] = acc;
         }
       }
       wsync();
@@ -332,29 +366,24 @@ __global__ __launch_bounds__(64 * WPB) void k_apply_uu_mf2(MfArgsT<R, XT> A) {
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
       if (pen_lane) {
-        R *b = S.V + comp * NN + pbase[d];
         R in[N1];
 #pragma unroll
-        for (int i = 0; i < N1; ++i) in[i] = b[i * pstride[d]];
+        for (int i = 0; i < N1; ++i) in[i] = Vs[padr[d][i]];
 #pragma unroll
         for (int o = 0; o < N1; ++o) {
           R acc = 0;
 #pragma unroll
           for (int i = 0; i < N1; ++i) acc += A.t.N[i * N1 + o] * in[i];
-          b[o * pstride[d]] = acc;
+          Vs[padr[d][o]] = acc;
         }
       }
       wsync();
     }
-    // ---- scatter into owned, unconstrained rows: consecutive lanes hit consecutive doubles of a node
-    // two-stage scatter: coalesced plain stores per cell, summed per node by k_mf_gather (atomics-free, deterministic)
-    if (active) {
+    // ---- two-stage scatter: plain stores of the cell's result ([node][component]), summed per node by k_mf_gather
+    // (atomics-free, deterministic); the DIM stores of a wave fill the same lines
+    if (active && q_lane) {
 #pragma unroll
-      for (int k = 0; k < (DIM * NN + 31) / 32; ++k) { // unrolled: a loop here makes the compiler drain the prefetch first
-        const int t = hl + 32 * k;
-        const int a = t / DIM, c = t - a * DIM;
-        if (t < DIM * NN) A.ycell[cell * (DIM * NN) + t] = S.V[c * NN + a];
-      }
+      for (int c = 0; c < DIM; ++c) A.ycell[cell * (DIM * NN) + hl * DIM + c] = Vs[qoff[c]];
     }
     wsync();
   }
