@@ -524,7 +524,7 @@ def main():
                        "rccl_nranks": comm["rccl_nranks"], "comm_transport": {0: "none (single rank)", 1: "rccl", 2: "local world"}[comm["transport"]],
                        "halo_neighbors": comm["n_neighbors"], "halo_stream": comm["halo_stream"],
                        "halo_exchanges_per_step": comm["halo_exchanges"] / args.steps, "allreduce_stream_per_step": comm["allreduce_dev"] / args.steps,
-                       "allreduce_host_per_step": comm["allreduce_host"] / args.steps,
+                       "allreduce_host_per_step": comm["allreduce_host"] / args.steps, "allreduce_vector_per_step": comm["allreduce_vec"] / args.steps,
                        "fgmres_iters": last.fgmres_iters, "cg_mp_iters": last.cg_mp_iters,
                        "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "inner_rel_first": args.inner_rel_first, "ainv_kind": args.ainv, "outer_matrix_free": args.outer_mf,
                        "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms,

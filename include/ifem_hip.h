@@ -234,8 +234,11 @@ typedef struct {
   uint64_t halo_exchanges; /* packed send/recv groups (forward and reverse) */
   uint64_t allreduce_dev;  /* all-reduces of device scalars ordered on the stream (no host wait) */
   uint64_t allreduce_host; /* all-reduces the host waited for (Gram-Schmidt coefficients, norms) */
+  uint64_t allreduce_vec;  /* stream-ordered all-reduces of whole level vectors: the hand-over to a replicated coarse level */
 } ifem_comm_stats;
 int ifem_comm_stats_get(ifem_ctx *ctx, ifem_comm_stats *out, int reset);
+/* the same counters of ONE level of the chain (0: ctx itself, k: the k-th context attached below it); `levels` = 1 */
+int ifem_comm_stats_level(ifem_ctx *ctx, int level, ifem_comm_stats *out);
 /* validation transport (see ifem_partition::local_world): nranks contexts of one process on one GPU */
 void *ifem_local_world_create(int nranks);
 void ifem_local_world_destroy(void *world);
@@ -297,7 +300,15 @@ int ifem_halo_exchange(ifem_ctx *ctx, int vec);           /* ghosted-vector assi
  * (per-weight masks rebuilt whenever a constrained-dof set changes) -- a weaker coarse correction inside the preconditioner,
  * the outer operator and its stopping rule are untouched (tests/test_gpu_fsi_caller.py runs InsIM with attached levels under
  * such lines).  The V-cycle of the A_uu block always runs on single-precision level vectors, whatever ifem_tuning::mf_f32 says
- * (that switch selects the cell arithmetic of the inner GMRES's operator only). */
+ * (that switch selects the cell arithmetic of the inner GMRES's operator only).
+ * REPLICATED coarse level (several ranks): `coarse` may be a SINGLE-RANK context of the WHOLE coarse mesh, created with identical
+ * content on every rank, below a partitioned `fine`.  All its nodes are "local": P columns index them directly, R has one row per
+ * coarse node and holds this rank's owned fine columns only -- the ranks' partial restrictions are summed by one stream-ordered
+ * vector all-reduce (ncclAllReduce) per V-cycle instead of a reverse halo exchange, the prolongation needs no exchange, and every
+ * level attached below the replica (ordinary single-rank levels) runs redundantly on every rank without communication.  inj_u[k] = -1
+ * where another rank owns the fine node under coarse node k (the injected evaluation point is summed over the ranks as well).
+ * Meant for the levels whose meshes are too small to be worth a message per smoothing step (the reference has
+ * no counterpart -- MUMPS gathers its coarse fronts the same way). */
 typedef struct {
   int64_t n_fine_p_owned, n_coarse_p_local;
   const int64_t *pp_ptr; const int32_t *pp_col; const double *pp_w; /* CSR of P_p */

@@ -116,7 +116,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof",
            "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag",
            "ifem_fsi_set_solid", "ifem_fsi_update_indicator", "ifem_fsi_find_fluid_bc", "ifem_fsi_get_stress",
-           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_true_residual", "ifem_tpp_ilu_probe", "ifem_tpp_override"]
+           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_comm_stats_level", "ifem_true_residual", "ifem_tpp_ilu_probe", "ifem_tpp_override"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -190,6 +190,7 @@ def load():
     L.ifem_mg_attach.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(MgTransfer)]
     L.ifem_mg_depth.argtypes = [C.c_void_p]
     L.ifem_comm_stats_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ifem_comm_stats_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.ifem_tpp_ilu_probe.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.ifem_tpp_override.argtypes = [C.c_void_p, C.c_void_p]
     L.ifem_true_residual.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -223,7 +224,8 @@ class FsiStats(C.Structure):  # ifem_fsi_stats
 class CommStats(C.Structure):  # ifem_comm_stats
     _fields_ = [("nranks", C.c_int32), ("rank", C.c_int32), ("n_neighbors", C.c_int32), ("transport", C.c_int32),
                 ("rccl_nranks", C.c_int32), ("halo_stream", C.c_int32), ("levels", C.c_int32), ("reserved_", C.c_int32),
-                ("halo_exchanges", C.c_uint64), ("allreduce_dev", C.c_uint64), ("allreduce_host", C.c_uint64)]
+                ("halo_exchanges", C.c_uint64), ("allreduce_dev", C.c_uint64), ("allreduce_host", C.c_uint64),
+                ("allreduce_vec", C.c_uint64)]
 
 
 ABI_STRUCTS = [MeshDesc, Partition, InsParams, SolverOpts, SolveStats, ScnsParams, Timing, Tuning, MgTransfer, FsiSolid, FsiStats,
@@ -237,6 +239,18 @@ def comm_stats(L, ctx, reset=False):
     if rc < 0:
         raise IfemError(rc, L.ifem_last_error().decode())
     return {k: int(getattr(st, k)) for k, _ in CommStats._fields_ if k != "reserved_"}
+
+
+def comm_stats_levels(L, ctx):
+    """ifem_comm_stats_level of every level of the chain below ctx (a list of dicts, level 0 first)"""
+    out = []
+    for k in range(L.ifem_mg_depth(ctx) + 1):
+        st = CommStats()
+        rc = L.ifem_comm_stats_level(ctx, k, C.byref(st))
+        if rc < 0:
+            raise IfemError(rc, L.ifem_last_error().decode())
+        out.append({f: int(getattr(st, f)) for f in ("nranks", "halo_exchanges", "allreduce_dev", "allreduce_host", "allreduce_vec")})
+    return out
 
 
 def make_params(mu=1.0, rho=1.0, gamma=0.1, dt=1e-3, g=(0, 0, 0), neumann=None):

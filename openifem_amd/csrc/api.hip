@@ -186,6 +186,7 @@ void ifem_ctx_destroy(ifem_ctx *ctx) {
   // on those of a level further up) and stay usable by themselves: the chain below gets streams of its own.
   if (ctx->mg_fine && ctx->mg_fine->mg_coarse == ctx) {
     ctx->mg_fine->mg_coarse = nullptr;
+    ctx->mg_fine->mg_replica = false;
     ctx->mg_fine->sm_mg_version = -1;
     ctx->mg_fine->uu_mg_version = -1;
   }
@@ -335,9 +336,12 @@ int ifem_set_hanging_constraints(ifem_ctx *ctx, int32_t n, const int32_t *dof, c
 int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t) {
   IFEM_API_BEGIN
   if (!fine || !coarse || !t || fine == coarse) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: two contexts and a transfer table");
-  if (fine->dim != coarse->dim || fine->kv != coarse->kv || fine->halo.nranks != coarse->halo.nranks ||
-      fine->halo.rank != coarse->halo.rank || fine->device != coarse->device)
-    throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: the levels must share dimension, velocity degree, device, rank and rank count");
+  // a single-rank coarse context below a partitioned fine one: the REPLICATED coarse level (see ifem_hip.h)
+  const bool replica = fine->halo.nranks > 1 && coarse->halo.nranks == 1;
+  if (fine->dim != coarse->dim || fine->kv != coarse->kv || fine->device != coarse->device ||
+      (!replica && (fine->halo.nranks != coarse->halo.nranks || fine->halo.rank != coarse->halo.rank)))
+    throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: the levels must share dimension, velocity degree, device, rank and rank count "
+                                 "(or the coarse context is a single-rank replica of the whole coarse mesh)");
   if (coarse->mg_fine && coarse->mg_fine != fine)
     throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: the coarse context already hangs below another level");
   for (const ifem_ctx *c = coarse; c; c = c->mg_coarse)
@@ -382,7 +386,8 @@ int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t) 
       if (t->ru_col[k] < 0 || t->ru_col[k] >= fine->nUo) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: R_u column out of range");
     }
     for (int64_t i = 0; i < coarse->nUo; ++i)
-      if (t->inj_u[i] < 0 || t->inj_u[i] >= fine->nUo) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: inj_u must name owned fine nodes");
+      if ((t->inj_u[i] < 0 && !(replica && t->inj_u[i] == -1)) || t->inj_u[i] >= fine->nUo)
+        throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: inj_u must name owned fine nodes (-1 below a replicated level: another rank owns the fine node)");
     fine->mg_Pu.n_rows = fine->nUo;
     fine->mg_Pu.ptr.upload(t->pu_ptr, (size_t)fine->nUo + 1, s);
     fine->mg_Pu.col.upload(t->pu_col, (size_t)nu, s);
@@ -396,6 +401,7 @@ int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t) 
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
   if (fine->mg_coarse && fine->mg_coarse != coarse) fine->mg_coarse->mg_fine = nullptr; // re-attach: the old level is on its own
   fine->mg_coarse = coarse;
+  fine->mg_replica = replica;
   coarse->mg_fine = fine;
   fine->sm_mg_version = -1;
   fine->uu_mg_version = -1;
@@ -887,6 +893,19 @@ int ifem_comm_stats_get(ifem_ctx *ctx, ifem_comm_stats *out, int reset) {
   IFEM_API_BEGIN
   if (!out) throw Error(IFEM_E_BADPARAM, "ifem_comm_stats_get: null output");
   ifem::comm_stats(ctx, out, reset != 0);
+  IFEM_API_END
+}
+
+int ifem_comm_stats_level(ifem_ctx *ctx, int level, ifem_comm_stats *out) {
+  IFEM_API_BEGIN
+  if (!out || level < 0) throw Error(IFEM_E_BADPARAM, "ifem_comm_stats_level: an output and a level >= 0");
+  ifem_ctx *c = ctx;
+  for (int k = 0; k < level && c; ++k) c = c->mg_coarse;
+  if (!c) throw Error(IFEM_E_BADPARAM, "ifem_comm_stats_level: the chain has fewer levels");
+  ifem_ctx *below = c->mg_coarse; // count this context alone
+  c->mg_coarse = nullptr;
+  try { ifem::comm_stats(c, out, false); } catch (...) { c->mg_coarse = below; throw; }
+  c->mg_coarse = below;
   IFEM_API_END
 }
 

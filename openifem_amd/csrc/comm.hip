@@ -42,7 +42,8 @@ struct LocalWorld {
   // the peers' send buffers; the peers' streams wait on those events, no host thread waits for the device
   std::vector<hipEvent_t> ev_packed, ev_copied;
   std::vector<const double *> red_ptr; // device scalars of every rank during a stream-ordered all-reduce
-  explicit LocalWorld(int n) : nranks(n), ctx(n, nullptr), red(n), ev_packed(n, nullptr), ev_copied(n, nullptr), red_ptr(n, nullptr) {}
+  std::vector<const void *> red_vec;   // ... and device vectors (hand-over to a replicated coarse level)
+  explicit LocalWorld(int n) : nranks(n), ctx(n, nullptr), red(n), ev_packed(n, nullptr), ev_copied(n, nullptr), red_ptr(n, nullptr), red_vec(n, nullptr) {}
   ~LocalWorld() {
     for (auto e : ev_packed) if (e) (void)hipEventDestroy(e);
     for (auto e : ev_copied) if (e) (void)hipEventDestroy(e);
@@ -495,6 +496,50 @@ void allreduce_sum_dev(ifem_ctx *ctx, double *dev_vals, int n) {
 }
 void allreduce_max(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, host_vals, n, true); }
 
+// ---- vector all-reduce: the hand-over to a replicated coarse level (ifem_mg_attach with a single-rank coarse context).  Every rank
+// holds its partial restriction over ALL coarse nodes; the sum is the restricted residual, identical on every rank (RCCL rings and
+// the rank-ordered sum below both give every rank the same bits, so the replicas stay in step).
+struct PeerVecs { const void *p[kMaxLocalPeers]; };
+template <typename T>
+__global__ void k_sum_peer_vecs(int64_t n, int nranks, PeerVecs pp, T *__restrict__ out) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    T s = 0;
+    for (int r = 0; r < nranks; ++r) s += static_cast<const T *>(pp.p[r])[i];
+    out[i] = s;
+  }
+}
+template <typename T>
+static void allreduce_vec_t(ifem_ctx *ctx, T *dev, int64_t n, T *scratch) {
+  Halo &h = ctx->halo;
+  if (h.nranks == 1 || n <= 0) return;
+  ++h.n_allreduce_vec;
+  if (h.local) {
+    auto *w = static_cast<LocalWorld *>(h.local);
+    if (h.nranks > kMaxLocalPeers) throw Error(IFEM_E_COMM, "local world: a replicated coarse level needs at most 8 virtual ranks");
+    // same protocol as the stream-ordered scalar all-reduce: publish, sum the peers' vectors into scratch once their producers
+    // have run, take the sum over once everybody has read
+    w->red_vec[h.rank] = dev;
+    IFEM_HIP_CHECK(hipEventRecord(w->ev_packed[h.rank], ctx->stream));
+    w->rendezvous();
+    PeerVecs pp{};
+    for (int r = 0; r < h.nranks; ++r) {
+      pp.p[r] = w->red_vec[r];
+      if (r != h.rank) IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_packed[r], 0));
+    }
+    const unsigned g = unsigned(std::min<int64_t>((n + 255) / 256, 4096));
+    hipLaunchKernelGGL((k_sum_peer_vecs<T>), dim3(g), dim3(256), 0, ctx->stream, n, h.nranks, pp, scratch);
+    IFEM_HIP_CHECK(hipEventRecord(w->ev_copied[h.rank], ctx->stream));
+    w->rendezvous();
+    for (int r = 0; r < h.nranks; ++r)
+      if (r != h.rank) IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_copied[r], 0));
+    IFEM_HIP_CHECK(hipMemcpyAsync(dev, scratch, size_t(n) * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+    return;
+  }
+  IFEM_NCCL_CHECK(ncclAllReduce(dev, dev, size_t(n), sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, (ncclComm_t)h.comm, ctx->stream));
+}
+void allreduce_sum_vec(ifem_ctx *ctx, double *dev, int64_t n, double *scratch) { allreduce_vec_t<double>(ctx, dev, n, scratch); }
+void allreduce_sum_vec_f32(ifem_ctx *ctx, float *dev, int64_t n, float *scratch) { allreduce_vec_t<float>(ctx, dev, n, scratch); }
+
 // One-rank RCCL round trip (communicator, all-reduce, grouped send/recv to self) on `device`: checks on a
 // single-GPU box that the library, the RCCL it resolves at run time and the stream semantics fit together.
 int comm_selftest(int device) {
@@ -573,8 +618,9 @@ void comm_stats(ifem_ctx *ctx, ifem_comm_stats *out, bool reset) {
     out->halo_exchanges += h.n_exchanges;
     out->allreduce_dev += h.n_allreduce_dev;
     out->allreduce_host += h.n_allreduce_host;
+    out->allreduce_vec += h.n_allreduce_vec;
     ++out->levels;
-    if (reset) h.n_exchanges = h.n_allreduce_dev = h.n_allreduce_host = 0;
+    if (reset) h.n_exchanges = h.n_allreduce_dev = h.n_allreduce_host = h.n_allreduce_vec = 0;
   }
 }
 

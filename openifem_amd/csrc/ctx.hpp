@@ -154,7 +154,7 @@ struct Halo {
   const void *rev_src = nullptr; // local world only: the extended vector whose ghosts the peers fetch in a reverse exchange
   // counters since the last ifem_comm_stats(reset): halo exchanges (forward + reverse), all-reduces ordered on the stream,
   // all-reduces that made the host wait for the device
-  uint64_t n_exchanges = 0, n_allreduce_dev = 0, n_allreduce_host = 0;
+  uint64_t n_exchanges = 0, n_allreduce_dev = 0, n_allreduce_host = 0, n_allreduce_vec = 0;
 };
 
 } // namespace ifem
@@ -305,6 +305,8 @@ struct ifem_ctx {
   // the S_m V-cycle: 1/diag(S_m), largest eigenvalue of D^-1 S_m, scratch vectors [nPl]
   ifem_ctx *mg_coarse = nullptr;
   ifem_ctx *mg_fine = nullptr; // back link (not owned): the level this context hangs below, whose stream(s) it borrows
+  bool mg_replica = false;     // mg_coarse is a REPLICATED single-rank context of the whole coarse mesh (several ranks here): restrictions are
+                               // summed over the ranks by a vector all-reduce, nothing below this level exchanges anything
   ifem::MgCsr mg_Pp, mg_Rp, mg_Pu, mg_Ru;
   ifem::DBuf<int32_t> mg_inj_u; // [nUo of the coarse level] coincident owned velocity node of this level
   ifem::DBuf<uint8_t> mg_Pu_mask, mg_Ru_mask; // per weight: components dropped by the Dirichlet flags of the two levels

@@ -391,6 +391,15 @@ int ifemx_set_multigrid(void *hv, int on, int min_cells, void *const *level_worl
     if (h->dim == 2) set(*h->s2); else set(*h->s3);
   });
 }
+// FluidSolver::mg_replica_cells: coarse meshes of at most this many cells are replicated on every rank instead of partitioned
+// (0: never).  Before ifemx_setup.
+int ifemx_set_mg_replica_cells(void *hv, int64_t cells) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    if (cells < 0) throw std::invalid_argument("ifemx_set_mg_replica_cells: a count >= 0");
+    if (h->dim == 2) h->s2->mg_replica_cells = cells; else h->s3->mg_replica_cells = cells;
+  });
+}
 // the levels attached below the solver's context: *n_levels, their global repetitions reps[level][3] and contexts (each
 // array may be NULL; room for 16 levels)
 int ifemx_mg_levels(void *hv, int *n_levels, int32_t *reps, void **ctxs) {
@@ -439,6 +448,17 @@ int ifemx_box_injection(int dim, const int *reps_fine, const int *reps_coarse, i
     std::array<int, 3> rf{1, 1, 1}, rc{1, 1, 1};
     for (int d = 0; d < dim; ++d) { rf[d] = reps_fine[d]; rc[d] = reps_coarse[d]; }
     auto inj = box_injection(dim, rf, rc, degree, l2g_coarse, n_coarse, l2g_fine, n_fine);
+    std::memcpy(out, inj.data(), inj.size() * sizeof(int32_t));
+  });
+}
+
+// ... below a replicated coarse level: -1 where the fine node under a coarse node is not in the (owned) fine list
+int ifemx_box_injection_partial(int dim, const int *reps_fine, const int *reps_coarse, int degree, const int64_t *l2g_coarse,
+                                int64_t n_coarse, const int64_t *l2g_fine, int64_t n_fine, int32_t *out) {
+  return guard([&] {
+    std::array<int, 3> rf{1, 1, 1}, rc{1, 1, 1};
+    for (int d = 0; d < dim; ++d) { rf[d] = reps_fine[d]; rc[d] = reps_coarse[d]; }
+    auto inj = box_injection(dim, rf, rc, degree, l2g_coarse, n_coarse, l2g_fine, n_fine, /*allow_missing=*/true);
     std::memcpy(out, inj.data(), inj.size() * sizeof(int32_t));
   });
 }

@@ -58,17 +58,38 @@ bool FluidSolver<dim>::attach_multigrid_levels() {
     n[d] = triangulation.reps[d] / proc_grid[d];
     extent[d] = triangulation.p1[d] - triangulation.p0[d];
   }
-  if (!next_coarser_level(dim, n, proc_grid, extent, mg_min_cells, next)) return false;
-  // validation transport: every level rendezvous in a world of its own, handed in by the caller; none left = chain ends
+  const int nranks = proc_grid[0] * proc_grid[1] * proc_grid[2];
+  bool have_next = next_coarser_level(dim, n, proc_grid, extent, mg_min_cells, next);
+  // several ranks: a small enough coarse mesh is replicated (one single-rank solver of the whole mesh per rank) instead of partitioned
+  bool replica = false;
+  std::array<int, 3> next_global{1, 1, 1};
+  if (nranks > 1 && mg_replica_cells > 0) {
+    bool cand = have_next;
+    if (have_next) {
+      for (int d = 0; d < dim; ++d) next_global[d] = next[d] * proc_grid[d];
+    } else { // the blocks cannot be halved any more: the whole mesh may still be
+      std::array<int, 3> whole{1, 1, 1};
+      for (int d = 0; d < dim; ++d) whole[d] = triangulation.reps[d];
+      cand = next_coarser_level(dim, whole, {1, 1, 1}, extent, mg_min_cells, next_global);
+    }
+    int64_t cells = 1;
+    for (int d = 0; d < dim; ++d) cells *= next_global[d];
+    replica = cand && cells <= mg_replica_cells;
+  }
+  if (!replica && !have_next) return false;
+  // validation transport: every partitioned level rendezvous in a world of its own, handed in by the caller; none left = chain ends
   void *level_world = nullptr;
-  if (local_world) {
+  if (local_world && !replica) {
     if (mg_local_worlds.empty()) return false;
     level_world = mg_local_worlds.front();
   }
   mg_tria.reset(new Triangulation<dim>());
   std::vector<unsigned> reps(dim);
   std::array<double, dim> a, b;
-  for (int d = 0; d < dim; ++d) { reps[d] = (unsigned)(next[d] * proc_grid[d]); a[d] = triangulation.p0[d]; b[d] = triangulation.p1[d]; }
+  for (int d = 0; d < dim; ++d) {
+    reps[d] = (unsigned)(replica ? next_global[d] : next[d] * proc_grid[d]);
+    a[d] = triangulation.p0[d]; b[d] = triangulation.p1[d];
+  }
   GridGenerator::subdivided_hyper_rectangle<dim>(*mg_tria, reps, a, b, triangulation.colorized, /*lazy=*/true);
   std::unique_ptr<FluidSolver<dim>> c = make_level_solver(*mg_tria);
   if (!c) { mg_tria.reset(); return false; }
@@ -78,8 +99,13 @@ bool FluidSolver<dim>::attach_multigrid_levels() {
   c->dofs.morton = dofs.morton;
   c->hard_coded_boundary_values = hard_coded_boundary_values;
   c->field_time = field_time;
-  c->set_partition(proc_grid, part_rank, nccl_id.empty() ? nullptr : nccl_id.data(), level_world);
-  c->mg_local_worlds.assign(mg_local_worlds.begin() + (mg_local_worlds.empty() ? 0 : 1), mg_local_worlds.end());
+  c->mg_replica_cells = mg_replica_cells;
+  if (replica) {
+    c->set_partition({1, 1, 1}, 0, nullptr, nullptr);
+  } else {
+    c->set_partition(proc_grid, part_rank, nccl_id.empty() ? nullptr : nccl_id.data(), level_world);
+    c->mg_local_worlds.assign(mg_local_worlds.begin() + (mg_local_worlds.empty() ? 0 : 1), mg_local_worlds.end());
+  }
   c->setup_dofs();
   c->make_constraints();
   c->initialize_system(); // recursion: attaches the levels below c
@@ -93,7 +119,7 @@ bool FluidSolver<dim>::attach_multigrid_levels() {
   box_prolongation(dim, rf, rc, kv, part.l2g_u.data(), dofs.n_unodes_owned, c->part.l2g_u.data(), c->dofs.n_unodes, Pu);
   transpose_transfer(Pu, Ru);
   const std::vector<int32_t> inj = box_injection(dim, rf, rc, kv, c->part.l2g_u.data(), c->dofs.n_unodes_owned,
-                                                 part.l2g_u.data(), dofs.n_unodes_owned);
+                                                 part.l2g_u.data(), dofs.n_unodes_owned, /*allow_missing=*/replica);
   ifem_mg_transfer t{};
   t.n_fine_p_owned = Pp.n_rows; t.n_coarse_p_local = Pp.n_cols;
   t.pp_ptr = Pp.ptr.data(); t.pp_col = Pp.col.data(); t.pp_w = Pp.w.data();

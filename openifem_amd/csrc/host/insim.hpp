@@ -115,6 +115,10 @@ public:
   // below this context with ifem_mg_attach.  The reference needs none: MUMPS (mpi_insim.cpp:124-127).
   bool multigrid = true;
   int mg_min_cells = 4; // a direction is halved only while it keeps this many cells per rank
+  // several ranks: a coarser level whose WHOLE mesh has at most this many cells is not partitioned but REPLICATED -- a single-rank
+  // solver of the whole coarse mesh on every rank (ifem_mg_attach's replicated coarse level), which then builds its own chain below
+  // it without any communication; 0 keeps every level partitioned
+  int64_t mg_replica_cells = 32768;
   // validation transport only (set_partition with local_world): the worlds of the coarser levels, finest coarse level
   // first -- every level's virtual ranks meet in a world of their own; the chain ends where the list does
   std::vector<void *> mg_local_worlds;

@@ -159,7 +159,7 @@ void transpose_transfer(const CsrTransfer &P, CsrTransfer &R) {
 }
 
 std::vector<int32_t> box_injection(int dim, const std::array<int, 3> &reps_f, const std::array<int, 3> &reps_c, int degree,
-                                   const int64_t *l2g_c, int64_t n_c, const int64_t *l2g_f, int64_t n_f) {
+                                   const int64_t *l2g_c, int64_t n_c, const int64_t *l2g_f, int64_t n_f, bool allow_missing) {
   int64_t Nf[3] = {1, 1, 1}, Nc[3] = {1, 1, 1}, ratio[3] = {1, 1, 1};
   for (int d = 0; d < dim; ++d) {
     Nf[d] = int64_t(degree) * reps_f[d] + 1;
@@ -173,7 +173,7 @@ std::vector<int32_t> box_injection(int dim, const std::array<int, 3> &reps_f, co
     int64_t r = l2g_c[i], c[3];
     for (int d = 0; d < 3; ++d) { c[d] = (r % Nc[d]) * ratio[d]; r /= Nc[d]; }
     const int32_t p = look.find(c);
-    if (p < 0) throw std::runtime_error("multigrid transfer: the fine node under an owned coarse node is not owned by the same rank");
+    if (p < 0 && !allow_missing) throw std::runtime_error("multigrid transfer: the fine node under an owned coarse node is not owned by the same rank");
     out[(size_t)i] = p;
   }
   return out;

@@ -37,7 +37,7 @@ void transpose_transfer(const CsrTransfer &P, CsrTransfer &R);
 // for every given coarse lattice node the position in l2g_fine of the fine node at the same point
 std::vector<int32_t> box_injection(int dim, const std::array<int, 3> &reps_fine, const std::array<int, 3> &reps_coarse,
                                    int degree, const int64_t *l2g_coarse, int64_t n_coarse, const int64_t *l2g_fine,
-                                   int64_t n_fine);
+                                   int64_t n_fine, bool allow_missing = false); // allow_missing: -1 where the fine node is not in the list (replicated coarse level)
 
 // Nodal transfers between two levels of a globally refined unstructured mesh (the cylinder benchmark under refine_global,
 // source/utilities.cpp:345-570): row i = fine node i, interpolated from the Q_degree shape functions of the PARENT of a fine cell

@@ -156,6 +156,9 @@ void v_axpy_f32v(ifem_ctx *ctx, int64_t n, float a, const float *x, float *y);
 void allreduce_sum(ifem_ctx *ctx, double *host_vals, int n);
 void allreduce_max(ifem_ctx *ctx, double *host_vals, int n);
 void allreduce_sum_dev(ifem_ctx *ctx, double *dev_vals, int n); // device scalars, in place, stream-ordered
+// sum of a device VECTOR over the ranks, in place, stream-ordered (the hand-over to a replicated coarse level); scratch: n entries
+void allreduce_sum_vec(ifem_ctx *ctx, double *dev, int64_t n, double *scratch);
+void allreduce_sum_vec_f32(ifem_ctx *ctx, float *dev, int64_t n, float *scratch);
 int comm_unique_id(uint8_t out[128]);
 int comm_selftest(int device);
 void comm_stats(ifem_ctx *ctx, ifem_comm_stats *out, bool reset);

@@ -390,7 +390,7 @@ __global__ void k_mg_inject(int64_t n_nodes, int dim, const int32_t *__restrict_
   for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < n_nodes * dim; t += int64_t(gridDim.x) * blockDim.x) {
     const int64_t i = t / dim;
     const int c = int(t - i * dim);
-    coarse[t] = fine[int64_t(inj[i]) * dim + c];
+    coarse[t] = inj[i] >= 0 ? fine[int64_t(inj[i]) * dim + c] : 0.0; // -1: another rank's node (replicated coarse level: summed over the ranks)
   }
 }
 void mg_inject_nodes(ifem_ctx *ctx, int64_t n_nodes, const int32_t *inj, const double *fine, double *coarse) {

@@ -507,7 +507,8 @@ static void mg_sm_vcycle(MgSm &M, size_t l) {
   SolveState &Sc = M.L[l + 1];
   ifem_ctx *cc = Sc.ctx;
   mg_csr_apply(c, c->mg_Rp, r, cc->mg_vec[0].p, false);
-  halo_reverse_add_p(cc, cc->mg_vec[0].p);
+  if (c->mg_replica) allreduce_sum_vec(c, cc->mg_vec[0].p, cc->nPo, cc->mg_vec[4].p); // replicated coarse level: sum of the ranks' partial rows
+  else halo_reverse_add_p(cc, cc->mg_vec[0].p);
   mg_sm_vcycle(M, l + 1);
   // prolongation e = P x_c from the ghost-extended coarse correction, then x += e, r -= S e
   halo_exchange_p(cc, cc->mg_vec[1].p);
@@ -636,7 +637,8 @@ static void mg_uu_setup(MgUu &M, bool force_bounds = false) {
       const size_t ne = size_t(c->dim) * size_t(c->nUl);
       if (c->mf_eval.n != ne) c->mf_eval.alloc(ne);
       mg_inject_nodes(c, c->nUo, p->mg_inj_u.p, p->mf_eval.p, c->mf_eval.p);
-      halo_exchange(c, c->mf_eval.p);
+      if (p->mg_replica) allreduce_sum_vec(p, c->mf_eval.p, int64_t(c->dim) * c->nUo, c->mgu_vec[1].p); // every rank injects the nodes it owns
+      else halo_exchange(c, c->mf_eval.p);
       c->mf_valid = true;
       uu_block_diag_mf(c);
       c->uu_mg_version = f0->asm_version;
@@ -731,7 +733,10 @@ static void mg_uu_vcycle(MgUu &M, size_t l) {
   SolveState &Sc = M.L[l + 1];
   ifem_ctx *cc = Sc.ctx;
   mg_csr_apply_nodes_f32(c, c->mg_Ru, r, c->mg_Ru_mask, cc->mguf_vec[0].p);
-  halo_reverse_add_f32(cc, cc->mguf_vec[0].p);
+  // partial restrictions -> the coarse residual: ghost rows to their owners, or (replicated coarse level: every rank holds all rows) the
+  // sum over the ranks; from there down nothing is exchanged and the prolongation reads the replica directly
+  if (c->mg_replica) allreduce_sum_vec_f32(c, cc->mguf_vec[0].p, int64_t(cc->dim) * cc->nUo, cc->mguf_vec[4].p);
+  else halo_reverse_add_f32(cc, cc->mguf_vec[0].p);
   mg_uu_vcycle(M, l + 1);
   halo_exchange_f32(cc, cc->mguf_vec[1].p);
   float *e = c->mguf_vec[4].p;

@@ -65,11 +65,13 @@ def _lib():
     L.ifemx_hanging_lines.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     L.ifemx_make_constraints.argtypes = [C.c_void_p, C.c_int]
     L.ifemx_set_multigrid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.ifemx_set_mg_replica_cells.argtypes = [C.c_void_p, C.c_int64]
     L.ifemx_mg_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
     L.ifemx_coarse_level_chain.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
     L.ifemx_box_prolongation.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifemx_box_injection.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    L.ifemx_box_injection_partial.argtypes = L.ifemx_box_injection.argtypes
     L.ifemx_nested_transfer_check.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.ifemx_channel_state.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_double]
     L._ifemx_bound = True
@@ -217,6 +219,11 @@ class FluidSolver:
         worlds = list(level_worlds or [])
         arr = (C.c_void_p * max(len(worlds), 1))(*worlds)
         self._chk(self.L.ifemx_set_multigrid(self.h, int(on), int(min_cells), arr if worlds else None, len(worlds)))
+
+    def set_mg_replica_cells(self, cells):
+        """FluidSolver::mg_replica_cells: on several ranks, coarse meshes of at most this many cells become replicated single-rank
+        levels (ifem_mg_attach's replicated coarse level) instead of partitioned ones; 0 keeps every level partitioned.  Before setup()."""
+        self._chk(self.L.ifemx_set_mg_replica_cells(self.h, int(cells)))
 
     def mg_levels(self):
         """[(global repetitions, context handle)] of the levels attached below this solver's context, finest first"""
@@ -414,13 +421,14 @@ def nested_transfer_check(dim, level, kv):
     return tuple(out)
 
 
-def box_injection(reps_fine, reps_coarse, degree, l2g_coarse, l2g_fine):
+def box_injection(reps_fine, reps_coarse, degree, l2g_coarse, l2g_fine, partial=False):
+    """partial: the fine list is one rank's owned nodes under a replicated coarse level -- -1 where another rank owns the node"""
     L = _lib()
     dim = len(reps_fine)
     rf, rc_ = np.ascontiguousarray(reps_fine, np.int32), np.ascontiguousarray(reps_coarse, np.int32)
     lf, lc = np.ascontiguousarray(l2g_fine, np.int64), np.ascontiguousarray(l2g_coarse, np.int64)
     out = np.zeros(len(lc), np.int32)
-    rc = L.ifemx_box_injection(dim, rf.ctypes.data_as(C.c_void_p), rc_.ctypes.data_as(C.c_void_p), degree,
+    rc = (L.ifemx_box_injection_partial if partial else L.ifemx_box_injection)(dim, rf.ctypes.data_as(C.c_void_p), rc_.ctypes.data_as(C.c_void_p), degree,
                                lc.ctypes.data_as(C.c_void_p), len(lc), lf.ctypes.data_as(C.c_void_p), len(lf),
                                out.ctypes.data_as(C.c_void_p))
     if rc < 0:

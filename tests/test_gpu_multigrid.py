@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 EXTENT = (2.0, 0.2, 0.2)
 
 
-def _hierarchy(n, P=(1, 1, 1), rank=0, worlds=None, kind="InsIM"):
+def _hierarchy(n, P=(1, 1, 1), rank=0, worlds=None, kind="InsIM", replica_cells=None):
     """the channel through the C++ host mirror: FluidSolver::attach_multigrid_levels (csrc/host/insim.cpp) builds the level
     chain, the transfers and the ifem_mg_attach calls inside initialize_system; on virtual ranks every level gets the
     world handed in for it"""
@@ -31,6 +31,8 @@ def _hierarchy(n, P=(1, 1, 1), rank=0, worlds=None, kind="InsIM"):
     if worlds is not None:
         s.set_partition(P, rank, local_world=worlds[0])
         s.set_multigrid(True, 0, worlds[1:])
+    if replica_cells is not None:
+        s.set_mg_replica_cells(replica_cells)
     s.setup(0)
     return s
 
@@ -355,10 +357,14 @@ def test_tight_first_inner_solve_backs_off_after_a_miss():
     s.close()
 
 
-@pytest.mark.parametrize("P", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
-def test_multigrid_ainv_on_virtual_ranks(P):
+@pytest.mark.parametrize("P,replica_cells", [((2, 1, 1), 0), ((2, 2, 1), 0), ((2, 2, 2), 0), ((2, 1, 1), 32768), ((2, 2, 2), 32768),
+                                             ((2, 2, 2), 600)])
+def test_multigrid_ainv_on_virtual_ranks(P, replica_cells):
     """the bench configuration (IFEM_AINV_MG + multigrid CG(S_m), halo overlap on) on the partitions bench.py uses for 2, 4 and
-    8 GPUs: face, edge and corner neighbours on every level, transfers across rank boundaries"""
+    8 GPUs: face, edge and corner neighbours on every level, transfers across rank boundaries.  replica_cells 0: every level
+    partitioned; 32768: every coarse level of these small meshes is a replicated single-rank context (ifem_mg_attach's replicated
+    coarse level: restrictions summed by a vector all-reduce, no exchange below the finest level); 600: one partitioned coarse level,
+    replicas below it"""
     from openifem_amd import capi
     L = capi.load()
     n, world = (8, 8, 8), int(np.prod(P))
@@ -377,21 +383,23 @@ def test_multigrid_ainv_on_virtual_ranks(P):
     depth = s1.L.ifem_mg_depth(s1.ctx)
     s1.close()
     worlds = [C.c_void_p(L.ifem_local_world_create(world)) for _ in range(depth + 1)]
-    out, errs = [None] * world, []
+    out, errs, levels = [None] * world, [], [None] * world
 
     def work(rank):
         try:
-            s = _hierarchy(n, P, rank, worlds)
+            s = _hierarchy(n, P, rank, worlds, replica_cells=replica_cells)
             s.channel_state()
             assert L.ifem_halo_exchange(s.ctx, capi.VEC_EVAL) == 0
             s.opts.ainv_kind = 4
             s.opts.fgmres_rel = 1e-9
             s.opts.inner_rel = 1e-4
             s.assemble(False)
+            capi.comm_stats(L, s.ctx, reset=True)
             st = s.solve(False)
             t = s.partition_tables()
             no = 3 * t["n_unodes_owned"] + t["n_pnodes_owned"]
             out[rank] = (t, _get(s, capi.VEC_UPDATE, no), st.inner_iters, st.fgmres_iters)
+            levels[rank] = capi.comm_stats_levels(L, s.ctx)
             s.close()
         except Exception:  # noqa
             import traceback
@@ -411,6 +419,15 @@ def test_multigrid_ainv_on_virtual_ranks(P):
     assert np.linalg.norm(xN - x1) <= 1e-6 * np.linalg.norm(x1)
     assert len({o[2] for o in out}) == 1 and len({o[3] for o in out}) == 1, "ranks disagree on the iteration counts"
     assert abs(out[0][2] - st1.inner_iters) <= max(3, st1.inner_iters // 4), (out[0][2], st1.inner_iters)
+    # per-level communication of the solve (ifem_comm_stats_level): replicated levels are single-rank contexts and never communicate;
+    # the level above the first replica hands over by vector all-reduces
+    lv = levels[0]
+    n_part = sum(1 for k in lv if k["nranks"] > 1)
+    assert n_part == {0: len(lv), 32768: 1, 600: 2}[replica_cells], lv
+    for k in lv[n_part:]:
+        assert k["nranks"] == 1 and k["halo_exchanges"] == k["allreduce_dev"] == k["allreduce_host"] == k["allreduce_vec"] == 0, lv
+    assert (lv[n_part - 1]["allreduce_vec"] > 0) == (replica_cells > 0), lv
+    assert all(k["allreduce_vec"] == 0 for k in lv[:n_part - 1]), lv
     for w in worlds:
         L.ifem_local_world_destroy(w)
 

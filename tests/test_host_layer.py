@@ -310,6 +310,52 @@ def test_cpp_transfer_tables_equal_the_numpy_restatement(dim, reps_f, reps_c, P,
     assert (host.box_injection(reps_f, reps_c, 2, co, fo) == capi.box_injection(reps_f, reps_c, 2, co, fo)).all()
 
 
+@pytest.mark.parametrize("dim,reps_f,reps_c,P", [(3, (8, 8, 8), (8, 4, 4), (2, 1, 1)), (3, (8, 8, 4), (4, 4, 2), (2, 2, 1)), (2, (12, 8), (6, 4), (1, 2, 1))])
+def test_transfers_onto_a_replicated_coarse_level_add_up_to_the_single_context_ones(dim, reps_f, reps_c, P):
+    """ifem_mg_attach's replicated coarse level (FluidSolver::mg_replica_cells): the coarse context is a single-rank solver of the whole
+    coarse mesh on every rank, every rank's P has its owned fine rows and ALL coarse nodes as columns.  The rows of the ranks together are
+    the rows of the single-context prolongation (so the all-reduced partial restrictions are P^T r), and the partial injections name every
+    coarse node exactly once"""
+    from openifem_amd import host
+    p0, p1 = (0,) * dim, (1.0,) * dim
+
+    def tables(reps, Pr, rank):
+        s = host.InsIM(host.channel_prm(dim), reps, p0, p1)
+        s.set_partition(Pr, rank, local_world=None)
+        s.set_multigrid(False)
+        s.setup_host_only(0)
+        t = s.partition_tables()
+        s.close()
+        return t
+
+    one = (1, 1, 1)
+    tc, tf1 = tables(reps_c, one, 0), tables(reps_f, one, 0)
+    world = int(np.prod(P))
+    for deg, key, no, ng in ((1, "l2g_p", "n_pnodes_owned", "n_pnodes_global"), (2, "l2g_u", "n_unodes_owned", "n_unodes_global")):
+        whole = host.box_prolongation(reps_f, reps_c, deg, tf1[key], tc[key]).tocsr()
+        pos = np.empty(tf1[ng], np.int64)
+        pos[tf1[key]] = np.arange(tf1[ng])  # lattice id -> row of the single-context table
+        seen = np.zeros(tf1[ng], bool)
+        hit = np.zeros(len(tc[key]), np.int64)
+        for rank in range(world):
+            tf = tables(reps_f, P, rank)
+            fo = tf[key][:tf[no]]
+            part = host.box_prolongation(reps_f, reps_c, deg, fo, tc[key]).tocsr()
+            assert part.shape == (len(fo), len(tc[key]))
+            assert abs(part - whole[pos[fo]]).max() == 0.0
+            assert not seen[fo].any()
+            seen[fo] = True
+            if deg == 2:
+                inj = host.box_injection(reps_f, reps_c, 2, tc[key], fo, partial=True)
+                own = inj >= 0
+                hit += own
+                full = host.box_injection(reps_f, reps_c, 2, tc[key], tf1[key])
+                assert (fo[inj[own]] == tf1[key][full[own]]).all()  # the same lattice point as the single-context injection
+        assert seen.all()
+        if deg == 2:
+            assert (hit == 1).all()
+
+
 # ---- one level of local refinement in the C++ host mirror against the tests' independent builder (tests/hangmesh.py)
 @pytest.mark.parametrize("dim,kv,reps,band", [(2, 1, (32, 8), (0.5, 1.75)), (2, 2, (8, 4), (1.0, 2.0)), (3, 2, (4, 3, 2), (0.9, 2.1)),
                                               (3, 1, (5, 3, 3), (0.0, 0.9))])
