@@ -136,11 +136,15 @@ bool FluidSolver<dim>::attach_multigrid_levels() {
 // Unstructured meshes that know their refinement history (Utils::GridCreator::flow_around_cylinder under refine_global,
 // source/utilities.cpp:345-570, mpi_insim.cpp:493-519): the level chain IS the history -- the same generator one level down, the same
 // formulation / boundary conditions on it, transfers from the parent-child tables (host/multigrid.cpp::nested_prolongation).
-// Single rank (the strips of partition_unstructured are cut per level; their ghost layers do not cover each other's transfers).
+// Several ranks: the strips of partition_unstructured are cut per level and their ghost layers do not cover each other's transfers, so
+// the coarser meshes are not partitioned at all: the next level is a REPLICATED single-rank solver of the whole coarser mesh on every rank
+// (ifem_mg_attach's replicated coarse level; these meshes are small), with the rows of the global transfer tables this rank owns.
 template <int dim>
 bool FluidSolver<dim>::attach_nested_levels() {
   if (!triangulation.generator || !triangulation.parent_of || triangulation.level < 1) return false;
-  if (proc_grid[0] * proc_grid[1] * proc_grid[2] > 1 || triangulation.locally_refined) return false;
+  if (triangulation.locally_refined) return false;
+  const bool replica = proc_grid[0] * proc_grid[1] * proc_grid[2] > 1;
+  if (replica && mg_replica_cells == 0) return false;
   mg_tria.reset(new Triangulation<dim>());
   mg_tria->generator = triangulation.generator;
   mg_tria->parent_of = triangulation.parent_of;
@@ -153,10 +157,17 @@ bool FluidSolver<dim>::attach_nested_levels() {
   c->dofs.morton = dofs.morton;
   c->hard_coded_boundary_values = hard_coded_boundary_values;
   c->field_time = field_time;
-  c->setup_dofs();
+  c->mg_replica_cells = mg_replica_cells;
+  c->setup_dofs(); // a level solver starts as a single rank: the replica of the whole coarser mesh when this level is partitioned
   c->make_constraints();
   c->initialize_system(); // recursion: attaches the levels below c
-  const size_t ncf = dofs.cell_unodes.size() / dofs.nu, ncc = c->dofs.cell_unodes.size() / c->dofs.nu;
+  // the tables of the WHOLE fine mesh in the generator's numbering (= this solver's own on one rank; rebuilt on several: these meshes
+  // are small and every rank built them once already in setup_dofs)
+  DoFTables<dim> whole_tables;
+  PartitionTables whole_part;
+  if (replica) distribute_dofs_unstructured<dim>(triangulation, (int)parameters.fluid_velocity_degree, whole_tables, whole_part);
+  const DoFTables<dim> &gt = replica ? whole_tables : dofs;
+  const size_t ncf = gt.cell_unodes.size() / gt.nu, ncc = c->dofs.cell_unodes.size() / c->dofs.nu;
   std::vector<size_t> parent(ncf);
   std::vector<int> offset(ncf);
   for (size_t k = 0; k < ncf; ++k) {
@@ -164,12 +175,36 @@ bool FluidSolver<dim>::attach_nested_levels() {
     if (parent[k] >= ncc) throw std::logic_error("attach_nested_levels: parent cell out of range");
   }
   CsrTransfer Pp, Rp, Pu, Ru;
-  nested_prolongation(dim, 1, dofs.cell_pnodes.data(), ncf, dofs.n_pnodes, c->dofs.cell_pnodes.data(), c->dofs.n_pnodes, parent, offset, Pp);
+  nested_prolongation(dim, 1, gt.cell_pnodes.data(), ncf, gt.n_pnodes, c->dofs.cell_pnodes.data(), c->dofs.n_pnodes, parent, offset, Pp);
+  nested_prolongation(dim, gt.kv, gt.cell_unodes.data(), ncf, gt.n_unodes, c->dofs.cell_unodes.data(), c->dofs.n_unodes, parent, offset, Pu);
+  std::vector<int32_t> inj = nested_injection(dim, gt.kv, gt.cell_unodes.data(), ncf, c->dofs.cell_unodes.data(), ncc,
+                                              c->dofs.n_unodes, parent, offset);
+  if (replica) { // keep the rows of the nodes this rank owns (local numbering: owned first); the columns are the replica's nodes already
+    auto owned_rows = [](const CsrTransfer &P, const std::vector<int64_t> &l2g, int64_t n_owned) {
+      CsrTransfer Q;
+      Q.n_rows = n_owned; Q.n_cols = P.n_cols;
+      Q.ptr.assign((size_t)n_owned + 1, 0);
+      for (int64_t i = 0; i < n_owned; ++i) {
+        const int64_t g = l2g[(size_t)i];
+        if (g < 0 || g >= P.n_rows) throw std::logic_error("attach_nested_levels: global node id out of range");
+        Q.ptr[(size_t)i + 1] = Q.ptr[(size_t)i] + (P.ptr[(size_t)g + 1] - P.ptr[(size_t)g]);
+      }
+      Q.col.reserve((size_t)Q.ptr[(size_t)n_owned]); Q.w.reserve((size_t)Q.ptr[(size_t)n_owned]);
+      for (int64_t i = 0; i < n_owned; ++i) {
+        const int64_t g = l2g[(size_t)i];
+        Q.col.insert(Q.col.end(), P.col.begin() + P.ptr[(size_t)g], P.col.begin() + P.ptr[(size_t)g + 1]);
+        Q.w.insert(Q.w.end(), P.w.begin() + P.ptr[(size_t)g], P.w.begin() + P.ptr[(size_t)g + 1]);
+      }
+      return Q;
+    };
+    Pp = owned_rows(Pp, part.l2g_p, dofs.n_pnodes_owned);
+    Pu = owned_rows(Pu, part.l2g_u, dofs.n_unodes_owned);
+    std::vector<int32_t> g2l((size_t)gt.n_unodes, -1); // owned velocity nodes only: exactly one rank injects a coarse node
+    for (int64_t i = 0; i < dofs.n_unodes_owned; ++i) g2l[(size_t)part.l2g_u[(size_t)i]] = (int32_t)i;
+    for (auto &v : inj) v = g2l[(size_t)v];
+  }
   transpose_transfer(Pp, Rp);
-  nested_prolongation(dim, dofs.kv, dofs.cell_unodes.data(), ncf, dofs.n_unodes, c->dofs.cell_unodes.data(), c->dofs.n_unodes, parent, offset, Pu);
   transpose_transfer(Pu, Ru);
-  const std::vector<int32_t> inj = nested_injection(dim, dofs.kv, dofs.cell_unodes.data(), ncf, c->dofs.cell_unodes.data(), ncc,
-                                                    c->dofs.n_unodes, parent, offset);
   ifem_mg_transfer t{};
   t.n_fine_p_owned = Pp.n_rows; t.n_coarse_p_local = Pp.n_cols;
   t.pp_ptr = Pp.ptr.data(); t.pp_col = Pp.col.data(); t.pp_w = Pp.w.data();

@@ -80,6 +80,7 @@ void spmv_bt_f32(ifem_ctx *ctx, const double *xp, double *yu); // (matrix-free S
 // y_p = A_pp x_p (SCnsIM pressure block on the M_p pattern); 1/diag(A_pp) for its Jacobi preconditioner
 void spmv_app(ifem_ctx *ctx, const double *xp, double *yp);
 void app_diag_setup(ifem_ctx *ctx);
+void sm_diag_from_blocks(ifem_ctx *ctx, const double *dinv_mu_ext, double *d); // diag(B diag(M_u)^-1 B^T), owned pressure rows
 void scalar_diag(ifem_ctx *ctx, const PlanarCsr &M, const double *val, double *d);
 // y_p = M_p x_p
 void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp, int part = 0, bool use_f32 = false);

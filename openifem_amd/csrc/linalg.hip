@@ -518,6 +518,31 @@ void scalar_diag(ifem_ctx *ctx, const PlanarCsr &M, const double *val, double *d
   if (n) hipLaunchKernelGGL(k_csr_diag, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, M.rowptr.p, M.col.p, val, d);
 }
 
+// diag(B diag(M_u)^-1 B^T) from the rows of B (1 x DIM blocks, planar) and the ghost-extended inverse lumped velocity mass: the
+// Jacobi scaling of the S_m smoother where S_m itself is only applied as two SpMVs (several ranks without a 2-deep pressure halo)
+template <int DIM>
+__global__ void k_sm_diag_b(int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col, const double *__restrict__ val,
+                            const double *__restrict__ dinv_ext, double *__restrict__ d) {
+  const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  const int64_t rs = rp[row];
+  const int len = int(rp[row + 1] - rs);
+  const double *vb = val + rs * DIM;
+  double s = 0;
+  for (int k = 0; k < len; ++k) {
+    const int64_t c = col[rs + k];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) { const double v = vb[int64_t(j) * len + k]; s += v * v * dinv_ext[c * DIM + j]; }
+  }
+  d[row] = s;
+}
+void sm_diag_from_blocks(ifem_ctx *ctx, const double *dinv_mu_ext, double *d) {
+  const int64_t n = ctx->B.n_rows;
+  if (!n) return;
+  if (ctx->dim == 3) hipLaunchKernelGGL(k_sm_diag_b<3>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, dinv_mu_ext, d);
+  else hipLaunchKernelGGL(k_sm_diag_b<2>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, dinv_mu_ext, d);
+}
+
 void app_diag_setup(ifem_ctx *ctx) {
   const int64_t n = ctx->Mp.n_rows;
   if (ctx->app_diag.n != (size_t)n) ctx->app_diag.alloc(n);

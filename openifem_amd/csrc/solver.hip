@@ -435,8 +435,16 @@ static void mg_sm_setup(MgSm &M, int use_nonzero) {
     }
     for (auto &v : c->mg_vec)
       if ((int64_t)v.n < c->nPl + 8) { v.alloc((size_t)c->nPl + 8); IFEM_HIP_CHECK(hipMemsetAsync(v.p, 0, v.n * sizeof(double), c->stream)); }
+    // S_m in operator form (the finest level of a partition without the 2-deep pressure halo: unstructured strips): the smoother
+    // needs its diagonal only, which the rows of B give; "valid" = the diagonal belongs to the present blocks
+    const bool opform = !sm_is_explicit(S);
+    if (opform && !c->sm_valid) { c->sm_valid = true; c->sm_version++; }
     if (c->sm_mg_version == c->sm_version && c->sm_lmax > 0) continue;
     if ((int64_t)c->sm_dinv.n != c->nPo) c->sm_dinv.alloc((size_t)c->nPo);
+    if (opform) {
+      const double *de; extend_u(S, c->dinvMu.p, &de);
+      sm_diag_from_blocks(c, de, c->sm_dinv.p);
+    } else
     scalar_diag(c, c->Sm, c->Sm.val.p, c->sm_dinv.p); // owned rows; the diagonal entry has a local column id on every layout
     vec_recip(c, S.npo, c->sm_dinv.p);
     // largest eigenvalue of D^-1 S_m: power iteration (set-up only: host-synchronised norms) from a fixed rough vector, or --
@@ -809,7 +817,9 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   sm_ensure(S);
   OpFn sm = [&](const double *x, double *y) { sm_apply(S, x, y, lowp_all); };
   // multigrid-preconditioned CG when coarser levels are attached (every level needs its S_m explicitly: Jacobi smoothing)
-  bool use_mg = o->sm_mg && c->mg_coarse && sm_is_explicit(S);
+  // (the finest level may apply S_m as two SpMVs -- several ranks without the 2-deep pressure halo, e.g. the strips of an unstructured
+  // mesh above replicated coarse levels: the V-cycle needs the operator and its diagonal there, not the matrix)
+  bool use_mg = o->sm_mg && c->mg_coarse && (sm_is_explicit(S) || (o->explicit_schur && c->halo.nranks > 1));
   MgSm M;
   if (use_mg) {
     M.lowp = lowp_all; M.nu = std::max(1, o->mg_smooth); M.ratio = std::max(1.5, o->mg_cheb_ratio);

@@ -457,7 +457,8 @@ def test_single_precision_operator_matches_the_fp64_operator(reps):
     ctx.close()
 
 
-def _cylinder_run(refinements, multigrid, steps=1):
+def _cylinder_run(refinements, multigrid, steps=1, partition=None):
+    """partition: (world, rank, local world handle) -- the strip partition of partition_unstructured on virtual ranks"""
     import os
     import re
     from openifem_amd import host
@@ -465,6 +466,8 @@ def _cylinder_run(refinements, multigrid, steps=1):
     prm = re.sub(r"set Global refinements\s*=\s*\d+", f"set Global refinements = {refinements}", prm)
     flow = host.InsIM(prm, mesh="cylinder")
     flow.add_hard_coded_boundary_condition(0, lambda p, c, t: 4 * 0.3 * p[1] * (0.41 - p[1]) / (0.41 * 0.41) if (c == 0 and abs(p[0]) < 1e-10) else 0.0)
+    if partition is not None:
+        flow.set_partition((partition[0], 1, 1), partition[1], local_world=partition[2])
     flow.set_multigrid(multigrid)
     if not multigrid:
         flow.opts.inner_rel = 1e-3
@@ -474,6 +477,9 @@ def _cylinder_run(refinements, multigrid, steps=1):
     flow.run_one_step(True)
     st = flow.last_stats()
     v, p = flow.get_current_solution()
+    if partition is not None:
+        t = flow.partition_tables()
+        v, p = v[:2 * t["n_unodes_owned"]], p[:t["n_pnodes_owned"]]
     out = dict(vmax=v.max(), pmax=p.max(), levels=n_levels, fgmres=st.fgmres_iters, inner=st.inner_iters / max(st.precond_applies, 1),
                cg_sm=st.cg_sm_iters / max(st.precond_applies, 1), n_dofs=len(v) + len(p), ainv=flow.opts.ainv_kind)
     flow.close()
@@ -500,3 +506,40 @@ def test_cylinder_level_chain_from_the_refinement_history():
         assert got[r]["cg_sm"] <= got[3]["cg_sm"] + 2, got
         assert got[r]["fgmres"] <= got[3]["fgmres"] + 4, got
     assert got[3]["inner"] < 0.25 * ref["inner"], (got, ref)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cylinder_level_chain_below_a_partitioned_mesh(world):
+    """... and on several ranks: the strips of partition_unstructured cannot be cut consistently per level, so the refinement history hangs
+    below the partitioned mesh as REPLICATED single-rank levels (attach_nested_levels, ifem_mg_attach's replicated coarse level).  Five
+    refinements (0.87 M DoF) on 2 / 4 virtual ranks: the same constants and -- within the block-Jacobi effects of the partition -- the
+    same counts as the single context"""
+    from openifem_amd import capi
+    L = capi.load()
+    one = _cylinder_run(5, True)
+    w = C.c_void_p(L.ifem_local_world_create(world))
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            out[rank] = _cylinder_run(5, True, partition=(world, rank, w))
+        except Exception:  # noqa
+            import traceback
+            errs.append((rank, traceback.format_exc()))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=900)
+    assert not errs, errs
+    L.ifem_local_world_destroy(w)
+    assert all(o["levels"] == 5 and o["ainv"] == capi.AINV_MG for o in out), out
+    assert sum(o["n_dofs"] for o in out) == one["n_dofs"]
+    vmax, pmax = max(o["vmax"] for o in out), max(o["pmax"] for o in out)
+    assert abs(vmax - one["vmax"]) < 1e-4 * one["vmax"] and abs(pmax - one["pmax"]) < 1e-3 * one["pmax"], (vmax, pmax, one)
+    assert len({o["fgmres"] for o in out}) == 1 and abs(out[0]["fgmres"] - one["fgmres"]) <= 3, (out, one)
+    assert out[0]["inner"] <= 1.3 * one["inner"] + 2, (out, one)
+    # CG(S_m): the strips have no 2-deep pressure halo, so the finest level applies S_m as two SpMVs -- the V-cycle smooths with that
+    # operator and the diagonal the rows of B give (linalg.hip::sm_diag_from_blocks); plain CG needed hundreds of iterations here
+    assert out[0]["cg_sm"] <= one["cg_sm"] + 3, (out, one)

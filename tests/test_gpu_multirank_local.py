@@ -287,7 +287,7 @@ def _cyl_case(kind, prm_name, world_handle, P, rank, out, errs):
         t = flow.partition_tables()
         st = flow.last_stats()
         out[rank] = (v[:2 * t["n_unodes_owned"]].max(), p[:t["n_pnodes_owned"]].max(), t["n_unodes_owned"], t["n_unodes_global"],
-                     st.inner_iters / max(st.precond_applies, 1))
+                     st.inner_iters / max(st.precond_applies, 1), flow.L.ifem_mg_depth(flow.ctx), flow.opts.ainv_kind)
         flow.close()
     except Exception:  # noqa
         import traceback
@@ -316,6 +316,11 @@ def test_cylinder_known_answers_on_partitioned_unstructured_mesh(kind, prm, worl
     assert abs(pmax - pref) / pref < 1e-3
     if kind == "SCnsIM":  # the per-rank ILU(0) of the owned block of T_pp (round 4; Jacobi needed several hundred here)
         assert max(o[4] for o in out) < 150, [o[4] for o in out]
+    else:
+        # round 4: the refinement history of the cylinder hangs below the partitioned mesh as REPLICATED single-rank levels
+        # (FluidSolver::attach_nested_levels on several ranks), so A~^-1 is the V-cycle-preconditioned inner solve here too
+        assert all(o[5] >= 1 and o[6] == capi.AINV_MG for o in out), [(o[5], o[6]) for o in out]
+        assert max(o[4] for o in out) < 40, [o[4] for o in out]
     L.ifem_local_world_destroy(w)
 
 
