@@ -518,6 +518,7 @@ static void allreduce_vec_t(ifem_ctx *ctx, T *dev, int64_t n, T *scratch) {
     if (h.nranks > kMaxLocalPeers) throw Error(IFEM_E_COMM, "local world: a replicated coarse level needs at most 8 virtual ranks");
     // same protocol as the stream-ordered scalar all-reduce: publish, sum the peers' vectors into scratch once their producers
     // have run, take the sum over once everybody has read
+    try {
     w->red_vec[h.rank] = dev;
     IFEM_HIP_CHECK(hipEventRecord(w->ev_packed[h.rank], ctx->stream));
     w->rendezvous();
@@ -533,6 +534,7 @@ static void allreduce_vec_t(ifem_ctx *ctx, T *dev, int64_t n, T *scratch) {
     for (int r = 0; r < h.nranks; ++r)
       if (r != h.rank) IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_copied[r], 0));
     IFEM_HIP_CHECK(hipMemcpyAsync(dev, scratch, size_t(n) * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+    } catch (...) { w->aborted.store(true, std::memory_order_release); throw; } // the peers leave their rendezvous with an error
     return;
   }
   IFEM_NCCL_CHECK(ncclAllReduce(dev, dev, size_t(n), sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, (ncclComm_t)h.comm, ctx->stream));
