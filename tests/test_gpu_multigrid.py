@@ -543,3 +543,90 @@ def test_cylinder_level_chain_below_a_partitioned_mesh(world):
     # CG(S_m): the strips have no 2-deep pressure halo, so the finest level applies S_m as two SpMVs -- the V-cycle smooths with that
     # operator and the diagonal the rows of B give (linalg.hip::sm_diag_from_blocks); plain CG needed hundreds of iterations here
     assert out[0]["cg_sm"] <= one["cg_sm"] + 3, (out, one)
+
+
+def _cylinder3d_run(refinements, multigrid, partition=None):
+    """tests/fluid_cylinder_mpi's dim == 3 branch (fluid_cylinder_mpi.cpp:98-104) on the host mirror's extruded cylinder mesh"""
+    import os
+    import re
+    from openifem_amd import host
+    prm = open(os.path.join(os.path.dirname(__file__), "golden", "prm", "fluid_cylinder_mpi.prm")).read()
+    prm = re.sub(r"set Dimension = 2", "set Dimension = 3", prm)
+    prm = re.sub(r"set Global refinements = 3, 0", f"set Global refinements = {refinements}, 0", prm)
+    prm = re.sub(r"set Gravity = 0.0, 0.0", "set Gravity = 0.0, 0.0, 0.0", prm)
+    prm = re.sub(r"set Initial velocity = 0.0, 0.0", "set Initial velocity = 0.0, 0.0, 0.0", prm)
+    prm = re.sub(r"set Number of Dirichlet BCs = 4", "set Number of Dirichlet BCs = 6", prm)
+    prm = re.sub(r"set Dirichlet boundary id = 0, 2, 3, 4", "set Dirichlet boundary id = 0, 2, 3, 4, 5, 6", prm)
+    prm = re.sub(r"set Dirichlet boundary components = 3, 3, 3, 3", "set Dirichlet boundary components = 7, 7, 7, 7, 7, 7", prm)
+    prm = re.sub(r"set Dirichlet boundary values = 0.2, 0, 0, 0, 0, 0, 0, 0", "set Dirichlet boundary values = " + ", ".join(["0"] * 18), prm)
+
+    from cylmesh import inflow_bc_3d  # parabolic in y and z at the inlet x = -0.3 (fluid_cylinder_mpi.cpp:56-75)
+    flow = host.InsIM(prm, mesh="cylinder")
+    flow.add_hard_coded_boundary_condition(0, lambda p, c, t: inflow_bc_3d(p, c))
+    if partition is not None:
+        flow.set_partition((partition[0], 1, 1), partition[1], local_world=partition[2])
+    flow.set_multigrid(multigrid)
+    if not multigrid:
+        flow.opts.inner_rel = 1e-3
+        flow.opts.inner_maxit = 4000
+    flow.setup(refinements)
+    n_levels = len(flow.mg_levels())
+    flow.run_one_step(True)
+    st = flow.last_stats()
+    v, p = flow.get_current_solution()
+    if partition is not None:
+        t = flow.partition_tables()
+        v, p = v[:3 * t["n_unodes_owned"]], p[:t["n_pnodes_owned"]]
+    out = dict(vmax=v.max(), pmax=p.max(), vsum=np.abs(v).sum(), levels=n_levels, fgmres=st.fgmres_iters,
+               inner=st.inner_iters / max(st.precond_applies, 1), cg_sm=st.cg_sm_iters / max(st.precond_applies, 1),
+               n_dofs=len(v) + len(p), ainv=flow.opts.ainv_kind)
+    flow.close()
+    return out
+
+
+def test_extruded_cylinder_level_chain():
+    """the 3D (extruded) cylinder mesh of Utils::GridCreator<3>::flow_around_cylinder refined once: its unrefined mesh hangs below it as a
+    level (parent-child tables of the hexahedral generator, multigrid.cpp::nested_prolongation in 3D), the matrix-core cell kernel and
+    the matrix-free operator run on an unstructured 3D mesh, and the multigrid-preconditioned inner solves reproduce the
+    Jacobi-preconditioned run"""
+    from openifem_amd import capi
+    ref = _cylinder3d_run(1, False)
+    got = _cylinder3d_run(1, True)
+    assert ref["levels"] == 0 and got["levels"] == 1 and got["ainv"] == capi.AINV_MG
+    assert got["n_dofs"] == ref["n_dofs"]
+    assert abs(got["vmax"] - ref["vmax"]) <= 1e-4 * abs(ref["vmax"]), (got, ref)
+    assert abs(got["pmax"] - ref["pmax"]) <= 1e-3 * abs(ref["pmax"]), (got, ref)
+    assert abs(got["vsum"] - ref["vsum"]) <= 1e-4 * ref["vsum"], (got, ref)
+    assert got["inner"] < 0.5 * ref["inner"], (got, ref)
+    assert got["cg_sm"] < 0.5 * ref["cg_sm"], (got, ref)
+
+
+def test_extruded_cylinder_level_chain_on_virtual_ranks():
+    """... and cut into two strips: the unrefined 3D mesh as a replicated level below the partitioned one"""
+    from openifem_amd import capi
+    L = capi.load()
+    one = _cylinder3d_run(1, True)
+    world = 2
+    w = C.c_void_p(L.ifem_local_world_create(world))
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            out[rank] = _cylinder3d_run(1, True, partition=(world, rank, w))
+        except Exception:  # noqa
+            import traceback
+            errs.append((rank, traceback.format_exc()))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errs, errs
+    L.ifem_local_world_destroy(w)
+    assert all(o["levels"] == 1 and o["ainv"] == capi.AINV_MG for o in out), out
+    assert sum(o["n_dofs"] for o in out) == one["n_dofs"]
+    assert abs(max(o["vmax"] for o in out) - one["vmax"]) <= 1e-4 * abs(one["vmax"]), (out, one)
+    assert abs(max(o["pmax"] for o in out) - one["pmax"]) <= 1e-3 * abs(one["pmax"]), (out, one)
+    assert abs(sum(o["vsum"] for o in out) - one["vsum"]) <= 1e-4 * one["vsum"], (out, one)
+    assert out[0]["inner"] <= 1.5 * one["inner"] + 2 and out[0]["cg_sm"] <= one["cg_sm"] + 3, (out, one)
