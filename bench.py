@@ -310,6 +310,18 @@ def extras(solver, capi, n_dofs, warm_ms):
     return out
 
 
+def _hbm_used_gb():
+    """device memory in use (hipMemGetInfo: total - free), GB; None when the runtime is not reachable"""
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        if hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0:
+            return (total.value - free.value) / 1e9
+    except OSError:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -453,6 +465,7 @@ def main():
         elapsed = float(t[0])
     asm_kernel_ms /= max(args.steps, 1)
     ms_per_step = elapsed / args.steps * 1e3
+    hbm_used_gb = _hbm_used_gb()  # of this rank's device, after the timed steps (the steady state of the step)
     # ---- per-kernel pass (outside the timed region): one more step with HIP events around every matrix-free application
     # and every A_uu SpMV on the context stream
     solver.set_profiling(True)
@@ -518,7 +531,7 @@ def main():
                                    f"(plane Poiseuille + seeded 1e-3 perturbation), {n}^3 cells per GPU",
                        "n_dofs": n_dofs_global, "cells_per_gpu": n_cells, "parallelism": f"dd{world}",
                        "assemble_ms": t_asm / args.steps * 1e3, "solve_ms": t_solve / args.steps * 1e3,
-                       "assemble_kernel_ms": asm_kernel_ms, "setup_s": t_setup,
+                       "assemble_kernel_ms": asm_kernel_ms, "setup_s": t_setup, "hbm_used_gb": hbm_used_gb,
                        "true_rel_residual": true_res / rhs_norm if rhs_norm > 0 else None, "fgmres_rel_residual": last.fgmres_res / rhs_norm if rhs_norm > 0 else None,
                        "fgmres_rel_tol": solver.opts.fgmres_rel, "seed": args.seed, "perturbation": args.rel,
                        "rccl_nranks": comm["rccl_nranks"], "comm_transport": {0: "none (single rank)", 1: "rccl", 2: "local world"}[comm["transport"]],

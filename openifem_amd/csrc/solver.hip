@@ -32,7 +32,9 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
                  const double *b, double *x, int m, int maxit, double tol, double *V, double *Z, double *w,
                  double *res_out,
                  const std::function<void(int, const double *, int64_t, const double *, double *)> &mdot,
-                 std::vector<double> *history = nullptr) { // residual norm after every iteration (verbose runs)
+                 std::vector<double> *history = nullptr, // residual norm after every iteration (verbose runs)
+                 const std::function<void(int, double *&, double *&)> *ensure = nullptr) { // bases that grow with the iteration count: called
+                                                                                        // with the V columns the next iteration needs
   std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), h(m + 1), h2(m + 1);
   v_zero(ctx, n, x);
   int it = 0;
@@ -53,6 +55,7 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
     int j = 0;
     bool done = false;
     for (; j < m && it < maxit; ++j) {
+      if (ensure) (*ensure)(j + 2, V, Z); // columns 0 .. j + 1 of V, 0 .. j of Z
       double *vj = V + (int64_t)j * ld;
       double *zj = flexible ? Z + (int64_t)j * ld : Z;
       Pinv(vj, zj);
@@ -108,6 +111,29 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
   if (res_out) *res_out = res;
   return it;
 }
+
+// Krylov bases of the flexible solvers grow with the iteration count instead of being sized for the restart length: FGMRES(30) at
+// 128^3 would hold 61 vectors of 425 MB where the bench's solves use 2 to 14.  Contents are kept; new columns are zero.
+static void grow_basis(ifem_ctx *c, DBuf<double> &B, int64_t ld, int64_t cols) {
+  const int64_t have = ld > 0 ? int64_t(B.n) / ld : 0;
+  if (have >= cols || ld <= 0) return;
+  const int64_t want = std::max<int64_t>((cols + 7) / 8 * 8, have + have / 2);
+  DBuf<double> nb;
+  nb.alloc(size_t(want) * size_t(ld));
+  if (have > 0) IFEM_HIP_CHECK(hipMemcpyAsync(nb.p, B.p, size_t(have) * size_t(ld) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  IFEM_HIP_CHECK(hipMemsetAsync(nb.p + size_t(have) * size_t(ld), 0, size_t(want - have) * size_t(ld) * sizeof(double), c->stream));
+  IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
+  B.swap(nb);
+}
+// the callback gmres() gets for the pair (V: up to max_v columns, Z: up to max_v - 1)
+static std::function<void(int, double *&, double *&)> basis_grower(ifem_ctx *c, DBuf<double> &Vb, DBuf<double> &Zb, int64_t ld, int max_v) {
+  return [c, &Vb, &Zb, ld, max_v](int cols, double *&V, double *&Z) {
+    grow_basis(c, Vb, ld, std::min(cols, max_v));
+    grow_basis(c, Zb, ld, std::min(cols - 1, max_v - 1));
+    V = Vb.p; Z = Zb.p;
+  };
+}
+constexpr int kBasisStart = 8; // columns a basis starts with
 
 // Inner solver of the preconditioner: right-preconditioned restarted GMRES, x0 = 0, Krylov basis stored in single
 // precision (half the Gram-Schmidt traffic; everything else fp64), single-pass classical Gram-Schmidt with the norm of
@@ -923,9 +949,11 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
       } else { // flexible GMRES: the preconditioned directions are kept, so the update needs no extra V-cycle
         const int64_t ld = basis_ld(S.ctx, S.nuo);
         const int mi = std::max(1, o->inner_restart);
-        if ((int64_t)c->innerZ.n < int64_t(mi) * ld) c->innerZ.alloc(size_t(mi) * size_t(ld));
+        grow_basis(c, c->innerV, ld, std::min(mi + 1, kBasisStart));
+        grow_basis(c, c->innerZ, ld, std::min(mi, kBasisStart));
+        const auto grow = basis_grower(c, c->innerV, c->innerZ, ld, mi + 1);
         S.st.inner_iters += gmres(c, S.nuo, ld, /*reorth=*/false, Amf, Vc, true, S.utmp, dst0, mi, o->inner_maxit, inner_rel_now * un,
-                                  c->innerV.p, c->innerZ.p, S.inner_w, &res, mdot);
+                                  c->innerV.p, c->innerZ.p, S.inner_w, &res, mdot, nullptr, &grow);
       }
       if (o->inner_maxit > 0) return std::isfinite(res); // the Arnoldi recurrence carries any NaN / Inf of the V-cycle
       double dn;
@@ -942,8 +970,14 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
         if (o->verbose) fprintf(stderr, "[ifem] A_uu V-cycle still non-finite: node-block Jacobi for this application\n");
         OpFn Pbj = [&](const double *x, double *y) { bjac_apply(c, x, y); };
         res = 0;
-        S.st.inner_iters += gmres(c, S.nuo, basis_ld(S.ctx, S.nuo), /*reorth=*/false, Amf, Pbj, false, S.utmp, dst0, std::max(1, o->inner_restart),
-                                  std::max(o->inner_maxit, 50), inner_rel_now * un, c->innerV.p, S.inner_z, S.inner_w, &res, mdot);
+        const int64_t ldj = basis_ld(S.ctx, S.nuo);
+        const int mj = std::max(1, o->inner_restart);
+        const std::function<void(int, double *&, double *&)> growv = [&](int cols, double *&V, double *&) {
+          grow_basis(c, c->innerV, ldj, std::min(cols, mj + 1)); // (not flexible: one z vector)
+          V = c->innerV.p;
+        };
+        S.st.inner_iters += gmres(c, S.nuo, ldj, /*reorth=*/false, Amf, Pbj, false, S.utmp, dst0, mj,
+                                  std::max(o->inner_maxit, 50), inner_rel_now * un, c->innerV.p, S.inner_z, S.inner_w, &res, mdot, nullptr, &growv);
       }
     }
     IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -991,9 +1025,10 @@ static void carve_workspace(SolveState &S, bool krylov) {
   S.outer_w = p;
   if (!krylov) return; // a coarse multigrid level: vector scratch only
   const int m = S.o->fgmres_restart, mi = S.o->inner_restart;
-  if ((int64_t)c->krylovV.n < (int64_t)(m + 1) * basis_ld(S.ctx, S.n)) c->krylovV.alloc((int64_t)(m + 1) * basis_ld(S.ctx, S.n));
-  if ((int64_t)c->krylovZ.n < (int64_t)m * basis_ld(S.ctx, S.n)) c->krylovZ.alloc((int64_t)m * basis_ld(S.ctx, S.n));
-  grow_inner_basis(c, (int64_t)(mi + 1) * basis_ld(S.ctx, S.nuo));
+  grow_basis(c, c->krylovV, basis_ld(S.ctx, S.n), std::min(m + 1, kBasisStart)); // the rest on demand (basis_grower)
+  grow_basis(c, c->krylovZ, basis_ld(S.ctx, S.n), std::min(m, kBasisStart));
+  // the inner solve of IFEM_AINV_MG is flexible too and grows its bases the same way; the other kinds' kernels want theirs whole
+  grow_inner_basis(c, (int64_t)(S.o->ainv_kind == IFEM_AINV_MG ? std::min(mi + 1, kBasisStart) : mi + 1) * basis_ld(S.ctx, S.nuo));
 }
 
 void ins_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, const double *src, double *dst) {
@@ -1111,8 +1146,9 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
     S.st.precond_applies++;
   };
   double res = 0;
+  const auto grow = basis_grower(ctx, ctx->krylovV, ctx->krylovZ, basis_ld(S.ctx, S.n), o->fgmres_restart + 1);
   const int it = gmres(ctx, S.n, basis_ld(S.ctx, S.n), true, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p,
-                       ctx->krylovZ.p, S.outer_w, &res, mdot);
+                       ctx->krylovZ.p, S.outer_w, &res, mdot, nullptr, &grow);
   apply_constraints(ctx, use_nonzero ? 1 : 0, upd);
   hanging_distribute(ctx, upd);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1148,8 +1184,9 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   OpFn Pop = [&](const double *x, double *y) { precond_vmult(S, x, y); };
   double res = 0;
   std::vector<double> hist;
+  const auto grow = basis_grower(ctx, ctx->krylovV, ctx->krylovZ, basis_ld(S.ctx, S.n), o->fgmres_restart + 1);
   const int it = gmres(ctx, S.n, basis_ld(S.ctx, S.n), /*reorth=*/true, Aop, Pop, true, rhs, upd, o->fgmres_restart, maxit, tol, ctx->krylovV.p, ctx->krylovZ.p,
-                       S.outer_w, &res, mdot, o->verbose ? &hist : nullptr);
+                       S.outer_w, &res, mdot, o->verbose ? &hist : nullptr, &grow);
   apply_constraints(ctx, use_nonzero ? 1 : 0, upd); // constraints_used.distribute(newton_update)
   hanging_distribute(ctx, upd);
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
