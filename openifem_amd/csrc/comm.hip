@@ -519,21 +519,21 @@ static void allreduce_vec_t(ifem_ctx *ctx, T *dev, int64_t n, T *scratch) {
     // same protocol as the stream-ordered scalar all-reduce: publish, sum the peers' vectors into scratch once their producers
     // have run, take the sum over once everybody has read
     try {
-    w->red_vec[h.rank] = dev;
-    IFEM_HIP_CHECK(hipEventRecord(w->ev_packed[h.rank], ctx->stream));
-    w->rendezvous();
-    PeerVecs pp{};
-    for (int r = 0; r < h.nranks; ++r) {
-      pp.p[r] = w->red_vec[r];
-      if (r != h.rank) IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_packed[r], 0));
-    }
-    const unsigned g = unsigned(std::min<int64_t>((n + 255) / 256, 4096));
-    hipLaunchKernelGGL((k_sum_peer_vecs<T>), dim3(g), dim3(256), 0, ctx->stream, n, h.nranks, pp, scratch);
-    IFEM_HIP_CHECK(hipEventRecord(w->ev_copied[h.rank], ctx->stream));
-    w->rendezvous();
-    for (int r = 0; r < h.nranks; ++r)
-      if (r != h.rank) IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_copied[r], 0));
-    IFEM_HIP_CHECK(hipMemcpyAsync(dev, scratch, size_t(n) * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+      w->red_vec[h.rank] = dev;
+      IFEM_HIP_CHECK(hipEventRecord(w->ev_packed[h.rank], ctx->stream));
+      w->rendezvous();
+      PeerVecs pp{};
+      for (int r = 0; r < h.nranks; ++r) {
+        pp.p[r] = w->red_vec[r];
+        if (r != h.rank) IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_packed[r], 0));
+      }
+      const unsigned g = unsigned(std::min<int64_t>((n + 255) / 256, 4096));
+      hipLaunchKernelGGL((k_sum_peer_vecs<T>), dim3(g), dim3(256), 0, ctx->stream, n, h.nranks, pp, scratch);
+      IFEM_HIP_CHECK(hipEventRecord(w->ev_copied[h.rank], ctx->stream));
+      w->rendezvous();
+      for (int r = 0; r < h.nranks; ++r)
+        if (r != h.rank) IFEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, w->ev_copied[r], 0));
+      IFEM_HIP_CHECK(hipMemcpyAsync(dev, scratch, size_t(n) * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
     } catch (...) { w->aborted.store(true, std::memory_order_release); throw; } // the peers leave their rendezvous with an error
     return;
   }
@@ -590,7 +590,18 @@ int comm_selftest(int device) {
   IFEM_HIP_CHECK(hipStreamWaitEvent(s, e1, 0));
   std::vector<double> out2(64);
   IFEM_HIP_CHECK(hipMemcpyAsync(out2.data(), c2.p, 64 * 8, hipMemcpyDeviceToHost, s));
+  // the hand-over to a replicated coarse level (allreduce_sum_vec_f32): an in-place single-precision all-reduce of a whole level vector
+  const size_t nv = size_t(1) << 20;
+  DBuf<float> fv;
+  fv.alloc(nv);
+  std::vector<float> hf(nv);
+  for (size_t i = 0; i < nv; ++i) hf[i] = float(i % 1021) * 0.25f;
+  IFEM_HIP_CHECK(hipMemcpyAsync(fv.p, hf.data(), nv * sizeof(float), hipMemcpyHostToDevice, s));
+  IFEM_NCCL_CHECK(ncclAllReduce(fv.p, fv.p, nv, ncclFloat, ncclSum, comm, s));
+  std::vector<float> of(nv);
+  IFEM_HIP_CHECK(hipMemcpyAsync(of.data(), fv.p, nv * sizeof(float), hipMemcpyDeviceToHost, s));
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  for (size_t i = 0; i < nv; ++i) if (of[i] != hf[i]) throw Error(IFEM_E_COMM, "RCCL self-test: wrong data after the vector all-reduce");
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   ncclCommDestroy(comm2);
   ncclCommDestroy(comm);
