@@ -60,6 +60,64 @@ def kernel_models(L, ctx, n_cells, n_u, n_p, dim=3, nu=27, npn=8, cached_blocks=
     return {"asm": (asm_bytes, asm_flops), "mf": (mf_bytes, mf_flops)}
 
 
+# what each kernel family of ifem_kprof is priced against: HBM for everything, plus the compute ceiling of the two kernels that
+# have one (FP64 matrix cores for the cell integrals, FP32 vector FMA for the single-precision matrix-free cells)
+FAMILY_KERNELS = {
+    "assemble_cells": "k_ins_assemble3<2> (cell integrals + fused scatter)",
+    "zero_fill": "__amd_rocclr_fillBufferAligned (system_matrix = 0, system_rhs = 0)",
+    "spmv_uu": "k_spmv_uu_pipe (stored fp64 A_uu of the outer operator)",
+    "spmv_b_bt": "k_spmv_planar<1,3,32,double> / <3,1,8,double> / k_spmv_planar_add (B, B^T)",
+    "mf_cell": "k_apply_uu_mf2<3,2,4,true,float,*> (matrix-free A_uu, all levels)",
+    "mf_gather": "k_mf_gather<3,float,*> (node gather + fused smoother update, all levels)",
+    "spmv_sm": "k_spmv_planar<1,1,32,float> (S_m, all levels)",
+    "spmv_mp": "k_spmv_planar<1,1,8,float> (M_p)",
+    "mdot": "k_mdot<K> + k_reduce_final",
+    "maxpy": "k_maxpy<K>",
+    "vector_ops": "k_axpy / k_axpby / k_scale / copies / conversions / Chebyshev updates",
+    "mg_transfer": "k_mg_csr_nodes / k_mg_csr / k_mg_inject",
+    "smoother_setup": "k_uu_diag + k_block_invert + k_bjac_setup",
+    "cg_recurrence": "k_cgd_init / k_cgd_update / k_cgd_p / k_cgd_scalars",
+    "schur_setup": "k_schur_numeric, masked geometry blocks",
+    "other": "constraints, hanging nodes",
+}
+COMPUTE_PEAK = {"assemble_cells": ("FP64 MFMA", FP64_PEAK_TFLOPS), "mf_cell": ("FP32 vector FMA", FP32_VECTOR_PEAK_TFLOPS)}
+
+
+def pmc_family_traffic(n, world):
+    """HBM bytes per step and family from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, "families"), single rank"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            fam = json.load(f)["families"][str(n)]
+        return fam
+    except Exception:
+        return {}
+
+
+def kernel_table(prof, prof_steps, n, world):
+    """roofline.kernels[]: per kernel family of one profiled step (ifem_kprof: HIP event pairs on the context stream around
+    every launch wrapper, read once after the step) launches, ms, algorithmic bytes / flops as the wrappers state them
+    (DESIGN.md section 4), achieved GB/s and TFLOP/s against the peaks, and the committed PMC traffic with its ratio."""
+    pmc = pmc_family_traffic(n, world)
+    rows = []
+    for fam, e in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+        ms = e["ms"] / prof_steps
+        if ms <= 0:
+            continue
+        nb, nf = e["bytes"] / prof_steps, e["flops"] / prof_steps
+        row = {"family": fam, "kernel": FAMILY_KERNELS.get(fam, fam), "launches_per_step": e["scopes"] / prof_steps, "ms_per_step": ms,
+               "algorithmic_bytes": nb, "algorithmic_flops": nf,
+               "gb_s": nb / (ms * 1e-3) / 1e9, "hbm_frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if fam in COMPUTE_PEAK and nf > 0:
+            row.update({"tflop_s": nf / (ms * 1e-3) / 1e12, "compute_peak": COMPUTE_PEAK[fam][0],
+                        "compute_frac": nf / (ms * 1e-3) / 1e12 / COMPUTE_PEAK[fam][1]})
+        t = pmc.get(fam)
+        if t:
+            row.update({"traffic": t["traffic_bytes"], "traffic_over_algorithmic": t["traffic_bytes"] / nb if nb else None,
+                        "traffic_source": t.get("source", "profiles/pmc_traffic.json") + ("" if world == 1 else " (single-rank pass)")})
+        rows.append(row)
+    return rows
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -322,6 +380,39 @@ def _hbm_used_gb():
     return None
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script on this node (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT in their environment, what torch.distributed.run --nnodes=1 --nproc-per-node N would give them),
+    pass their output through, and return the first non-zero exit code (the others are ended: a rank that died would leave
+    its peers waiting in a collective)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:  # exactly the processes started above
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -363,20 +454,35 @@ def main():
     if min(x for x in (physical_cores(), _aff, _quota) if x) >= physical_cores():
         os.environ.setdefault("OMP_PROC_BIND", "spread")
         os.environ.setdefault("OMP_PLACES", "cores")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly (`python bench.py --gpus N`, the way the driver starts --gpus 1): become the launcher of N ranks
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "IFEM_BENCH_DEVICE" in os.environ:  # debugging aid: several ranks on one GPU (RCCL normally refuses this)
         local_rank = int(os.environ["IFEM_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it plainly (it launches its own ranks) or "
+                         f"with torch.distributed.run --nproc-per-node {args.gpus}")
     dist = None
     if world > 1:
         import torch.distributed as dist  # rendezvous + barrier + max-over-ranks only (gloo on the host)
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        print(f"[bench rank {rank}] gloo rendezvous of {world} ranks complete", file=sys.stderr, flush=True)
 
     from openifem_amd import host, capi
+    # one rank per GPU: every rank needs its own device (the reference: one MPI rank per core, tests/CMakeLists.txt:52,71)
+    n_dev = capi.load().ifem_device_count()
+    need = 1 if "IFEM_BENCH_DEVICE" in os.environ else max(world, 1)
+    if n_dev < need:
+        msg = (f"[bench rank {rank}] IFEM_E_NODEVICE: {n_dev} HIP device(s) visible, --gpus {args.gpus} needs {need} "
+               f"(one rank per GPU, no CPU fallback)")
+        print(msg, file=sys.stderr, flush=True)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        raise SystemExit(capi.E_NODEVICE_EXIT)
     if args.solver == "insimex":
         return bench_insimex(args, host)
     n = args.n
@@ -466,59 +572,63 @@ def main():
     asm_kernel_ms /= max(args.steps, 1)
     ms_per_step = elapsed / args.steps * 1e3
     hbm_used_gb = _hbm_used_gb()  # of this rank's device, after the timed steps (the steady state of the step)
-    # ---- per-kernel pass (outside the timed region): one more step with HIP events around every matrix-free application
-    # and every A_uu SpMV on the context stream
-    solver.set_profiling(True)
-    step()
-    tm = solver.timing()
-    solver.set_profiling(False)
-    spmv_ms, spmv_calls = tm.spmv_uu_ms_avg * tm.spmv_uu_calls, tm.spmv_uu_calls
-    mf_ms, mf_calls = tm.mf_ms_avg * tm.mf_calls, tm.mf_calls
-    prof_steps = 1
+    # ---- per-kernel pass (outside the timed region): more steps with an event pair around every launch wrapper on the context
+    # stream (ifem_kprof: nothing waits until the end of the pass, so the queue runs ahead of the host as in the timed steps)
+    prof_steps = 2
+    solver.kprof_begin()
+    tp0 = time.time()
+    for _ in range(prof_steps):
+        step()
+    solver.synchronize()
+    prof_wall_ms = (time.time() - tp0) / prof_steps * 1e3
+    prof = solver.kprof_end()
     if rank == 0:
-        spmv_avg_ms = spmv_ms / max(spmv_calls, 1)
-        mf_avg_ms = mf_ms / max(mf_calls, 1)
-        # dominant kernel = largest total time per step among the three heavy kernels, each timed live with HIP events
-        totals = {"asm": asm_kernel_ms, "mf": mf_ms / prof_steps, "spmv": spmv_ms / prof_steps}
-        dom = max(totals, key=totals.get)
+        kernels = kernel_table(prof, prof_steps, n, world)
+        kernel_ms_sum = sum(k["ms_per_step"] for k in kernels)
         cached = args.warmup >= 1  # the timed steps keep B, B^T, M_p, diag(M_u), S_m of the warm-up (same constrained-dof set)
         models = kernel_models(solver.L, solver.ctx, n_cells, n_u, n_p, cached_blocks=cached)
-        if dom == "spmv":
-            achieved = tm.spmv_uu_bytes / (spmv_avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_spmv_uu<3,32,%s> (A_uu block-row SpMV of the inner solver)" % ("float" if args.ainv == 1 else "double"),
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic("k_spmv_uu", n, "f32" if args.ainv == 1 else "f64") if world == 1 else None,
-                    "launch_ms": spmv_avg_ms, "launches_timed": spmv_calls, "algorithmic_bytes": tm.spmv_uu_bytes}
-        else:
-            name = {"asm": "k_ins_assemble3 (one wavefront per cell: sum-factorised front, FP64 MFMA contraction, row-image atomic scatter)", "mf": "k_apply_uu_mf2<3,2,float> (matrix-free A_uu of the inner solver, fp32 cell arithmetic)"}[dom]
-            ms = asm_kernel_ms if dom == "asm" else mf_avg_ms
-            nb, nf = models[dom]
+        by_fam = {k["family"]: k for k in kernels}
+        # dominant kernel = the family with the largest time per step; the assembly's launch time is the live HIP-event
+        # measurement of the TIMED steps (ifem_timing::assemble_kernel_ms), the others come from the profiled steps
+        dom = kernels[0]["family"] if kernels else "assemble_cells"
+        if dom == "assemble_cells" or asm_kernel_ms >= kernels[0]["ms_per_step"]:
+            ms = asm_kernel_ms
+            nb, nf = models["asm"]
             gbs, tfs = nb / (ms * 1e-3) / 1e9, nf / (ms * 1e-3) / 1e12
-            # compute ceiling: FP64 matrix cores for the assembly, FP32 vector FMA for the single-precision matrix-free
-            # kernel (there is no matrix-core formulation of its 3-point 1D passes); report against the nearer ceiling,
-            # both fractions stay in the line
-            peak_tf = FP64_PEAK_TFLOPS if dom == "asm" else FP32_VECTOR_PEAK_TFLOPS
-            if tfs / peak_tf >= gbs / HBM_PEAK_GBS:
-                roof = {"bound": "mfma", "achieved": tfs, "peak": peak_tf, "unit": "TFLOP/s", "frac": tfs / peak_tf}
+            roof = {"bound": "mfma", "achieved": tfs, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / FP64_PEAK_TFLOPS,
+                    "kernel": "k_ins_assemble3 (one wavefront per cell: sum-factorised front, FP64 MFMA contraction, row-image atomic scatter)",
+                    "traffic": pmc_traffic("k_ins_assemble3", n, "f64_cached" if cached else "f64"),
+                    "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the 128^3 launch on one GPU"
+                                      + ("" if world == 1 else " (single-rank pass; the per-rank launch of this run is the same kernel on the same block size)"),
+                    "launch_ms": ms, "launches_timed": args.steps, "algorithmic_bytes": nb, "algorithmic_flops": nf,
+                    "hbm_frac": gbs / HBM_PEAK_GBS, "compute_frac": tfs / FP64_PEAK_TFLOPS, "compute_peak": "FP64 MFMA"}
+            # what actually bounds this kernel: the memory-side rate of its f64 atomic requests.  One atomic per
+            # (cell, dof pair) of the velocity-velocity block; the unit retires ~24 G requests of up to 64 bytes per second
+            # whatever the lane count (tools/atomics_types.hip: 23.9 G/s f64, 188 G atomics/s only when 8 lanes share a
+            # segment); the kernel's staged scatter touches 871 segments per cell (tools/scatter_sim.py, CPU replay)
+            n_atom = float(n_cells) * (27 * 3) ** 2
+            n_seg = float(n_cells) * 871.0
+            roof.update({"atomic_adds": n_atom, "atomic_rate_gatom_s": n_atom / (ms * 1e-3) / 1e9, "atomic_peak_gatom_s": 188.0,
+                         "atomic_frac": n_atom / (ms * 1e-3) / 1e9 / 188.0,
+                         "atomic_segments": n_seg, "atomic_segment_rate_g_s": n_seg / (ms * 1e-3) / 1e9, "atomic_segment_peak_g_s": 24.0,
+                         "atomic_segment_frac": n_seg / (ms * 1e-3) / 1e9 / 24.0})
+        else:
+            k = kernels[0]
+            if "compute_frac" in k and k["compute_frac"] >= k["hbm_frac"]:
+                roof = {"bound": "mfma", "achieved": k["tflop_s"], "peak": COMPUTE_PEAK[dom][1], "unit": "TFLOP/s", "frac": k["compute_frac"]}
             else:
-                roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
-            roof.update({"kernel": name, "traffic": pmc_traffic("k_ins_assemble3" if dom == "asm" else "k_apply_uu_mf2", n,
-                                                                 ("f64_cached" if cached else "f64") if dom == "asm" else "f32") if world == 1 else None,
-                         "launch_ms": ms, "launches_timed": args.steps if dom == "asm" else mf_calls,
-                         "algorithmic_bytes": nb, "algorithmic_flops": nf, "hbm_frac": gbs / HBM_PEAK_GBS, "compute_frac": tfs / peak_tf,
-                         "compute_peak": "FP64 MFMA" if dom == "asm" else "FP32 vector FMA",
-                         "kernel_ms_per_step": totals})
-            if dom == "asm":
-                # what actually bounds this kernel: the memory-side rate of its f64 atomic requests.  One atomic per
-                # (cell, dof pair) of the velocity-velocity block; the unit retires ~24 G requests of up to 64 bytes per second
-                # whatever the lane count (tools/atomics_types.hip: 23.9 G/s f64, 188 G atomics/s only when 8 lanes share a
-                # segment); the kernel's staged scatter touches 871 segments per cell (tools/scatter_sim.py, CPU replay)
-                n_atom = float(n_cells) * (27 * 3) ** 2
-                n_seg = float(n_cells) * 871.0
-                roof.update({"atomic_adds": n_atom, "atomic_rate_gatom_s": n_atom / (ms * 1e-3) / 1e9, "atomic_peak_gatom_s": 188.0,
-                             "atomic_frac": n_atom / (ms * 1e-3) / 1e9 / 188.0,
-                             "atomic_segments": n_seg, "atomic_segment_rate_g_s": n_seg / (ms * 1e-3) / 1e9, "atomic_segment_peak_g_s": 24.0,
-                             "atomic_segment_frac": n_seg / (ms * 1e-3) / 1e9 / 24.0})
+                roof = {"bound": "hbm", "achieved": k["gb_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["hbm_frac"]}
+            roof.update({"kernel": k["kernel"], "traffic": k.get("traffic"), "launch_ms": k["ms_per_step"] / max(k["launches_per_step"], 1),
+                         "launches_timed": k["launches_per_step"] * prof_steps, "algorithmic_bytes": k["algorithmic_bytes"],
+                         "algorithmic_flops": k["algorithmic_flops"]})
+        mfk = by_fam.get("mf_cell", {})
+        mf_calls, mf_ms = mfk.get("launches_per_step", 0), mfk.get("ms_per_step", 0.0)
+        roof.update({"kernels": kernels, "kernel_ms_sum": kernel_ms_sum, "profiled_step_ms": prof_wall_ms,
+                     "unattributed_ms": ms_per_step - kernel_ms_sum,
+                     "kernels_note": "one entry per kernel family of the step, from HIP event pairs around every launch wrapper over "
+                                     f"{prof_steps} profiled steps after the timed region (include/ifem_hip.h: ifem_kprof_begin / _end); "
+                                     "unattributed_ms = ms_per_step - kernel_ms_sum: host launch gaps and the waits for reduction results",
+                     "kernel_ms_per_step": {k["family"]: k["ms_per_step"] for k in kernels}})
         out = {
             "metric": "DoF/s per Newton step (assemble+solve), 3D INS Q2/Q1",
             "value": n_dofs_global / (elapsed / args.steps),
@@ -567,6 +677,14 @@ def main():
             solver.opts.mp_rel, solver.opts.sm_rel, solver.opts.outer_matrix_free = keep  # the legs below use the reference's again
         if world == 1 and args.extras:
             out.update(extras(solver, capi, n_dofs_global, ms_per_step))
+            # the three figures side by side: `value` keeps B, B^T, M_p, diag(M_u), S_m of the previous iteration
+            # (same constrained-dof set) and is the FIRST Newton iteration of a step; value_cold re-integrates / re-forms them
+            # inside the step as the reference does in every iteration; value_sustained = DoF x Newton iterations / time of a
+            # whole run_one_step loop from the same state (later iterations need more FGMRES iterations)
+            if "cold_step" in out:
+                out["value_cold"] = out["cold_step"]["value"]
+            if "dofs_per_s_per_iteration" in out.get("time_step", {}):
+                out["value_sustained"] = out["time_step"]["dofs_per_s_per_iteration"]
         if world == 1 and args.fsi:
             # side measurement, last device leg: its Dirichlet-mode call edits the constraint sets of the context
             try:
@@ -579,8 +697,27 @@ def main():
             except Exception as e:  # a side leg must not take the headline line with it
                 out["fsi_inputs"] = {"error": repr(e)}
         cpu_sizes = [int(v) for v in str(args.cpu_n).split(",") if int(v) > 0]
+        cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ifem_cpu_baseline_n1.json")
         if cpu_sizes and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             out["cpu_baseline"] = cpu_baseline(cpu_sizes)
+            try:  # the N > 1 runs that follow on this host quote it instead of repeating it
+                with open(cache, "w") as f:
+                    json.dump(dict(out["cpu_baseline"], measured_unix_time=time.time()), f)
+            except OSError:
+                pass
+        elif world > 1:
+            # measured on rank 0 at N = 1 only: an N > 1 line names the N = 1 sample it re-uses -- the one the --gpus 1 run left on
+            # this host, else the committed one of the round's single-GPU run (profiles/cpu_baseline_n1.json)
+            for path, origin in ((cache, "the --gpus 1 run of this bench on this host"),
+                                 (os.path.join(ROOT, "profiles", "cpu_baseline_n1.json"), "committed sample of the round's 1-GPU run (profiles/cpu_baseline_n1.json)")):
+                try:
+                    with open(path) as f:
+                        cb = json.load(f)
+                    cb["reused_from"] = f"N = 1 sample, not re-measured at N = {world}: {origin}"
+                    out["cpu_baseline"] = cb
+                    break
+                except (OSError, ValueError):
+                    continue
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

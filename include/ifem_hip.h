@@ -213,7 +213,8 @@ enum {
 const char *ifem_last_error(void);
 /* sizeof of the structs above as this library was compiled, for a binding to check its mirror against:
  * 0 ifem_mesh_desc, 1 ifem_partition, 2 ifem_ins_params, 3 ifem_solver_opts, 4 ifem_solve_stats, 5 ifem_scns_params,
- * 6 ifem_timing, 7 ifem_tuning, 8 ifem_mg_transfer, 9 ifem_fsi_solid, 10 ifem_fsi_stats, 11 ifem_comm_stats; -1 for anything else */
+ * 6 ifem_timing, 7 ifem_tuning, 8 ifem_mg_transfer, 9 ifem_fsi_solid, 10 ifem_fsi_stats, 11 ifem_comm_stats, 12 ifem_kprof_entry;
+ * -1 for anything else */
 int64_t ifem_abi_sizeof(int which);
 int ifem_device_count(void);
 void ifem_default_solver_opts(ifem_solver_opts *o);
@@ -495,6 +496,40 @@ typedef struct {
   double mf_ms_avg; uint64_t mf_calls; /* matrix-free A_uu application (IFEM_AINV_GMRES_BJACOBI_MF) */
 } ifem_timing;
 int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t);
+/* Per-kernel-family log of one profiled step -- the reference's TimerOutput sections ("Assemble system", "CG for Mp",
+ * "CG for Sm", "MUMPS for A_inv", "Solve linear system": mpi_insim.cpp:33,70,87,125,155,368) at kernel granularity.
+ * ifem_kprof_begin starts recording: every launch wrapper of the library then brackets its launches with an event pair on the
+ * context stream (all multigrid levels log into the context they hang below); nothing waits for the device until
+ * ifem_kprof_end, which stops recording, waits once, and sums per family: scopes logged, milliseconds, and the ALGORITHMIC
+ * bytes / flops the wrappers state for their launches (DESIGN.md section 4 gives the formulas).  Returns the number of
+ * families written (<= max_entries, families without a launch are skipped). */
+#define IFEM_KC_ASSEMBLE 0      /* the cell kernel (k_ins_assemble3 / k_ins_assemble2) */
+#define IFEM_KC_ZERO_FILL 1     /* system_matrix = 0, system_rhs = 0 (mpi_insim.cpp:163-165) */
+#define IFEM_KC_SPMV_UU 2       /* k_spmv_uu_pipe / k_spmv_uu: the stored fp64 A_uu of the outer operator */
+#define IFEM_KC_SPMV_BBT 3      /* k_spmv_planar on B and B^T (fp64) */
+#define IFEM_KC_MF_CELL 4       /* k_apply_uu_mf2: matrix-free A_uu, cell kernel */
+#define IFEM_KC_MF_GATHER 5     /* k_mf_gather: node gather of the matrix-free product (+ fused smoother update) */
+#define IFEM_KC_SPMV_SM 6       /* k_spmv_planar on S_m */
+#define IFEM_KC_SPMV_MP 7       /* k_spmv_planar on M_p */
+#define IFEM_KC_MDOT 8          /* k_mdot<K>: fused dot products */
+#define IFEM_KC_MAXPY 9         /* k_maxpy<K>: fused multi-axpy */
+#define IFEM_KC_VECTOR 10       /* axpy / axpby / scale / copy / convert / Chebyshev updates */
+#define IFEM_KC_MG_TRANSFER 11  /* k_mg_csr*: prolongation / restriction / injection */
+#define IFEM_KC_SMOOTHER_SETUP 12 /* k_uu_diag, k_bjac_setup, k_block_invert, eigenvalue bounds */
+#define IFEM_KC_CG_RECURRENCE 13 /* k_cgd_*: device-resident CG recurrences */
+#define IFEM_KC_SCHUR_SETUP 14  /* geometry blocks, k_schur_numeric */
+#define IFEM_KC_OTHER 15        /* constraints, hanging nodes, halo packing */
+#define IFEM_KC_COUNT 16
+typedef struct {
+  int32_t family;   /* IFEM_KC_* */
+  uint32_t scopes;  /* launch-wrapper calls logged (a scope may hold two launches, e.g. the two stages of a reduction) */
+  double ms;        /* device time between the scopes' event pairs, summed */
+  double bytes;     /* algorithmic bytes, summed (0: not stated for this family) */
+  double flops;     /* algorithmic flops, summed */
+} ifem_kprof_entry;
+int ifem_kprof_begin(ifem_ctx *ctx);
+int ifem_kprof_end(ifem_ctx *ctx, ifem_kprof_entry *out, int32_t max_entries);
+const char *ifem_kprof_family_name(int32_t family);
 /* on != 0: time every A_uu SpMV launch with HIP events on the context stream (one sync per launch) */
 int ifem_set_profiling(ifem_ctx *ctx, int on);
 /* block until everything queued on the context's stream (and on its halo-exchange stream) has finished: the bracket of

@@ -14,6 +14,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 LIB_PATH = os.path.join(_HERE, "lib", "libifem_hip.so")
 
 VEC_PRESENT, VEC_EVAL, VEC_FSI_ACC, VEC_UPDATE, VEC_RHS, VEC_INCREMENT, VEC_TMP = range(7)
+E_BADPARAM, E_NODEVICE, E_HIP, E_KRYLOV_NOCONV, E_NEWTON_MAXIT, E_COMM = -1, -2, -3, -4, -5, -6  # IFEM_E_*
+E_NODEVICE_EXIT = 66  # exit status of a bench rank that stopped at IFEM_E_NODEVICE (distinct from a Python traceback's 1)
 AINV_GMRES_BJACOBI, AINV_GMRES_BJACOBI_F32, AINV_SCALAR_GMRES, AINV_GMRES_BJACOBI_MF, AINV_MG = range(5)  # IFEM_AINV_*
 
 
@@ -105,6 +107,24 @@ class Timing(C.Structure):
                 ("mf_calls", C.c_uint64)]
 
 
+class KprofEntry(C.Structure):
+    """ifem_kprof_entry"""
+    _fields_ = [("family", C.c_int32), ("scopes", C.c_uint32), ("ms", C.c_double), ("bytes", C.c_double), ("flops", C.c_double)]
+
+
+KC_COUNT = 16  # IFEM_KC_COUNT
+
+
+def kprof_end(L, ctx):
+    """ifem_kprof_end as a dict family name -> {scopes, ms, bytes, flops}"""
+    buf = (KprofEntry * KC_COUNT)()
+    n = L.ifem_kprof_end(ctx, buf, KC_COUNT)
+    if n < 0:
+        raise IfemError(n, L.ifem_last_error().decode())
+    return {L.ifem_kprof_family_name(e.family).decode(): {"scopes": int(e.scopes), "ms": e.ms, "bytes": e.bytes, "flops": e.flops}
+            for e in buf[:n]}
+
+
 EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "ifem_comm_unique_id",
            "ifem_local_world_create", "ifem_local_world_destroy", "ifem_comm_selftest",
            "ifem_ctx_create", "ifem_ctx_destroy", "ifem_n_local_dofs", "ifem_nnz", "ifem_set_constraints",
@@ -116,7 +136,8 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof",
            "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag",
            "ifem_fsi_set_solid", "ifem_fsi_update_indicator", "ifem_fsi_find_fluid_bc", "ifem_fsi_get_stress",
-           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_comm_stats_level", "ifem_true_residual", "ifem_tpp_ilu_probe", "ifem_tpp_override"]
+           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_comm_stats_level", "ifem_true_residual", "ifem_tpp_ilu_probe", "ifem_tpp_override",
+           "ifem_kprof_begin", "ifem_kprof_end", "ifem_kprof_family_name"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -194,6 +215,10 @@ def load():
     L.ifem_tpp_ilu_probe.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.ifem_tpp_override.argtypes = [C.c_void_p, C.c_void_p]
     L.ifem_true_residual.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ifem_kprof_begin.argtypes = [C.c_void_p]
+    L.ifem_kprof_end.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.ifem_kprof_family_name.argtypes = [C.c_int32]
+    L.ifem_kprof_family_name.restype = C.c_char_p
     L.ifem_uu_block_diag.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.ifem_fsi_set_solid.argtypes = [C.c_void_p, C.POINTER(FsiSolid)]
     L.ifem_fsi_update_indicator.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
@@ -229,7 +254,7 @@ class CommStats(C.Structure):  # ifem_comm_stats
 
 
 ABI_STRUCTS = [MeshDesc, Partition, InsParams, SolverOpts, SolveStats, ScnsParams, Timing, Tuning, MgTransfer, FsiSolid, FsiStats,
-               CommStats]
+               CommStats, KprofEntry]
 
 
 def comm_stats(L, ctx, reset=False):

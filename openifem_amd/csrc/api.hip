@@ -77,6 +77,7 @@ int64_t ifem_abi_sizeof(int which) {
   case 9: return sizeof(ifem_fsi_solid);
   case 10: return sizeof(ifem_fsi_stats);
   case 11: return sizeof(ifem_comm_stats);
+  case 12: return sizeof(ifem_kprof_entry);
   default: return -1;
   }
 }
@@ -907,6 +908,45 @@ int ifem_comm_stats_level(ifem_ctx *ctx, int level, ifem_comm_stats *out) {
   try { ifem::comm_stats(c, out, false); } catch (...) { c->mg_coarse = below; throw; }
   c->mg_coarse = below;
   IFEM_API_END
+}
+
+int ifem_kprof_begin(ifem_ctx *ctx) {
+  IFEM_API_BEGIN
+  ifem::KProf &k = ifem::kprof_root(ctx);
+  k.recs.clear();
+  k.used = 0;
+  k.depth = 0;
+  k.on = true;
+  IFEM_API_END
+}
+
+int ifem_kprof_end(ifem_ctx *ctx, ifem_kprof_entry *out, int32_t max_entries) {
+  int written = 0;
+  IFEM_API_BEGIN
+  ifem::KProf &k = ifem::kprof_root(ctx);
+  k.on = false;
+  IFEM_HIP_CHECK(hipSetDevice(ctx->device));
+  IFEM_HIP_CHECK(hipDeviceSynchronize());
+  ifem_kprof_entry acc[IFEM_KC_COUNT];
+  for (int f = 0; f < IFEM_KC_COUNT; ++f) acc[f] = {f, 0u, 0.0, 0.0, 0.0};
+  for (const auto &r : k.recs) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, k.ev[r.e0], k.ev[r.e1]) != hipSuccess) continue; // a scope cut short by an exception
+    ifem_kprof_entry &a = acc[r.cat >= 0 && r.cat < IFEM_KC_COUNT ? r.cat : IFEM_KC_OTHER];
+    a.scopes++; a.ms += ms; a.bytes += r.bytes; a.flops += r.flops;
+  }
+  k.recs.clear();
+  k.used = 0;
+  for (int f = 0; f < IFEM_KC_COUNT && out && written < max_entries; ++f)
+    if (acc[f].scopes) out[written++] = acc[f];
+  return written;
+  IFEM_API_END
+}
+
+const char *ifem_kprof_family_name(int32_t family) {
+  static const char *names[IFEM_KC_COUNT] = {"assemble_cells", "zero_fill", "spmv_uu", "spmv_b_bt", "mf_cell", "mf_gather", "spmv_sm", "spmv_mp",
+                                             "mdot", "maxpy", "vector_ops", "mg_transfer", "smoother_setup", "cg_recurrence", "schur_setup", "other"};
+  return family >= 0 && family < IFEM_KC_COUNT ? names[family] : "?";
 }
 
 int ifem_set_ainv_kind(ifem_ctx *ctx, int kind) { ctx->want_shat = kind == IFEM_AINV_SCALAR_GMRES; return IFEM_OK; }

@@ -543,6 +543,14 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const XT *xu, double *yu, const MfFuseT
     else { static const unsigned cap = grid_for_kernel(reinterpret_cast<const void *>(&k_apply_uu_mf2<D, K, WPB, false, R, XT>));     \
            hipLaunchKernelGGL((k_apply_uu_mf2<D, K, WPB, false, R, XT>), dim3(std::min(cap, g_all)), block, 0, s, a); } }
   if (n_pairs > 0) {
+    // algorithmic traffic of the cell kernel: x, evaluation point (fp64 in HBM), constraint flags once per entry,
+    // the per-cell results once, vertex coordinates and node ids per cell; flops of the sum-factorised passes + the point stage
+    const int64_t nc = a.n_cells - a.first_cell;
+    const int d = ctx->dim, n1 = ctx->kv + 1, npc = 1 << d;
+    const double share = ctx->n_cells > 0 ? double(nc) / double(ctx->n_cells) : 0.0;
+    const double passes = double((2 * d) * d * ctx->nu * n1 * 2 * 2 + d * d * ctx->nu * n1 * 2 * 2);
+    KScope ks(ctx, IFEM_KC_MF_CELL, share * double(n) * (sizeof(XT) + 8 + 1) + double(nc) * (npc * d * 8 + ctx->nu * 4 + ctx->nu * d * sizeof(R)),
+              double(nc) * (passes + ctx->nu * 190.0));
     if (ctx->dim == 3 && ctx->kv == 2) IFEM_MF2(3, 2)
     else if (ctx->dim == 3) IFEM_MF2(3, 1)
     else if (ctx->kv == 2) IFEM_MF2(2, 2)
@@ -552,6 +560,10 @@ static void apply_uu_mf_t(ifem_ctx *ctx, const XT *xu, double *yu, const MfFuseT
   if (part == 1) return; // the node gather follows the boundary cells
   if (time_it) IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
   const MfFuseT<XT> f0 = fuse ? *fuse : MfFuseT<XT>{};
+  // node gather: the per-cell results and the incidence entries once, the node's row pointer; fused form: the inverse node block
+  // (single precision) and the smoother's vectors (mode 1: xs, r read + written, x read; modes 2 / 3: d written too)
+  const double per_node = ctx->dim * double(sizeof(XT)) * (fuse ? (fuse->mode >= 2 ? 6.0 : 5.0) : 2.0) + (fuse ? 4.0 * ctx->dim * ctx->dim : 0.0) + 8.0 + ctx->dim;
+  KScope ksg(ctx, IFEM_KC_MF_GATHER, double(ctx->n_cells) * ctx->nu * (ctx->dim * sizeof(R) + 4.0) + double(ctx->nUo) * per_node);
 #define IFEM_MFG(D, F)                                                                                                 \
   hipLaunchKernelGGL((k_mf_gather<D, R, F, XT>), dim3(unsigned((n / D + 255) / 256)), dim3(256), 0, s, n, ctx->nu, ctx->uinc.rowptr.p, \
                      ctx->uinc.col.p, a.ycell, a.is_c, ctx->bjac.p, fuse ? bjac_f32_ptr(ctx) : nullptr, xu, yu, f0)

@@ -56,6 +56,7 @@ __global__ void k_mask_b(int64_t n_rows, const int64_t *__restrict__ rp, const i
   }
 }
 static void masked_geometry_blocks(ifem_ctx *ctx, int use_nonzero) {
+  KScope ks(ctx, IFEM_KC_SCHUR_SETUP, 16.0 * double(ctx->B.val.n + ctx->Bt.val.n));
   const int w = use_nonzero ? 1 : 0;
   const uint8_t *flags = ctx->has_c[w] ? ctx->is_c[w].p : nullptr;
   hipStream_t s = ctx->stream;
@@ -138,6 +139,9 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
     }
   }
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
+  {
+  KScope ks_fill(ctx, IFEM_KC_ZERO_FILL, 8.0 * ((assemble_system && !geo_only ? double(ctx->Auu.val.n) : 0.0) + double(ctx->vec[IFEM_VEC_RHS].n) +
+                                                (assemble_system && !skip_geo ? double(ctx->Bt.val.n + ctx->B.val.n + ctx->Mp.val.n + ctx->diagMu.n) : 0.0)));
   if (assemble_system) {
     // (a hand-written fill kernel with 16-byte non-temporal stores measures the same 15 ms for the 78 GB at 128^3)
     if (!geo_only) IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
@@ -154,6 +158,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
     IFEM_HIP_CHECK(hipMemsetAsync(ctx->Shat.p, 0, ctx->Shat.n * sizeof(double), s));
   }
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->vec[IFEM_VEC_RHS].p, 0, ctx->vec[IFEM_VEC_RHS].n * sizeof(double), s));
+  }
   AsmArgs A{};
   A.n_cells = ctx->n_cells; A.nUo = ctx->nUo; A.nUl = ctx->nUl; A.nPo = ctx->nPo;
   A.fe = ctx->d_fe.p;
@@ -181,8 +186,20 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   A.n_neumann = p->n_neumann;
   for (int i = 0; i < 8; ++i) { A.neumann_id[i] = p->neumann_id[i]; A.neumann_p[i] = p->neumann_p[i]; }
   IFEM_HIP_CHECK(hipEventRecord(ctx->ev0, s));
+  {
+    // algorithmic traffic / work of the cell kernel: every stored value of the blocks it integrates
+    // written once, the right-hand side, per cell the mesh tables and the three nodal vectors it gathers; flops of the
+    // component-block form: per (node pair, point) dim^2 (2 FMA) + dim (2 FMA) + 5 products (53 flop in 3D), per (velocity
+    // node, pressure node, point) 2 (1 + dim) when B / B^T / M_p are integrated.  MFMA padding is not counted.
+    const double nuu = A.skip_uu || A.rhs_only ? 0.0 : double(ctx->Auu.val.n);
+    const double ngeo = A.skip_geo || A.rhs_only ? 0.0 : double(ctx->Bt.val.n + ctx->B.val.n + ctx->Mp.val.n + ctx->diagMu.n);
+    const int nd = ctx->nu * dim + ctx->np, npc = 1 << dim;
+    const double pair = 2.0 * (2 * dim * dim + 2 * dim) + 5.0; // 24 FMA + 5 products in 3D
+    KScope ks_asm(ctx, IFEM_KC_ASSEMBLE, 8.0 * (nuu + ngeo + double(ctx->nUo) * dim + double(ctx->nPo)) + double(ctx->n_cells) * (npc * dim * 8.0 + (ctx->nu + ctx->np) * 4.0 + 3.0 * nd * 8.0),
+                  double(ctx->n_cells) * ctx->nq * ((nuu > 0 ? double(ctx->nu) * ctx->nu * pair : 0.0) + (ngeo > 0 ? double(ctx->nu) * ctx->np * 2.0 * (1 + dim) : 0.0)));
   if (!launch_ins_assemble3_kernel(ctx, A)) // assemble3.hip: 3D Q2/Q1 on the FP64 matrix cores
     launch_ins_assemble2_kernel(ctx, A);    // assemble2.hip (quadrature-point-outer, register accumulators)
+  }
   IFEM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
   if (unconstrained) return; // the caller copies the blocks away
   if (assemble_system) { ctx->geo_valid = true; ctx->geo_key = geo_key; }

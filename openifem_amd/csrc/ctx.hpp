@@ -212,6 +212,32 @@ struct FsiState {
 } // namespace ifem
 
 namespace ifem {
+// Per-kernel-family timing of one profiled step (ifem_kprof_begin / ifem_kprof_end): every launch wrapper opens a KScope, which
+// records an event pair on the context stream around its launches -- nothing waits until ifem_kprof_end reads them all, so the
+// queue keeps running ahead of the host as in a timed step.  One recorder per level chain: coarse multigrid levels log into
+// the finest level's (they run on its stream).  The reference's counterpart: the TimerOutput sections of InsIM
+// (mpi_insim.cpp:33,70,87,125,155,368).
+struct KProf {
+  bool on = false;
+  int depth = 0; // a scope opened inside another one is part of the outer scope
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+  struct Rec { int cat; uint32_t e0, e1; double bytes, flops; };
+  std::vector<Rec> recs;
+  ~KProf() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+};
+struct KScope {
+  KProf *k = nullptr;
+  hipStream_t s = nullptr;
+  uint32_t e1 = 0;
+  inline KScope(ifem_ctx *ctx, int cat, double bytes = 0, double flops = 0);
+  inline ~KScope();
+  KScope(const KScope &) = delete;
+  KScope &operator=(const KScope &) = delete;
+};
+} // namespace ifem
+
+namespace ifem {
 // one CSR transfer table of the multigrid hierarchy (row-parallel gather on the device)
 struct MgCsr {
   int64_t n_rows = 0;
@@ -368,4 +394,34 @@ struct ifem_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int tight_first_misses = 0, tight_first_backoff = 0; // ifem_solver_opts::inner_rel_first: consecutive misses, qualifying solves left to skip
   double spmv_uu_ms_total = 0;
+  ifem::KProf kprof; // per-kernel-family event log of a profiled step (used on the finest level of a chain only)
 };
+
+namespace ifem {
+inline KProf &kprof_root(ifem_ctx *c) {
+  while (c->mg_fine) c = c->mg_fine;
+  return c->kprof;
+}
+inline KScope::KScope(ifem_ctx *ctx, int cat, double bytes, double flops) {
+  KProf &r = kprof_root(ctx);
+  if (!r.on) return;
+  k = &r;
+  if (r.depth++ > 0) return;
+  s = ctx->stream;
+  while (r.ev.size() < r.used + 2) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { r.depth--; k = nullptr; return; }
+    r.ev.push_back(e);
+  }
+  const uint32_t e0 = uint32_t(r.used);
+  e1 = e0 + 1;
+  r.used += 2;
+  r.recs.push_back({cat, e0, e1, bytes, flops});
+  (void)hipEventRecord(r.ev[e0], s);
+}
+inline KScope::~KScope() {
+  if (!k) return;
+  if (--k->depth > 0) return;
+  (void)hipEventRecord(k->ev[e1], s);
+}
+} // namespace ifem

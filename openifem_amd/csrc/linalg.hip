@@ -282,6 +282,13 @@ void auu_f32_refresh(ifem_ctx *ctx) {
   ctx->auu_f32_valid = true;
 }
 
+// algorithmic bytes of one planar-CSR product: values (vb bytes each) + 4-byte column index per block, row pointer + output
+// per row, the gathered input once per column
+static inline double planar_bytes(const PlanarCsr &M, int64_t rows, int vb, int64_t n_cols, int in_b, int out_b) {
+  const double share = M.n_rows > 0 ? double(rows) / double(M.n_rows) : 0.0;
+  return share * double(M.nnzb) * (double(M.bs) * vb + 4) + double(rows) * (8 + out_b) + double(n_cols) * in_b;
+}
+
 void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool use_f32, int part) {
   const RowPart rp_ = row_part(ctx->Auu, part);
   const int64_t n = rp_.n;
@@ -294,12 +301,18 @@ void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool
   if (ctx->dim == 3 && !use_f32 && IFEM_UU_INTERLEAVED && ctx->tune.spmv_pipe) {
     const int rpb = 16; // rows per block = two per half-wave (measured at 128^3: 8 / 16 / 32 / 64 rows -> 14.4 / 14.4 / 15.1 / 16.0 ms)
     const unsigned nb = unsigned((n + rpb - 1) / rpb);
-    hipLaunchKernelGGL(k_spmv_uu_pipe, dim3(nb), dim3(256), size_t(2 * rpb) * sizeof(int64_t), s, n, ctx->Auu.rowptr.p, ctx->Auu.col.p,
-                       ctx->Auu.val.p, xu, yu, rows, rpb);
-    if (xp && ctx->Bt.n_rows) // + B^T x_p on the same rows
+    {
+      KScope ks(ctx, IFEM_KC_SPMV_UU, planar_bytes(ctx->Auu, n, 8, ctx->nUl, 24, 24));
+      hipLaunchKernelGGL(k_spmv_uu_pipe, dim3(nb), dim3(256), size_t(2 * rpb) * sizeof(int64_t), s, n, ctx->Auu.rowptr.p, ctx->Auu.col.p,
+                         ctx->Auu.val.p, xu, yu, rows, rpb);
+    }
+    if (xp && ctx->Bt.n_rows) { // + B^T x_p on the same rows
+      KScope ks(ctx, IFEM_KC_SPMV_BBT, planar_bytes(ctx->Bt, n, 8, ctx->nPl, 8, 48));
       hipLaunchKernelGGL((k_spmv_planar_add<3, 1, 8>), dim3(blocks_for_rows(n, 8)), dim3(256), 0, s, n, ctx->Bt.rowptr.p, ctx->Bt.col.p,
                          ctx->Bt.val.p, xp, yu, rows);
+    }
   } else if (ctx->dim == 3) {
+    KScope ks(ctx, IFEM_KC_SPMV_UU, planar_bytes(ctx->Auu, n, use_f32 ? 4 : 8, ctx->nUl, 24, 24) + (xp ? planar_bytes(ctx->Bt, n, 8, ctx->nPl, 8, 0) : 0.0));
     const int Gsel = ctx->tune.spmv_lanes;
 #define IFEM_SPMV3(G)                                                                                                  \
   if (use_f32)                                                                                                         \
@@ -311,6 +324,7 @@ void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool
     if (Gsel == 16) { IFEM_SPMV3(16) } else if (Gsel == 64) { IFEM_SPMV3(64) } else if (Gsel == 8) { IFEM_SPMV3(8) } else { IFEM_SPMV3(32) }
 #undef IFEM_SPMV3
   } else {
+    KScope ks(ctx, IFEM_KC_SPMV_UU, planar_bytes(ctx->Auu, n, use_f32 ? 4 : 8, ctx->nUl, 16, 16) + (xp ? planar_bytes(ctx->Bt, n, 8, ctx->nPl, 8, 0) : 0.0));
     constexpr int G = 16;
     if (use_f32)
       hipLaunchKernelGGL((k_spmv_uu<2, G, float>), dim3(blocks_for_rows(n, G)), dim3(256), 0, s, n, ctx->Auu.rowptr.p,
@@ -452,6 +466,7 @@ void spmv_b(ifem_ctx *ctx, const double *xu, double *yp, int part) {
   const RowPart rp_ = row_part(ctx->B, part);
   const int64_t n = rp_.n;
   if (n == 0) return;
+  KScope ks(ctx, IFEM_KC_SPMV_BBT, planar_bytes(ctx->B, n, 8, ctx->nUl, 8 * ctx->dim, 8));
   if (ctx->dim == 3)
     hipLaunchKernelGGL((k_spmv_planar<1, 3, 32>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n,
                        ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, xu, yp, rp_.rows);
@@ -463,6 +478,7 @@ void spmv_b(ifem_ctx *ctx, const double *xu, double *yp, int part) {
 void spmv_bt(ifem_ctx *ctx, const double *xp, double *yu) {
   const int64_t n = ctx->Bt.n_rows;
   if (n == 0) return;
+  KScope ks(ctx, IFEM_KC_SPMV_BBT, planar_bytes(ctx->Bt, n, 8, ctx->nPl, 8, 8 * ctx->dim));
   if (ctx->dim == 3)
     hipLaunchKernelGGL((k_spmv_planar<3, 1, 8>), dim3(blocks_for_rows(n, 8)), dim3(256), 0, ctx->stream, n,
                        ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt.val.p, xp, yu);
@@ -486,6 +502,7 @@ void spmv_b_f32(ifem_ctx *ctx, const double *xu, double *yp) {
   const int64_t n = ctx->B.n_rows;
   if (n == 0) return;
   bbt_f32_refresh(ctx);
+  KScope ks(ctx, IFEM_KC_SPMV_BBT, planar_bytes(ctx->B, n, 4, ctx->nUl, 8 * ctx->dim, 8));
   if (ctx->dim == 3)
     hipLaunchKernelGGL((k_spmv_planar<1, 3, 32, float>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n,
                        ctx->B.rowptr.p, ctx->B.col.p, ctx->B_f32.p, xu, yp);
@@ -497,6 +514,7 @@ void spmv_bt_f32(ifem_ctx *ctx, const double *xp, double *yu) {
   const int64_t n = ctx->Bt.n_rows;
   if (n == 0) return;
   bbt_f32_refresh(ctx);
+  KScope ks(ctx, IFEM_KC_SPMV_BBT, planar_bytes(ctx->Bt, n, 4, ctx->nPl, 8, 8 * ctx->dim));
   if (ctx->dim == 3)
     hipLaunchKernelGGL((k_spmv_planar<3, 1, 8, float>), dim3(blocks_for_rows(n, 8)), dim3(256), 0, ctx->stream, n,
                        ctx->Bt.rowptr.p, ctx->Bt.col.p, ctx->Bt_f32.p, xp, yu);
@@ -508,6 +526,7 @@ void spmv_bt_f32(ifem_ctx *ctx, const double *xp, double *yu) {
 void spmv_app(ifem_ctx *ctx, const double *xp, double *yp) {
   const int64_t n = ctx->Mp.n_rows;
   if (n == 0) return;
+  KScope ks(ctx, IFEM_KC_SPMV_MP, planar_bytes(ctx->Mp, n, 8, ctx->nPl, 8, 8));
   hipLaunchKernelGGL((k_spmv_planar<1, 1, 8>), dim3(blocks_for_rows(n, 8)), dim3(256), 0, ctx->stream, n,
                      ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->App.p, xp, yp);
 }
@@ -562,6 +581,7 @@ void spmv_mp(ifem_ctx *ctx, const double *xp, double *yp, int part, bool use_f32
     ctx->mp_f32_valid = true;
   }
   const unsigned nb = blocks_for_rows(n, 8);
+  KScope ks(ctx, IFEM_KC_SPMV_MP, planar_bytes(ctx->Mp, n, use_f32 ? 4 : 8, ctx->nPl, 8, 8));
   if (use_f32) hipLaunchKernelGGL((k_spmv_planar<1, 1, 8, float>), dim3(nb), dim3(256), 0, ctx->stream, n, ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->Mp_f32.p, xp, yp, rp_.rows);
   else hipLaunchKernelGGL((k_spmv_planar<1, 1, 8>), dim3(nb), dim3(256), 0, ctx->stream, n, ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->Mp.val.p, xp, yp, rp_.rows);
 }
@@ -732,6 +752,7 @@ void schur_numeric(ifem_ctx *ctx) {
   const int64_t n = ctx->Sm.n_rows;
   if (n == 0) return;
   hipStream_t s = ctx->stream;
+  KScope ks(ctx, IFEM_KC_SCHUR_SETUP, 8.0 * double(ctx->Sm.val.n + ctx->B.val.n + ctx->Bt.val.n));
   // With the unconstrained blocks at hand (assemble.hip: B / B^T are masked copies of them) only the rows whose B row touches
   // a constrained dof differ from the S_m of the unconstrained blocks: that one is formed once per mesh, a new set copies it
   // and recomputes the touched rows (a few per cent of them on a box with Dirichlet walls).
@@ -764,6 +785,7 @@ void schur_numeric(ifem_ctx *ctx) {
 void spmv_planar_scalar(ifem_ctx *ctx, const PlanarCsr &M, const double *val, const double *xp, double *yp) {
   const int64_t n = M.n_rows;
   if (n == 0) return;
+  KScope ks(ctx, IFEM_KC_SPMV_SM, planar_bytes(M, n, 8, n, 8, 8));
   hipLaunchKernelGGL((k_spmv_planar<1, 1, 32>), dim3(blocks_for_rows(n, 32)), dim3(256), 0, ctx->stream, n, M.rowptr.p, M.col.p,
                      val, xp, yp);
 }
@@ -780,6 +802,7 @@ void spmv_sm(ifem_ctx *ctx, const double *xp, double *yp, bool use_f32, int part
   const int64_t n = rp_.n;
   if (n == 0) return;
   const int Gs = ctx->tune.sm_lanes;
+  KScope ks(ctx, IFEM_KC_SPMV_SM, planar_bytes(ctx->Sm, n, use_f32 ? 4 : 8, ctx->halo.nranks > 1 ? ctx->halo.n_s_cols : ctx->nPl, 8, 8));
   if (use_f32 && Gs == 64)
     hipLaunchKernelGGL((k_spmv_planar<1, 1, 64, float>), dim3(blocks_for_rows(n, 64)), dim3(256), 0, ctx->stream, n,
                        ctx->Sm.rowptr.p, ctx->Sm.col.p, ctx->Sm_f32.p, xp, yp, rp_.rows);
@@ -818,27 +841,34 @@ __global__ void k_recip(int64_t n, const double *__restrict__ d, double *__restr
 }
 
 void v_axpy(ifem_ctx *ctx, int64_t n, double a, const double *x, double *y) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 24.0 * double(n));
   if (n) hipLaunchKernelGGL(k_axpy, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, x, y);
 }
 void v_axpby(ifem_ctx *ctx, int64_t n, double a, const double *x, double b, double *y) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 24.0 * double(n));
   if (n) hipLaunchKernelGGL(k_axpby, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, x, b, y);
 }
 void v_scale(ifem_ctx *ctx, int64_t n, double a, double *x) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 16.0 * double(n));
   if (n) hipLaunchKernelGGL(k_scale, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, x);
 }
 void v_copy(ifem_ctx *ctx, int64_t n, const double *x, double *y) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 16.0 * double(n));
   if (n) IFEM_HIP_CHECK(hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
 }
 void v_zero(ifem_ctx *ctx, int64_t n, double *x) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 8.0 * double(n));
   if (n) IFEM_HIP_CHECK(hipMemsetAsync(x, 0, n * sizeof(double), ctx->stream));
 }
 void vec_mul(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 24.0 * double(n));
   if (n) hipLaunchKernelGGL(k_mul, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, d, x, y);
 }
 __global__ void k_div(int64_t n, const double *__restrict__ d, const double *__restrict__ x, double *__restrict__ y) {
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] = x[i] / (d[i] != 0.0 ? d[i] : 1.0);
 }
 void vec_div(ifem_ctx *ctx, int64_t n, const double *d, const double *x, double *y) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 24.0 * double(n));
   if (n) hipLaunchKernelGGL(k_div, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, d, x, y);
 }
 void dinv_setup(ifem_ctx *ctx) {
@@ -932,6 +962,9 @@ void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const 
     return;
   }
   const unsigned nblk = vgrid(n);
+  {
+  // every pass of K columns re-reads w; a column that IS w (norms) is counted once
+  KScope ks(ctx, IFEM_KC_MDOT, 8.0 * double(n) * (double(k) + double((k + 7) / 8) - (V == w ? 1.0 : 0.0)), 2.0 * double(n) * k);
   int k0 = 0;
   while (k0 < k && n > 0) {
     const int r = k - k0;
@@ -941,6 +974,7 @@ void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const 
     else { hipLaunchKernelGGL((k_mdot<1>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, w, ctx->partials.p); k0 += 1; }
   }
   hipLaunchKernelGGL(k_reduce_final, dim3(k), dim3(256), 0, s, (int)nblk, ctx->partials.p, ctx->scal.p);
+  }
   if (all_ranks) allreduce_sum_dev(ctx, ctx->scal.p, k);
   IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->scal.p, k * sizeof(double), hipMemcpyDeviceToHost, s));
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
@@ -957,6 +991,8 @@ void v_maxpy(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const
   // coefficients go through the second half of the scalar buffer
   for (int i = 0; i < k; ++i) ctx->h_scal[64 + i] = h_host[i];
   IFEM_HIP_CHECK(hipMemcpyAsync(ctx->scal.p + 64, ctx->h_scal + 64, k * sizeof(double), hipMemcpyHostToDevice, s));
+  {
+  KScope ks(ctx, IFEM_KC_MAXPY, 8.0 * double(n) * (double(k) + 2.0 * double((k + 7) / 8)), 2.0 * double(n) * k);
   int k0 = 0;
   while (k0 < k) {
     const int r = k - k0;
@@ -964,6 +1000,7 @@ void v_maxpy(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const
     else if (r >= 4) { hipLaunchKernelGGL((k_maxpy<4>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, ctx->scal.p + 64, w); k0 += 4; }
     else if (r >= 2) { hipLaunchKernelGGL((k_maxpy<2>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, ctx->scal.p + 64, w); k0 += 2; }
     else { hipLaunchKernelGGL((k_maxpy<1>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, ctx->scal.p + 64, w); k0 += 1; }
+  }
   }
   // h_scal[64..] must stay untouched until the copy has been consumed
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
@@ -1015,6 +1052,8 @@ void v_mdot_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, con
   if (pad4(k) > 64) throw Error(IFEM_E_BADPARAM, "single-precision basis: at most 64 vectors");
   const unsigned nblk = vgrid(n);
   const int kp = pad4(k);
+  {
+  KScope ks(ctx, IFEM_KC_MDOT, double(n) * (4.0 * kp + 8.0 * ((kp + 15) / 16)), 2.0 * double(n) * k);
   for (int k0 = 0; k0 < kp;) {
     const int r = kp - k0;
     if (r >= 16) { hipLaunchKernelGGL((k_mdot_f32<16>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, w, ctx->partials.p); k0 += 16; }
@@ -1023,6 +1062,7 @@ void v_mdot_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, con
     else { hipLaunchKernelGGL((k_mdot_f32<4>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, w, ctx->partials.p); k0 += 4; }
   }
   hipLaunchKernelGGL(k_reduce_final, dim3(k), dim3(256), 0, s, (int)nblk, ctx->partials.p, ctx->scal.p);
+  }
   IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->scal.p, k * sizeof(double), hipMemcpyDeviceToHost, s));
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
   for (int i = 0; i < k; ++i) out_host[i] = ctx->h_scal[i];
@@ -1039,6 +1079,8 @@ void v_maxpy_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, co
   const unsigned nblk = vgrid(n);
   double *part = ctx->partials.p;
   const double *hd = ctx->scal.p + 64;
+  {
+  KScope ks(ctx, IFEM_KC_MAXPY, double(n) * (4.0 * kp + 16.0 * ((kp + 15) / 16)), 2.0 * double(n) * k);
 #define IFEM_MAXPY(K)                                                                                                  \
   { if (last && norm2_out) hipLaunchKernelGGL((k_maxpy_f32<K, true>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, hd, w, part, 0); \
     else hipLaunchKernelGGL((k_maxpy_f32<K, false>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, hd, w, part, 0);        \
@@ -1050,6 +1092,7 @@ void v_maxpy_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, co
     if (step == 16) IFEM_MAXPY(16) else if (step == 12) IFEM_MAXPY(12) else if (step == 8) IFEM_MAXPY(8) else IFEM_MAXPY(4)
   }
 #undef IFEM_MAXPY
+  }
   if (norm2_out) {
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, (int)nblk, part, ctx->scal.p);
     IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1059,6 +1102,7 @@ void v_maxpy_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, co
 }
 
 void v_scale_store_f32(ifem_ctx *ctx, int64_t n, double a, const double *w, float *v) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 12.0 * double(n));
   if (n) hipLaunchKernelGGL(k_scale_store_f32, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, w, v);
 }
 
@@ -1136,17 +1180,20 @@ __global__ void k_cgd_p(int64_t n, const double *__restrict__ sc, const double *
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) p[i] = z[i] + be * p[i];
 }
 void cgd_init(ifem_ctx *ctx, int64_t n, const double *b, const double *diag, double *x, double *r, double *z, double *p) {
+  KScope ks(ctx, IFEM_KC_CG_RECURRENCE, double(n) * (diag ? 48.0 : 32.0));
   if (ctx->partials.n == 0) ctx->partials.alloc(size_t(64) * MDOT_MAXB);
   const unsigned nblk = vgrid(n);
   hipLaunchKernelGGL(k_cgd_init, dim3(nblk), dim3(256), 0, ctx->stream, n, b, diag, x, r, z, p, ctx->partials.p);
   cgd_scalars(ctx, nblk, 0);
 }
 void cgd_alpha(ifem_ctx *ctx, int64_t n, const double *p, const double *q) {
+  KScope ks(ctx, IFEM_KC_CG_RECURRENCE, 16.0 * double(n));
   const unsigned nblk = vgrid(n);
   hipLaunchKernelGGL((k_mdot<1>), dim3(nblk), dim3(256), 0, ctx->stream, n, 0, p, n, q, ctx->partials.p);
   cgd_scalars(ctx, nblk, 1);
 }
 void cgd_update(ifem_ctx *ctx, int64_t n, const double *diag, double *p, const double *q, double *x, double *r, double *z) {
+  KScope ks(ctx, IFEM_KC_CG_RECURRENCE, double(n) * (diag ? 88.0 : 64.0));
   const unsigned nblk = vgrid(n);
   hipLaunchKernelGGL(k_cgd_update, dim3(nblk), dim3(256), 0, ctx->stream, n, ctx->scal.p, diag, p, q, x, r, z, ctx->partials.p);
   cgd_scalars(ctx, nblk, 2);
@@ -1271,6 +1318,7 @@ void bjac_apply_f32(ifem_ctx *ctx, const float *x, double *y) {
   const int64_t n = ctx->nUo;
   if (!n) return;
   (void)bjac_f32_ptr(ctx);
+  KScope ks(ctx, IFEM_KC_VECTOR, double(n) * ctx->dim * (4.0 * ctx->dim + 4 + 8));
   if (ctx->dim == 3)
     hipLaunchKernelGGL((k_bjac_apply_f32<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ctx->bjac_f32.p, x, y);
   else
@@ -1281,6 +1329,7 @@ void bjac_setup(ifem_ctx *ctx) {
   ctx->bjac_f32_valid = false;
   const int64_t n = ctx->nUo;
   if (!n) return;
+  KScope ks(ctx, IFEM_KC_SMOOTHER_SETUP, double(n) * ctx->dim * ctx->dim * 16.0);
   if (ctx->dim == 3)
     hipLaunchKernelGGL((k_bjac_setup<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
                        ctx->Auu.rowptr.p, ctx->uu_diag_pos.p, ctx->Auu.val.p, ctx->bjac.p);
@@ -1292,6 +1341,7 @@ void bjac_setup(ifem_ctx *ctx) {
 void bjac_apply(ifem_ctx *ctx, const double *x, double *y) {
   const int64_t n = ctx->nUo;
   if (!n) return;
+  KScope ks(ctx, IFEM_KC_VECTOR, double(n) * ctx->dim * (8.0 * ctx->dim + 16));
   if (ctx->dim == 3)
     hipLaunchKernelGGL((k_bjac_apply<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ctx->bjac.p, x, y);
   else
@@ -1311,6 +1361,7 @@ __global__ void k_apply_constraints(int64_t n_u_owned, int64_t n_owned, int64_t 
 void apply_constraints(ifem_ctx *ctx, int which, double *x) {
   if (!ctx->has_c[which]) return;
   const int64_t nuo = ctx->dim * ctx->nUo, n = nuo + ctx->nPo;
+  KScope ks(ctx, IFEM_KC_OTHER, double(n));
   hipLaunchKernelGGL(k_apply_constraints, dim3(vgrid(n)), dim3(256), 0, ctx->stream, nuo, n, ctx->dim * ctx->nUl,
                      ctx->is_c[which].p, ctx->cval[which].p, x);
 }

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void k_mg_csr(int64_t n_rows, const int64_t *_
 
 void mg_csr_apply(ifem_ctx *ctx, const MgCsr &M, const double *x, double *y, bool add) {
   if (!M.n_rows) return;
+  KScope ks(ctx, IFEM_KC_MG_TRANSFER, double(M.col.n) * 20.0 + double(M.n_rows) * 16.0);
   if (add) hipLaunchKernelGGL((k_mg_csr<true>), dim3(mgrid(M.n_rows)), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, M.w.p, x, y);
   else hipLaunchKernelGGL((k_mg_csr<false>), dim3(mgrid(M.n_rows)), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, M.w.p, x, y);
 }
@@ -47,9 +48,11 @@ __global__ void k_cheb_step(int64_t n, double a, double b, const double *__restr
   }
 }
 void cheb_init(ifem_ctx *ctx, int64_t n, double c0, const double *dinv, const double *r, double *d) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 24.0 * double(n));
   if (n) hipLaunchKernelGGL(k_cheb_init, dim3(mgrid(n)), dim3(256), 0, ctx->stream, n, c0, dinv, r, d);
 }
 void cheb_step(ifem_ctx *ctx, int64_t n, double a, double b, const double *dinv, const double *t, double *x, double *r, double *d) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 64.0 * double(n));
   if (n) hipLaunchKernelGGL(k_cheb_step, dim3(mgrid(n)), dim3(256), 0, ctx->stream, n, a, b, dinv, t, x, r, d);
 }
 
@@ -273,6 +276,7 @@ void uu_block_diag_mf(ifem_ctx *ctx) {
   ctx->bjac_f32_valid = false;
   if (!n) return;
   hipStream_t s = ctx->stream;
+  KScope ks(ctx, IFEM_KC_SMOOTHER_SETUP, double(ctx->n_cells) * ctx->nu * dim * dim * 8.0 + double(n) * dim * dim * 24.0);
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->bjac.p, 0, ctx->bjac.n * sizeof(double), s));
   DiagArgs a{};
   a.n_cells = ctx->n_cells; a.nUo = ctx->nUo;
@@ -323,6 +327,7 @@ __global__ void k_mg_mask(int64_t n_rows, const int64_t *__restrict__ ptr, const
 void mg_csr_mask(ifem_ctx *ctx, const MgCsr &M, const uint8_t *flag_in, const uint8_t *flag_out, DBuf<uint8_t> &mask) {
   if (!M.n_rows) return;
   if (mask.n != M.col.n) mask.alloc(M.col.n);
+  KScope ks(ctx, IFEM_KC_MG_TRANSFER, double(M.col.n) * 8.0);
   if (ctx->dim == 3) hipLaunchKernelGGL((k_mg_mask<3>), dim3(mgrid(M.n_rows)), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, flag_in, flag_out, mask.p);
   else hipLaunchKernelGGL((k_mg_mask<2>), dim3(mgrid(M.n_rows)), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, flag_in, flag_out, mask.p);
 }
@@ -367,6 +372,8 @@ static void launch_csr_nodes(ifem_ctx *ctx, const MgCsr &M, const V *x, const ui
   const double mean = double(M.col.n) / double(M.n_rows);
   const int g = mean <= 6 ? 4 : (mean <= 12 ? 8 : (mean <= 24 ? 16 : 32));
   const unsigned blocks = unsigned((M.n_rows * g + 255) / 256);
+  // weights (8 B) + column (4) + mask (1) per entry; per row its pointer and DIM outputs; the gathered input is re-used from cache
+  KScope ks(ctx, IFEM_KC_MG_TRANSFER, double(M.col.n) * 13.0 + double(M.n_rows) * (8.0 + DIM * sizeof(V)));
 #define IFEM_CSRN(G) hipLaunchKernelGGL((k_mg_csr_nodes<DIM, G, V>), dim3(blocks), dim3(256), 0, ctx->stream, M.n_rows, M.ptr.p, M.col.p, M.w.p, x, mask, y)
   if (g == 4) IFEM_CSRN(4); else if (g == 8) IFEM_CSRN(8); else if (g == 16) IFEM_CSRN(16); else IFEM_CSRN(32);
 #undef IFEM_CSRN
@@ -394,6 +401,7 @@ __global__ void k_mg_inject(int64_t n_nodes, int dim, const int32_t *__restrict_
   }
 }
 void mg_inject_nodes(ifem_ctx *ctx, int64_t n_nodes, const int32_t *inj, const double *fine, double *coarse) {
+  KScope ks(ctx, IFEM_KC_MG_TRANSFER, double(n_nodes) * (4.0 + 16.0 * ctx->dim));
   if (n_nodes) hipLaunchKernelGGL(k_mg_inject, dim3(mgrid(n_nodes * ctx->dim)), dim3(256), 0, ctx->stream, n_nodes, ctx->dim, inj, fine, coarse);
 }
 
@@ -420,6 +428,7 @@ static void cheb_init_block_t(ifem_ctx *ctx, double c0, const V *r, V *d) {
   if (!n) return;
   const dim3 g(unsigned((n + 255) / 256)), b(256);
   const float *bjf = bjac_f32_ptr(ctx);
+  KScope ks(ctx, IFEM_KC_VECTOR, double(n) * ctx->dim * (4.0 * ctx->dim + 2.0 * sizeof(V)));
   if (ctx->dim == 3) hipLaunchKernelGGL((k_cheb_init_block<3, V>), g, b, 0, ctx->stream, n, c0, bjf, r, d);
   else hipLaunchKernelGGL((k_cheb_init_block<2, V>), g, b, 0, ctx->stream, n, c0, bjf, r, d);
 }
@@ -437,12 +446,15 @@ __global__ void k_axpy_f32v(int64_t n, float a, const float *__restrict__ x, flo
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] += a * x[i];
 }
 void v_cvt_d2f(ifem_ctx *ctx, int64_t n, const double *x, float *y) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 12.0 * double(n));
   if (n) hipLaunchKernelGGL(k_cvt_d2f, dim3(mgrid(n)), dim3(256), 0, ctx->stream, n, x, y);
 }
 void v_cvt_f2d(ifem_ctx *ctx, int64_t n, const float *x, double *y) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 12.0 * double(n));
   if (n) hipLaunchKernelGGL(k_cvt_f2d, dim3(mgrid(n)), dim3(256), 0, ctx->stream, n, x, y);
 }
 void v_axpy_f32v(ifem_ctx *ctx, int64_t n, float a, const float *x, float *y) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 12.0 * double(n));
   if (n) hipLaunchKernelGGL(k_axpy_f32v, dim3(mgrid(n)), dim3(256), 0, ctx->stream, n, a, x, y);
 }
 } // namespace ifem

@@ -362,6 +362,16 @@ class FluidSolver:
     def set_profiling(self, on=True):
         self.L.ifem_set_profiling(self.ctx, int(on))
 
+    def kprof_begin(self):
+        """start the per-kernel-family event log of the level chain (ifem_kprof_begin)"""
+        rc = self.L.ifem_kprof_begin(self.ctx)
+        if rc < 0:
+            raise HostError(rc, self.L.ifem_last_error().decode())
+
+    def kprof_end(self):
+        """stop it: {family: {scopes, ms, bytes, flops}} (ifem_kprof_end)"""
+        return capi.kprof_end(self.L, self.ctx)
+
     def synchronize(self):
         rc = self.L.ifem_synchronize(self.ctx)
         if rc < 0:

@@ -41,6 +41,9 @@ def _worker(rank, world, port, P, reps, dim, q):
             s.setup_host_only(0)
         t = s.partition_tables()
         nUo, nUl, nPo, nPl = t["n_unodes_owned"], t["n_unodes_local"], t["n_pnodes_owned"], t["n_pnodes_local"]
+        if tuple(P) == (2, 2, 2):
+            # the north-star octant split: every rank talks to 3 face + 3 edge + 1 corner neighbours
+            assert sorted(int(v) for v in t["neighbors"]) == [r for r in range(8) if r != rank], t["neighbors"]
         # (a) every global node is owned by exactly one rank
         for key, no, ng in (("l2g_u", nUo, t["n_unodes_global"]), ("l2g_p", nPo, t["n_pnodes_global"])):
             cnt = torch.zeros(ng, dtype=torch.int64)
@@ -139,7 +142,8 @@ def _worker(rank, world, port, P, reps, dim, q):
 
 
 @pytest.mark.parametrize("world,P,reps,dim", [(2, (2, 1, 1), (4, 2, 2), 3), (4, (2, 2, 1), (4, 4, 2), 3), (2, (2, 1), (6, 3), 2),
-                                               (4, (2, 2, 1), (8, 6, 3), 3), (2, (2, 1, 1), "cylinder", 2), (3, (3, 1, 1), "cylinder", 2)])
+                                               (4, (2, 2, 1), (8, 6, 3), 3), (2, (2, 1, 1), "cylinder", 2), (3, (3, 1, 1), "cylinder", 2),
+                                               (8, (2, 2, 2), (4, 4, 4), 3)])
 def test_block_partition_over_gloo(world, P, reps, dim):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
