@@ -486,6 +486,11 @@ int ifem_tpp_override(ifem_ctx *ctx, const double *val);
  * The columns of a row are NOT sorted in general: 3D Q2/Q1 contexts store the velocity-velocity blocks of a row in scatter
  * order (ifem_tuning::uu_row_order); every (row, column) appears once. */
 int ifem_export_csr(ifem_ctx *ctx, int which, int64_t *rowptr, int32_t *col, double *val);
+/* The same for the rows [row0, row0 + nrows) only: rowptr has nrows + 1 entries and starts at 0; only the slices of the device
+ * arrays these rows own are downloaded (at 128^3 the whole A_uu is 78 GB).  Call with col = val = NULL first to size the arrays
+ * (nnz = rowptr[nrows]).  A parity test's window onto a bench-size system: a slab of rows against the oracle's assembly of the
+ * cells that touch it (the reference's counterpart: one rank's rows of system_matrix, mpi_insim.cpp:343-361). */
+int ifem_export_rows(ifem_ctx *ctx, int which, int64_t row0, int64_t nrows, int64_t *rowptr, int32_t *col, double *val);
 
 /* per-kernel timing of the last assemble/solve, HIP events on the context stream */
 typedef struct {

@@ -137,7 +137,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag",
            "ifem_fsi_set_solid", "ifem_fsi_update_indicator", "ifem_fsi_find_fluid_bc", "ifem_fsi_get_stress",
            "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_comm_stats_level", "ifem_true_residual", "ifem_tpp_ilu_probe", "ifem_tpp_override",
-           "ifem_kprof_begin", "ifem_kprof_end", "ifem_kprof_family_name"]
+           "ifem_kprof_begin", "ifem_kprof_end", "ifem_kprof_family_name", "ifem_export_rows"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -187,6 +187,7 @@ def load():
     L.ifem_mass_vmult.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.ifem_precond_vmult.argtypes = [C.c_void_p, C.POINTER(InsParams), C.POINTER(SolverOpts), C.c_int, C.c_int]
     L.ifem_export_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifem_export_rows.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifem_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.ifem_comm_unique_id.argtypes = [C.c_void_p]
     L.ifem_local_world_create.restype = C.c_void_p
@@ -255,6 +256,19 @@ class CommStats(C.Structure):  # ifem_comm_stats
 
 ABI_STRUCTS = [MeshDesc, Partition, InsParams, SolverOpts, SolveStats, ScnsParams, Timing, Tuning, MgTransfer, FsiSolid, FsiStats,
                CommStats, KprofEntry]
+
+
+def export_rows(L, ctx, row0, nrows, which=0):
+    """ifem_export_rows: (rowptr, col, val) of the rows [row0, row0 + nrows) of the local [u|p] system"""
+    rp = np.zeros(nrows + 1, np.int64)
+    rc = L.ifem_export_rows(ctx, which, row0, nrows, _ptr(rp), None, None)
+    if rc < 0:
+        raise IfemError(rc, L.ifem_last_error().decode())
+    col, val = np.zeros(rp[-1], np.int32), np.zeros(rp[-1])
+    rc = L.ifem_export_rows(ctx, which, row0, nrows, _ptr(rp), _ptr(col), _ptr(val))
+    if rc < 0:
+        raise IfemError(rc, L.ifem_last_error().decode())
+    return rp, col, val
 
 
 def comm_stats(L, ctx, reset=False):
@@ -651,6 +665,9 @@ class Context:
         val = np.zeros(rp[-1])
         self._chk(self.L.ifem_export_csr(self.h, which, _ptr(rp), _ptr(col), _ptr(val)))
         return sp.csr_matrix((val, col, rp), shape=(n, self.n_local))
+
+    def export_rows(self, row0, nrows, which=0):
+        return export_rows(self.L, self.h, row0, nrows, which)
 
     def timing(self):
         t = Timing()

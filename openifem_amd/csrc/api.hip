@@ -59,6 +59,19 @@ void constraint_set_identity(ifem_ctx *ctx, int which, bool differs_self, bool d
 }
 } // namespace ifem
 
+namespace {
+template <typename T>
+std::vector<T> download_range(const ifem::DBuf<T> &b, int64_t off, int64_t count, hipStream_t s) {
+  if (off < 0 || count < 0 || size_t(off + count) > b.n) throw ifem::Error(IFEM_E_BADPARAM, "ifem_export_rows: slice outside its array");
+  std::vector<T> h((size_t)count);
+  if (count) {
+    IFEM_HIP_CHECK(hipMemcpyAsync(h.data(), b.p + off, size_t(count) * sizeof(T), hipMemcpyDeviceToHost, s));
+    IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  return h;
+}
+} // namespace
+
 extern "C" {
 
 const char *ifem_last_error(void) { return g_err.c_str(); }
@@ -879,6 +892,88 @@ int ifem_export_csr(ifem_ctx *ctx, int which, int64_t *rowptr, int32_t *col, dou
       col[o] = int32_t(poff + cM[ms + k]);
       val[o] = (which == 0) ? (ctx->has_app ? vApp[ms + k] : 0.0) : vM[ms + k];
       ++o;
+    }
+  }
+  IFEM_API_END
+}
+
+// rows [row0, row0 + nrows) of the CSR ifem_export_csr describes, downloading only the slices of the device arrays those rows own
+// (the whole A_uu of the 128^3 channel is 78 GB: ifem_export_csr cannot be called there)
+int ifem_export_rows(ifem_ctx *ctx, int which, int64_t row0, int64_t nrows, int64_t *rowptr, int32_t *col, double *val) {
+  IFEM_API_BEGIN
+  hipStream_t s = ctx->stream;
+  const int dim = ctx->dim, bs = dim * dim;
+  const int64_t nuo = dim * ctx->nUo, npo = ctx->nPo, n = nuo + npo, poff = dim * ctx->nUl;
+  if (!rowptr || row0 < 0 || nrows < 0 || row0 + nrows > n) throw Error(IFEM_E_BADPARAM, "ifem_export_rows: row range outside the local system");
+  rowptr[0] = 0;
+  // ---- velocity rows: nodes A0 .. A1-1 cover them
+  const int64_t u0 = std::min(row0, nuo), u1 = std::min(row0 + nrows, nuo);
+  if (u1 > u0) {
+    const int64_t A0 = u0 / dim, A1 = (u1 + dim - 1) / dim;
+    auto rpA = download_range(ctx->Auu.rowptr, A0, A1 - A0 + 1, s), rpT = download_range(ctx->Bt.rowptr, A0, A1 - A0 + 1, s);
+    for (int64_t r = u0; r < u1; ++r) {
+      const int64_t a = r / dim - A0;
+      rowptr[r - row0 + 1] = rowptr[r - row0] + (rpA[a + 1] - rpA[a]) * dim + (rpT[a + 1] - rpT[a]);
+    }
+    if (col && val) {
+      const int64_t b0 = rpA[0], b1 = rpA[A1 - A0], t0 = rpT[0], t1 = rpT[A1 - A0];
+      auto cA = download_range(ctx->Auu.col, b0, b1 - b0, s);
+      auto vA = download_range(ctx->Auu.val, b0 * bs, (b1 - b0) * bs, s);
+      auto cT = download_range(ctx->Bt.col, t0, t1 - t0, s);
+      auto vT = download_range(ctx->Bt.val, t0 * dim, (t1 - t0) * dim, s);
+      auto dM = download_range(ctx->diagMu, A0 * dim, (A1 - A0) * dim, s);
+      for (int64_t r = u0; r < u1; ++r) {
+        const int64_t A = r / dim, a = A - A0;
+        const int c = int(r % dim);
+        const int64_t rs = rpA[a], len = rpA[a + 1] - rs, ts = rpT[a], tlen = rpT[a + 1] - ts;
+        int64_t o = rowptr[r - row0];
+        for (int64_t k = 0; k < len; ++k)
+          for (int d = 0; d < dim; ++d) {
+            col[o] = cA[rs - b0 + k] * dim + d;
+            if (which == 0) val[o] = vA[uu_base(rs, len, k, bs) + (c * dim + d) * uu_estride(len) - b0 * bs];
+            else val[o] = (cA[rs - b0 + k] == A && c == d) ? dM[a * dim + c] : 0.0;
+            ++o;
+          }
+        for (int64_t k = 0; k < tlen; ++k) {
+          col[o] = int32_t(poff + cT[ts - t0 + k]);
+          val[o] = (which == 0) ? vT[ts * dim + c * tlen + k - t0 * dim] : 0.0;
+          ++o;
+        }
+      }
+    }
+  }
+  // ---- pressure rows
+  const int64_t p0 = std::max(row0, nuo) - nuo, p1 = row0 + nrows - nuo;
+  if (p1 > p0) {
+    auto rpB = download_range(ctx->B.rowptr, p0, p1 - p0 + 1, s), rpM = download_range(ctx->Mp.rowptr, p0, p1 - p0 + 1, s);
+    for (int64_t i = p0; i < p1; ++i) {
+      const int64_t j = i - p0, r = nuo + i - row0;
+      rowptr[r + 1] = rowptr[r] + (rpB[j + 1] - rpB[j]) * dim + (rpM[j + 1] - rpM[j]);
+    }
+    if (col && val) {
+      const int64_t b0 = rpB[0], b1 = rpB[p1 - p0], m0 = rpM[0], m1 = rpM[p1 - p0];
+      auto cB = download_range(ctx->B.col, b0, b1 - b0, s);
+      auto vB = download_range(ctx->B.val, b0 * dim, (b1 - b0) * dim, s);
+      auto cM = download_range(ctx->Mp.col, m0, m1 - m0, s);
+      auto vM = download_range(ctx->Mp.val, m0, m1 - m0, s);
+      std::vector<double> vApp;
+      if (ctx->has_app) vApp = download_range(ctx->App, m0, m1 - m0, s);
+      for (int64_t i = p0; i < p1; ++i) {
+        const int64_t j = i - p0;
+        const int64_t rs = rpB[j], len = rpB[j + 1] - rs, ms = rpM[j], mlen = rpM[j + 1] - ms;
+        int64_t o = rowptr[nuo + i - row0];
+        for (int64_t k = 0; k < len; ++k)
+          for (int d = 0; d < dim; ++d) {
+            col[o] = cB[rs - b0 + k] * dim + d;
+            val[o] = (which == 0) ? vB[rs * dim + d * len + k - b0 * dim] : 0.0;
+            ++o;
+          }
+        for (int64_t k = 0; k < mlen; ++k) {
+          col[o] = int32_t(poff + cM[ms - m0 + k]);
+          val[o] = (which == 0) ? (ctx->has_app ? vApp[ms - m0 + k] : 0.0) : vM[ms - m0 + k];
+          ++o;
+        }
+      }
     }
   }
   IFEM_API_END

@@ -46,10 +46,21 @@ struct DBuf { // owning device buffer
     std::swap(p, o.p);
     std::swap(n, o.n);
   }
-  void alloc(size_t count) {
+  // `what` names the array in the error message of a failed allocation (an over-sized mesh must say which table did not fit)
+  void alloc(size_t count, const char *what = nullptr) {
     release();
+    if (!count) return;
+    const hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    if (e != hipSuccess) {
+      p = nullptr;
+      (void)hipGetLastError(); // the failed allocation must not poison the next call's error check
+      size_t fr = 0, tot = 0;
+      (void)hipMemGetInfo(&fr, &tot);
+      throw ::ifem::Error(IFEM_E_HIP, std::string("hipMalloc of ") + std::to_string(count * sizeof(T)) + " bytes for " + (what ? what : "a device array") +
+                                          " (" + std::to_string(count) + " x " + std::to_string(sizeof(T)) + " B): " + hipGetErrorString(e) + "; device memory free " +
+                                          std::to_string(fr >> 20) + " of " + std::to_string(tot >> 20) + " MiB");
+    }
     n = count;
-    if (count) IFEM_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
   }
   void upload(const T *h, size_t count, hipStream_t s) {
     alloc(count);

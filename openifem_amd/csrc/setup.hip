@@ -72,7 +72,7 @@ static int grid_for(int64_t n) {
 static void pattern_from_keys(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_rows_owned, DBuf<uint64_t> &k0, int64_t N) {
   hipStream_t s = ctx->stream;
   DBuf<uint64_t> k1;
-  k1.alloc(N);
+  k1.alloc(N, "the (row, column) keys of the sparsity pattern");
   size_t tmp_bytes = 0;
   IFEM_HIP_CHECK(rocprim::radix_sort_keys(nullptr, tmp_bytes, k0.p, k1.p, (size_t)N, 0, 64, s));
   DBuf<char> tmp;
@@ -97,7 +97,7 @@ static void pattern_from_keys(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_row
   M.n_rows = n_rows_owned;
   M.nnzb = nnzb;
   M.bs = bs;
-  M.col.alloc(nnzb);
+  M.col.alloc(nnzb, "the column indices of a block of the sparsity pattern");
   DBuf<int64_t> rowcnt;
   rowcnt.alloc(n_rows_owned + 1);
   IFEM_HIP_CHECK(hipMemsetAsync(rowcnt.p, 0, (n_rows_owned + 1) * 8, s));
@@ -119,7 +119,7 @@ static void pattern_from_keys(ifem_ctx *ctx, PlanarCsr &M, int bs, int64_t n_row
     M.max_row = (int)mx;
   }
   if (bs > 0 && &M != &ctx->Auu) { // bs == 0: pattern only (incidence lists); A_uu values: see ensure_auu_values
-    M.val.alloc((size_t)nnzb * bs);
+    M.val.alloc((size_t)nnzb * bs, "the values of a block of system_matrix (B, B^T or M_p)");
     IFEM_HIP_CHECK(hipMemsetAsync(M.val.p, 0, (size_t)nnzb * bs * sizeof(double), s));
   }
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
@@ -308,7 +308,7 @@ void ensure_auu_values(ifem_ctx *ctx) {
   if (ctx->tune.uu_row_order && ctx->dim == 3 && ctx->kv == 2 && M.val.n == 0) reorder_uu_rows(ctx);
   ctx->uu_diag_pos.alloc((size_t)M.n_rows + 1);
   if (M.n_rows) hipLaunchKernelGGL(k_diag_pos, dim3(unsigned((M.n_rows + 255) / 256)), dim3(256), 0, ctx->stream, M.n_rows, M.rowptr.p, M.col.p, ctx->uu_diag_pos.p);
-  M.val.alloc(n);
+  M.val.alloc(n, "the values of A_uu (system_matrix.block(0, 0))");
   IFEM_HIP_CHECK(hipMemsetAsync(M.val.p, 0, n * sizeof(double), ctx->stream));
 }
 

@@ -8,6 +8,7 @@
 // Jacobi; the outer solver is *flexible* GMRES precisely so that such an inexact inner solve is admissible.
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -47,7 +48,7 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
     mdot(1, w, n, w, &bb);
     const double beta = std::sqrt(bb);
     res = beta;
-    if (res <= tol || it >= maxit) break;
+    if (res <= tol || it >= maxit || !std::isfinite(res)) break; // (deal.II's SolverControl::check fails on a NaN as well)
     v_copy(ctx, n, w, V);
     v_scale(ctx, n, 1.0 / beta, V);
     std::fill(g.begin(), g.end(), 0.0);
@@ -88,7 +89,7 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
       res = std::fabs(g[j + 1]);
       ++it;
       if (history) history->push_back(res);
-      if (res <= tol || hn == 0) { ++j; done = true; break; }
+      if (res <= tol || hn == 0 || !std::isfinite(res)) { ++j; done = true; break; }
     }
     for (int i = j - 1; i >= 0; --i) {
       double t = g[i];
@@ -154,7 +155,7 @@ static int gmres_f32basis(ifem_ctx *ctx, int64_t n, int64_t ld, const OpFn &A, c
     allreduce(&bb, 1);
     const double beta = std::sqrt(bb);
     res = beta;
-    if (res <= tol || it >= maxit) break;
+    if (res <= tol || it >= maxit || !std::isfinite(res)) break;
     v_scale_store_f32(ctx, n, 1.0 / beta, w, V);
     std::fill(g.begin(), g.end(), 0.0);
     g[0] = beta;
@@ -183,7 +184,7 @@ static int gmres_f32basis(ifem_ctx *ctx, int64_t n, int64_t ld, const OpFn &A, c
       g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
       res = std::fabs(g[j + 1]);
       ++it;
-      if (res <= tol || hn == 0) { ++j; done = true; break; }
+      if (res <= tol || hn == 0 || !std::isfinite(res)) { ++j; done = true; break; }
     }
     for (int i = j - 1; i >= 0; --i) {
       double t = g[i];
@@ -1067,6 +1068,14 @@ void ins_system_vmult(ifem_ctx *ctx, const double *src, double *dst) {
 //   P_vv^-1  : node-block Jacobi of A_vv            (reference: Hypre-Euclid ILU(0))
 //   T_pp     : A_pp - A_pv P_vv^-1 A_vp, solved by GMRES(200) to 1e-3 ||.|| with the ILU(0) of the explicit T_pp
 //                                                   (reference: ILU(0) of B2pp = A_pp - A_pv rowsum|A_vv|^-1 A_vp)
+// what deal.II's SolverControl::NoConvergence carries: the last step and the last residual
+static void throw_noconv(const char *solver, int it, double res, double tol) {
+  char msg[256];
+  snprintf(msg, sizeof msg, "%s did not converge (SolverControl::NoConvergence): residual %.6e after %d iteration%s, tolerance %.6e%s", solver, res, it,
+           it == 1 ? "" : "s", tol, std::isfinite(res) ? "" : " -- the system holds non-finite values (check the state vectors)");
+  throw Error(IFEM_E_KRYLOV_NOCONV, msg);
+}
+
 int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats) {
   if (!ctx->assembled || !ctx->has_app) throw Error(IFEM_E_BADPARAM, "ifem_scns_solve called before ifem_scns_assemble");
   SolveState S{ctx, nullptr, o};
@@ -1157,7 +1166,8 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
   if (o->verbose)
     fprintf(stderr, "[ifem] scns solve: fgmres %d its res %.3e (tol %.3e) | inner Tpp its %u | %.1f ms\n", it, res, tol,
             S.st.inner_iters, S.st.t_total_ms);
-  return res <= tol ? 0 : IFEM_E_KRYLOV_NOCONV;
+  if (!(res <= tol)) throw_noconv("FGMRES", it, res, tol);
+  return 0;
 }
 
 int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, int use_nonzero,
@@ -1212,7 +1222,8 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
     for (double r : hist) fprintf(stderr, " %.2e", r / bn);
     fprintf(stderr, "\n");
   }
-  return res <= tol ? 0 : IFEM_E_KRYLOV_NOCONV;
+  if (!(res <= tol)) throw_noconv("FGMRES", it, res, tol);
+  return 0;
 }
 
 } // namespace ifem

@@ -142,6 +142,155 @@ def test_assembled_auu_equals_matrix_free_and_solve_residual(solver):
     assert abs(true_res - st.fgmres_res) <= 0.5 * st.fgmres_res + 1e-12 * np.linalg.norm(b)
 
 
+class _SubMesh:
+    """the cells around a set of nodes as a mesh of their own (nodes renumbered in ascending context id) for the oracle"""
+
+    def __init__(self, cells, cu, cp, fb, vc):
+        self.dim, self.kv = 3, 2
+        self.unodes, self.pnodes = np.unique(cu[cells]), np.unique(cp[cells])
+        self.cell_unodes = np.searchsorted(self.unodes, cu[cells]).astype(np.int32)
+        self.cell_pnodes = np.searchsorted(self.pnodes, cp[cells]).astype(np.int32)
+        self.cell_face_bid = np.ascontiguousarray(fb[cells])
+        self.vcoords = np.ascontiguousarray(vc[cells])
+        self.n_cells, self.n_unodes, self.n_pnodes = len(cells), len(self.unodes), len(self.pnodes)
+        self.n_dofs = 3 * self.n_unodes + self.n_pnodes
+
+    def to_sub(self, dofs, n_u):
+        """context dof ids [u|p] -> sub-mesh dof ids, -1 where the dof is not in the sub-mesh"""
+        dofs = np.asarray(dofs, np.int64)
+        out = np.full(len(dofs), -1, np.int64)
+        isu = dofs < n_u
+        nd, c = dofs[isu] // 3, dofs[isu] % 3
+        k = np.searchsorted(self.unodes, nd)
+        ok = (k < self.n_unodes) & (self.unodes[np.minimum(k, self.n_unodes - 1)] == nd)
+        out[np.flatnonzero(isu)[ok]] = 3 * k[ok] + c[ok]
+        pn = dofs[~isu] - n_u
+        k = np.searchsorted(self.pnodes, pn)
+        ok = (k < self.n_pnodes) & (self.pnodes[np.minimum(k, self.n_pnodes - 1)] == pn)
+        out[np.flatnonzero(~isu)[ok]] = 3 * self.n_unodes + k[ok]
+        return out
+
+    def ctx_dofs(self, n_u):
+        """sub-mesh dof id -> context dof id"""
+        return np.concatenate([(3 * self.unodes[:, None] + np.arange(3)[None, :]).ravel(), n_u + self.pnodes])
+
+
+def test_row_slabs_against_the_oracle_at_bench_size(solver):
+    """Entrywise oracle parity AT bench size (mpi_insim.cpp:343-361: what distribute_local_to_global leaves in system_matrix and
+    system_rhs).  Slabs of velocity rows -- the first nodes, the nodes whose A_uu values straddle offset 2^31 of the 9.8e9-double
+    array, the last nodes -- and of pressure rows come off the device through ifem_export_rows; the oracle (oracle/oracle.c)
+    assembles the cells that touch a slab as a mesh of their own, with the same state, constraints and boundary ids.  Every row of
+    a slab is complete in that sub-mesh, so A_uu, B^T, B entries and the right-hand side must agree to 1e-11."""
+    import scipy.sparse as sp
+    import orc
+    from openifem_amd import capi
+    from cases import CHANNEL_KW
+    S, n = solver, solver.n
+    n_cells, n_u, n_p = S.sizes()
+    nt, n_nodes = n_u + n_p, n_u // 3
+    S.channel_state()
+    S.assemble(False)
+    ev, present = _vec_get(S, capi.VEC_EVAL, nt), _vec_get(S, capi.VEC_PRESENT, nt)
+    b = _vec_get(S, capi.VEC_RHS, nt)
+    cdofs, cvals = S.constraints()
+    cu, cp, fb, vc = S.cell_tables()
+    uc, _ = S.node_coords()
+    # blocks per velocity row from the mesh: a node couples to every node it shares a cell with
+    h = (np.array(P1) - np.array(P0)) / n
+    ulat = np.rint((uc - np.array(P0)) / (h / 2)).astype(np.int64)
+    per_dir = np.where(ulat % 2 == 1, 3, np.where((ulat == 0) | (ulat == 2 * n), 3, 5))
+    blocks = per_dir.prod(axis=1)
+    off = np.concatenate([[0], np.cumsum(blocks)]) * 9  # offset of a node's first A_uu value
+    assert off[-1] == 9 * blocks.sum()
+    w = 24
+    slabs = [("first velocity rows", 0, 3 * w), ("last velocity rows", n_u - 3 * w, 3 * w)]
+    if off[-1] > 2 ** 31:
+        a31 = int(np.searchsorted(off, 2 ** 31))
+        assert off[a31 - w // 2] < 2 ** 31 <= off[a31 + w // 2]
+        slabs.append(("velocity rows around A_uu offset 2^31", 3 * (a31 - w // 2), 3 * w))
+    if off[-1] > 2 ** 33:  # 128^3: also far beyond 32-bit BYTE offsets of every index type
+        a33 = int(np.searchsorted(off, 2 ** 33))
+        slabs.append(("velocity rows around A_uu offset 2^33", 3 * (a33 - w // 2), 3 * w))
+    slabs += [("first pressure rows", n_u, w), ("middle pressure rows", n_u + n_p // 2, w), ("last pressure rows", nt - w, w)]
+    P = orc.make_params(**dict(CHANNEL_KW, g=GRAVITY))
+    for name, row0, nrows in slabs:
+        rows = np.arange(row0, row0 + nrows)
+        if row0 < n_u:
+            nodes = np.unique(rows // 3)
+            cells = np.flatnonzero(np.isin(cu, nodes).any(axis=1))
+        else:
+            cells = np.flatnonzero(np.isin(cp, rows - n_u).any(axis=1))
+        assert 0 < len(cells) <= 8 * nrows
+        sub = _SubMesh(cells, cu, cp, fb, vc)
+        ids = sub.ctx_dofs(n_u)
+        O = orc.System(sub)
+        cs = sub.to_sub(cdofs, n_u)
+        O.set_constraints(0, cs[cs >= 0], None)
+        O.set_constraints(1, cs[cs >= 0], cvals[cs >= 0])
+        O.assemble(P, False, ev[ids], present[ids])
+        A_ref, b_ref = O.csr("A"), O.rhs()
+        rs = sub.to_sub(rows, n_u)
+        assert (rs >= 0).all()
+        rp, col, val = capi.export_rows(S.L, S.ctx, row0, nrows)
+        # the context's columns: velocity dof 3 node + c, pressure 3 n_nodes + pressure node (one rank: local = owned)
+        cs_ = sub.to_sub(col, n_u)
+        assert (cs_ >= 0).all(), name + ": an exported column lies outside the cells around its row"
+        A_dev = sp.csr_matrix((val, cs_, rp), shape=(nrows, sub.n_dofs))
+        A_dev.sum_duplicates()
+        assert A_dev.nnz == rp[-1], name + ": a (row, column) pair appears twice"
+        if row0 < n_u:  # the row lengths the offsets above were computed from
+            want_len = 3 * blocks[rows // 3]
+            got_u = np.diff(rp) - np.array([np.count_nonzero(col[rp[i]:rp[i + 1]] >= n_u) for i in range(nrows)])
+            assert np.array_equal(got_u, want_len), name
+        D = (A_dev - A_ref[rs]).tocoo()
+        scale = np.abs(A_ref[rs].data).max()
+        err = np.abs(D.data).max() if D.nnz else 0.0
+        assert err <= 1e-11 * scale, (name, err, scale)
+        # no entry the oracle holds is missing on the device (explicit zeros of the pattern aside)
+        assert np.abs(A_ref[rs]).sum() > 0 and abs(np.abs(A_dev).sum() - np.abs(A_ref[rs]).sum()) <= 1e-9 * np.abs(A_ref[rs]).sum()
+        berr = np.abs(b[rows] - b_ref[rs]).max()
+        assert berr <= 1e-11 * max(np.abs(b_ref).max(), 1e-300), (name, berr)
+
+
+def test_divergence_blocks_closed_form(solver):
+    """B and B^T at bench size against their closed forms on the uniform box: B applied to a linear velocity field is
+    -(div u) int psi_b on every pressure row that meets no constrained velocity dof, and B^T applied to a linear pressure is
+    (grad p)_c int N_a on every interior velocity node (integration by parts; Q1 holds a linear function exactly)"""
+    from openifem_amd import capi
+    S, n = solver, solver.n
+    _, n_u, n_p = S.sizes()
+    nt = n_u + n_p
+    S.channel_state()
+    S.assemble(False)
+    h = (np.array(P1) - np.array(P0)) / n
+    uc, pc = S.node_coords()
+    ulat = np.rint((uc - np.array(P0)) / (h / 2)).astype(np.int64)
+    plat = np.rint((pc - np.array(P0)) / h).astype(np.int64)
+    a = np.array([0.7, -1.3, 2.1])
+    x = np.zeros(nt)
+    x[:n_u] = (uc * a[None, :]).ravel()
+    _vec_set(S, capi.VEC_TMP, x)
+    assert S.L.ifem_system_vmult(S.ctx, capi.VEC_UPDATE, capi.VEC_TMP) == 0, S.L.ifem_last_error()
+    y = _vec_get(S, capi.VEC_UPDATE, nt)
+    plump = np.ones(n_p)
+    for d in range(3):
+        plump *= np.where((plat[:, d] == 0) | (plat[:, d] == n), 0.5, 1.0) * h[d]
+    away = ((plat[:, 1:] >= 2) & (plat[:, 1:] <= n - 2)).all(axis=1)  # no wall node among the row's velocity neighbours
+    assert away.sum() > 0.8 * n_p * ((n - 3) / (n + 1)) ** 2 - 1
+    assert np.abs(y[n_u:][away] + a.sum() * plump[away]).max() < 1e-11 * a.sum() * plump.max()
+    g = np.array([3.0, -0.5, 1.25])
+    x = np.zeros(nt)
+    x[n_u:] = pc @ g + 0.4
+    _vec_set(S, capi.VEC_TMP, x)
+    assert S.L.ifem_system_vmult(S.ctx, capi.VEC_UPDATE, capi.VEC_TMP) == 0, S.L.ifem_last_error()
+    y = _vec_get(S, capi.VEC_UPDATE, nt)[:n_u].reshape(-1, 3)
+    lump = np.ones(n_u // 3)
+    for d in range(3):
+        lump *= _int_1d(ulat[:, d], n, h[d], 1.0 / 6.0, 4.0 / 6.0)
+    inner = ((ulat > 0) & (ulat < 2 * n)).all(axis=1)
+    assert np.abs(y[inner] - lump[inner, None] * g[None, :]).max() < 1e-11 * np.abs(g).max() * lump.max()
+
+
 def test_fsi_inputs_closed_form_on_affine_fields(solver):
     """the device-side FSI inputs (csrc/fsi.hip) at bench size against what must hold on ANY mesh: with affine solid fields
     and an affine fluid velocity, update_indicator marks exactly the cells whose vertices lie in the (analytically known)
