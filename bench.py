@@ -442,6 +442,13 @@ def main():
     ap.add_argument("--dump-update", default=None, help="test aid: every rank writes its owned entries of the last Newton update and their global lattice ids to <path>.rank<r>.npz")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
     ap.add_argument("--outer-mf", type=int, default=0, help="experiment: apply the u-u block of the OUTER operator matrix-free too")
+    ap.add_argument("--workload", default="channel3d", choices=["channel3d", "cylinder2d", "cylinder2d_scnsim", "cylinder3d"],
+                    help="channel3d (default): the BASELINE metric's 3D channel; cylinder2d / cylinder2d_scnsim: BASELINE configs 2 and 4, the "
+                         "reference's cylinder drivers on the host mirror with the reference .prm; cylinder3d: the extruded cylinder of "
+                         "GridCreator<3>::flow_around_cylinder at --refinements (3: 0.43 M cells, 11 M DoF) -- tools/cylbench.py")
+    ap.add_argument("--refinements", type=int, default=3, help="global refinements of the cylinder workloads (the reference's .prm: 3)")
+    ap.add_argument("--cylinder-legs", type=int, default=1, help="N = 1 only: append the cylinder workloads (configs 2 and 4, and the 3D "
+                                                                 "cylinder at 3 refinements) to the channel line as side measurements")
     ap.add_argument("--solver", default="insim", choices=["insim", "insimex"],
                     help="insim (default, the BASELINE metric): one Newton iteration of MPI::InsIM; insimex: one steady-state "
                          "time step of MPI::InsIMEX (rhs-only assembly + solve), reported as a side measurement")
@@ -483,6 +490,13 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         raise SystemExit(capi.E_NODEVICE_EXIT)
+    if args.workload != "channel3d":
+        if world != 1:
+            raise SystemExit("the cylinder workloads run on one GPU (the host mirror cuts unstructured meshes into strips: tools/cyl_ranks.py)")
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import cylbench
+        print(json.dumps(cylbench.run(args.workload, args.refinements, steps=max(args.steps, 1), device=local_rank)), flush=True)
+        return
     if args.solver == "insimex":
         return bench_insimex(args, host)
     n = args.n
@@ -696,6 +710,23 @@ def main():
                 out["fsi_inputs"] = leg
             except Exception as e:  # a side leg must not take the headline line with it
                 out["fsi_inputs"] = {"error": repr(e)}
+        if world == 1 and args.cylinder_legs:
+            # side measurements (configs 2 and 4 report DoF/s too; VERDICT r4 item 5: the cell kernel on an unstructured 3D
+            # mesh of scale).  The channel's contexts are released first: the 3D cylinder needs ~40 GB of its own.
+            try:
+                solver.close()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import cylbench
+                legs = {}
+                for w, r in (("cylinder2d", 3), ("cylinder2d_scnsim", 3), ("cylinder3d", 3)):
+                    o = cylbench.run(w, r, steps=2, device=local_rank)
+                    legs[w] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "config": o["config"]}
+                    if "roofline" in o and "assemble3_unstructured" in o["roofline"]:
+                        legs[w]["assemble3_unstructured"] = o["roofline"]["assemble3_unstructured"]
+                        legs[w]["kernel_ms_per_step"] = {k["family"]: k["ms_per_step"] for k in o["roofline"]["kernels"]}
+                out["cylinder_workloads"] = legs
+            except Exception as e:  # a side leg must not take the headline line with it
+                out["cylinder_workloads"] = {"error": repr(e)}
         cpu_sizes = [int(v) for v in str(args.cpu_n).split(",") if int(v) > 0]
         cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ifem_cpu_baseline_n1.json")
         if cpu_sizes and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement

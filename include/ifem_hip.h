@@ -491,6 +491,11 @@ int ifem_export_csr(ifem_ctx *ctx, int which, int64_t *rowptr, int32_t *col, dou
  * (nnz = rowptr[nrows]).  A parity test's window onto a bench-size system: a slab of rows against the oracle's assembly of the
  * cells that touch it (the reference's counterpart: one rank's rows of system_matrix, mpi_insim.cpp:343-361). */
 int ifem_export_rows(ifem_ctx *ctx, int which, int64_t row0, int64_t nrows, int64_t *rowptr, int32_t *col, double *val);
+/* The stored block pattern of A_uu for the velocity nodes [node0, node0 + n_nodes): rowptr (n_nodes + 1 entries) holds ABSOLUTE
+ * block offsets into the value array (block k owns the doubles [k dim^2, (k + 1) dim^2)), col (rowptr[n_nodes] - rowptr[0] entries,
+ * may be NULL) the block columns in storage order (ifem_tuning::uu_row_order).  Measurement aid: the addresses the fused scatter
+ * of the cell kernel hits (tools/scatter_sim.py replays them into 64-byte segments per cell on any mesh). */
+int ifem_export_uu_pattern(ifem_ctx *ctx, int64_t node0, int64_t n_nodes, int64_t *rowptr, int32_t *col);
 
 /* per-kernel timing of the last assemble/solve, HIP events on the context stream */
 typedef struct {

@@ -137,7 +137,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag",
            "ifem_fsi_set_solid", "ifem_fsi_update_indicator", "ifem_fsi_find_fluid_bc", "ifem_fsi_get_stress",
            "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_comm_stats_level", "ifem_true_residual", "ifem_tpp_ilu_probe", "ifem_tpp_override",
-           "ifem_kprof_begin", "ifem_kprof_end", "ifem_kprof_family_name", "ifem_export_rows"]
+           "ifem_kprof_begin", "ifem_kprof_end", "ifem_kprof_family_name", "ifem_export_rows", "ifem_export_uu_pattern"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -188,6 +188,7 @@ def load():
     L.ifem_precond_vmult.argtypes = [C.c_void_p, C.POINTER(InsParams), C.POINTER(SolverOpts), C.c_int, C.c_int]
     L.ifem_export_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifem_export_rows.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifem_export_uu_pattern.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     L.ifem_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.ifem_comm_unique_id.argtypes = [C.c_void_p]
     L.ifem_local_world_create.restype = C.c_void_p
@@ -269,6 +270,19 @@ def export_rows(L, ctx, row0, nrows, which=0):
     if rc < 0:
         raise IfemError(rc, L.ifem_last_error().decode())
     return rp, col, val
+
+
+def export_uu_pattern(L, ctx, node0, n_nodes):
+    """ifem_export_uu_pattern: (absolute block offsets, block columns in storage order) of the A_uu rows of these nodes"""
+    rp = np.zeros(n_nodes + 1, np.int64)
+    rc = L.ifem_export_uu_pattern(ctx, node0, n_nodes, _ptr(rp), None)
+    if rc < 0:
+        raise IfemError(rc, L.ifem_last_error().decode())
+    col = np.zeros(rp[-1] - rp[0], np.int32)
+    rc = L.ifem_export_uu_pattern(ctx, node0, n_nodes, _ptr(rp), _ptr(col))
+    if rc < 0:
+        raise IfemError(rc, L.ifem_last_error().decode())
+    return rp, col
 
 
 def comm_stats(L, ctx, reset=False):

@@ -979,6 +979,21 @@ int ifem_export_rows(ifem_ctx *ctx, int which, int64_t row0, int64_t nrows, int6
   IFEM_API_END
 }
 
+// the stored block pattern of A_uu for the nodes [node0, node0 + n_nodes): ABSOLUTE block offsets (block k of the array holds the
+// values [k * dim^2, (k + 1) * dim^2)) and block columns in storage order -- what the scatter of the cell kernel addresses
+int ifem_export_uu_pattern(ifem_ctx *ctx, int64_t node0, int64_t n_nodes, int64_t *rowptr, int32_t *col) {
+  IFEM_API_BEGIN
+  if (!rowptr || node0 < 0 || n_nodes < 0 || node0 + n_nodes > ctx->Auu.n_rows) throw Error(IFEM_E_BADPARAM, "ifem_export_uu_pattern: node range outside the owned rows");
+  hipStream_t s = ctx->stream;
+  auto rp = download_range(ctx->Auu.rowptr, node0, n_nodes + 1, s);
+  std::copy(rp.begin(), rp.end(), rowptr);
+  if (col) {
+    auto c = download_range(ctx->Auu.col, rp.front(), rp.back() - rp.front(), s);
+    std::copy(c.begin(), c.end(), col);
+  }
+  IFEM_API_END
+}
+
 int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t) {
   IFEM_API_BEGIN
   *t = ctx->timing; // spmv_uu_bytes is set by the profiled launches themselves (linalg.hip::spmv_uu)

@@ -519,6 +519,17 @@ int ifemx_last_stats(void *hv, ifem_solve_stats *st) {
     if (h->dim == 2) with_family<2>(h->s2.get(), get, get); else with_family<3>(h->s3.get(), get, get);
   });
 }
+// Newton iterations and summed FGMRES iterations of the solver's most recent run_one_step
+int ifemx_last_newton(void *hv, int32_t *newton_iterations, int32_t *fgmres_iterations) {
+  auto *h = static_cast<Handle *>(hv);
+  return guard([&] {
+    auto get = [&](auto &s) {
+      if (newton_iterations) *newton_iterations = int32_t(s.last_newton_iterations);
+      if (fgmres_iterations) *fgmres_iterations = int32_t(s.last_fgmres_iterations);
+    };
+    if (h->dim == 2) with_family<2>(h->s2.get(), get, get); else with_family<3>(h->s3.get(), get, get);
+  });
+}
 int ifemx_assemble(void *hv, int use_nonzero) {
   auto *h = static_cast<Handle *>(hv);
   return guard([&] {

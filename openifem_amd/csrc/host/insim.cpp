@@ -431,6 +431,7 @@ void InsIM<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_syst
            << "Time step = " << time.get_timestep() << ", at t = " << std::scientific << time.current() << std::endl;
   double current_residual = 1.0, initial_residual = 1.0, relative_residual = 1.0;
   unsigned int outer_iteration = 0;
+  this->last_newton_iterations = this->last_fgmres_iterations = 0;
   check(ifem_vec_copy(ctx, IFEM_VEC_EVAL, IFEM_VEC_PRESENT), "run_one_step"); // evaluation_point = present_solution
   while (relative_residual > parameters.fluid_tolerance && current_residual > 1e-11) {
     if (!(outer_iteration < parameters.fluid_max_iterations))
@@ -447,6 +448,8 @@ void InsIM<dim>::run_one_step(bool apply_nonzero_constraints, bool assemble_syst
              << " ABS_RES = " << current_residual << " REL_RES = " << relative_residual
              << " GMRES_ITR = " << std::setw(3) << state.first << " GMRES_RES = " << state.second << std::endl;
     outer_iteration++;
+    this->last_newton_iterations = outer_iteration;
+    this->last_fgmres_iterations += state.first;
   }
   // solution_increment = present - evaluation; present_solution = evaluation_point
   check(ifem_vec_copy(ctx, IFEM_VEC_INCREMENT, IFEM_VEC_PRESENT), "run_one_step");

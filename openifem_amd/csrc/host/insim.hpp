@@ -129,6 +129,8 @@ public:
   void setup_dofs();
   void make_constraints();
   virtual void initialize_system();
+  // counters of the most recent run_one_step (the reference prints them per iteration: " ITR = .. GMRES_ITR = ..")
+  unsigned int last_newton_iterations = 0, last_fgmres_iterations = 0;
 
 protected:
   void check(int rc, const char *what) const;

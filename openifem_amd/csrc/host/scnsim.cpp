@@ -62,6 +62,7 @@ void SUPGFluidSolver<dim>::run_one_step(bool apply_nonzero_constraints, bool ass
                  << "Time step = " << time.get_timestep() << ", at t = " << std::scientific << time.current() << std::endl;
   double current_residual = 1.0, initial_residual = 1.0, relative_residual = 1.0;
   unsigned int outer_iteration = 0;
+  this->last_newton_iterations = this->last_fgmres_iterations = 0;
   check(ifem_vec_copy(ctx, IFEM_VEC_EVAL, IFEM_VEC_PRESENT), "run_one_step");
   while (relative_residual > parameters.fluid_tolerance && current_residual > 1e-14) {
     if (!(outer_iteration < parameters.fluid_max_iterations))
@@ -79,6 +80,8 @@ void SUPGFluidSolver<dim>::run_one_step(bool apply_nonzero_constraints, bool ass
                    << " GMRES_ITR = " << std::setw(3) << state.first << " GMRES_RES = " << state.second
                    << " INNER_GMRES_ITR = " << std::setw(3) << last_stats.inner_iters << std::endl;
     outer_iteration++;
+    this->last_newton_iterations = outer_iteration;
+    this->last_fgmres_iterations += state.first;
   }
   check(ifem_vec_copy(ctx, IFEM_VEC_INCREMENT, IFEM_VEC_PRESENT), "run_one_step");
   check(ifem_vec_axpy(ctx, -1.0, IFEM_VEC_EVAL, IFEM_VEC_INCREMENT), "run_one_step");

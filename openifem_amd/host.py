@@ -47,6 +47,7 @@ def _lib():
     L.ifemx_assemble.argtypes = [C.c_void_p, C.c_int]
     L.ifemx_solve.argtypes = [C.c_void_p, C.c_int, C.POINTER(capi.SolveStats)]
     L.ifemx_last_stats.argtypes = [C.c_void_p, C.POINTER(capi.SolveStats)]
+    L.ifemx_last_newton.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ifemx_solver_opts.restype = C.POINTER(capi.SolverOpts)
     L.ifemx_solver_opts.argtypes = [C.c_void_p]
     L.ifemx_ctx.restype = C.c_void_p
@@ -303,6 +304,12 @@ class FluidSolver:
         st = capi.SolveStats()
         self._chk(self.L.ifemx_last_stats(self.h, C.byref(st)))
         return st
+
+    def last_newton(self):
+        """(Newton iterations, summed FGMRES iterations) of the most recent run_one_step"""
+        a, b = C.c_int32(), C.c_int32()
+        self._chk(self.L.ifemx_last_newton(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def assemble(self, use_nonzero):
         self._chk(self.L.ifemx_assemble(self.h, int(use_nonzero)))
