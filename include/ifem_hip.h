@@ -171,7 +171,9 @@ typedef struct {
                             exchange completes on the context stream before the operator starts */
   int32_t asm3_variant;  /* 3D Q2/Q1 cell kernel: 0 (default) = the matrix-core kernel of assemble3.hip (one wavefront per cell); 1 = the
                             general vector kernel of assemble2.hip (also taken when an A_uu row holds 512 blocks or more) */
-  int32_t asm3_reserved; /* unused */
+  int32_t cg_single_reduction; /* 1 (default): the device-resident CG of the pressure solves (CG(M_p), plain CG(S_m)) forms its three dot
+                            products in one pass and one all-reduce per iteration (Chronopoulos / Gear recurrence); 0: the textbook
+                            recurrence with two reductions per iteration */
   int32_t asm3_cpb;      /* 2: cells (= wavefronts) per workgroup of that kernel (1, 2, 4 or 8) */
   int32_t tpp_milu_permille; /* SCnsIM, ILU(0) of T_pp: 950 (default); 0 plain ILU(0); w in (0, 1000]: relaxed modified ILU, w/1000 of every dropped
                                 fill-in entry is added to the diagonal of its row */
@@ -479,7 +481,7 @@ int ifem_tpp_ilu_probe(ifem_ctx *ctx, int64_t *rowptr, int32_t *col, double *val
 /* Test aid: replace the values of the explicit T_pp (pattern and order as returned by ifem_tpp_ilu_probe) so that the next
  * factorisation sees them -- the breakdown path of the ILU(0) (zero / non-finite pivot -> IFEM_E_KRYLOV_NOCONV from the probe, Jacobi
  * in ifem_scns_solve) cannot be reached from an assembled fluid matrix at will. */
-int ifem_tpp_override(ifem_ctx *ctx, const double *val);
+int ifem_tpp_override(ifem_ctx *ctx, const double *val); /* TEST AID ONLY: single rank, not part of the reference's interface */
 
 /* Export the assembled block system as one CSR over the local dofs [u|p] (host arrays; call twice: first
  * with col = val = NULL to get nnz through rowptr[n]).  which: 0 system_matrix, 1 mass (diag(M_u), M_p).

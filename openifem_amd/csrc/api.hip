@@ -117,7 +117,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
 
 void ifem_default_tuning(ifem_tuning *t) {
   t->geo_cache = 1; t->xcd_swizzle = 1; t->asm_skip = 0; t->spmv_lanes = 32; t->sm_lanes = 32; t->mf_f32 = 1;
-  t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->asm3_reserved = 0; t->asm3_cpb = 2; t->tpp_milu_permille = 950; t->tpp_ilu_order = 2; t->basis_pad = 32 * 33; t->tpp_tri_sweeps = 0; t->uu_row_order = 1;
+  t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->cg_single_reduction = 1; t->asm3_cpb = 2; t->tpp_milu_permille = 950; t->tpp_ilu_order = 2; t->basis_pad = 32 * 33; t->tpp_tri_sweeps = 0; t->uu_row_order = 1;
 }
 
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
@@ -221,6 +221,7 @@ void ifem_ctx_destroy(ifem_ctx *ctx) {
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  for (hipEvent_t e : ctx->pc_ev) (void)hipEventDestroy(e);
   hipStream_t s = ctx->owns_stream ? ctx->stream : nullptr;
   delete ctx;
   if (s) (void)hipStreamDestroy(s);
@@ -835,8 +836,11 @@ int ifem_tpp_ilu_probe(ifem_ctx *ctx, int64_t *rowptr, int32_t *col, double *val
 
 int ifem_tpp_override(ifem_ctx *ctx, const double *val) {
   IFEM_API_BEGIN
+  if (!ctx) throw Error(IFEM_E_BADPARAM, "ifem_tpp_override: null context");
+  if (ctx->halo.nranks > 1) throw Error(IFEM_E_BADPARAM, "ifem_tpp_override is a single-rank test aid");
   if (!ctx->tpp_valid || !val) throw Error(IFEM_E_BADPARAM, "ifem_tpp_override after ifem_tpp_ilu_probe, with values");
   IFEM_HIP_CHECK(hipMemcpyAsync(ctx->Tpp.p, val, ctx->Tpp.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  scalar_diag(ctx, ctx->Sm, ctx->Tpp.p, ctx->tpp_diag.p); // (single rank: T_pp lives on the pattern of S_m) the Jacobi fallback of a broken-down ILU divides by THIS matrix's diagonal
   IFEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   ctx->tpp_ilu.factored = false;
   IFEM_API_END
@@ -1013,10 +1017,7 @@ int ifem_comm_stats_level(ifem_ctx *ctx, int level, ifem_comm_stats *out) {
   ifem_ctx *c = ctx;
   for (int k = 0; k < level && c; ++k) c = c->mg_coarse;
   if (!c) throw Error(IFEM_E_BADPARAM, "ifem_comm_stats_level: the chain has fewer levels");
-  ifem_ctx *below = c->mg_coarse; // count this context alone
-  c->mg_coarse = nullptr;
-  try { ifem::comm_stats(c, out, false); } catch (...) { c->mg_coarse = below; throw; }
-  c->mg_coarse = below;
+  ifem::comm_stats(c, out, false, /*single_level=*/true);
   IFEM_API_END
 }
 

@@ -82,13 +82,19 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   const bool geo_only = assemble_system >= 2; // 3: the same without constraints (pristine blocks)
   if (assemble_system == 2) {
     const int64_t key = ctx->flag_id[use_nonzero ? 1 : 0];
+    // a multigrid level is asked once per preconditioner application: it counts ASSEMBLIES of the finest level (its version stamp)
+    const ifem_ctx *f0 = ctx;
+    while (f0->mg_fine) f0 = f0->mg_fine;
+    const bool new_assembly = uint64_t(f0->asm_version) != ctx->geo_seen_asm;
+    ctx->geo_seen_asm = uint64_t(f0->asm_version);
     if (ctx->geo_valid && ctx->geo_key == key && ctx->tune.geo_cache != 2) { // still the blocks of this constrained-dof set
-      if (++ctx->geo_unchanged == 4 && ctx->geo0_valid) { // a multigrid level: its unconstrained copies go the way of the finest level's (below)
+      if (new_assembly && ++ctx->geo_unchanged == 4 && ctx->geo0_valid && ctx->geo_set_changes == 0) { // its unconstrained copies go the way of the finest level's (below)
         ctx->B0.release(); ctx->Bt0.release(); ctx->Sm0.release();
         ctx->geo0_valid = false; ctx->sm0_valid = false;
       }
       return;
     }
+    if (ctx->geo_valid) ctx->geo_set_changes++;
     ctx->geo_unchanged = 0;
   } else if (assemble_system == 1)
     ensure_auu_values(ctx);
@@ -110,11 +116,13 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   const int64_t geo_key = ctx->flag_id[use_nonzero ? 1 : 0];
   bool skip_geo = ctx->tune.geo_cache == 1 && assemble_system && assemble_system != 3 && ctx->geo_valid && ctx->geo_key == geo_key;
   // the unconstrained copies of B / B^T / S_m (19 + 4 GB at 128^3) only serve a CHANGE of the constrained-dof set (FSI steps): a run
-  // whose set has stood still for a few assemblies (pure-fluid runs: for ever) gives them back; a later change re-integrates them
-  // once (one geometry-only launch)
+  // whose set has NEVER changed and has stood still for a few assemblies (pure-fluid runs) gives them back; a context that has seen
+  // a change (an FSI run: a new set every time step, several Newton assemblies in between) keeps them -- releasing them there would
+  // repeat a hipFree / hipMalloc / geometry launch every time step
   if (assemble_system == 1) {
+    if (!skip_geo && ctx->geo_valid && ctx->geo_key != geo_key) ctx->geo_set_changes++;
     ctx->geo_unchanged = skip_geo ? ctx->geo_unchanged + 1 : 0;
-    if (ctx->geo_unchanged == 4 && ctx->geo0_valid) {
+    if (ctx->geo_unchanged == 4 && ctx->geo0_valid && ctx->geo_set_changes == 0) {
       ctx->B0.release(); ctx->Bt0.release(); ctx->Sm0.release();
       ctx->geo0_valid = false; ctx->sm0_valid = false;
     }

@@ -9,6 +9,7 @@
 // can be validated on a single-GPU box; it shares everything with the RCCL path except the transport calls.
 // Single-rank runs never touch either.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <rccl/rccl.h>
 #include <algorithm>
 #include <array>
@@ -48,11 +49,17 @@ struct LocalWorld {
     for (auto e : ev_packed) if (e) (void)hipEventDestroy(e);
     for (auto e : ev_copied) if (e) (void)hipEventDestroy(e);
   }
+  // A world whose `aborted` flag is up (a rank left an exchange by an exception) is DEAD: every later barrier / rendezvous of it
+  // fails with IFEM_E_COMM on every rank instead of waiting for the rank that will never come; the flag is never cleared --
+  // destroy the contexts and the world and build new ones.
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
+    if (aborted.load(std::memory_order_acquire)) throw Error(IFEM_E_COMM, "local world: a peer rank aborted an exchange (the world is dead)");
     const long gen = generation;
     if (++waiting == nranks) { waiting = 0; ++generation; cv.notify_all(); }
-    else cv.wait(lk, [&] { return generation != gen; });
+    else
+      while (!cv.wait_for(lk, std::chrono::milliseconds(20), [&] { return generation != gen; }))
+        if (aborted.load(std::memory_order_acquire)) { --waiting; throw Error(IFEM_E_COMM, "local world: a peer rank aborted an exchange (the world is dead)"); }
   }
   // host-only rendezvous of the exchanges (no device synchronisation around it): spin briefly, then yield
   std::atomic<long> spin_count{0};
@@ -498,7 +505,8 @@ void allreduce_max(ifem_ctx *ctx, double *host_vals, int n) { allreduce(ctx, hos
 
 // ---- vector all-reduce: the hand-over to a replicated coarse level (ifem_mg_attach with a single-rank coarse context).  Every rank
 // holds its partial restriction over ALL coarse nodes; the sum is the restricted residual, identical on every rank (RCCL rings and
-// the rank-ordered sum below both give every rank the same bits, so the replicas stay in step).
+// the rank-ordered sum below both give every rank the same bits).  The replicas themselves agree to rounding only (their level
+// operators use atomics whose order differs between devices); solver.hip::replica_world agrees the smoother bounds across ranks.
 struct PeerVecs { const void *p[kMaxLocalPeers]; };
 template <typename T>
 __global__ void k_sum_peer_vecs(int64_t n, int nranks, PeerVecs pp, T *__restrict__ out) {
@@ -613,7 +621,7 @@ int comm_selftest(int device) {
 }
 
 // what the context's communicator looks like and how much it was used (the whole multigrid chain below ctx included)
-void comm_stats(ifem_ctx *ctx, ifem_comm_stats *out, bool reset) {
+void comm_stats(ifem_ctx *ctx, ifem_comm_stats *out, bool reset, bool single_level) {
   std::memset(out, 0, sizeof(*out));
   const Halo &h0 = ctx->halo;
   out->nranks = h0.nranks;
@@ -634,6 +642,7 @@ void comm_stats(ifem_ctx *ctx, ifem_comm_stats *out, bool reset) {
     out->allreduce_vec += h.n_allreduce_vec;
     ++out->levels;
     if (reset) h.n_exchanges = h.n_allreduce_dev = h.n_allreduce_host = h.n_allreduce_vec = 0;
+    if (single_level) break; // (ifem_comm_stats_level: this context alone -- the chain itself is never edited)
   }
 }
 

@@ -329,7 +329,9 @@ struct ifem_ctx {
   // constrained-dof set are masked copies of them instead of a re-integration (M_p and diag(M_u) do not depend on the set)
   ifem::DBuf<double> B0, Bt0;
   bool geo0_valid = false;
-  int geo_unchanged = 0; // consecutive full assemblies that kept the cached blocks (assemble.hip: the copies are released at 4)
+  int geo_unchanged = 0; // consecutive assemblies OF THE FINEST LEVEL that kept the cached blocks (assemble.hip: the copies are released at 4 ...)
+  int geo_set_changes = 0; // ... unless the constrained-dof set has ever changed after the first assembly (an FSI run): then they stay
+  uint64_t geo_seen_asm = 0; // a multigrid level: the finest level's asm_version its geo_unchanged last counted
   // S_m of the unconstrained blocks (same mesh-only idea): a constrained-dof set only changes the rows whose B row touches a
   // constrained dof, so S_m of a new set = this copy with those rows recomputed (linalg.hip::schur_numeric)
   ifem::DBuf<double> Sm0;
@@ -406,6 +408,10 @@ struct ifem_ctx {
   int tight_first_misses = 0, tight_first_backoff = 0; // ifem_solver_opts::inner_rel_first: consecutive misses, qualifying solves left to skip
   double spmv_uu_ms_total = 0;
   ifem::KProf kprof; // per-kernel-family event log of a profiled step (used on the finest level of a chain only)
+  // section marks of the preconditioner applications of one solve (start, after CG(M_p), after CG(S_m) + B^T, end): recorded on the
+  // stream, read once when the solve has finished (ifem_solve_stats::t_cg_mp_ms / t_cg_sm_ms / t_ainv_ms) -- no host wait per section
+  std::vector<hipEvent_t> pc_ev;
+  size_t pc_used = 0;
 };
 
 namespace ifem {

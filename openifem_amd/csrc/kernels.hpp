@@ -117,6 +117,10 @@ void cgd_init(ifem_ctx *ctx, int64_t n, const double *b, const double *diag, dou
 void cgd_alpha(ifem_ctx *ctx, int64_t n, const double *p, const double *q);
 void cgd_update(ifem_ctx *ctx, int64_t n, const double *diag, double *p, const double *q, double *x, double *r, double *z);
 double cgd_rr(ifem_ctx *ctx);
+// the same recurrence with one fused reduction per iteration (Chronopoulos / Gear): u = D^-1 r (u == r without diag), w = A u, s = A p
+void cg1_init(ifem_ctx *ctx, int64_t n, const double *b, const double *diag, double *x, double *r, double *u, double *p, double *s);
+void cg1_dots(ifem_ctx *ctx, int64_t n, const double *r, const double *u, const double *w, bool first);
+void cg1_update(ifem_ctx *ctx, int64_t n, const double *diag, double *u, const double *w, double *p, double *s, double *x, double *r);
 void v_minmax(ifem_ctx *ctx, int64_t n, const double *x, double *mn, double *mx);
 // x[dof] = value for constrained dofs (AffineConstraints::distribute, Dirichlet lines)
 void apply_constraints(ifem_ctx *ctx, int which, double *x);
@@ -162,7 +166,7 @@ void allreduce_sum_vec(ifem_ctx *ctx, double *dev, int64_t n, double *scratch);
 void allreduce_sum_vec_f32(ifem_ctx *ctx, float *dev, int64_t n, float *scratch);
 int comm_unique_id(uint8_t out[128]);
 int comm_selftest(int device);
-void comm_stats(ifem_ctx *ctx, ifem_comm_stats *out, bool reset);
+void comm_stats(ifem_ctx *ctx, ifem_comm_stats *out, bool reset, bool single_level = false);
 void *local_world_create(int nranks);
 void local_world_destroy(void *w);
 // ghost refresh of a ghost-extended velocity buffer [dim*nUl] / pressure buffer [nPl] (RCCL send/recv over xGMI)

@@ -1205,6 +1205,95 @@ double cgd_rr(ifem_ctx *ctx) { // the only host synchronisation of the loop
   return ctx->h_scal[200];
 }
 
+// ---- the same with ONE reduction per iteration (Chronopoulos / Gear): with u = D^-1 r and w = A u at hand,
+//   gamma = <r,u>, delta = <w,u>, rho = <r,r>   (one fused pass, one all-reduce of three numbers on several ranks)
+//   beta = gamma / gamma_old, alpha = gamma / (delta - beta gamma / alpha_old)
+//   p = u + beta p,  s = w + beta s (= A p),  x += alpha p,  r -= alpha s,  u = D^-1 r          (one fused pass)
+// Same iterates as the two-reduction recurrence in exact arithmetic; per iteration one all-reduce instead of two (CG(M_p):
+// 36 iterations x every preconditioner application), 4 launches instead of 6 and 120 instead of 128 bytes per entry.
+// Scalars in ctx->scal[CGD ..]: 0 rho, 1 gamma, 2 delta, 3 alpha, 4 beta; 8..10 staging of the all-reduce.
+__global__ __launch_bounds__(256) void k_cg1_init(int64_t n, const double *__restrict__ b, const double *__restrict__ diag,
+                                                  double *__restrict__ x, double *__restrict__ r, double *__restrict__ u,
+                                                  double *__restrict__ p, double *__restrict__ s) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const double ri = b[i];
+    x[i] = 0.0; r[i] = ri; p[i] = 0.0; s[i] = 0.0;
+    if (diag) u[i] = ri / (diag[i] != 0.0 ? diag[i] : 1.0);
+  }
+}
+__global__ __launch_bounds__(256) void k_cg1_dots(int64_t n, const double *__restrict__ r, const double *__restrict__ u,
+                                                  const double *__restrict__ w, double *__restrict__ part) {
+  double acc[3] = {0, 0, 0};
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const double ri = r[i], ui = u[i];
+    acc[0] += ri * ui; acc[1] += w[i] * ui; acc[2] += ri * ri;
+  }
+  block_reduce_store<3>(acc, part);
+}
+__global__ __launch_bounds__(256) void k_cg1_scalars(int nblk, const double *__restrict__ part, double *__restrict__ sc, int first, int piece) {
+  __shared__ double sh[3][4];
+  double v[3] = {0, 0, 0};
+  if (piece != 2) {
+    for (int k = 0; k < 3; ++k) {
+      double t = 0;
+      for (int i = threadIdx.x; i < nblk; i += blockDim.x) t += part[int64_t(k) * MDOT_MAXB + i];
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+      if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    for (int k = 0; k < 3; ++k) v[k] = sh[k][0] + sh[k][1] + sh[k][2] + sh[k][3];
+  }
+  if (threadIdx.x == 0) {
+    if (piece == 1) { sc[CGD + 8] = v[0]; sc[CGD + 9] = v[1]; sc[CGD + 10] = v[2]; return; }
+    if (piece == 2) { v[0] = sc[CGD + 8]; v[1] = sc[CGD + 9]; v[2] = sc[CGD + 10]; }
+    const double gam = v[0], del = v[1];
+    double be = 0.0, al;
+    if (first) al = del != 0.0 ? gam / del : 0.0;
+    else {
+      const double go = sc[CGD + 1], ao = sc[CGD + 3];
+      be = go != 0.0 ? gam / go : 0.0;
+      const double den = del - (ao != 0.0 ? be * gam / ao : 0.0);
+      al = den != 0.0 ? gam / den : 0.0;
+    }
+    sc[CGD + 0] = v[2]; sc[CGD + 1] = gam; sc[CGD + 2] = del; sc[CGD + 3] = al; sc[CGD + 4] = be;
+  }
+}
+__global__ __launch_bounds__(256) void k_cg1_update(int64_t n, const double *__restrict__ sc, const double *__restrict__ diag,
+                                                    double *u, const double *__restrict__ w, double *__restrict__ p,
+                                                    double *__restrict__ s, double *__restrict__ x, double *r) {
+  const double al = sc[CGD + 3], be = sc[CGD + 4];
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const double pi = u[i] + be * p[i], si = w[i] + be * s[i];
+    p[i] = pi; s[i] = si;
+    x[i] += al * pi;
+    const double ri = r[i] - al * si;
+    r[i] = ri;
+    if (diag) u[i] = ri / (diag[i] != 0.0 ? diag[i] : 1.0); // (without a preconditioner u IS r: the caller passes the same array)
+  }
+}
+void cg1_init(ifem_ctx *ctx, int64_t n, const double *b, const double *diag, double *x, double *r, double *u, double *p, double *s) {
+  KScope ks(ctx, IFEM_KC_CG_RECURRENCE, double(n) * (diag ? 56.0 : 40.0));
+  if (ctx->partials.n == 0) ctx->partials.alloc(size_t(64) * MDOT_MAXB);
+  if (n) hipLaunchKernelGGL(k_cg1_init, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, b, diag, x, r, u, p, s);
+}
+void cg1_dots(ifem_ctx *ctx, int64_t n, const double *r, const double *u, const double *w, bool first) {
+  KScope ks(ctx, IFEM_KC_CG_RECURRENCE, double(n) * (u == r ? 16.0 : 24.0), 6.0 * double(n));
+  hipStream_t st = ctx->stream;
+  const unsigned nblk = vgrid(n);
+  hipLaunchKernelGGL(k_cg1_dots, dim3(nblk), dim3(256), 0, st, n, r, u, w, ctx->partials.p);
+  if (ctx->halo.nranks == 1) {
+    hipLaunchKernelGGL(k_cg1_scalars, dim3(1), dim3(256), 0, st, (int)nblk, ctx->partials.p, ctx->scal.p, first ? 1 : 0, 0);
+    return;
+  }
+  hipLaunchKernelGGL(k_cg1_scalars, dim3(1), dim3(256), 0, st, (int)nblk, ctx->partials.p, ctx->scal.p, first ? 1 : 0, 1);
+  allreduce_sum_dev(ctx, ctx->scal.p + CGD + 8, 3);
+  hipLaunchKernelGGL(k_cg1_scalars, dim3(1), dim3(64), 0, st, (int)nblk, ctx->partials.p, ctx->scal.p, first ? 1 : 0, 2);
+}
+void cg1_update(ifem_ctx *ctx, int64_t n, const double *diag, double *u, const double *w, double *p, double *s, double *x, double *r) {
+  KScope ks(ctx, IFEM_KC_CG_RECURRENCE, double(n) * (diag ? 104.0 : 88.0), 8.0 * double(n));
+  if (n) hipLaunchKernelGGL(k_cg1_update, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, ctx->scal.p, diag, u, w, p, s, x, r);
+}
+
 double v_dot(ifem_ctx *ctx, int64_t n, const double *x, const double *y) {
   double out = 0;
   v_mdot(ctx, n, 1, x, n, y, &out);

@@ -115,10 +115,13 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
 
 // Krylov bases of the flexible solvers grow with the iteration count instead of being sized for the restart length: FGMRES(30) at
 // 128^3 would hold 61 vectors of 425 MB where the bench's solves use 2 to 14.  Contents are kept; new columns are zero.
-static void grow_basis(ifem_ctx *c, DBuf<double> &B, int64_t ld, int64_t cols) {
+// max_cols: the most columns the solver can ever ask for (restart length + 1): growth never goes beyond it (rounded up to the
+// multiple of 4 the fused kernels read), so FGMRES(30) ends at 32 columns, not at 36
+static void grow_basis(ifem_ctx *c, DBuf<double> &B, int64_t ld, int64_t cols, int64_t max_cols) {
   const int64_t have = ld > 0 ? int64_t(B.n) / ld : 0;
   if (have >= cols || ld <= 0) return;
-  const int64_t want = std::max<int64_t>((cols + 7) / 8 * 8, have + have / 2);
+  const int64_t cap = std::max<int64_t>((std::max(max_cols, cols) + 3) / 4 * 4, cols);
+  const int64_t want = std::min(cap, std::max<int64_t>((cols + 7) / 8 * 8, have + have / 2));
   DBuf<double> nb;
   nb.alloc(size_t(want) * size_t(ld));
   if (have > 0) IFEM_HIP_CHECK(hipMemcpyAsync(nb.p, B.p, size_t(have) * size_t(ld) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -129,8 +132,8 @@ static void grow_basis(ifem_ctx *c, DBuf<double> &B, int64_t ld, int64_t cols) {
 // the callback gmres() gets for the pair (V: up to max_v columns, Z: up to max_v - 1)
 static std::function<void(int, double *&, double *&)> basis_grower(ifem_ctx *c, DBuf<double> &Vb, DBuf<double> &Zb, int64_t ld, int max_v) {
   return [c, &Vb, &Zb, ld, max_v](int cols, double *&V, double *&Z) {
-    grow_basis(c, Vb, ld, std::min(cols, max_v));
-    grow_basis(c, Zb, ld, std::min(cols - 1, max_v - 1));
+    grow_basis(c, Vb, ld, std::min(cols, max_v), max_v);
+    grow_basis(c, Zb, ld, std::min(cols - 1, max_v - 1), max_v - 1);
     V = Vb.p; Z = Zb.p;
   };
 }
@@ -231,7 +234,28 @@ static int cg(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *b, double *
 // tighten the solve).  Same iterates as cg() / pcg_jacobi() up to that point.  On several ranks the partial sums are
 // all-reduced on the stream (RCCL) between the reduction and the scalar update: still no host round trip per iteration.
 static int cg_device(ifem_ctx *ctx, int64_t n, const OpFn &A, const double *diag, const double *b, double *x, double tol,
-                     int maxit, double *r, double *z, double *p, double *q, int chk) {
+                     int maxit, double *r, double *z, double *p, double *q, int chk, double *s = nullptr) {
+  if (s && ctx->tune.cg_single_reduction) {
+    // one reduction per iteration (linalg.hip::cg1_*): u = D^-1 r lives in z (or IS r), w = A u in q, s = A p
+    double *u = diag ? z : r, *w = q;
+    cg1_init(ctx, n, b, diag, x, r, u, p, s);
+    A(u, w);
+    cg1_dots(ctx, n, r, u, w, true);
+    int it = 0;
+    double rr = cgd_rr(ctx);
+    while (std::sqrt(rr) > tol && it < maxit) {
+      const int burst = std::min(chk, maxit - it);
+      for (int k = 0; k < burst; ++k) {
+        cg1_update(ctx, n, diag, u, w, p, s, x, r);
+        A(u, w);
+        cg1_dots(ctx, n, r, u, w, false);
+      }
+      it += burst;
+      rr = cgd_rr(ctx);
+      if (!(rr == rr)) break; // NaN guard
+    }
+    return it;
+  }
   cgd_init(ctx, n, b, diag, x, r, z, p);
   int it = 0;
   double rr = cgd_rr(ctx);
@@ -292,7 +316,7 @@ struct SolveState {
   double p_src_norm = 0, u_src_norm = 0; // norms of the pressure / velocity parts of the vector the preconditioner is applied to
   bool tight_candidate = false, tight_used = false; // inner_rel_first: the solve qualified for it / its first application ran with it
   // workspace carved out of ctx->work
-  double *xu_ext, *xp_ext, *tu, *tp[6], *utmp, *inner_w, *inner_z, *outer_w;
+  double *xu_ext, *xp_ext, *tu, *tp[7], *utmp, *inner_w, *inner_z, *outer_w;
 };
 
 // ghost-extended views of a compact owned vector [u_o | p_o]
@@ -438,6 +462,18 @@ static void sm_apply(SolveState &S, const double *x, double *y, bool lowp) {
 // CG may use it as its preconditioner.  Level vectors (ctx->mg_vec, nPl + 8 each): 0 right-hand side / residual,
 // 1 solution, 2 Chebyshev direction, 3 operator product, 4 prolongated correction.  Compact owned entries come first, so
 // the same buffers serve as ghost-extended pressure vectors for the transfers.
+// A replicated coarse level (a single-rank context of the whole coarse mesh below a partitioned level) is computed by every rank
+// on its own device: its operators carry float / double atomics whose order differs between devices, so the replicas agree to
+// rounding only, and replica-local decisions (the 1 % early exit of a power iteration) may differ.  Quantities that steer the
+// smoother -- the Chebyshev bounds -- are therefore agreed on over the partitioned level's communicator (maximum over the ranks):
+// every rank then applies the SAME polynomial, and the level stays one (symmetric) preconditioner for all of them.
+static ifem_ctx *replica_world(ifem_ctx *c) {
+  if (c->halo.nranks > 1) return nullptr;
+  for (ifem_ctx *p = c->mg_fine; p; p = p->mg_fine)
+    if (p->halo.nranks > 1) return p;
+  return nullptr;
+}
+
 struct MgSm {
   std::vector<SolveState> L; // level 0 = the context being solved
   bool lowp = false;
@@ -500,6 +536,7 @@ static void mg_sm_setup(MgSm &M, int use_nonzero) {
       if ((int64_t)c->sm_eig.n != S.npo) c->sm_eig.alloc((size_t)S.npo);
       v_copy(c, S.npo, x, c->sm_eig.p);
     }
+    if (ifem_ctx *w = replica_world(c)) allreduce_max(w, &lam, 1);
     c->sm_lmax = lam > 0 ? lam : 1.0;
     c->sm_mg_version = c->sm_version;
   }
@@ -726,6 +763,7 @@ static void mg_uu_setup(MgUu &M, bool force_bounds = false) {
       if ((int64_t)c->uu_eig.n != S.nuo) c->uu_eig.alloc((size_t)S.nuo);
       v_copy(c, S.nuo, x, c->uu_eig.p);
     }
+    if (ifem_ctx *w = replica_world(c)) allreduce_max(w, &lam, 1);
     c->uu_lmax = lam > 0 && std::isfinite(lam) ? lam : 1.0;
     c->uu_lmax_evn = f0->uu_evn;
     for (int i = 0; i < 6; ++i) c->uu_lmax_key[i] = key[i];
@@ -798,7 +836,16 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     allreduce_sum(S.ctx, &uu, 1);
     S.u_src_norm = std::sqrt(uu);
   }
-  Clock ck;
+  // section marks on the stream (read by precond_section_times once the solve is over)
+  auto mark = [&]() {
+    if (c->pc_ev.size() <= c->pc_used) {
+      hipEvent_t e = nullptr;
+      IFEM_HIP_CHECK(hipEventCreate(&e));
+      c->pc_ev.push_back(e);
+    }
+    IFEM_HIP_CHECK(hipEventRecord(c->pc_ev[c->pc_used++], c->stream));
+  };
+  mark();
   // CG for Mp (:69-84)
   // the approximate-preconditioner kinds stream M_p in single precision like S_m (the solve is to 1e-6, the rounding of the
   // values 6e-8).  (p.q fused into this SpMV was measured: a block reduction in each of its 67 k small blocks costs more
@@ -829,17 +876,15 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   if (dev_cg) {
     if (pjac) scalar_diag(c, c->Mp, c->Mp.val.p, S.tp[5]);
     S.st.cg_mp_iters += cg_device(c, S.npo, mp, pjac ? S.tp[5] : nullptr, src1, tmp, std::max(o->mp_abs, o->mp_rel * n1), pmax,
-                                  S.tp[1], S.tp[2], S.tp[3], S.tp[4], 4);
+                                  S.tp[1], S.tp[2], S.tp[3], S.tp[4], 4, S.tp[6]);
   } else if (pjac) {
     scalar_diag(c, c->Mp, c->Mp.val.p, S.tp[5]);
     S.st.cg_mp_iters += pcg_jacobi(c, S.npo, mp, S.tp[5], src1, tmp, std::max(o->mp_abs, o->mp_rel * n1), pmax, S.tp[1], c->nPl, S.tp[3], S.tp[4], pmdot); // r = tp[1], z = tp[2]
   } else
   S.st.cg_mp_iters += cg(c, S.npo, mp, src1, tmp, std::max(o->mp_abs, o->mp_rel * n1), pmax, r, p, q, pdot);
   v_scale(c, S.npo, -(P->viscosity + P->grad_div * P->rho), tmp);
-  IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
-  S.st.t_cg_mp_ms += ck.ms();
+  mark();
   // CG for Sm (:86-112)
-  Clock ck2;
   const bool lowp_all = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF || o->ainv_kind == IFEM_AINV_MG;
   sm_ensure(S);
   OpFn sm = [&](const double *x, double *y) { sm_apply(S, x, y, lowp_all); };
@@ -864,7 +909,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     S.st.sm_mg_levels = (uint32_t)M.L.size();
   } else if (dev_cg) // (Jacobi on S_m was measured too: 176 instead of 172 iterations -- its diagonal is nearly constant)
     S.st.cg_sm_iters += cg_device(c, S.npo, sm, nullptr, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, S.tp[1], S.tp[2],
-                                  S.tp[3], S.tp[4], 4);
+                                  S.tp[3], S.tp[4], 4, S.tp[6]);
   else
     S.st.cg_sm_iters += cg(c, S.npo, sm, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, r, p, q, pdot);
   v_axpby(c, S.npo, 1.0, tmp, -P->rho / P->dt, dst1);
@@ -874,10 +919,8 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     spmv_bt(c, xe, S.utmp);
     v_axpby(c, S.nuo, 1.0, src0, -1.0, S.utmp);
   }
-  IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
-  S.st.t_cg_sm_ms += ck2.ms();
+  mark();
   // A~^-1 utmp (:124-127)
-  Clock ck3;
   const bool f32 = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32;
   OpFn Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_uu(c, xe, nullptr, y, f32); };
   if (o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF)
@@ -950,8 +993,8 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
       } else { // flexible GMRES: the preconditioned directions are kept, so the update needs no extra V-cycle
         const int64_t ld = basis_ld(S.ctx, S.nuo);
         const int mi = std::max(1, o->inner_restart);
-        grow_basis(c, c->innerV, ld, std::min(mi + 1, kBasisStart));
-        grow_basis(c, c->innerZ, ld, std::min(mi, kBasisStart));
+        grow_basis(c, c->innerV, ld, std::min(mi + 1, kBasisStart), mi + 1);
+        grow_basis(c, c->innerZ, ld, std::min(mi, kBasisStart), mi);
         const auto grow = basis_grower(c, c->innerV, c->innerZ, ld, mi + 1);
         S.st.inner_iters += gmres(c, S.nuo, ld, /*reorth=*/false, Amf, Vc, true, S.utmp, dst0, mi, o->inner_maxit, inner_rel_now * un,
                                   c->innerV.p, c->innerZ.p, S.inner_w, &res, mdot, nullptr, &grow);
@@ -974,15 +1017,14 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
         const int64_t ldj = basis_ld(S.ctx, S.nuo);
         const int mj = std::max(1, o->inner_restart);
         const std::function<void(int, double *&, double *&)> growv = [&](int cols, double *&V, double *&) {
-          grow_basis(c, c->innerV, ldj, std::min(cols, mj + 1)); // (not flexible: one z vector)
+          grow_basis(c, c->innerV, ldj, std::min(cols, mj + 1), mj + 1); // (not flexible: one z vector)
           V = c->innerV.p;
         };
         S.st.inner_iters += gmres(c, S.nuo, ldj, /*reorth=*/false, Amf, Pbj, false, S.utmp, dst0, mj,
                                   std::max(o->inner_maxit, 50), inner_rel_now * un, c->innerV.p, S.inner_z, S.inner_w, &res, mdot, nullptr, &growv);
       }
     }
-    IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
-    S.st.t_ainv_ms += ck3.ms();
+    mark();
     S.st.precond_applies++;
     return;
   }
@@ -995,9 +1037,20 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   } else
   S.st.inner_iters += gmres(c, S.nuo, basis_ld(S.ctx, S.nuo), /*reorth=*/false, Auu, Pj, false, S.utmp, dst0, o->inner_restart,
                             o->inner_maxit, inner_rel_now * un, c->innerV.p, S.inner_z, S.inner_w, &res, mdot);
-  IFEM_HIP_CHECK(hipStreamSynchronize(c->stream));
-  S.st.t_ainv_ms += ck3.ms();
+  mark();
   S.st.precond_applies++;
+}
+
+// device time of the three sections of every preconditioner application since pc_used was reset; the stream must be idle
+static void precond_section_times(ifem_ctx *c, ifem_solve_stats &st) {
+  for (size_t k = 0; k + 3 < c->pc_used; k += 4) {
+    float a = 0, b = 0, d = 0;
+    if (hipEventElapsedTime(&a, c->pc_ev[k], c->pc_ev[k + 1]) == hipSuccess && hipEventElapsedTime(&b, c->pc_ev[k + 1], c->pc_ev[k + 2]) == hipSuccess &&
+        hipEventElapsedTime(&d, c->pc_ev[k + 2], c->pc_ev[k + 3]) == hipSuccess) {
+      st.t_cg_mp_ms += a; st.t_cg_sm_ms += b; st.t_ainv_ms += d;
+    }
+  }
+  c->pc_used = 0;
 }
 
 // The inner Krylov basis is shared by every solver of the context.  The single-precision-basis kernels read (with zero
@@ -1013,7 +1066,7 @@ static void carve_workspace(SolveState &S, bool krylov) {
   ifem_ctx *c = S.ctx;
   const int64_t nul = c->dim * c->nUl, npl = c->nPl;
   S.nuo = c->dim * c->nUo; S.npo = c->nPo; S.n = S.nuo + S.npo;
-  const int64_t need = nul + npl + 4 * nul + 6 * npl + S.n + 64;
+  const int64_t need = nul + npl + 4 * nul + 7 * npl + S.n + 64;
   if ((int64_t)c->work.n < need) c->work.alloc(need);
   double *p = c->work.p;
   S.xu_ext = p; p += nul;
@@ -1022,12 +1075,12 @@ static void carve_workspace(SolveState &S, bool krylov) {
   S.utmp = p; p += nul;
   S.inner_w = p; p += nul;
   S.inner_z = p; p += nul;
-  for (int i = 0; i < 6; ++i) { S.tp[i] = p; p += npl; }
+  for (int i = 0; i < 7; ++i) { S.tp[i] = p; p += npl; }
   S.outer_w = p;
   if (!krylov) return; // a coarse multigrid level: vector scratch only
   const int m = S.o->fgmres_restart, mi = S.o->inner_restart;
-  grow_basis(c, c->krylovV, basis_ld(S.ctx, S.n), std::min(m + 1, kBasisStart)); // the rest on demand (basis_grower)
-  grow_basis(c, c->krylovZ, basis_ld(S.ctx, S.n), std::min(m, kBasisStart));
+  grow_basis(c, c->krylovV, basis_ld(S.ctx, S.n), std::min(m + 1, kBasisStart), m + 1); // the rest on demand (basis_grower)
+  grow_basis(c, c->krylovZ, basis_ld(S.ctx, S.n), std::min(m, kBasisStart), m);
   // the inner solve of IFEM_AINV_MG is flexible too and grows its bases the same way; the other kinds' kernels want theirs whole
   grow_inner_basis(c, (int64_t)(S.o->ainv_kind == IFEM_AINV_MG ? std::min(mi + 1, kBasisStart) : mi + 1) * basis_ld(S.ctx, S.nuo));
 }
@@ -1035,7 +1088,9 @@ static void carve_workspace(SolveState &S, bool krylov) {
 void ins_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o, const double *src, double *dst) {
   SolveState S{ctx, P, o};
   carve_workspace(S);
+  ctx->pc_used = 0;
   precond_vmult(S, src, dst);
+  ctx->pc_used = 0;
 }
 
 // right-hand side of the condensed system after an assembly that treated the hanging dofs as ordinary ones:
@@ -1176,6 +1231,7 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   SolveState S{ctx, P, o};
   carve_workspace(S);
   Clock total;
+  ctx->pc_used = 0;
   ctx->spmv_uu_ms_total = 0;
   ctx->timing.spmv_uu_calls = 0;
   ctx->mf_ms_total = 0;
@@ -1207,6 +1263,7 @@ int ins_solve(ifem_ctx *ctx, const ifem_ins_params *P, const ifem_solver_opts *o
   } else if (S.tight_candidate && ctx->tight_first_backoff > 0)
     ctx->tight_first_backoff--;
   S.st.inner_first_tight = S.tight_used ? 1u : 0u;
+  precond_section_times(ctx, S.st); // (the stream was synchronised above)
   S.st.fgmres_iters = it;
   S.st.fgmres_res = res;
   S.st.t_total_ms = total.ms();
