@@ -79,6 +79,7 @@ FAMILY_KERNELS = {
     "cg_recurrence": "k_cgd_init / k_cgd_update / k_cgd_p / k_cgd_scalars",
     "schur_setup": "k_schur_numeric, masked geometry blocks",
     "other": "constraints, hanging nodes",
+    "tpp_ilu": "k_tpp_numeric, k_ilu_factor, k_ilu_solve / k_ilu_solve_batch, SpMV of T_pp (SCnsIM)",
 }
 COMPUTE_PEAK = {"assemble_cells": ("FP64 MFMA", FP64_PEAK_TFLOPS), "mf_cell": ("FP32 vector FMA", FP32_VECTOR_PEAK_TFLOPS)}
 

@@ -187,6 +187,9 @@ typedef struct {
   int32_t uu_row_order;  /* 1 (default): 3D Q2/Q1 contexts store the blocks of an A_uu row in the order (last cell, first cell, column) of the
                             cells that touch them instead of column order, so that a cell's part of a row is a few contiguous runs for the
                             cell kernel's atomics (takes effect before the first assembly of the context); 0: column order */
+  int32_t eig_steps;     /* 0 (default: 12 / 14): power-iteration steps of a COLD estimate of the smoothers' eigenvalue bounds (lambda_max of
+                            (block D)^-1 A_uu and of D^-1 S_m on every level); > 0: that many */
+  int32_t eig_reserved;
 } ifem_tuning;
 void ifem_default_tuning(ifem_tuning *t);
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t);
@@ -531,7 +534,8 @@ int ifem_get_timing(ifem_ctx *ctx, ifem_timing *t);
 #define IFEM_KC_CG_RECURRENCE 13 /* k_cgd_*: device-resident CG recurrences */
 #define IFEM_KC_SCHUR_SETUP 14  /* geometry blocks, k_schur_numeric */
 #define IFEM_KC_OTHER 15        /* constraints, hanging nodes, halo packing */
-#define IFEM_KC_COUNT 16
+#define IFEM_KC_TPP 16          /* SCnsIM: k_tpp_numeric, the ILU(0) of T_pp (factorisation, level-scheduled triangular solves), its SpMV */
+#define IFEM_KC_COUNT 17
 typedef struct {
   int32_t family;   /* IFEM_KC_* */
   uint32_t scopes;  /* launch-wrapper calls logged (a scope may hold two launches, e.g. the two stages of a reduction) */

@@ -98,7 +98,7 @@ class MgTransfer(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("geo_cache", C.c_int32), ("xcd_swizzle", C.c_int32), ("asm_skip", C.c_int32), ("spmv_lanes", C.c_int32),
                 ("sm_lanes", C.c_int32), ("mf_f32", C.c_int32), ("tpp_operator", C.c_int32), ("spmv_pipe", C.c_int32), ("halo_overlap", C.c_int32),
-                ("asm3_variant", C.c_int32), ("cg_single_reduction", C.c_int32), ("asm3_cpb", C.c_int32), ("tpp_milu_permille", C.c_int32), ("tpp_ilu_order", C.c_int64), ("basis_pad", C.c_int64), ("tpp_tri_sweeps", C.c_int32), ("uu_row_order", C.c_int32)]
+                ("asm3_variant", C.c_int32), ("cg_single_reduction", C.c_int32), ("asm3_cpb", C.c_int32), ("tpp_milu_permille", C.c_int32), ("tpp_ilu_order", C.c_int64), ("basis_pad", C.c_int64), ("tpp_tri_sweeps", C.c_int32), ("uu_row_order", C.c_int32), ("eig_steps", C.c_int32), ("eig_reserved", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -112,7 +112,7 @@ class KprofEntry(C.Structure):
     _fields_ = [("family", C.c_int32), ("scopes", C.c_uint32), ("ms", C.c_double), ("bytes", C.c_double), ("flops", C.c_double)]
 
 
-KC_COUNT = 16  # IFEM_KC_COUNT
+KC_COUNT = 17  # IFEM_KC_COUNT
 
 
 def kprof_end(L, ctx):

@@ -117,7 +117,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
 
 void ifem_default_tuning(ifem_tuning *t) {
   t->geo_cache = 1; t->xcd_swizzle = 1; t->asm_skip = 0; t->spmv_lanes = 32; t->sm_lanes = 32; t->mf_f32 = 1;
-  t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->cg_single_reduction = 1; t->asm3_cpb = 2; t->tpp_milu_permille = 950; t->tpp_ilu_order = 2; t->basis_pad = 32 * 33; t->tpp_tri_sweeps = 0; t->uu_row_order = 1;
+  t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->cg_single_reduction = 1; t->asm3_cpb = 2; t->tpp_milu_permille = 950; t->tpp_ilu_order = 2; t->basis_pad = 32 * 33; t->tpp_tri_sweeps = 0; t->uu_row_order = 1; t->eig_steps = 0; t->eig_reserved = 0;
 }
 
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
@@ -1056,7 +1056,7 @@ int ifem_kprof_end(ifem_ctx *ctx, ifem_kprof_entry *out, int32_t max_entries) {
 
 const char *ifem_kprof_family_name(int32_t family) {
   static const char *names[IFEM_KC_COUNT] = {"assemble_cells", "zero_fill", "spmv_uu", "spmv_b_bt", "mf_cell", "mf_gather", "spmv_sm", "spmv_mp",
-                                             "mdot", "maxpy", "vector_ops", "mg_transfer", "smoother_setup", "cg_recurrence", "schur_setup", "other"};
+                                             "mdot", "maxpy", "vector_ops", "mg_transfer", "smoother_setup", "cg_recurrence", "schur_setup", "other", "tpp_ilu"};
   return family >= 0 && family < IFEM_KC_COUNT ? names[family] : "?";
 }
 

@@ -428,6 +428,7 @@ static void launch_scns_t(ifem_ctx *ctx, const ScnsArgs &A) {
 
 void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonzero) {
   hipStream_t s = ctx->stream;
+  KScope ks(ctx, IFEM_KC_ASSEMBLE, 16.0 * double(ctx->Auu.val.n + ctx->Bt.val.n + ctx->B.val.n + ctx->Mp.val.n)); // (zero fill + cell kernel + block-Jacobi set-up)
   if (ctx->App.n != ctx->Mp.val.n) ctx->App.alloc(ctx->Mp.val.n);
   ensure_auu_values(ctx);
   IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));

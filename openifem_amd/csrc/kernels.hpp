@@ -101,12 +101,14 @@ void v_axpy(ifem_ctx *ctx, int64_t n, double a, const double *x, double *y);    
 void v_axpby(ifem_ctx *ctx, int64_t n, double a, const double *x, double b, double *y); // y = a x + b y
 void v_scale(ifem_ctx *ctx, int64_t n, double a, double *x);
 void v_copy(ifem_ctx *ctx, int64_t n, const double *x, double *y);
+void v_scale_to(ifem_ctx *ctx, int64_t n, double a, const double *x, double *y); // y = a x
 void v_zero(ifem_ctx *ctx, int64_t n, double *x);
 double v_dot(ifem_ctx *ctx, int64_t n, const double *x, const double *y); // local (no all-reduce), syncs
 // multi-dot: out[i] = <V_i, w> for i < k (V column-major with leading dimension ld), one pass, syncs
 void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *w, double *out_host, bool all_ranks = false);
 // w -= sum_i h[i] V_i
-void v_maxpy(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *h_host, double *w);
+void v_maxpy(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *h_host, double *w, double *norm2_out = nullptr,
+             bool all_ranks = false);
 // single-precision Krylov basis (inner solver): V float, w / coefficients / accumulation double
 void v_mdot_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, const double *w, double *out_host);
 void v_maxpy_f32(ifem_ctx *ctx, int64_t n, int k, const float *V, int64_t ld, const double *h_host, double *w, double *norm2_out);

@@ -852,6 +852,14 @@ void v_scale(ifem_ctx *ctx, int64_t n, double a, double *x) {
   KScope ks(ctx, IFEM_KC_VECTOR, 16.0 * double(n));
   if (n) hipLaunchKernelGGL(k_scale, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, x);
 }
+__global__ void k_scale_to(int64_t n, double a, const double *__restrict__ x, double *__restrict__ y) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] = a * x[i];
+}
+// y = a x (the normalised Krylov vector in one pass instead of a copy and a scaling)
+void v_scale_to(ifem_ctx *ctx, int64_t n, double a, const double *x, double *y) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 16.0 * double(n));
+  if (n) hipLaunchKernelGGL(k_scale_to, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, x, y);
+}
 void v_copy(ifem_ctx *ctx, int64_t n, const double *x, double *y) {
   KScope ks(ctx, IFEM_KC_VECTOR, 16.0 * double(n));
   if (n) IFEM_HIP_CHECK(hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -927,18 +935,50 @@ __global__ __launch_bounds__(256) void k_mdot(int64_t n, int k0, const double *_
   block_reduce_store<K>(acc, out + int64_t(k0) * MDOT_MAXB);
 }
 
-template <int K>
-__global__ __launch_bounds__(256) void k_maxpy(int64_t n, int k0, const double *__restrict__ V, int64_t ld,
-                                               const double *__restrict__ h, double *__restrict__ w) {
-  double hk[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) hk[k] = h[k0 + k];
+// the K coefficients of one pass travel as kernel arguments (no staging buffer, no host wait); NORM: the pass also leaves the
+// block sums of ||w||^2 of the updated vector in `part` (the last pass of a Gram-Schmidt sweep: the norm costs no extra pass)
+struct MaxpyCoef { double v[8]; };
+template <int K, bool NORM>
+__global__ __launch_bounds__(256) void k_maxpy(int64_t n, int k0, const double *__restrict__ V, int64_t ld, MaxpyCoef hk,
+                                               double *__restrict__ w, double *__restrict__ part) {
+  double acc[1] = {0};
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
     double t = w[i];
 #pragma unroll
-    for (int k = 0; k < K; ++k) t -= hk[k] * V[int64_t(k0 + k) * ld + i];
+    for (int k = 0; k < K; ++k) t -= hk.v[k] * V[int64_t(k0 + k) * ld + i];
     w[i] = t;
+    if (NORM) acc[0] += t * t;
   }
+  if (NORM) block_reduce_store<1>(acc, part);
+}
+
+// Short vectors (the pressure space of the reference's SCnsIM tests: a few thousand entries, GMRES(200) on T_pp): the passes above
+// cost a launch per 8 columns plus the final reduction, and the launches -- not the bytes -- are the time.  One launch for any number
+// of columns: block b owns column b and writes its dot product directly; the multi-axpy takes up to 64 coefficients as arguments.
+constexpr int64_t kShortVector = 32768;
+__global__ __launch_bounds__(256) void k_mdot_cols(int64_t n, const double *__restrict__ V, int64_t ld, const double *__restrict__ w,
+                                                   double *__restrict__ out) {
+  const double *v = V + int64_t(blockIdx.x) * ld;
+  double t = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) t += v[i] * w[i];
+  __shared__ double sh[4];
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+struct MaxpyCoef64 { double v[64]; };
+template <bool NORM>
+__global__ __launch_bounds__(256) void k_maxpy_cols(int64_t n, int k, const double *__restrict__ V, int64_t ld, MaxpyCoef64 hk,
+                                                    double *__restrict__ w, double *__restrict__ part) {
+  double acc[1] = {0};
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    double t = w[i];
+    for (int c = 0; c < k; ++c) t -= hk.v[c] * V[int64_t(c) * ld + i];
+    w[i] = t;
+    if (NORM) acc[0] += t * t;
+  }
+  if (NORM) block_reduce_store<1>(acc, part);
 }
 
 // out_host[i] = <V_i, w>, i < k.  Device scalars live in ctx->scal[0..63].  all_ranks = false: the local sums; true: summed
@@ -962,7 +1002,10 @@ void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const 
     return;
   }
   const unsigned nblk = vgrid(n);
-  {
+  if (n <= kShortVector) {
+    KScope ks(ctx, IFEM_KC_MDOT, 16.0 * double(n) * k, 2.0 * double(n) * k);
+    hipLaunchKernelGGL(k_mdot_cols, dim3(k), dim3(256), 0, s, n, V, ld, w, ctx->scal.p);
+  } else {
   // every pass of K columns re-reads w; a column that IS w (norms) is counted once
   KScope ks(ctx, IFEM_KC_MDOT, 8.0 * double(n) * (double(k) + double((k + 7) / 8) - (V == w ? 1.0 : 0.0)), 2.0 * double(n) * k);
   int k0 = 0;
@@ -981,29 +1024,51 @@ void v_mdot(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const 
   for (int i = 0; i < k; ++i) out_host[i] = ctx->h_scal[i];
 }
 
-void v_maxpy(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *h_host, double *w) {
-  if (n == 0 || k == 0) return;
-  if (k > 64) {
-    for (int k0 = 0; k0 < k; k0 += 64) v_maxpy(ctx, n, std::min(64, k - k0), V + int64_t(k0) * ld, ld, h_host + k0, w);
-    return;
-  }
+// w -= sum_i h_i V_i.  norm2_out != nullptr: ||w||^2 of the result comes back with it (fused into the last pass; summed over the ranks
+// on the stream when all_ranks) -- the one host wait of the call; without it the call does not wait for the device at all.
+void v_maxpy(ifem_ctx *ctx, int64_t n, int k, const double *V, int64_t ld, const double *h_host, double *w, double *norm2_out, bool all_ranks) {
   hipStream_t s = ctx->stream;
-  // coefficients go through the second half of the scalar buffer
-  for (int i = 0; i < k; ++i) ctx->h_scal[64 + i] = h_host[i];
-  IFEM_HIP_CHECK(hipMemcpyAsync(ctx->scal.p + 64, ctx->h_scal + 64, k * sizeof(double), hipMemcpyHostToDevice, s));
-  {
-  KScope ks(ctx, IFEM_KC_MAXPY, 8.0 * double(n) * (double(k) + 2.0 * double((k + 7) / 8)), 2.0 * double(n) * k);
-  int k0 = 0;
-  while (k0 < k) {
-    const int r = k - k0;
-    if (r >= 8) { hipLaunchKernelGGL((k_maxpy<8>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, ctx->scal.p + 64, w); k0 += 8; }
-    else if (r >= 4) { hipLaunchKernelGGL((k_maxpy<4>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, ctx->scal.p + 64, w); k0 += 4; }
-    else if (r >= 2) { hipLaunchKernelGGL((k_maxpy<2>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, ctx->scal.p + 64, w); k0 += 2; }
-    else { hipLaunchKernelGGL((k_maxpy<1>), dim3(vgrid(n)), dim3(256), 0, s, n, k0, V, ld, ctx->scal.p + 64, w); k0 += 1; }
+  all_ranks = all_ranks && ctx->halo.nranks > 1;
+  if (norm2_out && ctx->partials.n == 0) ctx->partials.alloc(size_t(64) * MDOT_MAXB);
+  const unsigned nblk = vgrid(n);
+  if (n > 0 && k > 0 && n <= kShortVector) {
+    KScope ks(ctx, IFEM_KC_MAXPY, 8.0 * double(n) * (double(k) + 2.0 * double((k + 63) / 64)), 2.0 * double(n) * k + (norm2_out ? 2.0 * double(n) : 0.0));
+    for (int k0 = 0; k0 < k; k0 += 64) {
+      const int kk = std::min(64, k - k0);
+      MaxpyCoef64 c{};
+      for (int i = 0; i < kk; ++i) c.v[i] = h_host[k0 + i];
+      if (norm2_out && k0 + kk >= k) hipLaunchKernelGGL((k_maxpy_cols<true>), dim3(nblk), dim3(256), 0, s, n, kk, V + int64_t(k0) * ld, ld, c, w, ctx->partials.p);
+      else hipLaunchKernelGGL((k_maxpy_cols<false>), dim3(nblk), dim3(256), 0, s, n, kk, V + int64_t(k0) * ld, ld, c, w, ctx->partials.p);
+    }
+  } else if (n > 0 && k > 0) {
+    KScope ks(ctx, IFEM_KC_MAXPY, 8.0 * double(n) * (double(k) + 2.0 * double((k + 7) / 8)), 2.0 * double(n) * k + (norm2_out ? 2.0 * double(n) : 0.0));
+    int k0 = 0;
+    while (k0 < k) {
+      const int r = k - k0;
+      const int K = r >= 8 ? 8 : (r >= 4 ? 4 : (r >= 2 ? 2 : 1));
+      const bool last = norm2_out && k0 + K >= k;
+      MaxpyCoef c{};
+      for (int i = 0; i < K; ++i) c.v[i] = h_host[k0 + i];
+#define IFEM_MAXPY_D(KK)                                                                                                \
+      { if (last) hipLaunchKernelGGL((k_maxpy<KK, true>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, c, w, ctx->partials.p);   \
+        else hipLaunchKernelGGL((k_maxpy<KK, false>), dim3(nblk), dim3(256), 0, s, n, k0, V, ld, c, w, ctx->partials.p); }
+      if (K == 8) IFEM_MAXPY_D(8) else if (K == 4) IFEM_MAXPY_D(4) else if (K == 2) IFEM_MAXPY_D(2) else IFEM_MAXPY_D(1)
+#undef IFEM_MAXPY_D
+      k0 += K;
+    }
   }
-  }
-  // h_scal[64..] must stay untouched until the copy has been consumed
+  if (!norm2_out) return;
+  if (n > 0 && k > 0) hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, (int)nblk, ctx->partials.p, ctx->scal.p);
+  else if (n > 0) { // nothing to subtract: the plain norm
+    double out = 0;
+    v_mdot(ctx, n, 1, w, n, w, &out, all_ranks);
+    *norm2_out = out;
+    return;
+  } else IFEM_HIP_CHECK(hipMemsetAsync(ctx->scal.p, 0, sizeof(double), s)); // a rank without entries still takes part in the sum
+  if (all_ranks) allreduce_sum_dev(ctx, ctx->scal.p, 1);
+  IFEM_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
   IFEM_HIP_CHECK(hipStreamSynchronize(s));
+  *norm2_out = ctx->h_scal[0];
 }
 
 // ---- single-precision Krylov basis of the inner (preconditioner-only) GMRES: V float, every other vector and all

@@ -49,8 +49,7 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
     const double beta = std::sqrt(bb);
     res = beta;
     if (res <= tol || it >= maxit || !std::isfinite(res)) break; // (deal.II's SolverControl::check fails on a NaN as well)
-    v_copy(ctx, n, w, V);
-    v_scale(ctx, n, 1.0 / beta, V);
+    v_scale_to(ctx, n, 1.0 / beta, w, V);
     std::fill(g.begin(), g.end(), 0.0);
     g[0] = beta;
     int j = 0;
@@ -61,22 +60,22 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
       double *zj = flexible ? Z + (int64_t)j * ld : Z;
       Pinv(vj, zj);
       A(zj, w);
+      // classical Gram-Schmidt (twice with reorth); ||w||^2 comes out of the last multi-axpy pass (summed over the ranks like the
+      // dot products of `mdot`): per iteration the host waits for the device once per pass, not three / five times
+      double ww = 0;
       mdot(j + 1, V, ld, w, h.data());
-      v_maxpy(ctx, n, j + 1, V, ld, h.data(), w);
       if (reorth) {
+        v_maxpy(ctx, n, j + 1, V, ld, h.data(), w);
         mdot(j + 1, V, ld, w, h2.data());
-        v_maxpy(ctx, n, j + 1, V, ld, h2.data(), w);
-      } else
+        v_maxpy(ctx, n, j + 1, V, ld, h2.data(), w, &ww, true);
+      } else {
+        v_maxpy(ctx, n, j + 1, V, ld, h.data(), w, &ww, true);
         std::fill(h2.begin(), h2.end(), 0.0);
+      }
       for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = h[i] + h2[i];
-      double ww;
-      mdot(1, w, n, w, &ww);
       const double hn = std::sqrt(ww);
       H[(size_t)(j + 1) * m + j] = hn;
-      if (hn > 0) {
-        v_copy(ctx, n, w, V + (int64_t)(j + 1) * ld);
-        v_scale(ctx, n, 1.0 / hn, V + (int64_t)(j + 1) * ld);
-      }
+      if (hn > 0) v_scale_to(ctx, n, 1.0 / hn, w, V + (int64_t)(j + 1) * ld);
       for (int i = 0; i < j; ++i) {
         const double t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
         H[(size_t)(i + 1) * m + j] = -sn[i] * H[(size_t)i * m + j] + cs[i] * H[(size_t)(i + 1) * m + j];
@@ -518,7 +517,8 @@ static void mg_sm_setup(MgSm &M, int use_nonzero) {
     if (warm) v_copy(c, S.npo, c->sm_eig.p, x);
     else vec_rough(c, S.npo, int64_t(c->halo.rank) * 1000003, x);
     double lam = 0;
-    for (int it = 0; it < 14; ++it) {
+    const int n_pow = c->tune.eig_steps > 0 ? c->tune.eig_steps : 14;
+    for (int it = 0; it < n_pow; ++it) {
       double nx = v_dot(c, S.npo, x, x);
       allreduce_sum(c, &nx, 1);
       if (!(nx > 0)) break;
@@ -745,7 +745,8 @@ static void mg_uu_setup(MgUu &M, bool force_bounds = false) {
     if (warm) v_copy(c, S.nuo, c->uu_eig.p, x);
     else vec_rough(c, S.nuo, int64_t(c->halo.rank) * 7000003, x);
     double lam = 0;
-    for (int it = 0; it < 12; ++it) {
+    const int n_pow = c->tune.eig_steps > 0 ? c->tune.eig_steps : 12;
+    for (int it = 0; it < n_pow; ++it) {
       double nx = v_dot(c, S.nuo, x, x);
       allreduce_sum(c, &nx, 1);
       if (!(nx > 0)) break;
@@ -765,6 +766,7 @@ static void mg_uu_setup(MgUu &M, bool force_bounds = false) {
     }
     if (ifem_ctx *w = replica_world(c)) allreduce_max(w, &lam, 1);
     c->uu_lmax = lam > 0 && std::isfinite(lam) ? lam : 1.0;
+    if (S.o->verbose) fprintf(stderr, "[ifem] A_uu V-cycle level %zu (%lld cells): lambda_max estimate %.4f (%s)\n", l, (long long)c->n_cells, c->uu_lmax, warm ? "warm" : "cold");
     c->uu_lmax_evn = f0->uu_evn;
     for (int i = 0; i < 6; ++i) c->uu_lmax_key[i] = key[i];
   }

@@ -113,6 +113,7 @@ void tpp_numeric(ifem_ctx *ctx) {
   const int maxlen = (Pt.max_row + 1) & ~1;
   const size_t smem = size_t(4) * maxlen * (sizeof(double) + sizeof(int32_t));
   const unsigned blocks = unsigned((n + 3) / 4);
+  KScope ks(ctx, IFEM_KC_TPP);
 #define IFEM_TPP(D)                                                                                                     \
   hipLaunchKernelGGL((k_tpp_numeric<D>), dim3(blocks), dim3(256), smem, ctx->stream, n, maxlen, Pt.rowptr.p,            \
                      Pt.col.p, ctx->Tpp.p, ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, ctx->Bt.rowptr.p,               \
@@ -128,6 +129,7 @@ void tpp_numeric(ifem_ctx *ctx) {
 
 void spmv_tpp(ifem_ctx *ctx, const double *xp, double *yp) {
   const PlanarCsr &Pt = tpp_pat(ctx);
+  KScope ks(ctx, IFEM_KC_TPP, double(Pt.nnzb) * 12.0 + double(Pt.n_rows) * 24.0);
   if (Pt.n_rows == 0) return;
   spmv_planar_scalar(ctx, Pt, ctx->Tpp.p, xp, yp);
 }
@@ -379,6 +381,7 @@ static void plan_sweep(const std::vector<int64_t> &lvl, std::vector<std::array<i
 }
 
 bool tpp_ilu_factor(ifem_ctx *ctx) {
+  KScope ks(ctx, IFEM_KC_TPP);
   TppIlu &I = ctx->tpp_ilu;
   const PlanarCsr &Pt = tpp_pat(ctx);
   const int64_t n = Pt.n_rows;
@@ -449,6 +452,7 @@ bool tpp_ilu_factor(ifem_ctx *ctx) {
 
 // y = (LU)^-1 x
 void tpp_ilu_apply(ifem_ctx *ctx, const double *x, double *y) {
+  KScope ks(ctx, IFEM_KC_TPP, double(tpp_pat(ctx).nnzb) * 12.0 + double(tpp_pat(ctx).n_rows) * 32.0);
   TppIlu &I = ctx->tpp_ilu;
   const PlanarCsr &Pt = tpp_pat(ctx);
   hipStream_t s = ctx->stream;
