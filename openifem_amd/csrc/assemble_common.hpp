@@ -49,17 +49,17 @@ struct AsmArgs {
   int debug_skip; // measurement builds only (-DIFEM_ASM_PROBES, ifem_tuning::asm_skip): 1 = no A_uu scatter, 2 = no contraction either
 };
 
-template <int DIM>
-__device__ inline double inv_small(const double *J, double *Ji) {
+template <int DIM, typename R = double>
+__device__ inline R inv_small(const R *J, R *Ji) {
   if constexpr (DIM == 2) {
-    const double det = J[0] * J[3] - J[1] * J[2];
-    const double r = 1.0 / det;
+    const R det = J[0] * J[3] - J[1] * J[2];
+    const R r = R(1) / det;
     Ji[0] = J[3] * r; Ji[1] = -J[1] * r; Ji[2] = -J[2] * r; Ji[3] = J[0] * r;
     return det;
   } else {
-    const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
-    const double det = J[0] * c00 + J[1] * c01 + J[2] * c02;
-    const double r = 1.0 / det;
+    const R c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+    const R det = J[0] * c00 + J[1] * c01 + J[2] * c02;
+    const R r = R(1) / det;
     Ji[0] = c00 * r; Ji[3] = c01 * r; Ji[6] = c02 * r;
     Ji[1] = (J[2] * J[7] - J[1] * J[8]) * r; Ji[4] = (J[0] * J[8] - J[2] * J[6]) * r; Ji[7] = (J[1] * J[6] - J[0] * J[7]) * r;
     Ji[2] = (J[1] * J[5] - J[2] * J[4]) * r; Ji[5] = (J[2] * J[3] - J[0] * J[5]) * r; Ji[8] = (J[0] * J[4] - J[1] * J[3]) * r;

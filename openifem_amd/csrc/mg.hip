@@ -103,37 +103,39 @@ struct DiagArgs {
 
 // Half a wavefront per cell (8 cells per block), 1D tables in LDS, every loop over nodes / points / components unrolled (the
 // node or point index of the inner loops is a compile-time constant, the lane's own index selects the LDS table row).
-template <int DIM, int KV>
+// R: arithmetic type of the integrals (float on the levels of the V-cycle: the smoother applies the inverse blocks in single precision
+// anyway, and the kernel is bound by its ~65 kFLOP per cell); the per-node sums are accumulated in double
+template <int DIM, int KV, typename R>
 __global__ __launch_bounds__(256) void k_uu_diag(DiagArgs A) {
   constexpr int N1 = KV + 1, NN = (DIM == 2) ? N1 * N1 : N1 * N1 * N1, NV = 1 << DIM, CPB = 8;
-  __shared__ double sX[CPB][NV * DIM], sJi[CPB][NN * DIM * DIM], sW[CPB][NN], sU[CPB][NN * DIM], sGu[CPB][NN * DIM * DIM], sE[CPB][NN * DIM];
-  __shared__ double tN[9], tD[9];
+  __shared__ R sX[CPB][NV * DIM], sJi[CPB][NN * DIM * DIM], sW[CPB][NN], sU[CPB][NN * DIM], sGu[CPB][NN * DIM * DIM], sE[CPB][NN * DIM];
+  __shared__ R tN[9], tD[9];
   __shared__ int32_t sNode[CPB][NN];
   const int slot = threadIdx.x >> 5, hl = threadIdx.x & 31;
   const int64_t cell = int64_t(blockIdx.x) * CPB + slot;
   const bool active = cell < A.n_cells;
   const int64_t cc = active ? cell : 0;
-  if (threadIdx.x < 9) { tN[threadIdx.x] = A.t.N[threadIdx.x]; tD[threadIdx.x] = A.t.dN[threadIdx.x]; }
+  if (threadIdx.x < 9) { tN[threadIdx.x] = R(A.t.N[threadIdx.x]); tD[threadIdx.x] = R(A.t.dN[threadIdx.x]); }
   if (hl < NN) {
     const int32_t nd = A.cell_unodes[cc * NN + hl];
     sNode[slot][hl] = nd;
 #pragma unroll
-    for (int c = 0; c < DIM; ++c) sE[slot][hl * DIM + c] = A.conv ? A.eval[int64_t(DIM) * nd + c] : 0.0;
+    for (int c = 0; c < DIM; ++c) sE[slot][hl * DIM + c] = A.conv ? R(A.eval[int64_t(DIM) * nd + c]) : R(0);
   }
-  if (hl < NV * DIM) sX[slot][hl] = A.vcoords[cc * NV * DIM + hl];
+  if (hl < NV * DIM) sX[slot][hl] = R(A.vcoords[cc * NV * DIM + hl]);
   __syncthreads();
   const int li = hl < NN ? hl : 0; // my point (first stage) / my node (second stage)
   const int l0 = li % N1, l1 = (li / N1) % N1, l2 = DIM == 3 ? li / (N1 * N1) : 0;
   if (hl < NN) { // lane = quadrature point: Jacobian of the d-linear map, fields of the evaluation point
     const int q = hl;
     const int qi[3] = {l0, l1, l2};
-    double L[3][2], J[DIM * DIM], Ji[DIM * DIM], wq = 1;
+    R L[3][2], J[DIM * DIM], Ji[DIM * DIM], wq = 1;
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
-      double x_ = A.t.xi[0], w_ = A.t.w[0];
+      R x_ = R(A.t.xi[0]), w_ = R(A.t.w[0]);
 #pragma unroll
-      for (int k = 1; k < N1; ++k) { x_ = qi[d] == k ? A.t.xi[k] : x_; w_ = qi[d] == k ? A.t.w[k] : w_; }
-      L[d][1] = x_; L[d][0] = 1.0 - x_; wq *= w_;
+      for (int k = 1; k < N1; ++k) { x_ = qi[d] == k ? R(A.t.xi[k]) : x_; w_ = qi[d] == k ? R(A.t.w[k]) : w_; }
+      L[d][1] = x_; L[d][0] = R(1) - x_; wq *= w_;
     }
 #pragma unroll
     for (int i = 0; i < DIM * DIM; ++i) J[i] = 0;
@@ -142,18 +144,18 @@ __global__ __launch_bounds__(256) void k_uu_diag(DiagArgs A) {
       const int b[3] = {v & 1, (v >> 1) & 1, (v >> 2) & 1};
 #pragma unroll
       for (int d = 0; d < DIM; ++d) {
-        double g = b[d] ? 1.0 : -1.0;
+        R g = b[d] ? R(1) : R(-1);
 #pragma unroll
         for (int o = 0; o < DIM; ++o) if (o != d) g *= L[o][b[o]];
 #pragma unroll
         for (int e = 0; e < DIM; ++e) J[e * DIM + d] += sX[slot][v * DIM + e] * g;
       }
     }
-    const double det = inv_small<DIM>(J, Ji);
-    sW[slot][q] = fabs(det) * wq;
+    const R det = inv_small<DIM, R>(J, Ji);
+    sW[slot][q] = R(fabs(det)) * wq;
 #pragma unroll
     for (int i = 0; i < DIM * DIM; ++i) sJi[slot][q * DIM * DIM + i] = Ji[i];
-    double u[DIM], gr[DIM * DIM];
+    R u[DIM], gr[DIM * DIM];
 #pragma unroll
     for (int c = 0; c < DIM; ++c) u[c] = 0;
 #pragma unroll
@@ -162,17 +164,17 @@ __global__ __launch_bounds__(256) void k_uu_diag(DiagArgs A) {
 #pragma unroll 1
     for (int a21 = 0; a21 < NN / N1; ++a21) {
       const int a1 = a21 % N1, a2 = a21 / N1;
-      const double n1v = tN[l1 * N1 + a1], d1v = tD[l1 * N1 + a1];
-      const double n2v = DIM == 3 ? tN[l2 * N1 + a2] : 1.0, d2v = DIM == 3 ? tD[l2 * N1 + a2] : 0.0;
+      const R n1v = tN[l1 * N1 + a1], d1v = tD[l1 * N1 + a1];
+      const R n2v = DIM == 3 ? tN[l2 * N1 + a2] : R(1), d2v = DIM == 3 ? tD[l2 * N1 + a2] : R(0);
 #pragma unroll
       for (int a0 = 0; a0 < N1; ++a0) {
         const int a = a21 * N1 + a0;
-        const double n0v = tN[l0 * N1 + a0], d0v = tD[l0 * N1 + a0];
-        const double N = n0v * n1v * n2v;
-        const double dr[3] = {d0v * n1v * n2v, n0v * d1v * n2v, n0v * n1v * d2v};
+        const R n0v = tN[l0 * N1 + a0], d0v = tD[l0 * N1 + a0];
+        const R N = n0v * n1v * n2v;
+        const R dr[3] = {d0v * n1v * n2v, n0v * d1v * n2v, n0v * n1v * d2v};
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
-          const double uv = sE[slot][a * DIM + c];
+          const R uv = sE[slot][a * DIM + c];
           u[c] += N * uv;
 #pragma unroll
           for (int e = 0; e < DIM; ++e) gr[c * DIM + e] += uv * dr[e];
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void k_uu_diag(DiagArgs A) {
       sU[slot][q * DIM + c] = u[c];
 #pragma unroll
       for (int d = 0; d < DIM; ++d) { // physical gradient d_d u_c = sum_e (d^_e u_c) Ji[e][d]
-        double t = 0;
+        R t = 0;
 #pragma unroll
         for (int e = 0; e < DIM; ++e) t += gr[c * DIM + e] * Ji[e * DIM + d];
         sGu[slot][q * DIM * DIM + c * DIM + d] = t;
@@ -194,39 +196,40 @@ __global__ __launch_bounds__(256) void k_uu_diag(DiagArgs A) {
   __syncthreads();
   if (hl < NN && active) { // lane = node a: its diagonal block
     const int a = hl;
-    double s = 0, D[DIM * DIM];
+    const R mu = R(A.mu), rho = R(A.rho), gamma = R(A.gamma), inv_dt = R(A.inv_dt);
+    R s = 0, D[DIM * DIM];
 #pragma unroll
     for (int i = 0; i < DIM * DIM; ++i) D[i] = 0;
 #pragma unroll 1
     for (int q21 = 0; q21 < NN / N1; ++q21) {
       const int q1 = q21 % N1, q2 = q21 / N1;
-      const double n1v = tN[q1 * N1 + l1], d1v = tD[q1 * N1 + l1];
-      const double n2v = DIM == 3 ? tN[q2 * N1 + l2] : 1.0, d2v = DIM == 3 ? tD[q2 * N1 + l2] : 0.0;
+      const R n1v = tN[q1 * N1 + l1], d1v = tD[q1 * N1 + l1];
+      const R n2v = DIM == 3 ? tN[q2 * N1 + l2] : R(1), d2v = DIM == 3 ? tD[q2 * N1 + l2] : R(0);
 #pragma unroll
       for (int q0 = 0; q0 < N1; ++q0) {
         const int q = q21 * N1 + q0;
-        const double n0v = tN[q0 * N1 + l0], d0v = tD[q0 * N1 + l0];
-        const double N = n0v * n1v * n2v;
-        const double dr[3] = {d0v * n1v * n2v, n0v * d1v * n2v, n0v * n1v * d2v};
-        double ga[DIM];
-        const double *Ji = &sJi[slot][q * DIM * DIM];
+        const R n0v = tN[q0 * N1 + l0], d0v = tD[q0 * N1 + l0];
+        const R N = n0v * n1v * n2v;
+        const R dr[3] = {d0v * n1v * n2v, n0v * d1v * n2v, n0v * n1v * d2v};
+        R ga[DIM];
+        const R *Ji = &sJi[slot][q * DIM * DIM];
 #pragma unroll
         for (int d = 0; d < DIM; ++d) {
-          double t = 0;
+          R t = 0;
 #pragma unroll
           for (int e = 0; e < DIM; ++e) t += dr[e] * Ji[e * DIM + d];
           ga[d] = t;
         }
-        const double w = sW[slot][q];
-        double gg = 0, ug = 0;
+        const R w = sW[slot][q];
+        R gg = 0, ug = 0;
 #pragma unroll
         for (int d = 0; d < DIM; ++d) { gg += ga[d] * ga[d]; ug += sU[slot][q * DIM + d] * ga[d]; }
-        s += w * (A.mu * gg + A.rho * N * ug + A.rho * A.inv_dt * N * N);
+        s += w * (mu * gg + rho * N * ug + rho * inv_dt * N * N);
 #pragma unroll
         for (int c = 0; c < DIM; ++c)
 #pragma unroll
           for (int d = 0; d < DIM; ++d)
-            D[c * DIM + d] += w * (A.rho * N * N * sGu[slot][q * DIM * DIM + c * DIM + d] + A.gamma * A.rho * ga[c] * ga[d]);
+            D[c * DIM + d] += w * (rho * N * N * sGu[slot][q * DIM * DIM + c * DIM + d] + gamma * rho * ga[c] * ga[d]);
       }
     }
 #pragma unroll
@@ -238,9 +241,9 @@ __global__ __launch_bounds__(256) void k_uu_diag(DiagArgs A) {
 #pragma unroll
       for (int d = 0; d < DIM; ++d) {
         const bool rc = own && A.is_c && A.is_c[int64_t(DIM) * nd + c], cd = own && A.is_c && A.is_c[int64_t(DIM) * nd + d];
-        double v = D[c * DIM + d];
-        if (rc || cd) v = (c == d) ? fabs(v) : 0.0;
-        sGu[slot][a * DIM * DIM + c * DIM + d] = own ? v : 0.0; // staged: the gradient table is consumed (same index range)
+        R v = D[c * DIM + d];
+        if (rc || cd) v = (c == d) ? R(fabs(v)) : R(0);
+        sGu[slot][a * DIM * DIM + c * DIM + d] = own ? v : R(0); // staged: the gradient table is consumed (same index range)
       }
   }
   __syncthreads();
@@ -249,8 +252,8 @@ __global__ __launch_bounds__(256) void k_uu_diag(DiagArgs A) {
   if (active)
     for (int t = hl; t < NN * DIM * DIM; t += 32) {
       const int a = t / (DIM * DIM), e = t - a * (DIM * DIM);
-      const double v = sGu[slot][t];
-      if (v != 0.0) unsafeAtomicAdd(&A.out[int64_t(sNode[slot][a]) * DIM * DIM + e], v);
+      const R v = sGu[slot][t];
+      if (v != R(0)) unsafeAtomicAdd(&A.out[int64_t(sNode[slot][a]) * DIM * DIM + e], double(v));
     }
 }
 
@@ -287,10 +290,18 @@ void uu_block_diag_mf(ifem_ctx *ctx) {
   a.conv = ctx->mf_noconv ? 0 : 1;
   tab1d(a.t, ctx->kv);
   const dim3 grid(unsigned((ctx->n_cells + 7) / 8)), block(256); // 8 cells per block
-  if (dim == 3 && ctx->kv == 2) hipLaunchKernelGGL((k_uu_diag<3, 2>), grid, block, 0, s, a);
-  else if (dim == 3) hipLaunchKernelGGL((k_uu_diag<3, 1>), grid, block, 0, s, a);
-  else if (ctx->kv == 2) hipLaunchKernelGGL((k_uu_diag<2, 2>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((k_uu_diag<2, 1>), grid, block, 0, s, a);
+  // single-precision integrals where the blocks serve the single-precision V-cycle (ifem_tuning::mf_f32, the default)
+  if (ctx->tune.mf_f32) {
+    if (dim == 3 && ctx->kv == 2) hipLaunchKernelGGL((k_uu_diag<3, 2, float>), grid, block, 0, s, a);
+    else if (dim == 3) hipLaunchKernelGGL((k_uu_diag<3, 1, float>), grid, block, 0, s, a);
+    else if (ctx->kv == 2) hipLaunchKernelGGL((k_uu_diag<2, 2, float>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_uu_diag<2, 1, float>), grid, block, 0, s, a);
+  } else {
+    if (dim == 3 && ctx->kv == 2) hipLaunchKernelGGL((k_uu_diag<3, 2, double>), grid, block, 0, s, a);
+    else if (dim == 3) hipLaunchKernelGGL((k_uu_diag<3, 1, double>), grid, block, 0, s, a);
+    else if (ctx->kv == 2) hipLaunchKernelGGL((k_uu_diag<2, 2, double>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_uu_diag<2, 1, double>), grid, block, 0, s, a);
+  }
   if (dim == 3) hipLaunchKernelGGL((k_block_invert<3>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, ctx->bjac.p);
   else hipLaunchKernelGGL((k_block_invert<2>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, ctx->bjac.p);
   IFEM_HIP_CHECK(hipGetLastError());
