@@ -174,7 +174,7 @@ typedef struct {
   int32_t cg_single_reduction; /* 1 (default): the device-resident CG of the pressure solves (CG(M_p), plain CG(S_m)) forms its three dot
                             products in one pass and one all-reduce per iteration (Chronopoulos / Gear recurrence); 0: the textbook
                             recurrence with two reductions per iteration */
-  int32_t asm3_cpb;      /* 2: cells (= wavefronts) per workgroup of that kernel (1, 2, 4 or 8) */
+  int32_t asm3_cpb;      /* 2: cells (= wavefronts) per workgroup of that kernel (2, 4 or 8; anything else is IFEM_E_BADPARAM) */
   int32_t tpp_milu_permille; /* SCnsIM, ILU(0) of T_pp: 950 (default); 0 plain ILU(0); w in (0, 1000]: relaxed modified ILU, w/1000 of every dropped
                                 fill-in entry is added to the diagonal of its row */
   int64_t tpp_ilu_order; /* SCnsIM, explicit T_pp: preconditioner of its inner GMRES -- 2 (default): ILU(0), natural row order when its

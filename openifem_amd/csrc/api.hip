@@ -127,6 +127,7 @@ int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
   for (int v : g)
     if (v != 8 && v != 16 && v != 32 && v != 64) throw Error(IFEM_E_BADPARAM, "lanes per row must be 8, 16, 32 or 64");
   if (t->basis_pad < 0) throw Error(IFEM_E_BADPARAM, "negative size in ifem_tuning");
+  if (t->asm3_cpb != 2 && t->asm3_cpb != 4 && t->asm3_cpb != 8) throw Error(IFEM_E_BADPARAM, "asm3_cpb must be 2, 4 or 8 (cells per workgroup of the 3D Q2/Q1 cell kernel)");
   if (t->tpp_ilu_order < -1 || t->tpp_ilu_order > 2) throw Error(IFEM_E_BADPARAM, "tpp_ilu_order must be -1, 0, 1 or 2");
   ctx->tune = *t;
   IFEM_API_END

@@ -672,8 +672,7 @@ bool launch_ins_assemble3_kernel(ifem_ctx *ctx, const AsmArgs &A) {
 #else
   if (ctx->dim != 3 || ctx->kv != 2 || ctx->tune.asm3_variant == 1) return false;
   if (!ensure_scat3(ctx, !A.skip_uu && !A.rhs_only)) return false;
-  switch (ctx->tune.asm3_cpb) {
-  case 1: launch3<1>(ctx, A); break;
+  switch (ctx->tune.asm3_cpb) { // (one cell per workgroup spilled 2 VGPRs and was never the fastest: not built since round 5)
   case 4: launch3<4>(ctx, A); break;
   case 8: launch3<8>(ctx, A); break;
   default: launch3<2>(ctx, A);

@@ -1,8 +1,8 @@
-import sys, time, ctypes as C
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os, sys, time, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from openifem_amd import host, capi
-import os
-prm = open('/root/repo/tests/golden/prm/fluid_body_force_mpi.prm').read()
+prm = open(os.path.join(ROOT, 'tests', 'golden', 'prm', 'fluid_body_force_mpi.prm')).read()
 def body_force(pt, component):
     return 1.0e3 / 1.3e-3 if (3.5 - 5e-4 < pt[0] < 4.5 + 5e-4 and component == 0) else 0.0
 def sigma_pml(pt, component):
