@@ -98,7 +98,7 @@ class MgTransfer(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("geo_cache", C.c_int32), ("xcd_swizzle", C.c_int32), ("asm_skip", C.c_int32), ("spmv_lanes", C.c_int32),
                 ("sm_lanes", C.c_int32), ("mf_f32", C.c_int32), ("tpp_operator", C.c_int32), ("spmv_pipe", C.c_int32), ("halo_overlap", C.c_int32),
-                ("asm3_variant", C.c_int32), ("cg_single_reduction", C.c_int32), ("asm3_cpb", C.c_int32), ("tpp_milu_permille", C.c_int32), ("tpp_ilu_order", C.c_int64), ("basis_pad", C.c_int64), ("tpp_tri_sweeps", C.c_int32), ("uu_row_order", C.c_int32), ("eig_steps", C.c_int32), ("eig_reserved", C.c_int32)]
+                ("asm3_variant", C.c_int32), ("cg_single_reduction", C.c_int32), ("asm3_cpb", C.c_int32), ("tpp_milu_permille", C.c_int32), ("tpp_ilu_order", C.c_int64), ("basis_pad", C.c_int64), ("tpp_tri_sweeps", C.c_int32), ("uu_row_order", C.c_int32), ("eig_steps", C.c_int32), ("vcycle_graph_cells", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -137,7 +137,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag",
            "ifem_fsi_set_solid", "ifem_fsi_update_indicator", "ifem_fsi_find_fluid_bc", "ifem_fsi_get_stress",
            "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_comm_stats_level", "ifem_true_residual", "ifem_tpp_ilu_probe", "ifem_tpp_override",
-           "ifem_kprof_begin", "ifem_kprof_end", "ifem_kprof_family_name", "ifem_export_rows", "ifem_export_uu_pattern"]
+           "ifem_kprof_begin", "ifem_kprof_end", "ifem_kprof_family_name", "ifem_export_rows", "ifem_export_uu_pattern", "ifem_vcycle_graph_stats"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
 ABI_STRUCTS = None  # filled below (needs every class defined)
@@ -189,6 +189,7 @@ def load():
     L.ifem_export_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifem_export_rows.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifem_export_uu_pattern.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.ifem_vcycle_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.ifem_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.ifem_comm_unique_id.argtypes = [C.c_void_p]
     L.ifem_local_world_create.restype = C.c_void_p
@@ -270,6 +271,15 @@ def export_rows(L, ctx, row0, nrows, which=0):
     if rc < 0:
         raise IfemError(rc, L.ifem_last_error().decode())
     return rp, col, val
+
+
+def vcycle_graph_stats(L, ctx):
+    """(captures, launches) of the hipGraph of the A_uu V-cycle of this context"""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    rc = L.ifem_vcycle_graph_stats(ctx, C.byref(a), C.byref(b))
+    if rc < 0:
+        raise IfemError(rc, L.ifem_last_error().decode())
+    return a.value, b.value
 
 
 def export_uu_pattern(L, ctx, node0, n_nodes):

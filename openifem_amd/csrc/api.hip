@@ -117,7 +117,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
 
 void ifem_default_tuning(ifem_tuning *t) {
   t->geo_cache = 1; t->xcd_swizzle = 1; t->asm_skip = 0; t->spmv_lanes = 32; t->sm_lanes = 32; t->mf_f32 = 1;
-  t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->cg_single_reduction = 1; t->asm3_cpb = 2; t->tpp_milu_permille = 950; t->tpp_ilu_order = 2; t->basis_pad = 32 * 33; t->tpp_tri_sweeps = 0; t->uu_row_order = 1; t->eig_steps = 0; t->eig_reserved = 0;
+  t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->cg_single_reduction = 1; t->asm3_cpb = 2; t->tpp_milu_permille = 950; t->tpp_ilu_order = 2; t->basis_pad = 32 * 33; t->tpp_tri_sweeps = 0; t->uu_row_order = 1; t->eig_steps = 0; t->vcycle_graph_cells = 262144;
 }
 
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
@@ -223,6 +223,7 @@ void ifem_ctx_destroy(ifem_ctx *ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (hipEvent_t e : ctx->pc_ev) (void)hipEventDestroy(e);
+  ctx->vc_graph.destroy();
   hipStream_t s = ctx->owns_stream ? ctx->stream : nullptr;
   delete ctx;
   if (s) (void)hipStreamDestroy(s);
@@ -1019,6 +1020,13 @@ int ifem_comm_stats_level(ifem_ctx *ctx, int level, ifem_comm_stats *out) {
   for (int k = 0; k < level && c; ++k) c = c->mg_coarse;
   if (!c) throw Error(IFEM_E_BADPARAM, "ifem_comm_stats_level: the chain has fewer levels");
   ifem::comm_stats(c, out, false, /*single_level=*/true);
+  IFEM_API_END
+}
+
+int ifem_vcycle_graph_stats(ifem_ctx *ctx, uint64_t *captures, uint64_t *launches) {
+  IFEM_API_BEGIN
+  if (captures) *captures = ctx->vc_graph.captures;
+  if (launches) *launches = ctx->vc_graph.launches;
   IFEM_API_END
 }
 

@@ -408,6 +408,22 @@ struct ifem_ctx {
   int tight_first_misses = 0, tight_first_backoff = 0; // ifem_solver_opts::inner_rel_first: consecutive misses, qualifying solves left to skip
   double spmv_uu_ms_total = 0;
   ifem::KProf kprof; // per-kernel-family event log of a profiled step (used on the finest level of a chain only)
+  // The A_uu V-cycle as a hipGraph (finest level of a single-rank chain with at most ifem_tuning::vcycle_graph_cells cells): a fixed
+  // sequence of ~100-200 short launches whose arguments (level vectors, tables, Chebyshev coefficients) do not change between
+  // applications -- captured once per state (`key`: pointers, bounds, parameters, constraint set, sweep counts) and replayed.  `armed`:
+  // the state has been seen once and ran eagerly (lazy buffers exist); the next application with the same key is captured.
+  struct VcGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<uint64_t> key;
+    bool armed = false;
+    uint64_t launches = 0, captures = 0;
+    void destroy() {
+      if (exec) (void)hipGraphExecDestroy(exec);
+      if (graph) (void)hipGraphDestroy(graph);
+      exec = nullptr; graph = nullptr;
+    }
+  } vc_graph;
   // section marks of the preconditioner applications of one solve (start, after CG(M_p), after CG(S_m) + B^T, end): recorded on the
   // stream, read once when the solve has finished (ifem_solve_stats::t_cg_mp_ms / t_cg_sm_ms / t_ainv_ms) -- no host wait per section
   std::vector<hipEvent_t> pc_ev;

@@ -971,9 +971,48 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     if (!c->mf_valid) throw Error(IFEM_E_BADPARAM, "IFEM_AINV_MG needs the operator state of ifem_ins_assemble / ifem_imex_assemble");
     mg_uu_setup(Mu);
     OpFn Amf = [&](const double *x, double *y) { uu_apply_level(S, x, y); };
+    // the cycle itself: eagerly, or as a captured hipGraph (ctx.hpp::VcGraph) on small single-rank chains
+    bool graph_ok = c->tune.vcycle_graph_cells > 0 && c->n_cells <= c->tune.vcycle_graph_cells && !c->profile && !kprof_root(c).on;
+    for (const SolveState &L : Mu.L) graph_ok = graph_ok && L.ctx->halo.nranks == 1 && !L.ctx->mg_replica;
+    auto run_vcycle = [&]() {
+      if (!graph_ok) { mg_uu_vcycle(Mu, 0); return; }
+      std::vector<uint64_t> key;
+      auto put = [&](const void *ptr) { key.push_back(uint64_t(reinterpret_cast<uintptr_t>(ptr))); };
+      auto putd = [&](double v) { uint64_t b; std::memcpy(&b, &v, 8); key.push_back(b); };
+      key.push_back(Mu.L.size()); key.push_back(uint64_t(Mu.nu)); key.push_back(uint64_t(Mu.nu_post)); putd(Mu.ratio);
+      for (const SolveState &L : Mu.L) {
+        ifem_ctx *lc = L.ctx;
+        (void)bjac_f32_ptr(lc); // lazy state (the single-precision copy of the inverse node blocks) stays outside the graph
+        for (auto &v : lc->mguf_vec) put(v.p);
+        put(lc->bjac_f32.p); put(lc->mf_eval.p); put(lc->mf_ycell.p); put(lc->mg_Ru_mask.p); put(lc->mg_Pu_mask.p);
+        put(lc->has_c[lc->asm_constraint_set] ? lc->is_c[lc->asm_constraint_set].p : nullptr);
+        key.push_back(uint64_t(lc->nUo)); key.push_back(uint64_t(lc->n_cells)); key.push_back(uint64_t(lc->mf_noconv)); key.push_back(uint64_t(lc->tune.xcd_swizzle));
+        putd(lc->uu_lmax); putd(lc->mf_params.viscosity); putd(lc->mf_params.rho); putd(lc->mf_params.grad_div); putd(lc->mf_params.dt);
+      }
+      ifem_ctx::VcGraph &G = c->vc_graph;
+      if (G.exec && key == G.key) {
+        IFEM_HIP_CHECK(hipGraphLaunch(G.exec, c->stream));
+        ++G.launches;
+        return;
+      }
+      if (!(G.armed && key == G.key)) { // a new state: this application runs eagerly (and allocates whatever is allocated lazily)
+        G.destroy();
+        G.key = key; G.armed = true;
+        mg_uu_vcycle(Mu, 0);
+        return;
+      }
+      IFEM_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      try { mg_uu_vcycle(Mu, 0); }
+      catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(c->stream, &dead); if (dead) (void)hipGraphDestroy(dead); G.armed = false; throw; }
+      IFEM_HIP_CHECK(hipStreamEndCapture(c->stream, &G.graph));
+      IFEM_HIP_CHECK(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
+      ++G.captures;
+      IFEM_HIP_CHECK(hipGraphLaunch(G.exec, c->stream));
+      ++G.launches;
+    };
     OpFn Vc = [&](const double *x, double *y) {
       v_cvt_d2f(c, S.nuo, x, c->mguf_vec[0].p);
-      mg_uu_vcycle(Mu, 0);
+      run_vcycle();
       v_cvt_f2d(c, S.nuo, c->mguf_vec[1].p, y);
     };
     // one attempt of A~^-1 with the V-cycle; returns false when the result is not finite (a Chebyshev bound below the

@@ -635,3 +635,41 @@ def test_extruded_cylinder_level_chain_on_virtual_ranks():
     assert abs(max(o["pmax"] for o in out) - one["pmax"]) <= 1e-3 * abs(one["pmax"]), (out, one)
     assert abs(sum(o["vsum"] for o in out) - one["vsum"]) <= 1e-4 * one["vsum"], (out, one)
     assert out[0]["inner"] <= 1.5 * one["inner"] + 2 and out[0]["cg_sm"] <= one["cg_sm"] + 3, (out, one)
+
+
+def test_captured_vcycle_graph_reproduces_the_eager_cycle():
+    """ifem_tuning::vcycle_graph_cells: on a small single-rank chain the A_uu V-cycle is captured into a hipGraph once per state and
+    replayed.  Same kernels in the same order on the same buffers: two time steps of tests/fluid_cylinder_mpi must come out as with eager
+    launches (to rounding: the coarse levels' block diagonals are summed with atomics, so two eager runs differ in the last bits too), with
+    the same iteration counts, and the graph must actually have been used."""
+    import ctypes as C
+    import os
+    from openifem_amd import host, capi
+    prm = open(os.path.join(os.path.dirname(__file__), "golden", "prm", "fluid_cylinder_mpi.prm")).read()
+
+    def run(cells):
+        flow = host.InsIM(prm, mesh="cylinder")
+        flow.add_hard_coded_boundary_condition(0, lambda p, c, t: 4 * 0.3 * p[1] * (0.41 - p[1]) / (0.41 * 0.41) if (c == 0 and abs(p[0]) < 1e-10) else 0.0)
+        flow.setup(3)
+        tun = capi.Tuning()
+        flow.L.ifem_default_tuning(C.byref(tun))
+        assert tun.vcycle_graph_cells == 262144
+        tun.vcycle_graph_cells = cells
+        for c in flow.all_ctxs():
+            assert flow.L.ifem_set_tuning(c, C.byref(tun)) == 0
+        flow.run_one_step(True)
+        flow.run_one_step(False)
+        v, p = flow.get_current_solution()
+        nit = flow.last_newton()
+        stats = capi.vcycle_graph_stats(flow.L, flow.ctx)
+        ainv = flow.opts.ainv_kind
+        flow.close()
+        return v, p, nit, stats, ainv
+
+    v0, p0, n0, s0, k0 = run(0)
+    v1, p1, n1, s1, k1 = run(262144)
+    assert k0 == k1 == capi.AINV_MG
+    assert s0 == (0, 0)
+    assert s1[0] >= 1 and s1[1] > 10 * s1[0], s1  # captured a few times (the bounds move with the first assemblies), replayed many times
+    assert n0 == n1
+    assert np.abs(v0 - v1).max() <= 1e-9 * np.abs(v0).max() and np.abs(p0 - p1).max() <= 1e-9 * np.abs(p0).max()
