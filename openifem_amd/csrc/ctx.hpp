@@ -426,6 +426,7 @@ struct ifem_ctx {
   } vc_graph;
   // section marks of the preconditioner applications of one solve (start, after CG(M_p), after CG(S_m) + B^T, end): recorded on the
   // stream, read once when the solve has finished (ifem_solve_stats::t_cg_mp_ms / t_cg_sm_ms / t_ainv_ms) -- no host wait per section
+  int inner_restart_eff = 0; // restart length of the inner GMRES of IFEM_AINV_MG once an application stagnated across restarts (solver.hip)
   std::vector<hipEvent_t> pc_ev;
   size_t pc_used = 0;
 };

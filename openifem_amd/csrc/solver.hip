@@ -1033,12 +1033,29 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
         S.st.inner_iters += k;
       } else { // flexible GMRES: the preconditioned directions are kept, so the update needs no extra V-cycle
         const int64_t ld = basis_ld(S.ctx, S.nuo);
-        const int mi = std::max(1, o->inner_restart);
+        // restart length: the caller's, lengthened by the context when an application needed more than two restart cycles -- a V-cycle
+        // that has lost its mesh independence (the refined cylinder, DESIGN section 6: 147 inner iterations with GMRES(16), 75 with
+        // GMRES(40), 59 with GMRES(100)) stagnates across restarts; the bases grow on demand, so the longer cycle costs memory
+        // only where it is used.  Capped at 128 columns and at a quarter of the free device memory.
+        const int mi = std::max(std::max(1, o->inner_restart), c->inner_restart_eff);
         grow_basis(c, c->innerV, ld, std::min(mi + 1, kBasisStart), mi + 1);
         grow_basis(c, c->innerZ, ld, std::min(mi, kBasisStart), mi);
         const auto grow = basis_grower(c, c->innerV, c->innerZ, ld, mi + 1);
-        S.st.inner_iters += gmres(c, S.nuo, ld, /*reorth=*/false, Amf, Vc, true, S.utmp, dst0, mi, o->inner_maxit, inner_rel_now * un,
-                                  c->innerV.p, c->innerZ.p, S.inner_w, &res, mdot, nullptr, &grow);
+        const int its = gmres(c, S.nuo, ld, /*reorth=*/false, Amf, Vc, true, S.utmp, dst0, mi, o->inner_maxit, inner_rel_now * un,
+                              c->innerV.p, c->innerZ.p, S.inner_w, &res, mdot, nullptr, &grow);
+        S.st.inner_iters += its;
+        if (its > 2 * mi && mi < 128) {
+          size_t fr = 0, tot = 0;
+          (void)hipMemGetInfo(&fr, &tot);
+          int want = std::min(128, 2 * mi);
+          const double per_col = 2.0 * double(ld) * sizeof(double);
+          const int fits = int(std::min<double>(128.0, 0.25 * double(fr) / std::max(per_col, 1.0)));
+          want = std::min(want, std::max(fits, mi));
+          if (want > mi) {
+            if (o->verbose) fprintf(stderr, "[ifem] inner GMRES(%d) needed %d iterations: restart length %d from now on\n", mi, its, want);
+            c->inner_restart_eff = want;
+          }
+        }
       }
       if (o->inner_maxit > 0) return std::isfinite(res); // the Arnoldi recurrence carries any NaN / Inf of the V-cycle
       double dn;
