@@ -598,7 +598,7 @@ def main():
     prof_wall_ms = (time.time() - tp0) / prof_steps * 1e3
     prof = solver.kprof_end()
     # device memory once the run has settled: the unconstrained copies of B / B^T / S_m (kept for a change of the constrained-dof set) are
-    # given back after four assemblies with an unchanged set on every level (assemble.hip); the default run reaches that here
+    # given back at the second cached assembly of a never-changed set on every level (assemble.hip)
     hbm_steady_gb = _hbm_used_gb()
     if rank == 0:
         kernels = kernel_table(prof, prof_steps, n, world)

@@ -55,6 +55,9 @@ __global__ void k_mask_b(int64_t n_rows, const int64_t *__restrict__ rp, const i
     }
   }
 }
+// assemblies with an unchanged (and never yet changed) constrained-dof set after which the unconstrained copies of B / B^T / S_m are given
+// back: the second cached assembly.  A run whose set does change later (FSI: every time step) re-integrates them once and keeps them from then on.
+constexpr int kGeoKeep = 2;
 static void masked_geometry_blocks(ifem_ctx *ctx, int use_nonzero) {
   KScope ks(ctx, IFEM_KC_SCHUR_SETUP, 16.0 * double(ctx->B.val.n + ctx->Bt.val.n));
   const int w = use_nonzero ? 1 : 0;
@@ -88,7 +91,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
     const bool new_assembly = uint64_t(f0->asm_version) != ctx->geo_seen_asm;
     ctx->geo_seen_asm = uint64_t(f0->asm_version);
     if (ctx->geo_valid && ctx->geo_key == key && ctx->tune.geo_cache != 2) { // still the blocks of this constrained-dof set
-      if (new_assembly && ++ctx->geo_unchanged == 4 && ctx->geo0_valid && ctx->geo_set_changes == 0) { // its unconstrained copies go the way of the finest level's (below)
+      if (new_assembly && ++ctx->geo_unchanged == kGeoKeep && ctx->geo0_valid && ctx->geo_set_changes == 0) { // its unconstrained copies go the way of the finest level's (below)
         ctx->B0.release(); ctx->Bt0.release(); ctx->Sm0.release();
         ctx->geo0_valid = false; ctx->sm0_valid = false;
       }
@@ -122,7 +125,7 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   if (assemble_system == 1) {
     if (!skip_geo && ctx->geo_valid && ctx->geo_key != geo_key) ctx->geo_set_changes++;
     ctx->geo_unchanged = skip_geo ? ctx->geo_unchanged + 1 : 0;
-    if (ctx->geo_unchanged == 4 && ctx->geo0_valid && ctx->geo_set_changes == 0) {
+    if (ctx->geo_unchanged == kGeoKeep && ctx->geo0_valid && ctx->geo_set_changes == 0) {
       ctx->B0.release(); ctx->Bt0.release(); ctx->Sm0.release();
       ctx->geo0_valid = false; ctx->sm0_valid = false;
     }

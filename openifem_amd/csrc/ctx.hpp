@@ -329,7 +329,7 @@ struct ifem_ctx {
   // constrained-dof set are masked copies of them instead of a re-integration (M_p and diag(M_u) do not depend on the set)
   ifem::DBuf<double> B0, Bt0;
   bool geo0_valid = false;
-  int geo_unchanged = 0; // consecutive assemblies OF THE FINEST LEVEL that kept the cached blocks (assemble.hip: the copies are released at 4 ...)
+  int geo_unchanged = 0; // consecutive assemblies OF THE FINEST LEVEL that kept the cached blocks (assemble.hip: the copies are released at kGeoKeep = 2 ...)
   int geo_set_changes = 0; // ... unless the constrained-dof set has ever changed after the first assembly (an FSI run): then they stay
   uint64_t geo_seen_asm = 0; // a multigrid level: the finest level's asm_version its geo_unchanged last counted
   // S_m of the unconstrained blocks (same mesh-only idea): a constrained-dof set only changes the rows whose B row touches a
