@@ -673,3 +673,33 @@ def test_captured_vcycle_graph_reproduces_the_eager_cycle():
     assert s1[0] >= 1 and s1[1] > 10 * s1[0], s1  # captured a few times (the bounds move with the first assemblies), replayed many times
     assert n0 == n1
     assert np.abs(v0 - v1).max() <= 1e-9 * np.abs(v0).max() and np.abs(p0 - p1).max() <= 1e-9 * np.abs(p0).max()
+
+
+def test_single_reduction_cg_gives_the_iterates_of_the_textbook_recurrence():
+    """ifem_tuning::cg_single_reduction: the Chronopoulos / Gear form of the device-resident pressure CGs (one fused reduction per iteration:
+    linalg.hip::cg1_*) against the two-reduction recurrence on the same solve -- same iteration counts (the checks come in bursts of four
+    either way), the same Newton update to rounding, and the reference's stopping rule on the true residual"""
+    import ctypes as C
+    from openifem_amd import capi
+    out = {}
+    for single in (0, 1):
+        s = _hierarchy((16, 16, 16))
+        tun = capi.Tuning()
+        s.L.ifem_default_tuning(C.byref(tun))
+        assert tun.cg_single_reduction == 1
+        tun.cg_single_reduction = single
+        for c in s.all_ctxs():
+            assert s.L.ifem_set_tuning(c, C.byref(tun)) == 0
+        s.channel_state()
+        s.opts.sm_mg = 0  # plain CG on S_m too: both pressure solves go through cg_device
+        s.assemble(False)
+        st = s.solve(False)
+        _, n_u, n_p = s.sizes()
+        x = _get(s, capi.VEC_UPDATE, n_u + n_p)
+        res, bn = s.true_residual()
+        assert res <= 1.05e-4 * bn
+        out[single] = (x, st.fgmres_iters, st.cg_mp_iters, st.cg_sm_iters)
+        s.close()
+    (x0, f0, m0, s0), (x1, f1, m1, s1) = out[0], out[1]
+    assert f0 == f1 and m0 == m1 and abs(s0 - s1) <= 4 * f0, out
+    assert np.abs(x0 - x1).max() <= 1e-6 * np.abs(x0).max()
