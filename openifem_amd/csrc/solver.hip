@@ -1001,14 +1001,23 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
         mg_uu_vcycle(Mu, 0);
         return;
       }
-      IFEM_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      try { mg_uu_vcycle(Mu, 0); }
-      catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(c->stream, &dead); if (dead) (void)hipGraphDestroy(dead); G.armed = false; throw; }
-      IFEM_HIP_CHECK(hipStreamEndCapture(c->stream, &G.graph));
-      IFEM_HIP_CHECK(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
-      ++G.captures;
-      IFEM_HIP_CHECK(hipGraphLaunch(G.exec, c->stream));
-      ++G.launches;
+      // capture; a runtime that cannot (capture, instantiation or the first launch fails) switches the context back to eager launches for good
+      bool captured = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (captured) {
+        try { mg_uu_vcycle(Mu, 0); }
+        catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(c->stream, &dead); if (dead) (void)hipGraphDestroy(dead); G.armed = false; throw; }
+        captured = hipStreamEndCapture(c->stream, &G.graph) == hipSuccess && G.graph != nullptr;
+        captured = captured && hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0) == hipSuccess;
+        captured = captured && hipGraphLaunch(G.exec, c->stream) == hipSuccess;
+      }
+      if (captured) { ++G.captures; ++G.launches; return; }
+      (void)hipGetLastError();
+      G.destroy();
+      G.armed = false;
+      c->tune.vcycle_graph_cells = 0;
+      graph_ok = false;
+      if (o->verbose) fprintf(stderr, "[ifem] hipGraph capture of the A_uu V-cycle failed: eager launches from now on\n");
+      mg_uu_vcycle(Mu, 0);
     };
     OpFn Vc = [&](const double *x, double *y) {
       v_cvt_d2f(c, S.nuo, x, c->mguf_vec[0].p);
