@@ -575,3 +575,60 @@ def test_mfma_assembly_entrywise_on_odd_mesh_with_many_workgroups(variant, cpb, 
         ya, ym = ctx.uu_vmult(x, 0)[:n_u], ctx.uu_vmult(x, 3)[:n_u]
         assert np.abs(ya - ym).max() / np.abs(ya).max() < 1e-12, label
     ctx.close()
+
+
+def test_export_rows_and_uu_pattern_agree_with_the_whole_matrix():
+    """ifem_export_rows (a slab of the CSR ifem_export_csr describes) and ifem_export_uu_pattern (absolute block offsets and block columns
+    of stored A_uu rows) on a small distorted 3D mesh: every slab equals the same rows of the whole export, the pattern's block columns are
+    the velocity columns of those rows in storage order, and consecutive rows' offsets tile the value array"""
+    capi = _capi()
+    rng = np.random.default_rng(5)
+    m = BoxMesh((4, 3, 3), (0, 0, 0), (2.0, 0.2, 0.2), kv=2)
+    m.vcoords = m.vcoords + 0.004 * rng.standard_normal(m.vcoords.shape)
+    dofs, vals, present, ev, kw = channel3d_state(m)
+    ctx = _ctx(m)
+    ctx.set_constraints(0, dofs, None)
+    ctx.set_constraints(1, dofs, vals)
+    ctx.vec_set(capi.VEC_PRESENT, present)
+    ctx.vec_set(capi.VEC_EVAL, ev)
+    ctx.assemble(capi.make_params(**kw), False)
+    A = ctx.export_csr(0)
+    n_u, n = 3 * m.n_unodes, m.n_dofs
+    for row0, nrows in ((0, 7), (n_u - 5, 11), (n_u + 3, 9), (n - 4, 4), (0, n)):
+        rp, col, val = ctx.export_rows(row0, nrows)
+        assert rp[0] == 0 and rp[-1] == len(col) == len(val)
+        sub = A[row0:row0 + nrows]
+        assert np.array_equal(np.diff(rp), np.diff(sub.indptr))
+        for i in range(nrows):
+            got = dict(zip(col[rp[i]:rp[i + 1]].tolist(), val[rp[i]:rp[i + 1]].tolist()))
+            want = dict(zip(sub.indices[sub.indptr[i]:sub.indptr[i + 1]].tolist(), sub.data[sub.indptr[i]:sub.indptr[i + 1]].tolist()))
+            assert got == want, (row0, i)
+    rp_all, col_all = capi.export_uu_pattern(ctx.L, ctx.h, 0, m.n_unodes)
+    assert rp_all[0] == 0 and np.all(np.diff(rp_all) > 0) and rp_all[-1] == len(col_all)
+    for a in (0, 17, m.n_unodes - 1):
+        rp, col = capi.export_uu_pattern(ctx.L, ctx.h, a, 1)
+        assert rp[0] == rp_all[a] and rp[1] == rp_all[a + 1] and np.array_equal(col, col_all[rp_all[a]:rp_all[a + 1]])
+        rpr, colr, _ = ctx.export_rows(3 * a, 1)
+        ucols = colr[colr < n_u]
+        assert np.array_equal(ucols[::3] // 3, col)  # the row's velocity columns, block by block, in storage order
+        assert len(np.unique(col)) == len(col)
+    ctx.close()
+
+
+def test_segments_per_cell_replay_on_the_device_pattern():
+    """tools/cylbench.py::segments_per_cell (the bench's figure for the scatter of the matrix-core cell kernel on ANY mesh, from
+    ifem_export_uu_pattern): on a box it must land between the layout floor (729 blocks of 72 bytes = 820 segments of 64 bytes) and the
+    count of one request per block and row-run, and its floor must not exceed it"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import cylbench
+    from openifem_amd import host
+    s = host.InsIM(host.channel_prm(3), (6, 6, 6), (0, 0, 0), (2.0, 0.2, 0.2))
+    s.setup(0)
+    s.channel_state()
+    s.assemble(False)
+    seg, floor, row_mean, row_max = cylbench.segments_per_cell(s, n_sample=40)
+    assert 820 <= floor <= seg < 1100, (seg, floor)
+    assert 27 <= row_mean <= 125 and row_max == 125
+    s.close()
