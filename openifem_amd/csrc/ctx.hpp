@@ -348,7 +348,7 @@ struct ifem_ctx {
                                // summed over the ranks by a vector all-reduce, nothing below this level exchanges anything
   ifem::MgCsr mg_Pp, mg_Rp, mg_Pu, mg_Ru;
   ifem::DBuf<int32_t> mg_inj_u; // [nUo of the coarse level] coincident owned velocity node of this level
-  ifem::DBuf<uint8_t> mg_Pu_mask, mg_Ru_mask; // per weight: components dropped by the Dirichlet flags of the two levels
+  ifem::DBuf<uint8_t> mg_Pu_mask, mg_Ru_mask; // per weight 8 bytes: {column | components dropped by the Dirichlet flags of the two levels << 29, weight as float} (mg.hip::mg_csr_mask)
   int64_t mg_mask_key[2] = {-1, -1};          // constrained-dof sets (flag ids of this level and the coarser one) of the masks
   ifem::DBuf<double> sm_dinv, mg_vec[6], mgu_vec[5];
   ifem::DBuf<float> mguf_vec[5]; // single-precision level vectors of the A_uu V-cycle (solver.hip)

@@ -719,7 +719,7 @@ static void mg_uu_setup(MgUu &M, bool force_bounds = false) {
       ifem_ctx *cc = M.L[l + 1].ctx;
       const int cs = f0->asm_constraint_set;
       const int64_t key[2] = {c->flag_id[cs], cc->flag_id[cs]};
-      if (c->mg_Pu_mask.n != c->mg_Pu.col.n || c->mg_mask_key[0] != key[0] || c->mg_mask_key[1] != key[1]) {
+      if (c->mg_Pu_mask.n != c->mg_Pu.col.n * 8 || c->mg_mask_key[0] != key[0] || c->mg_mask_key[1] != key[1]) {
         const uint8_t *ff = c->has_c[cs] ? c->is_c[cs].p : nullptr, *fc = cc->has_c[cs] ? cc->is_c[cs].p : nullptr;
         mg_csr_mask(c, c->mg_Ru, ff, fc, c->mg_Ru_mask); // rows: local coarse nodes, columns: owned fine nodes
         mg_csr_mask(c, c->mg_Pu, fc, ff, c->mg_Pu_mask); // rows: owned fine nodes, columns: local coarse nodes
