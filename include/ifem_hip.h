@@ -548,6 +548,9 @@ typedef struct {
 /* how often the A_uu V-cycle of this context was captured into a hipGraph and how often a captured graph was launched
  * (ifem_tuning::vcycle_graph_cells) */
 int ifem_vcycle_graph_stats(ifem_ctx *ctx, uint64_t *captures, uint64_t *launches);
+/* the restart length the inner GMRES of IFEM_AINV_MG has lengthened itself to on this context (0: never -- ifem_solver_opts::inner_restart
+ * is in use): an application that needs more than two restart cycles doubles it, up to 128 columns and a quarter of the free memory */
+int ifem_inner_restart_length(ifem_ctx *ctx);
 int ifem_kprof_begin(ifem_ctx *ctx);
 int ifem_kprof_end(ifem_ctx *ctx, ifem_kprof_entry *out, int32_t max_entries);
 const char *ifem_kprof_family_name(int32_t family);

@@ -1023,6 +1023,8 @@ int ifem_comm_stats_level(ifem_ctx *ctx, int level, ifem_comm_stats *out) {
   IFEM_API_END
 }
 
+int ifem_inner_restart_length(ifem_ctx *ctx) { return ctx ? ctx->inner_restart_eff : IFEM_E_BADPARAM; }
+
 int ifem_vcycle_graph_stats(ifem_ctx *ctx, uint64_t *captures, uint64_t *launches) {
   IFEM_API_BEGIN
   if (captures) *captures = ctx->vc_graph.captures;

@@ -42,14 +42,15 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
   double res = 0;
   bool first = true;
   while (true) {
-    if (first) { v_copy(ctx, n, b, w); first = false; }
+    const double *r0 = w; // the residual the cycle starts from: b itself in the first cycle (x = 0), b - A x after a restart
+    if (first) { r0 = b; first = false; }
     else { A(x, w); v_axpby(ctx, n, 1.0, b, -1.0, w); }
     double bb;
-    mdot(1, w, n, w, &bb);
+    mdot(1, r0, n, r0, &bb);
     const double beta = std::sqrt(bb);
     res = beta;
     if (res <= tol || it >= maxit || !std::isfinite(res)) break; // (deal.II's SolverControl::check fails on a NaN as well)
-    v_scale_to(ctx, n, 1.0 / beta, w, V);
+    v_scale_to(ctx, n, 1.0 / beta, r0, V);
     std::fill(g.begin(), g.end(), 0.0);
     g[0] = beta;
     int j = 0;

@@ -703,3 +703,28 @@ def test_single_reduction_cg_gives_the_iterates_of_the_textbook_recurrence():
     (x0, f0, m0, s0), (x1, f1, m1, s1) = out[0], out[1]
     assert f0 == f1 and m0 == m1 and abs(s0 - s1) <= 4 * f0, out
     assert np.abs(x0 - x1).max() <= 1e-6 * np.abs(x0).max()
+
+
+def test_inner_gmres_lengthens_its_restart_cycle_when_it_stagnates():
+    """an application of A~^-1 that needs more than two restart cycles doubles the restart length of the context's inner GMRES for the
+    applications that follow (solver.hip::precond_vmult; the refined cylinder needed it: 147 -> 59 inner iterations per application).  Forced
+    here with GMRES(2) and a tight inner tolerance on a small channel: the length grows, the outer solve keeps the reference's stopping rule
+    and the second solve needs no more inner iterations than the first"""
+    s = _hierarchy((16, 16, 16))
+    s.channel_state()
+    s.opts.inner_restart = 2
+    s.opts.inner_rel = 1e-7
+    s.opts.inner_rel_first = 0.0
+    s.assemble(False)
+    assert s.L.ifem_inner_restart_length(s.ctx) == 0
+    st1 = s.solve(False)
+    grown = s.L.ifem_inner_restart_length(s.ctx)
+    assert grown >= 4, grown
+    res, bn = s.true_residual()
+    assert res <= 1.05e-4 * bn
+    st2 = s.solve(False)
+    res, bn = s.true_residual()
+    assert res <= 1.05e-4 * bn
+    assert s.L.ifem_inner_restart_length(s.ctx) >= grown
+    assert st2.inner_iters <= st1.inner_iters, (st1.inner_iters, st2.inner_iters)
+    s.close()
