@@ -190,8 +190,9 @@ typedef struct {
   int32_t eig_steps;     /* 0 (default: 12 / 14): power-iteration steps of a COLD estimate of the smoothers' eigenvalue bounds (lambda_max of
                             (block D)^-1 A_uu and of D^-1 S_m on every level); > 0: that many */
   int32_t vcycle_graph_cells; /* 262144 (default): on a single-rank level chain whose finest level has at most this many cells the A_uu V-cycle
-                                 of IFEM_AINV_MG is captured into a hipGraph once per state and replayed (its ~100-200 short launches are launch
-                                 latency there: the reference's test meshes); 0: always launched eagerly */
+                                 of IFEM_AINV_MG and the S_m V-cycle inside CG(S_m) are captured into hipGraphs once per state and replayed
+                                 (their ~100-200 short launches are launch latency there: the reference's test meshes); 0: always launched
+                                 eagerly */
 } ifem_tuning;
 void ifem_default_tuning(ifem_tuning *t);
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t);
@@ -545,7 +546,7 @@ typedef struct {
   double bytes;     /* algorithmic bytes, summed (0: not stated for this family) */
   double flops;     /* algorithmic flops, summed */
 } ifem_kprof_entry;
-/* how often the A_uu V-cycle of this context was captured into a hipGraph and how often a captured graph was launched
+/* how often the V-cycles of this context (A_uu and S_m) were captured into a hipGraph and how often a captured graph was launched
  * (ifem_tuning::vcycle_graph_cells) */
 int ifem_vcycle_graph_stats(ifem_ctx *ctx, uint64_t *captures, uint64_t *launches);
 /* the restart length the inner GMRES of IFEM_AINV_MG has lengthened itself to on this context (0: never -- ifem_solver_opts::inner_restart

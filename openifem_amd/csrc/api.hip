@@ -224,6 +224,7 @@ void ifem_ctx_destroy(ifem_ctx *ctx) {
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (hipEvent_t e : ctx->pc_ev) (void)hipEventDestroy(e);
   ctx->vc_graph.destroy();
+  ctx->sm_graph.destroy();
   hipStream_t s = ctx->owns_stream ? ctx->stream : nullptr;
   delete ctx;
   if (s) (void)hipStreamDestroy(s);
@@ -1027,8 +1028,8 @@ int ifem_inner_restart_length(ifem_ctx *ctx) { return ctx ? ctx->inner_restart_e
 
 int ifem_vcycle_graph_stats(ifem_ctx *ctx, uint64_t *captures, uint64_t *launches) {
   IFEM_API_BEGIN
-  if (captures) *captures = ctx->vc_graph.captures;
-  if (launches) *launches = ctx->vc_graph.launches;
+  if (captures) *captures = ctx->vc_graph.captures + ctx->sm_graph.captures;
+  if (launches) *launches = ctx->vc_graph.launches + ctx->sm_graph.launches;
   IFEM_API_END
 }
 

@@ -423,7 +423,7 @@ struct ifem_ctx {
       if (graph) (void)hipGraphDestroy(graph);
       exec = nullptr; graph = nullptr;
     }
-  } vc_graph;
+  } vc_graph, sm_graph; // (sm_graph: the same for the V-cycle on S_m inside CG(S_m))
   // section marks of the preconditioner applications of one solve (start, after CG(M_p), after CG(S_m) + B^T, end): recorded on the
   // stream, read once when the solve has finished (ifem_solve_stats::t_cg_mp_ms / t_cg_sm_ms / t_ainv_ms) -- no host wait per section
   int inner_restart_eff = 0; // restart length of the inner GMRES of IFEM_AINV_MG once an application stagnated across restarts (solver.hip)

@@ -462,6 +462,40 @@ static void sm_apply(SolveState &S, const double *x, double *y, bool lowp) {
 // CG may use it as its preconditioner.  Level vectors (ctx->mg_vec, nPl + 8 each): 0 right-hand side / residual,
 // 1 solution, 2 Chebyshev direction, 3 operator product, 4 prolongated correction.  Compact owned entries come first, so
 // the same buffers serve as ghost-extended pressure vectors for the transfers.
+// A fixed launch sequence on fixed buffers as a hipGraph (ctx.hpp::VcGraph): replayed while `key` -- every pointer, bound, parameter and count the
+// sequence's kernel arguments are made of -- stays what it was when the graph was captured.  A new key runs `body` eagerly once (whatever is
+// allocated or converted lazily inside exists afterwards) and is captured at its next occurrence.  Returns false when the runtime refused the
+// capture: the caller stops asking (body has run eagerly by then).
+static bool graph_run(ifem_ctx *c, ifem_ctx::VcGraph &G, std::vector<uint64_t> &key, const std::function<void()> &body) {
+  if (G.exec && key == G.key) {
+    IFEM_HIP_CHECK(hipGraphLaunch(G.exec, c->stream));
+    ++G.launches;
+    return true;
+  }
+  if (!(G.armed && key == G.key)) {
+    G.destroy();
+    G.key = key; G.armed = true;
+    body();
+    return true;
+  }
+  bool captured = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+  if (captured) {
+    try { body(); }
+    catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(c->stream, &dead); if (dead) (void)hipGraphDestroy(dead); G.armed = false; throw; }
+    captured = hipStreamEndCapture(c->stream, &G.graph) == hipSuccess && G.graph != nullptr;
+    captured = captured && hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0) == hipSuccess;
+    captured = captured && hipGraphLaunch(G.exec, c->stream) == hipSuccess;
+  }
+  if (captured) { ++G.captures; ++G.launches; return true; }
+  (void)hipGetLastError();
+  G.destroy();
+  G.armed = false;
+  body();
+  return false;
+}
+static inline void key_ptr(std::vector<uint64_t> &key, const void *p) { key.push_back(uint64_t(reinterpret_cast<uintptr_t>(p))); }
+static inline void key_f64(std::vector<uint64_t> &key, double v) { uint64_t b; std::memcpy(&b, &v, 8); key.push_back(b); }
+
 // A replicated coarse level (a single-rank context of the whole coarse mesh below a partitioned level) is computed by every rank
 // on its own device: its operators carry float / double atomics whose order differs between devices, so the replicas agree to
 // rounding only, and replica-local decisions (the 1 % early exit of a power iteration) may differ.  Quantities that steer the
@@ -604,6 +638,23 @@ static int pcg_mg_sm(MgSm &M, const double *b, double *x, double tol, int maxit,
     allreduce_sum(c, out, 2);
   };
   double *zin = c->mg_vec[0].p, *z = c->mg_vec[1].p;
+  // the cycle: eagerly, or replayed as a hipGraph on small single-rank chains (as the A_uu V-cycle, precond_vmult)
+  bool graph_ok = c->tune.vcycle_graph_cells > 0 && c->n_cells <= c->tune.vcycle_graph_cells && !c->profile && !kprof_root(c).on;
+  for (const SolveState &L : M.L) graph_ok = graph_ok && L.ctx->halo.nranks == 1 && !L.ctx->mg_replica && sm_is_explicit(L);
+  auto sm_cycle = [&]() {
+    if (!graph_ok) { mg_sm_vcycle(M, 0); return; }
+    std::vector<uint64_t> key;
+    key.push_back(M.L.size()); key.push_back(uint64_t(M.nu)); key_f64(key, M.ratio); key.push_back(uint64_t(M.lowp));
+    for (const SolveState &L : M.L) {
+      ifem_ctx *lc = L.ctx;
+      for (auto &v : lc->mg_vec) key_ptr(key, v.p);
+      key_ptr(key, lc->sm_dinv.p); key_ptr(key, lc->Sm.val.p); key_ptr(key, lc->Sm_f32.p); key_ptr(key, lc->Sm.rowptr.p);
+      key_ptr(key, lc->mg_Rp.col.p); key_ptr(key, lc->mg_Pp.col.p);
+      key.push_back(uint64_t(lc->nPo)); key.push_back(uint64_t(lc->sm_version)); key.push_back(uint64_t(lc->tune.sm_lanes)); key.push_back(uint64_t(lc->sm_f32_valid));
+      key_f64(key, lc->sm_lmax);
+    }
+    if (!graph_run(c, c->sm_graph, key, [&]() { mg_sm_vcycle(M, 0); })) { c->tune.vcycle_graph_cells = 0; graph_ok = false; }
+  };
   v_zero(c, S.npo, x);
   v_copy(c, S.npo, b, r);
   double d2[2];
@@ -612,7 +663,7 @@ static int pcg_mg_sm(MgSm &M, const double *b, double *x, double tol, int maxit,
   int it = 0;
   while (std::sqrt(rr) > tol && it < maxit) {
     v_copy(c, S.npo, r, zin);
-    mg_sm_vcycle(M, 0);
+    sm_cycle();
     double rz_new[2];
     dot2(r, z, r, z, rz_new);
     if (it == 0) v_copy(c, S.npo, z, p);
@@ -978,8 +1029,8 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     auto run_vcycle = [&]() {
       if (!graph_ok) { mg_uu_vcycle(Mu, 0); return; }
       std::vector<uint64_t> key;
-      auto put = [&](const void *ptr) { key.push_back(uint64_t(reinterpret_cast<uintptr_t>(ptr))); };
-      auto putd = [&](double v) { uint64_t b; std::memcpy(&b, &v, 8); key.push_back(b); };
+      auto put = [&](const void *ptr) { key_ptr(key, ptr); };
+      auto putd = [&](double v) { key_f64(key, v); };
       key.push_back(Mu.L.size()); key.push_back(uint64_t(Mu.nu)); key.push_back(uint64_t(Mu.nu_post)); putd(Mu.ratio);
       for (const SolveState &L : Mu.L) {
         ifem_ctx *lc = L.ctx;
@@ -990,35 +1041,11 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
         key.push_back(uint64_t(lc->nUo)); key.push_back(uint64_t(lc->n_cells)); key.push_back(uint64_t(lc->mf_noconv)); key.push_back(uint64_t(lc->tune.xcd_swizzle));
         putd(lc->uu_lmax); putd(lc->mf_params.viscosity); putd(lc->mf_params.rho); putd(lc->mf_params.grad_div); putd(lc->mf_params.dt);
       }
-      ifem_ctx::VcGraph &G = c->vc_graph;
-      if (G.exec && key == G.key) {
-        IFEM_HIP_CHECK(hipGraphLaunch(G.exec, c->stream));
-        ++G.launches;
-        return;
+      if (!graph_run(c, c->vc_graph, key, [&]() { mg_uu_vcycle(Mu, 0); })) {
+        c->tune.vcycle_graph_cells = 0;
+        graph_ok = false;
+        if (o->verbose) fprintf(stderr, "[ifem] hipGraph capture of the A_uu V-cycle failed: eager launches from now on\n");
       }
-      if (!(G.armed && key == G.key)) { // a new state: this application runs eagerly (and allocates whatever is allocated lazily)
-        G.destroy();
-        G.key = key; G.armed = true;
-        mg_uu_vcycle(Mu, 0);
-        return;
-      }
-      // capture; a runtime that cannot (capture, instantiation or the first launch fails) switches the context back to eager launches for good
-      bool captured = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-      if (captured) {
-        try { mg_uu_vcycle(Mu, 0); }
-        catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(c->stream, &dead); if (dead) (void)hipGraphDestroy(dead); G.armed = false; throw; }
-        captured = hipStreamEndCapture(c->stream, &G.graph) == hipSuccess && G.graph != nullptr;
-        captured = captured && hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0) == hipSuccess;
-        captured = captured && hipGraphLaunch(G.exec, c->stream) == hipSuccess;
-      }
-      if (captured) { ++G.captures; ++G.launches; return; }
-      (void)hipGetLastError();
-      G.destroy();
-      G.armed = false;
-      c->tune.vcycle_graph_cells = 0;
-      graph_ok = false;
-      if (o->verbose) fprintf(stderr, "[ifem] hipGraph capture of the A_uu V-cycle failed: eager launches from now on\n");
-      mg_uu_vcycle(Mu, 0);
     };
     OpFn Vc = [&](const double *x, double *y) {
       v_cvt_d2f(c, S.nuo, x, c->mguf_vec[0].p);
