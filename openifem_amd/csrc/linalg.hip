@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(256) void k_cg1_update(int64_t n, const double *__r
     x[i] += al * pi;
     const double ri = r[i] - al * si;
     r[i] = ri;
-    if (diag) u[i] = ri / (diag[i] != 0.0 ? diag[i] : 1.0); // (without a preconditioner u IS r: the caller passes the same array)
+    if (diag) u[i] = ri / (diag[i] != 0.0 ? diag[i] : 1.0); // (no diag: u IS r -- plain CG, the caller passes the same array -- or the output of an external preconditioner, pcg_mg_sm)
   }
 }
 void cg1_init(ifem_ctx *ctx, int64_t n, const double *b, const double *diag, double *x, double *r, double *u, double *p, double *s) {

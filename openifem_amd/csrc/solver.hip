@@ -629,12 +629,12 @@ static void mg_sm_vcycle(MgSm &M, size_t l) {
 
 // CG preconditioned by one V-cycle, zero initial guess, absolute tolerance on the true residual ||b - S x||_2 (the
 // reference's stopping rule for CG(S_m), mpi_insim.cpp:88-89)
-static int pcg_mg_sm(MgSm &M, const double *b, double *x, double tol, int maxit, double *r, double *p, double *q) {
+static int pcg_mg_sm(MgSm &M, const double *b, double *x, double tol, int maxit, double *r, double *p, double *q, double *sv = nullptr) {
   SolveState &S = M.L[0];
   ifem_ctx *c = S.ctx;
   auto dot2 = [&](const double *a1, const double *b1, const double *a2, const double *b2, double *out) {
     out[0] = v_dot(c, S.npo, a1, b1);
-    out[1] = v_dot(c, S.npo, a2, b2);
+    out[1] = (a1 == a2 && b1 == b2) ? out[0] : v_dot(c, S.npo, a2, b2);
     allreduce_sum(c, out, 2);
   };
   double *zin = c->mg_vec[0].p, *z = c->mg_vec[1].p;
@@ -655,6 +655,26 @@ static int pcg_mg_sm(MgSm &M, const double *b, double *x, double tol, int maxit,
     }
     if (!graph_run(c, c->sm_graph, key, [&]() { mg_sm_vcycle(M, 0); })) { c->tune.vcycle_graph_cells = 0; graph_ok = false; }
   };
+  if (sv && c->tune.cg_single_reduction) {
+    // the recurrence of linalg.hip::cg1_* with the V-cycle as its preconditioner: u = V r, w = S u, the two inner products of the step in one
+    // pass with alpha / beta formed on the device (several ranks: one all-reduce on the stream), the vectors updated in one pass; the host
+    // waits once per iteration, for ||r||^2 of the stopping rule (it waited six times: three pairs of separate dot products)
+    auto norm2 = [&](const double *v) { double t = v_dot(c, S.npo, v, v); allreduce_sum(c, &t, 1); return t; };
+    cg1_init(c, S.npo, b, nullptr, x, r, r, p, sv);
+    double rr = norm2(r);
+    int it = 0;
+    while (std::sqrt(rr) > tol && it < maxit) {
+      v_copy(c, S.npo, r, zin);
+      sm_cycle();                      // z = V r
+      sm_apply(S, z, q, M.lowp);       // w = S z
+      cg1_dots(c, S.npo, r, z, q, it == 0);
+      cg1_update(c, S.npo, nullptr, z, q, p, sv, x, r);
+      rr = norm2(r);
+      ++it;
+      if (!(rr == rr)) break; // NaN guard
+    }
+    return it;
+  }
   v_zero(c, S.npo, x);
   v_copy(c, S.npo, b, r);
   double d2[2];
@@ -959,7 +979,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   }
   if (use_mg) {
     mg_sm_setup(M, c->asm_constraint_set);
-    S.st.cg_sm_iters += pcg_mg_sm(M, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, S.tp[1], S.tp[2], S.tp[3]);
+    S.st.cg_sm_iters += pcg_mg_sm(M, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, S.tp[1], S.tp[2], S.tp[3], S.tp[4]);
     S.st.sm_mg_levels = (uint32_t)M.L.size();
   } else if (dev_cg) // (Jacobi on S_m was measured too: 176 instead of 172 iterations -- its diagonal is nearly constant)
     S.st.cg_sm_iters += cg_device(c, S.npo, sm, nullptr, src1, dst1, std::max(o->sm_abs, o->sm_rel * n1), pmax, S.tp[1], S.tp[2],
