@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <functional>
 #include <vector>
 #include "ctx.hpp"
@@ -493,6 +494,19 @@ static bool graph_run(ifem_ctx *c, ifem_ctx::VcGraph &G, std::vector<uint64_t> &
   body();
   return false;
 }
+// rocprofv3 (rocprofiler-sdk 7.2) dies with a segmentation fault inside hipGraphLaunch when kernel tracing is on: under a profiler the cycles are
+// launched eagerly.  Detected once per process by the tool library being loaded (or announced: rocprofv3 exports ROCP_TOOL_LIBRARIES for its
+// child) -- the one place where this library looks at its environment.
+static bool profiler_attached() {
+  static const bool on = [] {
+    if (std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("ROCPROFILER_REGISTER_FORCE_LOAD")) return true;
+    for (const char *lib : {"librocprofiler-sdk-tool.so", "librocprofiler-sdk-tool.so.1", "librocprofiler-sdk-tool.so.0"}) {
+      if (void *h = dlopen(lib, RTLD_NOLOAD | RTLD_LAZY)) { dlclose(h); return true; }
+    }
+    return false;
+  }();
+  return on;
+}
 static inline void key_ptr(std::vector<uint64_t> &key, const void *p) { key.push_back(uint64_t(reinterpret_cast<uintptr_t>(p))); }
 static inline void key_f64(std::vector<uint64_t> &key, double v) { uint64_t b; std::memcpy(&b, &v, 8); key.push_back(b); }
 
@@ -639,7 +653,7 @@ static int pcg_mg_sm(MgSm &M, const double *b, double *x, double tol, int maxit,
   };
   double *zin = c->mg_vec[0].p, *z = c->mg_vec[1].p;
   // the cycle: eagerly, or replayed as a hipGraph on small single-rank chains (as the A_uu V-cycle, precond_vmult)
-  bool graph_ok = c->tune.vcycle_graph_cells > 0 && c->n_cells <= c->tune.vcycle_graph_cells && !c->profile && !kprof_root(c).on;
+  bool graph_ok = c->tune.vcycle_graph_cells > 0 && c->n_cells <= c->tune.vcycle_graph_cells && !c->profile && !kprof_root(c).on && !profiler_attached();
   for (const SolveState &L : M.L) graph_ok = graph_ok && L.ctx->halo.nranks == 1 && !L.ctx->mg_replica && sm_is_explicit(L);
   auto sm_cycle = [&]() {
     if (!graph_ok) { mg_sm_vcycle(M, 0); return; }
@@ -1044,7 +1058,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     mg_uu_setup(Mu);
     OpFn Amf = [&](const double *x, double *y) { uu_apply_level(S, x, y); };
     // the cycle itself: eagerly, or as a captured hipGraph (ctx.hpp::VcGraph) on small single-rank chains
-    bool graph_ok = c->tune.vcycle_graph_cells > 0 && c->n_cells <= c->tune.vcycle_graph_cells && !c->profile && !kprof_root(c).on;
+    bool graph_ok = c->tune.vcycle_graph_cells > 0 && c->n_cells <= c->tune.vcycle_graph_cells && !c->profile && !kprof_root(c).on && !profiler_attached();
     for (const SolveState &L : Mu.L) graph_ok = graph_ok && L.ctx->halo.nranks == 1 && !L.ctx->mg_replica;
     auto run_vcycle = [&]() {
       if (!graph_ok) { mg_uu_vcycle(Mu, 0); return; }
