@@ -363,6 +363,8 @@ def bench_insimex(args, host):
     from openifem_amd import multigpu
     solver, _, _ = multigpu.make_channel_solver(n, 0, 1, int(os.environ.get("LOCAL_RANK", "0")), None, multigrid=bool(args.mg), kind="InsIMEX")
     n_cells, n_u, n_p = solver.sizes()
+    args.ainv = 4 if args.ainv is None else args.ainv
+    args.inner_rel = 1e-2 if args.inner_rel is None else args.inner_rel
     solver.opts.ainv_kind = args.ainv
     solver.opts.inner_rel = args.inner_rel  # the host class defaults to the reference's 1e-4 (CG for A); 1e-2 is the measured optimum
     # A~^-1 = exactly one V-cycle (inner_maxit = 0) is the measured optimum for this symmetric operator at 1e-8 ||rhs||:
@@ -524,12 +526,12 @@ def main():
     ap.add_argument("--cells", dest="n", type=int, default=128, help="cells per direction per GPU")
     ap.add_argument("--cpu-cells", dest="cpu_n", default="32,64", help="cells per direction of the CPU baseline sample(s), comma separated (0 = skip; BASELINE.md section 3 plans 32 and 64: 14 s and 63 s on the 64 threads the sweep picks)")
     ap.add_argument("--extras", type=int, default=1, help="N = 1 only: also measure cold_step (geometry blocks and S_m rebuilt, as the reference does every iteration) and time_step (a whole run_one_step Newton loop)")
-    ap.add_argument("--inner-rel", type=float, default=1e-2, help="relative residual target of the inner A_uu solve inside the preconditioner (the reference applies an exact LU there, mpi_insim.cpp:124-127)")
-    ap.add_argument("--inner-rel-first", type=float, default=5e-5, help="the same for the FIRST preconditioner application of a solve (0: as --inner-rel).  Measured at 128^3 (profiles/r02_inner_sweep.txt): with 1e-2 the outer FGMRES needs two iterations (relative residual 9.1e-4 after the first), with 5e-5 in the first application one (7.8e-5 <= 1e-4) for the same four inner iterations in total: 275 -> 239 ms per step; later applications (later Newton iterations need 3-5 outer iterations whatever the inner accuracy) keep the cheap setting")
-    ap.add_argument("--ainv", type=int, default=4, help="IFEM_AINV_* kind of the A_uu^-1 replacement (4 = matrix-free operator + geometric multigrid V-cycle, 3 = matrix-free inner operator + block Jacobi, 1 = fp32 inner matrix, 0 = fp64 matrix)")
+    ap.add_argument("--inner-rel", type=float, default=None, help="relative residual target of the inner A_uu solve inside the preconditioner (the reference applies an exact LU there, mpi_insim.cpp:124-127)")
+    ap.add_argument("--inner-rel-first", type=float, default=None, help="experiment (default: what InsIM::initialize_system sets, 5e-5 with multigrid levels): the same for the FIRST preconditioner application of a solve (0: as --inner-rel).  Measured at 128^3 (profiles/r02_inner_sweep.txt): with 1e-2 the outer FGMRES needs two iterations (relative residual 9.1e-4 after the first), with 5e-5 in the first application one (7.8e-5 <= 1e-4) for the same four inner iterations in total: 275 -> 239 ms per step; later applications (later Newton iterations need 3-5 outer iterations whatever the inner accuracy) keep the cheap setting")
+    ap.add_argument("--ainv", type=int, default=None, help="IFEM_AINV_* kind of the A_uu^-1 replacement (4 = matrix-free operator + geometric multigrid V-cycle, 3 = matrix-free inner operator + block Jacobi, 1 = fp32 inner matrix, 0 = fp64 matrix)")
     ap.add_argument("--sm-rel", type=float, default=None, help="experiment: relative tolerance of CG(S_m) inside the preconditioner (reference and default: 1e-3)")
     ap.add_argument("--mp-rel", type=float, default=None, help="experiment: relative tolerance of CG(M_p) inside the preconditioner (reference and default: 1e-6)")
-    ap.add_argument("--inner-restart", type=int, default=16, help="restart length of the inner GMRES of the A_uu^-1 replacement (measured at 128^3: 8/10/12/15/20/30/45 -> 557/533/537/518/522/531/543 ms per step; 16 = one multi-dot pass of the single-precision basis; the library default is 30)")
+    ap.add_argument("--inner-restart", type=int, default=None, help="restart length of the inner GMRES of the A_uu^-1 replacement (measured at 128^3: 8/10/12/15/20/30/45 -> 557/533/537/518/522/531/543 ms per step; 16 = one multi-dot pass of the single-precision basis; the library default is 30)")
     ap.add_argument("--tuned", type=int, default=1, help="also time the relaxed-preconditioner variant (reported as tuned_preconditioner, N = 1 only)")
     ap.add_argument("--mg", type=int, default=1, help="1 (default): attach the chain of coarser (semi-coarsened) box meshes so that CG(S_m) inside the preconditioner is multigrid-preconditioned; 0: plain CG as in the reference")
     ap.add_argument("--inner-maxit", type=int, default=None, help="cap of the inner A_uu iterations (--ainv 4: 0 = exactly one V-cycle)")
@@ -607,15 +609,23 @@ def main():
     solver, reps, t_setup = multigpu.make_channel_solver(n, rank, world, local_rank, dist, multigrid=bool(args.mg), min_cells=args.mg_min_cells)
     n_cells, n_u, n_p = solver.sizes()
     n_dofs_global = solver.global_dofs() if world > 1 else n_u + n_p
-    solver.opts.inner_rel = args.inner_rel
-    solver.opts.inner_rel_first = args.inner_rel_first
+    # The timed configuration is the PRODUCT default: whatever InsIM<3>::initialize_system leaves in solver_opts (host/insim.cpp:
+    # V-cycle inner solver, restart 16, inner_rel 1e-2, inner_rel_first 5e-5 when multigrid levels attach) -- the flags below are
+    # experiment overrides and the line names every one that was used (config.solver_opts_overridden)
+    overridden = [k for k in ("inner_rel", "inner_rel_first", "inner_restart", "ainv", "sm_rel", "mp_rel", "fgmres_rel", "inner_maxit",
+                              "mg_smooth_u", "mg_post_u", "mg_ratio_u") if getattr(args, k) is not None] + (["outer_mf"] if args.outer_mf else []) + (["tune"] if args.tune else []) + ([] if args.mg else ["mg=0"])
+    if args.inner_rel is not None:
+        solver.opts.inner_rel = args.inner_rel
+    if args.inner_rel_first is not None:
+        solver.opts.inner_rel_first = args.inner_rel_first
     if args.inner_restart:
         solver.opts.inner_restart = args.inner_restart
     if args.sm_rel is not None:
         solver.opts.sm_rel = args.sm_rel
     if args.mp_rel is not None:
         solver.opts.mp_rel = args.mp_rel
-    solver.opts.ainv_kind = args.ainv
+    if args.ainv is not None:
+        solver.opts.ainv_kind = args.ainv
     if args.fgmres_rel is not None:
         solver.opts.fgmres_rel = args.fgmres_rel
     if args.inner_maxit is not None:
@@ -769,7 +779,10 @@ def main():
                        "halo_exchanges_per_step": comm["halo_exchanges"] / args.steps, "allreduce_stream_per_step": comm["allreduce_dev"] / args.steps,
                        "allreduce_host_per_step": comm["allreduce_host"] / args.steps, "allreduce_vector_per_step": comm["allreduce_vec"] / args.steps,
                        "fgmres_iters": last.fgmres_iters, "cg_mp_iters": last.cg_mp_iters,
-                       "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": args.inner_rel, "inner_rel_first": args.inner_rel_first, "ainv_kind": args.ainv, "outer_matrix_free": args.outer_mf,
+                       "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": solver.opts.inner_rel, "inner_rel_first": solver.opts.inner_rel_first, "ainv_kind": solver.opts.ainv_kind, "outer_matrix_free": args.outer_mf,
+                       "solver_opts": {"ainv_kind": solver.opts.ainv_kind, "inner_restart": solver.opts.inner_restart, "inner_rel": solver.opts.inner_rel,
+                                       "inner_rel_first": solver.opts.inner_rel_first, "source": "InsIM::initialize_system defaults" if not overridden else "overridden: " + ",".join(overridden)},
+                       "solver_opts_overridden": overridden,
                        "t_cg_mp_ms": last.t_cg_mp_ms, "t_cg_sm_ms": last.t_cg_sm_ms, "t_ainv_ms": last.t_ainv_ms,
                        "mf_apply_ms": mf_ms / max(mf_calls, 1), "mf_applies": mf_calls,
                        "sm_multigrid_levels": int(last.sm_mg_levels),

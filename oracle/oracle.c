@@ -1512,3 +1512,282 @@ void orc_update_stress(const orc_mesh *m, double mu, const double *present, doub
   for (int k = 0; k < dim * dim; ++k) for (int i = 0; i < n_un; ++i) stress[(size_t)k * n_un + i] /= cnt[i];
   free(cnt);
 }
+
+/* ==== SUPGFluidSolver::BlockIncompSchurPreconditioner + SUPGFluidSolver::solve ========================================
+ * mpi_supg_solver.cpp:19-32 (SchurComplementTpp::vmult), :35-134 (constructor: Pvv_inverse = Euclid ILU(0) of A_vv,
+ * B2pp = A_pp - A_pv rowsum(|A_vv|)^-1 A_vp, B2pp_inverse = Euclid ILU(0) of it), :141-192 (vmult), :297-328 (solve).
+ * Third-party arithmetic restated (absent from /root/reference): Hypre Euclid with its defaults on one rank = ILU(0) in
+ * the natural row order (preconditioner_pilut.cpp:100-138: `levels = 0`); deal.II SolverGMRES<>(AdditionalData(200)) =
+ * LEFT-preconditioned restarted GMRES whose stopping test reads the preconditioned residual (use_default_residual) and
+ * which honours the incoming dst as initial guess; SolverFGMRES as in orc_ins_solve.  Iterates are parity unpinned
+ * (no reference test prints them); the restatement exists so that the iteration counts of the HIP path can be set
+ * beside those of the reference's preconditioner STRUCTURE on the same matrix.
+ * perm_v / perm_p (NULL = natural order) are measurement hooks: ILU(0) in another elimination order. */
+typedef struct { int n; int64_t *rp; int32_t *col; double *val; int32_t *diag; const int32_t *ord; } ilu_t;
+
+static void ilu_free(ilu_t *f) { free(f->rp); free(f->col); free(f->val); free(f->diag); memset(f, 0, sizeof(*f)); }
+
+/* in-place ILU(0) (IKJ) of a CSR whose columns are sorted; ord[i] = elimination position of row i (NULL: i) */
+static int ilu0_factor(ilu_t *f) {
+  const int n = f->n; const int32_t *ord = f->ord;
+  int32_t *by = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  for (int i = 0; i < n; ++i) by[ord ? ord[i] : i] = i;
+  f->diag = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    f->diag[i] = -1;
+    for (int64_t k = f->rp[i]; k < f->rp[i + 1]; ++k) if (f->col[k] == i) f->diag[i] = (int32_t)(k - f->rp[i]);
+    if (f->diag[i] < 0) { free(by); return -1; }
+  }
+  int32_t *pos = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  for (int i = 0; i < n; ++i) pos[i] = -1;
+  int maxlen = 0;
+  for (int i = 0; i < n; ++i) if (f->rp[i + 1] - f->rp[i] > maxlen) maxlen = (int)(f->rp[i + 1] - f->rp[i]);
+  int32_t *low = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxlen);
+  int rc = 0;
+  for (int p = 0; p < n && rc == 0; ++p) {
+    const int i = by[p]; const int64_t rs = f->rp[i]; const int len = (int)(f->rp[i + 1] - rs);
+    for (int t = 0; t < len; ++t) pos[f->col[rs + t]] = t;
+    int nl = 0; /* lower entries of the row, in elimination order */
+    for (int t = 0; t < len; ++t) { const int c = f->col[rs + t]; if (c != i && (ord ? ord[c] : c) < p) low[nl++] = t; }
+    for (int a = 1; a < nl; ++a) { /* insertion sort by elimination position */
+      const int32_t v = low[a]; int b = a - 1;
+      while (b >= 0 && (ord ? ord[f->col[rs + low[b]]] : f->col[rs + low[b]]) > (ord ? ord[f->col[rs + v]] : f->col[rs + v])) { low[b + 1] = low[b]; --b; }
+      low[b + 1] = v;
+    }
+    for (int a = 0; a < nl; ++a) {
+      const int t = low[a]; const int k = f->col[rs + t]; const int64_t ks = f->rp[k];
+      const double lik = f->val[rs + t] / f->val[ks + f->diag[k]];
+      f->val[rs + t] = lik;
+      const int pk = ord ? ord[k] : k;
+      for (int64_t u = ks; u < f->rp[k + 1]; ++u) { /* upper entries of row k */
+        const int j = f->col[u];
+        if (j == k || (ord ? ord[j] : j) < pk) continue;
+        if (pos[j] >= 0) f->val[rs + pos[j]] -= lik * f->val[u];
+      }
+    }
+    const double d = f->val[rs + f->diag[i]];
+    if (!(fabs(d) > 0) || !isfinite(d)) rc = -2;
+    for (int t = 0; t < len; ++t) pos[f->col[rs + t]] = -1;
+  }
+  free(by); free(pos); free(low);
+  return rc;
+}
+
+/* y = (LU)^-1 x */
+static void ilu0_apply(const ilu_t *f, const double *x, double *y) {
+  const int n = f->n; const int32_t *ord = f->ord;
+  if (!ord) {
+    for (int i = 0; i < n; ++i) {
+      double t = x[i]; const int64_t rs = f->rp[i];
+      for (int64_t k = rs; k < rs + f->diag[i]; ++k) t -= f->val[k] * y[f->col[k]];
+      y[i] = t;
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      const int64_t rs = f->rp[i]; double t = y[i];
+      for (int64_t k = rs + f->diag[i] + 1; k < f->rp[i + 1]; ++k) t -= f->val[k] * y[f->col[k]];
+      y[i] = t / f->val[rs + f->diag[i]];
+    }
+    return;
+  }
+  int32_t *by = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  for (int i = 0; i < n; ++i) by[ord[i]] = i;
+  for (int p = 0; p < n; ++p) {
+    const int i = by[p]; double t = x[i];
+    for (int64_t k = f->rp[i]; k < f->rp[i + 1]; ++k) { const int c = f->col[k]; if (c != i && ord[c] < p) t -= f->val[k] * y[c]; }
+    y[i] = t;
+  }
+  for (int p = n - 1; p >= 0; --p) {
+    const int i = by[p]; double t = y[i];
+    for (int64_t k = f->rp[i]; k < f->rp[i + 1]; ++k) { const int c = f->col[k]; if (c != i && ord[c] > p) t -= f->val[k] * y[c]; }
+    y[i] = t / f->val[f->rp[i] + f->diag[i]];
+  }
+  free(by);
+}
+
+typedef struct {
+  orc_system *s; ilu_t Pvv, B2;
+  long tpp_itr, n_apply, pvv_applies; /* Tpp_itr (:176), vmult calls */
+  double *u1, *u2, *p1;
+} supg_pc;
+
+static void spmv_pv(const orc_system *s, const double *xu, double *yp) { /* A_pv = block(1,0) */
+  for (int i = 0; i < s->n_p; ++i) {
+    const int r = s->n_u + i; double t = 0; const int64_t b = s->rowptr[r], e = b + s->psplit[r];
+    for (int64_t k = b; k < e; ++k) t += s->A[k] * xu[s->col[k]];
+    yp[i] = t;
+  }
+}
+static void spmv_pp(const orc_system *s, const double *xp, double *yp) { /* A_pp = block(1,1) */
+  for (int i = 0; i < s->n_p; ++i) {
+    const int r = s->n_u + i; double t = 0; const int64_t b = s->rowptr[r] + s->psplit[r], e = s->rowptr[r + 1];
+    for (int64_t k = b; k < e; ++k) t += s->A[k] * xp[s->col[k] - s->n_u];
+    yp[i] = t;
+  }
+}
+
+/* SchurComplementTpp::vmult, :19-32: dst = A_pp src - A_pv Pvv^-1 A_vp src */
+static void supg_tpp(void *vc, const double *src, double *dst) {
+  supg_pc *c = (supg_pc *)vc; orc_system *s = c->s;
+  spmv_up(s, src, c->u1);
+  ilu0_apply(&c->Pvv, c->u1, c->u2); c->pvv_applies++;
+  spmv_pv(s, c->u2, c->p1);
+  spmv_pp(s, src, dst);
+  for (int i = 0; i < s->n_p; ++i) dst[i] -= c->p1[i];
+}
+static void supg_b2inv(void *vc, const double *x, double *y) { ilu0_apply(&((supg_pc *)vc)->B2, x, y); }
+
+/* constructor, :35-134 */
+static int supg_pc_setup(supg_pc *c, orc_system *s, const int32_t *perm_v, const int32_t *perm_p) {
+  memset(c, 0, sizeof(*c));
+  c->s = s;
+  const int n_u = s->n_u, n_p = s->n_p;
+  /* Pvv_inverse.initialize(system_matrix->block(0, 0)), :49-51 */
+  ilu_t *f = &c->Pvv; f->n = n_u; f->ord = perm_v;
+  f->rp = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n_u + 1)); f->rp[0] = 0;
+  for (int i = 0; i < n_u; ++i) f->rp[i + 1] = f->rp[i] + s->psplit[i];
+  f->col = (int32_t *)malloc(sizeof(int32_t) * (size_t)f->rp[n_u]);
+  f->val = (double *)malloc(sizeof(double) * (size_t)f->rp[n_u]);
+  double *rsum = (double *)calloc((size_t)n_u, sizeof(double));
+  for (int i = 0; i < n_u; ++i) {
+    memcpy(f->col + f->rp[i], s->col + s->rowptr[i], sizeof(int32_t) * (size_t)s->psplit[i]);
+    memcpy(f->val + f->rp[i], s->A + s->rowptr[i], sizeof(double) * (size_t)s->psplit[i]);
+    /* RowSumAvv = |A_vv| 1, :62-109; ReverseRowSum = 1 / RowSumAvv, :110-124 */
+    for (int64_t k = s->rowptr[i]; k < s->rowptr[i] + s->psplit[i]; ++k) rsum[i] += fabs(s->A[k]);
+  }
+  int rc = ilu0_factor(f);
+  /* schur = A_pv diag(ReverseRowSum) A_vp on the pattern of the product; B2pp = A_pp - schur, :126-132.  Sparse accumulator per row. */
+  ilu_t *g = &c->B2; g->n = n_p; g->ord = perm_p;
+  g->rp = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n_p + 1)); g->rp[0] = 0;
+  int32_t *mark = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_p);
+  for (int i = 0; i < n_p; ++i) mark[i] = -1;
+  int64_t cap = 64 * (int64_t)n_p, nnz = 0;
+  g->col = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap); g->val = (double *)malloc(sizeof(double) * (size_t)cap);
+  for (int i = 0; i < n_p; ++i) {
+    const int r = n_u + i; const int64_t start = nnz;
+    for (int64_t kb = s->rowptr[r]; kb < s->rowptr[r] + s->psplit[r]; ++kb) {
+      const int k = s->col[kb]; const double a = s->A[kb] / rsum[k];
+      for (int64_t kt = s->rowptr[k] + s->psplit[k]; kt < s->rowptr[k + 1]; ++kt) {
+        const int j = s->col[kt] - n_u;
+        if (mark[j] < start) {
+          if (nnz == cap) { cap *= 2; g->col = (int32_t *)realloc(g->col, sizeof(int32_t) * (size_t)cap); g->val = (double *)realloc(g->val, sizeof(double) * (size_t)cap); }
+          mark[j] = (int32_t)nnz; g->col[nnz] = j; g->val[nnz] = 0; ++nnz;
+        }
+        g->val[mark[j]] -= a * s->A[kt];
+      }
+    }
+    for (int64_t kp = s->rowptr[r] + s->psplit[r]; kp < s->rowptr[r + 1]; ++kp) {
+      const int j = s->col[kp] - n_u;
+      if (mark[j] < start) {
+        if (nnz == cap) { cap *= 2; g->col = (int32_t *)realloc(g->col, sizeof(int32_t) * (size_t)cap); g->val = (double *)realloc(g->val, sizeof(double) * (size_t)cap); }
+        mark[j] = (int32_t)nnz; g->col[nnz] = j; g->val[nnz] = 0; ++nnz;
+      }
+      g->val[mark[j]] += s->A[kp];
+    }
+    /* sort the row by column */
+    for (int64_t a = start + 1; a < nnz; ++a) {
+      const int32_t cj = g->col[a]; const double cv = g->val[a]; int64_t b = a - 1;
+      while (b >= start && g->col[b] > cj) { g->col[b + 1] = g->col[b]; g->val[b + 1] = g->val[b]; --b; }
+      g->col[b + 1] = cj; g->val[b + 1] = cv;
+    }
+    for (int64_t a = start; a < nnz; ++a) mark[g->col[a]] = -1;
+    g->rp[i + 1] = nnz;
+  }
+  free(mark); free(rsum);
+  if (rc == 0) rc = ilu0_factor(g); /* B2pp_inverse.initialize(*B2pp_matrix), :133 */
+  c->u1 = (double *)malloc(sizeof(double) * (size_t)n_u); c->u2 = (double *)malloc(sizeof(double) * (size_t)n_u);
+  c->p1 = (double *)malloc(sizeof(double) * (size_t)n_p);
+  return rc;
+}
+static void supg_pc_free(supg_pc *c) { ilu_free(&c->Pvv); ilu_free(&c->B2); free(c->u1); free(c->u2); free(c->p1); }
+
+/* deal.II SolverGMRES (left preconditioning, default residual): solves A x = b from the given x; stops when the norm of the
+ * PRECONDITIONED residual is <= tol.  Returns the number of iterations. */
+static int left_gmres(int n, op_fn A, void *actx, op_fn Pinv, void *pctx, const double *b, double *x, int m, int maxit, double tol) {
+  double *V = (double *)malloc(sizeof(double) * (size_t)n * (m + 1));
+  double *H = (double *)calloc((size_t)(m + 1) * m, sizeof(double));
+  double *cs = (double *)calloc((size_t)m, sizeof(double)), *sn = (double *)calloc((size_t)m, sizeof(double));
+  double *g = (double *)calloc((size_t)m + 1, sizeof(double)), *y = (double *)calloc((size_t)m, sizeof(double));
+  double *w = (double *)malloc(sizeof(double) * (size_t)n), *p = (double *)malloc(sizeof(double) * (size_t)n);
+  int it = 0;
+  while (1) {
+    A(actx, x, w);
+    for (int i = 0; i < n; ++i) w[i] = b[i] - w[i];
+    Pinv(pctx, w, p);
+    const double rho = vnorm(n, p);
+    if (rho <= tol || it >= maxit) break;
+    for (int i = 0; i < n; ++i) V[i] = p[i] / rho;
+    memset(g, 0, sizeof(double) * ((size_t)m + 1)); g[0] = rho;
+    int j = 0, done = 0;
+    for (; j < m && it < maxit; ++j) {
+      A(actx, V + (size_t)n * j, w);
+      Pinv(pctx, w, p);
+      for (int i = 0; i <= j; ++i) { const double h = vdot(n, p, V + (size_t)n * i); H[i * m + j] = h; vaxpy(n, -h, V + (size_t)n * i, p); }
+      const double hn = vnorm(n, p);
+      H[(j + 1) * m + j] = hn;
+      if (hn != 0) for (int i = 0; i < n; ++i) V[(size_t)n * (j + 1) + i] = p[i] / hn;
+      for (int i = 0; i < j; ++i) {
+        const double t = cs[i] * H[i * m + j] + sn[i] * H[(i + 1) * m + j];
+        H[(i + 1) * m + j] = -sn[i] * H[i * m + j] + cs[i] * H[(i + 1) * m + j];
+        H[i * m + j] = t;
+      }
+      const double a = H[j * m + j], bb = H[(j + 1) * m + j], r = hypot(a, bb);
+      cs[j] = a / r; sn[j] = bb / r;
+      H[j * m + j] = r; H[(j + 1) * m + j] = 0;
+      g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
+      ++it;
+      if (fabs(g[j + 1]) <= tol) { ++j; done = 1; break; }
+    }
+    for (int i = j - 1; i >= 0; --i) {
+      double t = g[i];
+      for (int k = i + 1; k < j; ++k) t -= H[i * m + k] * y[k];
+      y[i] = t / H[i * m + i];
+    }
+    for (int i = 0; i < j; ++i) vaxpy(n, y[i], V + (size_t)n * i, x);
+    if (done || it >= maxit) break;
+  }
+  free(V); free(H); free(cs); free(sn); free(g); free(y); free(w); free(p);
+  return it;
+}
+
+/* BlockIncompSchurPreconditioner::vmult, :141-192 */
+static void supg_pc_vmult(void *vc, const double *src, double *dst) {
+  supg_pc *c = (supg_pc *)vc; orc_system *s = c->s;
+  const int n_u = s->n_u, n_p = s->n_p;
+  const double *src0 = src, *src1 = src + n_u; double *dst0 = dst, *dst1 = dst + n_u;
+  double *ptmp1 = (double *)malloc(sizeof(double) * (size_t)n_u), *ptmp = (double *)malloc(sizeof(double) * (size_t)n_p);
+  double *Sc = (double *)malloc(sizeof(double) * (size_t)n_p), *utmp1 = (double *)malloc(sizeof(double) * (size_t)n_u);
+  double *utmp2 = (double *)malloc(sizeof(double) * (size_t)n_u);
+  ilu0_apply(&c->Pvv, src0, ptmp1); c->pvv_applies++;          /* :150 */
+  spmv_pv(s, ptmp1, ptmp);                                      /* :151 */
+  for (int i = 0; i < n_p; ++i) ptmp[i] = src1[i] - ptmp[i];    /* :152-153 */
+  supg_tpp(c, ptmp, Sc);                                        /* initial guess alpha c, :165-171 */
+  const double sc = vdot(n_p, Sc, ptmp);
+  const double alpha = sc != 0 ? vdot(n_p, ptmp, ptmp) / sc : 0.0;
+  for (int i = 0; i < n_p; ++i) dst1[i] = alpha * ptmp[i];
+  c->tpp_itr += left_gmres(n_p, supg_tpp, c, supg_b2inv, c, ptmp, dst1, 200, n_p, 1e-3 * vnorm(n_p, ptmp)); /* :174-182 */
+  spmv_up(s, dst1, utmp1);                                      /* :187 */
+  ilu0_apply(&c->Pvv, utmp1, utmp2);                            /* :188 */
+  ilu0_apply(&c->Pvv, src0, dst0); c->pvv_applies += 2;         /* :189 */
+  for (int i = 0; i < n_u; ++i) dst0[i] -= utmp2[i];            /* :190 */
+  c->n_apply++;
+  free(ptmp1); free(ptmp); free(Sc); free(utmp1); free(utmp2);
+}
+
+/* SUPGFluidSolver::solve, :297-328: FGMRES to 1e-6 ||rhs|| (system_matrix.m() iterations at most), constraints.distribute.
+ * counts[0..3] = FGMRES iterations, Tpp_itr, preconditioner applications, Pvv applications. */
+int32_t orc_scns_solve(orc_system *s, int32_t use_nonzero, int32_t fgmres_restart, const int32_t *perm_v, const int32_t *perm_p,
+                       double *newton_update, int64_t *counts, double *res) {
+  supg_pc c;
+  int rc = supg_pc_setup(&c, s, perm_v, perm_p);
+  if (rc < 0) { supg_pc_free(&c); return -3; }
+  const double tol = 1e-6 * vnorm(s->n, s->rhs);
+  pc_ctx full; memset(&full, 0, sizeof(full)); full.s = s;
+  double r = 0;
+  const int it = fgmres(s->n, op_full, &full, supg_pc_vmult, &c, s->rhs, newton_update, fgmres_restart > 0 ? fgmres_restart : 30, s->n, tol, &r);
+  const unsigned char *isc = s->is_c[use_nonzero ? 1 : 0]; const double *cv = s->cval[use_nonzero ? 1 : 0];
+  for (int i = 0; i < s->n; ++i) if (isc[i]) newton_update[i] = cv[i];
+  if (counts) { counts[0] = it; counts[1] = c.tpp_itr; counts[2] = c.n_apply; counts[3] = c.pvv_applies; }
+  if (res) *res = r;
+  supg_pc_free(&c);
+  return r <= tol ? 0 : -2;
+}

@@ -159,6 +159,12 @@ void orc_scns_cell(const orc_mesh *m, const orc_scns_params *p, int32_t cell, co
 void orc_scns_assemble(orc_system *s, const orc_scns_params *p, int32_t use_nonzero, const double *eval,
                        const double *present, const double *fsi_acc);
 /* Newton loop of SUPGFluidSolver::run_one_step (mpi_supg_solver.cpp:331-425): floor 1e-14; returns iterations or <0 */
+/* SUPGFluidSolver::solve with BlockIncompSchurPreconditioner as the reference builds it (mpi_supg_solver.cpp:19-192, 297-328):
+ * ILU(0)(A_vv), T_pp as an operator, ILU(0)(B2pp) inside left-preconditioned GMRES(200); on the system of the last
+ * orc_scns_assemble.  counts[4] = FGMRES iterations, Tpp_itr, preconditioner applications, Pvv^-1 applications.
+ * perm_v / perm_p: elimination order of the two ILU(0) (NULL: natural = Euclid on one rank) -- measurement hooks. */
+int32_t orc_scns_solve(orc_system *s, int32_t use_nonzero, int32_t fgmres_restart, const int32_t *perm_v, const int32_t *perm_p,
+                       double *newton_update, int64_t *counts, double *res);
 int32_t orc_scns_run_one_step(orc_system *s, const orc_scns_params *p, int32_t apply_nonzero, double newton_tol,
                               int32_t newton_maxit, orc_full_solve_fn solve, void *user, double *present,
                               const double *fsi_acc, double *log);

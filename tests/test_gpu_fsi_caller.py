@@ -558,3 +558,32 @@ def test_insim_with_attached_multigrid_levels_under_fsi_dirichlet_lines():
     assert np.abs(a[:n_u3] - b[:n_u3]).max() <= 1e-5 * np.abs(b[:n_u3]).max()
     assert np.abs(a[n_u3:] - b[n_u3:]).max() <= 1e-4 * np.abs(b[n_u3:]).max()
     assert its[True] <= 30, its
+
+
+def test_insim_run_one_step_leaves_the_projected_stress_of_the_new_solution():
+    """InsIM::run_one_step ends with update_stress() (mpi_insim.cpp:474-475): an FSI caller on InsIM<3> (the reference's
+    fsi_gravity_mpi) reads the projected viscous stress of the step's solution through ifem_fsi_fluid_at_points, not a stale or
+    zero field.  Checked against an explicit ifem_update_stress of the same solution and against mu du/dy of the flow."""
+    from openifem_amd import capi, host
+    import ctypes as C
+    s = host.InsIM(host.channel_prm(3, dt=1.0), (4, 4, 4), (0, 0, 0), (2.0, 0.2, 0.2))  # dt = 1: one step lands near steady Poiseuille
+    s.setup(0)
+    s.run_one_step(True)
+    L = s.L
+    pts = np.array([[0.7, 0.05, 0.1], [1.3, 0.15, 0.06], [0.31, 0.1, 0.13]])
+    n, dim = len(pts), 3
+
+    def at_points():
+        vals, st, cell = np.zeros((n, dim + 1)), np.zeros((n, dim, dim)), np.zeros(n, np.int32)
+        assert L.ifem_fsi_fluid_at_points(s.ctx, n, pts.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
+                                          st.ctypes.data_as(C.c_void_p), cell.ctypes.data_as(C.c_void_p)) == 0
+        return vals, st, cell
+    v1, st1, c1 = at_points()
+    assert (c1 >= 0).all() and np.abs(st1).max() > 0
+    assert L.ifem_update_stress(s.ctx, C.c_double(1.0), None) == 0  # the same projection once more, explicitly
+    v2, st2, c2 = at_points()
+    assert np.array_equal(st1, st2) and np.array_equal(v1, v2)
+    # the flow is (close to) plane Poiseuille: T_xy = mu du/dy = dP / (2 L) (H - 2 y)
+    exact = 10.0 / (2 * 2.0) * (0.2 - 2 * pts[:, 1])
+    assert np.abs(st1[:, 0, 1] - exact).max() < 0.05 * np.abs(exact).max() + 0.02
+    s.close()
