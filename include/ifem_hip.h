@@ -193,6 +193,16 @@ typedef struct {
                                  of IFEM_AINV_MG and the S_m V-cycle inside CG(S_m) are captured into hipGraphs once per state and replayed
                                  (their ~100-200 short launches are launch latency there: the reference's test meshes); 0: always launched
                                  eagerly */
+  int32_t scns_pc;       /* SCnsIM / SUPGInsIM block preconditioner.  2 (default): the reference's structure (mpi_supg_solver.cpp:35-192):
+                            P_vv^-1 = ILU(0) of A_vv (node blocks, natural order; the owned x owned block per rank), T_pp applied as the
+                            OPERATOR A_pp - A_pv P_vv^-1 A_vp, inner GMRES(200) preconditioned by the ILU(0) of the assembled
+                            B2pp = A_pp - A_pv rowsum(|A_vv|)^-1 A_vp.  1: rounds 2-5: node-block Jacobi P_vv^-1, T_pp explicit (tpp_*) */
+  int32_t pvv_sweeps;    /* 3: Jacobi sweeps per triangular system when ILU(0)(A_vv) is applied (bilu.hip); < 0: exact substitution */
+  int32_t b2pp_sweeps;   /* 5: the same for ILU(0)(B2pp) */
+  int32_t scns_inner_reorth; /* 0 (default): the inner GMRES(200) on T_pp orthogonalises once per iteration (classical Gram-Schmidt, one
+                            fused pass: it is a preconditioner solved to 1e-3); 1: twice, as the outer FGMRES */
+  int32_t scns_inner_left; /* 1 (default): that GMRES is LEFT-preconditioned and stops on the preconditioned residual, as deal.II's SolverGMRES
+                            does with its defaults (mpi_supg_solver.cpp:174-182); 0: right-preconditioned, true residual */
 } ifem_tuning;
 void ifem_default_tuning(ifem_tuning *t);
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t);
@@ -479,15 +489,8 @@ int ifem_uu_vmult(ifem_ctx *ctx, int dst, int src, int variant);
 /* z = P^-1 v, BlockSchurPreconditioner::vmult (mpi_insim.cpp:57-128) on context vectors -- test hook */
 int ifem_precond_vmult(ifem_ctx *ctx, const ifem_ins_params *p, const ifem_solver_opts *o, int dst, int src);
 
-/* Test hook of the SCnsIM preconditioner (single-rank contexts, after ifem_scns_assemble): forms the explicit
- * T_pp = A_pp - A_pv P_vv^-1 A_vp and its ILU(0) (ifem_tuning::tpp_ilu_order) as ifem_scns_solve would.  Call with rowptr only
- * to size the arrays (n_p + 1 entries, nnz = rowptr[n_p]); with col / val it also returns the CSR of T_pp, and with x / y
- * (host, n_p entries) y = (LU)^-1 x.  *levels (may be NULL) receives the number of forward levels of the schedule. */
-int ifem_tpp_ilu_probe(ifem_ctx *ctx, int64_t *rowptr, int32_t *col, double *val, const double *x, double *y, int32_t *levels);
-/* Test aid: replace the values of the explicit T_pp (pattern and order as returned by ifem_tpp_ilu_probe) so that the next
- * factorisation sees them -- the breakdown path of the ILU(0) (zero / non-finite pivot -> IFEM_E_KRYLOV_NOCONV from the probe, Jacobi
- * in ifem_scns_solve) cannot be reached from an assembled fluid matrix at will. */
-int ifem_tpp_override(ifem_ctx *ctx, const double *val); /* TEST AID ONLY: single rank, not part of the reference's interface */
+/* (the test aids of the SCnsIM preconditioner -- ifem_tpp_ilu_probe, ifem_tpp_override, ifem_scns_pc_probe -- live in
+ * ifem_hip_testing.h: they are not part of the drop-in surface) */
 
 /* Export the assembled block system as one CSR over the local dofs [u|p] (host arrays; call twice: first
  * with col = val = NULL to get nnz through rowptr[n]).  which: 0 system_matrix, 1 mass (diag(M_u), M_p).

@@ -98,7 +98,8 @@ class MgTransfer(C.Structure):
 class Tuning(C.Structure):
     _fields_ = [("geo_cache", C.c_int32), ("xcd_swizzle", C.c_int32), ("asm_skip", C.c_int32), ("spmv_lanes", C.c_int32),
                 ("sm_lanes", C.c_int32), ("mf_f32", C.c_int32), ("tpp_operator", C.c_int32), ("spmv_pipe", C.c_int32), ("halo_overlap", C.c_int32),
-                ("asm3_variant", C.c_int32), ("cg_single_reduction", C.c_int32), ("asm3_cpb", C.c_int32), ("tpp_milu_permille", C.c_int32), ("tpp_ilu_order", C.c_int64), ("basis_pad", C.c_int64), ("tpp_tri_sweeps", C.c_int32), ("uu_row_order", C.c_int32), ("eig_steps", C.c_int32), ("vcycle_graph_cells", C.c_int32)]
+                ("asm3_variant", C.c_int32), ("cg_single_reduction", C.c_int32), ("asm3_cpb", C.c_int32), ("tpp_milu_permille", C.c_int32), ("tpp_ilu_order", C.c_int64), ("basis_pad", C.c_int64), ("tpp_tri_sweeps", C.c_int32), ("uu_row_order", C.c_int32), ("eig_steps", C.c_int32), ("vcycle_graph_cells", C.c_int32),
+                ("scns_pc", C.c_int32), ("pvv_sweeps", C.c_int32), ("b2pp_sweeps", C.c_int32), ("scns_inner_reorth", C.c_int32), ("scns_inner_left", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -136,7 +137,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof",
            "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag",
            "ifem_fsi_set_solid", "ifem_fsi_update_indicator", "ifem_fsi_find_fluid_bc", "ifem_fsi_get_stress",
-           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_comm_stats_level", "ifem_true_residual", "ifem_tpp_ilu_probe", "ifem_tpp_override",
+           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_comm_stats_level", "ifem_true_residual", "ifem_tpp_ilu_probe", "ifem_tpp_override", "ifem_scns_pc_probe",
            "ifem_kprof_begin", "ifem_kprof_end", "ifem_kprof_family_name", "ifem_export_rows", "ifem_export_uu_pattern", "ifem_vcycle_graph_stats", "ifem_inner_restart_length"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
@@ -218,6 +219,7 @@ def load():
     L.ifem_comm_stats_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.ifem_tpp_ilu_probe.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.ifem_tpp_override.argtypes = [C.c_void_p, C.c_void_p]
+    L.ifem_scns_pc_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.ifem_true_residual.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ifem_kprof_begin.argtypes = [C.c_void_p]
     L.ifem_kprof_end.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include "../../include/ifem_hip_testing.h"
 #include "ctx.hpp"
 #include "kernels.hpp"
 
@@ -118,6 +119,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
 void ifem_default_tuning(ifem_tuning *t) {
   t->geo_cache = 1; t->xcd_swizzle = 1; t->asm_skip = 0; t->spmv_lanes = 32; t->sm_lanes = 32; t->mf_f32 = 1;
   t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->cg_single_reduction = 1; t->asm3_cpb = 2; t->tpp_milu_permille = 950; t->tpp_ilu_order = 2; t->basis_pad = 32 * 33; t->tpp_tri_sweeps = 0; t->uu_row_order = 1; t->eig_steps = 0; t->vcycle_graph_cells = 262144;
+  t->scns_pc = 2; t->pvv_sweeps = 3; t->b2pp_sweeps = 5; t->scns_inner_reorth = 0; t->scns_inner_left = 1;
 }
 
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
@@ -127,9 +129,12 @@ int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
   for (int v : g)
     if (v != 8 && v != 16 && v != 32 && v != 64) throw Error(IFEM_E_BADPARAM, "lanes per row must be 8, 16, 32 or 64");
   if (t->basis_pad < 0) throw Error(IFEM_E_BADPARAM, "negative size in ifem_tuning");
-  if (t->asm3_cpb != 2 && t->asm3_cpb != 4 && t->asm3_cpb != 8) throw Error(IFEM_E_BADPARAM, "asm3_cpb must be 2, 4 or 8 (cells per workgroup of the 3D Q2/Q1 cell kernel)");
+  if (t->asm3_cpb > 0 && t->asm3_cpb != 2 && t->asm3_cpb != 4 && t->asm3_cpb != 8) throw Error(IFEM_E_BADPARAM, "asm3_cpb must be 2, 4 or 8 (cells per workgroup of the 3D Q2/Q1 cell kernel)");
   if (t->tpp_ilu_order < -1 || t->tpp_ilu_order > 2) throw Error(IFEM_E_BADPARAM, "tpp_ilu_order must be -1, 0, 1 or 2");
+  if (t->scns_pc != 0 && t->scns_pc != 1 && t->scns_pc != 2) throw Error(IFEM_E_BADPARAM, "scns_pc must be 1 (explicit T_pp) or 2 (the reference's structure); 0 = default");
   ctx->tune = *t;
+  if (ctx->tune.asm3_cpb <= 0) ctx->tune.asm3_cpb = 2; // a zero-initialised struct: the defaults of the fields added after round 4
+  if (ctx->tune.scns_pc == 0) { ctx->tune.scns_pc = 2; if (!ctx->tune.pvv_sweeps) ctx->tune.pvv_sweeps = 3; if (!ctx->tune.b2pp_sweeps) ctx->tune.b2pp_sweeps = 5; ctx->tune.scns_inner_left = 1; }
   IFEM_API_END
 }
 
@@ -834,6 +839,22 @@ int ifem_tpp_ilu_probe(ifem_ctx *ctx, int64_t *rowptr, int32_t *col, double *val
     IFEM_HIP_CHECK(hipStreamSynchronize(s));
     if (levels) *levels = ifem::tpp_ilu_levels(ctx);
   }
+  IFEM_API_END
+}
+
+int ifem_scns_pc_probe(ifem_ctx *ctx, int which, const double *x, double *y) {
+  IFEM_API_BEGIN
+  if (!ctx->assembled || !ctx->has_app) throw Error(IFEM_E_BADPARAM, "ifem_scns_pc_probe after ifem_scns_assemble");
+  if (ctx->halo.nranks > 1) throw Error(IFEM_E_BADPARAM, "ifem_scns_pc_probe: single-rank contexts only");
+  if (!x || !y) throw Error(IFEM_E_BADPARAM, "ifem_scns_pc_probe: null vector");
+  hipStream_t s = ctx->stream;
+  const size_t n = which == 0 ? (size_t)ctx->dim * ctx->nUo : (size_t)ctx->nPo;
+  DBuf<double> dx, dy;
+  dx.upload(x, n, s);
+  dy.alloc(n);
+  ifem::scns_pc_probe(ctx, which, dx.p, dy.p);
+  IFEM_HIP_CHECK(hipMemcpyAsync(y, dy.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  IFEM_HIP_CHECK(hipStreamSynchronize(s));
   IFEM_API_END
 }
 

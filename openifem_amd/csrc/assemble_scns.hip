@@ -477,6 +477,7 @@ void launch_scns_assemble(ifem_ctx *ctx, const ifem_scns_params *p, int use_nonz
   ctx->sm_valid = false; ctx->sm_key = -1;
   ctx->shat_valid = false;
   ctx->tpp_valid = false; ctx->tpp_ilu.factored = false;
+  ctx->b2_valid = false; ctx->pvv_ilu.factored = false; ctx->b2_ilu.factored = false;
   ctx->geo_valid = false; // B / B^T now hold the SUPG-stabilised blocks
   ctx->asm_constraint_set = use_nonzero ? 1 : 0;
   hanging_condense_rhs(ctx, use_nonzero);

@@ -184,6 +184,19 @@ struct TppIlu {
   DBuf<unsigned long long> chk; // [3] device: min |pivot|, max |pivot| (bit patterns), non-finite entries
   int order_kind = 0, order_used = 0; // ifem_tuning::tpp_ilu_order the analysis was made for; the order it chose (0 natural, 1 multicolour)
 };
+// ILU(0) with dim x dim blocks in the natural row order (bilu.hip): the two Euclid factorisations of the SUPG block preconditioner
+struct BIlu {
+  int dim = 1, max_row = 0;
+  int64_t n = 0, nnz = 0;
+  DBuf<int64_t> rp, srcpos;          // the factor's own column-sorted CSR (owned x owned) and where each entry sits in the source values
+  DBuf<int32_t> col, diag, rows_f, rows_b;
+  std::vector<int64_t> lvl_f, lvl_b; // elimination levels (host: launch plan of the factorisation)
+  DBuf<int64_t> d_lvl_f, d_lvl_b;
+  DBuf<double> LU, dinv, t0, t1, t2; // factors (unit-lower L and U without its diagonal blocks), inverse pivot blocks, sweep scratch
+  DBuf<unsigned long long> chk;
+  bool analysed = false, factored = false, broken = false;
+  double pivot_min = 0, pivot_max = 0;
+};
 // hanging-node constraint lines x[dof_i] = sum_k w_k x[master_k] (closed), see hanging.hip
 struct Hanging {
   int32_t n = 0;
@@ -365,6 +378,10 @@ struct ifem_ctx {
   ifem::DBuf<double> Tpp, tpp_diag;
   bool tpp_valid = false;
   ifem::TppIlu tpp_ilu; // level-scheduled ILU(0) of T_pp (tpp.hip)
+  // the reference's structure (ifem_tuning::scns_pc = 2): ILU(0)(A_vv), B2pp = A_pp - A_pv rowsum(|A_vv|)^-1 A_vp and its ILU(0)
+  ifem::BIlu pvv_ilu, b2_ilu;
+  ifem::DBuf<double> B2pp, rsinv;
+  bool b2_valid = false;
   ifem::PlanarCsr TppPat; // several ranks: pattern of the owned x owned block of T_pp (the per-rank ILU(0), tpp.hip)
   // matrix-free A_uu (IFEM_AINV_GMRES_BJACOBI_MF): state of the last ifem_ins_assemble
   ifem::DBuf<double> mf_ycell; // per-cell results of the matrix-free apply [n_cells][nu][dim] (two-stage scatter)

@@ -133,6 +133,15 @@ void spmv_tpp(ifem_ctx *ctx, const double *xp, double *yp);
 bool tpp_ilu_factor(ifem_ctx *ctx); // false: zero / tiny / non-finite pivot (ctx->tpp_ilu.broken): do not apply the factors
 void tpp_ilu_apply(ifem_ctx *ctx, const double *x, double *y);
 int tpp_ilu_levels(const ifem_ctx *ctx);
+void schur_pp_numeric(ifem_ctx *ctx, const double *binv, double *out); // out = A_pp - A_pv blockdiag(binv) A_vp on the pattern of T_pp
+const PlanarCsr &tpp_pattern(ifem_ctx *ctx);                          // that pattern (built on first use)
+// ILU(0) with dim x dim blocks, natural order, Jacobi-sweep application (bilu.hip)
+void bilu_analyse(ifem_ctx *ctx, BIlu &I, int dim, int64_t n, const int64_t *rp_dev, const int32_t *col_dev);
+bool bilu_factor(ifem_ctx *ctx, BIlu &I, const double *src);
+void bilu_apply(ifem_ctx *ctx, BIlu &I, int sweeps, const double *x, double *y);
+void rowsum_abs_inv(ifem_ctx *ctx, double *out);
+void scns_refpc_setup(ifem_ctx *ctx, int verbose, bool *pvv_ok, bool *b2_ok);
+void scns_pc_probe(ifem_ctx *ctx, int which, const double *x, double *y);
 // hanging-node lines (hanging.hip): C x on a copy of x, C^T and the hanging rows on y, distribute, set-up
 void hanging_set(ifem_ctx *ctx, int32_t n, const int32_t *dof, const int32_t *ptr, const int32_t *master, const double *weight);
 const double *hanging_input(ifem_ctx *ctx, const double *x); // ghost-extended [u_l | p_l] copy of x with C applied

@@ -35,8 +35,10 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
                  double *res_out,
                  const std::function<void(int, const double *, int64_t, const double *, double *)> &mdot,
                  std::vector<double> *history = nullptr, // residual norm after every iteration (verbose runs)
-                 const std::function<void(int, double *&, double *&)> *ensure = nullptr) { // bases that grow with the iteration count: called
+                 const std::function<void(int, double *&, double *&)> *ensure = nullptr, // bases that grow with the iteration count: called
                                                                                         // with the V columns the next iteration needs
+                 bool left = false) { // LEFT preconditioning (not flexible): the Krylov space of P^-1 A, the stopping test reads the
+                                      // PRECONDITIONED residual -- deal.II's SolverGMRES with its defaults (mpi_supg_solver.cpp:176-182)
   std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), h(m + 1), h2(m + 1);
   v_zero(ctx, n, x);
   int it = 0;
@@ -46,6 +48,7 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
     const double *r0 = w; // the residual the cycle starts from: b itself in the first cycle (x = 0), b - A x after a restart
     if (first) { r0 = b; first = false; }
     else { A(x, w); v_axpby(ctx, n, 1.0, b, -1.0, w); }
+    if (left) { Pinv(r0, Z); r0 = Z; }
     double bb;
     mdot(1, r0, n, r0, &bb);
     const double beta = std::sqrt(bb);
@@ -60,8 +63,8 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
       if (ensure) (*ensure)(j + 2, V, Z); // columns 0 .. j + 1 of V, 0 .. j of Z
       double *vj = V + (int64_t)j * ld;
       double *zj = flexible ? Z + (int64_t)j * ld : Z;
-      Pinv(vj, zj);
-      A(zj, w);
+      if (left) { A(vj, zj); Pinv(zj, w); }
+      else { Pinv(vj, zj); A(zj, w); }
       // classical Gram-Schmidt (twice with reorth); ||w||^2 comes out of the last multi-axpy pass (summed over the ranks like the
       // dot products of `mdot`): per iteration the host waits for the device once per pass, not three / five times
       double ww = 0;
@@ -97,9 +100,9 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
       for (int k = i + 1; k < j; ++k) t -= H[(size_t)i * m + k] * y[k];
       y[i] = t / H[(size_t)i * m + i];
     }
-    if (flexible) {
+    if (flexible || left) {
       for (int i = 0; i < j; ++i) h[i] = -y[i];
-      v_maxpy(ctx, n, j, Z, ld, h.data(), x); // x += sum y_i z_i
+      v_maxpy(ctx, n, j, left ? V : Z, ld, h.data(), x); // x += sum y_i z_i   (left preconditioning: x += V y)
     } else {
       // x += P^-1 (V y): one preconditioner application instead of storing every z_j
       v_zero(ctx, n, w);
@@ -1260,6 +1263,55 @@ static void throw_noconv(const char *solver, int it, double res, double tol) {
   throw Error(IFEM_E_KRYLOV_NOCONV, msg);
 }
 
+// constructor of BlockIncompSchurPreconditioner (mpi_supg_solver.cpp:35-134) in the reference's structure: ILU(0)(A_vv), B2pp and its
+// ILU(0); cached until the next assembly
+void scns_refpc_setup(ifem_ctx *ctx, int verbose, bool *pvv_ok, bool *b2_ok) {
+  BIlu &Iv = ctx->pvv_ilu, &Ip = ctx->b2_ilu;
+#if !IFEM_UU_INTERLEAVED
+  throw Error(IFEM_E_BADPARAM, "scns_pc = 2 needs the block-interleaved A_uu layout");
+#endif
+  if (!Iv.analysed) bilu_analyse(ctx, Iv, ctx->dim, ctx->nUo, ctx->Auu.rowptr.p, ctx->Auu.col.p);
+  *pvv_ok = Iv.factored ? !Iv.broken : bilu_factor(ctx, Iv, ctx->Auu.val.p);
+  if (!*pvv_ok && verbose) fprintf(stderr, "[ifem] scns solve: ILU(0) of A_vv broke down: node-block Jacobi instead\n");
+  const PlanarCsr &Pt = tpp_pattern(ctx);
+  if (!ctx->b2_valid) {
+    const size_t nb = (size_t)ctx->nUo * ctx->dim * ctx->dim;
+    if (ctx->rsinv.n != nb) ctx->rsinv.alloc(nb);
+    if (ctx->B2pp.n != (size_t)Pt.nnzb) ctx->B2pp.alloc((size_t)Pt.nnzb);
+    rowsum_abs_inv(ctx, ctx->rsinv.p);
+    schur_pp_numeric(ctx, ctx->rsinv.p, ctx->B2pp.p);
+    ctx->b2_valid = true; Ip.factored = false;
+  }
+  if (!Ip.analysed) bilu_analyse(ctx, Ip, 1, Pt.n_rows, Pt.rowptr.p, Pt.col.p);
+  *b2_ok = Ip.factored ? !Ip.broken : bilu_factor(ctx, Ip, ctx->B2pp.p);
+  if (!*b2_ok && verbose) fprintf(stderr, "[ifem] scns solve: ILU(0) of B2pp broke down: Jacobi instead\n");
+}
+
+// test hook (ifem_scns_pc_probe, single rank): the pieces of the preconditioner on device vectors
+void scns_pc_probe(ifem_ctx *ctx, int which, const double *x, double *y) {
+  ifem_solver_opts o;
+  ifem_default_solver_opts(&o);
+  SolveState S{ctx, nullptr, &o};
+  carve_workspace(S);
+  bool pvv_ok = false, b2_ok = false;
+  scns_refpc_setup(ctx, 0, &pvv_ok, &b2_ok);
+  if (!pvv_ok || !b2_ok) throw Error(IFEM_E_KRYLOV_NOCONV, "ILU(0) broke down");
+  switch (which) {
+  case 0: bilu_apply(ctx, ctx->pvv_ilu, ctx->tune.pvv_sweeps, x, y); break;
+  case 1: bilu_apply(ctx, ctx->b2_ilu, ctx->tune.b2pp_sweeps, x, y); break;
+  case 2: spmv_planar_scalar(ctx, tpp_pattern(ctx), ctx->B2pp.p, x, y); break;
+  case 3: {
+    spmv_bt(ctx, x, S.tu);
+    bilu_apply(ctx, ctx->pvv_ilu, ctx->tune.pvv_sweeps, S.tu, S.utmp);
+    spmv_b(ctx, S.utmp, S.tp[4]);
+    spmv_app(ctx, x, y);
+    v_axpy(ctx, S.npo, -1.0, S.tp[4], y);
+    break;
+  }
+  default: throw Error(IFEM_E_BADPARAM, "ifem_scns_pc_probe: which must be 0..3");
+  }
+}
+
 int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_solve_stats *stats) {
   if (!ctx->assembled || !ctx->has_app) throw Error(IFEM_E_BADPARAM, "ifem_scns_solve called before ifem_scns_assemble");
   SolveState S{ctx, nullptr, o};
@@ -1301,7 +1353,30 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
   // Euclid does across ranks, mpi_supg_solver.cpp:49-53,120-133).  ifem_tuning::tpp_operator keeps the operator form with
   // Jacobi, tpp_ilu_order = -1 the explicit matrix with Jacobi.  A factorisation that breaks down (zero / tiny / non-finite
   // pivot) is not applied: Jacobi instead.
-  const bool tpp_explicit = ctx->halo.nranks == 1 && !ctx->tune.tpp_operator;
+  // ifem_tuning::scns_pc = 2 (default): the reference's structure.  P_vv^-1 = ILU(0) of A_vv (mpi_supg_solver.cpp:49-51), T_pp the
+  // operator A_pp - A_pv P_vv^-1 A_vp (:19-32), the inner GMRES(200) preconditioned by the ILU(0) of the assembled
+  // B2pp = A_pp - A_pv rowsum(|A_vv|)^-1 A_vp (:56-133); both factorisations once per Newton iteration, applied by Jacobi sweeps on
+  // the triangular systems (bilu.hip).  A factorisation that breaks down falls back to (node-block) Jacobi.
+  const bool refpc = ctx->tune.scns_pc == 2;
+  bool pvv_ok = false;
+  OpFn Pvv = [&](const double *x, double *y) {
+    if (pvv_ok) bilu_apply(ctx, ctx->pvv_ilu, ctx->tune.pvv_sweeps, x, y);
+    else bjac_apply(ctx, x, y);
+  };
+  if (refpc) {
+    bool b2_ok = false;
+    scns_refpc_setup(ctx, o->verbose, &pvv_ok, &b2_ok);
+    Tpp = [&](const double *x, double *y) { // SchurComplementTpp::vmult
+      const double *xe; extend_p(S, x, &xe);
+      spmv_bt(ctx, xe, S.tu);
+      Pvv(S.tu, S.utmp);
+      b_apply(S.utmp, S.tp[4]);
+      spmv_app(ctx, xe, y);
+      v_axpy(ctx, S.npo, -1.0, S.tp[4], y);
+    };
+    if (b2_ok) Jpp = [&](const double *x, double *y) { bilu_apply(ctx, ctx->b2_ilu, ctx->tune.b2pp_sweeps, x, y); };
+  }
+  const bool tpp_explicit = !refpc && ctx->halo.nranks == 1 && !ctx->tune.tpp_operator;
   auto ilu_or_warn = [&]() {
     const bool ok = tpp_ilu_factor(ctx);
     if (!ok && o->verbose)
@@ -1316,24 +1391,36 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
       Jpp = [&](const double *x, double *y) { tpp_ilu_apply(ctx, x, y); };
     else
       Jpp = [&](const double *x, double *y) { vec_div(ctx, S.npo, ctx->tpp_diag.p, x, y); };
-  } else if (ctx->halo.nranks > 1 && !ctx->tune.tpp_operator && ctx->tune.tpp_ilu_order >= 0) {
+  } else if (!refpc && ctx->halo.nranks > 1 && !ctx->tune.tpp_operator && ctx->tune.tpp_ilu_order >= 0) {
     tpp_numeric(ctx); // the owned x owned block
     if (ilu_or_warn()) Jpp = [&](const double *x, double *y) { tpp_ilu_apply(ctx, x, y); };
   }
   OpFn Pop = [&](const double *src, double *dst) {
     const double *src0 = src, *src1 = src + S.nuo;
     double *dst0 = dst, *dst1 = dst + S.nuo;
-    bjac_apply(ctx, src0, S.inner_w);              // ptmp1 = P_vv^-1 src0
+    Pvv(src0, S.inner_w);                          // ptmp1 = P_vv^-1 src0
     b_apply(S.inner_w, S.tp[0]);                   // A_pv ptmp1
     v_axpby(ctx, S.npo, 1.0, src1, -1.0, S.tp[0]); // ptmp = src1 - A_pv ptmp1
     double pn;
     mdot_p(1, S.tp[0], S.npo, S.tp[0], &pn);
     double res = 0;
     const double inner_tol = 1e-3 * std::sqrt(pn);
-    S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.ctx, S.npo), /*reorth=*/true, Tpp, Jpp, false, S.tp[0], dst1, mt, 100000, inner_tol,
-                              ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p);
+    if (refpc && pn > 0) {
+      // initial guess alpha ptmp with alpha = (ptmp . ptmp) / (T_pp ptmp . ptmp) (:165-171); the Krylov solve runs on the correction
+      // with the same ABSOLUTE tolerance 1e-3 ||ptmp|| (:174-175)
+      Tpp(S.tp[0], S.tp[6]);
+      double sc;
+      mdot_p(1, S.tp[6], S.npo, S.tp[0], &sc);
+      const double alpha = sc != 0 && std::isfinite(sc) ? pn / sc : 0.0;
+      v_axpby(ctx, S.npo, 1.0, S.tp[0], -alpha, S.tp[6]); // r0 = ptmp - alpha T_pp ptmp
+      S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.ctx, S.npo), ctx->tune.scns_inner_reorth != 0, Tpp, Jpp, false, S.tp[6], dst1, mt, 100000,
+                                inner_tol, ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p, nullptr, nullptr, /*left=*/ctx->tune.scns_inner_left != 0);
+      v_axpy(ctx, S.npo, alpha, S.tp[0], dst1);
+    } else
+      S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.ctx, S.npo), /*reorth=*/true, Tpp, Jpp, false, S.tp[0], dst1, mt, 100000, inner_tol,
+                                ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p);
     bt_apply(dst1, S.tu);                          // A_vp dst1
-    bjac_apply(ctx, S.tu, S.utmp);
+    Pvv(S.tu, S.utmp);
     v_copy(ctx, S.nuo, S.inner_w, dst0);
     v_axpy(ctx, S.nuo, -1.0, S.utmp, dst0);        // dst0 = P_vv^-1 src0 - P_vv^-1 A_vp dst1
     S.st.precond_applies++;

@@ -103,6 +103,30 @@ __global__ __launch_bounds__(256) void k_tpp_numeric(int64_t n_rows, int maxlen,
   for (int i = lane; i < len; i += 64) valS[rs + i] = acc[i];
 }
 
+const PlanarCsr &tpp_pattern(ifem_ctx *ctx) {
+  PlanarCsr &Pt = tpp_pat(ctx);
+  if (Pt.n_rows == 0) { if (ctx->halo.nranks > 1) build_schur_pattern_owned(ctx); else build_schur_pattern(ctx); }
+  return Pt;
+}
+
+// out = A_pp - A_pv blockdiag(binv) A_vp on the pattern of T_pp (owned velocity nodes only on several ranks)
+void schur_pp_numeric(ifem_ctx *ctx, const double *binv, double *out) {
+  const PlanarCsr &Pt = tpp_pattern(ctx);
+  const int64_t n = Pt.n_rows;
+  if (n == 0) return;
+  const int maxlen = (Pt.max_row + 1) & ~1;
+  const size_t smem = size_t(4) * maxlen * (sizeof(double) + sizeof(int32_t));
+  const unsigned blocks = unsigned((n + 3) / 4);
+  KScope ks(ctx, IFEM_KC_TPP);
+#define IFEM_TPP(D)                                                                                                     \
+  hipLaunchKernelGGL((k_tpp_numeric<D>), dim3(blocks), dim3(256), smem, ctx->stream, n, maxlen, Pt.rowptr.p,            \
+                     Pt.col.p, out, ctx->B.rowptr.p, ctx->B.col.p, ctx->B.val.p, ctx->Bt.rowptr.p,                      \
+                     ctx->Bt.col.p, ctx->Bt.val.p, binv, ctx->Mp.rowptr.p, ctx->Mp.col.p, ctx->App.p, ctx->nUo)
+  if (ctx->dim == 3) IFEM_TPP(3); else IFEM_TPP(2);
+#undef IFEM_TPP
+  IFEM_HIP_CHECK(hipGetLastError());
+}
+
 void tpp_numeric(ifem_ctx *ctx) {
   if (ctx->tpp_valid) return;
   PlanarCsr &Pt = tpp_pat(ctx);

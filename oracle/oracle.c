@@ -1523,7 +1523,7 @@ void orc_update_stress(const orc_mesh *m, double mu, const double *present, doub
  * (no reference test prints them); the restatement exists so that the iteration counts of the HIP path can be set
  * beside those of the reference's preconditioner STRUCTURE on the same matrix.
  * perm_v / perm_p (NULL = natural order) are measurement hooks: ILU(0) in another elimination order. */
-typedef struct { int n; int64_t *rp; int32_t *col; double *val; int32_t *diag; const int32_t *ord; } ilu_t;
+typedef struct { int n; int64_t *rp; int32_t *col; double *val; int32_t *diag; const int32_t *ord; int sweeps; } ilu_t;
 
 static void ilu_free(ilu_t *f) { free(f->rp); free(f->col); free(f->val); free(f->diag); memset(f, 0, sizeof(*f)); }
 
@@ -1573,9 +1573,41 @@ static int ilu0_factor(ilu_t *f) {
   return rc;
 }
 
+/* measurement hook (not the reference): k > 0 replaces the exact triangular solves of an ILU(0) application by k Jacobi sweeps on
+ * each triangular system (what a level-free device application would do); [0] for P_vv, [1] for B2pp */
+static int g_tri_sweeps[2] = {0, 0};
+void orc_set_tri_sweeps(int32_t kv, int32_t kp) { g_tri_sweeps[0] = kv; g_tri_sweeps[1] = kp; }
+static void ilu0_apply_sweeps(const ilu_t *f, const double *x, double *y, int k) {
+  const int n = f->n; const int32_t *ord = f->ord;
+  double *a = (double *)malloc(sizeof(double) * 2 * (size_t)n), *b = a + n;
+  memcpy(a, x, sizeof(double) * (size_t)n);
+  for (int s_ = 0; s_ < k; ++s_) { /* forward: y <- x - (L - I) y_old */
+    for (int i = 0; i < n; ++i) {
+      double t = x[i]; const int pi = ord ? ord[i] : i;
+      for (int64_t q = f->rp[i]; q < f->rp[i + 1]; ++q) { const int c = f->col[q]; if (c != i && (ord ? ord[c] : c) < pi) t -= f->val[q] * a[c]; }
+      b[i] = t;
+    }
+    double *t_ = a; a = b; b = t_;
+  }
+  double *z = (double *)malloc(sizeof(double) * (size_t)n);
+  memcpy(z, a, sizeof(double) * (size_t)n);
+  for (int i = 0; i < n; ++i) a[i] = z[i] / f->val[f->rp[i] + f->diag[i]];
+  for (int s_ = 0; s_ < k; ++s_) { /* backward: y <- (z - (U - D) y_old) / D */
+    for (int i = 0; i < n; ++i) {
+      double t = z[i]; const int pi = ord ? ord[i] : i;
+      for (int64_t q = f->rp[i]; q < f->rp[i + 1]; ++q) { const int c = f->col[q]; if (c != i && (ord ? ord[c] : c) > pi) t -= f->val[q] * a[c]; }
+      b[i] = t / f->val[f->rp[i] + f->diag[i]];
+    }
+    double *t_ = a; a = b; b = t_;
+  }
+  memcpy(y, a, sizeof(double) * (size_t)n);
+  free(a < b ? a : b); free(z);
+}
+
 /* y = (LU)^-1 x */
 static void ilu0_apply(const ilu_t *f, const double *x, double *y) {
   const int n = f->n; const int32_t *ord = f->ord;
+  if (f->sweeps > 0) { ilu0_apply_sweeps(f, x, y, f->sweeps); return; }
   if (!ord) {
     for (int i = 0; i < n; ++i) {
       double t = x[i]; const int64_t rs = f->rp[i];
@@ -1642,7 +1674,7 @@ static int supg_pc_setup(supg_pc *c, orc_system *s, const int32_t *perm_v, const
   c->s = s;
   const int n_u = s->n_u, n_p = s->n_p;
   /* Pvv_inverse.initialize(system_matrix->block(0, 0)), :49-51 */
-  ilu_t *f = &c->Pvv; f->n = n_u; f->ord = perm_v;
+  ilu_t *f = &c->Pvv; f->n = n_u; f->ord = perm_v; f->sweeps = g_tri_sweeps[0];
   f->rp = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n_u + 1)); f->rp[0] = 0;
   for (int i = 0; i < n_u; ++i) f->rp[i + 1] = f->rp[i] + s->psplit[i];
   f->col = (int32_t *)malloc(sizeof(int32_t) * (size_t)f->rp[n_u]);
@@ -1656,7 +1688,7 @@ static int supg_pc_setup(supg_pc *c, orc_system *s, const int32_t *perm_v, const
   }
   int rc = ilu0_factor(f);
   /* schur = A_pv diag(ReverseRowSum) A_vp on the pattern of the product; B2pp = A_pp - schur, :126-132.  Sparse accumulator per row. */
-  ilu_t *g = &c->B2; g->n = n_p; g->ord = perm_p;
+  ilu_t *g = &c->B2; g->n = n_p; g->ord = perm_p; g->sweeps = g_tri_sweeps[1];
   g->rp = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n_p + 1)); g->rp[0] = 0;
   int32_t *mark = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_p);
   for (int i = 0; i < n_p; ++i) mark[i] = -1;
@@ -1790,4 +1822,32 @@ int32_t orc_scns_solve(orc_system *s, int32_t use_nonzero, int32_t fgmres_restar
   if (res) *res = r;
   supg_pc_free(&c);
   return r <= tol ? 0 : -2;
+}
+
+/* the pieces of the preconditioner on the system of the last orc_scns_assemble (natural-order, exact substitutions):
+ * which 0: y = Pvv^-1 x (n_u); 1: y = B2pp_inverse x (n_p); 2: y = B2pp x (n_p); 3: y = T_pp x (n_p) */
+int32_t orc_scns_pc_probe(orc_system *s, int32_t which, const double *x, double *y) {
+  supg_pc c;
+  const int save[2] = {g_tri_sweeps[0], g_tri_sweeps[1]};
+  g_tri_sweeps[0] = g_tri_sweeps[1] = 0;
+  /* B2pp itself is needed unfactored for which = 2: build twice (the second copy is factored) */
+  int rc = supg_pc_setup(&c, s, NULL, NULL);
+  g_tri_sweeps[0] = save[0]; g_tri_sweeps[1] = save[1];
+  if (rc < 0) { supg_pc_free(&c); return -3; }
+  if (which == 0) ilu0_apply(&c.Pvv, x, y);
+  else if (which == 1) ilu0_apply(&c.B2, x, y);
+  else if (which == 3) supg_tpp(&c, x, y);
+  else { /* B2pp x = L U x with the ILU(0) factors is NOT B2pp (dropped fill): recompute the product directly */
+    const int n_u = s->n_u, n_p = s->n_p;
+    double *rs = (double *)calloc((size_t)n_u, sizeof(double)), *u = (double *)malloc(sizeof(double) * (size_t)n_u);
+    for (int i = 0; i < n_u; ++i) for (int64_t k = s->rowptr[i]; k < s->rowptr[i] + s->psplit[i]; ++k) rs[i] += fabs(s->A[k]);
+    spmv_up(s, x, u);
+    for (int i = 0; i < n_u; ++i) u[i] /= rs[i];
+    spmv_pv(s, u, c.p1);
+    spmv_pp(s, x, y);
+    for (int i = 0; i < n_p; ++i) y[i] -= c.p1[i];
+    free(rs); free(u);
+  }
+  supg_pc_free(&c);
+  return 0;
 }

@@ -165,6 +165,9 @@ void orc_scns_assemble(orc_system *s, const orc_scns_params *p, int32_t use_nonz
  * perm_v / perm_p: elimination order of the two ILU(0) (NULL: natural = Euclid on one rank) -- measurement hooks. */
 int32_t orc_scns_solve(orc_system *s, int32_t use_nonzero, int32_t fgmres_restart, const int32_t *perm_v, const int32_t *perm_p,
                        double *newton_update, int64_t *counts, double *res);
+/* pieces of that preconditioner (exact substitutions): which 0: y = Pvv^-1 x; 1: y = B2pp_inverse x; 2: y = B2pp x; 3: y = T_pp x */
+int32_t orc_scns_pc_probe(orc_system *s, int32_t which, const double *x, double *y);
+void orc_set_tri_sweeps(int32_t kv, int32_t kp); /* measurement hook: Jacobi sweeps instead of substitution in orc_scns_solve */
 int32_t orc_scns_run_one_step(orc_system *s, const orc_scns_params *p, int32_t apply_nonzero, double newton_tol,
                               int32_t newton_maxit, orc_full_solve_fn solve, void *user, double *present,
                               const double *fsi_acc, double *log);

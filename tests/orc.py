@@ -96,6 +96,10 @@ def _bind(L):
     L.orc_scns_assemble.argtypes = [C.c_void_p, C.POINTER(ScnsParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_scns_cell.argtypes = [C.POINTER(_Mesh), C.POINTER(ScnsParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]
+    L.orc_scns_pc_probe.restype = C.c_int32
+    L.orc_scns_pc_probe.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.orc_scns_solve.restype = C.c_int32
+    L.orc_scns_solve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     L.orc_scns_run_one_step.restype = C.c_int32
     L.orc_scns_run_one_step.argtypes = [C.c_void_p, C.POINTER(ScnsParams), C.c_int32, C.c_double, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -299,6 +303,22 @@ class System:
         rc = self.L.orc_scns_run_one_step(self.h, C.byref(params), int(apply_nonzero), newton_tol, newton_maxit,
                                           C.cast(solver.cb, C.c_void_p), None, _ptr(present), _ptr(fsi_acc), _ptr(log))
         return rc, log[:max(rc, 0)]
+
+    def scns_solve(self, use_nonzero, fgmres_restart=30, perm_v=None, perm_p=None):
+        """SUPGFluidSolver::solve with the reference's BlockIncompSchurPreconditioner (ILU(0)(A_vv), operator T_pp, ILU(0)(B2pp)) on
+        the last scns_assemble; returns (rc, update, (FGMRES its, Tpp_itr, preconditioner applications, Pvv applications), residual)"""
+        upd, counts, res = np.zeros(self.n), np.zeros(4, np.int64), C.c_double()
+        pv = None if perm_v is None else np.ascontiguousarray(perm_v, np.int32)
+        pp = None if perm_p is None else np.ascontiguousarray(perm_p, np.int32)
+        rc = self.L.orc_scns_solve(self.h, int(use_nonzero), fgmres_restart, _ptr(pv), _ptr(pp), _ptr(upd), _ptr(counts), C.byref(res))
+        return rc, upd, tuple(int(v) for v in counts), res.value
+
+    def scns_pc_probe(self, which, x):
+        """pieces of the reference-structure SUPG preconditioner: 0 Pvv^-1 x, 1 B2pp_inverse x, 2 B2pp x, 3 T_pp x"""
+        x = np.ascontiguousarray(x, float)
+        y = np.zeros(len(x))
+        assert self.L.orc_scns_pc_probe(self.h, which, _ptr(x), _ptr(y)) == 0
+        return y
 
     def update_stress(self, mu, present):
         out = np.zeros((self.mesh.dim, self.mesh.dim, self.mesh.n_unodes))

@@ -161,6 +161,7 @@ def test_cylinder_scnsim_refined_once_more_converges_without_a_dense_factorisati
         ctx.L.ifem_default_tuning(C.byref(t))
         assert (t.tpp_ilu_order, t.tpp_milu_permille) == (2, 950)
         t.tpp_ilu_order = kind
+        t.scns_pc = 1  # the explicit-T_pp structure of rounds 2-5 (the default since round 6 is the reference's: tests/test_gpu_scns_refpc.py)
         if milu is not None:
             t.tpp_milu_permille = milu
         assert ctx.L.ifem_set_tuning(ctx.h, C.byref(t)) == 0
@@ -182,6 +183,7 @@ def test_box3d_q1q1_32_scnsim_converges_in_under_50_inner_iterations():
     ctx = _ctx(m)
     ctx.set_constraints(0, dofs, None)
     ctx.set_constraints(1, dofs, vals)
+    _tune(ctx, scns_pc=1)
     per, st = _inner_per_application(ctx, capi.make_scns_params(mu=1.8e-4, rho=1.3e-3, dt=1e-2))
     assert per < 50, (per, st.fgmres_iters, st.inner_iters)  # (370 rows per natural-order level: the default takes the multicolour order, 19-25)
     ctx.close()

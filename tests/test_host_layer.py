@@ -15,9 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     import openifem_amd.capi as capi
     L = capi.load()
-    hdr = open(os.path.join(ROOT, "include", "ifem_hip.h")).read()
+    # the drop-in surface and the test aids (include/*.h: every declared symbol must be exported)
+    hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in ("ifem_hip.h", "ifem_hip_testing.h"))
     declared = set(re.findall(r"\b(ifem_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"ifem_ctx"}
+    # ... and the test aids stay out of the public header
+    pub = open(os.path.join(ROOT, "include", "ifem_hip.h")).read()
+    for aid in ("ifem_tpp_override", "ifem_tpp_ilu_probe", "ifem_scns_pc_probe"):
+        assert not re.search(r"\b%s\s*\(" % aid, pub), aid
     assert declared, "no declarations parsed"
     for name in sorted(declared):
         assert hasattr(L, name), f"libifem_hip.so does not export {name}"
