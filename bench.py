@@ -148,10 +148,10 @@ def compact_line(out, detail_path=None):
     wl = str(cfg.get("workload", ""))
     line["config"] = dict({"workload": wl if len(wl) <= 200 else wl[:197] + "..."},
                           **_pick(cfg, ("n_dofs", "cells_per_gpu", "parallelism", "assemble_ms", "solve_ms", "assemble_kernel_ms", "fgmres_iters",
-                                        "inner_iters", "cg_mp_iters", "cg_sm_iters", "true_rel_residual", "fgmres_rel_tol", "solver_opts",
+                                        "inner_iters", "cg_mp_iters", "cg_sm_iters", "t_cg_mp_ms", "t_cg_sm_ms", "t_ainv_ms", "true_rel_residual", "fgmres_rel_tol", "solver_opts",
                                         "rccl_nranks", "comm_transport", "halo_exchanges_per_step", "allreduce_stream_per_step",
                                         "allreduce_host_per_step", "hbm_used_gb")))
-    for k in ("value_cold", "value_sustained"):
+    for k in ("value_cold", "value_sustained", "value_matrix_free"):
         if k in out:
             line[k] = out[k]
     ts = out.get("time_step", {})
@@ -363,15 +363,17 @@ def bench_insimex(args, host):
     from openifem_amd import multigpu
     solver, _, _ = multigpu.make_channel_solver(n, 0, 1, int(os.environ.get("LOCAL_RANK", "0")), None, multigrid=bool(args.mg), kind="InsIMEX")
     n_cells, n_u, n_p = solver.sizes()
-    args.ainv = 4 if args.ainv is None else args.ainv
-    args.inner_rel = 1e-2 if args.inner_rel is None else args.inner_rel
-    solver.opts.ainv_kind = args.ainv
-    solver.opts.inner_rel = args.inner_rel  # the host class defaults to the reference's 1e-4 (CG for A); 1e-2 is the measured optimum
-    # A~^-1 = exactly one V-cycle (inner_maxit = 0) is the measured optimum for this symmetric operator at 1e-8 ||rhs||:
-    # 16 outer iterations x 58 ms against 13 x 80 ms with two inner GMRES steps (profiles/r02_insimex_sweep.txt)
-    solver.opts.inner_maxit = 0 if args.inner_maxit is None else args.inner_maxit
+    # product defaults: what InsIMEX::initialize_system leaves in solver_opts (host/insim.cpp: one V-cycle as A~^-1, the outer
+    # velocity block matrix-free); the flags are experiment overrides
+    if args.ainv is not None:
+        solver.opts.ainv_kind = args.ainv
+    if args.inner_rel is not None:
+        solver.opts.inner_rel = args.inner_rel
+    if args.inner_maxit is not None:
+        solver.opts.inner_maxit = args.inner_maxit
     if args.inner_restart:
         solver.opts.inner_restart = args.inner_restart
+    args.ainv, args.inner_rel = solver.opts.ainv_kind, solver.opts.inner_rel
     if args.mg_smooth_u is not None:
         solver.opts.mg_smooth_u = args.mg_smooth_u
     solver.opts.verbose = args.verbose
@@ -381,20 +383,35 @@ def bench_insimex(args, host):
     assert solver.L.ifem_vec_copy(solver.ctx, capi.VEC_PRESENT, capi.VEC_EVAL) == 0
     solver.run_one_step(True, True)
     solver.run_one_step(False, True)
+    if args.outer_mf is not None:
+        solver.opts.outer_matrix_free = args.outer_mf
+    if args.sm_rel is not None:
+        solver.opts.sm_rel = args.sm_rel
+    if args.mp_rel is not None:
+        solver.opts.mp_rel = args.mp_rel
+    solver.synchronize()
     t0 = time.time()
-    its = 0
     for _ in range(args.steps):
         solver.run_one_step(False, False)
+    solver.synchronize()
     dt = (time.time() - t0) / args.steps
     st = solver.last_stats()
-    print(json.dumps({"metric": "DoF/s per InsIMEX time step (rhs assembly + solve), 3D Q2/Q1", "value": (n_u + n_p) / dt,
-                      "unit": "DoF/s", "n_gpus": 1, "steps": args.steps, "warmup": 2, "ms_per_step": dt * 1e3,
-                      "higher_is_better": True, "dtype": "f64", "data": "synthetic",
-                      "config": {"workload": f"3D channel flow {n}^3 Q2/Q1, mpi_insimex steady-state time step", "n_dofs": n_u + n_p,
-                                 "ainv_kind": args.ainv, "inner_rel": args.inner_rel, "inner_maxit": solver.opts.inner_maxit, "mg_smooth_u": solver.opts.mg_smooth_u,
-                                 "multigrid_levels": 1 + len(solver.mg_levels()),
-                                 "fgmres_iters": st.fgmres_iters, "cg_mp_iters": st.cg_mp_iters, "cg_sm_iters": st.cg_sm_iters,
-                                 "inner_iters": st.inner_iters}}), flush=True)
+    # one more step under the per-kernel-family event log: where the time step goes
+    solver.kprof_begin()
+    solver.run_one_step(False, False)
+    prof = solver.kprof_end()
+    fam = {k: v["ms"] for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0.05}
+    emit({"metric": "DoF/s per InsIMEX time step (rhs assembly + solve), 3D Q2/Q1", "value": (n_u + n_p) / dt,
+          "unit": "DoF/s", "n_gpus": 1, "steps": args.steps, "warmup": 2, "ms_per_step": dt * 1e3,
+          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+          "config": {"workload": f"3D channel flow {n}^3 Q2/Q1, mpi_insimex steady-state time step", "n_dofs": n_u + n_p,
+                     "ainv_kind": args.ainv, "inner_rel": args.inner_rel, "inner_maxit": solver.opts.inner_maxit, "mg_smooth_u": solver.opts.mg_smooth_u,
+                     "outer_matrix_free": solver.opts.outer_matrix_free, "cg_mp_rel": solver.opts.mp_rel, "cg_sm_rel": solver.opts.sm_rel,
+                     "multigrid_levels": 1 + len(solver.mg_levels()),
+                     "fgmres_iters": st.fgmres_iters, "cg_mp_iters": st.cg_mp_iters, "cg_sm_iters": st.cg_sm_iters,
+                     "inner_iters": st.inner_iters, "t_cg_mp_ms": st.t_cg_mp_ms, "t_cg_sm_ms": st.t_cg_sm_ms, "t_ainv_ms": st.t_ainv_ms,
+                     "t_solve_ms": st.t_total_ms},
+          "roofline": {"kernel_ms_per_step": fam, "kernel_ms_sum": sum(v["ms"] for v in prof.values())}})
 
 
 def extras(solver, capi, n_dofs, warm_ms):
@@ -441,6 +458,23 @@ def extras(solver, capi, n_dofs, warm_ms):
     one_step("new_constraint_set_step", "what a change of the constrained-dof set costs here (every FSI step): B / B^T as masked "
                                         "copies of the unconstrained blocks (integrated once per mesh), S_m re-formed on every level")
     set_geo_cache(1)
+    # matrix_free_step (never `value`): the same Newton iteration with ifem_tuning::stored_uu = 0 -- no A_uu values are
+    # written or read: the cell kernel integrates the right-hand side, the outer operator applies A_uu matrix-free in fp64
+    try:
+        tun.stored_uu = 0
+        for c_ in solver.all_ctxs():
+            assert L.ifem_set_tuning(c_, C.byref(tun)) == 0
+        one_step("matrix_free_step", "ifem_tuning::stored_uu = 0: A_uu never stored (rhs-only cell kernel, fp64 matrix-free outer operator, node blocks of "
+                                     "the smoother from the cell integrals); same stopping rule, residual below recomputed with the matrix-free operator "
+                                     "(equal to the block CSR to 1e-13: tests/test_gpu_multigrid.py)")
+        res, bn = solver.true_residual()
+        out["matrix_free_step"]["true_rel_residual"] = res / bn if bn > 0 else None
+    except Exception as e:  # a side measurement
+        out["matrix_free_step"] = {"error": repr(e)}
+    tun.stored_uu = 1
+    for c_ in solver.all_ctxs():
+        assert L.ifem_set_tuning(c_, C.byref(tun)) == 0
+    solver.assemble(False)  # the block CSR again for the legs below
     solver.channel_state()
     # present := perturbed state, so that the Newton loop has something to converge from
     assert L.ifem_vec_copy(ctx, capi.VEC_PRESENT, capi.VEC_EVAL) == 0
@@ -546,7 +580,7 @@ def main():
     ap.add_argument("--fgmres-rel", type=float, default=None, help="test aid: relative tolerance of the outer FGMRES (reference and default: 1e-4)")
     ap.add_argument("--dump-update", default=None, help="test aid: every rank writes its owned entries of the last Newton update and their global lattice ids to <path>.rank<r>.npz")
     ap.add_argument("--verbosity", dest="verbose", type=int, default=0)
-    ap.add_argument("--outer-mf", type=int, default=0, help="experiment: apply the u-u block of the OUTER operator matrix-free too")
+    ap.add_argument("--outer-mf", type=int, default=None, help="experiment: apply the u-u block of the OUTER operator matrix-free too")
     ap.add_argument("--workload", default="channel3d", choices=["channel3d", "cylinder2d", "cylinder2d_scnsim", "cylinder3d"],
                     help="channel3d (default): the BASELINE metric's 3D channel; cylinder2d / cylinder2d_scnsim: BASELINE configs 2 and 4, the "
                          "reference's cylinder drivers on the host mirror with the reference .prm; cylinder3d: the extruded cylinder of "
@@ -613,7 +647,7 @@ def main():
     # V-cycle inner solver, restart 16, inner_rel 1e-2, inner_rel_first 5e-5 when multigrid levels attach) -- the flags below are
     # experiment overrides and the line names every one that was used (config.solver_opts_overridden)
     overridden = [k for k in ("inner_rel", "inner_rel_first", "inner_restart", "ainv", "sm_rel", "mp_rel", "fgmres_rel", "inner_maxit",
-                              "mg_smooth_u", "mg_post_u", "mg_ratio_u") if getattr(args, k) is not None] + (["outer_mf"] if args.outer_mf else []) + (["tune"] if args.tune else []) + ([] if args.mg else ["mg=0"])
+                              "mg_smooth_u", "mg_post_u", "mg_ratio_u") if getattr(args, k) is not None] + (["outer_mf"] if args.outer_mf is not None else []) + (["tune"] if args.tune else []) + ([] if args.mg else ["mg=0"])
     if args.inner_rel is not None:
         solver.opts.inner_rel = args.inner_rel
     if args.inner_rel_first is not None:
@@ -636,7 +670,8 @@ def main():
         solver.opts.mg_smooth_u_post = args.mg_post_u
     if args.mg_ratio_u is not None:
         solver.opts.mg_cheb_ratio_u = args.mg_ratio_u
-    solver.opts.outer_matrix_free = args.outer_mf
+    if args.outer_mf is not None:
+        solver.opts.outer_matrix_free = args.outer_mf
     solver.opts.verbose = args.verbose if rank == 0 else 0
     if args.tune:
         tun = capi.Tuning()
@@ -779,7 +814,7 @@ def main():
                        "halo_exchanges_per_step": comm["halo_exchanges"] / args.steps, "allreduce_stream_per_step": comm["allreduce_dev"] / args.steps,
                        "allreduce_host_per_step": comm["allreduce_host"] / args.steps, "allreduce_vector_per_step": comm["allreduce_vec"] / args.steps,
                        "fgmres_iters": last.fgmres_iters, "cg_mp_iters": last.cg_mp_iters,
-                       "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": solver.opts.inner_rel, "inner_rel_first": solver.opts.inner_rel_first, "ainv_kind": solver.opts.ainv_kind, "outer_matrix_free": args.outer_mf,
+                       "cg_sm_iters": last.cg_sm_iters, "inner_iters": last.inner_iters, "inner_rel": solver.opts.inner_rel, "inner_rel_first": solver.opts.inner_rel_first, "ainv_kind": solver.opts.ainv_kind, "outer_matrix_free": solver.opts.outer_matrix_free,
                        "solver_opts": {"ainv_kind": solver.opts.ainv_kind, "inner_restart": solver.opts.inner_restart, "inner_rel": solver.opts.inner_rel,
                                        "inner_rel_first": solver.opts.inner_rel_first, "source": "InsIM::initialize_system defaults" if not overridden else "overridden: " + ",".join(overridden)},
                        "solver_opts_overridden": overridden,
@@ -794,7 +829,7 @@ def main():
         # Side measurement, never `value`: the same Newton step with the accuracy knobs of the PRECONDITIONER relaxed
         # (pressure CG solves to 1e-2 / 1e-1 instead of the reference's 1e-6 / 1e-3) and the u-u block of the outer operator
         # applied matrix-free.  The outer FGMRES still stops at the reference's 1e-4 ||rhs|| on the same operator.
-        if world == 1 and args.tuned and args.sm_rel is None and args.mp_rel is None and not args.outer_mf:
+        if world == 1 and args.tuned and args.sm_rel is None and args.mp_rel is None and not solver.opts.outer_matrix_free:
             keep = (solver.opts.mp_rel, solver.opts.sm_rel, solver.opts.outer_matrix_free)
             solver.opts.mp_rel, solver.opts.sm_rel, solver.opts.outer_matrix_free = 1e-2, 1e-1, 1
             step()
@@ -818,6 +853,8 @@ def main():
                 out["value_cold"] = out["cold_step"]["value"]
             if "dofs_per_s_per_iteration" in out.get("time_step", {}):
                 out["value_sustained"] = out["time_step"]["dofs_per_s_per_iteration"]
+            if "value" in out.get("matrix_free_step", {}):
+                out["value_matrix_free"] = out["matrix_free_step"]["value"]
         if world == 1 and args.fsi:
             # side measurement, last device leg: its Dirichlet-mode call edits the constraint sets of the context
             try:

@@ -197,13 +197,25 @@ typedef struct {
                             P_vv^-1 = ILU(0) of A_vv (node blocks, natural order; the owned x owned block per rank), T_pp applied as the
                             OPERATOR A_pp - A_pv P_vv^-1 A_vp, inner GMRES(200) preconditioned by the ILU(0) of the assembled
                             B2pp = A_pp - A_pv rowsum(|A_vv|)^-1 A_vp.  1: rounds 2-5: node-block Jacobi P_vv^-1, T_pp explicit (tpp_*) */
-  int32_t pvv_sweeps;    /* 3: Jacobi sweeps per triangular system when ILU(0)(A_vv) is applied (bilu.hip); < 0: exact substitution */
-  int32_t b2pp_sweeps;   /* 5: the same for ILU(0)(B2pp) */
+  int32_t pvv_sweeps;    /* 4: Jacobi sweeps per triangular system when ILU(0)(A_vv) is applied (bilu.hip); < 0: exact substitution */
+  int32_t b2pp_sweeps;   /* 6: the same for ILU(0)(B2pp) (measured on the cylinder at 3 / 4 refinements: 3/5 -> 85 / 455 ms per solve,
+                            4/6 -> 79 / 437, 5/8 -> 83 / 417; exact substitution: 1.4 / 10.7 s) */
   int32_t scns_inner_reorth; /* 0 (default): the inner GMRES(200) on T_pp orthogonalises once per iteration (classical Gram-Schmidt, one
                             fused pass: it is a preconditioner solved to 1e-3); 1: twice, as the outer FGMRES */
   int32_t scns_inner_left; /* 1 (default): that GMRES is LEFT-preconditioned and stops on the preconditioned residual, as deal.II's SolverGMRES
                             does with its defaults (mpi_supg_solver.cpp:174-182); 0: right-preconditioned, true residual */
+  int32_t scns_graph;    /* 1 (default): single rank: the ~20 short launches of one inner iteration's B2pp_inverse (T_pp v) are replayed as a
+                            captured hipGraph (their cost is the host's launch rate); 0: launched eagerly */
+  int32_t stored_uu;     /* 1 (default): ifem_ins_assemble scatters the velocity-velocity block into the block CSR, as the reference does
+                            (mpi_insim.cpp:343-361).  0: A_uu is never stored: the assembly integrates the right-hand side (B, B^T, M_p, diag(M_u)
+                            through the cached geometry path), the outer operator applies A_uu matrix-free in fp64 (equal to the stored block to
+                            1e-13) and the smoothers take their node blocks from the cell integrals.  Needs the matrix-free inner solvers
+                            (IFEM_AINV_MG / _BJACOBI_MF), geo_cache >= 1, no hanging nodes, and assemblies whose constraint values are all zero
+                            (an inhomogeneous first Newton iteration is assembled with stored_uu = 1).  78 GB less memory and ~2 x the step
+                            rate at 128^3; the block CSR stays the default because the north star prescribes it. */
 } ifem_tuning;
+/* Initialise an ifem_tuning with ifem_default_tuning before changing fields: a zero-initialised struct gets the documented defaults
+ * only for the fields where 0 is not a meaningful value (asm3_cpb, scns_pc, pvv_sweeps, b2pp_sweeps). */
 void ifem_default_tuning(ifem_tuning *t);
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t);
 

@@ -99,7 +99,7 @@ class Tuning(C.Structure):
     _fields_ = [("geo_cache", C.c_int32), ("xcd_swizzle", C.c_int32), ("asm_skip", C.c_int32), ("spmv_lanes", C.c_int32),
                 ("sm_lanes", C.c_int32), ("mf_f32", C.c_int32), ("tpp_operator", C.c_int32), ("spmv_pipe", C.c_int32), ("halo_overlap", C.c_int32),
                 ("asm3_variant", C.c_int32), ("cg_single_reduction", C.c_int32), ("asm3_cpb", C.c_int32), ("tpp_milu_permille", C.c_int32), ("tpp_ilu_order", C.c_int64), ("basis_pad", C.c_int64), ("tpp_tri_sweeps", C.c_int32), ("uu_row_order", C.c_int32), ("eig_steps", C.c_int32), ("vcycle_graph_cells", C.c_int32),
-                ("scns_pc", C.c_int32), ("pvv_sweeps", C.c_int32), ("b2pp_sweeps", C.c_int32), ("scns_inner_reorth", C.c_int32), ("scns_inner_left", C.c_int32)]
+                ("scns_pc", C.c_int32), ("pvv_sweeps", C.c_int32), ("b2pp_sweeps", C.c_int32), ("scns_inner_reorth", C.c_int32), ("scns_inner_left", C.c_int32), ("scns_graph", C.c_int32), ("stored_uu", C.c_int32)]
 
 
 class Timing(C.Structure):

@@ -119,7 +119,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
 void ifem_default_tuning(ifem_tuning *t) {
   t->geo_cache = 1; t->xcd_swizzle = 1; t->asm_skip = 0; t->spmv_lanes = 32; t->sm_lanes = 32; t->mf_f32 = 1;
   t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->cg_single_reduction = 1; t->asm3_cpb = 2; t->tpp_milu_permille = 950; t->tpp_ilu_order = 2; t->basis_pad = 32 * 33; t->tpp_tri_sweeps = 0; t->uu_row_order = 1; t->eig_steps = 0; t->vcycle_graph_cells = 262144;
-  t->scns_pc = 2; t->pvv_sweeps = 3; t->b2pp_sweeps = 5; t->scns_inner_reorth = 0; t->scns_inner_left = 1;
+  t->scns_pc = 2; t->pvv_sweeps = 4; t->b2pp_sweeps = 6; t->scns_inner_reorth = 0; t->scns_inner_left = 1; t->scns_graph = 1; t->stored_uu = 1;
 }
 
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
@@ -133,8 +133,9 @@ int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
   if (t->tpp_ilu_order < -1 || t->tpp_ilu_order > 2) throw Error(IFEM_E_BADPARAM, "tpp_ilu_order must be -1, 0, 1 or 2");
   if (t->scns_pc != 0 && t->scns_pc != 1 && t->scns_pc != 2) throw Error(IFEM_E_BADPARAM, "scns_pc must be 1 (explicit T_pp) or 2 (the reference's structure); 0 = default");
   ctx->tune = *t;
+  ++ctx->graph_epoch;
   if (ctx->tune.asm3_cpb <= 0) ctx->tune.asm3_cpb = 2; // a zero-initialised struct: the defaults of the fields added after round 4
-  if (ctx->tune.scns_pc == 0) { ctx->tune.scns_pc = 2; if (!ctx->tune.pvv_sweeps) ctx->tune.pvv_sweeps = 3; if (!ctx->tune.b2pp_sweeps) ctx->tune.b2pp_sweeps = 5; ctx->tune.scns_inner_left = 1; }
+  if (ctx->tune.scns_pc == 0) { ctx->tune.scns_pc = 2; if (!ctx->tune.pvv_sweeps) ctx->tune.pvv_sweeps = 4; if (!ctx->tune.b2pp_sweeps) ctx->tune.b2pp_sweeps = 6; ctx->tune.scns_inner_left = 1; ctx->tune.scns_graph = 1; ctx->tune.stored_uu = 1; }
   IFEM_API_END
 }
 
@@ -230,6 +231,7 @@ void ifem_ctx_destroy(ifem_ctx *ctx) {
   for (hipEvent_t e : ctx->pc_ev) (void)hipEventDestroy(e);
   ctx->vc_graph.destroy();
   ctx->sm_graph.destroy();
+  ctx->pa_graph.destroy();
   hipStream_t s = ctx->owns_stream ? ctx->stream : nullptr;
   delete ctx;
   if (s) (void)hipStreamDestroy(s);
@@ -300,6 +302,12 @@ int ifem_set_constraints(ifem_ctx *ctx, int which, int32_t n, const int32_t *dof
   ctx->is_c[which].swap(nf);
   ctx->cval[which].swap(nv);
   ctx->has_c[which] = !kd.empty();
+  {
+    double any = 0; // (collective on partitioned contexts: a rank without inhomogeneous lines must agree with one that has them)
+    for (double v : kv) if (v != 0.0) { any = 1; break; }
+    allreduce_max(ctx, &any, 1);
+    ctx->inhom_any[which] = any != 0.0;
+  }
   constraint_set_identity(ctx, which, differs[0] != 0.0, differs[1] != 0.0);
   IFEM_API_END
 }
@@ -396,6 +404,11 @@ int ifem_mg_attach(ifem_ctx *fine, ifem_ctx *coarse, const ifem_mg_transfer *t) 
   fine->mg_Rp.col.upload(t->rp_col, (size_t)nnz, s);
   fine->mg_Rp.w.upload(t->rp_w, (size_t)nnz, s);
   fine->mg_Pu.n_rows = fine->mg_Ru.n_rows = 0;
+  // the packed transfer entries (columns, weights and drop bits baked in) and the captured cycles belong to the tables that are replaced
+  fine->mg_mask_key[0] = fine->mg_mask_key[1] = -1;
+  ++fine->graph_epoch; ++coarse->graph_epoch;
+  fine->vc_graph.destroy(); fine->sm_graph.destroy();
+  fine->vc_graph.armed = fine->sm_graph.armed = false; fine->vc_graph.key.clear(); fine->sm_graph.key.clear();
   if (t->pu_ptr) { // velocity-node transfers: optional
     if (!t->pu_col || !t->pu_w || !t->ru_ptr || !t->ru_col || !t->ru_w || !t->inj_u) throw Error(IFEM_E_BADPARAM, "ifem_mg_attach: incomplete velocity transfer tables");
     if (t->n_fine_u_owned != fine->nUo || t->n_coarse_u_local != coarse->nUl)
@@ -1049,8 +1062,8 @@ int ifem_inner_restart_length(ifem_ctx *ctx) { return ctx ? ctx->inner_restart_e
 
 int ifem_vcycle_graph_stats(ifem_ctx *ctx, uint64_t *captures, uint64_t *launches) {
   IFEM_API_BEGIN
-  if (captures) *captures = ctx->vc_graph.captures + ctx->sm_graph.captures;
-  if (launches) *launches = ctx->vc_graph.launches + ctx->sm_graph.launches;
+  if (captures) *captures = ctx->vc_graph.captures + ctx->sm_graph.captures + ctx->pa_graph.captures;
+  if (launches) *launches = ctx->vc_graph.launches + ctx->sm_graph.launches + ctx->pa_graph.launches;
   IFEM_API_END
 }
 
@@ -1094,7 +1107,7 @@ const char *ifem_kprof_family_name(int32_t family) {
 }
 
 int ifem_set_ainv_kind(ifem_ctx *ctx, int kind) { ctx->want_shat = kind == IFEM_AINV_SCALAR_GMRES; return IFEM_OK; }
-int ifem_set_profiling(ifem_ctx *ctx, int on) { ctx->profile = on != 0; return IFEM_OK; }
+int ifem_set_profiling(ifem_ctx *ctx, int on) { ctx->profile = on != 0; ++ctx->graph_epoch; return IFEM_OK; }
 int ifem_synchronize(ifem_ctx *ctx) {
   IFEM_API_BEGIN
   IFEM_HIP_CHECK(hipSetDevice(ctx->device));

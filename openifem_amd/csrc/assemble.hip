@@ -99,8 +99,19 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
     }
     if (ctx->geo_valid) ctx->geo_set_changes++;
     ctx->geo_unchanged = 0;
-  } else if (assemble_system == 1)
+  } else if (assemble_system == 1 && ctx->tune.stored_uu != 0)
     ensure_auu_values(ctx);
+  // ifem_tuning::stored_uu = 0: the velocity-velocity block is never stored.  The cell kernel integrates the right-hand side (and,
+  // through the geometry path, B / B^T / M_p / diag(M_u)); A_uu is applied matrix-free in fp64 by the outer operator (the same
+  // operator to 1e-13, test_matrix_free_uu_apply_equals_assembled_block) and its node-block diagonal comes from the cell integrals.
+  const bool mf_only = assemble_system == 1 && ctx->tune.stored_uu == 0;
+  if (mf_only) {
+    if (ctx->kv != 2 && !(ctx->dim == 3 || ctx->dim == 2)) throw Error(IFEM_E_BADPARAM, "stored_uu = 0: unsupported element");
+    if (use_nonzero && ctx->inhom_any[1])
+      throw Error(IFEM_E_BADPARAM, "stored_uu = 0: an assembly with inhomogeneous constraint values needs the element matrix columns "
+                                   "(distribute_local_to_global moves K g into the right-hand side): assemble that Newton iteration with stored_uu = 1");
+    if (ctx->hang.active) throw Error(IFEM_E_BADPARAM, "stored_uu = 0 with hanging-node constraints is not supported");
+  }
   if (!assemble_system && !ctx->assembled) throw Error(IFEM_E_BADPARAM, "rhs-only assembly before any matrix assembly");
   if (assemble_system == 1) { // state the matrix-free A_uu needs to reproduce this matrix (apply_mf.hip)
     const size_t nu = size_t(dim) * size_t(ctx->nUl);
@@ -151,11 +162,11 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   }
   // system_matrix = 0; mass_matrix = 0; system_rhs = 0  (:163-165)
   {
-  KScope ks_fill(ctx, IFEM_KC_ZERO_FILL, 8.0 * ((assemble_system && !geo_only ? double(ctx->Auu.val.n) : 0.0) + double(ctx->vec[IFEM_VEC_RHS].n) +
+  KScope ks_fill(ctx, IFEM_KC_ZERO_FILL, 8.0 * ((assemble_system && !geo_only && !mf_only ? double(ctx->Auu.val.n) : 0.0) + double(ctx->vec[IFEM_VEC_RHS].n) +
                                                 (assemble_system && !skip_geo ? double(ctx->Bt.val.n + ctx->B.val.n + ctx->Mp.val.n + ctx->diagMu.n) : 0.0)));
   if (assemble_system) {
     // (a hand-written fill kernel with 16-byte non-temporal stores measures the same 15 ms for the 78 GB at 128^3)
-    if (!geo_only) IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
+    if (!geo_only && !mf_only) IFEM_HIP_CHECK(hipMemsetAsync(ctx->Auu.val.p, 0, ctx->Auu.val.n * sizeof(double), s));
     if (!skip_geo) {
       IFEM_HIP_CHECK(hipMemsetAsync(ctx->Bt.val.p, 0, ctx->Bt.val.n * sizeof(double), s));
       IFEM_HIP_CHECK(hipMemsetAsync(ctx->B.val.p, 0, ctx->B.val.n * sizeof(double), s));
@@ -190,7 +201,8 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
   A.debug_skip = ctx->tune.asm_skip;
   A.xcd_swizzle = ctx->tune.xcd_swizzle;
   A.eval = ctx->vec[imex ? IFEM_VEC_PRESENT : IFEM_VEC_EVAL].p; A.present = ctx->vec[IFEM_VEC_PRESENT].p;
-  A.imex = imex; A.rhs_only = assemble_system ? 0 : 1;
+  A.imex = imex; A.rhs_only = assemble_system && !mf_only ? 0 : 1;
+  if (mf_only && !skip_geo) throw Error(IFEM_E_BADPARAM, "stored_uu = 0 needs ifem_tuning::geo_cache >= 1 (the geometry blocks come from their own launch)");
   A.fsi_acc = ctx->indicator.p ? ctx->vec[IFEM_VEC_FSI_ACC].p : nullptr;
   A.mu = p->viscosity; A.rho = p->rho; A.gamma = p->grad_div; A.inv_dt = 1.0 / p->dt;
   for (int i = 0; i < 3; ++i) A.g[i] = p->gravity[i];
@@ -244,7 +256,8 @@ static void ifem_ctx_unconstrained_geometry(ifem_ctx *ctx, const ifem_ins_params
 
 static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero) {
   dinv_setup(ctx);
-  bjac_setup(ctx);
+  if (ctx->tune.stored_uu == 0) { ctx->asm_constraint_set = use_nonzero ? 1 : 0; uu_block_diag_mf(ctx); }
+  else bjac_setup(ctx);
   IFEM_HIP_CHECK(hipEventSynchronize(ctx->ev1));
   float ms = 0;
   IFEM_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));

@@ -362,6 +362,8 @@ struct ifem_ctx {
   ifem::MgCsr mg_Pp, mg_Rp, mg_Pu, mg_Ru;
   ifem::DBuf<int32_t> mg_inj_u; // [nUo of the coarse level] coincident owned velocity node of this level
   ifem::DBuf<uint8_t> mg_Pu_mask, mg_Ru_mask; // per weight 8 bytes: {column | components dropped by the Dirichlet flags of the two levels << 29, weight as float} (mg.hip::mg_csr_mask)
+  bool inhom_any[2] = {false, false};         // constraint object `which` carries a non-zero inhomogeneity somewhere (any rank)
+  uint64_t graph_epoch = 0;                   // bumped by ifem_set_tuning / ifem_set_profiling / ifem_mg_attach: part of every hipGraph replay key
   int64_t mg_mask_key[2] = {-1, -1};          // constrained-dof sets (flag ids of this level and the coarser one) of the masks
   ifem::DBuf<double> sm_dinv, mg_vec[6], mgu_vec[5];
   ifem::DBuf<float> mguf_vec[5]; // single-precision level vectors of the A_uu V-cycle (solver.hip)
@@ -440,7 +442,7 @@ struct ifem_ctx {
       if (graph) (void)hipGraphDestroy(graph);
       exec = nullptr; graph = nullptr;
     }
-  } vc_graph, sm_graph; // (sm_graph: the same for the V-cycle on S_m inside CG(S_m))
+  } vc_graph, sm_graph, pa_graph; // (pa_graph: the inner iteration's B2pp_inverse T_pp of the SCnsIM preconditioner)  // (sm_graph: the same for the V-cycle on S_m inside CG(S_m))
   // section marks of the preconditioner applications of one solve (start, after CG(M_p), after CG(S_m) + B^T, end): recorded on the
   // stream, read once when the solve has finished (ifem_solve_stats::t_cg_mp_ms / t_cg_sm_ms / t_ainv_ms) -- no host wait per section
   int inner_restart_eff = 0; // restart length of the inner GMRES of IFEM_AINV_MG once an application stagnated across restarts (solver.hip)

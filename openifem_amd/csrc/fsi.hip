@@ -924,6 +924,7 @@ void fsi_find_fluid_bc(ifem_ctx *ctx, double dt, int use_dirichlet_bc, const int
     A.is_c1 = ctx->is_c[1].p;
     A.cval0 = ctx->cval[0].p;
     A.cval1 = ctx->cval[1].p;
+    ctx->inhom_any[1] = true; // the merged lines carry v_solid - present: inhomogeneous in general
     launch_node_bc(ctx, A);
     if (ctx->halo.nranks > 1) {
       // a ghost dof carries its owner's line: the owner saw every cell that touches the node (a ghost may be the master of a

@@ -102,6 +102,7 @@ void v_axpby(ifem_ctx *ctx, int64_t n, double a, const double *x, double b, doub
 void v_scale(ifem_ctx *ctx, int64_t n, double a, double *x);
 void v_copy(ifem_ctx *ctx, int64_t n, const double *x, double *y);
 void v_scale_to(ifem_ctx *ctx, int64_t n, double a, const double *x, double *y); // y = a x
+void v_scale_to2(ifem_ctx *ctx, int64_t n, double a, const double *x, double *y, double *z); // y = z = a x
 void v_zero(ifem_ctx *ctx, int64_t n, double *x);
 double v_dot(ifem_ctx *ctx, int64_t n, const double *x, const double *y); // local (no all-reduce), syncs
 // multi-dot: out[i] = <V_i, w> for i < k (V column-major with leading dimension ld), one pass, syncs

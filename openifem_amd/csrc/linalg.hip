@@ -294,6 +294,7 @@ void spmv_uu(ifem_ctx *ctx, const double *xu, const double *xp, double *yu, bool
   const int64_t n = rp_.n;
   const int32_t *rows = rp_.rows;
   if (n == 0) return;
+  if (ctx->Auu.val.n == 0) throw Error(IFEM_E_BADPARAM, "A_uu has no stored values (ifem_tuning::stored_uu = 0, or no assembly yet): this operation needs the block CSR");
   hipStream_t s = ctx->stream;
   const bool time_it = ctx->profile && xp == nullptr; // the A_uu-only launches of the inner solver: the dominant kernel
   if (use_f32) auu_f32_refresh(ctx);
@@ -859,6 +860,14 @@ __global__ void k_scale_to(int64_t n, double a, const double *__restrict__ x, do
 void v_scale_to(ifem_ctx *ctx, int64_t n, double a, const double *x, double *y) {
   KScope ks(ctx, IFEM_KC_VECTOR, 16.0 * double(n));
   if (n) hipLaunchKernelGGL(k_scale_to, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, x, y);
+}
+__global__ void k_scale_to2(int64_t n, double a, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ z) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) { const double v = a * x[i]; y[i] = v; z[i] = v; }
+}
+// y = z = a x (the normalised Krylov vector into its basis column and into the fixed input vector of a captured operator)
+void v_scale_to2(ifem_ctx *ctx, int64_t n, double a, const double *x, double *y, double *z) {
+  KScope ks(ctx, IFEM_KC_VECTOR, 24.0 * double(n));
+  if (n) hipLaunchKernelGGL(k_scale_to2, dim3(vgrid(n)), dim3(256), 0, ctx->stream, n, a, x, y, z);
 }
 void v_copy(ifem_ctx *ctx, int64_t n, const double *x, double *y) {
   KScope ks(ctx, IFEM_KC_VECTOR, 16.0 * double(n));

@@ -37,8 +37,10 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
                  std::vector<double> *history = nullptr, // residual norm after every iteration (verbose runs)
                  const std::function<void(int, double *&, double *&)> *ensure = nullptr, // bases that grow with the iteration count: called
                                                                                         // with the V columns the next iteration needs
-                 bool left = false) { // LEFT preconditioning (not flexible): the Krylov space of P^-1 A, the stopping test reads the
+                 bool left = false, // LEFT preconditioning (not flexible): the Krylov space of P^-1 A, the stopping test reads the
                                       // PRECONDITIONED residual -- deal.II's SolverGMRES with its defaults (mpi_supg_solver.cpp:176-182)
+                 double *stage = nullptr,    // left only: every new basis vector is also written here and the operators read IT, so that
+                 const OpFn *PA = nullptr) { // ... the fused w = P^-1 A stage (a sequence with constant kernel arguments: a hipGraph) can replace the pair
   std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), h(m + 1), h2(m + 1);
   v_zero(ctx, n, x);
   int it = 0;
@@ -54,7 +56,8 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
     const double beta = std::sqrt(bb);
     res = beta;
     if (res <= tol || it >= maxit || !std::isfinite(res)) break; // (deal.II's SolverControl::check fails on a NaN as well)
-    v_scale_to(ctx, n, 1.0 / beta, r0, V);
+    if (left && stage) v_scale_to2(ctx, n, 1.0 / beta, r0, V, stage);
+    else v_scale_to(ctx, n, 1.0 / beta, r0, V);
     std::fill(g.begin(), g.end(), 0.0);
     g[0] = beta;
     int j = 0;
@@ -63,7 +66,8 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
       if (ensure) (*ensure)(j + 2, V, Z); // columns 0 .. j + 1 of V, 0 .. j of Z
       double *vj = V + (int64_t)j * ld;
       double *zj = flexible ? Z + (int64_t)j * ld : Z;
-      if (left) { A(vj, zj); Pinv(zj, w); }
+      if (left && stage && PA) (*PA)(stage, w);
+      else if (left) { A(stage ? stage : vj, zj); Pinv(zj, w); }
       else { Pinv(vj, zj); A(zj, w); }
       // classical Gram-Schmidt (twice with reorth); ||w||^2 comes out of the last multi-axpy pass (summed over the ranks like the
       // dot products of `mdot`): per iteration the host waits for the device once per pass, not three / five times
@@ -80,7 +84,10 @@ static int gmres(ifem_ctx *ctx, int64_t n, int64_t ld, bool reorth, const OpFn &
       for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = h[i] + h2[i];
       const double hn = std::sqrt(ww);
       H[(size_t)(j + 1) * m + j] = hn;
-      if (hn > 0) v_scale_to(ctx, n, 1.0 / hn, w, V + (int64_t)(j + 1) * ld);
+      if (hn > 0) {
+        if (left && stage) v_scale_to2(ctx, n, 1.0 / hn, w, V + (int64_t)(j + 1) * ld, stage);
+        else v_scale_to(ctx, n, 1.0 / hn, w, V + (int64_t)(j + 1) * ld);
+      }
       for (int i = 0; i < j; ++i) {
         const double t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
         H[(size_t)(i + 1) * m + j] = -sn[i] * H[(size_t)i * m + j] + cs[i] * H[(size_t)(i + 1) * m + j];
@@ -346,7 +353,7 @@ static void system_apply_ext(SolveState &S, const double *xu, const double *xp, 
 // rows without a ghost column are multiplied (comm.hip::halo_start / halo_wait, PlanarCsr::split_rows)
 static void system_apply_raw(SolveState &S, const double *x, double *y, bool time_it) {
   ifem_ctx *c = S.ctx;
-  if (halo_overlap_ok(c) && !c->has_app && !(S.o->outer_matrix_free && c->mf_valid)) {
+  if (halo_overlap_ok(c) && !c->has_app && !((S.o->outer_matrix_free || !c->tune.stored_uu) && c->mf_valid)) {
     build_row_split(c, c->Auu, c->nUo, &c->Bt, c->nPo);
     build_row_split(c, c->B, c->nUo);
     v_copy(c, S.nuo, x, S.xu_ext);
@@ -377,7 +384,7 @@ static void system_apply(SolveState &S, const double *x, double *y, bool time_it
 
 static void system_apply_ext(SolveState &S, const double *xu, const double *xp, double *y, bool time_it) {
   ifem_ctx *c = S.ctx;
-  if (S.o->outer_matrix_free && c->mf_valid && !c->has_app) { // experiment: A_uu x_u without the stored matrix
+  if ((S.o->outer_matrix_free || !c->tune.stored_uu) && c->mf_valid && !c->has_app) { // A_uu x_u without the stored matrix (fp64 cell arithmetic)
     apply_uu_mf(c, xu, y);
     spmv_bt(c, xp, S.tu);
     v_axpy(c, S.nuo, 1.0, S.tu, y);
@@ -472,9 +479,12 @@ static void sm_apply(SolveState &S, const double *x, double *y, bool lowp) {
 // capture: the caller stops asking (body has run eagerly by then).
 static bool graph_run(ifem_ctx *c, ifem_ctx::VcGraph &G, std::vector<uint64_t> &key, const std::function<void()> &body) {
   if (G.exec && key == G.key) {
-    IFEM_HIP_CHECK(hipGraphLaunch(G.exec, c->stream));
-    ++G.launches;
-    return true;
+    if (hipGraphLaunch(G.exec, c->stream) == hipSuccess) { ++G.launches; return true; }
+    (void)hipGetLastError(); // a replay the runtime refuses: give the graph up and run the sequence eagerly
+    G.destroy();
+    G.armed = false;
+    body();
+    return false;
   }
   if (!(G.armed && key == G.key)) {
     G.destroy();
@@ -484,8 +494,19 @@ static bool graph_run(ifem_ctx *c, ifem_ctx::VcGraph &G, std::vector<uint64_t> &
   }
   bool captured = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
   if (captured) {
+    bool threw = false;
     try { body(); }
-    catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(c->stream, &dead); if (dead) (void)hipGraphDestroy(dead); G.armed = false; throw; }
+    catch (...) { threw = true; } // e.g. a call that is illegal during capture on a path the eager warm-up did not reach
+    if (threw) { // end and discard the capture, clear the error, and run the sequence eagerly: an eager run may well succeed
+      hipGraph_t dead = nullptr;
+      (void)hipStreamEndCapture(c->stream, &dead);
+      if (dead) (void)hipGraphDestroy(dead);
+      (void)hipGetLastError();
+      G.destroy();
+      G.armed = false;
+      body();
+      return false;
+    }
     captured = hipStreamEndCapture(c->stream, &G.graph) == hipSuccess && G.graph != nullptr;
     captured = captured && hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0) == hipSuccess;
     captured = captured && hipGraphLaunch(G.exec, c->stream) == hipSuccess;
@@ -1013,6 +1034,8 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   mark();
   // A~^-1 utmp (:124-127)
   const bool f32 = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32;
+  if (!c->tune.stored_uu && o->ainv_kind != IFEM_AINV_GMRES_BJACOBI_MF && o->ainv_kind != IFEM_AINV_MG)
+    throw Error(IFEM_E_BADPARAM, "ifem_tuning::stored_uu = 0 keeps no A_uu values: use IFEM_AINV_MG or IFEM_AINV_GMRES_BJACOBI_MF (the matrix-free inner operators)");
   OpFn Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_uu(c, xe, nullptr, y, f32); };
   if (o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF)
     Auu = [&](const double *x, double *y) { uu_apply_level(S, x, y); };
@@ -1062,7 +1085,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     OpFn Amf = [&](const double *x, double *y) { uu_apply_level(S, x, y); };
     // the cycle itself: eagerly, or as a captured hipGraph (ctx.hpp::VcGraph) on small single-rank chains
     bool graph_ok = c->tune.vcycle_graph_cells > 0 && c->n_cells <= c->tune.vcycle_graph_cells && !c->profile && !kprof_root(c).on && !profiler_attached();
-    for (const SolveState &L : Mu.L) graph_ok = graph_ok && L.ctx->halo.nranks == 1 && !L.ctx->mg_replica;
+    for (const SolveState &L : Mu.L) graph_ok = graph_ok && L.ctx->halo.nranks == 1 && !L.ctx->mg_replica && !L.ctx->profile;
     auto run_vcycle = [&]() {
       if (!graph_ok) { mg_uu_vcycle(Mu, 0); return; }
       std::vector<uint64_t> key;
@@ -1076,6 +1099,9 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
         put(lc->bjac_f32.p); put(lc->mf_eval.p); put(lc->mf_ycell.p); put(lc->mg_Ru_mask.p); put(lc->mg_Pu_mask.p);
         put(lc->has_c[lc->asm_constraint_set] ? lc->is_c[lc->asm_constraint_set].p : nullptr);
         key.push_back(uint64_t(lc->nUo)); key.push_back(uint64_t(lc->n_cells)); key.push_back(uint64_t(lc->mf_noconv)); key.push_back(uint64_t(lc->tune.xcd_swizzle));
+        // everything else the captured launches are made of: the epoch moves with ifem_set_tuning / ifem_set_profiling / ifem_mg_attach
+        key.push_back(lc->graph_epoch); key.push_back(uint64_t(lc->tune.mf_f32));
+        put(lc->bjac.p); put(lc->vcoords.p); put(lc->cell_unodes.p); put(lc->uinc.col.p);
         putd(lc->uu_lmax); putd(lc->mf_params.viscosity); putd(lc->mf_params.rho); putd(lc->mf_params.grad_div); putd(lc->mf_params.dt);
       }
       if (!graph_run(c, c->vc_graph, key, [&]() { mg_uu_vcycle(Mu, 0); })) {
@@ -1125,6 +1151,9 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
           const double per_col = 2.0 * double(ld) * sizeof(double);
           const int fits = int(std::min<double>(128.0, 0.25 * double(fr) / std::max(per_col, 1.0)));
           want = std::min(want, std::max(fits, mi));
+          // `its` and `mi` are the same on every rank, free memory and `ld` are not: the restart length must be (the ranks restart
+          // together -- their all-reduces and halo exchanges pair up), so the smallest wish of all ranks wins
+          if (c->halo.nranks > 1) { double w = -double(want); allreduce_max(c, &w, 1); want = int(-w); }
           if (want > mi) {
             if (o->verbose) fprintf(stderr, "[ifem] inner GMRES(%d) needed %d iterations: restart length %d from now on\n", mi, its, want);
             c->inner_restart_eff = want;
@@ -1376,6 +1405,21 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
     };
     if (b2_ok) Jpp = [&](const double *x, double *y) { bilu_apply(ctx, ctx->b2_ilu, ctx->tune.b2pp_sweeps, x, y); };
   }
+  // w = B2pp_inverse (T_pp stage) of the inner iteration: ~20 short launches with constant arguments (the Jacobi sweeps of the two ILU(0)
+  // applications, three SpMVs) whose cost is the host's launch rate -- one captured hipGraph on a single rank (ifem_tuning::scns_graph)
+  bool pa_graph_ok = refpc && ctx->tune.scns_graph != 0 && ctx->halo.nranks == 1 && !ctx->profile && !ctx->kprof.on && !profiler_attached();
+  OpFn PAg = [&](const double *x, double *y) {
+    auto body = [&]() { Tpp(x, S.tp[1]); Jpp(S.tp[1], y); };
+    if (!pa_graph_ok) { body(); return; }
+    std::vector<uint64_t> key;
+    for (const void *p : {(const void *)x, (const void *)y, (const void *)S.tp[1], (const void *)S.tp[4], (const void *)S.tu, (const void *)S.utmp,
+                          (const void *)ctx->pvv_ilu.LU.p, (const void *)ctx->pvv_ilu.t0.p, (const void *)ctx->b2_ilu.LU.p, (const void *)ctx->b2_ilu.t0.p,
+                          (const void *)ctx->App.p, (const void *)ctx->B.val.p, (const void *)ctx->Bt.val.p})
+      key_ptr(key, p);
+    key.push_back(uint64_t(ctx->tune.pvv_sweeps)); key.push_back(uint64_t(ctx->tune.b2pp_sweeps)); key.push_back(uint64_t(pvv_ok));
+    key.push_back(uint64_t(ctx->pvv_ilu.nnz)); key.push_back(uint64_t(ctx->b2_ilu.nnz));
+    if (!graph_run(ctx, ctx->pa_graph, key, body)) pa_graph_ok = false;
+  };
   const bool tpp_explicit = !refpc && ctx->halo.nranks == 1 && !ctx->tune.tpp_operator;
   auto ilu_or_warn = [&]() {
     const bool ok = tpp_ilu_factor(ctx);
@@ -1413,8 +1457,10 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
       mdot_p(1, S.tp[6], S.npo, S.tp[0], &sc);
       const double alpha = sc != 0 && std::isfinite(sc) ? pn / sc : 0.0;
       v_axpby(ctx, S.npo, 1.0, S.tp[0], -alpha, S.tp[6]); // r0 = ptmp - alpha T_pp ptmp
+      const bool left = ctx->tune.scns_inner_left != 0;
       S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.ctx, S.npo), ctx->tune.scns_inner_reorth != 0, Tpp, Jpp, false, S.tp[6], dst1, mt, 100000,
-                                inner_tol, ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p, nullptr, nullptr, /*left=*/ctx->tune.scns_inner_left != 0);
+                                inner_tol, ctx->innerV.p, S.tp[1], S.tp[2], &res, mdot_p, nullptr, nullptr, left, left ? S.tp[5] : nullptr,
+                                left && pa_graph_ok ? &PAg : nullptr);
       v_axpy(ctx, S.npo, alpha, S.tp[0], dst1);
     } else
       S.st.inner_iters += gmres(ctx, S.npo, basis_ld(S.ctx, S.npo), /*reorth=*/true, Tpp, Jpp, false, S.tp[0], dst1, mt, 100000, inner_tol,

@@ -582,7 +582,7 @@ def test_insim_run_one_step_leaves_the_projected_stress_of_the_new_solution():
     assert (c1 >= 0).all() and np.abs(st1).max() > 0
     assert L.ifem_update_stress(s.ctx, C.c_double(1.0), None) == 0  # the same projection once more, explicitly
     v2, st2, c2 = at_points()
-    assert np.array_equal(st1, st2) and np.array_equal(v1, v2)
+    assert np.abs(st1 - st2).max() <= 1e-12 * np.abs(st1).max() and np.array_equal(v1, v2)  # (the nodal average sums atomically: equal to rounding)
     # the flow is (close to) plane Poiseuille: T_xy = mu du/dy = dP / (2 L) (H - 2 y)
     exact = 10.0 / (2 * 2.0) * (0.2 - 2 * pts[:, 1])
     assert np.abs(st1[:, 0, 1] - exact).max() < 0.05 * np.abs(exact).max() + 0.02

@@ -728,3 +728,80 @@ def test_inner_gmres_lengthens_its_restart_cycle_when_it_stagnates():
     assert s.L.ifem_inner_restart_length(s.ctx) >= grown
     assert st2.inner_iters <= st1.inner_iters, (st1.inner_iters, st2.inner_iters)
     s.close()
+
+
+def test_stored_uu_0_newton_step_against_the_oracles_assembled_matrix():
+    """ifem_tuning::stored_uu = 0 (VERDICT r5 item 6a): no A_uu values are kept -- the assembly integrates the right-hand side, the outer
+    operator applies A_uu matrix-free in fp64.  Same right-hand side as the stored assembly (1e-12), and the Newton update meets the
+    reference's stopping rule on the ORACLE's assembled matrix; the same solve with the block CSR gives the same update."""
+    import ctypes as C
+    import orc
+    from boxmesh import BoxMesh
+    from cases import channel3d_state
+    from openifem_amd import capi, host
+    n = 8
+    upd = {}
+    rhs = {}
+    for stored in (1, 0):
+        s = host.InsIM(host.channel_prm(3), (n, n, n), (0, 0, 0), EXTENT)
+        s.set_node_order(morton=False)  # lexicographic: the oracle's numbering
+        s.setup(0)
+        tun = capi.Tuning()
+        s.L.ifem_default_tuning(C.byref(tun))
+        tun.stored_uu = stored
+        for c_ in s.all_ctxs():
+            assert s.L.ifem_set_tuning(c_, C.byref(tun)) == 0
+        s.channel_state()
+        s.opts.inner_rel_first = 0.0
+        s.assemble(False)
+        st = s.solve(False)
+        nl = sum(s.sizes()[1:])
+        b, u = np.zeros(nl), np.zeros(nl)
+        assert s.L.ifem_vec_get(s.ctx, capi.VEC_RHS, b.ctypes.data_as(C.c_void_p)) == 0
+        assert s.L.ifem_vec_get(s.ctx, capi.VEC_UPDATE, u.ctypes.data_as(C.c_void_p)) == 0
+        ev, pr = np.zeros(nl), np.zeros(nl)
+        assert s.L.ifem_vec_get(s.ctx, capi.VEC_EVAL, ev.ctypes.data_as(C.c_void_p)) == 0
+        assert s.L.ifem_vec_get(s.ctx, capi.VEC_PRESENT, pr.ctypes.data_as(C.c_void_p)) == 0
+        rhs[stored], upd[stored] = b, u
+        res, bn = s.true_residual()  # with the operator the solve used
+        assert res <= 1.05e-4 * bn
+        if stored == 0:
+            assert s.L.ifem_nnz(s.ctx, 0) > 0  # the pattern exists, the values were never allocated:
+            y = np.zeros(nl)
+            assert s.L.ifem_uu_vmult(s.ctx, capi.VEC_UPDATE, capi.VEC_RHS, 0) < 0 and b"stored" in s.L.ifem_last_error()
+        s.close()
+    assert np.abs(rhs[0] - rhs[1]).max() <= 1e-12 * np.abs(rhs[1]).max()
+    assert np.abs(upd[0] - upd[1]).max() <= 5e-4 * np.abs(upd[1]).max()
+    # the oracle's matrix at the same state
+    m = BoxMesh([n] * 3, (0, 0, 0), EXTENT, kv=2)
+    dofs, vals, present, _, kw = channel3d_state(m)
+    assert np.abs(present - pr).max() <= 1e-14  # same numbering, same analytic state; the perturbed point comes from the mirror's generator
+    evalp = ev
+    S = orc.System(m)
+    S.set_constraints(0, dofs, None)
+    S.set_constraints(1, dofs, vals)
+    S.assemble(orc.make_params(**kw), False, evalp, present)
+    A, bo = S.csr("A"), S.rhs()
+    assert np.abs(bo - rhs[0]).max() <= 1e-11 * np.abs(bo).max()
+    free = np.ones(S.n, bool)
+    free[dofs] = False
+    assert np.linalg.norm((A @ upd[0] - bo)[free]) <= 1.05e-4 * np.linalg.norm(bo)
+
+
+def test_stored_uu_0_refuses_what_it_cannot_do():
+    import ctypes as C
+    from openifem_amd import capi, host
+    s = host.InsIM(host.channel_prm(3), (4, 4, 4), (0, 0, 0), EXTENT)
+    s.setup(0)
+    tun = capi.Tuning()
+    s.L.ifem_default_tuning(C.byref(tun))
+    tun.stored_uu = 0
+    for c_ in s.all_ctxs():
+        assert s.L.ifem_set_tuning(c_, C.byref(tun)) == 0
+    s.channel_state()
+    s.assemble(False)
+    s.opts.ainv_kind = 0  # needs the stored block
+    with pytest.raises(host.HostError) as e:
+        s.solve(False)
+    assert "stored_uu" in str(e.value)
+    s.close()

@@ -326,10 +326,11 @@ def test_cylinder_known_answers_on_partitioned_unstructured_mesh(kind, prm, worl
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_refined_cylinder_scnsim_on_virtual_ranks_converges_with_the_per_rank_ilu(world):
-    """row A12 on several ranks: the cylinder mesh refined once beyond the reference's test (24 k pressure rows) cut into strips;
-    the operator T_pp is distributed, its preconditioner the ILU(0) of the owned block of T_pp on every rank (block-Jacobi ILU,
-    what Euclid does across ranks, mpi_supg_solver.cpp:49-53,120-133).  Round 3 fell back to Jacobi here: 1777 inner iterations per
-    application on one rank.  The outer iteration count stays that of the single context."""
+    """row A12 on several ranks: the cylinder mesh refined once beyond the reference's test (24 k pressure rows) cut into strips.
+    Round 6, the reference's structure (ifem_tuning::scns_pc = 2): the operator T_pp = A_pp - A_pv P_vv^-1 A_vp is distributed, P_vv^-1 and
+    the preconditioner of its inner GMRES are the ILU(0) of the OWNED block of A_vv / of B2pp on every rank (block-Jacobi ILU across
+    ranks, mpi_supg_solver.cpp:49-53,120-133).  The iteration counts stay those of the single context (which equal the oracle's
+    restatement of the reference's preconditioner: tests/test_gpu_scns_refpc.py): 21 / 96 per application there, 22 / 104 on strips."""
     from openifem_amd import capi
     from cylmesh import CylinderMesh
     from partmesh import local_dirichlet, partition_mesh, run_virtual_ranks
@@ -343,10 +344,6 @@ def test_refined_cylinder_scnsim_on_virtual_ranks_converges_with_the_per_rank_il
 
     def work(rank, part, ctx):
         ld, lv = (dofs, vals) if not hasattr(part, "g2l_dof") else local_dirichlet(part, dofs, vals)
-        t = capi.Tuning()
-        ctx.L.ifem_default_tuning(C.byref(t))
-        t.tpp_ilu_order = 0  # natural order: the count VERDICT r3 set the bar with (the default's multicolour order: ~3 x, faster on the clock)
-        assert ctx.L.ifem_set_tuning(ctx.h, C.byref(t)) == 0
         ctx.set_constraints(0, ld, None)
         ctx.set_constraints(1, ld, lv)
         ctx.scns_assemble(Pm, True)
@@ -362,5 +359,5 @@ def test_refined_cylinder_scnsim_on_virtual_ranks_converges_with_the_per_rank_il
     single = run_virtual_ranks(capi, [m], work)[0]
     res = run_virtual_ranks(capi, parts, work, timeout=900)
     assert all(r[0] == res[0][0] for r in res)  # one collective solve
-    assert max(r[1] for r in res) < 100, (single, res)
-    assert abs(res[0][0] - single[0]) <= 2, (single, res)
+    assert max(r[1] for r in res) <= 1.25 * single[1], (single, res)
+    assert abs(res[0][0] - single[0]) <= 3 and single[0] <= 24, (single, res)

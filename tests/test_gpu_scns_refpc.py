@@ -78,7 +78,7 @@ def test_pieces_match_the_oracle(dim, kv, reps):
 
 def test_jacobi_sweeps_converge_to_the_exact_substitution():
     """k sweeps reproduce the first k terms of the (finite) Neumann series of each triangular inverse: as many sweeps as
-    elimination levels give the exact solve; the default 3 / 5 are within a fraction of it"""
+    elimination levels give the exact solve; a handful are within a fraction of it"""
     m, S, ctx, rng = _box_case(2, 1, (9, 7))
     n_u, n_p = m.n_u, m.n_pnodes
     xu, xp = rng.standard_normal(n_u), rng.standard_normal(n_p)

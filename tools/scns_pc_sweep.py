@@ -14,7 +14,7 @@ from cylmesh import CylinderMesh
 
 VARIANTS = [("default", {}), ("reorth", dict(scns_inner_reorth=1)), ("exact", dict(pvv_sweeps=-1, b2pp_sweeps=-1)),
             ("s2/4", dict(pvv_sweeps=2, b2pp_sweeps=4)), ("s2/3", dict(pvv_sweeps=2, b2pp_sweeps=3)), ("s4/6", dict(pvv_sweeps=4, b2pp_sweeps=6)),
-            ("s5/8", dict(pvv_sweeps=5, b2pp_sweeps=8)), ("right", dict(scns_inner_left=0)), ("left+re", dict(scns_inner_reorth=1)), ("legacy", dict(scns_pc=1))]
+            ("s5/8", dict(pvv_sweeps=5, b2pp_sweeps=8)), ("nograph", dict(scns_graph=0)), ("right", dict(scns_inner_left=0)), ("left+re", dict(scns_inner_reorth=1)), ("legacy", dict(scns_pc=1))]
 if os.environ.get("SCNS_VARIANTS"):
     VARIANTS = [v for v in VARIANTS if v[0] in os.environ["SCNS_VARIANTS"].split(",")]
 
