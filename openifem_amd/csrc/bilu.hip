@@ -10,8 +10,8 @@
 //     (a 2D stencil in natural order has hundreds of levels of a few dozen rows) are walked by ONE workgroup inside one launch.
 //   * application: k Jacobi sweeps on each triangular system (y <- x - (L - I) y, y <- D^-1 (z - (U - D) y)) instead of
 //     substitution: every sweep is one row-parallel launch whatever the number of levels, and the triangular factors of an ILU(0)
-//     are so diagonally dominant that 3 / 5 sweeps reproduce the iteration counts of exact substitution to ~10 % (measured with the
-//     oracle's restatement of the same preconditioner, profiles/r06_scns_pc_oracle.txt).  A fixed k is a fixed linear operator.
+//     are so diagonally dominant that 4 / 6 sweeps reproduce the iteration counts of exact substitution to ~15 % (measured on the
+//     cylinder benchmark at 3 and 4 refinements, profiles/r06_scns_pc_sweep.txt).  A fixed k is a fixed linear operator.
 //     sweeps < 0: exact substitution, level by level in one workgroup (verification of the factors; slow).
 #include <hip/hip_runtime.h>
 #include <algorithm>
