@@ -149,7 +149,7 @@ def compact_line(out, detail_path=None):
     line["config"] = dict({"workload": wl if len(wl) <= 200 else wl[:197] + "..."},
                           **_pick(cfg, ("n_dofs", "cells_per_gpu", "parallelism", "assemble_ms", "solve_ms", "assemble_kernel_ms", "fgmres_iters",
                                         "inner_iters", "cg_mp_iters", "cg_sm_iters", "t_cg_mp_ms", "t_cg_sm_ms", "t_ainv_ms", "true_rel_residual", "fgmres_rel_tol", "solver_opts",
-                                        "rccl_nranks", "comm_transport", "halo_exchanges_per_step", "allreduce_stream_per_step",
+                                        "rccl_nranks", "comm_transport", "halo_neighbors", "halo_exchanges_per_step", "allreduce_stream_per_step",
                                         "allreduce_host_per_step", "hbm_used_gb")))
     for k in ("value_cold", "value_sustained", "value_matrix_free"):
         if k in out:
