@@ -116,7 +116,8 @@ typedef struct {
   double  sm_rel, sm_abs;     /* CG(S_m) 1e-3, 1e-10 (mpi_insim.cpp:88-89) */
   int32_t ainv_kind;          /* IFEM_AINV_* */
   int32_t inner_restart, inner_maxit; /* IFEM_AINV_MG: inner_maxit = 0 makes A~^-1 exactly one V-cycle, -k makes it k
-                                         stationary V-cycle sweeps x += V(b - A x) (no inner Krylov loop in either case) */
+                                         stationary V-cycle sweeps x += V(b - A x) (no inner Krylov loop in either case); the Krylov kinds
+                                         read inner_maxit <= 0 as the default cap of 400 */
   double  inner_rel;          /* relative residual target of the inner A_uu solve */
   int32_t explicit_schur;     /* 1: form S_m = B diag(M_u)^-1 B^T explicitly like the reference (on several GPUs this
                                  needs the 2-deep pressure halo plan of ifem_partition); 0: apply it as two SpMVs */

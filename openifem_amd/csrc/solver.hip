@@ -1189,15 +1189,17 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
     S.st.precond_applies++;
     return;
   }
+  // inner_maxit <= 0 means "one V-cycle / stationary sweeps" to IFEM_AINV_MG only; for the Krylov kinds it is the library default cap
+  const int inner_cap = o->inner_maxit > 0 ? o->inner_maxit : 400;
   const bool f32_basis = (f32 || o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF) && o->inner_restart + 6 <= 64;
   if (f32_basis) { // columns 0..m: basis, m+1: scratch for V y, up to the next multiple of 4: padding read by the fused kernels
     OpF32 Pf = [&](const float *x, double *y) { bjac_apply_f32(c, x, y); };
-    S.st.inner_iters += gmres_f32basis(c, S.nuo, basis_ld(S.ctx, S.nuo), Auu, Pf, S.utmp, dst0, o->inner_restart, o->inner_maxit,
+    S.st.inner_iters += gmres_f32basis(c, S.nuo, basis_ld(S.ctx, S.nuo), Auu, Pf, S.utmp, dst0, o->inner_restart, inner_cap,
                                        inner_rel_now * un, reinterpret_cast<float *>(c->innerV.p), S.inner_z, S.inner_w, &res,
                                        [&](double *v, int k) { allreduce_sum(c, v, k); });
   } else
   S.st.inner_iters += gmres(c, S.nuo, basis_ld(S.ctx, S.nuo), /*reorth=*/false, Auu, Pj, false, S.utmp, dst0, o->inner_restart,
-                            o->inner_maxit, inner_rel_now * un, c->innerV.p, S.inner_z, S.inner_w, &res, mdot);
+                            inner_cap, inner_rel_now * un, c->innerV.p, S.inner_z, S.inner_w, &res, mdot);
   mark();
   S.st.precond_applies++;
 }
