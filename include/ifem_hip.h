@@ -211,9 +211,10 @@ typedef struct {
                             (mpi_insim.cpp:343-361).  0: A_uu is never stored: the assembly integrates the right-hand side (B, B^T, M_p, diag(M_u)
                             through the cached geometry path), the outer operator applies A_uu matrix-free in fp64 (equal to the stored block to
                             1e-13) and the smoothers take their node blocks from the cell integrals.  Needs the matrix-free inner solvers
-                            (IFEM_AINV_MG / _BJACOBI_MF), geo_cache >= 1, no hanging nodes, and assemblies whose constraint values are all zero
-                            (an inhomogeneous first Newton iteration is assembled with stored_uu = 1).  78 GB less memory and ~2 x the step
-                            rate at 128^3; the block CSR stays the default because the north star prescribes it. */
+                            (IFEM_AINV_MG / _BJACOBI_MF), geo_cache >= 1 and no hanging nodes.  An assembly whose constraint set carries
+                            non-zero values (the first Newton iteration of a step with inhomogeneous boundary values: distribute_local_to_global
+                            needs the element matrix columns) takes the stored path by itself -- and allocates the values then.  Without such
+                            assemblies 78 GB less memory at 128^3; ~2 x the step rate.  The block CSR stays the default (north star). */
 } ifem_tuning;
 /* Initialise an ifem_tuning with ifem_default_tuning before changing fields: a zero-initialised struct gets the documented defaults
  * only for the fields where 0 is not a meaningful value (asm3_cpb, scns_pc, pvv_sweeps, b2pp_sweeps). */

@@ -99,19 +99,17 @@ void launch_ins_assemble_ex(ifem_ctx *ctx, const ifem_ins_params *p, int use_non
     }
     if (ctx->geo_valid) ctx->geo_set_changes++;
     ctx->geo_unchanged = 0;
-  } else if (assemble_system == 1 && ctx->tune.stored_uu != 0)
-    ensure_auu_values(ctx);
+  }
   // ifem_tuning::stored_uu = 0: the velocity-velocity block is never stored.  The cell kernel integrates the right-hand side (and,
   // through the geometry path, B / B^T / M_p / diag(M_u)); A_uu is applied matrix-free in fp64 by the outer operator (the same
   // operator to 1e-13, test_matrix_free_uu_apply_equals_assembled_block) and its node-block diagonal comes from the cell integrals.
-  const bool mf_only = assemble_system == 1 && ctx->tune.stored_uu == 0;
-  if (mf_only) {
-    if (ctx->kv != 2 && !(ctx->dim == 3 || ctx->dim == 2)) throw Error(IFEM_E_BADPARAM, "stored_uu = 0: unsupported element");
-    if (use_nonzero && ctx->inhom_any[1])
-      throw Error(IFEM_E_BADPARAM, "stored_uu = 0: an assembly with inhomogeneous constraint values needs the element matrix columns "
-                                   "(distribute_local_to_global moves K g into the right-hand side): assemble that Newton iteration with stored_uu = 1");
-    if (ctx->hang.active) throw Error(IFEM_E_BADPARAM, "stored_uu = 0 with hanging-node constraints is not supported");
-  }
+  // An assembly with inhomogeneous constraint values needs the element matrix columns (distribute_local_to_global moves K g into the
+  // right-hand side): that one -- the first Newton iteration of a step with non-zero boundary values -- takes the stored path.
+  const bool mf_only = assemble_system == 1 && ctx->tune.stored_uu == 0 && !(use_nonzero && ctx->inhom_any[1]);
+  if (assemble_system == 1 && ctx->tune.stored_uu == 0 && ctx->hang.active)
+    throw Error(IFEM_E_BADPARAM, "stored_uu = 0 with hanging-node constraints is not supported");
+  if (assemble_system == 1 && !mf_only) ensure_auu_values(ctx);
+  if (assemble_system == 1) ctx->uu_is_stored = !mf_only;
   if (!assemble_system && !ctx->assembled) throw Error(IFEM_E_BADPARAM, "rhs-only assembly before any matrix assembly");
   if (assemble_system == 1) { // state the matrix-free A_uu needs to reproduce this matrix (apply_mf.hip)
     const size_t nu = size_t(dim) * size_t(ctx->nUl);
@@ -256,7 +254,7 @@ static void ifem_ctx_unconstrained_geometry(ifem_ctx *ctx, const ifem_ins_params
 
 static void assemble_epilogue(ifem_ctx *ctx, int use_nonzero) {
   dinv_setup(ctx);
-  if (ctx->tune.stored_uu == 0) { ctx->asm_constraint_set = use_nonzero ? 1 : 0; uu_block_diag_mf(ctx); }
+  if (!ctx->uu_is_stored) { ctx->asm_constraint_set = use_nonzero ? 1 : 0; uu_block_diag_mf(ctx); }
   else bjac_setup(ctx);
   IFEM_HIP_CHECK(hipEventSynchronize(ctx->ev1));
   float ms = 0;

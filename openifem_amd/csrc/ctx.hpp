@@ -362,6 +362,7 @@ struct ifem_ctx {
   ifem::MgCsr mg_Pp, mg_Rp, mg_Pu, mg_Ru;
   ifem::DBuf<int32_t> mg_inj_u; // [nUo of the coarse level] coincident owned velocity node of this level
   ifem::DBuf<uint8_t> mg_Pu_mask, mg_Ru_mask; // per weight 8 bytes: {column | components dropped by the Dirichlet flags of the two levels << 29, weight as float} (mg.hip::mg_csr_mask)
+  bool uu_is_stored = true;                   // the last full assembly scattered A_uu (false: ifem_tuning::stored_uu = 0 took the matrix-free path)
   bool inhom_any[2] = {false, false};         // constraint object `which` carries a non-zero inhomogeneity somewhere (any rank)
   uint64_t graph_epoch = 0;                   // bumped by ifem_set_tuning / ifem_set_profiling / ifem_mg_attach: part of every hipGraph replay key
   int64_t mg_mask_key[2] = {-1, -1};          // constrained-dof sets (flag ids of this level and the coarser one) of the masks

@@ -353,7 +353,7 @@ static void system_apply_ext(SolveState &S, const double *xu, const double *xp, 
 // rows without a ghost column are multiplied (comm.hip::halo_start / halo_wait, PlanarCsr::split_rows)
 static void system_apply_raw(SolveState &S, const double *x, double *y, bool time_it) {
   ifem_ctx *c = S.ctx;
-  if (halo_overlap_ok(c) && !c->has_app && !((S.o->outer_matrix_free || !c->tune.stored_uu) && c->mf_valid)) {
+  if (halo_overlap_ok(c) && !c->has_app && !((S.o->outer_matrix_free || !c->uu_is_stored) && c->mf_valid)) {
     build_row_split(c, c->Auu, c->nUo, &c->Bt, c->nPo);
     build_row_split(c, c->B, c->nUo);
     v_copy(c, S.nuo, x, S.xu_ext);
@@ -384,7 +384,7 @@ static void system_apply(SolveState &S, const double *x, double *y, bool time_it
 
 static void system_apply_ext(SolveState &S, const double *xu, const double *xp, double *y, bool time_it) {
   ifem_ctx *c = S.ctx;
-  if ((S.o->outer_matrix_free || !c->tune.stored_uu) && c->mf_valid && !c->has_app) { // A_uu x_u without the stored matrix (fp64 cell arithmetic)
+  if ((S.o->outer_matrix_free || !c->uu_is_stored) && c->mf_valid && !c->has_app) { // A_uu x_u without the stored matrix (fp64 cell arithmetic)
     apply_uu_mf(c, xu, y);
     spmv_bt(c, xp, S.tu);
     v_axpy(c, S.nuo, 1.0, S.tu, y);
@@ -1034,7 +1034,7 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
   mark();
   // A~^-1 utmp (:124-127)
   const bool f32 = o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_F32;
-  if (!c->tune.stored_uu && o->ainv_kind != IFEM_AINV_GMRES_BJACOBI_MF && o->ainv_kind != IFEM_AINV_MG)
+  if (!c->uu_is_stored && o->ainv_kind != IFEM_AINV_GMRES_BJACOBI_MF && o->ainv_kind != IFEM_AINV_MG)
     throw Error(IFEM_E_BADPARAM, "ifem_tuning::stored_uu = 0 keeps no A_uu values: use IFEM_AINV_MG or IFEM_AINV_GMRES_BJACOBI_MF (the matrix-free inner operators)");
   OpFn Auu = [&](const double *x, double *y) { const double *xe; extend_u(S, x, &xe); spmv_uu(c, xe, nullptr, y, f32); };
   if (o->ainv_kind == IFEM_AINV_GMRES_BJACOBI_MF)

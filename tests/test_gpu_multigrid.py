@@ -805,3 +805,30 @@ def test_stored_uu_0_refuses_what_it_cannot_do():
         s.solve(False)
     assert "stored_uu" in str(e.value)
     s.close()
+
+
+def test_stored_uu_0_newton_loop_with_inhomogeneous_boundary_values():
+    """tests/fluid_cylinder_mpi (parabolic inflow: non-zero constraint values) with ifem_tuning::stored_uu = 0: the first Newton iteration of the
+    step -- the one assembled with nonzero_constraints -- takes the stored path by itself, the others run matrix-free; the reference's constants
+    come out as with the block CSR"""
+    import ctypes as C
+    import os
+    from openifem_amd import capi, host
+    prm = open(os.path.join(os.path.dirname(__file__), "golden", "prm", "fluid_cylinder_mpi.prm")).read()
+    out = {}
+    for stored in (1, 0):
+        flow = host.InsIM(prm, mesh="cylinder")
+        flow.add_hard_coded_boundary_condition(0, lambda p, c, t: 4 * 0.3 * p[1] * (0.41 - p[1]) / (0.41 * 0.41) if (c == 0 and abs(p[0]) < 1e-10) else 0.0)
+        flow.setup(3)
+        tun = capi.Tuning()
+        flow.L.ifem_default_tuning(C.byref(tun))
+        tun.stored_uu = stored
+        for c_ in flow.all_ctxs():
+            assert flow.L.ifem_set_tuning(c_, C.byref(tun)) == 0
+        flow.run_one_step(True)
+        v, p = flow.get_current_solution()
+        out[stored] = (v.max(), p.max(), flow.last_newton())
+        flow.close()
+    assert abs(out[0][0] - 0.374235) / 0.374235 < 1e-3 and abs(out[0][1] - 46.5226) / 46.5226 < 1e-3, out
+    assert abs(out[0][0] - out[1][0]) <= 1e-5 * out[1][0] and abs(out[0][1] - out[1][1]) <= 1e-5 * out[1][1], out
+    assert out[0][2][0] == out[1][2][0], out  # the same number of Newton iterations
