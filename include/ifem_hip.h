@@ -205,8 +205,9 @@ typedef struct {
                             fused pass: it is a preconditioner solved to 1e-3); 1: twice, as the outer FGMRES */
   int32_t scns_inner_left; /* 1 (default): that GMRES is LEFT-preconditioned and stops on the preconditioned residual, as deal.II's SolverGMRES
                             does with its defaults (mpi_supg_solver.cpp:174-182); 0: right-preconditioned, true residual */
-  int32_t scns_graph;    /* 1 (default): single rank: the ~20 short launches of one inner iteration's B2pp_inverse (T_pp v) are replayed as a
-                            captured hipGraph (their cost is the host's launch rate); 0: launched eagerly */
+  int32_t scns_graph;    /* 0 (default): eager launches.  1: single rank: the ~20 short launches of one inner iteration's B2pp_inverse (T_pp v)
+                            are replayed as a captured hipGraph -- measured: no gain (84.6 against 85.3 ms per solve: the device-side
+                            dependency chain of the short kernels, not the host's launch rate, sets the pace) */
   int32_t stored_uu;     /* 1 (default): ifem_ins_assemble scatters the velocity-velocity block into the block CSR, as the reference does
                             (mpi_insim.cpp:343-361).  0: A_uu is never stored: the assembly integrates the right-hand side (B, B^T, M_p, diag(M_u)
                             through the cached geometry path), the outer operator applies A_uu matrix-free in fp64 (equal to the stored block to

@@ -119,7 +119,7 @@ void ifem_default_solver_opts(ifem_solver_opts *o) {
 void ifem_default_tuning(ifem_tuning *t) {
   t->geo_cache = 1; t->xcd_swizzle = 1; t->asm_skip = 0; t->spmv_lanes = 32; t->sm_lanes = 32; t->mf_f32 = 1;
   t->tpp_operator = 0; t->spmv_pipe = 1; t->halo_overlap = 1; t->asm3_variant = 0; t->cg_single_reduction = 1; t->asm3_cpb = 2; t->tpp_milu_permille = 950; t->tpp_ilu_order = 2; t->basis_pad = 32 * 33; t->tpp_tri_sweeps = 0; t->uu_row_order = 1; t->eig_steps = 0; t->vcycle_graph_cells = 262144;
-  t->scns_pc = 2; t->pvv_sweeps = 4; t->b2pp_sweeps = 6; t->scns_inner_reorth = 0; t->scns_inner_left = 1; t->scns_graph = 1; t->stored_uu = 1;
+  t->scns_pc = 2; t->pvv_sweeps = 4; t->b2pp_sweeps = 6; t->scns_inner_reorth = 0; t->scns_inner_left = 1; t->scns_graph = 0; t->stored_uu = 1;
 }
 
 int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
@@ -135,7 +135,7 @@ int ifem_set_tuning(ifem_ctx *ctx, const ifem_tuning *t) {
   ctx->tune = *t;
   ++ctx->graph_epoch;
   if (ctx->tune.asm3_cpb <= 0) ctx->tune.asm3_cpb = 2; // a zero-initialised struct: the defaults of the fields added after round 4
-  if (ctx->tune.scns_pc == 0) { ctx->tune.scns_pc = 2; if (!ctx->tune.pvv_sweeps) ctx->tune.pvv_sweeps = 4; if (!ctx->tune.b2pp_sweeps) ctx->tune.b2pp_sweeps = 6; ctx->tune.scns_inner_left = 1; ctx->tune.scns_graph = 1; ctx->tune.stored_uu = 1; }
+  if (ctx->tune.scns_pc == 0) { ctx->tune.scns_pc = 2; if (!ctx->tune.pvv_sweeps) ctx->tune.pvv_sweeps = 4; if (!ctx->tune.b2pp_sweeps) ctx->tune.b2pp_sweeps = 6; ctx->tune.scns_inner_left = 1; ctx->tune.stored_uu = 1; }
   IFEM_API_END
 }
 

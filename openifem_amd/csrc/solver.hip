@@ -1394,8 +1394,8 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
     if (pvv_ok) bilu_apply(ctx, ctx->pvv_ilu, ctx->tune.pvv_sweeps, x, y);
     else bjac_apply(ctx, x, y);
   };
+  bool b2_ok = false;
   if (refpc) {
-    bool b2_ok = false;
     scns_refpc_setup(ctx, o->verbose, &pvv_ok, &b2_ok);
     Tpp = [&](const double *x, double *y) { // SchurComplementTpp::vmult
       const double *xe; extend_p(S, x, &xe);
@@ -1418,7 +1418,7 @@ int scns_solve(ifem_ctx *ctx, const ifem_solver_opts *o, int use_nonzero, ifem_s
                           (const void *)ctx->pvv_ilu.LU.p, (const void *)ctx->pvv_ilu.t0.p, (const void *)ctx->b2_ilu.LU.p, (const void *)ctx->b2_ilu.t0.p,
                           (const void *)ctx->App.p, (const void *)ctx->B.val.p, (const void *)ctx->Bt.val.p})
       key_ptr(key, p);
-    key.push_back(uint64_t(ctx->tune.pvv_sweeps)); key.push_back(uint64_t(ctx->tune.b2pp_sweeps)); key.push_back(uint64_t(pvv_ok));
+    key.push_back(uint64_t(ctx->tune.pvv_sweeps)); key.push_back(uint64_t(ctx->tune.b2pp_sweeps)); key.push_back(uint64_t(pvv_ok)); key.push_back(uint64_t(b2_ok));
     key.push_back(uint64_t(ctx->pvv_ilu.nnz)); key.push_back(uint64_t(ctx->b2_ilu.nnz));
     if (!graph_run(ctx, ctx->pa_graph, key, body)) pa_graph_ok = false;
   };
