@@ -29,6 +29,11 @@ int ifem_tpp_override(ifem_ctx *ctx, const double *val); /* TEST AID ONLY: singl
  * ifem_tuning::pvv_sweeps / b2pp_sweeps < 0 make the two ILU applications exact substitutions. */
 int ifem_scns_pc_probe(ifem_ctx *ctx, int which, const double *x, double *y);
 
+/* Stand-in for the free-memory bound of the self-lengthening inner restart (solver.hip::precond_vmult) on THIS rank: `columns` > 0 is
+ * the number of basis column pairs this rank says it can afford, 0 restores the hipMemGetInfo estimate.  The decision itself is
+ * collective (the smallest wish of all ranks wins): a test gives the ranks different bounds and checks that they agree. */
+int ifem_test_restart_fits(ifem_ctx *ctx, int columns);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,7 +137,7 @@ EXPORTS = ["ifem_last_error", "ifem_device_count", "ifem_default_solver_opts", "
            "ifem_imex_step", "ifem_set_eddy_viscosity", "ifem_default_tuning", "ifem_set_tuning", "ifem_abi_sizeof",
            "ifem_mass_vmult", "ifem_mg_attach", "ifem_mg_depth", "ifem_uu_block_diag",
            "ifem_fsi_set_solid", "ifem_fsi_update_indicator", "ifem_fsi_find_fluid_bc", "ifem_fsi_get_stress",
-           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_comm_stats_level", "ifem_true_residual", "ifem_tpp_ilu_probe", "ifem_tpp_override", "ifem_scns_pc_probe",
+           "ifem_get_constraints", "ifem_fsi_fluid_at_points", "ifem_comm_stats_get", "ifem_comm_stats_level", "ifem_true_residual", "ifem_tpp_ilu_probe", "ifem_tpp_override", "ifem_scns_pc_probe", "ifem_test_restart_fits",
            "ifem_kprof_begin", "ifem_kprof_end", "ifem_kprof_family_name", "ifem_export_rows", "ifem_export_uu_pattern", "ifem_vcycle_graph_stats", "ifem_inner_restart_length"]
 
 # ifem_abi_sizeof(which): the ctypes mirror of every struct of the header
@@ -220,6 +220,7 @@ def load():
     L.ifem_tpp_ilu_probe.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.ifem_tpp_override.argtypes = [C.c_void_p, C.c_void_p]
     L.ifem_scns_pc_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.ifem_test_restart_fits.argtypes = [C.c_void_p, C.c_int]
     L.ifem_true_residual.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ifem_kprof_begin.argtypes = [C.c_void_p]
     L.ifem_kprof_end.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]

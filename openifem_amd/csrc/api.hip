@@ -1058,6 +1058,12 @@ int ifem_comm_stats_level(ifem_ctx *ctx, int level, ifem_comm_stats *out) {
   IFEM_API_END
 }
 
+int ifem_test_restart_fits(ifem_ctx *ctx, int columns) {
+  if (!ctx || columns < 0) return IFEM_E_BADPARAM;
+  ctx->test_restart_fits = columns;
+  return IFEM_OK;
+}
+
 int ifem_inner_restart_length(ifem_ctx *ctx) { return ctx ? ctx->inner_restart_eff : IFEM_E_BADPARAM; }
 
 int ifem_vcycle_graph_stats(ifem_ctx *ctx, uint64_t *captures, uint64_t *launches) {

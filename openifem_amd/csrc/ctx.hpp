@@ -446,6 +446,7 @@ struct ifem_ctx {
   } vc_graph, sm_graph, pa_graph; // (pa_graph: the inner iteration's B2pp_inverse T_pp of the SCnsIM preconditioner)  // (sm_graph: the same for the V-cycle on S_m inside CG(S_m))
   // section marks of the preconditioner applications of one solve (start, after CG(M_p), after CG(S_m) + B^T, end): recorded on the
   // stream, read once when the solve has finished (ifem_solve_stats::t_cg_mp_ms / t_cg_sm_ms / t_ainv_ms) -- no host wait per section
+  int test_restart_fits = 0; // test aid: stands in for the free-memory bound of the restart lengthening on this rank
   int inner_restart_eff = 0; // restart length of the inner GMRES of IFEM_AINV_MG once an application stagnated across restarts (solver.hip)
   std::vector<hipEvent_t> pc_ev;
   size_t pc_used = 0;

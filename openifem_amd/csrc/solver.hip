@@ -1149,7 +1149,8 @@ static void precond_vmult(SolveState &S, const double *src, double *dst) {
           (void)hipMemGetInfo(&fr, &tot);
           int want = std::min(128, 2 * mi);
           const double per_col = 2.0 * double(ld) * sizeof(double);
-          const int fits = int(std::min<double>(128.0, 0.25 * double(fr) / std::max(per_col, 1.0)));
+          int fits = int(std::min<double>(128.0, 0.25 * double(fr) / std::max(per_col, 1.0)));
+          if (c->test_restart_fits > 0) fits = c->test_restart_fits; // test aid (ifem_test_restart_fits): a rank that is short of memory
           want = std::min(want, std::max(fits, mi));
           // `its` and `mi` are the same on every rank, free memory and `ld` are not: the restart length must be (the ranks restart
           // together -- their all-reduces and halo exchanges pair up), so the smallest wish of all ranks wins

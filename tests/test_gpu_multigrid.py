@@ -832,3 +832,47 @@ def test_stored_uu_0_newton_loop_with_inhomogeneous_boundary_values():
     assert abs(out[0][0] - 0.374235) / 0.374235 < 1e-3 and abs(out[0][1] - 46.5226) / 46.5226 < 1e-3, out
     assert abs(out[0][0] - out[1][0]) <= 1e-5 * out[1][0] and abs(out[0][1] - out[1][1]) <= 1e-5 * out[1][1], out
     assert out[0][2][0] == out[1][2][0], out  # the same number of Newton iterations
+
+
+def test_restart_lengthening_is_one_decision_of_all_ranks():
+    """the self-lengthening inner restart reads the free device memory, which differs between ranks -- ranks that chose
+    different restart lengths would restart at different iterations and their all-reduces / halo exchanges would no longer pair up.  Two virtual
+    ranks, one of which can afford 5 column pairs only (ifem_test_restart_fits): both end with the same length (the smaller wish), the solve
+    completes and meets the stopping rule"""
+    from openifem_amd import capi
+    L = capi.load()
+    P, n, world = (2, 1, 1), (8, 8, 8), 2
+    probe = _hierarchy((16, 8, 8))
+    depth = probe.L.ifem_mg_depth(probe.ctx)
+    probe.close()
+    worlds = [C.c_void_p(L.ifem_local_world_create(world)) for _ in range(depth + 1)]
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            s = _hierarchy(n, P, rank, worlds)
+            s.channel_state()
+            assert L.ifem_halo_exchange(s.ctx, capi.VEC_EVAL) == 0
+            s.opts.inner_restart = 2
+            s.opts.inner_rel = 1e-7
+            s.opts.inner_rel_first = 0.0
+            assert L.ifem_test_restart_fits(s.ctx, 5 if rank == 0 else 100) == 0
+            s.assemble(False)
+            st = s.solve(False)
+            res, bn = s.true_residual()
+            out[rank] = (L.ifem_inner_restart_length(s.ctx), st.inner_iters, st.fgmres_iters, res / bn)
+            s.close()
+        except Exception:  # noqa
+            import traceback
+            errs.append((rank, traceback.format_exc()))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errs and all(o is not None for o in out), (errs, out)
+    assert out[0][0] == out[1][0] and 2 < out[0][0] <= 5, out  # rank 1 alone would have doubled to 4, 8, ...: the smaller wish wins
+    assert out[0][1:3] == out[1][1:3] and out[0][3] <= 1.05e-4, out
+    for w in worlds:
+        L.ifem_local_world_destroy(w)

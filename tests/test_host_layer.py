@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     declared -= {"ifem_ctx"}
     # ... and the test aids stay out of the public header
     pub = open(os.path.join(ROOT, "include", "ifem_hip.h")).read()
-    for aid in ("ifem_tpp_override", "ifem_tpp_ilu_probe", "ifem_scns_pc_probe"):
+    for aid in ("ifem_tpp_override", "ifem_tpp_ilu_probe", "ifem_scns_pc_probe", "ifem_test_restart_fits"):
         assert not re.search(r"\b%s\s*\(" % aid, pub), aid
     assert declared, "no declarations parsed"
     for name in sorted(declared):
