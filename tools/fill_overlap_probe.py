@@ -1,4 +1,4 @@
-"""A/B of ifem_tuning::auu_double_buffer at n^3: host-timed assemble / solve per step with a device fence after each.
+"""A/B of the (removed, profiles/r06_fill_overlap.txt) ifem_tuning::auu_double_buffer at n^3; without that field it times the plain step: host-timed assemble / solve per step with a device fence after each.
 python tools/fill_overlap_probe.py [n]"""
 import ctypes as C
 import os
@@ -15,7 +15,10 @@ for db in (1, 0):
     solver, reps, _ = multigpu.make_channel_solver(n, 0, 1, 0, None, multigrid=True)
     tun = capi.Tuning()
     solver.L.ifem_default_tuning(C.byref(tun))
-    tun.auu_double_buffer = db
+    if hasattr(tun, "auu_double_buffer"):
+        tun.auu_double_buffer = db
+    elif db:
+        continue
     for c_ in solver.all_ctxs():
         assert solver.L.ifem_set_tuning(c_, C.byref(tun)) == 0
     solver.channel_state()
