@@ -61,7 +61,7 @@ def _box_case(dim, kv, reps, seed=5):
     return m, S, ctx, rng
 
 
-@pytest.mark.parametrize("dim,kv,reps", [(2, 1, (9, 7)), (3, 1, (4, 4, 3)), (2, 2, (5, 4))])
+@pytest.mark.parametrize("dim,kv,reps", [(2, 1, (9, 7)), (3, 1, (4, 4, 3)), (2, 2, (5, 4)), (3, 2, (3, 2, 2))])
 def test_pieces_match_the_oracle(dim, kv, reps):
     """exact substitution on the device (sweeps < 0) = Euclid's ILU(0) of the oracle, entry for entry of the result: the block
     ILU(0) on velocity nodes IS the scalar ILU(0) on the reference's pattern of full dim x dim blocks"""
